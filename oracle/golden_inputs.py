@@ -1,0 +1,194 @@
+"""Seeded input builders shared by oracle/gen_golden.py (which feeds them to the reference) and by
+tests/ (which feed the same tensors to the oracle and to the HIP path).
+
+TEST INFRASTRUCTURE.  Pure torch-CPU; imports nothing from the reference.  Every fixture stores a
+digest of the inputs it was generated with, so a change in torch's CPU generator would be detected
+(tests/test_oracle_golden.py::test_input_digests) instead of silently invalidating the fixtures.
+"""
+import hashlib
+
+import numpy as np
+import torch
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def digest(*tensors) -> np.ndarray:
+    h = hashlib.sha256()
+    for t in tensors:
+        a = t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+        h.update(np.ascontiguousarray(a).tobytes())
+    return np.frombuffer(h.digest(), dtype=np.uint8).copy()
+
+
+def planted_features(N, h0, w0, h1, w1, seed, sigma=0.5, noise=0.5):
+    """Stand-in backbone outputs with planted correspondences: map1 = map0 shifted by one coarse
+    cell (+noise).  Returns ((c0, f0), (c1, f1)); c* [N,256,h,w], f* [N,128,4h,4w]."""
+    g = gen(seed)
+    H, W = max(h0, h1) + 1, max(w0, w1) + 1
+    big = torch.randn(N, 256, H, W, generator=g) * sigma
+    c0 = big[:, :, :h0, :w0].contiguous()
+    c1 = (big[:, :, 1:1 + h1, 1:1 + w1] + noise * torch.randn(N, 256, h1, w1, generator=g)).contiguous()
+    bigf = torch.randn(N, 128, 4 * H, 4 * W, generator=g)
+    f0 = bigf[:, :, :4 * h0, :4 * w0].contiguous()
+    f1 = (bigf[:, :, 4:4 + 4 * h1, 4:4 + 4 * w1]
+          + noise * torch.randn(N, 128, 4 * h1, 4 * w1, generator=g)).contiguous()
+    return (c0, f0), (c1, f1)
+
+
+def textured_pair(h, w, seed, noise=0.3):
+    """image1 = image0 shifted by 8 px; low-frequency texture + pixel noise, in [0,1]."""
+    g = gen(seed)
+    base = torch.rand(1, 1, h // 8 + 2, w // 8 + 2, generator=g)
+    img = torch.nn.functional.interpolate(base, size=(h + 8, w + 8), mode='bicubic', align_corners=True)
+    img = (img + noise * torch.rand(1, 1, h + 8, w + 8, generator=g)).clamp(0, 1)
+    return img[:, :, :h, :w].contiguous(), img[:, :, 8:, 8:].contiguous()
+
+
+# ------------------------------------------------------------------------------------------
+def g1_inputs():
+    return {'x': torch.randn(1, 256, 4, 5, generator=gen(11)),
+            'sample_ys': np.array([0, 1, 7, 79, 128, 255, 200, 3]),
+            'sample_xs': np.array([0, 2, 9, 79, 64, 255, 17, 250])}
+
+
+def g2_inputs():
+    g = gen(21)
+    d = {'q': torch.randn(2, 24, 8, 32, generator=g), 'k': torch.randn(2, 40, 8, 32, generator=g),
+         'v': torch.randn(2, 40, 8, 32, generator=g)}
+    qm = torch.ones(2, 24, dtype=torch.bool); qm[1, 18:] = False
+    km = torch.ones(2, 40, dtype=torch.bool); km[0, 33:] = False; km[1, 29:] = False
+    d.update(q_mask=qm, kv_mask=km, qf=torch.randn(3, 25, 8, 16, generator=g),
+             kf=torch.randn(3, 25, 8, 16, generator=g), vf=torch.randn(3, 25, 8, 16, generator=g))
+    return d
+
+
+def g3_inputs():
+    g = gen(31)
+    d = {'x': torch.randn(2, 24, 256, generator=g), 'src': torch.randn(2, 40, 256, generator=g)}
+    m = g2_inputs()
+    d.update(x_mask=m['q_mask'], src_mask=m['kv_mask'], xf=torch.randn(4, 25, 128, generator=g),
+             sf=torch.randn(4, 25, 128, generator=g), f0=torch.randn(2, 30, 256, generator=g),
+             f1=torch.randn(2, 35, 256, generator=g))
+    m0 = torch.ones(2, 30, dtype=torch.bool); m0[1, 24:] = False
+    m1 = torch.ones(2, 35, dtype=torch.bool); m1[1, 28:] = False
+    d.update(m0=m0, m1=m1)
+    return d
+
+
+def g4_inputs():
+    g = gen(41)
+    d = {'x_self': torch.randn(1, 40, 256, generator=g), 'src_self': torch.randn(1, 13, 256, generator=g),
+         'x_cross': torch.randn(40, 1, 256, generator=g), 'src_cross': torch.randn(40, 25, 256, generator=g)}
+    kvm = torch.rand(40, 25, generator=g) > 0.3
+    kvm[7] = False; kvm[8, 1:] = False
+    d.update(kv_mask=kvm, qa=torch.randn(3, 9, 4, 64, generator=g), ka=torch.randn(3, 25, 4, 64, generator=g),
+             va=torch.randn(3, 25, 4, 64, generator=g))
+    kam = torch.rand(3, 25, generator=g) > 0.4; kam[2] = False
+    d['kam'] = kam
+    return d
+
+
+def g5_inputs():
+    """Coarse-matching cases on a 6x8 vs 7x9 grid; f1 holds noisy copies of 36 rows of f0 at
+    permuted positions, so the confidence matrix is sharp but graded."""
+    g = gen(51)
+    L, S = 48, 63
+    f0 = torch.randn(2, L, 256, generator=g) * 1.3
+    perm = torch.stack([torch.randperm(S, generator=g) for _ in range(2)])
+    f1 = torch.randn(2, S, 256, generator=g) * 1.3
+    for b in range(2):
+        f1[b, perm[b, :36]] = f0[b, :36] + 0.45 * torch.randn(36, 256, generator=g)
+    m0 = torch.ones(2, 6, 8, dtype=torch.bool); m0[1, 5:] = False; m0[1, :, 6:] = False
+    m1 = torch.ones(2, 7, 9, dtype=torch.bool); m1[0, :, 8:] = False; m1[1, 6:] = False
+    sc0 = torch.tensor([[1.5, 1.25], [2.0, 1.0]]); sc1 = torch.tensor([[1.0, 1.75], [1.1, 0.9]])
+    f0e = f0.clone(); f0e[1] = torch.randn(L, 256, generator=g) * 0.05   # sample 1 flat -> no match
+    f0t = f0.clone(); f1t = f1.clone()
+    f1t[0, 5] = f1t[0, perm[0, 3]]          # duplicated column -> exact tie inside row 3
+    f0t[0, 40] = f0t[0, 7]                  # duplicated row    -> exact tie inside a column
+    return {'hw0': (6, 8), 'hw1': (7, 9), 'thr': 0.2,
+            'plain': dict(f0=f0, f1=f1), 'masked': dict(f0=f0, f1=f1, mask0=m0, mask1=m1, scale0=sc0, scale1=sc1),
+            'forced': dict(f0=f0e, f1=f1, dataset_name='x'), 'ties': dict(f0=f0t, f1=f1t)}
+
+
+G6_HOMOGRAPHIES = {
+    'identity': np.eye(3),
+    'shift': np.array([[1., 0, -8], [0, 1, -8], [0, 0, 1]]),
+    'affine': np.array([[0.93, -0.21, 14.3], [0.18, 1.07, -9.6], [0, 0, 1]]),
+    'persp': np.array([[1.12, 0.08, -21.0], [-0.05, 0.9, 17.5], [9e-4, -1.3e-3, 1]]),
+}
+
+
+def g6_inputs():
+    return {'dims': (64, 80, 56, 72), 'fmap': torch.randn(1, 16, 7, 9, generator=gen(61)), 'H': G6_HOMOGRAPHIES}
+
+
+def g7_inputs():
+    """GeoModule inputs on a 6x8 grid, batch 2: sample 0 has 14 matches (11 follow the planted
+    one-cell shift, 3 are outliers), sample 1 has 5 matches (<= 8: RANSAC is not attempted)."""
+    h, w = 6, 8
+    (c0, _), (c1, _) = planted_features(2, h, w, h, w, 72)
+    g = gen(71)
+    cells0 = torch.randperm((h - 1) * (w - 1), generator=g)[:14]
+    y0, x0 = cells0 // (w - 1), cells0 % (w - 1)
+    mk0 = torch.stack([x0, y0], 1).float() * 8
+    mk1 = mk0 + 8
+    mk1[3] = torch.tensor([0., 40.]); mk1[9] = torch.tensor([56., 0.]); mk1[12] = torch.tensor([40., 8.])
+    mk0b = torch.tensor([[0., 0.], [8., 16.], [24., 8.], [56., 40.], [40., 32.]]); mk1b = mk0b.flip(0).contiguous()
+    return {'h': h, 'w': w, 'c0': c0, 'c1': c1, 'mkpts0_c': torch.cat([mk0, mk0b]), 'mkpts1_c': torch.cat([mk1, mk1b]),
+            'm_bids': torch.cat([torch.zeros(14, dtype=torch.long), torch.ones(5, dtype=torch.long)]),
+            'H_shift': np.array([[1., 0, 8], [0, 1, 8], [0, 0, 1]]), 'H_persp': G6_HOMOGRAPHIES['persp']}
+
+
+def g8_inputs():
+    g = gen(81)
+    return {'feat_f0': torch.randn(2, 128, 32, 40, generator=g), 'feat_f1': torch.randn(2, 128, 28, 36, generator=g),
+            'feat_c0': torch.randn(2, 80, 256, generator=g), 'feat_c1': torch.randn(2, 63, 256, generator=g),
+            'b_ids': torch.tensor([0, 0, 0, 1, 1, 1]), 'i_ids': torch.tensor([0, 9, 79, 3, 44, 70]),
+            'j_ids': torch.tensor([62, 0, 31, 8, 9, 54]), 'hw0_f': (32, 40), 'hw0_c': (8, 10), 'hw1_c': (7, 9)}
+
+
+def g9_inputs():
+    g = gen(91)
+    Mn = 10
+    a = torch.randn(Mn, 25, 128, generator=g) * 1.2
+    b = torch.randn(Mn, 25, 128, generator=g) * 1.2
+    for m in range(Mn):
+        tgt = int(torch.randint(0, 25, (1,), generator=g)); src = int(torch.randint(0, 25, (1,), generator=g))
+        if m % 3:
+            b[m, tgt] = a[m, src] * 2.0 + 0.2 * torch.randn(128, generator=g)
+        else:         # every third match: unplanted and weak -> flat 25x25 confidence, fails fine_thr
+            b[m] *= 0.2
+    return {'f0': a, 'f1': b, 'b_ids': torch.tensor([0, 0, 0, 1, 1, 1, 1, 1, 1, 1]),
+            'mkpts0_c': torch.randint(0, 10, (Mn, 2), generator=g).float() * 8,
+            'mkpts1_c': torch.randint(0, 9, (Mn, 2), generator=g).float() * 8,
+            'hw0_i': (64, 80), 'hw0_c': (8, 10), 'hw0_f': (32, 40),
+            'scale0': torch.tensor([[1.5, 1.25], [2.0, 1.0]]), 'scale1': torch.tensor([[1.0, 1.75], [1.1, 0.9]]),
+            'temperature': 0.1, 'thr': 0.1}
+
+
+def g10_cases():
+    """End-to-end cases.  'feats' None = real backbone on a textured pair."""
+    cases = {}
+    i0, i1 = textured_pair(64, 80, 101)
+    cases['g10a_e2e_backbone'] = dict(data={'image0': i0, 'image1': i1}, feats=None, coarse_thr=0.0, fine_thr=0.0)
+    cases['g10b_e2e_planted_n2'] = dict(
+        data={'image0': torch.zeros(2, 1, 64, 80), 'image1': torch.zeros(2, 1, 64, 80)},
+        feats=planted_features(2, 8, 10, 8, 10, 102), coarse_thr=0.2, fine_thr=0.1)
+    cases['g10c_e2e_planted_unequal'] = dict(
+        data={'image0': torch.zeros(1, 1, 64, 80), 'image1': torch.zeros(1, 1, 56, 72)},
+        feats=planted_features(1, 8, 10, 7, 9, 103), coarse_thr=0.2, fine_thr=0.1)
+    m0 = torch.ones(1, 8, 10, dtype=torch.bool); m0[:, 7:] = False
+    m1 = torch.ones(1, 8, 10, dtype=torch.bool); m1[:, :, 8:] = False
+    cases['g10d_e2e_planted_masked'] = dict(
+        data={'image0': torch.zeros(1, 1, 64, 80), 'image1': torch.zeros(1, 1, 64, 80), 'mask0': m0, 'mask1': m1,
+              'scale0': torch.tensor([[1.5, 1.25]]), 'scale1': torch.tensor([[1.0, 1.75]]), 'dataset_name': ['x']},
+        feats=planted_features(1, 8, 10, 8, 10, 104), coarse_thr=0.2, fine_thr=0.1)
+    return cases
+
+
+def g11_inputs():
+    return {'feats': planted_features(1, 80, 80, 80, 80, 111), 'coarse_thr': 0.2, 'fine_thr': 0.1,
+            'data': {'image0': torch.zeros(1, 1, 640, 640), 'image1': torch.zeros(1, 1, 640, 640)}}
