@@ -1,0 +1,54 @@
+"""ctypes binding of libgeoformer_hip.so (the C ABI declared in include/geoformer_hip.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `python -m geoformer_amd.build`.
+There is NO fallback: if the shared object is missing or a symbol is absent, importing an op
+raises.  PyTorch is used only for device memory and streams.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgeoformer_hip.so')
+
+GF_F32, GF_F16 = 0, 1
+
+c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, argtypes).  Kept in the order of include/geoformer_hip.h;
+# tests/test_abi.py checks this table against the header.
+SIGNATURES = {
+    'gf_abi_version': (c_int, []),
+    'gf_last_error': (ctypes.c_char_p, []),
+    'gf_dual_softmax_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'gf_dual_softmax_match': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                      c_float, c_float, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_size_t, c_void_p]),
+}
+
+
+class GeoFormerHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GeoFormerHipError(
+                f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                '(hipcc --offload-arch=gfx950).  geoformer_amd has no CPU / PyTorch fallback.')
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)       # AttributeError if the symbol is missing: fail loudly
+            fn.restype, fn.argtypes = res, args
+        _lib = h
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        raise GeoFormerHipError(f'{what} failed ({status}): {lib().gf_last_error().decode()}')

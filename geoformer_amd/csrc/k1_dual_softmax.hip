@@ -1,0 +1,617 @@
+// K1: dual-softmax correlation sweep + mutual-nearest match extraction (CDNA4 / gfx950).
+//
+// Replaces CoarseMatching.forward / get_coarse_match of the reference
+// (model/loftr_src/loftr/utils/coarse_matching.py:90-130, :132-212): there, ~10 full passes over
+// the [N,L,S] fp32 matrix (einsum, 2 softmax, >, 2 max, 2 ==, 2 *, max, where).  Here:
+//
+//   pass A  k1_stats   : 128x128 MFMA tiles of sim = f0.f1^T/(C*tau); per tile the row and column
+//                        (max, sum-exp) partials -> workspace.                       (no L*S traffic)
+//   reduce  k1_reduce  : combine partials -> row/col softmax statistics.
+//   pass B  k1_conf    : recompute the same tile (bit-identical), conf = softmax_col*softmax_row,
+//                        ONE streaming write of conf [N,L,S] fp32 (the algorithmic 4*L*S bytes).
+//                        Entries with conf > thr are rare (a row holds at most 1/thr of them), so the
+//                        row-best (value, first column) key and the column maximum are kept with
+//                        atomicMax on those candidates only - no cross-lane reduction in the hot loop
+//                        (a dense in-tile reduction is used instead when thr < 0.05).
+//   select  k1_select  : per row: best key, equality with the column maximum; exact
+//                        first-True-column semantics incl. the tie case (re-reads that ONE row).
+//   compact k1_compact : ordered compaction (torch.where order) + keypoint arithmetic.
+//
+// HBM roofline: pass B is bound by the conf write (L*S*4 B per sample); everything else is O(L*C).
+#include <math.h>
+
+#include <type_traits>
+
+#include "gf_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, NT = 256;
+constexpr int ROWB = 128;                        // bytes per LDS operand row = one K step
+constexpr int STAGE_BYTES = (BM + BN) * ROWB;    // 32 KiB per stage, two stages
+constexpr float NEG_INF = -INFINITY;
+
+struct K1Args {
+    const void* f0;
+    const void* f1;
+    int N, L, S, C;
+    const uint8_t* mask0;
+    const uint8_t* mask1;
+    float inv_c, temperature, mult;   // sim = acc*inv_c/temperature (exact) or acc*mult (fast)
+    int tilesM, tilesN;
+    float2* rowpart;   // [N][tilesN][L]  (max, sumexp)
+    float2* colpart;   // [N][tilesM][S]
+    float2* rstat;     // [N][L]  (max, sum)
+    float2* cstat;     // [N][S]
+    unsigned long long* rowbest;   // [N][L]  max over candidates of (conf bits << 32 | ~col); 0 = none
+    unsigned* colmax;              // [N][S]  max conf bits over candidates; 0 = none
+    float* conf;
+    float thr;
+    int dense;                     // thr so low that candidates are not rare: reduce in the tile first
+};
+
+// ---------------------------------------------------------------------------------------------
+// tile engine: acc[mi][ni] (wave-local 64x64 block = 2x2 MFMA 32x32 tiles) of f0[m0:,:] . f1[n0:,:]^T
+// register-staged double buffering, one barrier per K step; operand rows clamped (masked later).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void sim_tile(const T* __restrict__ A, const T* __restrict__ B, int L, int S, int C,
+                                         int m0, int n0, char* smem, v16f (&acc)[2][2]) {
+    using M = Mma32<T>;
+    using Frag = typename M::Frag;
+    constexpr int EPC = 16 / sizeof(T);
+    constexpr int BK = ROWB / sizeof(T);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, lr = lane & 31;
+    const int srow = tid >> 3, schunk = tid & 7;
+    v4u ra[4], rb[4];   // native vectors: HIP's uint4 (a union-based struct) kept these arrays in scratch
+    const T* ga[4];
+    const T* gb[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        ga[p] = A + (size_t)min(m0 + srow + 32 * p, L - 1) * C + schunk * EPC;
+        gb[p] = B + (size_t)min(n0 + srow + 32 * p, S - 1) * C + schunk * EPC;
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            ra[p] = *reinterpret_cast<const v4u*>(ga[p] + k0);
+            rb[p] = *reinterpret_cast<const v4u*>(gb[p] + k0);
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* sa = smem + buf * STAGE_BYTES;
+        char* sb = sa + BM * ROWB;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            *reinterpret_cast<v4u*>(sa + gf_lds_off(srow + 32 * p, schunk)) = ra[p];
+            *reinterpret_cast<v4u*>(sb + gf_lds_off(srow + 32 * p, schunk)) = rb[p];
+        }
+    };
+    const int nk = C / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+        const char* sa = smem + buf * STAGE_BYTES;
+        const char* sb = sa + BM * ROWB;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int chunk = 2 * g + h;
+            Frag a0 = *reinterpret_cast<const Frag*>(sa + gf_lds_off(wm * 64 + lr, chunk));
+            Frag a1 = *reinterpret_cast<const Frag*>(sa + gf_lds_off(wm * 64 + 32 + lr, chunk));
+            Frag b0 = *reinterpret_cast<const Frag*>(sb + gf_lds_off(wn * 64 + lr, chunk));
+            Frag b1 = *reinterpret_cast<const Frag*>(sb + gf_lds_off(wn * 64 + 32 + lr, chunk));
+            M::mma(a0, b0, acc[0][0]);
+            M::mma(a0, b1, acc[0][1]);
+            M::mma(a1, b0, acc[1][0]);
+            M::mma(a1, b1, acc[1][1]);
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+template <bool EXACT>
+__device__ __forceinline__ float k1_exp(float x) {
+    if constexpr (EXACT) return expf(x);
+    else return __expf(x);
+}
+
+// Per-lane view of the wave's 64x64 block after the MFMAs: validity of its 32 row slots
+// (slot q = mi*16 + r -> row m0 + wm*64 + mi*32 + acc_row(r, h)) and its 2 columns.
+struct LaneGeom {
+    unsigned row_in, row_ok;   // bit q: row < L ; mask0 true (or no mask)
+    unsigned col_in, col_ok;   // bit ni
+};
+
+// Branch-free; the packed words are made opaque so that the compiler keeps them as two VGPRs
+// instead of 64 live lane masks in SGPRs (which spilled thousands of SGPRs).
+__device__ __forceinline__ LaneGeom k1_geom(const K1Args& a, int n, int m0, int n0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, lr = lane & 31;
+    LaneGeom g;
+    const int row0 = m0 + wm * 64, col0 = n0 + wn * 64 + lr;
+    g.row_in = 0;
+    g.row_ok = 0;
+    const bool masked = a.mask0 != nullptr;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        const int row = row0 + (q >> 4) * 32 + gf_acc_row(q & 15, h);
+        const unsigned in = row < a.L ? 1u : 0u;
+        g.row_in |= in << q;
+        if (masked) g.row_ok |= (in & (a.mask0[(size_t)n * a.L + min(row, a.L - 1)] != 0 ? 1u : 0u)) << q;
+    }
+    if (!masked) g.row_ok = g.row_in;
+    g.col_in = 0;
+    g.col_ok = 0;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int col = col0 + ni * 32;
+        const unsigned in = col < a.S ? 1u : 0u;
+        g.col_in |= in << ni;
+        if (masked) g.col_ok |= (in & (a.mask1[(size_t)n * a.S + min(col, a.S - 1)] != 0 ? 1u : 0u)) << ni;
+    }
+    if (!masked) g.col_ok = g.col_in;
+    asm volatile("" : "+v"(g.row_in), "+v"(g.row_ok), "+v"(g.col_in), "+v"(g.col_ok));
+    return g;
+}
+
+// sim values of this lane: sv[q][ni]; out-of-range -> -inf (ignored by every reduction),
+// masked pair -> -1e9 exactly as masked_fill does (coarse_matching.py:123-124).
+// GUARD=false is the interior, unmasked tile: no predicates at all.
+template <bool EXACT, bool GUARD>
+__device__ __forceinline__ void k1_sim_values(const K1Args& a, const LaneGeom& g, const v16f (&acc)[2][2],
+                                              float (&sv)[32][2]) {
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const float raw = acc[q >> 4][ni][q & 15];
+            float s;
+            if constexpr (EXACT) s = (raw * a.inv_c) / a.temperature;
+            else s = raw * a.mult;
+            if constexpr (GUARD) {
+                const bool in = ((g.row_in >> q) & (g.col_in >> ni) & 1u) != 0;
+                const bool ok = ((g.row_ok >> q) & (g.col_ok >> ni) & 1u) != 0;
+                s = in ? (ok ? s : -1e9f) : NEG_INF;
+            }
+            sv[q][ni] = s;
+        }
+    }
+}
+
+__device__ __forceinline__ bool k1_interior(const K1Args& a, int m0, int n0) {
+    return a.mask0 == nullptr && m0 + BM <= a.L && n0 + BN <= a.S;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass A: row / column (max, sum-exp) partials of one tile
+// ---------------------------------------------------------------------------------------------
+template <typename T, bool GUARD>
+__device__ __forceinline__ void k1_stats_epilogue(const K1Args& a, const v16f (&acc)[2][2], char* smem, int n, int bm,
+                                                  int bn) {
+    constexpr bool EXACT = std::is_same<T, float>::value;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, lr = lane & 31;
+    LaneGeom g;
+    if constexpr (GUARD) g = k1_geom(a, n, m0, n0);
+    float sv[32][2];
+    k1_sim_values<EXACT, GUARD>(a, g, acc, sv);
+
+    float* scratch = reinterpret_cast<float*>(smem);   // staging buffers are free after the K loop
+    float* rowbc = scratch + wave * 64;                // [4][64]   row maxima broadcast, per wave
+    float2* colx = reinterpret_cast<float2*>(scratch + 256);          // [2(wm)][128] column partials
+    float2* rowx = colx + 256;                                         // [2(wn)][128] row partials
+
+    // ---- columns: lane-local over its 32 rows, then the other lane half
+    float cm[2], cl[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        float m = NEG_INF;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) m = fmaxf(m, sv[q][ni]);
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const float ms = (GUARD && m == NEG_INF) ? 0.f : m;
+        float l = 0.f;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) l += k1_exp<EXACT>(sv[q][ni] - ms);
+        l += __shfl_xor(l, 32, 64);
+        cm[ni] = m;
+        cl[ni] = l;
+    }
+    // ---- rows: reduce-scatter over the 32 lanes of each half
+    float rq[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) rq[q] = fmaxf(sv[q][0], sv[q][1]);
+    const float rmax_mine = gf_reduce_scatter32(rq, GfMaxF());   // lane lr: slot q = lr
+    rowbc[h * 32 + lr] = rmax_mine;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        const float m = rowbc[h * 32 + q];
+        const float ms = (GUARD && m == NEG_INF) ? 0.f : m;
+        rq[q] = k1_exp<EXACT>(sv[q][0] - ms) + k1_exp<EXACT>(sv[q][1] - ms);
+    }
+    const float rsum_mine = gf_reduce_scatter32(rq, GfAddF());
+    // ---- combine the two waves that share rows (wn) / columns (wm) through LDS
+    const int myrow_local = wm * 64 + (lr >> 4) * 32 + gf_acc_row(lr & 15, h);   // slot lr
+    rowx[wn * 128 + myrow_local] = make_float2(rmax_mine, rsum_mine);
+    if (h == 0) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) colx[wm * 128 + wn * 64 + ni * 32 + lr] = make_float2(cm[ni], cl[ni]);
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    const float2* px = (t < 128) ? rowx : colx;
+    const int c = t & 127;
+    const float2 p = px[c], q2 = px[128 + c];
+    const float m = fmaxf(p.x, q2.x);
+    const float ms = (m == NEG_INF) ? 0.f : m;
+    const float l = p.y * k1_exp<EXACT>(p.x - ms) + q2.y * k1_exp<EXACT>(q2.x - ms);
+    if (t < 128) {
+        const int row = m0 + c;
+        if (row < a.L) a.rowpart[((size_t)n * a.tilesN + bn) * a.L + row] = make_float2(m, l);
+    } else {
+        const int col = n0 + c;
+        if (col < a.S) a.colpart[((size_t)n * a.tilesM + bm) * a.S + col] = make_float2(m, l);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void k1_stats(K1Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bn = blockIdx.x, bm = blockIdx.y, n = blockIdx.z;
+    v16f acc[2][2];
+    sim_tile<T>((const T*)a.f0 + (size_t)n * a.L * a.C, (const T*)a.f1 + (size_t)n * a.S * a.C, a.L, a.S, a.C,
+                bm * BM, bn * BN, smem, acc);
+    if (k1_interior(a, bm * BM, bn * BN)) k1_stats_epilogue<T, false>(a, acc, smem, n, bm, bn);
+    else k1_stats_epilogue<T, true>(a, acc, smem, n, bm, bn);
+}
+
+// combine per-tile (max, sumexp) partials: 32 rows (blockIdx.y==0) or columns (==1) per block,
+// 8 threads per row each striding over the partials, merged through LDS
+template <bool EXACT>
+__global__ __launch_bounds__(256) void k1_reduce_stats(K1Args a) {
+    __shared__ float2 sh[8][32];
+    const int n = blockIdx.z;
+    const bool rows = blockIdx.y == 0;
+    const int len = rows ? a.L : a.S, np = rows ? a.tilesN : a.tilesM;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + tx;
+    if (blockIdx.x * 32 >= len) return;
+    const float2* part = (rows ? a.rowpart : a.colpart) + (size_t)n * np * len + min(i, len - 1);
+    float m = NEG_INF, l = 0.f;
+    for (int p = ty; p < np; p += 8) {
+        const float2 v = part[(size_t)p * len];
+        const float mn = fmaxf(m, v.x);
+        const float ms = (mn == NEG_INF) ? 0.f : mn;
+        l = l * k1_exp<EXACT>(m - ms) + v.y * k1_exp<EXACT>(v.x - ms);
+        m = mn;
+    }
+    sh[ty][tx] = make_float2(m, l);
+    __syncthreads();
+    if (ty == 0 && i < len) {
+        float M = NEG_INF;
+#pragma unroll
+        for (int y = 0; y < 8; ++y) M = fmaxf(M, sh[y][tx].x);
+        const float ms = (M == NEG_INF) ? 0.f : M;
+        float lt = 0.f;
+#pragma unroll
+        for (int y = 0; y < 8; ++y) lt += sh[y][tx].y * k1_exp<EXACT>(sh[y][tx].x - ms);
+        (rows ? a.rstat : a.cstat)[(size_t)n * len + i] = make_float2(M, lt);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass B: confidence tile -> HBM, row-best keys, column maxima
+// ---------------------------------------------------------------------------------------------
+template <typename T, bool GUARD, bool DENSE>
+__device__ __forceinline__ void k1_conf_epilogue(const K1Args& a, const v16f (&acc)[2][2], char* smem, int n, int bm,
+                                                 int bn) {
+    constexpr bool EXACT = std::is_same<T, float>::value;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, lr = lane & 31;
+    LaneGeom g;
+    if constexpr (GUARD) g = k1_geom(a, n, m0, n0);
+    float sv[32][2];
+    k1_sim_values<EXACT, GUARD>(a, g, acc, sv);
+    const int row0 = m0 + wm * 64, col0 = n0 + wn * 64 + lr;
+
+    // row statistics of the tile -> LDS once (a per-slot global load inside the store loop would wait
+    // vmcnt(0), i.e. drain the store queue, 32 times per wave)
+    float2* rst = reinterpret_cast<float2*>(smem);
+    if (threadIdx.x < BM) {
+        const float2 st = a.rstat[(size_t)n * a.L + min(m0 + (int)threadIdx.x, a.L - 1)];
+        rst[threadIdx.x] = make_float2(st.x, EXACT ? st.y : __builtin_amdgcn_rcpf(st.y));
+    }
+    float cmx[2], cden[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int col = GUARD ? min(col0 + ni * 32, a.S - 1) : col0 + ni * 32;
+        const float2 st = a.cstat[(size_t)n * a.S + col];
+        cmx[ni] = st.x;
+        cden[ni] = EXACT ? st.y : __builtin_amdgcn_rcpf(st.y);
+    }
+    __syncthreads();
+    unsigned long long key[DENSE ? 32 : 1];
+    unsigned cbest[2] = {0u, 0u};
+    float* cbase = a.conf + (size_t)n * a.L * a.S;
+    unsigned long long* rbest = a.rowbest + (size_t)n * a.L;
+    unsigned* cmax = a.colmax + (size_t)n * a.S;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        const int row = row0 + (q >> 4) * 32 + gf_acc_row(q & 15, h);
+        const float2 st = rst[wm * 64 + (q >> 4) * 32 + gf_acc_row(q & 15, h)];
+        const float rden = st.y;
+        unsigned long long k = 0ull;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const float s = sv[q][ni];
+            float pc, pr;
+            if constexpr (EXACT) {
+                pc = expf(s - cmx[ni]) / cden[ni];
+                pr = expf(s - st.x) / rden;
+            } else {
+                pc = __expf(s - cmx[ni]) * cden[ni];
+                pr = __expf(s - st.x) * rden;
+            }
+            const float cf = pc * pr;
+            bool in = true;
+            if constexpr (GUARD) in = ((g.row_in >> q) & (g.col_in >> ni) & 1u) != 0;
+            if (in) {
+                const int col = col0 + ni * 32;
+                cbase[(size_t)row * a.S + col] = cf;
+                if (cf > a.thr) {
+                    const unsigned bits = __float_as_uint(cf);
+                    const unsigned long long kk = ((unsigned long long)bits << 32) | (0xFFFFFFFFu - (unsigned)col);
+                    if constexpr (DENSE) {
+                        cbest[ni] = max(cbest[ni], bits);
+                        k = kk > k ? kk : k;
+                    } else {      // rare: at most 1/thr entries of a row (column) can exceed thr
+                        atomicMax(rbest + row, kk);
+                        atomicMax(cmax + col, bits);
+                    }
+                }
+            }
+        }
+        if constexpr (DENSE) key[q] = k;
+    }
+    if constexpr (DENSE) {
+        const unsigned long long kbest = gf_reduce_scatter32(key, GfMaxU64());
+        const int myrow = row0 + (lr >> 4) * 32 + gf_acc_row(lr & 15, h);
+        if (kbest != 0ull) atomicMax(rbest + myrow, kbest);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const unsigned c = max(cbest[ni], (unsigned)__shfl_xor((int)cbest[ni], 32, 64));
+            if (h == 0 && c != 0u) atomicMax(cmax + col0 + ni * 32, c);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void k1_conf(K1Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bn = blockIdx.x, bm = blockIdx.y, n = blockIdx.z;
+    v16f acc[2][2];
+    sim_tile<T>((const T*)a.f0 + (size_t)n * a.L * a.C, (const T*)a.f1 + (size_t)n * a.S * a.C, a.L, a.S, a.C,
+                bm * BM, bn * BN, smem, acc);
+    const bool interior = k1_interior(a, bm * BM, bn * BN);
+    if (a.dense) {
+        if (interior) k1_conf_epilogue<T, false, true>(a, acc, smem, n, bm, bn);
+        else k1_conf_epilogue<T, true, true>(a, acc, smem, n, bm, bn);
+    } else {
+        if (interior) k1_conf_epilogue<T, false, false>(a, acc, smem, n, bm, bn);
+        else k1_conf_epilogue<T, true, false>(a, acc, smem, n, bm, bn);
+    }
+}
+
+struct SelArgs {
+    int N, L, S;
+    const unsigned long long* rowbest;   // [N][L]
+    const unsigned* colmax;              // [N][S]
+    const float* conf;
+    int* selj;             // [N][L]  matched column or -1
+    int* samplecnt;        // [N][chunks]  matches per 1024-row chunk
+    int chunks;
+    int force_one;
+    int w0c, w1c;
+    float scale;
+    const float* scale0;
+    const float* scale1;
+    int64_t* b_ids;
+    int64_t* i_ids;
+    int64_t* j_ids;
+    float* mconf;
+    float* mk0;
+    float* mk1;
+    int32_t* counts;
+};
+
+// one thread per (n, i): coarse_matching.py:161-185 on the candidate statistics instead of the matrix.
+// rowbest holds the row maximum only if it exceeds thr (otherwise 0: no candidate, no match).
+__global__ void k1_select(SelArgs a) {
+    const int n = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.L) return;
+    const unsigned long long k = a.rowbest[(size_t)n * a.L + i];
+    int sel = -1;
+    if (k != 0ull) {
+        const unsigned bits = (unsigned)(k >> 32);
+        const int j = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
+        const unsigned* cm = a.colmax + (size_t)n * a.S;
+        if (cm[j] == bits) {
+            sel = j;
+        } else {
+            // exact `mask.max(dim=2)` semantics: a later column may tie the row maximum AND be its
+            // column's maximum.  Only then is the row re-read (rare: needs an exact fp32 tie).
+            const float* row = a.conf + ((size_t)n * a.L + i) * a.S;
+            for (int j2 = j + 1; j2 < a.S; ++j2) {
+                if (__float_as_uint(row[j2]) == bits && cm[j2] == bits) {
+                    sel = j2;
+                    break;
+                }
+            }
+        }
+    }
+    a.selj[(size_t)n * a.L + i] = sel;
+    // per-1024-row chunk counts (blockDim = 256: one ballot + one atomic per wave)
+    const unsigned long long bal = __ballot(sel >= 0);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&a.samplecnt[n * a.chunks + (i >> 10)], __popcll(bal));
+}
+
+// one workgroup per (1024-row chunk, sample): ordered compaction in (n, i) order + keypoints
+// (coarse_matching.py:186-201).  Bases come from the chunk counts of everything in front.
+__global__ __launch_bounds__(1024) void k1_compact(SelArgs a) {
+    __shared__ int wave_tot[16];
+    __shared__ int sh_base, sh_forced;
+    const int c = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) {
+        int base = 0, forced = 0;
+        for (int b = 0; b <= n; ++b) {
+            int tot = 0, upto = 0;
+            for (int k = 0; k < a.chunks; ++k) {
+                const int v = a.samplecnt[b * a.chunks + k];
+                tot += v;
+                if (k < c) upto += v;
+            }
+            const bool f = (tot == 0 && a.force_one);
+            if (b < n) base += f ? 1 : tot;
+            else {
+                base += upto;
+                forced = f;
+                if (c == 0) a.counts[1 + n] = f ? 1 : tot;
+                if (c == 0 && n == a.N - 1) a.counts[0] = base + (f ? 1 : tot);
+            }
+        }
+        sh_base = base;
+        sh_forced = forced;
+    }
+    __syncthreads();
+    const int base = sh_base;
+    const float s0x = a.scale0 ? a.scale * a.scale0[2 * n] : a.scale, s0y = a.scale0 ? a.scale * a.scale0[2 * n + 1] : a.scale;
+    const float s1x = a.scale1 ? a.scale * a.scale1[2 * n] : a.scale, s1y = a.scale1 ? a.scale * a.scale1[2 * n + 1] : a.scale;
+    auto emit = [&](int pos, int i, int j) {
+        a.b_ids[pos] = n;
+        a.i_ids[pos] = i;
+        a.j_ids[pos] = j;
+        a.mconf[pos] = a.conf[((size_t)n * a.L + i) * a.S + j];
+        a.mk0[2 * pos] = (float)(i % a.w0c) * s0x;
+        a.mk0[2 * pos + 1] = (float)(i / a.w0c) * s0y;
+        a.mk1[2 * pos] = (float)(j % a.w1c) * s1x;
+        a.mk1[2 * pos + 1] = (float)(j / a.w1c) * s1y;
+    };
+    if (sh_forced) {
+        if (tid == 0 && c == 0) emit(base, 0, 0);
+        return;
+    }
+    const int i = c * 1024 + tid;
+    const int j = (i < a.L) ? a.selj[(size_t)n * a.L + i] : -1;
+    const bool f = j >= 0;
+    const unsigned long long bal = __ballot(f);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wave] = __popcll(bal);
+    __syncthreads();
+    int woff = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) woff += (w < wave) ? wave_tot[w] : 0;
+    if (f) emit(base + woff + before, i, j);
+}
+
+template <typename T>
+int k1_launch(K1Args a, SelArgs s, void* zero_begin, size_t zero_bytes, hipStream_t st) {
+    constexpr bool EXACT = std::is_same<T, float>::value;
+    const dim3 grid(a.tilesN, a.tilesM, a.N);
+    (void)hipMemsetAsync(zero_begin, 0, zero_bytes, st);   // rowbest, colmax, samplecnt (contiguous)
+    k1_stats<T><<<grid, NT, 2 * STAGE_BYTES, st>>>(a);
+    const int mx = a.L > a.S ? a.L : a.S;
+    k1_reduce_stats<EXACT><<<dim3((mx + 31) / 32, 2, a.N), 256, 0, st>>>(a);
+    k1_conf<T><<<grid, NT, 2 * STAGE_BYTES, st>>>(a);
+    k1_select<<<dim3((a.L + 255) / 256, a.N), 256, 0, st>>>(s);
+    k1_compact<<<dim3(s.chunks, a.N), 1024, 0, st>>>(s);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}
+
+struct K1Workspace {
+    float2 *rowpart, *colpart, *rstat, *cstat;
+    unsigned long long* rowbest;
+    unsigned* colmax;
+    int *samplecnt, *selj;
+    size_t zero_bytes, bytes;
+};
+
+K1Workspace k1_carve(void* ws, int N, int L, int S) {
+    const int tilesM = (L + BM - 1) / BM, tilesN = (S + BN - 1) / BN;
+    GfCarver c(ws);
+    K1Workspace w;
+    // zeroed every call (one memset): rowbest | colmax | samplecnt
+    w.rowbest = c.take<unsigned long long>((size_t)N * L);
+    w.colmax = c.take<unsigned>((size_t)N * S);
+    w.samplecnt = c.take<int>((size_t)N * ((L + 1023) / 1024));
+    w.zero_bytes = c.used();
+    w.rowpart = c.take<float2>((size_t)N * tilesN * L);
+    w.colpart = c.take<float2>((size_t)N * tilesM * S);
+    w.rstat = c.take<float2>((size_t)N * L);
+    w.cstat = c.take<float2>((size_t)N * S);
+    w.selj = c.take<int>((size_t)N * L);
+    w.bytes = c.used();
+    return w;
+}
+
+}   // namespace
+
+extern "C" size_t gf_dual_softmax_workspace_bytes(int N, int L, int S) {
+    if (N <= 0 || L <= 0 || S <= 0) return 0;
+    return k1_carve(nullptr, N, L, S).bytes;
+}
+
+extern "C" int gf_dual_softmax_match(const void* f0, const void* f1, int dtype, int N, int L, int S, int C,
+                                     const uint8_t* mask0, const uint8_t* mask1, float temperature, float thr,
+                                     int force_one, int w0c, int w1c, float scale, const float* scale0,
+                                     const float* scale1, float* conf, int64_t* b_ids, int64_t* i_ids,
+                                     int64_t* j_ids, float* mconf, float* mkpts0_c, float* mkpts1_c,
+                                     int32_t* counts, void* workspace, size_t workspace_bytes, void* stream) {
+    GF_CHECK_ARG(f0 && f1 && conf && b_ids && i_ids && j_ids && mconf && mkpts0_c && mkpts1_c && counts, "null pointer");
+    GF_CHECK_ARG(N > 0 && L > 0 && S > 0, "empty problem");
+    GF_CHECK_ARG(dtype == GF_F32 || dtype == GF_F16, "dtype must be GF_F32 or GF_F16");
+    GF_CHECK_ARG(C > 0 && C % (dtype == GF_F32 ? 32 : 64) == 0, "C must be a multiple of 32 (f32) / 64 (f16)");
+    GF_CHECK_ARG((mask0 == nullptr) == (mask1 == nullptr), "mask0/mask1 must both be set or both be NULL");
+    GF_CHECK_ARG(temperature > 0.f && w0c > 0 && w1c > 0, "bad temperature / grid width");
+    GF_CHECK_ARG(thr >= 0.f, "thr must be >= 0 (confidences are probabilities)");
+    if (workspace == nullptr || workspace_bytes < gf_dual_softmax_workspace_bytes(N, L, S)) {
+        gf_set_error("gf_dual_softmax_match: workspace too small (%zu < %zu)", workspace_bytes,
+                     gf_dual_softmax_workspace_bytes(N, L, S));
+        return GF_ERR_WORKSPACE;
+    }
+    const K1Workspace w = k1_carve(workspace, N, L, S);
+    K1Args a;
+    a.f0 = f0; a.f1 = f1; a.N = N; a.L = L; a.S = S; a.C = C;
+    a.mask0 = mask0; a.mask1 = mask1;
+    a.inv_c = 1.0f / (float)C;                         // feat/sqrt(C) on both sides (coarse_matching.py:113)
+    a.temperature = temperature;
+    a.mult = (1.0f / (float)C) / temperature;
+    a.tilesM = (L + BM - 1) / BM; a.tilesN = (S + BN - 1) / BN;
+    a.rowpart = w.rowpart; a.colpart = w.colpart; a.rstat = w.rstat; a.cstat = w.cstat;
+    a.rowbest = w.rowbest; a.colmax = w.colmax; a.conf = conf; a.thr = thr; a.dense = thr < 0.05f;
+    SelArgs s;
+    s.N = N; s.L = L; s.S = S;
+    s.rowbest = w.rowbest; s.colmax = w.colmax; s.conf = conf;
+    s.selj = w.selj; s.samplecnt = w.samplecnt; s.chunks = (L + 1023) / 1024; s.force_one = force_one; s.w0c = w0c; s.w1c = w1c;
+    s.scale = scale; s.scale0 = scale0; s.scale1 = scale1;
+    s.b_ids = b_ids; s.i_ids = i_ids; s.j_ids = j_ids; s.mconf = mconf; s.mk0 = mkpts0_c; s.mk1 = mkpts1_c;
+    s.counts = counts;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == GF_F32 ? k1_launch<float>(a, s, w.rowbest, w.zero_bytes, st)
+                           : k1_launch<_Float16>(a, s, w.rowbest, w.zero_bytes, st);
+}

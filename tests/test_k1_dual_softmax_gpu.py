@@ -1,0 +1,127 @@
+"""K1 parity: HIP dual-softmax + match extraction vs the oracle and vs the reference's golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+import geoformer_oracle as O
+import golden_inputs as GI
+
+pytestmark = pytest.mark.gpu
+
+
+def _data(hw0, hw1, extra=None):
+    d = {'hw0_i': torch.tensor([hw0[0] * 8, hw0[1] * 8]), 'hw1_i': torch.tensor([hw1[0] * 8, hw1[1] * 8]),
+         'hw0_c': torch.tensor(hw0), 'hw1_c': torch.tensor(hw1)}
+    d.update(extra or {})
+    return d
+
+
+def _run_hip(f0, f1, thr, hw0, hw1, case, dtype):
+    from geoformer_amd import ops
+    dev = 'cuda:0'
+    kw = {}
+    if 'mask0' in case:
+        kw.update(mask0=case['mask0'].to(dev), mask1=case['mask1'].to(dev))
+    if 'scale0' in case:
+        kw.update(scale0=case['scale0'], scale1=case['scale1'])
+    out = ops.dual_softmax_match(f0.to(dev, dtype), f1.to(dev, dtype), 0.1, thr, hw0, hw1, 8.0,
+                                 force_one='dataset_name' in case, **kw)
+    torch.cuda.synchronize()
+    M = int(out['counts'][0])
+    res = {k: out[k][:M].cpu() for k in ('b_ids', 'i_ids', 'j_ids', 'mconf', 'mkpts0_c', 'mkpts1_c')}
+    res['conf_matrix'] = out['conf_matrix'].cpu()
+    res['counts'] = out['counts'].cpu()
+    return res
+
+
+@pytest.mark.parametrize('tag', ['plain', 'masked', 'forced', 'ties'])
+def test_golden_fp32(golden, tag):
+    """fp32 path against the REFERENCE's outputs: indices bit-exact, floats to fp32 rounding."""
+    G, I = golden('g5_coarse_matching'), GI.g5_inputs()
+    c = I[tag]
+    out = _run_hip(c['f0'], c['f1'], I['thr'], I['hw0'], I['hw1'], c, torch.float32)
+    np.testing.assert_allclose(out['conf_matrix'].numpy(), G[f'{tag}_conf_matrix'], rtol=2e-5, atol=1e-9)
+    for k in ('b_ids', 'i_ids', 'j_ids'):
+        np.testing.assert_array_equal(out[k].numpy(), G[f'{tag}_{k}'])
+    np.testing.assert_array_equal(out['mkpts0_c'].numpy(), G[f'{tag}_mkpts0_c'])
+    np.testing.assert_array_equal(out['mkpts1_c'].numpy(), G[f'{tag}_mkpts1_c'])
+    np.testing.assert_allclose(out['mconf'].numpy(), G[f'{tag}_mconf'], rtol=2e-5, atol=1e-9)
+
+
+def _planted(N, L, S, C, seed, noise=0.35, scale=1.3):
+    g = torch.Generator().manual_seed(seed)
+    f0 = torch.randn(N, L, C, generator=g) * scale
+    f1 = torch.randn(N, S, C, generator=g) * scale
+    k = min(L, S) * 2 // 3
+    for b in range(N):
+        pi = torch.randperm(L, generator=g)[:k]
+        pj = torch.randperm(S, generator=g)[:k]
+        f1[b, pj] = f0[b, pi] + noise * scale * torch.randn(k, C, generator=g)
+    return f0, f1
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+@pytest.mark.parametrize('shape', [(1, 300, 500, 256), (2, 1200, 1184, 256), (1, 4800, 4560, 256)])
+def test_vs_oracle_ragged(shape, dtype):
+    """Ragged sizes (not multiples of the 128 tile), oracle run on the SAME rounded inputs."""
+    N, L, S, C = shape
+    f0, f1 = _planted(N, L, S, C, seed=L + S)
+    f0, f1 = f0.to(dtype).float(), f1.to(dtype).float()          # identical rounded inputs on both sides
+    w0, w1 = 20, 16
+    hw0, hw1 = (L // w0, w0), (S // w1, w1)
+    out = _run_hip(f0, f1, 0.2, hw0, hw1, {}, dtype)
+    torch.set_num_threads(8)
+    conf = O.dual_softmax(f0, f1, 0.1)
+    ref = O.coarse_match(conf, _data(hw0, hw1), 0.2)
+    assert len(ref['b_ids']) > min(L, S) // 4
+    np.testing.assert_allclose(out['conf_matrix'].numpy(), conf.numpy(), rtol=1e-4, atol=1e-9)
+    for k in ('b_ids', 'i_ids', 'j_ids'):
+        np.testing.assert_array_equal(out[k].numpy(), ref[k].numpy())
+    np.testing.assert_array_equal(out['mkpts0_c'].numpy(), ref['mkpts0_c'].numpy())
+    np.testing.assert_array_equal(out['mkpts1_c'].numpy(), ref['mkpts1_c'].numpy())
+    np.testing.assert_allclose(out['mconf'].numpy(), ref['mconf'].numpy(), rtol=1e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize('thr', [0.0, 0.01])
+def test_low_threshold_dense_path(thr):
+    """thr < 0.05 switches pass B to the in-tile (dense) reduction: same results required."""
+    N, L, S, C = 2, 300, 500, 256
+    f0, f1 = _planted(N, L, S, C, seed=5)
+    hw0, hw1 = (15, 20), (25, 20)
+    out = _run_hip(f0, f1, thr, hw0, hw1, {}, torch.float32)
+    conf = O.dual_softmax(f0, f1, 0.1)
+    ref = O.coarse_match(conf, _data(hw0, hw1), thr)
+    assert len(ref['b_ids']) > 100
+    for k in ('b_ids', 'i_ids', 'j_ids'):
+        np.testing.assert_array_equal(out[k].numpy(), ref[k].numpy())
+    np.testing.assert_allclose(out['mconf'].numpy(), ref['mconf'].numpy(), rtol=1e-4, atol=1e-12)
+
+
+def test_full_size_properties():
+    """BASELINE size (L=S=6400, fp16 features): size-independent properties of the dual-softmax -
+    row/column sums of sqrt-factors, mutual-nearest consistency, ordering, planted recovery."""
+    from geoformer_amd import ops
+    N, L, S, C = 2, 6400, 6400, 256
+    g = torch.Generator().manual_seed(7)
+    f0 = torch.randn(N, L, C, generator=g) * 1.3
+    perm = torch.stack([torch.randperm(S, generator=g) for _ in range(N)])
+    f1 = torch.stack([f0[b][perm[b]] for b in range(N)]) + 0.4 * torch.randn(N, S, C, generator=g)
+    out = ops.dual_softmax_match(f0.cuda().half(), f1.cuda().half(), 0.1, 0.2, (80, 80), (80, 80), 8.0)
+    torch.cuda.synchronize()
+    M = int(out['counts'][0])
+    conf = out['conf_matrix']
+    b, i, j = (out[k][:M] for k in ('b_ids', 'i_ids', 'j_ids'))
+    assert M > 0.9 * N * L
+    # planted permutation recovered: f1[b, j] = f0[b, perm[b, j]]  ->  i == perm[b, j]
+    assert torch.equal(perm.cuda()[b, j], i)
+    # torch.where order and per-sample counts
+    key = b * L + i
+    assert torch.all(key[1:] > key[:-1])
+    assert int(out['counts'][1:].sum()) == M
+    # every reported match is the maximum of its row and column and exceeds thr
+    assert torch.equal(conf[b, i].argmax(-1), j)
+    assert torch.equal(conf[b, :, j].argmax(0) if False else conf.transpose(1, 2)[b, j].argmax(-1), i)
+    assert torch.all(out['mconf'][:M] > 0.2) and torch.equal(out['mconf'][:M], conf[b, i, j])
+    # conf <= 1 and each row / column of conf sums to <= 1 (product of two probabilities)
+    assert float(conf.max()) <= 1.0 + 1e-5
+    assert float(conf.sum(-1).max()) <= 1.0 + 1e-4 and float(conf.sum(-2).max()) <= 1.0 + 1e-4
