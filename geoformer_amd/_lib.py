@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, 'libgeoformer_hip.so')
 GF_F32, GF_F16 = 0, 1
 
 c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+c_long, c_uint32 = ctypes.c_long, ctypes.c_uint32
 
 # name -> (restype, argtypes).  Kept in the order of include/geoformer_hip.h;
 # tests/test_abi.py checks this table against the header.
@@ -24,6 +25,33 @@ SIGNATURES = {
                                       c_float, c_float, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_size_t, c_void_p]),
+    'gf_pos_encode': (c_int, [c_void_p, c_int, c_long, c_long, c_long, c_long, c_void_p, c_void_p, c_int, c_int, c_int,
+                              c_int, c_int, c_void_p]),
+    'gf_linear_attention_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
+    'gf_linear_attention': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_long,
+                                    c_long, c_long, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_size_t,
+                                    c_void_p]),
+    'gf_ransac_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'gf_ransac_homography': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_float,
+                                     c_int, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_size_t, c_void_p]),
+    'gf_window_geometry': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'gf_inlier_index': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'gf_self_attention_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'gf_self_attention_gathered': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_long,
+                                           c_long, c_long, c_void_p, c_long, c_void_p, c_int, c_void_p, c_void_p,
+                                           c_size_t, c_void_p]),
+    'gf_window_cross_attention': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                          c_long, c_long, c_long, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'gf_fine_gather': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                               c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                               c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'gf_fine_match_workspace_bytes': (c_size_t, [c_int]),
+    'gf_fine_match': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p,
+                              c_void_p, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 
 

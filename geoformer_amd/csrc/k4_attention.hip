@@ -1,0 +1,253 @@
+// K4: dense softmax attention of all L query tokens over the K << L tokens at RANSAC-inlier cells
+// (GeoTransformer 'self' layers, model/geo_transformer/transformer.py:111-124 ->
+//  FullAttention.forward, model/geo_transformer/geo_attention.py:72-101, no masks on this path).
+//
+// Two launches per call:
+//   attn_gather_kv : keys/values of the listed tokens are gathered from the already projected
+//                    [L, C] maps into compact, 32-key padded buffers (K row-major; V row-major for
+//                    fp32, [channel][key] with the MFMA k-order baked in for fp16).  K is read from
+//                    device memory, so no host sync is needed to size anything.
+//   attn_self      : flash-style forward.  One workgroup = 32 queries x 4 heads (wave = head).
+//                    S^T = K.Q^T is computed "swapped" so that the softmax axis (keys) lies in the
+//                    accumulator registers of the lane that owns the query: running max / sum /
+//                    rescale are lane-local, P^T feeds the P.V MFMA straight from registers
+//                    (accumulator-as-B-operand), and O^T is normalised per lane at the end.
+#include <math.h>
+
+#include <type_traits>
+
+#include "gf_common.h"
+
+namespace {
+
+constexpr int HD = 64;      // head dim
+constexpr int NH = 4;       // heads  (geo_config.py:12)
+constexpr int CC = 256;     // channels
+constexpr int KT = 32;      // keys per tile
+
+struct AtArgs {
+    const void* q;          // [N][L][ldq]
+    const void* kmap;       // [N][L][ldk]   projected keys of every token
+    const void* vmap;
+    long ldq, ldk, ldv;
+    const int32_t* idx;     // [N][idx_stride] ascending token list
+    long idx_stride;
+    const int32_t* nkeys;   // nkeys[n * nkeys_stride]
+    int nkeys_stride;
+    void* out;              // [N][L][CC]
+    void* kc;               // [N][Kpad][CC]
+    void* vc;               // fp32: [N][Kpad][CC]; fp16: [N][CC][Kpad]
+    int N, L, Kpad;
+    float softmax_temp;
+};
+
+// position of key p (0..31) inside its 32-key block of the fp16 V^T image: element j of lane half h
+// in k-step s of the P.V MFMA must be key 16s + 8(j>>2) + 4h + (j&3)  ->  swap bits 2 and 3
+__device__ __forceinline__ int vt_pos(int p) { return (p & 19) | ((p & 4) << 1) | ((p & 8) >> 1); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_gather_kv(AtArgs a) {
+    const int n = blockIdx.y, p0 = blockIdx.x * KT, t = threadIdx.x;
+    const int K = a.nkeys[(size_t)n * a.nkeys_stride];
+    if (p0 >= ((K + KT - 1) / KT) * KT) return;
+    const int32_t* idx = a.idx + (size_t)n * a.idx_stride;
+    const T* km = (const T*)a.kmap + (size_t)n * a.L * a.ldk;
+    const T* vm = (const T*)a.vmap + (size_t)n * a.L * a.ldv;
+    T* kc = (T*)a.kc + ((size_t)n * a.Kpad + p0) * CC;
+    if constexpr (std::is_same<T, float>::value) {
+        T* vc = (T*)a.vc + ((size_t)n * a.Kpad + p0) * CC;
+        for (int p = 0; p < KT; ++p) {
+            const bool ok = p0 + p < K;
+            const int tok = ok ? idx[p0 + p] : 0;
+            kc[(size_t)p * CC + t] = ok ? km[(size_t)tok * a.ldk + t] : 0.f;
+            vc[(size_t)p * CC + t] = ok ? vm[(size_t)tok * a.ldv + t] : 0.f;
+        }
+    } else {
+        _Float16 vt[KT];
+#pragma unroll
+        for (int p = 0; p < KT; ++p) {
+            const bool ok = p0 + p < K;
+            const int tok = ok ? idx[p0 + p] : 0;
+            kc[(size_t)p * CC + t] = ok ? km[(size_t)tok * a.ldk + t] : (T)0;
+            vt[vt_pos(p)] = ok ? vm[(size_t)tok * a.ldv + t] : (T)0;
+        }
+        v8h* dst = reinterpret_cast<v8h*>((T*)a.vc + ((size_t)n * CC + t) * a.Kpad + p0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            dst[c] = v8h{vt[8 * c], vt[8 * c + 1], vt[8 * c + 2], vt[8 * c + 3], vt[8 * c + 4], vt[8 * c + 5], vt[8 * c + 6], vt[8 * c + 7]};
+    }
+}
+
+// LDS images.  K: [32 keys][CC] rows of CC*sizeof(T) bytes, 16-B chunk c stored at c ^ (row & 15)
+// (16 distinct slots for the 16 rows of a ds_read_b128 lane group).
+template <typename T>
+__device__ __forceinline__ int k_off(int row, int chunk) { return row * (CC * (int)sizeof(T)) + ((chunk ^ (row & 15)) << 4); }
+// fp16 V^T: [CC channels][32 keys] rows of 64 B, chunk c (0..3) stored at c ^ ((row >> 2) & 3)
+__device__ __forceinline__ int vt_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_self(AtArgs a) {
+    using M = Mma32<T>;
+    using Frag = typename M::Frag;
+    constexpr bool F32 = std::is_same<T, float>::value;
+    constexpr int KG = M::kGroup;            // head-dim elements per k-group
+    constexpr int NG = HD / KG;
+    constexpr int EPC = 16 / sizeof(T);      // elements per 16-B chunk
+    constexpr int KBYTES = KT * CC * sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ks = smem;
+    char* vs = smem + KBYTES;
+    const int n = blockIdx.y, q0 = blockIdx.x * 32, tid = threadIdx.x;
+    const int head = tid >> 6, lane = tid & 63, h = lane >> 5, lr = lane & 31;
+    const int K = a.nkeys[(size_t)n * a.nkeys_stride];
+    const int qrow = min(q0 + lr, a.L - 1);
+    const T* qp = (const T*)a.q + ((size_t)n * a.L + qrow) * a.ldq + head * HD;
+    Frag qf[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) qf[g] = *reinterpret_cast<const Frag*>(qp + g * KG + h * (KG / 2));
+    v16f o[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const T* kc = (const T*)a.kc + (size_t)n * a.Kpad * CC;
+    const int ntiles = (K + KT - 1) / KT;
+    for (int tile = 0; tile < ntiles; ++tile) {
+        __syncthreads();
+        // ---- stage the K tile (all heads): 32 rows x CC, 16 B per thread per pass
+        {
+            constexpr int CPR = CC / EPC;                 // chunks per row
+            constexpr int PASSES = KT * CPR / 256;
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const int e = p * 256 + tid, row = e / CPR, c = e % CPR;
+                *reinterpret_cast<v4u*>(ks + k_off<T>(row, c)) =
+                    *reinterpret_cast<const v4u*>(kc + ((size_t)tile * KT + row) * CC + c * EPC);
+            }
+            if constexpr (F32) {
+                const T* vc = (const T*)a.vc + ((size_t)n * a.Kpad + (size_t)tile * KT) * CC;
+#pragma unroll
+                for (int p = 0; p < PASSES; ++p) {
+                    const int e = p * 256 + tid;
+                    *reinterpret_cast<v4u*>(vs + (size_t)e * 16) = *reinterpret_cast<const v4u*>(vc + (size_t)e * EPC);
+                }
+            } else {
+                const T* vt = (const T*)a.vc + ((size_t)n * CC + tid) * a.Kpad + (size_t)tile * KT;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    *reinterpret_cast<v4u*>(vs + vt_off(tid, c)) = *reinterpret_cast<const v4u*>(vt + c * 8);
+            }
+        }
+        __syncthreads();
+        // ---- S^T tile: rows = keys (registers), column = query (lane)
+        v16f s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int chunk = (head * HD + g * KG + h * (KG / 2)) / EPC;
+            const Frag kf = *reinterpret_cast<const Frag*>(ks + k_off<T>(lr, chunk));
+            M::mma(kf, qf[g], s);
+        }
+        float x[16];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = tile * KT + gf_acc_row(r, h);
+            x[r] = key < K ? s[r] * a.softmax_temp : -INFINITY;
+            tmax = fmaxf(tmax, x[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mnew = fmaxf(m, tmax);          // finite: every tile holds at least one real key
+        const float alpha = expf(m - mnew);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            x[r] = expf(x[r] - mnew);
+            psum += x[r];
+        }
+        l = l * alpha + psum;
+        m = mnew;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
+        // ---- O^T += V^T . P^T with P^T taken from the registers as the B operand
+        if constexpr (F32) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* vrow = reinterpret_cast<const float*>(vs) + gf_acc_row(r, h) * CC + head * HD + lr;
+                o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[0], x[r], o[0], 0, 0, 0);
+                o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32], x[r], o[1], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const v8h pf{(_Float16)x[8 * s2], (_Float16)x[8 * s2 + 1], (_Float16)x[8 * s2 + 2], (_Float16)x[8 * s2 + 3],
+                             (_Float16)x[8 * s2 + 4], (_Float16)x[8 * s2 + 5], (_Float16)x[8 * s2 + 6], (_Float16)x[8 * s2 + 7]};
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const v8h vf = *reinterpret_cast<const v8h*>(vs + vt_off(head * HD + b * 32 + lr, 2 * s2 + h));
+                    o[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[b], 0, 0, 0);
+                }
+            }
+        }
+    }
+    l += __shfl_xor(l, 32, 64);
+    if (q0 + lr < a.L) {
+        T* op = (T*)a.out + ((size_t)n * a.L + q0 + lr) * CC + head * HD;
+        const float inv = K > 0 ? 1.0f / l : 0.f;       // K == 0: zeros (the caller skips the layer)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {             // registers 4*r4..4*r4+3 = 4 consecutive channels
+                const int d = b * 32 + 8 * r4 + 4 * h;
+                const v4f v{o[b][4 * r4] * inv, o[b][4 * r4 + 1] * inv, o[b][4 * r4 + 2] * inv, o[b][4 * r4 + 3] * inv};
+                if constexpr (F32) *reinterpret_cast<v4f*>(op + d) = v;
+                else *reinterpret_cast<v4h*>(op + d) = v4h{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+            }
+    }
+}
+
+}   // namespace
+
+extern "C" size_t gf_self_attention_workspace_bytes(int N, int L, int dtype) {
+    if (N <= 0 || L <= 0) return 0;
+    const size_t kpad = gf_align_up((size_t)L, KT);
+    const size_t es = dtype == GF_F32 ? 4 : 2;
+    return 2 * gf_align_up((size_t)N * kpad * CC * es, 256);
+}
+
+extern "C" int gf_self_attention_gathered(const void* q, const void* kmap, const void* vmap, int dtype, int N, int L,
+                                          int H, int D, long ldq, long ldk, long ldv, const int32_t* idx,
+                                          long idx_stride, const int32_t* nkeys, int nkeys_stride, void* out,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+    GF_CHECK_ARG(q && kmap && vmap && idx && nkeys && out, "null pointer");
+    GF_CHECK_ARG(N > 0 && L > 0, "empty problem");
+    GF_CHECK_ARG(H == NH && D == HD, "built for nhead=4, head dim 64 (geo_config.py:12, d_model 256)");
+    GF_CHECK_ARG(dtype == GF_F32 || dtype == GF_F16, "dtype must be GF_F32 or GF_F16");
+    if (workspace == nullptr || workspace_bytes < gf_self_attention_workspace_bytes(N, L, dtype)) {
+        gf_set_error("gf_self_attention_gathered: workspace too small");
+        return GF_ERR_WORKSPACE;
+    }
+    AtArgs a;
+    a.q = q; a.kmap = kmap; a.vmap = vmap; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
+    a.idx = idx; a.idx_stride = idx_stride; a.nkeys = nkeys; a.nkeys_stride = nkeys_stride; a.out = out;
+    a.N = N; a.L = L; a.Kpad = (int)gf_align_up((size_t)L, KT);
+    const size_t es = dtype == GF_F32 ? 4 : 2;
+    a.kc = workspace;
+    a.vc = (char*)workspace + gf_align_up((size_t)N * a.Kpad * CC * es, 256);
+    a.softmax_temp = 1.0f / sqrtf((float)D);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 ggrid(a.Kpad / KT, N), agrid((L + 31) / 32, N);
+    if (dtype == GF_F32) {
+        attn_gather_kv<float><<<ggrid, 256, 0, st>>>(a);
+        attn_self<float><<<agrid, 256, 2 * KT * CC * 4, st>>>(a);
+    } else {
+        attn_gather_kv<_Float16><<<ggrid, 256, 0, st>>>(a);
+        attn_self<_Float16><<<agrid, 256, 2 * KT * CC * 2, st>>>(a);
+    }
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}

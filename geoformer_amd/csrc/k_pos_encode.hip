@@ -1,0 +1,82 @@
+// a1: position encoding add + flatten to [N, H*W, C]  (PositionEncodingSine.forward,
+// model/loftr_src/loftr/utils/position_encoding.py:37-42, followed by the permute/reshape of
+// model/full_model.py:69-77).  The sin/cos table is built on the host exactly as the reference builds
+// its buffer (:22-35) and passed in as fp32 [H, W, C]; the kernel is a strided read + add + cast.
+#include "gf_common.h"
+
+namespace {
+
+struct PeArgs {
+    const void* x;
+    long sn, sc, sh, sw;   // element strides of x viewed as [N, C, H, W]
+    const float* pe;       // [H][W][C]
+    void* out;             // [N][H*W][C]
+    int N, C, H, W;
+};
+
+// channels-last input (sc == 1): plain elementwise over [N*H*W, C]
+template <typename TI, typename TO>
+__global__ void pe_nhwc(PeArgs a) {
+    const long total = (long)a.N * a.H * a.W * a.C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % a.C);
+        const long p = i / a.C;
+        const int w = (int)(p % a.W);
+        const long q = p / a.W;
+        const int h = (int)(q % a.H), n = (int)(q / a.H);
+        const float v = gf_to_float(((const TI*)a.x)[n * a.sn + c * a.sc + h * a.sh + w * a.sw]);
+        ((TO*)a.out)[i] = gf_from_float<TO>(v + a.pe[((long)h * a.W + w) * a.C + c]);
+    }
+}
+
+// NCHW input (sw == 1): 32 x 32 (position x channel) tile transposed through LDS
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void pe_nchw(PeArgs a) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z, HW = a.H * a.W;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, p = p0 + tx;
+        float v = 0.f;
+        if (c < a.C && p < HW) {
+            const int h = p / a.W, w = p % a.W;
+            v = gf_to_float(((const TI*)a.x)[n * a.sn + c * a.sc + h * a.sh + w * a.sw]);
+        }
+        tile[ty + 8 * k][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int p = p0 + ty + 8 * k, c = c0 + tx;
+        if (c < a.C && p < HW)
+            ((TO*)a.out)[((long)n * HW + p) * a.C + c] = gf_from_float<TO>(tile[tx][ty + 8 * k] + a.pe[(long)p * a.C + c]);
+    }
+}
+
+template <typename TI, typename TO>
+int pe_launch(const PeArgs& a, hipStream_t st) {
+    if (a.sc == 1) {
+        const long total = (long)a.N * a.H * a.W * a.C;
+        const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        pe_nhwc<TI, TO><<<blocks, 256, 0, st>>>(a);
+    } else {
+        pe_nchw<TI, TO><<<dim3((a.H * a.W + 31) / 32, (a.C + 31) / 32, a.N), 256, 0, st>>>(a);
+    }
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}
+
+}   // namespace
+
+extern "C" int gf_pos_encode(const void* x, int x_dtype, long sn, long sc, long sh, long sw, const float* pe,
+                             void* out, int out_dtype, int N, int C, int H, int W, void* stream) {
+    GF_CHECK_ARG(x && pe && out, "null pointer");
+    GF_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0, "empty problem");
+    GF_CHECK_ARG((x_dtype == GF_F32 || x_dtype == GF_F16) && (out_dtype == GF_F32 || out_dtype == GF_F16), "bad dtype");
+    PeArgs a{x, sn, sc, sh, sw, pe, out, N, C, H, W};
+    hipStream_t st = (hipStream_t)stream;
+    if (x_dtype == GF_F32) return out_dtype == GF_F32 ? pe_launch<float, float>(a, st) : pe_launch<float, _Float16>(a, st);
+    return out_dtype == GF_F32 ? pe_launch<_Float16, float>(a, st) : pe_launch<_Float16, _Float16>(a, st);
+}

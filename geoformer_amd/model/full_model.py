@@ -1,0 +1,122 @@
+"""GeoFormer - drop-in for the reference's model/full_model.py:18-129.
+
+Same constructor `GeoFormer(loftr_config, geoformer_cfg=default_cfg)`, same `forward(data) -> data`
+contract (keys written: bs, hw0_i, hw1_i, hw0_c, hw1_c, hw0_f, hw1_f, conf_matrix, dect_conf_matrix,
+b_ids, i_ids, j_ids, m_bids, mkpts0_c, mkpts1_c, mconf, W, fine_matrix, mkpts0_f, mkpts1_f), same
+state-dict keys (253 tensors) and the same `matcher.` prefix stripping in load_state_dict.
+
+What differs is where the arithmetic runs: the backbone stays on PyTorch-ROCm/MIOpen; everything after
+it goes through the HIP kernels of libgeoformer_hip.so.  The forward synchronises with the host twice
+per batch (number of coarse matches after the second coarse matching, number of fine matches at the
+end); the RANSAC homography of GeoModule runs on the device, so nothing synchronises in between.
+"""
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from .backbone import build_backbone
+from .geo_config import default_cfg
+from .modules import (CoarseMatching, FineMatching2, FinePreprocess, GeoModule, LocalFeatureTransformer,
+                      PositionEncodingSine, materialize_matches)
+
+_PRECISIONS = {'fp32': torch.float32, 'fp16': torch.float16}
+
+
+class GeoFormer(nn.Module):
+    def __init__(self, loftr_config, geoformer_cfg=default_cfg):
+        super().__init__()
+        self.config = loftr_config
+        self.backbone = build_backbone(loftr_config)
+        self.loftr_coarse = LocalFeatureTransformer(loftr_config['coarse'])
+        self.pos_encoding = PositionEncodingSine(loftr_config['coarse']['d_model'],
+                                                 temp_bug_fix=loftr_config['coarse']['temp_bug_fix'])
+        loftr_config['match_coarse']['thr'] = geoformer_cfg['coarse_thr']     # same side effect as the reference (:31)
+        self.coarse_matching = CoarseMatching(loftr_config['match_coarse'])
+        self.fine_preprocess = FinePreprocess(loftr_config)
+        self.loftr_fine = LocalFeatureTransformer(loftr_config['fine'])
+        self.fine_matching = FineMatching2(geoformer_cfg['fine_temperature'], geoformer_cfg['fine_thr'])
+        self.geo_module = GeoModule(geoformer_cfg, loftr_config['coarse']['d_model'])
+        self.set_precision(geoformer_cfg.get('precision', 'fp32'))
+
+    # -- precision of the matching path: 'fp32' (parity mode) or 'fp16' (fp16 storage, fp32 accumulate)
+    def set_precision(self, precision: str, backbone_dtype: Optional[torch.dtype] = None):
+        if precision not in _PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
+        self.precision = precision
+        self.compute_dtype = _PRECISIONS[precision]
+        self.backbone_dtype = backbone_dtype or self.compute_dtype
+        self.backbone.to(self.backbone_dtype)
+        return self
+
+    def _invalidate(self):
+        for m in self.modules():
+            if hasattr(m, 'invalidate'):
+                m.invalidate()
+
+    def _backbone(self, x):
+        x = x.to(self.backbone_dtype)
+        if x.is_cuda and self.backbone_dtype != torch.float32:
+            x = x.contiguous(memory_format=torch.channels_last)
+        return self.backbone(x)
+
+    def forward(self, data: Dict[str, torch.Tensor]):
+        img0, img1 = data['image0'], data['image1']
+        if not img0.is_cuda:
+            raise RuntimeError('geoformer_amd.GeoFormer runs on an MI355X (CUDA/HIP device) only; there is no CPU path')
+        data.update({'bs': torch.tensor(img0.size(0)), 'hw0_i': torch.tensor(img0.shape[2:]),
+                     'hw1_i': torch.tensor(img1.shape[2:])})
+        n = img0.size(0)
+        # 1. backbone (PyTorch-ROCm).  Same-shape pairs go through it as one batch (:55-57)
+        if img0.shape[2:] == img1.shape[2:]:
+            feats_c, feats_f = self._backbone(torch.cat([img0, img1], dim=0))
+            (feat_c0, feat_c1), (feat_f0, feat_f1) = feats_c.split(n), feats_f.split(n)
+        else:
+            (feat_c0, feat_f0), (feat_c1, feat_f1) = self._backbone(img0), self._backbone(img1)
+        return self.forward_features(data, feat_c0, feat_f0, feat_c1, feat_f1)
+
+    def forward_features(self, data, feat_c0, feat_f0, feat_c1, feat_f1):
+        """Everything after the backbone.  Public so that parity tests and benchmarks can drive the
+        matching path with given feature maps ([N,256,h,w] coarse, [N,128,4h,4w] fine)."""
+        dt = self.compute_dtype
+        data.update({'hw0_c': torch.tensor(feat_c0.shape[2:]), 'hw1_c': torch.tensor(feat_c1.shape[2:]),
+                     'hw0_f': torch.tensor(feat_f0.shape[2:]), 'hw1_f': torch.tensor(feat_f1.shape[2:])})
+        if 'bs' not in data:
+            data.update({'bs': torch.tensor(data['image0'].size(0)), 'hw0_i': torch.tensor(data['image0'].shape[2:]),
+                         'hw1_i': torch.tensor(data['image1'].shape[2:])})
+        # 2. position encoding + flatten, coarse LoFTR transformer
+        pe0 = self.pos_encoding(feat_c0, dt)
+        pe1 = self.pos_encoding(feat_c1, dt)
+        mask_c0 = mask_c1 = None
+        if 'mask0' in data:
+            mask_c0, mask_c1 = data['mask0'].flatten(-2), data['mask1'].flatten(-2)
+        feat0, feat1 = self.loftr_coarse(pe0, pe1, mask_c0, mask_c1)
+        # 3. first coarse matching (detector) -> geometry-guided transformer -> second coarse matching
+        self.coarse_matching(feat0, feat1, data, mask_c0=mask_c0, mask_c1=mask_c1, lazy=True)
+        data['dect_conf_matrix'] = data['conf_matrix']
+        same_pe = self.pos_encoding.temp_bug_fix == self.geo_module.pos_encoding.temp_bug_fix
+        geo0, geo1 = self.geo_module(feat_c0, feat_c1, data, pe0 if same_pe else None, pe1 if same_pe else None, dt)
+        raw = self.coarse_matching(geo0, geo1, data, mask_c0=mask_c0, mask_c1=mask_c1, lazy=True)
+        data.update(materialize_matches(raw))                      # host sync #1: M
+        # 4. fine level
+        f0u, f1u = self.fine_preprocess(feat_f0, feat_f1, geo0, geo1, data)
+        if f0u.size(0) != 0:
+            f0u, f1u = self.loftr_fine(f0u, f1u)
+        # 5. fine matching                                         # host sync #2: Mf
+        self.fine_matching(f0u, f1u, data)
+        data['_feat_dev'] = {'loftr_f0': feat0, 'loftr_f1': feat1, 'geo_f0': geo0, 'geo_f1': geo1, 'fine_f0': f0u, 'fine_f1': f1u}
+        return data
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        for k in list(state_dict.keys()):
+            if k.startswith('matcher.'):
+                state_dict[k.replace('matcher.', '', 1)] = state_dict.pop(k)
+        out = super().load_state_dict(state_dict, *args, **kwargs)
+        self._invalidate()
+        self.backbone.to(self.backbone_dtype)
+        return out
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._invalidate()
+        return out

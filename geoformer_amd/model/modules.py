@@ -1,0 +1,403 @@
+"""Host-side mirror of the reference's module interfaces for the matching path.  Same class names,
+constructor arguments, forward signatures and state-dict keys as the reference; the arithmetic runs
+in the HIP kernels of libgeoformer_hip.so (geoformer_amd.ops).  PyTorch supplies device memory,
+streams, the plain library GEMMs (nn.Linear -> hipBLASLt) and LayerNorm.
+
+There is no CPU path: every forward here needs CUDA(HIP) tensors and the built library.
+"""
+import copy
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+
+# ---------------------------------------------------------------------------------------------
+# position encoding  (reference: model/loftr_src/loftr/utils/position_encoding.py:6-42)
+# ---------------------------------------------------------------------------------------------
+class PositionEncodingSine(nn.Module):
+    """x [N,C,H,W] -> x + pe, returned FLATTENED as [N, H*W, C] (the reference's callers permute and
+    reshape right after, model/full_model.py:69-77, model/geo_module.py:28-29).  The sin/cos table is
+    built on the host with the reference's own formula - including its operator-precedence quirk when
+    temp_bug_fix is False (:28) - cached per (H, W) in [H, W, C] layout, and added by gf_pos_encode."""
+
+    def __init__(self, d_model, max_shape=(256, 256), temp_bug_fix=False):
+        super().__init__()
+        self.d_model, self.max_shape, self.temp_bug_fix = d_model, tuple(max_shape), temp_bug_fix
+        self._tables = {}
+
+    def table(self, h, w, device):
+        key = (h, w, str(device))
+        if key not in self._tables:
+            if h > self.max_shape[0] or w > self.max_shape[1]:
+                raise ValueError(f'feature map {h}x{w} exceeds max_shape {self.max_shape}')
+            c = self.d_model
+            ypos = torch.ones(h, w).cumsum(0).float().unsqueeze(0)
+            xpos = torch.ones(h, w).cumsum(1).float().unsqueeze(0)
+            k2 = torch.arange(0, c // 2, 2).float()
+            if self.temp_bug_fix:
+                div = torch.exp(k2 * (-math.log(10000.0) / (c // 2)))
+            else:
+                div = torch.exp(k2 * (-math.log(10000.0) / c // 2))
+            div = div[:, None, None]
+            pe = torch.zeros(c, h, w)
+            pe[0::4], pe[1::4] = torch.sin(xpos * div), torch.cos(xpos * div)
+            pe[2::4], pe[3::4] = torch.sin(ypos * div), torch.cos(ypos * div)
+            self._tables[key] = pe.permute(1, 2, 0).contiguous().to(device)
+        return self._tables[key]
+
+    def forward(self, x, out_dtype=None):
+        _, _, h, w = x.shape
+        return ops.pos_encode(x, self.table(h, w, x.device), out_dtype or x.dtype)
+
+
+# ---------------------------------------------------------------------------------------------
+# encoder layer  (reference: model/loftr_src/loftr/loftr_module/transformer.py:9-60 with ReLU and
+# linear attention; model/geo_transformer/transformer.py:9-66 with Tanh and full attention)
+# ---------------------------------------------------------------------------------------------
+class LoFTREncoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, attention='linear', activation='relu'):
+        super().__init__()
+        self.dim, self.nhead, self.d_model = d_model // nhead, nhead, d_model
+        self.attention_kind, self.activation = attention, activation
+        self.q_proj = nn.Linear(d_model, d_model, bias=False)
+        self.k_proj = nn.Linear(d_model, d_model, bias=False)
+        self.v_proj = nn.Linear(d_model, d_model, bias=False)
+        self.merge = nn.Linear(d_model, d_model, bias=False)
+        self.mlp = nn.Sequential(nn.Linear(d_model * 2, d_model * 2, bias=False),
+                                 nn.ReLU(True) if activation == 'relu' else nn.Tanh(),
+                                 nn.Linear(d_model * 2, d_model, bias=False))
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self._cache = {}
+
+    # weights in compute dtype; k_proj|v_proj fused so one GEMM projects keys and values
+    def weights(self, dtype):
+        w = self._cache.get(dtype)
+        if w is None:
+            c = self.d_model
+            w1 = self.mlp[0].weight.detach()
+            w = {'q': self.q_proj.weight.detach().to(dtype).contiguous(),
+                 'kv': torch.cat([self.k_proj.weight, self.v_proj.weight], 0).detach().to(dtype).contiguous(),
+                 'merge': self.merge.weight.detach().to(dtype).contiguous(),
+                 'w1x': w1[:, :c].to(dtype).contiguous(), 'w1m': w1[:, c:].to(dtype).contiguous(),
+                 'w2': self.mlp[2].weight.detach().to(dtype).contiguous(),
+                 'n1w': self.norm1.weight.detach().to(dtype), 'n1b': self.norm1.bias.detach().to(dtype),
+                 'n2w': self.norm2.weight.detach().to(dtype), 'n2b': self.norm2.bias.detach().to(dtype)}
+            self._cache[dtype] = w
+        return w
+
+    def invalidate(self):
+        self._cache = {}
+
+    def project_q(self, x):
+        return F.linear(x, self.weights(x.dtype)['q'])
+
+    def project_kv(self, source):
+        kv = F.linear(source, self.weights(source.dtype)['kv'])
+        c = self.d_model
+        return kv[..., :c], kv[..., c:]
+
+    def finish(self, x, message):
+        """merge -> norm1 -> mlp([x, message]) -> norm2; returns the residual update (without + x)."""
+        w = self.weights(x.dtype)
+        c = self.d_model
+        message = F.layer_norm(F.linear(message, w['merge']), (c,), w['n1w'], w['n1b'])
+        hid = F.linear(x, w['w1x']) + F.linear(message, w['w1m'])     # == Linear(cat([x, message]))
+        hid = torch.relu_(hid) if self.activation == 'relu' else torch.tanh_(hid)
+        return F.layer_norm(F.linear(hid, w['w2']), (c,), w['n2w'], w['n2b'])
+
+    def forward(self, x, source, x_mask: Optional[torch.Tensor] = None, source_mask: Optional[torch.Tensor] = None):
+        """x [N,L,C], source [N,S,C] -> [N,L,C]  (linear-attention flavour; the geometry-guided flavours
+        are driven by GeoTransformer, which owns the token lists / windows)."""
+        if self.attention_kind != 'linear':
+            raise NotImplementedError('full attention layers are driven by GeoTransformer')
+        q = self.project_q(x)
+        k, v = self.project_kv(source)
+        message = ops.linear_attention(q, k, v, self.nhead, x_mask, source_mask)
+        return x + self.finish(x, message)
+
+
+class LocalFeatureTransformer(nn.Module):
+    """reference: model/loftr_src/loftr/loftr_module/transformer.py:63-104"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.d_model, self.nhead, self.layer_names = config['d_model'], config['nhead'], config['layer_names']
+        if config['attention'] != 'linear':
+            raise NotImplementedError("only attention='linear' (the GeoFormer configuration) is built")
+        layer = LoFTREncoderLayer(config['d_model'], config['nhead'], 'linear', 'relu')
+        self.layers = nn.ModuleList([copy.deepcopy(layer) for _ in self.layer_names])
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, feat0, feat1, mask0: Optional[torch.Tensor] = None, mask1: Optional[torch.Tensor] = None):
+        assert self.d_model == feat0.size(2), 'the feature number of src and transformer must be equal'
+        same = feat0.shape == feat1.shape
+        for layer, name in zip(self.layers, self.layer_names):
+            if name == 'self':
+                if same:      # both images through one batched launch set (same weights, independent rows)
+                    both = torch.cat([feat0, feat1], 0)
+                    m = None if mask0 is None else torch.cat([mask0, mask1], 0)
+                    both = layer(both, both, m, m)
+                    feat0, feat1 = both[:feat0.shape[0]], both[feat0.shape[0]:]
+                else:
+                    feat0 = layer(feat0, feat0, mask0, mask0)
+                    feat1 = layer(feat1, feat1, mask1, mask1)
+            elif name == 'cross':  # feat1 attends to the UPDATED feat0 (transformer.py:99-100)
+                feat0 = layer(feat0, feat1, mask0, mask1)
+                feat1 = layer(feat1, feat0, mask1, mask0)
+            else:
+                raise KeyError
+        return feat0, feat1
+
+
+# ---------------------------------------------------------------------------------------------
+# coarse matching  (reference: model/loftr_src/loftr/utils/coarse_matching.py:25-212)
+# ---------------------------------------------------------------------------------------------
+class CoarseMatching(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.thr = config['thr']
+        self.border_rm = 0                        # forced to 0 in the reference (:31-32)
+        self.train_coarse_percent = config['train_coarse_percent']
+        self.train_pad_num_gt_min = config['train_pad_num_gt_min']
+        self.match_type = config['match_type']
+        if self.match_type != 'dual_softmax':
+            raise NotImplementedError("only match_type='dual_softmax' is built (sinkhorn needs superglue.py, "
+                                      'which the reference does not ship either)')
+        self.temperature = config['dsmax_temperature']
+
+    def forward(self, feat_c0, feat_c1, data: Dict[str, torch.Tensor], mask_c0: Optional[torch.Tensor] = None,
+                mask_c1: Optional[torch.Tensor] = None, lazy: bool = False):
+        """Updates data with conf_matrix, b_ids, i_ids, j_ids, m_bids, mkpts0_c, mkpts1_c, mconf.
+        lazy=True keeps the match arrays at capacity with their count on the device (data['_coarse_dev'])
+        and does not synchronise; GeoModule consumes that form directly."""
+        scale = float(data['hw0_i'][0]) / float(data['hw0_c'][0])
+        raw = ops.dual_softmax_match(feat_c0, feat_c1, self.temperature, self.thr, data['hw0_c'], data['hw1_c'], scale,
+                                     mask_c0, mask_c1, data.get('scale0'), data.get('scale1'),
+                                     force_one='dataset_name' in data)
+        data['conf_matrix'] = raw['conf_matrix']
+        data['_coarse_dev'] = raw
+        if not lazy:
+            data.update(materialize_matches(raw))
+        return raw
+
+
+def materialize_matches(raw):
+    m = int(raw['counts'][0])              # the one host sync of the coarse stage
+    out = {k: raw[k][:m] for k in ('b_ids', 'i_ids', 'j_ids', 'mkpts0_c', 'mkpts1_c', 'mconf')}
+    out['m_bids'] = out['b_ids']
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# GeoModule / GeoTransformer  (reference: model/geo_module.py, model/geo_transformer/transformer.py)
+# ---------------------------------------------------------------------------------------------
+class GeoTransformer(nn.Module):
+    def __init__(self, config, layer_names, d_model, linear=True):
+        super().__init__()
+        if linear:
+            raise NotImplementedError('GeoModule builds its transformer with linear=False (geo_module.py:20-21)')
+        self.config, self.d_model, self.layer_names, self.nhead = config, d_model, layer_names, config['nhead']
+        layer = LoFTREncoderLayer(d_model, self.nhead, 'full', 'tanh')
+        self.layers = nn.ModuleList([copy.deepcopy(layer) for _ in self.layer_names])
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        self.norm = nn.LayerNorm(d_model)         # present in the checkpoint, never applied (:144-145)
+
+    def forward(self, feat0, feat1, geo):
+        """feat0 [N,L,C], feat1 [N,S,C]; geo = dict(idx0, idx1, nidx, win0, win1, valid) on the device:
+        idx*/nidx = tokens at inlier cells (self layers), win1 = cells of image1 seen from each cell of
+        image0 and win0 the converse (cross layers), valid = per-sample 'homography found'."""
+        assert self.d_model == feat0.size(2), 'the feature number of src and transformer must be equal'
+        n = feat0.shape[0]
+        same = feat0.shape == feat1.shape
+        nk = geo['nidx']
+        has0, has1 = (nk[:, 0] > 0)[:, None, None], (nk[:, 1] > 0)[:, None, None]
+        ok = (geo['valid'] > 0)[:, None, None]
+        for layer, name in zip(self.layers, self.layer_names):
+            if name == 'self':
+                if same:
+                    both = torch.cat([feat0, feat1], 0)
+                    k, v = layer.project_kv(both)
+                    msg = ops.self_attention_gathered(layer.project_q(both), k, v, geo['idx_both'], geo['nidx_both'],
+                                                      self.nhead)
+                    upd = layer.finish(both, msg)
+                    feat0 = torch.where(has0, feat0 + upd[:n], feat0)
+                    feat1 = torch.where(has1, feat1 + upd[n:], feat1)
+                else:
+                    k, v = layer.project_kv(feat0)
+                    m0 = ops.self_attention_gathered(layer.project_q(feat0), k, v, geo['idx0'], nk[:, 0], self.nhead)
+                    k, v = layer.project_kv(feat1)
+                    m1 = ops.self_attention_gathered(layer.project_q(feat1), k, v, geo['idx1'], nk[:, 1], self.nhead)
+                    feat0 = torch.where(has0, feat0 + layer.finish(feat0, m0), feat0)
+                    feat1 = torch.where(has1, feat1 + layer.finish(feat1, m1), feat1)
+            elif name == 'cross':
+                # keys/values of BOTH images come from the pre-update features (the reference gathers
+                # feat0_cross and feat1_cross before either update, :126-129); project, then gather.
+                k0, v0 = layer.project_kv(feat0)
+                k1, v1 = layer.project_kv(feat1)
+                m0 = ops.window_cross_attention(layer.project_q(feat0), k1, v1, geo['win1'], geo['valid'], self.nhead)
+                m1 = ops.window_cross_attention(layer.project_q(feat1), k0, v0, geo['win0'], geo['valid'], self.nhead)
+                u0, u1 = layer.finish(feat0, m0), layer.finish(feat1, m1)
+                feat0 = torch.where(ok, feat0 + u0, feat0)
+                feat1 = torch.where(ok, feat1 + u1, feat1)
+            else:
+                raise KeyError
+        return feat0, feat1
+
+
+class GeoModule(nn.Module):
+    def __init__(self, config, d_model):
+        super().__init__()
+        self.d_model = d_model
+        self.window_size = config['window_size']
+        self.pos_encoding = PositionEncodingSine(d_model)
+        self.des_transformer = GeoTransformer(config, config['layer_names'], d_model, linear=False)
+        self.ransac_thr = 8.0                     # cv2.findHomography(..., cv2.RANSAC, 8.0) (geo_module.py:48)
+        self.ransac_iters, self.ransac_seed = ops.RANSAC_ITERS, ops.RANSAC_SEED
+        # Optional HOST callback with cv2.findHomography's contract, `fn(kp0 [n,2] int64 ndarray, kp1) ->
+        # (M float64 [3,3] | None, mask uint8 [n,1])`, called per sample with > 8 matches exactly like
+        # geo_module.py:45-48 (e.g. lambda a, b: cv2.findHomography(a, b, cv2.RANSAC, 8.0), or a replay of
+        # recorded homographies in parity tests).  None (default) = the device RANSAC, no host round trip.
+        self.homography_fn = None
+
+    def _host_homographies(self, rs, counts, n, dev):
+        cnt = counts.cpu().tolist()                      # host sync (only on this optional path)
+        kp0, kp1 = rs['kp0'].cpu().numpy(), rs['kp1'].cpu().numpy()
+        M = torch.zeros(n, 3, 3, dtype=torch.float64)
+        valid = torch.zeros(n, dtype=torch.int32)
+        keep = torch.ones(max(cnt[0], 1), dtype=torch.uint8)
+        off = 0
+        for b in range(n):
+            c = cnt[1 + b]
+            if c > 8:
+                Mb, mask = self.homography_fn(kp0[off:off + c].astype('int64'), kp1[off:off + c].astype('int64'))
+                if Mb is not None:
+                    M[b] = torch.as_tensor(Mb, dtype=torch.float64)
+                    valid[b] = 1
+                    keep[off:off + c] = torch.as_tensor(mask).reshape(-1).to(torch.uint8)
+            off += c
+        rs['M'], rs['valid'] = M.to(dev), valid.to(dev)
+        rs['keep'][:keep.numel()] = keep.to(dev)
+        rs['M_f32'] = M.float().to(dev)                                   # cast of geo_module.py:58
+        safe = torch.where(valid.bool()[:, None, None], M, torch.eye(3, dtype=torch.float64))
+        rs['Minv_f32'] = torch.inverse(safe).float().to(dev)              # inverse in fp64, then cast (:67)
+
+    def geometry(self, batch, n, hw0c, hw1c, dev):
+        """RANSAC -> inlier token lists -> window cell tables, all on the device (apply_RANSAC, :23-94)."""
+        raw = batch.get('_coarse_dev')
+        if raw is None:                            # plain tensors: rebuild the device-side form
+            mb = batch['m_bids']
+            counts = torch.cat([torch.tensor([mb.numel()], device=dev), torch.bincount(mb, minlength=n)]).to(torch.int32)
+            raw = {'mkpts0_c': batch['mkpts0_c'].contiguous(), 'mkpts1_c': batch['mkpts1_c'].contiguous(), 'counts': counts}
+        H0, W0 = batch['image0'].shape[2:]
+        H1, W1 = batch['image1'].shape[2:]
+        scale = int(batch['hw0_i'][0]) // int(batch['hw0_c'][0])
+        s0, s1 = batch.get('scale0'), batch.get('scale1')
+        rs = ops.ransac_homography(raw['mkpts0_c'], raw['mkpts1_c'], raw['counts'], n, scale, s0, s1, self.ransac_thr,
+                                   self.ransac_iters, self.ransac_seed)
+        if self.homography_fn is not None:
+            self._host_homographies(rs, raw['counts'], n, dev)
+        L, S = hw0c[0] * hw0c[1], hw1c[0] * hw1c[1]
+        geo = ops.inlier_index(rs['kp0'], rs['kp1'], rs['keep'], raw['counts'], n, L, S, hw0c[1], hw1c[1], scale)
+        # windows in image1 for the cells of image0 (M), and in image0 for the cells of image1 (M^-1)
+        geo['win1'] = ops.window_geometry(rs['M_f32'], rs['valid'], hw0c, (H1, W1), hw1c[1], scale, self.window_size, s1)
+        geo['win0'] = ops.window_geometry(rs['Minv_f32'], rs['valid'], hw1c, (H0, W0), hw0c[1], scale, self.window_size, s0)
+        geo['valid'] = rs['valid']
+        if L == S:
+            geo['idx_both'] = torch.cat([geo['idx0'], geo['idx1']], 0)
+            geo['nidx_both'] = geo['nidx'].t().contiguous().view(-1)
+        geo['ransac'] = rs
+        return geo
+
+    def forward(self, cnn_desc0, cnn_desc1, batch, desc_map0=None, desc_map1=None, dtype=None):
+        """cnn_desc0/1: raw backbone coarse maps [N,C,h,w]; position encoding is added here
+        (geo_module.py:28-29) unless the caller passes the already encoded [N,L,C] maps."""
+        n = cnn_desc0.shape[0]
+        hw0c, hw1c = tuple(cnn_desc0.shape[2:]), tuple(cnn_desc1.shape[2:])
+        if desc_map0 is None:
+            desc_map0 = self.pos_encoding(cnn_desc0, dtype)
+            desc_map1 = self.pos_encoding(cnn_desc1, dtype)
+        geo = self.geometry(batch, n, hw0c, hw1c, cnn_desc0.device)
+        batch['_geo_dev'] = geo
+        return self.des_transformer(desc_map0, desc_map1, geo)
+
+
+# ---------------------------------------------------------------------------------------------
+# fine level  (reference: loftr_module/fine_preprocess.py, model/fine_matching2.py)
+# ---------------------------------------------------------------------------------------------
+class FinePreprocess(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.cat_c_feat = config['fine_concat_coarse_feat']
+        self.W = config['fine_window_size']
+        d_c, d_f = config['coarse']['d_model'], config['fine']['d_model']
+        self.d_model_f = d_f
+        if not self.cat_c_feat:
+            raise NotImplementedError('GeoFormer always concatenates the coarse context (cvpr_ds_config.py:13)')
+        self.down_proj = nn.Linear(d_c, d_f, bias=True)
+        self.merge_feat = nn.Linear(2 * d_f, d_f, bias=True)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.kaiming_normal_(p, mode='fan_out', nonlinearity='relu')
+        self._cache = {}
+
+    def invalidate(self):
+        self._cache = {}
+
+    def weights(self, dtype):
+        w = self._cache.get(dtype)
+        if w is None:
+            d = self.d_model_f
+            mw = self.merge_feat.weight.detach()
+            w = {'dw': self.down_proj.weight.detach().to(dtype).contiguous(), 'db': self.down_proj.bias.detach().to(dtype),
+                 'mw_win': mw[:, :d].to(dtype).contiguous(), 'mw_ctx': mw[:, d:].to(dtype).contiguous(),
+                 'mb': self.merge_feat.bias.detach().to(dtype)}
+            self._cache[dtype] = w
+        return w
+
+    def forward(self, feat_f0, feat_f1, feat_c0, feat_c1, data: Dict[str, torch.Tensor]):
+        W = self.W
+        stride = int(data['hw0_f'][0]) // int(data['hw0_c'][0])
+        data.update({'W': torch.tensor(W)})
+        dtype = feat_c0.dtype
+        M = data['b_ids'].shape[0]
+        if M == 0:
+            e = torch.empty(0, W ** 2, self.d_model_f, device=feat_f0.device, dtype=dtype)
+            return e, e.clone()
+        win, ccat = ops.fine_gather(feat_f0, feat_f1, feat_c0, feat_c1, data['b_ids'], data['i_ids'], data['j_ids'],
+                                    int(data['hw0_c'][1]), int(data['hw1_c'][1]), stride, W, dtype)
+        w = self.weights(dtype)
+        ctx = F.linear(F.linear(ccat, w['dw'], w['db']), w['mw_ctx'], w['mb'])          # once per match, not per cell
+        out = F.linear(win, w['mw_win']) + ctx[:, None, :]                              # == merge_feat(cat([win, ctx]))
+        return out[:M], out[M:]
+
+
+class FineMatching2(nn.Module):
+    def __init__(self, temperature=0.1, thr=0.1):
+        super().__init__()
+        self.temperature, self.thr = temperature, thr
+
+    def forward(self, feat_f0, feat_f1, data: Dict[str, torch.Tensor]):
+        M, WW, C = feat_f0.shape
+        if M == 0:        # fine_matching2.py:34-42: mconf / m_bids keep their coarse values
+            data.update({'fine_matrix': torch.empty(0, WW, WW, device=feat_f0.device),
+                         'mkpts0_f': data['mkpts0_c'], 'mkpts1_f': data['mkpts1_c']})
+            return
+        hi, hc, hf = float(data['hw0_i'][0]), float(data['hw0_c'][0]), float(data['hw0_f'][0])
+        out = ops.fine_match(feat_f0, feat_f1, self.temperature, self.thr, data['b_ids'], data['mkpts0_c'],
+                             data['mkpts1_c'], hi / hc, hf / hc, hi / hf, data.get('scale0'), data.get('scale1'))
+        mf = int(out['count'][0])           # final host sync: number of fine matches
+        data.update({'fine_matrix': out['fine_matrix'], 'm_bids': out['m_bids'][:mf], 'mkpts0_f': out['mkpts0_f'][:mf],
+                     'mkpts1_f': out['mkpts1_f'][:mf], 'mconf': out['mconf'][:mf]})

@@ -86,3 +86,195 @@ def dual_softmax_match(f0, f1, temperature, thr, hw0_c, hw1_c, scale, mask0=None
                                    _p(counts), _p(ws), ws.numel(), _stream()), 'gf_dual_softmax_match')
     return {'conf_matrix': conf, 'b_ids': ids[0], 'i_ids': ids[1], 'j_ids': ids[2], 'mconf': mconf,
             'mkpts0_c': mk[0], 'mkpts1_c': mk[1], 'counts': counts}
+
+
+def _i32p(t):
+    return _p(t)
+
+
+def pos_encode(x, pe_hwc, out_dtype):
+    """a1.  x [N,C,H,W] (any strides, fp32/fp16), pe_hwc fp32 [H,W,C] on the device -> [N, H*W, C]."""
+    _need_cuda(x, pe_hwc)
+    N, C, H, W = x.shape
+    out = torch.empty(N, H * W, C, dtype=out_dtype, device=x.device)
+    sn, sc, sh, sw = x.stride()
+    check(_lib.lib().gf_pos_encode(_p(x), _dt(x), sn, sc, sh, sw, _p(pe_hwc), _p(out), _DTYPES[out_dtype], N, C, H, W,
+                                   _stream()), 'gf_pos_encode')
+    return out
+
+
+def _rows(t):
+    """[..., C] tensor whose last dim is contiguous -> (tensor, row stride in elements)."""
+    if t.stride(-1) != 1:
+        t = t.contiguous()
+    return t, t.stride(-2)
+
+
+def linear_attention(q, k, v, nhead, q_mask=None, kv_mask=None, eps=1e-6):
+    """K2.  q [N,L,C], k,v [N,S,C] (row-strided views allowed) -> [N,L,C]."""
+    _need_cuda(q, k, v)
+    N, L, C = q.shape
+    S = k.shape[1]
+    D = C // nhead
+    q, ldq = _rows(q)
+    k, ldk = _rows(k)
+    v, ldv = _rows(v)
+    for t, ld, n in ((q, ldq, L), (k, ldk, S), (v, ldv, S)):
+        if t.stride(0) != ld * n:
+            raise ValueError('linear_attention needs batch stride == rows * row stride')
+    out = torch.empty(N, L, C, dtype=q.dtype, device=q.device)
+    qm = None if q_mask is None else _contig(q_mask.reshape(N, L).to(torch.uint8))
+    km = None if kv_mask is None else _contig(kv_mask.reshape(N, S).to(torch.uint8))
+    L_ = _lib.lib()
+    nbytes = L_.gf_linear_attention_workspace_bytes(N, S, nhead, D)
+    ws = _ws.get('k2', nbytes, q.device)
+    check(L_.gf_linear_attention(_p(q), _p(k), _p(v), _dt(q), N, L, S, nhead, D, ldq, ldk, ldv, _p(qm), _p(km),
+                                 float(eps), _p(out), _p(ws), ws.numel(), _stream()), 'gf_linear_attention')
+    return out
+
+
+RANSAC_ITERS = 1024
+RANSAC_SEED = 0x5EED
+
+
+def ransac_homography(mkpts0_c, mkpts1_c, counts, N, scale, scale0=None, scale1=None, thr=8.0, iters=RANSAC_ITERS,
+                      seed=RANSAC_SEED):
+    """Device RANSAC on the first-pass coarse matches.  Returns dict(kp0, kp1 int32 [cap,2], M fp64 [N,3,3],
+    M_f32, Minv_f32 [N,3,3], valid int32 [N], keep uint8 [cap])."""
+    _need_cuda(mkpts0_c, mkpts1_c, counts)
+    dev = mkpts0_c.device
+    cap = mkpts0_c.shape[0]
+    kp = torch.empty(2, max(cap, 1), 2, dtype=torch.int32, device=dev)
+    M = torch.empty(N, 3, 3, dtype=torch.float64, device=dev)
+    Mf = torch.empty(2, N, 3, 3, dtype=torch.float32, device=dev)
+    valid = torch.empty(N, dtype=torch.int32, device=dev)
+    keep = torch.empty(max(cap, 1), dtype=torch.uint8, device=dev)
+    s0 = None if scale0 is None else _contig(scale0.to(device=dev, dtype=torch.float32))
+    s1 = None if scale1 is None else _contig(scale1.to(device=dev, dtype=torch.float32))
+    L_ = _lib.lib()
+    nbytes = L_.gf_ransac_workspace_bytes(N, iters)
+    ws = _ws.get('ransac', nbytes, dev)
+    check(L_.gf_ransac_homography(_p(mkpts0_c), _p(mkpts1_c), _p(counts), N, max(cap, 1), float(scale), _p(s0), _p(s1),
+                                  float(thr), int(iters), int(seed), _p(kp[0]), _p(kp[1]), _p(M), _p(Mf[0]), _p(Mf[1]),
+                                  _p(valid), _p(keep), _p(ws), ws.numel(), _stream()), 'gf_ransac_homography')
+    return {'kp0': kp[0], 'kp1': kp[1], 'M': M, 'M_f32': Mf[0], 'Minv_f32': Mf[1], 'valid': valid, 'keep': keep}
+
+
+def window_geometry(H_f32, valid, grid_hw, img_hw, key_grid_w, scale=8, window_size=5, window_scale=None,
+                    debug=False):
+    """a8.  H_f32 [N,3,3] maps the query grid (grid_hw cells) into the image of size img_hw (pixels).
+    -> win int32 [N, L, ws*ws] (+ kps int32 [N,L,ww,2], warped fp32 [N,L,2] when debug)."""
+    _need_cuda(H_f32)
+    N = H_f32.shape[0]
+    hq, wq = grid_hw
+    L = hq * wq
+    ww = window_size * window_size
+    dev = H_f32.device
+    win = torch.empty(N, L, ww, dtype=torch.int32, device=dev)
+    kps = torch.empty(N, L, ww, 2, dtype=torch.int32, device=dev) if debug else None
+    warped = torch.empty(N, L, 2, dtype=torch.float32, device=dev) if debug else None
+    wsc = None if window_scale is None else _contig(window_scale.to(device=dev, dtype=torch.float32))
+    Hc = _contig(H_f32.reshape(N, 9).float())
+    check(_lib.lib().gf_window_geometry(_p(Hc), _p(valid), N, hq, wq, int(img_hw[0]), int(img_hw[1]), int(key_grid_w),
+                                        int(scale), int(window_size), _p(wsc), _p(win), _p(kps), _p(warped), _stream()),
+          'gf_window_geometry')
+    return (win, kps, warped) if debug else win
+
+
+def inlier_index(kp0, kp1, keep, counts, N, L, S, w0, w1, scale=8):
+    """a7.  -> dict(map0 uint8 [N,L], map1 [N,S], idx0 int32 [N,L], idx1 [N,S], nidx int32 [N,2])."""
+    dev = kp0.device
+    map0 = torch.empty(N, L, dtype=torch.uint8, device=dev)
+    map1 = torch.empty(N, S, dtype=torch.uint8, device=dev)
+    idx0 = torch.empty(N, L, dtype=torch.int32, device=dev)
+    idx1 = torch.empty(N, S, dtype=torch.int32, device=dev)
+    nidx = torch.empty(N, 2, dtype=torch.int32, device=dev)
+    check(_lib.lib().gf_inlier_index(_p(kp0), _p(kp1), _p(keep), _p(counts), N, L, S, int(w0), int(w1), int(scale),
+                                     _p(map0), _p(map1), _p(idx0), _p(idx1), _p(nidx), _stream()), 'gf_inlier_index')
+    return {'map0': map0, 'map1': map1, 'idx0': idx0, 'idx1': idx1, 'nidx': nidx}
+
+
+def self_attention_gathered(q, kmap, vmap, idx, nkeys, nhead=4):
+    """K4.  q, kmap, vmap [N,L,256] (row-strided views ok); idx int32 [N,>=L]; nkeys int32 view with one
+    entry per sample (any stride) -> [N,L,256]."""
+    _need_cuda(q, kmap, vmap, idx, nkeys)
+    N, L, C = q.shape
+    q, ldq = _rows(q)
+    kmap, ldk = _rows(kmap)
+    vmap, ldv = _rows(vmap)
+    for t, ld in ((q, ldq), (kmap, ldk), (vmap, ldv)):
+        if t.stride(0) != ld * L:
+            raise ValueError('self_attention_gathered needs batch stride == L * row stride')
+    out = torch.empty(N, L, C, dtype=q.dtype, device=q.device)
+    L_ = _lib.lib()
+    nbytes = L_.gf_self_attention_workspace_bytes(N, L, _dt(q))
+    ws = _ws.get('k4', nbytes, q.device)
+    check(L_.gf_self_attention_gathered(_p(q), _p(kmap), _p(vmap), _dt(q), N, L, nhead, C // nhead, ldq, ldk, ldv,
+                                        _p(idx), idx.stride(0), _p(nkeys), nkeys.stride(0) if nkeys.dim() else 1,
+                                        _p(out), _p(ws), ws.numel(), _stream()), 'gf_self_attention_gathered')
+    return out
+
+
+def window_cross_attention(q, kmap, vmap, win, valid=None, nhead=4):
+    """K5.  q [N,L,256]; kmap, vmap [N,S,256]; win int32 [N,L,25] -> [N,L,256]."""
+    _need_cuda(q, kmap, vmap, win)
+    N, L, C = q.shape
+    S = kmap.shape[1]
+    q, ldq = _rows(q)
+    kmap, ldk = _rows(kmap)
+    vmap, ldv = _rows(vmap)
+    if q.stride(0) != ldq * L or kmap.stride(0) != ldk * S or vmap.stride(0) != ldv * S:
+        raise ValueError('window_cross_attention needs batch stride == rows * row stride')
+    out = torch.empty(N, L, C, dtype=q.dtype, device=q.device)
+    check(_lib.lib().gf_window_cross_attention(_p(q), _p(kmap), _p(vmap), _dt(q), N, L, S, nhead, C // nhead, ldq, ldk,
+                                               ldv, _p(win), win.shape[-1], _p(valid), _p(out), _stream()),
+          'gf_window_cross_attention')
+    return out
+
+
+def fine_gather(feat_f0, feat_f1, feat_c0, feat_c1, b_ids, i_ids, j_ids, w0c, w1c, stride, window, out_dtype):
+    """K7.  feat_f* [N,Cf,H,W] any strides; feat_c* [N,L,CC] contiguous of out_dtype; ids int64 [M] (M > 0)
+    -> (win [2M, W*W, Cf], ccat [2M, CC])."""
+    _need_cuda(feat_f0, feat_f1, feat_c0, feat_c1, b_ids)
+    M = b_ids.shape[0]
+    Cf = feat_f0.shape[1]
+    CC = feat_c0.shape[-1]
+    dev = feat_f0.device
+    win = torch.empty(2 * M, window * window, Cf, dtype=out_dtype, device=dev)
+    ccat = torch.empty(2 * M, CC, dtype=out_dtype, device=dev)
+    s0 = (ctypes.c_long * 4)(*feat_f0.stride())
+    s1 = (ctypes.c_long * 4)(*feat_f1.stride())
+    fc0, fc1 = _contig(feat_c0), _contig(feat_c1)
+    if fc0.dtype != out_dtype or fc1.dtype != out_dtype or feat_f0.dtype != feat_f1.dtype:
+        raise TypeError('fine_gather: coarse features must already be in out_dtype; fine maps must share a dtype')
+    check(_lib.lib().gf_fine_gather(_p(feat_f0), _p(feat_f1), _dt(feat_f0), ctypes.cast(s0, ctypes.c_void_p),
+                                    ctypes.cast(s1, ctypes.c_void_p), feat_f0.shape[2], feat_f0.shape[3], feat_f1.shape[2],
+                                    feat_f1.shape[3], Cf, _p(fc0), _p(fc1), _DTYPES[out_dtype], fc0.shape[1], fc1.shape[1],
+                                    CC, _p(_contig(b_ids)), _p(_contig(i_ids)), _p(_contig(j_ids)), M, int(w0c), int(w1c),
+                                    int(stride), int(window), _p(win), _p(ccat), _stream()), 'gf_fine_gather')
+    return win, ccat
+
+
+def fine_match(f0, f1, temperature, thr, b_ids, mkpts0_c, mkpts1_c, coarse_scale, c2f_scale, fine_scale, scale0=None,
+               scale1=None):
+    """K8.  f0, f1 [M,25,C] (M > 0) -> dict(fine_matrix [M,25,25], mkpts0_f/mkpts1_f [M,2] (first count rows
+    valid), mconf [M], m_bids int64 [M], count int32 [1])."""
+    _need_cuda(f0, f1)
+    f0, f1 = _contig(f0), _contig(f1)
+    M, WW, C = f0.shape
+    dev = f0.device
+    fm = torch.empty(M, WW, WW, dtype=torch.float32, device=dev)
+    mk = torch.empty(2, M, 2, dtype=torch.float32, device=dev)
+    mconf = torch.empty(M, dtype=torch.float32, device=dev)
+    mb = torch.empty(M, dtype=torch.int64, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    s0 = None if scale0 is None else _contig(scale0.to(device=dev, dtype=torch.float32))
+    s1 = None if scale1 is None else _contig(scale1.to(device=dev, dtype=torch.float32))
+    L_ = _lib.lib()
+    nbytes = L_.gf_fine_match_workspace_bytes(M)
+    ws = _ws.get('k8', nbytes, dev)
+    check(L_.gf_fine_match(_p(f0), _p(f1), _dt(f0), M, WW, C, float(temperature), float(thr), _p(_contig(b_ids)),
+                           _p(_contig(mkpts0_c)), _p(_contig(mkpts1_c)), float(coarse_scale), float(c2f_scale),
+                           float(fine_scale), _p(s0), _p(s1), _p(fm), _p(mk[0]), _p(mk[1]), _p(mconf), _p(mb), _p(count),
+                           _p(ws), ws.numel(), _stream()), 'gf_fine_match')
+    return {'fine_matrix': fm, 'mkpts0_f': mk[0], 'mkpts1_f': mk[1], 'mconf': mconf, 'm_bids': mb, 'count': count}

@@ -59,6 +59,121 @@ int gf_dual_softmax_match(const void* f0, const void* f1, int dtype, int N, int 
                           int64_t* j_ids, float* mconf, float* mkpts0_c, float* mkpts1_c,
                           int32_t* counts, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * a1  position encoding add + flatten
+ * replaces PositionEncodingSine.forward (model/loftr_src/loftr/utils/position_encoding.py:37-42)
+ *          and the permute/reshape of model/full_model.py:69-77
+ *   out[n, y*W+x, c] = x[n,c,y,x] + pe[y,x,c];  x viewed as [N,C,H,W] through element strides
+ *   (NCHW or channels_last), pe fp32 [H,W,C] (host table built as position_encoding.py:22-35).
+ * ------------------------------------------------------------------------------------------ */
+int gf_pos_encode(const void* x, int x_dtype, long sn, long sc, long sh, long sw, const float* pe,
+                  void* out, int out_dtype, int N, int C, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K2  linear attention
+ * replaces LinearAttention.forward (model/loftr_src/loftr/loftr_module/linear_attention.py:21-51)
+ *   q [N,L,H,D], k,v [N,S,H,D] with row strides ldq/ldk/ldv (elements), masks uint8 or NULL,
+ *   out [N,L,H*D] contiguous.  D in {16,32,64}, H*D in {64,128,192,256}.
+ * ------------------------------------------------------------------------------------------ */
+size_t gf_linear_attention_workspace_bytes(int N, int S, int H, int D);
+int gf_linear_attention(const void* q, const void* k, const void* v, int dtype, int N, int L, int S, int H,
+                        int D, long ldq, long ldk, long ldv, const uint8_t* q_mask, const uint8_t* kv_mask,
+                        float eps, void* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * homography RANSAC on the device
+ * replaces the cv2.findHomography(kp0, kp1, cv2.RANSAC, 8.0) host round trip and the inlier
+ * filtering of GeoModule.apply_RANSAC (model/geo_module.py:38-52).  OpenCV parity is unpinned;
+ * the algorithm is the one stated in oracle/ransac_oracle.c (bit-exact inlier mask).
+ *   mkpts0_c/mkpts1_c [cap,2] fp32 and counts int32[1+N] as written by gf_dual_softmax_match;
+ *   outputs: kp0/kp1 int32 [cap,2] (the .long() keypoints), M fp64 [N,9], M_f32 / Minv_f32 [N,9]
+ *   (the casts of :58 and :67), valid int32 [N] (0 = "M is None"), keep uint8 [cap] (inlier, or 1
+ *   for every match of a sample without model: what feeds the occupancy maps of :82-94).
+ * ------------------------------------------------------------------------------------------ */
+size_t gf_ransac_workspace_bytes(int N, int iters);
+int gf_ransac_homography(const float* mkpts0_c, const float* mkpts1_c, const int32_t* counts, int N,
+                         int capacity, float scale, const float* scale0, const float* scale1, float thr,
+                         int iters, uint32_t seed, int32_t* kp0, int32_t* kp1, double* M, float* M_f32,
+                         float* Minv_f32, int32_t* valid, uint8_t* keep, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a8  window geometry
+ * replaces get_map_keypoints (utils/common_utils.py:137-144) + warp_points_batch
+ * (utils/homography.py:86-105) + generate_window (utils/common_utils.py:65-91) + the cell lookup of
+ * sample_descriptors (utils/common_utils.py:171-181)
+ *   H fp32 [N,9] maps the (hq x wq) coarse grid of the query image into the other image
+ *   (Himg x Wimg pixels, coarse width wk); win int32 [N, hq*wq, ws*ws] = coarse cell sampled by each
+ *   window position or -1 when out of bounds (or when valid[n] == 0).
+ *   Optional outputs for tests: kps int32 [N,L,ws*ws,2] (the .long() window coordinates, 0 when
+ *   out of bounds) and warped fp32 [N,L,2].
+ * ------------------------------------------------------------------------------------------ */
+int gf_window_geometry(const float* H, const int32_t* valid, int N, int hq, int wq, int Himg, int Wimg,
+                       int wk, int scale, int window_size, const float* window_scale, int32_t* win,
+                       int32_t* kps_or_null, float* warped_or_null, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a7  inlier occupancy maps + token lists
+ * replaces model/geo_module.py:82-94 and the boolean-mask gathers feat[mask] of
+ * model/geo_transformer/transformer.py:118,121
+ *   map0 uint8 [N,L], map1 uint8 [N,S]; idx0 int32 [N,L], idx1 int32 [N,S] ascending cell lists;
+ *   nidx int32 [N,2] their lengths.
+ * ------------------------------------------------------------------------------------------ */
+int gf_inlier_index(const int32_t* kp0, const int32_t* kp1, const uint8_t* keep, const int32_t* counts, int N,
+                    int L, int S, int w0, int w1, int scale, uint8_t* map0, uint8_t* map1, int32_t* idx0,
+                    int32_t* idx1, int32_t* nidx, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K4  self attention over the tokens at inlier cells
+ * replaces FullAttention.forward (model/geo_transformer/geo_attention.py:72-101) as called from the
+ * 'self' branch of GeoTransformer.forward (model/geo_transformer/transformer.py:111-124)
+ *   q [N,L,256], kmap/vmap [N,L,256] = k_proj/v_proj of EVERY token (row strides ld*), idx/nkeys =
+ *   the token list of gf_inlier_index; out [N,L,256]; nkeys == 0 -> zeros (layer skipped by caller).
+ * ------------------------------------------------------------------------------------------ */
+size_t gf_self_attention_workspace_bytes(int N, int L, int dtype);
+int gf_self_attention_gathered(const void* q, const void* kmap, const void* vmap, int dtype, int N, int L, int H,
+                               int D, long ldq, long ldk, long ldv, const int32_t* idx, long idx_stride,
+                               const int32_t* nkeys, int nkeys_stride, void* out, void* workspace,
+                               size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K5  windowed cross attention
+ * replaces sample_descriptors (utils/common_utils.py:166-208) + FullAttention.forward with kv_mask
+ * (model/geo_transformer/geo_attention.py:72-101) as called from the 'cross' branch of
+ * GeoTransformer.forward (model/geo_transformer/transformer.py:125-139)
+ *   q [N,L,256]; kmap/vmap [N,S,256] = k_proj/v_proj of every token of the OTHER image;
+ *   win int32 [N,L,25] from gf_window_geometry; out [N,L,256] (zeros where all 25 are masked).
+ * ------------------------------------------------------------------------------------------ */
+int gf_window_cross_attention(const void* q, const void* kmap, const void* vmap, int dtype, int N, int L, int S,
+                              int H, int D, long ldq, long ldk, long ldv, const int32_t* win, int WW,
+                              const int32_t* valid, void* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K7  fine window extraction
+ * replaces F.unfold + gather + coarse-row gather of FinePreprocess.forward
+ * (model/loftr_src/loftr/loftr_module/fine_preprocess.py:41-61)
+ *   feat_f0/1 viewed as [N,C,H,W] through strides (4 longs each); feat_c0 [N,L,CC], feat_c1 [N,S,CC];
+ *   win_out [2M, W*W, C] (image0 windows then image1), ccat_out [2M, CC].
+ * ------------------------------------------------------------------------------------------ */
+int gf_fine_gather(const void* feat_f0, const void* feat_f1, int feat_dtype, const long* strides0,
+                   const long* strides1, int H0, int W0, int H1, int W1, int C, const void* feat_c0,
+                   const void* feat_c1, int dtype, int L, int S, int CC, const int64_t* b_ids,
+                   const int64_t* i_ids, const int64_t* j_ids, int M, int w0c, int w1c, int stride, int window,
+                   void* win_out, void* ccat_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K8  fine matching
+ * replaces FineMatching2.forward + get_fine_match (model/fine_matching2.py:21-126), M > 0 branch
+ *   f0, f1 [M,25,C]; fine_matrix fp32 [M,25,25]; compacted mkpts0_f/mkpts1_f [Mf,2], mconf [Mf],
+ *   m_bids int64 [Mf]; count int32 [1] = Mf (device).
+ * ------------------------------------------------------------------------------------------ */
+size_t gf_fine_match_workspace_bytes(int M);
+int gf_fine_match(const void* f0, const void* f1, int dtype, int M, int WW, int C, float temperature, float thr,
+                  const int64_t* b_ids, const float* mkpts0_c, const float* mkpts1_c, float coarse_scale,
+                  float c2f_scale, float fine_scale, const float* scale0, const float* scale1,
+                  float* fine_matrix, float* mkpts0_f, float* mkpts1_f, float* mconf, int64_t* m_bids,
+                  int32_t* count, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

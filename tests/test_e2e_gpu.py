@@ -1,0 +1,111 @@
+"""End-to-end parity of geoformer_amd.GeoFormer against the reference's golden vectors (fp32 parity
+mode: coarse indices bit-exact) and against the oracle (fp16 mode; device RANSAC)."""
+import numpy as np
+import pytest
+import torch
+
+import geoformer_oracle as O
+import golden_inputs as GI
+import ransac_oracle as RO
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def build(coarse_thr, fine_thr, precision='fp32'):
+    from geoformer_amd.model.full_model import GeoFormer
+    from geoformer_amd.model.cvpr_ds_config import get_default_cfg
+    from geoformer_amd.model.geo_config import get_cfg_model
+    gc = get_cfg_model(); gc.update(coarse_thr=coarse_thr, fine_thr=fine_thr, precision=precision)
+    m = GeoFormer(get_default_cfg(), gc).eval()
+    m.load_state_dict(O.make_weights())
+    return m.to(DEV)
+
+
+def replay(G):
+    calls = iter(range(int(G['ransac_ncalls'])))
+
+    def fn(a, b):
+        i = next(calls)
+        np.testing.assert_array_equal(a, G[f'ransac{i}_kp0']); np.testing.assert_array_equal(b, G[f'ransac{i}_kp1'])
+        return (G[f'ransac{i}_M'].copy() if G[f'ransac{i}_valid'] else None), G[f'ransac{i}_mask'].copy()
+    return fn
+
+
+def to_dev(d):
+    return {k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in d.items()}
+
+
+def close(a, b, rtol, atol):
+    np.testing.assert_allclose(a.detach().float().cpu().numpy(), np.asarray(b), rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize('name', list(GI.g10_cases().keys()))
+def test_golden_fp32(golden, name):
+    """Reference outputs, injected reference homographies: coarse and fine indices bit-exact."""
+    G, case = golden(name), GI.g10_cases()[name]
+    m = build(case['coarse_thr'], case['fine_thr'])
+    m.geo_module.homography_fn = replay(G)
+    data = to_dev(case['data'])
+    with torch.no_grad():
+        if case['feats'] is None:
+            out = m(data)
+        else:
+            (c0, f0), (c1, f1) = case['feats']
+            out = m.forward_features(data, c0.to(DEV), f0.to(DEV), c1.to(DEV), f1.to(DEV))
+    for k in ('b_ids', 'i_ids', 'j_ids', 'm_bids'):
+        np.testing.assert_array_equal(out[k].cpu().numpy(), G['out_' + k])
+    for k in ('mkpts0_c', 'mkpts1_c', 'mkpts0_f', 'mkpts1_f'):
+        close(out[k], G['out_' + k], 1e-6, 1e-5)
+    close(out['mconf'], G['out_mconf'], 1e-3, 1e-6)
+    close(out['conf_matrix'], G['out_conf_matrix'], 5e-3, 1e-7)
+    close(out['dect_conf_matrix'], G['out_dect_conf_matrix'], 5e-3, 1e-7)
+    close(out['fine_matrix'][:12], G['out_fine_matrix_head'], 5e-3, 1e-7)
+    for k in ('loftr_f0', 'loftr_f1', 'geo_f0', 'geo_f1'):
+        close(out['_feat_dev'][k][..., ::4], G['mid_' + k], 1e-3, 5e-4)
+    assert int(out['W']) == 5
+
+
+def test_640_digest_fp32(golden):
+    """BASELINE size (80x80 grids): coarse ids and fine keypoints bit-identical to the reference run."""
+    G, case = golden('g11_e2e_640_digest'), GI.g11_inputs()
+    m = build(case['coarse_thr'], case['fine_thr'])
+    n = int(G['ransac0_n'])
+    mask = np.unpackbits(G['ransac0_mask'])[:n].astype(np.uint8)[:, None]
+    m.geo_module.homography_fn = lambda a, b: (G['ransac0_M'].copy(), mask)
+    (c0, f0), (c1, f1) = case['feats']
+    with torch.no_grad():
+        out = m.forward_features(to_dev(case['data']), c0.to(DEV), f0.to(DEV), c1.to(DEV), f1.to(DEV))
+    assert len(out['b_ids']) == int(G['M']) and len(out['mkpts0_f']) == int(G['Mf'])
+    np.testing.assert_array_equal(out['i_ids'].cpu().numpy(), G['i_ids'].astype(np.int64))
+    np.testing.assert_array_equal(out['j_ids'].cpu().numpy(), G['j_ids'].astype(np.int64))
+    np.testing.assert_array_equal(GI.digest(out['b_ids'].cpu(), out['i_ids'].cpu(), out['j_ids'].cpu()), G['coarse_ids_digest'])
+    np.testing.assert_array_equal(GI.digest(out['mkpts0_f'].cpu(), out['mkpts1_f'].cpu()), G['fine_kpts_digest'])
+    close(out['mconf'][:64], G['mconf_head'], 2e-3, 1e-6)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'fp16'])
+def test_device_ransac_vs_oracle(precision):
+    """No injection: device RANSAC in the product, its C statement in the oracle."""
+    case = GI.g10_cases()['g10b_e2e_planted_n2']
+    m = build(case['coarse_thr'], case['fine_thr'], precision)
+    (c0, f0), (c1, f1) = case['feats']
+    if precision == 'fp16':      # the oracle sees the same rounded backbone features
+        c0, f0, c1, f1 = (t.half().float() for t in (c0, f0, c1, f1))
+    with torch.no_grad():
+        out = m.forward_features(to_dev(case['data']), *(t.to(DEV, m.compute_dtype) for t in (c0, f0, c1, f1)))
+    geo_cfg = O.default_geo_config(); geo_cfg.update(coarse_thr=case['coarse_thr'], fine_thr=case['fine_thr'])
+    ref = O.geoformer_forward(O.make_weights(), dict(case['data']), None, geo_cfg, RO.make_homography_fn(), None,
+                              ((c0, f0), (c1, f1)))
+    rs = out['_geo_dev']['ransac']
+    assert [int(v) for v in rs['valid']] == [1, 1]
+    if precision == 'fp32':
+        for k in ('b_ids', 'i_ids', 'j_ids', 'm_bids'):
+            np.testing.assert_array_equal(out[k].cpu().numpy(), ref[k].numpy())
+        close(out['mkpts0_f'], ref['mkpts0_f'], 1e-6, 1e-5); close(out['mkpts1_f'], ref['mkpts1_f'], 1e-6, 1e-5)
+        close(out['mconf'], ref['mconf'], 1e-3, 1e-6)
+    else:                        # fp16 storage: same matches up to a handful of borderline ones
+        a = set(zip(out['b_ids'].tolist(), out['i_ids'].tolist(), out['j_ids'].tolist()))
+        b = set(zip(ref['b_ids'].tolist(), ref['i_ids'].tolist(), ref['j_ids'].tolist()))
+        assert len(a & b) >= 0.97 * max(len(a), len(b))
+        close(out['conf_matrix'], ref['conf_matrix'], 0.1, 2e-2)

@@ -1,0 +1,310 @@
+"""Op-level parity of the HIP kernels (through the C ABI) against the reference's golden vectors and
+the oracle.  fp32 = parity mode (tight tolerances, exact integers); fp16 = oracle on the same
+rounded inputs."""
+import numpy as np
+import pytest
+import torch
+
+import geoformer_oracle as O
+import golden_inputs as GI
+import ransac_oracle as RO
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def close(a, b, rtol, atol):
+    a = a.detach().double().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().double().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def exact(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    np.testing.assert_array_equal(a, b)
+
+
+# ------------------------------------------------------------------ a1
+@pytest.mark.parametrize('tag,fix', [('bug', False), ('fix', True)])
+@pytest.mark.parametrize('layout', ['nchw', 'nhwc'])
+def test_pos_encode_golden(golden, tag, fix, layout):
+    from geoformer_amd.model.modules import PositionEncodingSine
+    G, I = golden('g1_position_encoding'), GI.g1_inputs()
+    pe = PositionEncodingSine(256, temp_bug_fix=fix)
+    x = I['x'].to(DEV)
+    if layout == 'nhwc':
+        x = x.contiguous(memory_format=torch.channels_last)
+    out = pe(x)                                   # [N, H*W, C]
+    ref = torch.from_numpy(G[f'out_{tag}']).permute(0, 2, 3, 1).reshape(1, -1, 256)
+    close(out, ref, 1e-6, 1e-6)
+    tab = pe.table(256, 256, 'cpu')               # [H, W, C]
+    # the table is built by torch CPU sin/cos exactly as the reference builds its buffer; those differ
+    # by a few 1e-6 between CPU generations (AVX2 vs AVX-512 Sleef paths) at large arguments
+    close(tab[I['sample_ys'], I['sample_xs']].T, G[f'table_{tag}_samples'], 1e-6, 2e-5)
+    half = pe(x.half(), torch.float16)
+    close(half, (x.half().float().cpu() + torch.from_numpy(G[f'table_{tag}_4x5'])[None]).permute(0, 2, 3, 1).reshape(1, -1, 256),
+          2e-3, 2e-3)
+
+
+# ------------------------------------------------------------------ K2
+def test_linear_attention_golden_fp32(golden):
+    from geoformer_amd import ops
+    G, I = golden('g2_linear_attention'), GI.g2_inputs()
+
+    def run(q, k, v, qm=None, km=None):
+        n, l, h, d = q.shape
+        o = ops.linear_attention(q.reshape(n, l, -1).to(DEV), k.reshape(n, k.shape[1], -1).to(DEV),
+                                 v.reshape(n, v.shape[1], -1).to(DEV), h, None if qm is None else qm.to(DEV),
+                                 None if km is None else km.to(DEV))
+        return o.reshape(n, l, h, d)
+    close(run(I['q'], I['k'], I['v']), G['out_nomask'], 2e-5, 2e-6)
+    close(run(I['q'], I['k'], I['v'], I['q_mask'], I['kv_mask']), G['out_mask'], 2e-5, 2e-6)
+    close(run(I['qf'], I['kf'], I['vf']), G['out_fine'], 2e-5, 2e-6)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_linear_attention_coarse_shape(dtype):
+    """Coarse-level shape (L = S = 6400, H 8, D 32), strided k/v views as produced by the fused kv GEMM."""
+    from geoformer_amd import ops
+    g = torch.Generator().manual_seed(3)
+    N, L, S, H, D = 2, 6400, 6400, 8, 32
+    q = torch.randn(N, L, H * D, generator=g).to(dtype)
+    kv = torch.randn(N, S, 2 * H * D, generator=g).to(dtype)
+    out = ops.linear_attention(q.to(DEV), kv.to(DEV)[..., :256], kv.to(DEV)[..., 256:], H)
+    ref = O.linear_attention(q.float().view(N, L, H, D), kv.float()[..., :256].reshape(N, S, H, D),
+                             kv.float()[..., 256:].reshape(N, S, H, D)).reshape(N, L, -1)
+    tol = (1e-4, 1e-5) if dtype == torch.float32 else (2e-3, 2e-3)
+    close(out, ref, *tol)
+
+
+# ------------------------------------------------------------------ RANSAC
+def _planted(n, n_out, H, seed):
+    rng = np.random.default_rng(seed)
+    p0 = np.stack([rng.integers(0, 80, n) * 8, rng.integers(0, 80, n) * 8], 1).astype(np.int64)
+    q = np.c_[p0, np.ones(n)] @ H.T
+    p1 = np.floor(q[:, :2] / q[:, 2:3] / 8).astype(np.int64) * 8
+    out = rng.choice(n, n_out, replace=False)
+    p1[out] = np.stack([rng.integers(0, 80, n_out) * 8, rng.integers(0, 80, n_out) * 8], 1)
+    return p0, p1
+
+
+def test_ransac_matches_c_oracle_bit_exact_mask():
+    from geoformer_amd import ops
+    Hs = [np.array([[1., 0, 8], [0, 1, 8], [0, 0, 1]]), np.array([[0.93, -0.21, 44.3], [0.18, 1.07, -9.6], [0, 0, 1]]),
+          np.array([[1.12, 0.08, -21.0], [-0.05, 0.9, 37.5], [2e-4, -1.3e-4, 1]])]
+    sets = [_planted(900, 300, Hs[0], 1), _planted(8, 0, Hs[0], 2), _planted(2500, 1500, Hs[1], 3),
+            (np.zeros((30, 2), np.int64), np.zeros((30, 2), np.int64)), _planted(640, 100, Hs[2], 4), _planted(9, 0, Hs[0], 5)]
+    N = len(sets)
+    counts = torch.tensor([sum(len(s[0]) for s in sets)] + [len(s[0]) for s in sets], dtype=torch.int32)
+    mk0 = torch.from_numpy(np.concatenate([s[0] for s in sets])).float()
+    mk1 = torch.from_numpy(np.concatenate([s[1] for s in sets])).float()
+    rs = ops.ransac_homography(mk0.to(DEV), mk1.to(DEV), counts.to(DEV), N, 8)
+    torch.cuda.synchronize()
+    off = 0
+    for b, (p0, p1) in enumerate(sets):
+        M, mask = RO.find_homography(p0, p1, sample=b)
+        n = len(p0)
+        exact(rs['kp0'][off:off + n], p0); exact(rs['kp1'][off:off + n], p1)
+        assert int(rs['valid'][b]) == (M is not None), b
+        if M is not None:
+            exact(rs['keep'][off:off + n], mask[:, 0])                 # bit-exact inlier mask
+            close(rs['M'][b].double(), M, 1e-9, 1e-9)
+            close(rs['Minv_f32'][b], np.linalg.inv(M), 1e-5, 1e-6)
+        else:
+            exact(rs['keep'][off:off + n], np.ones(n))                 # no model: every match feeds the maps
+        off += n
+    assert [int(v) for v in rs['valid']] == [1, 0, 1, 0, 1, 1]
+
+
+# ------------------------------------------------------------------ a8 / a12
+def test_window_geometry_golden(golden):
+    from geoformer_amd import ops
+    G, I = golden('g6_window_geometry'), GI.g6_inputs()
+    H0, W0, H1, W1 = I['dims']
+    tags = list(I['H'].keys())
+    Hm = torch.tensor(np.stack([I['H'][t] for t in tags])).float().to(DEV)
+    win, kps, warped = ops.window_geometry(Hm, None, (H0 // 8, W0 // 8), (H1, W1), W1 // 8, 8, 5, debug=True)
+    fmap = I['fmap'][0]                                                  # [C, h1, w1]
+    flat = fmap.reshape(fmap.shape[0], -1).T                             # [cells, C]
+    for b, t in enumerate(tags):
+        close(warped[b], G[f'{t}_warped'], 1e-6, 1e-4)
+        exact(kps[b], G[f'{t}_kps'].astype(np.int32))
+        exact(win[b] >= 0, G[f'{t}_mask'])
+        # what the windows gather equals sample_descriptors' output wherever the mask is set
+        got = flat[win[b].cpu().clamp(min=0).long()]                     # [L, 25, C]
+        m = torch.from_numpy(G[f'{t}_mask'])
+        exact(got[m], torch.from_numpy(G[f'{t}_gather'])[m])
+    # valid == 0 -> every window masked
+    valid = torch.tensor([1, 0, 1, 0], dtype=torch.int32, device=DEV)
+    win2 = ops.window_geometry(Hm, valid, (H0 // 8, W0 // 8), (H1, W1), W1 // 8)
+    assert bool((win2[1] == -1).all()) and bool((win2[3] == -1).all()) and torch.equal(win2[0], win[0])
+
+
+def test_inlier_index():
+    from geoformer_amd import ops
+    rng = np.random.default_rng(0)
+    N, h0, w0, h1, w1 = 3, 9, 12, 7, 10
+    cnts = [40, 0, 17]
+    kp0 = np.concatenate([np.stack([rng.integers(0, w0, c) * 8, rng.integers(0, h0, c) * 8], 1) for c in cnts]).astype(np.int32)
+    kp1 = np.concatenate([np.stack([rng.integers(0, w1, c) * 8, rng.integers(0, h1, c) * 8], 1) for c in cnts]).astype(np.int32)
+    keep = (rng.random(sum(cnts)) > 0.3).astype(np.uint8)
+    counts = torch.tensor([sum(cnts)] + cnts, dtype=torch.int32)
+    g = ops.inlier_index(torch.from_numpy(kp0).to(DEV), torch.from_numpy(kp1).to(DEV), torch.from_numpy(keep).to(DEV),
+                         counts.to(DEV), N, h0 * w0, h1 * w1, w0, w1)
+    off = 0
+    for b, c in enumerate(cnts):
+        m0 = np.zeros(h0 * w0, bool); m1 = np.zeros(h1 * w1, bool)
+        sel = keep[off:off + c].astype(bool)
+        m0[(kp0[off:off + c][sel, 1] // 8) * w0 + kp0[off:off + c][sel, 0] // 8] = True
+        m1[(kp1[off:off + c][sel, 1] // 8) * w1 + kp1[off:off + c][sel, 0] // 8] = True
+        exact(g['map0'][b].bool(), m0); exact(g['map1'][b].bool(), m1)
+        k0, k1 = int(g['nidx'][b, 0]), int(g['nidx'][b, 1])
+        exact(g['idx0'][b, :k0], np.nonzero(m0)[0]); exact(g['idx1'][b, :k1], np.nonzero(m1)[0])
+        off += c
+
+
+# ------------------------------------------------------------------ K4
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_self_attention_gathered(dtype):
+    from geoformer_amd import ops
+    g = torch.Generator().manual_seed(4)
+    N, L, C, H = 3, 1000, 256, 4
+    q = torch.randn(N, L, C, generator=g).to(dtype)
+    kv = torch.randn(N, L, 2 * C, generator=g).to(dtype)
+    nk = [333, 0, 70]
+    idx = torch.zeros(N, L, dtype=torch.int32)
+    for b in range(N):
+        idx[b, :nk[b]] = torch.sort(torch.randperm(L, generator=g)[:nk[b]])[0].int()
+    nkeys = torch.tensor(nk, dtype=torch.int32)
+    out = ops.self_attention_gathered(q.to(DEV), kv.to(DEV)[..., :C], kv.to(DEV)[..., C:], idx.to(DEV), nkeys.to(DEV), H)
+    tol = (1e-4, 1e-5) if dtype == torch.float32 else (4e-3, 4e-3)
+    for b in range(N):
+        if nk[b] == 0:
+            assert float(out[b].abs().max()) == 0.0
+            continue
+        sel = idx[b, :nk[b]].long()
+        ref = O.full_attention(q[b].float().view(1, L, H, -1), kv[b, sel, :C].float().view(1, nk[b], H, -1),
+                               kv[b, sel, C:].float().view(1, nk[b], H, -1)).reshape(L, C)
+        close(out[b], ref, *tol)
+
+
+# ------------------------------------------------------------------ K5
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_window_cross_attention(dtype):
+    from geoformer_amd import ops
+    g = torch.Generator().manual_seed(5)
+    N, L, S, C, H = 2, 300, 280, 256, 4
+    q = torch.randn(N, L, C, generator=g).to(dtype)
+    kv = torch.randn(N, S, 2 * C, generator=g).to(dtype)
+    win = torch.randint(0, S, (N, L, 25), generator=g, dtype=torch.int32)
+    win[torch.rand(N, L, 25, generator=g) < 0.3] = -1
+    win[0, 7] = -1                     # a query whose 25 keys are all masked
+    win[1, 8, 1:] = -1
+    valid = torch.tensor([1, 1], dtype=torch.int32)
+    out = ops.window_cross_attention(q.to(DEV), kv.to(DEV)[..., :C], kv.to(DEV)[..., C:], win.to(DEV), valid.to(DEV), H)
+    tol = (1e-4, 1e-5) if dtype == torch.float32 else (4e-3, 4e-3)
+    for b in range(N):
+        cell = win[b].clamp(min=0).long()
+        ks, vs = kv[b, :, :C].float()[cell], kv[b, :, C:].float()[cell]          # [L, 25, C]
+        ref = O.full_attention(q[b].float().view(L, 1, H, -1), ks.view(L, 25, H, -1), vs.view(L, 25, H, -1), None,
+                               win[b] >= 0).reshape(L, C)
+        close(out[b], ref, *tol)
+    assert float(out[0, 7].abs().max()) == 0.0
+    skipped = ops.window_cross_attention(q.to(DEV), kv.to(DEV)[..., :C], kv.to(DEV)[..., C:], win.to(DEV),
+                                         torch.tensor([0, 1], dtype=torch.int32, device=DEV), H)
+    assert float(skipped[0].abs().max()) == 0.0 and torch.equal(skipped[1], out[1])
+
+
+# ------------------------------------------------------------------ K7
+@pytest.mark.parametrize('layout', ['nchw', 'nhwc'])
+def test_fine_gather_vs_oracle(layout):
+    from geoformer_amd import ops
+    I = GI.g8_inputs()
+    f0, f1 = I['feat_f0'].to(DEV), I['feat_f1'].to(DEV)
+    if layout == 'nhwc':
+        f0, f1 = f0.contiguous(memory_format=torch.channels_last), f1.contiguous(memory_format=torch.channels_last)
+    win, ccat = ops.fine_gather(f0, f1, I['feat_c0'].to(DEV), I['feat_c1'].to(DEV), I['b_ids'].to(DEV), I['i_ids'].to(DEV),
+                                I['j_ids'].to(DEV), I['hw0_c'][1], I['hw1_c'][1], 4, 5, torch.float32)
+    M = len(I['b_ids'])
+    exact(win[:M], O.fine_windows(I['feat_f0'], I['b_ids'], I['i_ids'], I['hw0_c'][1], 4, 5))
+    exact(win[M:], O.fine_windows(I['feat_f1'], I['b_ids'], I['j_ids'], I['hw1_c'][1], 4, 5))
+    exact(ccat[:M], I['feat_c0'][I['b_ids'], I['i_ids']]); exact(ccat[M:], I['feat_c1'][I['b_ids'], I['j_ids']])
+
+
+def test_fine_preprocess_golden(golden):
+    from geoformer_amd.model.modules import FinePreprocess
+    from geoformer_amd.model.cvpr_ds_config import get_default_cfg
+    G, I = golden('g8_fine_preprocess'), GI.g8_inputs()
+    fp = FinePreprocess(get_default_cfg())
+    W = O.make_weights()
+    fp.load_state_dict({k[len('fine_preprocess.'):]: v for k, v in W.items() if k.startswith('fine_preprocess.')})
+    fp = fp.to(DEV)
+    d = {'hw0_f': torch.tensor(I['hw0_f']), 'hw0_c': torch.tensor(I['hw0_c']), 'hw1_c': torch.tensor(I['hw1_c']),
+         'b_ids': I['b_ids'].to(DEV), 'i_ids': I['i_ids'].to(DEV), 'j_ids': I['j_ids'].to(DEV)}
+    u0, u1 = fp(I['feat_f0'].to(DEV), I['feat_f1'].to(DEV), I['feat_c0'].to(DEV), I['feat_c1'].to(DEV), d)
+    close(u0, G['out0'], 2e-4, 2e-5); close(u1, G['out1'], 2e-4, 2e-5)
+    d.update(b_ids=d['b_ids'][:0], i_ids=d['i_ids'][:0], j_ids=d['j_ids'][:0])
+    e0, e1 = fp(I['feat_f0'].to(DEV), I['feat_f1'].to(DEV), I['feat_c0'].to(DEV), I['feat_c1'].to(DEV), d)
+    exact(np.array(e0.shape + e1.shape), G['empty_shape'])
+
+
+# ------------------------------------------------------------------ K8
+@pytest.mark.parametrize('tag', ['plain', 'scaled'])
+def test_fine_match_golden(golden, tag):
+    from geoformer_amd import ops
+    G, I = golden('g9_fine_matching'), GI.g9_inputs()
+    kw = dict(scale0=I['scale0'], scale1=I['scale1']) if tag == 'scaled' else {}
+    out = ops.fine_match(I['f0'].to(DEV), I['f1'].to(DEV), I['temperature'], I['thr'], I['b_ids'].to(DEV),
+                         I['mkpts0_c'].to(DEV), I['mkpts1_c'].to(DEV), 8.0, 4.0, 2.0, **kw)
+    mf = int(out['count'][0])
+    assert mf == len(G[f'{tag}_mconf']) and mf < len(I['b_ids'])
+    close(out['fine_matrix'], G[f'{tag}_fine_matrix'], 2e-5, 1e-9)
+    exact(out['m_bids'][:mf], G[f'{tag}_m_bids'])
+    close(out['mkpts0_f'][:mf], G[f'{tag}_mkpts0_f'], 1e-6, 1e-5); close(out['mkpts1_f'][:mf], G[f'{tag}_mkpts1_f'], 1e-6, 1e-5)
+    close(out['mconf'][:mf], G[f'{tag}_mconf'], 2e-5, 1e-9)
+
+
+# ------------------------------------------------------------------ encoder layers / schedules
+def _load(module, prefix, W):
+    module.load_state_dict({k[len(prefix):]: v for k, v in W.items() if k.startswith(prefix)})
+    return module.to(DEV)
+
+
+def test_loftr_layers_golden(golden):
+    from geoformer_amd.model.modules import LoFTREncoderLayer, LocalFeatureTransformer
+    from geoformer_amd.model.cvpr_ds_config import get_default_cfg
+    G, I, W = golden('g3_loftr_layer'), GI.g3_inputs(), O.make_weights()
+    lay = _load(LoFTREncoderLayer(256, 8), 'loftr_coarse.layers.0.', W)
+    layf = _load(LoFTREncoderLayer(128, 8), 'loftr_fine.layers.1.', W)
+    d = lambda t: t.to(DEV)
+    close(lay(d(I['x']), d(I['src'])), G['out_cross'], 2e-4, 2e-5)
+    close(lay(d(I['x']), d(I['src']), d(I['x_mask']), d(I['src_mask'])), G['out_cross_masked'], 2e-4, 2e-5)
+    close(lay(d(I['x']), d(I['x'])), G['out_self'], 2e-4, 2e-5)
+    close(layf(d(I['xf']), d(I['sf'])), G['out_fine'], 2e-4, 2e-5)
+    lft = _load(LocalFeatureTransformer(get_default_cfg()['coarse']), 'loftr_coarse.', W)
+    a, b = lft(d(I['f0'][:1]), d(I['f1'][:1]))
+    close(a, G['sched_f0'], 5e-4, 2e-4); close(b, G['sched_f1'], 5e-4, 2e-4)
+    a, b = lft(d(I['f0']), d(I['f1']), d(I['m0']), d(I['m1']))
+    close(a, G['sched_f0_masked'], 5e-4, 2e-4); close(b, G['sched_f1_masked'], 5e-4, 2e-4)
+    # equal shapes take the batched self-layer route: must agree with the oracle too
+    f = I['f0'][:1]
+    a, b = lft(d(f), d(f.flip(1).contiguous()))
+    ra, rb = O.local_feature_transformer(W, 'loftr_coarse.', ['self', 'cross'] * 4, 8, f, f.flip(1).contiguous())
+    close(a, ra, 5e-4, 2e-4); close(b, rb, 5e-4, 2e-4)
+
+
+@pytest.mark.parametrize('tag', ['shift', 'nohomo', 'persp'])
+def test_geo_module_golden(golden, tag):
+    from geoformer_amd.model.modules import GeoModule
+    from geoformer_amd.model.geo_config import get_cfg_model
+    G, I, W = golden('g7_geo_module'), GI.g7_inputs(), O.make_weights()
+    gm = _load(GeoModule(get_cfg_model(), 256), 'geo_module.', W)
+    gm.homography_fn = lambda a, b: ((G[f'{tag}_M'].copy() if G[f'{tag}_valid'] else None), G[f'{tag}_mask'].copy())
+    h, w = I['h'], I['w']
+    batch = {'image0': torch.zeros(2, 1, h * 8, w * 8, device=DEV), 'image1': torch.zeros(2, 1, h * 8, w * 8, device=DEV),
+             'hw0_i': torch.tensor([h * 8, w * 8]), 'hw0_c': torch.tensor([h, w]), 'mkpts0_c': I['mkpts0_c'].to(DEV),
+             'mkpts1_c': I['mkpts1_c'].to(DEV), 'm_bids': I['m_bids'].to(DEV)}
+    o0, o1 = gm(I['c0'].to(DEV), I['c1'].to(DEV), batch)
+    sub = slice(None) if tag == 'shift' else slice(None, None, 4)
+    close(o0[..., sub], G[f'{tag}_out0'], 5e-4, 2e-4); close(o1[..., sub], G[f'{tag}_out1'], 5e-4, 2e-4)
