@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Throughput bench of the GeoFormer matching path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--precision fp16|fp32]
+
+Workload (BASELINE.json configs[4], "batched inference, synthetic 640x640 pairs, fp16 features"):
+every rank owns its static shard of the pair list and runs `steps` batches of `batch` pairs through
+the FULL forward (ResNet-FPN backbone on PyTorch-ROCm + the HIP matching path); there is no data-path
+collective (pairs are independent), so scaling is weak: per-GPU work is fixed as N grows.
+Inputs are resident in HBM before the timed region.  Weights: deterministic closed-form fill of the
+reference architecture (no checkpoint offline); thresholds 0 so that matches flow through every stage,
+as in the reference CPU measurement of BASELINE.md section 2 - M (coarse matches) and K (inlier cells)
+are reported because cost scales with them.
+
+One JSON line on rank 0 (see README / DESIGN.md for the fields).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def synth_pairs(batch, seed, size=640, device='cpu'):
+    """bench-pair(seed): low-frequency texture + pixel noise; image1 = image0 under a random homography
+    (corner perturbation <= 32 px).  SURVEY section 8d."""
+    g = torch.Generator().manual_seed(seed)
+    base = torch.rand(batch, 1, size // 8 + 2, size // 8 + 2, generator=g)
+    img = torch.nn.functional.interpolate(base, size=(size + 16, size + 16), mode='bicubic', align_corners=True)
+    img = (img + 0.15 * torch.rand(batch, 1, size + 16, size + 16, generator=g)).clamp(0, 1)
+    image0 = img[:, :, 8:8 + size, 8:8 + size].contiguous()
+    # projective warp through a sampling grid: corners move by up to +-32 px
+    src = torch.tensor([[-1., -1.], [1., -1.], [-1., 1.], [1., 1.]])
+    dst = src[None] + (torch.rand(batch, 4, 2, generator=g) - 0.5) * (2 * 64.0 / size)
+    A = torch.zeros(batch, 8, 8)
+    for k in range(4):
+        x, y = src[k]
+        u, v = dst[:, k, 0], dst[:, k, 1]
+        A[:, 2 * k, 0], A[:, 2 * k, 1], A[:, 2 * k, 2] = x, y, 1
+        A[:, 2 * k, 6], A[:, 2 * k, 7] = -u * x, -u * y
+        A[:, 2 * k + 1, 3], A[:, 2 * k + 1, 4], A[:, 2 * k + 1, 5] = x, y, 1
+        A[:, 2 * k + 1, 6], A[:, 2 * k + 1, 7] = -v * x, -v * y
+    h = torch.linalg.solve(A, dst.reshape(batch, 8))
+    Hm = torch.cat([h, torch.ones(batch, 1)], 1).view(batch, 3, 3)
+    ys, xs = torch.meshgrid(torch.linspace(-1, 1, size), torch.linspace(-1, 1, size), indexing='ij')
+    pts = torch.stack([xs, ys, torch.ones_like(xs)], -1).view(1, -1, 3) @ Hm.transpose(1, 2)
+    grid = (pts[..., :2] / pts[..., 2:]).view(batch, size, size, 2) * (size / (size + 16.0))
+    image1 = torch.nn.functional.grid_sample(img, grid, mode='bilinear', padding_mode='border', align_corners=True)
+    return image0.to(device), image1.contiguous().to(device)
+
+
+def build_model(precision, coarse_thr, fine_thr, device):
+    from geoformer_amd.model.full_model import GeoFormer
+    from geoformer_amd.model.cvpr_ds_config import get_default_cfg
+    from geoformer_amd.model.geo_config import get_cfg_model
+    from geoformer_amd.weights import deterministic_init_
+    gc = get_cfg_model()
+    gc.update(coarse_thr=coarse_thr, fine_thr=fine_thr, precision='fp32')
+    m = deterministic_init_(GeoFormer(get_default_cfg(), gc).eval())
+    W = {k: v.detach().clone() for k, v in m.state_dict().items()}      # fp32 copy for the CPU baseline leg
+    m.set_precision(precision)
+    return m.to(device), W
+
+
+def cpu_baseline(W, coarse_thr, fine_thr, size, seconds_budget=25.0):
+    """The oracle (a PyTorch-CPU port of the reference's forward) on the host cores, same workload,
+    a bounded sample of pairs."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import geoformer_oracle as O
+    import ransac_oracle as RO
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.default_geo_config()
+    cfg.update(coarse_thr=coarse_thr, fine_thr=fine_thr)
+    done, t0, ms = 0, time.perf_counter(), []
+    while done < 8:
+        i0, i1 = synth_pairs(1, 1000 + done, size)
+        t = time.perf_counter()
+        with torch.no_grad():
+            out = O.geoformer_forward(W, {'image0': i0, 'image1': i1}, None, cfg, RO.make_homography_fn())
+        ms.append(time.perf_counter() - t)
+        done += 1
+        if time.perf_counter() - t0 > seconds_budget:
+            break
+    timed = ms[1:] if len(ms) > 1 else ms           # first pair warms the allocator / thread pool
+    per_pair = sum(timed) / len(timed)
+    return {'value': 1.0 / per_pair, 'unit': 'image-pairs/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{len(timed)} synthetic {size}x{size} pairs (+1 warm-up), batch 1, fp32, oracle/geoformer_oracle.py '
+                      f'(PyTorch-CPU port of the reference forward incl. backbone and RANSAC), M={len(out["b_ids"])}'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=8, help='pairs per GPU per step')
+    ap.add_argument('--size', type=int, default=640)
+    ap.add_argument('--precision', default='fp16', choices=['fp16', 'fp32'])
+    ap.add_argument('--coarse-thr', type=float, default=0.0)
+    ap.add_argument('--fine-thr', type=float, default=0.0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+
+    torch.backends.cudnn.benchmark = True      # MIOpen picks its fastest convolution per shape during warm-up
+    from geoformer_amd import _lib
+    L = _lib.lib()
+    model, W = build_model(args.precision, args.coarse_thr, args.fine_thr, dev)
+    # static shard: rank r owns pairs [r*steps*batch, (r+1)*steps*batch); a few distinct batches are
+    # kept resident and cycled so that HBM holds the inputs before the timed region starts
+    nres = min(args.steps, 4)
+    batches = [synth_pairs(args.batch, seed=rank * 100003 + i, size=args.size, device=dev) for i in range(nres)]
+
+    def step(i):
+        i0, i1 = batches[i % nres]
+        with torch.no_grad():
+            return model({'image0': i0, 'image1': i1})
+
+    for i in range(args.warmup):
+        out = step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    L.gf_profile_enable(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    Ms, Mfs = [], []
+    for i in range(args.steps):
+        out = step(i)
+        Ms.append(len(out['b_ids'])); Mfs.append(len(out['mkpts0_f']))
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    L.gf_profile_enable(0)
+    tot, cnt = ctypes.c_double(0), ctypes.c_int(0)
+    L.gf_profile_collect(b'k1_conf', ctypes.byref(tot), ctypes.byref(cnt))
+    conf_ms = tot.value / max(cnt.value, 1)
+    tot2, cnt2 = ctypes.c_double(0), ctypes.c_int(0)
+    L.gf_profile_collect(b'k1_stats', ctypes.byref(tot2), ctypes.byref(cnt2))
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    pairs = args.batch * args.steps * world
+    Lc = (args.size // 8) ** 2
+    e = 2 if args.precision == 'fp16' else 4
+    algo_bytes = args.batch * (2 * Lc * 256 * e + Lc * Lc * 4)     # per k1_conf launch (170.4 MB/pair-call at e=2)
+    achieved = algo_bytes / (conf_ms * 1e-3) / 1e9 if conf_ms > 0 else 0.0
+    traffic = None
+    pmc = os.path.join(ROOT, 'profiles', 'k1_conf_pmc_r01.json')
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get('hbm_bytes_per_launch_batch%d' % args.batch)
+        except Exception:
+            traffic = None
+    geo = out.get('_geo_dev', {})
+    K = int(geo['nidx'][:, 0].float().mean()) if 'nidx' in geo else None
+    res = {
+        'metric': 'image-pairs/sec (640x640)', 'value': pairs / elapsed, 'unit': 'image-pairs/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f16' if args.precision == 'fp16' else 'f32', 'data': 'synthetic',
+        'config': {'workload': f'batched inference, synthetic {args.size}x{args.size} pairs (BASELINE configs[4] shard), '
+                               f'full forward incl. ResNet-FPN backbone; closed-form random-init weights; '
+                               f'coarse_thr={args.coarse_thr} fine_thr={args.fine_thr}',
+                   'pairs_per_gpu_per_step': args.batch, 'global_pairs_per_step': args.batch * world,
+                   'coarse_matches_per_pair': sum(Ms) / len(Ms) / args.batch, 'fine_matches_per_pair': sum(Mfs) / len(Mfs) / args.batch,
+                   'inlier_cells_per_pair': K, 'parallelism': f'pair-shard x{world} (no collective)'},
+        'roofline': {'kernel': 'k1_conf (dual-softmax correlation sweep, conf_matrix write)', 'bound': 'hbm',
+                     'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
+                     'traffic': traffic, 'launches': cnt.value, 'avg_launch_ms': conf_ms,
+                     'algorithmic_bytes_per_launch': algo_bytes,
+                     'k1_stats_avg_launch_ms': tot2.value / max(cnt2.value, 1)},
+    }
+    if not args.no_cpu_baseline:
+        res['cpu_baseline'] = cpu_baseline(W, args.coarse_thr, args.fine_thr, args.size)
+    print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -20,6 +20,8 @@ c_long, c_uint32 = ctypes.c_long, ctypes.c_uint32
 SIGNATURES = {
     'gf_abi_version': (c_int, []),
     'gf_last_error': (ctypes.c_char_p, []),
+    'gf_profile_enable': (None, [c_int]),
+    'gf_profile_collect': (c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
     'gf_dual_softmax_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'gf_dual_softmax_match': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                       c_float, c_float, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
@@ -31,6 +33,9 @@ SIGNATURES = {
     'gf_linear_attention': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_long,
                                     c_long, c_long, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_size_t,
                                     c_void_p]),
+    'gf_linear': (c_int, [c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                          c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p, c_int, c_void_p, c_long, c_int, c_int,
+                          c_int, c_void_p]),
     'gf_ransac_workspace_bytes': (c_size_t, [c_int, c_int]),
     'gf_ransac_homography': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_float,
                                      c_int, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -421,7 +421,10 @@ struct SelArgs {
     int N, L, S;
     const unsigned long long* rowbest;   // [N][L]
     const unsigned* colmax;              // [N][S]
+    unsigned* colset;                    // [N][SET_WORDS] bitset over hash(colmax value)
     const float* conf;
+    int* scanlist;         // [N*L] rows whose first-True column needs the tie rescan
+    int* scancnt;          // [1]
     int* selj;             // [N][L]  matched column or -1
     int* samplecnt;        // [N][chunks]  matches per 1024-row chunk
     int chunks;
@@ -439,6 +442,24 @@ struct SelArgs {
     int32_t* counts;
 };
 
+constexpr int SET_BITS = 1 << 20;                // per-sample bitset of column-maximum values
+constexpr int SET_WORDS = SET_BITS / 32;
+__device__ __forceinline__ unsigned set_hash(unsigned bits) {
+    unsigned x = bits;
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x & (SET_BITS - 1);
+}
+
+// membership filter: which fp32 values occur as the maximum of SOME column
+__global__ void k1_colset(SelArgs a) {
+    const int n = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.S) return;
+    const unsigned v = a.colmax[(size_t)n * a.S + j];
+    if (v == 0u) return;
+    const unsigned h = set_hash(v);
+    atomicOr(a.colset + (size_t)n * SET_WORDS + (h >> 5), 1u << (h & 31));
+}
+
 // one thread per (n, i): coarse_matching.py:161-185 on the candidate statistics instead of the matrix.
 // rowbest holds the row maximum only if it exceeds thr (otherwise 0: no candidate, no match).
 __global__ void k1_select(SelArgs a) {
@@ -453,21 +474,44 @@ __global__ void k1_select(SelArgs a) {
         if (cm[j] == bits) {
             sel = j;
         } else {
-            // exact `mask.max(dim=2)` semantics: a later column may tie the row maximum AND be its
-            // column's maximum.  Only then is the row re-read (rare: needs an exact fp32 tie).
-            const float* row = a.conf + ((size_t)n * a.L + i) * a.S;
-            for (int j2 = j + 1; j2 < a.S; ++j2) {
-                if (__float_as_uint(row[j2]) == bits && cm[j2] == bits) {
-                    sel = j2;
-                    break;
-                }
-            }
+            // exact `mask.max(dim=2)` semantics: a LATER column may tie the row maximum AND be its own
+            // column's maximum.  That needs some column whose maximum equals this row's maximum bit for
+            // bit; the value filter rules that out for almost every row, the rest is queued for k1_rescan.
+            const unsigned h = set_hash(bits);
+            if ((a.colset[(size_t)n * SET_WORDS + (h >> 5)] >> (h & 31)) & 1u)
+                a.scanlist[atomicAdd(a.scancnt, 1)] = n * a.L + i;
         }
     }
     a.selj[(size_t)n * a.L + i] = sel;
     // per-1024-row chunk counts (blockDim = 256: one ballot + one atomic per wave)
     const unsigned long long bal = __ballot(sel >= 0);
     if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&a.samplecnt[n * a.chunks + (i >> 10)], __popcll(bal));
+}
+
+// rows queued by k1_select: one wave per row walks the (L2-resident) column maxima for later columns
+// that hold the same value and confirms the tie on the confidence matrix itself
+__global__ __launch_bounds__(256) void k1_rescan(SelArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int nwaves = gridDim.x * 4, total = *a.scancnt;
+    for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < total; e += nwaves) {
+        const int row = a.scanlist[e], n = row / a.L, i = row % a.L;
+        const unsigned long long k = a.rowbest[row];
+        const unsigned bits = (unsigned)(k >> 32);
+        const int j = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
+        const unsigned* cm = a.colmax + (size_t)n * a.S;
+        const float* crow = a.conf + (size_t)row * a.S;
+        int sel = -1;
+        for (int j0 = ((j + 1) / 64) * 64; j0 < a.S && sel < 0; j0 += 64) {
+            const int j2 = j0 + lane;
+            const bool hit = j2 > j && j2 < a.S && cm[j2] == bits && __float_as_uint(crow[j2]) == bits;
+            const unsigned long long bal = __ballot(hit);
+            if (bal) sel = j0 + __ffsll((long long)bal) - 1;
+        }
+        if (lane == 0 && sel >= 0) {
+            a.selj[row] = sel;
+            atomicAdd(&a.samplecnt[n * a.chunks + (i >> 10)], 1);
+        }
+    }
 }
 
 // one workgroup per (1024-row chunk, sample): ordered compaction in (n, i) order + keypoints
@@ -533,11 +577,17 @@ int k1_launch(K1Args a, SelArgs s, void* zero_begin, size_t zero_bytes, hipStrea
     constexpr bool EXACT = std::is_same<T, float>::value;
     const dim3 grid(a.tilesN, a.tilesM, a.N);
     (void)hipMemsetAsync(zero_begin, 0, zero_bytes, st);   // rowbest, colmax, samplecnt (contiguous)
+    void* p0 = gf_prof_begin("k1_stats", st);
     k1_stats<T><<<grid, NT, 2 * STAGE_BYTES, st>>>(a);
+    gf_prof_end("k1_stats", p0, st);
     const int mx = a.L > a.S ? a.L : a.S;
     k1_reduce_stats<EXACT><<<dim3((mx + 31) / 32, 2, a.N), 256, 0, st>>>(a);
+    void* p1 = gf_prof_begin("k1_conf", st);
     k1_conf<T><<<grid, NT, 2 * STAGE_BYTES, st>>>(a);
+    gf_prof_end("k1_conf", p1, st);
+    k1_colset<<<dim3((a.S + 255) / 256, a.N), 256, 0, st>>>(s);
     k1_select<<<dim3((a.L + 255) / 256, a.N), 256, 0, st>>>(s);
+    k1_rescan<<<256, 256, 0, st>>>(s);
     k1_compact<<<dim3(s.chunks, a.N), 1024, 0, st>>>(s);
     GF_CHECK_LAUNCH();
     return GF_OK;
@@ -546,8 +596,8 @@ int k1_launch(K1Args a, SelArgs s, void* zero_begin, size_t zero_bytes, hipStrea
 struct K1Workspace {
     float2 *rowpart, *colpart, *rstat, *cstat;
     unsigned long long* rowbest;
-    unsigned* colmax;
-    int *samplecnt, *selj;
+    unsigned *colmax, *colset;
+    int *samplecnt, *scancnt, *selj, *scanlist;
     size_t zero_bytes, bytes;
 };
 
@@ -555,16 +605,19 @@ K1Workspace k1_carve(void* ws, int N, int L, int S) {
     const int tilesM = (L + BM - 1) / BM, tilesN = (S + BN - 1) / BN;
     GfCarver c(ws);
     K1Workspace w;
-    // zeroed every call (one memset): rowbest | colmax | samplecnt
+    // zeroed every call (one memset): rowbest | colmax | colset | samplecnt | scancnt
     w.rowbest = c.take<unsigned long long>((size_t)N * L);
     w.colmax = c.take<unsigned>((size_t)N * S);
+    w.colset = c.take<unsigned>((size_t)N * (1 << 15));
     w.samplecnt = c.take<int>((size_t)N * ((L + 1023) / 1024));
+    w.scancnt = c.take<int>(1);
     w.zero_bytes = c.used();
     w.rowpart = c.take<float2>((size_t)N * tilesN * L);
     w.colpart = c.take<float2>((size_t)N * tilesM * S);
     w.rstat = c.take<float2>((size_t)N * L);
     w.cstat = c.take<float2>((size_t)N * S);
     w.selj = c.take<int>((size_t)N * L);
+    w.scanlist = c.take<int>((size_t)N * L);
     w.bytes = c.used();
     return w;
 }
@@ -606,8 +659,8 @@ extern "C" int gf_dual_softmax_match(const void* f0, const void* f1, int dtype, 
     a.rowbest = w.rowbest; a.colmax = w.colmax; a.conf = conf; a.thr = thr; a.dense = thr < 0.05f;
     SelArgs s;
     s.N = N; s.L = L; s.S = S;
-    s.rowbest = w.rowbest; s.colmax = w.colmax; s.conf = conf;
-    s.selj = w.selj; s.samplecnt = w.samplecnt; s.chunks = (L + 1023) / 1024; s.force_one = force_one; s.w0c = w0c; s.w1c = w1c;
+    s.rowbest = w.rowbest; s.colmax = w.colmax; s.colset = w.colset; s.conf = conf;
+    s.selj = w.selj; s.scanlist = w.scanlist; s.scancnt = w.scancnt; s.samplecnt = w.samplecnt; s.chunks = (L + 1023) / 1024; s.force_one = force_one; s.w0c = w0c; s.w1c = w1c;
     s.scale = scale; s.scale0 = scale0; s.scale1 = scale1;
     s.b_ids = b_ids; s.i_ids = i_ids; s.j_ids = j_ids; s.mconf = mconf; s.mk0 = mkpts0_c; s.mk1 = mkpts1_c;
     s.counts = counts;

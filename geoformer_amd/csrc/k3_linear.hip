@@ -1,0 +1,267 @@
+// K3: the encoder-layer GEMM chain with fused epilogues (CDNA4 / gfx950).
+//
+// Replaces, inside LoFTREncoderLayer.forward (model/loftr_src/loftr/loftr_module/transformer.py:45-60,
+// ReLU) and its Geo twin (model/geo_transformer/transformer.py:49-66, Tanh):
+//     q/k/v projections                         -> EPI_NONE
+//     merge + norm1                              -> EPI_LN
+//     mlp.0 on cat([x, message]) + ReLU/Tanh     -> EPI_RELU / EPI_TANH with a two-part A operand (no cat)
+//     mlp.2 + norm2 + residual (+ per-sample     -> EPI_LN_RES
+//         "layer skipped" predicate of GeoTransformer)
+// and the two biased linears of FinePreprocess (fine_preprocess.py:61-72), whose per-match context term
+// enters as a row-group bias.
+//
+// out[m, n] = epi( sum_k A[m,k] * W[n,k] )          A = [A1 | A2] along k, W row-major [N, K] (nn.Linear)
+//
+// The product is computed TRANSPOSED (MFMA A-operand = weight rows, B-operand = token rows) so that the
+// accumulator layout has the TOKEN on the lane and its channels in registers: LayerNorm statistics,
+// the activation, the residual and the predicate are then lane-local (one lane-pair exchange for the
+// mean/variance), with no cross-lane reduction tree.  One wave = 32 tokens x (32*NB) channels;
+// workgroup = 4 waves = 128 tokens; LN epilogues need NB*32 == N (whole rows in one wave pair).
+#include <math.h>
+
+#include <type_traits>
+
+#include "gf_common.h"
+
+namespace {
+
+enum { EPI_NONE = 0, EPI_RELU = 1, EPI_TANH = 2, EPI_LN = 3, EPI_LN_RES = 4 };
+
+struct LinArgs {
+    const void* a1;
+    const void* a2;
+    long lda1, lda2;
+    int k1, k2;              // K = k1 + k2 (k2 == 0: single operand)
+    const void* w;           // [N][K]
+    const float* bias;       // [N] or null
+    const void* rgbias;      // [M / rg_rows][N] of T or null  (added per row group)
+    int rg_rows;
+    const float* gamma;      // LN affine (fp32)
+    const float* beta;
+    float eps;
+    const void* res;         // residual [M][ldres] of T (EPI_LN_RES)
+    long ldres;
+    const int32_t* flag;     // [M / flag_rows] or null: 0 -> out = res (update skipped)
+    int flag_rows;
+    void* out;
+    long ldo;
+    int M, N;
+};
+
+template <typename T, int NB, int EPI>
+__global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
+    using Mm = Mma32<T>;
+    using Frag = typename Mm::Frag;
+    constexpr int EPC = 16 / sizeof(T);
+    constexpr int BK = 128 / sizeof(T);
+    constexpr int WROWS = 32 * NB;
+    constexpr int ROWS = 128 + WROWS;
+    constexpr int NLD = ROWS * 8 / 256;          // 16-B chunks staged per thread per K step
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* st = smem;                              // token rows
+    char* sw = smem + 128 * 128;                  // weight rows
+    float* vec = reinterpret_cast<float*>(smem + ROWS * 128);   // bias | gamma | beta  [3][WROWS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, lr = lane & 31;
+    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * WROWS;
+    const int K = a.k1 + a.k2;
+
+    if (tid < WROWS) {
+        vec[tid] = (a.bias && n0 + tid < a.N) ? a.bias[n0 + tid] : 0.f;
+        if constexpr (EPI >= EPI_LN) {
+            vec[WROWS + tid] = a.gamma[n0 + tid];
+            vec[2 * WROWS + tid] = a.beta[n0 + tid];
+        }
+    }
+    // per-thread staging slots: chunk e -> (row, chunk-in-row); rows < 128 are tokens, the rest weights
+    const T* src[NLD];
+    int dst[NLD];
+    bool isa[NLD];
+#pragma unroll
+    for (int p = 0; p < NLD; ++p) {
+        const int e = p * 256 + tid, row = e >> 3, c = e & 7;
+        isa[p] = row < 128;
+        if (isa[p]) {
+            src[p] = nullptr;                      // resolved per K step (two-part operand)
+            dst[p] = gf_lds_off(row, c);
+        } else {
+            const int wr = row - 128;
+            src[p] = (const T*)a.w + (size_t)min(n0 + wr, a.N - 1) * K + c * EPC;
+            dst[p] = 128 * 128 + gf_lds_off(wr, c);
+        }
+    }
+    v4u regs[NLD];
+    auto gload = [&](int k0) {
+        const bool first = k0 < a.k1;
+        const T* ab = (const T*)(first ? a.a1 : a.a2);
+        const long ld = first ? a.lda1 : a.lda2;
+        const int kk = first ? k0 : k0 - a.k1;
+#pragma unroll
+        for (int p = 0; p < NLD; ++p) {
+            const int e = p * 256 + tid, row = e >> 3, c = e & 7;
+            const T* g = isa[p] ? ab + (size_t)min(m0 + row, a.M - 1) * ld + kk + c * EPC : src[p] + k0;
+            regs[p] = *reinterpret_cast<const v4u*>(g);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int p = 0; p < NLD; ++p) *reinterpret_cast<v4u*>(smem + dst[p]) = regs[p];
+    };
+    v16f acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+    const int nk = K / BK;
+    gload(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();                           // previous step's fragments are consumed
+        lstore();
+        __syncthreads();
+        if (kt + 1 < nk) gload((kt + 1) * BK);     // in flight while the MFMAs run
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int chunk = 2 * g + h;
+            const Frag tf = *reinterpret_cast<const Frag*>(st + gf_lds_off(wave * 32 + lr, chunk));
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const Frag wf = *reinterpret_cast<const Frag*>(sw + gf_lds_off(nb * 32 + lr, chunk));
+                Mm::mma(wf, tf, acc[nb]);
+            }
+        }
+    }
+    // ---------------- epilogue: lane = token, registers = channels n0 + nb*32 + acc_row(r, h)
+    const int token = m0 + wave * 32 + lr;
+    const bool live = token < a.M;
+    const int tk = live ? token : a.M - 1;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] += vec[nb * 32 + gf_acc_row(r, h)];
+    if (a.rgbias) {
+        const T* rb = (const T*)a.rgbias + (size_t)(tk / a.rg_rows) * a.N + n0;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] += gf_to_float(rb[nb * 32 + gf_acc_row(r, h)]);
+    }
+    if constexpr (EPI == EPI_RELU) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = fmaxf(acc[nb][r], 0.f);
+    } else if constexpr (EPI == EPI_TANH) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = tanhf(acc[nb][r]);
+    } else if constexpr (EPI >= EPI_LN) {
+        // nn.LayerNorm over the WROWS channels of the token: two-pass mean / variance in fp32
+        float s = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += acc[nb][r];
+        s += __shfl_xor(s, 32, 64);
+        const float mean = s / (float)WROWS;
+        float q = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float d = acc[nb][r] - mean;
+                q += d * d;
+            }
+        q += __shfl_xor(q, 32, 64);
+        const float rstd = 1.0f / sqrtf(q / (float)WROWS + a.eps);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = nb * 32 + gf_acc_row(r, h);
+                acc[nb][r] = (acc[nb][r] - mean) * rstd * vec[WROWS + c] + vec[2 * WROWS + c];
+            }
+    }
+    bool keep = true;
+    if constexpr (EPI == EPI_LN_RES) keep = a.flag == nullptr || a.flag[tk / a.flag_rows] != 0;
+    if (!live) return;
+    T* op = (T*)a.out + (size_t)token * a.ldo + n0;
+    const T* rp = EPI == EPI_LN_RES ? (const T*)a.res + (size_t)token * a.ldres + n0 : nullptr;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int c = nb * 32 + 8 * r4 + 4 * h;                     // 4 consecutive channels
+            if (n0 + c >= a.N) continue;
+            v4f v{acc[nb][4 * r4], acc[nb][4 * r4 + 1], acc[nb][4 * r4 + 2], acc[nb][4 * r4 + 3]};
+            if constexpr (EPI == EPI_LN_RES) {
+                v4f x;
+                if constexpr (std::is_same<T, float>::value) x = *reinterpret_cast<const v4f*>(rp + c);
+                else {
+                    const v4h xh = *reinterpret_cast<const v4h*>(rp + c);
+                    x = v4f{(float)xh.x, (float)xh.y, (float)xh.z, (float)xh.w};
+                }
+                v = keep ? v4f{x.x + v.x, x.y + v.y, x.z + v.z, x.w + v.w} : x;
+            }
+            if constexpr (std::is_same<T, float>::value) *reinterpret_cast<v4f*>(op + c) = v;
+            else *reinterpret_cast<v4h*>(op + c) = v4h{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        }
+}
+
+template <typename T, int NB, int EPI>
+void lin_launch1(const LinArgs& a, hipStream_t st) {
+    constexpr int WROWS = 32 * NB;
+    const size_t lds = (size_t)(128 + WROWS) * 128 + 3 * WROWS * sizeof(float);
+    linear_kernel<T, NB, EPI><<<dim3((a.M + 127) / 128, (a.N + WROWS - 1) / WROWS), 256, lds, st>>>(a);
+}
+
+template <typename T, int NB>
+void lin_launch(const LinArgs& a, int epi, hipStream_t st) {
+    switch (epi) {
+        case EPI_NONE: lin_launch1<T, NB, EPI_NONE>(a, st); break;
+        case EPI_RELU: lin_launch1<T, NB, EPI_RELU>(a, st); break;
+        case EPI_TANH: lin_launch1<T, NB, EPI_TANH>(a, st); break;
+        case EPI_LN: lin_launch1<T, NB, EPI_LN>(a, st); break;
+        default: lin_launch1<T, NB, EPI_LN_RES>(a, st); break;
+    }
+}
+
+}   // namespace
+
+extern "C" int gf_linear(const void* a1, long lda1, int k1, const void* a2, long lda2, int k2, const void* w,
+                         const float* bias, const void* rowgroup_bias, int rowgroup_rows, int epilogue,
+                         const float* ln_gamma, const float* ln_beta, float ln_eps, const void* residual,
+                         long ldres, const int32_t* row_flag, int flag_rows, void* out, long ldo, int dtype, int M,
+                         int N, void* stream) {
+    GF_CHECK_ARG(a1 && w && out, "null pointer");
+    GF_CHECK_ARG(M > 0 && N > 0 && k1 > 0 && k2 >= 0, "bad sizes");
+    GF_CHECK_ARG(dtype == GF_F32 || dtype == GF_F16, "dtype must be GF_F32 or GF_F16");
+    const int bk = dtype == GF_F32 ? 32 : 64;
+    GF_CHECK_ARG(k1 % bk == 0 && k2 % bk == 0, "k1 and k2 must be multiples of 32 (f32) / 64 (f16)");
+    GF_CHECK_ARG(k2 == 0 || a2 != nullptr, "a2 missing");
+    GF_CHECK_ARG(N % 32 == 0, "N must be a multiple of 32");
+    GF_CHECK_ARG(epilogue >= EPI_NONE && epilogue <= EPI_LN_RES, "unknown epilogue");
+    GF_CHECK_ARG(rowgroup_bias == nullptr || rowgroup_rows > 0, "rowgroup_rows must be > 0");
+    const int es = dtype == GF_F32 ? 4 : 2;
+    GF_CHECK_ARG((lda1 * es) % 16 == 0 && (k2 == 0 || (lda2 * es) % 16 == 0), "operand rows must be 16-byte aligned");
+    GF_CHECK_ARG((ldo * es) % (4 * es) == 0, "ldo must be a multiple of 4");
+    if (epilogue >= EPI_LN) {
+        GF_CHECK_ARG(ln_gamma && ln_beta, "LayerNorm epilogue needs gamma and beta");
+        GF_CHECK_ARG(N == 128 || N == 256, "LayerNorm epilogue is built for N = 128 or 256 (whole rows per wave pair)");
+        GF_CHECK_ARG(epilogue != EPI_LN_RES || residual != nullptr, "residual missing");
+        GF_CHECK_ARG(row_flag == nullptr || flag_rows > 0, "flag_rows must be > 0");
+    }
+    LinArgs a{a1, a2, lda1, lda2, k1, k2, w, bias, rowgroup_bias, rowgroup_rows, ln_gamma, ln_beta, ln_eps, residual,
+              ldres, row_flag, flag_rows, out, ldo, M, N};
+    hipStream_t st = (hipStream_t)stream;
+    const bool wide = (epilogue >= EPI_LN) ? N == 256 : N % 256 == 0;
+    if (dtype == GF_F32) {
+        if (wide) lin_launch<float, 8>(a, epilogue, st);
+        else lin_launch<float, 4>(a, epilogue, st);
+    } else {
+        if (wide) lin_launch<_Float16, 8>(a, epilogue, st);
+        else lin_launch<_Float16, 4>(a, epilogue, st);
+    }
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}

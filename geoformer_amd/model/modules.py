@@ -11,8 +11,6 @@ from typing import Dict, Optional
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
-
 from .. import ops
 
 
@@ -75,19 +73,19 @@ class LoFTREncoderLayer(nn.Module):
         self.norm2 = nn.LayerNorm(d_model)
         self._cache = {}
 
-    # weights in compute dtype; k_proj|v_proj fused so one GEMM projects keys and values
+    # weights in compute dtype; k_proj|v_proj fused so one GEMM projects keys and values; LayerNorm
+    # affine terms stay fp32 (the K3 epilogue normalises in fp32)
     def weights(self, dtype):
         w = self._cache.get(dtype)
         if w is None:
-            c = self.d_model
-            w1 = self.mlp[0].weight.detach()
+            f32 = torch.float32
             w = {'q': self.q_proj.weight.detach().to(dtype).contiguous(),
                  'kv': torch.cat([self.k_proj.weight, self.v_proj.weight], 0).detach().to(dtype).contiguous(),
                  'merge': self.merge.weight.detach().to(dtype).contiguous(),
-                 'w1x': w1[:, :c].to(dtype).contiguous(), 'w1m': w1[:, c:].to(dtype).contiguous(),
+                 'w1': self.mlp[0].weight.detach().to(dtype).contiguous(),
                  'w2': self.mlp[2].weight.detach().to(dtype).contiguous(),
-                 'n1w': self.norm1.weight.detach().to(dtype), 'n1b': self.norm1.bias.detach().to(dtype),
-                 'n2w': self.norm2.weight.detach().to(dtype), 'n2b': self.norm2.bias.detach().to(dtype)}
+                 'n1': (self.norm1.weight.detach().to(f32).contiguous(), self.norm1.bias.detach().to(f32).contiguous()),
+                 'n2': (self.norm2.weight.detach().to(f32).contiguous(), self.norm2.bias.detach().to(f32).contiguous())}
             self._cache[dtype] = w
         return w
 
@@ -95,21 +93,23 @@ class LoFTREncoderLayer(nn.Module):
         self._cache = {}
 
     def project_q(self, x):
-        return F.linear(x, self.weights(x.dtype)['q'])
+        return ops.linear(x, self.weights(x.dtype)['q'])
 
     def project_kv(self, source):
-        kv = F.linear(source, self.weights(source.dtype)['kv'])
+        kv = ops.linear(source, self.weights(source.dtype)['kv'])
         c = self.d_model
         return kv[..., :c], kv[..., c:]
 
-    def finish(self, x, message):
-        """merge -> norm1 -> mlp([x, message]) -> norm2; returns the residual update (without + x)."""
+    def finish(self, x, message, row_flag=None, flag_rows=0):
+        """x + norm2(mlp([x, norm1(merge(message))])) in three K3 launches: merge+LN, mlp.0 on the
+        two-part operand (no concat) + activation, mlp.2+LN+residual.  row_flag (int32 per `flag_rows`
+        rows) == 0 leaves x unchanged - GeoTransformer's per-sample 'layer skipped' cases."""
         w = self.weights(x.dtype)
-        c = self.d_model
-        message = F.layer_norm(F.linear(message, w['merge']), (c,), w['n1w'], w['n1b'])
-        hid = F.linear(x, w['w1x']) + F.linear(message, w['w1m'])     # == Linear(cat([x, message]))
-        hid = torch.relu_(hid) if self.activation == 'relu' else torch.tanh_(hid)
-        return F.layer_norm(F.linear(hid, w['w2']), (c,), w['n2w'], w['n2b'])
+        act = ops.EPI_RELU if self.activation == 'relu' else ops.EPI_TANH
+        message = ops.linear(message, w['merge'], epilogue=ops.EPI_LN, ln=w['n1'], eps=self.norm1.eps)
+        hid = ops.linear(x, w['w1'], a2=message, epilogue=act)
+        return ops.linear(hid, w['w2'], epilogue=ops.EPI_LN_RES, ln=w['n2'], eps=self.norm2.eps, residual=x,
+                          row_flag=row_flag, flag_rows=flag_rows)
 
     def forward(self, x, source, x_mask: Optional[torch.Tensor] = None, source_mask: Optional[torch.Tensor] = None):
         """x [N,L,C], source [N,S,C] -> [N,L,C]  (linear-attention flavour; the geometry-guided flavours
@@ -119,7 +119,7 @@ class LoFTREncoderLayer(nn.Module):
         q = self.project_q(x)
         k, v = self.project_kv(source)
         message = ops.linear_attention(q, k, v, self.nhead, x_mask, source_mask)
-        return x + self.finish(x, message)
+        return self.finish(x, message)
 
 
 class LocalFeatureTransformer(nn.Module):
@@ -219,28 +219,25 @@ class GeoTransformer(nn.Module):
         idx*/nidx = tokens at inlier cells (self layers), win1 = cells of image1 seen from each cell of
         image0 and win0 the converse (cross layers), valid = per-sample 'homography found'."""
         assert self.d_model == feat0.size(2), 'the feature number of src and transformer must be equal'
-        n = feat0.shape[0]
+        n, L, S = feat0.shape[0], feat0.shape[1], feat1.shape[1]
         same = feat0.shape == feat1.shape
         nk = geo['nidx']
-        has0, has1 = (nk[:, 0] > 0)[:, None, None], (nk[:, 1] > 0)[:, None, None]
-        ok = (geo['valid'] > 0)[:, None, None]
         for layer, name in zip(self.layers, self.layer_names):
-            if name == 'self':
+            if name == 'self':       # keys/values = tokens at inlier cells; a sample without any keeps its features
                 if same:
                     both = torch.cat([feat0, feat1], 0)
                     k, v = layer.project_kv(both)
                     msg = ops.self_attention_gathered(layer.project_q(both), k, v, geo['idx_both'], geo['nidx_both'],
                                                       self.nhead)
-                    upd = layer.finish(both, msg)
-                    feat0 = torch.where(has0, feat0 + upd[:n], feat0)
-                    feat1 = torch.where(has1, feat1 + upd[n:], feat1)
+                    both = layer.finish(both, msg, geo['nidx_both'], L)
+                    feat0, feat1 = both[:n], both[n:]
                 else:
                     k, v = layer.project_kv(feat0)
                     m0 = ops.self_attention_gathered(layer.project_q(feat0), k, v, geo['idx0'], nk[:, 0], self.nhead)
                     k, v = layer.project_kv(feat1)
                     m1 = ops.self_attention_gathered(layer.project_q(feat1), k, v, geo['idx1'], nk[:, 1], self.nhead)
-                    feat0 = torch.where(has0, feat0 + layer.finish(feat0, m0), feat0)
-                    feat1 = torch.where(has1, feat1 + layer.finish(feat1, m1), feat1)
+                    feat0 = layer.finish(feat0, m0, geo['nidx_t'][0], L)
+                    feat1 = layer.finish(feat1, m1, geo['nidx_t'][1], S)
             elif name == 'cross':
                 # keys/values of BOTH images come from the pre-update features (the reference gathers
                 # feat0_cross and feat1_cross before either update, :126-129); project, then gather.
@@ -248,9 +245,8 @@ class GeoTransformer(nn.Module):
                 k1, v1 = layer.project_kv(feat1)
                 m0 = ops.window_cross_attention(layer.project_q(feat0), k1, v1, geo['win1'], geo['valid'], self.nhead)
                 m1 = ops.window_cross_attention(layer.project_q(feat1), k0, v0, geo['win0'], geo['valid'], self.nhead)
-                u0, u1 = layer.finish(feat0, m0), layer.finish(feat1, m1)
-                feat0 = torch.where(ok, feat0 + u0, feat0)
-                feat1 = torch.where(ok, feat1 + u1, feat1)
+                feat0 = layer.finish(feat0, m0, geo['valid'], L)
+                feat1 = layer.finish(feat1, m1, geo['valid'], S)
             else:
                 raise KeyError
         return feat0, feat1
@@ -314,9 +310,10 @@ class GeoModule(nn.Module):
         geo['win1'] = ops.window_geometry(rs['M_f32'], rs['valid'], hw0c, (H1, W1), hw1c[1], scale, self.window_size, s1)
         geo['win0'] = ops.window_geometry(rs['Minv_f32'], rs['valid'], hw1c, (H0, W0), hw0c[1], scale, self.window_size, s0)
         geo['valid'] = rs['valid']
+        geo['nidx_t'] = geo['nidx'].t().contiguous()          # [2, N]: per-side key counts, also the 'skip' predicates
         if L == S:
             geo['idx_both'] = torch.cat([geo['idx0'], geo['idx1']], 0)
-            geo['nidx_both'] = geo['nidx'].t().contiguous().view(-1)
+            geo['nidx_both'] = geo['nidx_t'].view(-1)
         geo['ransac'] = rs
         return geo
 
@@ -361,9 +358,10 @@ class FinePreprocess(nn.Module):
         if w is None:
             d = self.d_model_f
             mw = self.merge_feat.weight.detach()
-            w = {'dw': self.down_proj.weight.detach().to(dtype).contiguous(), 'db': self.down_proj.bias.detach().to(dtype),
+            w = {'dw': self.down_proj.weight.detach().to(dtype).contiguous(),
+                 'db': self.down_proj.bias.detach().float().contiguous(),
                  'mw_win': mw[:, :d].to(dtype).contiguous(), 'mw_ctx': mw[:, d:].to(dtype).contiguous(),
-                 'mb': self.merge_feat.bias.detach().to(dtype)}
+                 'mb': self.merge_feat.bias.detach().float().contiguous()}
             self._cache[dtype] = w
         return w
 
@@ -379,8 +377,10 @@ class FinePreprocess(nn.Module):
         win, ccat = ops.fine_gather(feat_f0, feat_f1, feat_c0, feat_c1, data['b_ids'], data['i_ids'], data['j_ids'],
                                     int(data['hw0_c'][1]), int(data['hw1_c'][1]), stride, W, dtype)
         w = self.weights(dtype)
-        ctx = F.linear(F.linear(ccat, w['dw'], w['db']), w['mw_ctx'], w['mb'])          # once per match, not per cell
-        out = F.linear(win, w['mw_win']) + ctx[:, None, :]                              # == merge_feat(cat([win, ctx]))
+        # merge_feat(cat([win, down_proj(c)])) = W_win.win + (W_ctx.down_proj(c) + b): the context term is
+        # computed once per match and enters the window GEMM as a row-group bias (25 rows per match)
+        ctx = ops.linear(ops.linear(ccat, w['dw'], bias=w['db']), w['mw_ctx'], bias=w['mb'])
+        out = ops.linear(win, w['mw_win'], rowgroup_bias=ctx, rowgroup_rows=W * W)
         return out[:M], out[M:]
 
 

@@ -278,3 +278,45 @@ def fine_match(f0, f1, temperature, thr, b_ids, mkpts0_c, mkpts1_c, coarse_scale
                            float(fine_scale), _p(s0), _p(s1), _p(fm), _p(mk[0]), _p(mk[1]), _p(mconf), _p(mb), _p(count),
                            _p(ws), ws.numel(), _stream()), 'gf_fine_match')
     return {'fine_matrix': fm, 'mkpts0_f': mk[0], 'mkpts1_f': mk[1], 'mconf': mconf, 'm_bids': mb, 'count': count}
+
+
+EPI_NONE, EPI_RELU, EPI_TANH, EPI_LN, EPI_LN_RES = 0, 1, 2, 3, 4
+
+
+def _rows2d(t):
+    """[..., K] -> (tensor viewed as rows, row stride); last dim contiguous and rows uniformly strided."""
+    if t.stride(-1) != 1:
+        t = t.contiguous()
+    lead = t.shape[:-1]
+    ld = t.stride(-2) if t.dim() > 1 else t.shape[-1]
+    # every leading dim must collapse onto one row stride
+    expect = ld
+    for size, stride in zip(reversed(lead), reversed(t.stride()[:-1])):
+        if size != 1 and stride != expect:
+            t = t.contiguous()
+            ld = t.shape[-1]
+            break
+        expect *= size
+    return t, ld
+
+
+def linear(a1, w, a2=None, bias=None, rowgroup_bias=None, rowgroup_rows=0, epilogue=EPI_NONE, ln=None, eps=1e-5,
+           residual=None, row_flag=None, flag_rows=0):
+    """K3.  out[..., n] = epi([a1|a2] @ w.T + bias + rowgroup_bias); see include/geoformer_hip.h (gf_linear).
+    ln = (gamma fp32 [N], beta fp32 [N]) for the LayerNorm epilogues."""
+    _need_cuda(a1, w)
+    a1, lda1 = _rows2d(a1)
+    k1 = a1.shape[-1]
+    k2, lda2 = 0, 0
+    if a2 is not None:
+        a2, lda2 = _rows2d(a2)
+        k2 = a2.shape[-1]
+    N = w.shape[0]
+    M = a1.numel() // k1
+    out = torch.empty(*a1.shape[:-1], N, dtype=a1.dtype, device=a1.device)
+    res, ldres = (None, 0) if residual is None else _rows2d(residual)
+    g, b = (None, None) if ln is None else ln
+    check(_lib.lib().gf_linear(_p(a1), lda1, k1, _p(a2), lda2, k2, _p(w), _p(bias), _p(rowgroup_bias), int(rowgroup_rows),
+                               int(epilogue), _p(g), _p(b), float(eps), _p(res), ldres, _p(row_flag), int(flag_rows), _p(out),
+                               N, _dt(a1), M, N, _stream()), 'gf_linear')
+    return out

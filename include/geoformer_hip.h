@@ -33,6 +33,11 @@ typedef enum { GF_F32 = 0, GF_F16 = 1 } gf_dtype;
 int gf_abi_version(void);
 const char* gf_last_error(void);
 
+/* Optional per-kernel timing with HIP events on the launch stream (used by bench.py's `roofline`).
+ * Tags: "k1_stats", "k1_conf".  gf_profile_collect synchronises on the recorded events. */
+void gf_profile_enable(int on);
+int gf_profile_collect(const char* tag, double* total_ms, int* count);
+
 /* ------------------------------------------------------------------------------------------
  * K1  dual-softmax correlation + mutual-nearest match extraction
  * replaces CoarseMatching.forward + get_coarse_match
@@ -79,6 +84,26 @@ size_t gf_linear_attention_workspace_bytes(int N, int S, int H, int D);
 int gf_linear_attention(const void* q, const void* k, const void* v, int dtype, int N, int L, int S, int H,
                         int D, long ldq, long ldk, long ldv, const uint8_t* q_mask, const uint8_t* kv_mask,
                         float eps, void* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K3  encoder-layer linears with fused epilogues
+ * replaces the nn.Linear / LayerNorm / activation / concat / residual sequence of
+ * LoFTREncoderLayer.forward (model/loftr_src/loftr/loftr_module/transformer.py:45-60 and
+ * model/geo_transformer/transformer.py:49-66) and the two linears of FinePreprocess.forward
+ * (model/loftr_src/loftr/loftr_module/fine_preprocess.py:61-72)
+ *   out[m,n] = epi( sum_k [a1|a2][m,k] * w[n,k] + bias[n] + rowgroup_bias[m / rowgroup_rows, n] )
+ *   a1 [M,k1] row stride lda1, a2 [M,k2] (k2 may be 0) - the two halves of torch.cat([x, message], 2);
+ *   w [N, k1+k2] row-major (nn.Linear.weight); bias fp32 [N] or NULL; rowgroup_bias [M/rows, N] or NULL;
+ *   epilogue: 0 none, 1 ReLU, 2 Tanh, 3 LayerNorm(gamma, beta, eps) over N,
+ *             4 residual + LayerNorm(...) with optional predicate row_flag[m / flag_rows]
+ *               (0 -> out = residual: the GeoTransformer "layer skipped for this sample" case);
+ *   LayerNorm epilogues need N in {128, 256}.
+ * ------------------------------------------------------------------------------------------ */
+int gf_linear(const void* a1, long lda1, int k1, const void* a2, long lda2, int k2, const void* w,
+              const float* bias, const void* rowgroup_bias, int rowgroup_rows, int epilogue,
+              const float* ln_gamma, const float* ln_beta, float ln_eps, const void* residual, long ldres,
+              const int32_t* row_flag, int flag_rows, void* out, long ldo, int dtype, int M, int N,
+              void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * homography RANSAC on the device

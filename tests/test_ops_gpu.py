@@ -308,3 +308,47 @@ def test_geo_module_golden(golden, tag):
     o0, o1 = gm(I['c0'].to(DEV), I['c1'].to(DEV), batch)
     sub = slice(None) if tag == 'shift' else slice(None, None, 4)
     close(o0[..., sub], G[f'{tag}_out0'], 5e-4, 2e-4); close(o1[..., sub], G[f'{tag}_out1'], 5e-4, 2e-4)
+
+
+# ------------------------------------------------------------------ K3
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+@pytest.mark.parametrize('C', [256, 128])
+def test_linear_epilogues(dtype, C):
+    """gf_linear against the same ops in plain PyTorch fp32 on the same (rounded) inputs."""
+    import torch.nn.functional as F
+    from geoformer_amd import ops
+    g = torch.Generator().manual_seed(C)
+    M = 3 * 25 * 7 + 11                                   # not a multiple of the 128-token tile
+    x = torch.randn(M, C, generator=g).to(dtype)
+    msg = torch.randn(M, C, generator=g).to(dtype)
+    w_sq = (torch.randn(C, C, generator=g) / C ** .5).to(dtype)
+    w1 = (torch.randn(2 * C, 2 * C, generator=g) / (2 * C) ** .5).to(dtype)
+    w2 = (torch.randn(C, 2 * C, generator=g) / (2 * C) ** .5).to(dtype)
+    gam, bet = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    bias = 0.1 * torch.randn(C, generator=g)
+    d = lambda t: t.to(DEV)
+    f = lambda t: t.float()
+    tol = (2e-4, 2e-5) if dtype == torch.float32 else (5e-3, 5e-3)
+    # plain, strided input view (as the k|v split produces) and bias
+    wide = torch.randn(M, 2 * C, generator=g).to(dtype)
+    close(ops.linear(d(wide)[:, C:], d(w_sq), bias=d(bias)), F.linear(f(wide)[:, C:], f(w_sq), bias), *tol)
+    # merge + LayerNorm
+    close(ops.linear(d(msg), d(w_sq), epilogue=ops.EPI_LN, ln=(d(gam), d(bet))),
+          F.layer_norm(F.linear(f(msg), f(w_sq)), (C,), gam, bet), *tol)
+    # two-part operand + activation
+    ref = F.linear(torch.cat([f(x), f(msg)], 1), f(w1))
+    close(ops.linear(d(x), d(w1), a2=d(msg), epilogue=ops.EPI_RELU), torch.relu(ref), *tol)
+    close(ops.linear(d(x), d(w1), a2=d(msg), epilogue=ops.EPI_TANH), torch.tanh(ref), *tol)
+    # mlp.2 + LayerNorm + residual with a per-group predicate
+    hid = torch.randn(M, 2 * C, generator=g).to(dtype)
+    rows = 50
+    flag = torch.tensor([1, 0, 1] * ((M + rows - 1) // rows // 3 + 1), dtype=torch.int32)[:(M + rows - 1) // rows]
+    upd = F.layer_norm(F.linear(f(hid), f(w2)), (C,), gam, bet)
+    keep = flag.repeat_interleave(rows)[:M].bool()[:, None]
+    close(ops.linear(d(hid), d(w2), epilogue=ops.EPI_LN_RES, ln=(d(gam), d(bet)), residual=d(x), row_flag=d(flag), flag_rows=rows),
+          torch.where(keep, f(x) + upd, f(x)), *tol)
+    close(ops.linear(d(hid), d(w2), epilogue=ops.EPI_LN_RES, ln=(d(gam), d(bet)), residual=d(x)), f(x) + upd, *tol)
+    # row-group bias (FinePreprocess: one context vector per 25 window rows)
+    ctx = torch.randn((M + 24) // 25, C, generator=g).to(dtype)
+    close(ops.linear(d(x), d(w_sq), rowgroup_bias=d(ctx), rowgroup_rows=25),
+          F.linear(f(x), f(w_sq)) + f(ctx).repeat_interleave(25, 0)[:M], *tol)
