@@ -21,10 +21,15 @@ import os
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# MIOpen's convolution search results for the bench shapes are shipped with the repo (plain-text user
+# find-db for gfx950), so warm-up looks the algorithms up instead of re-running a multi-minute search
+os.environ.setdefault('MIOPEN_USER_DB_PATH', os.path.join(ROOT, 'geoformer_amd', 'miopen_db'))
+# compiled MIOpen kernels are cached next to it (git-ignored build artefact, like the .so)
+os.environ.setdefault('MIOPEN_CUSTOM_CACHE_DIR', os.path.join(ROOT, 'geoformer_amd', 'miopen_db', 'cache'))
+
+import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
 
@@ -110,6 +115,8 @@ def main():
     ap.add_argument('--precision', default='fp16', choices=['fp16', 'fp32'])
     ap.add_argument('--coarse-thr', type=float, default=0.0)
     ap.add_argument('--fine-thr', type=float, default=0.0)
+    ap.add_argument('--streams', type=int, default=2, help='concurrent forward pipelines (host threads, one HIP stream each)')
+    ap.add_argument('--tune', action='store_true', help='let MIOpen search its convolution algorithms (minutes) and extend the shipped find-db')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -126,9 +133,17 @@ def main():
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
 
-    torch.backends.cudnn.benchmark = True      # MIOpen picks its fastest convolution per shape during warm-up
+    # MIOpen: the repo ships the user find-db (geoformer_amd/miopen_db) holding the tuned convolution picks
+    # for the bench shapes, so immediate mode finds them without a search (4 s start-up instead of minutes,
+    # same speed).  --tune re-runs the search (and extends the db) for other batch sizes.
+    torch.backends.cudnn.benchmark = args.tune
     from geoformer_amd import _lib
     L = _lib.lib()
+    tlog = time.perf_counter()
+
+    def log(msg):
+        if rank == 0:
+            print(f'[bench +{time.perf_counter() - tlog:6.1f}s] {msg}', file=sys.stderr, flush=True)
     model, W = build_model(args.precision, args.coarse_thr, args.fine_thr, dev)
     # static shard: rank r owns pairs [r*steps*batch, (r+1)*steps*batch); a few distinct batches are
     # kept resident and cycled so that HBM holds the inputs before the timed region starts
@@ -140,23 +155,52 @@ def main():
         with torch.no_grad():
             return model({'image0': i0, 'image1': i1})
 
-    for i in range(args.warmup):
-        out = step(i)
+    # `streams` host threads, each with its own HIP stream, take the steps round-robin: while one forward
+    # waits on its two host syncs (match counts) or runs small latency-bound kernels (RANSAC, compaction),
+    # the other keeps the GPU fed.  All of the K timed steps are still executed inside the timed region.
+    import threading
+    nstreams = max(1, min(args.streams, args.steps))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+    results = {}
+
+    def worker(w, first, count):
+        torch.cuda.set_device(dev)
+        with torch.cuda.stream(streams[w]):
+            for i in range(first + w, first + count, nstreams):
+                out = step(i)
+                results[i] = (len(out['b_ids']), len(out['mkpts0_f']), out)
+        streams[w].synchronize()
+
+    def run(first, count):
+        ts = [threading.Thread(target=worker, args=(w, first, count)) for w in range(nstreams)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+
+    log('model + inputs ready')
+    step(0)                          # single-threaded first pass: fills the weight / table caches and MIOpen's picks
     torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    log('first forward done (MIOpen algorithm lookup / search)')
+    run(0, args.warmup)
+    torch.cuda.synchronize()
+    log('warm-up done')
     if dist is not None:
         dist.barrier()
     L.gf_profile_enable(1)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    Ms, Mfs = [], []
-    for i in range(args.steps):
-        out = step(i)
-        Ms.append(len(out['b_ids'])); Mfs.append(len(out['mkpts0_f']))
+    run(args.warmup, args.steps)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    log('timed region done')
+    Ms = [results[i][0] for i in range(args.warmup, args.warmup + args.steps)]
+    Mfs = [results[i][1] for i in range(args.warmup, args.warmup + args.steps)]
+    out = results[args.warmup + args.steps - 1][2]
     L.gf_profile_enable(0)
     tot, cnt = ctypes.c_double(0), ctypes.c_int(0)
     L.gf_profile_collect(b'k1_conf', ctypes.byref(tot), ctypes.byref(cnt))
@@ -196,7 +240,8 @@ def main():
                                f'coarse_thr={args.coarse_thr} fine_thr={args.fine_thr}',
                    'pairs_per_gpu_per_step': args.batch, 'global_pairs_per_step': args.batch * world,
                    'coarse_matches_per_pair': sum(Ms) / len(Ms) / args.batch, 'fine_matches_per_pair': sum(Mfs) / len(Mfs) / args.batch,
-                   'inlier_cells_per_pair': K, 'parallelism': f'pair-shard x{world} (no collective)'},
+                   'inlier_cells_per_pair': K, 'parallelism': f'pair-shard x{world} (no collective)',
+                   'host_pipelines_per_gpu': nstreams},
         'roofline': {'kernel': 'k1_conf (dual-softmax correlation sweep, conf_matrix write)', 'bound': 'hbm',
                      'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
                      'traffic': traffic, 'launches': cnt.value, 'avg_launch_ms': conf_ms,

@@ -122,45 +122,89 @@ __device__ __forceinline__ int gf_acc_row(int r, int h) { return (r & 3) + 8 * (
 __device__ __forceinline__ int gf_lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 // ---------------------------------------------------------------------------------------------
-// cross-lane reduce-scatter over the 32 lanes of each wave half.
+// cross-lane reduce-scatter over the 32 lanes of each wave half, entirely on the VALU (no LDS
+// round trips: the ds_bpermute form measured ~60 dependent LDS latencies per call).
 // In: v[q], q = 0..31 (a per-lane array of partials for 32 "slots").  Out: lane c (= lane&31)
-// returns op-reduction over the 32 lanes of its half of slot q = c.  31 exchanges instead of the
-// 160 a butterfly per slot would need.
+// returns the op-reduction over the 32 lanes of its half of slot q = c.  31 exchanges:
+//   d = 16 : v_permlane16_swap_b32 exchanges the odd 16-lane rows of one register with the even rows
+//            of the other, which IS the keep/send selection - one swap + one op per slot pair;
+//   d = 8, 2, 1 : blend (v_bfi) keep/send, fetch the partner with one DPP mov (row_ror:8, quad_perm);
+//   d = 4  : two bank-masked DPP movs (row_ror:12 for lanes with bit 2 clear, row_ror:4 for the rest).
+// Lane mappings verified on gfx950 with tools/probes/dpp_probe.hip.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float gf_shfl_xor(float v, int d) { return __shfl_xor(v, d, 64); }
-__device__ __forceinline__ unsigned long long gf_shfl_xor(unsigned long long v, int d) {
-    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-    lo = __shfl_xor(lo, d, 64);
-    hi = __shfl_xor(hi, d, 64);
-    return ((unsigned long long)hi << 32) | lo;
-}
+typedef unsigned gf_v2u __attribute__((ext_vector_type(2)));
 
 // Lane-dependent choice between two registers as a bit blend (v_bfi_b32).  A `cond ? v[i+d] : v[i]`
 // select gets rewritten by LLVM into a dynamically indexed register array, which it then lowers to
 // a 32-way compare/select chain per access (measured: 3,800 v_cmp + 7,500 SGPR spills).
-__device__ __forceinline__ float gf_blend(unsigned m, float a, float b) {   // m all-ones -> a, zero -> b
-    return __uint_as_float((__float_as_uint(a) & m) | (__float_as_uint(b) & ~m));
+__device__ __forceinline__ unsigned gf_blend_u(unsigned m, unsigned a, unsigned b) { return (a & m) | (b & ~m); }
+
+template <int D>
+__device__ __forceinline__ unsigned gf_fetch_xor(unsigned x) {   // value of lane ^ D, D in {1, 2, 4, 8}
+    if constexpr (D == 8) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xF, 0xF, true);
+    else if constexpr (D == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);
+    else if constexpr (D == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);
+    else {
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)x, 0x12C, 0xF, 0x5, false);     // banks 0,2 <- lane+4
+        return (unsigned)__builtin_amdgcn_update_dpp(lo, (int)x, 0x124, 0xF, 0xA, false);   // banks 1,3 <- lane-4
+    }
 }
-__device__ __forceinline__ unsigned long long gf_blend(unsigned m, unsigned long long a, unsigned long long b) {
-    const unsigned long long mm = ((unsigned long long)m << 32) | m;
-    return (a & mm) | (b & ~mm);
+
+struct GfBitsF {      // float <-> register words
+    static constexpr int W = 1;
+    static __device__ __forceinline__ void unpack(float v, unsigned (&w)[1]) { w[0] = __float_as_uint(v); }
+    static __device__ __forceinline__ float pack(const unsigned (&w)[1]) { return __uint_as_float(w[0]); }
+};
+struct GfBitsU64 {
+    static constexpr int W = 2;
+    static __device__ __forceinline__ void unpack(unsigned long long v, unsigned (&w)[2]) { w[0] = (unsigned)v; w[1] = (unsigned)(v >> 32); }
+    static __device__ __forceinline__ unsigned long long pack(const unsigned (&w)[2]) { return ((unsigned long long)w[1] << 32) | w[0]; }
+};
+template <typename V> struct GfBits;
+template <> struct GfBits<float> : GfBitsF {};
+template <> struct GfBits<unsigned long long> : GfBitsU64 {};
+
+template <int D, typename V, typename Op>
+__device__ __forceinline__ void gf_rs_stage(V (&v)[32], unsigned up, Op op) {
+    using B = GfBits<V>;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        unsigned a[B::W], b[B::W], keep[B::W], recv[B::W];
+        B::unpack(v[i], a);
+        B::unpack(v[i + D], b);
+#pragma unroll
+        for (int k = 0; k < B::W; ++k) {
+            keep[k] = gf_blend_u(up, b[k], a[k]);
+            recv[k] = gf_fetch_xor<D>(gf_blend_u(up, a[k], b[k]));
+        }
+        v[i] = op(B::pack(keep), B::pack(recv));
+    }
 }
 
 template <typename V, typename Op>
 __device__ __forceinline__ V gf_reduce_scatter32(V (&v)[32], Op op) {
+    using B = GfBits<V>;
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int s = 4; s >= 0; --s) {
-        const int d = 1 << s;
-        unsigned up = (unsigned)(-(int)((lane >> s) & 1));   // all-ones in the upper lane of each pair
-        asm volatile("" : "+v"(up));
+    for (int i = 0; i < 16; ++i) {                 // d = 16
+        unsigned a[B::W], b[B::W], x[B::W], y[B::W];
+        B::unpack(v[i], a);
+        B::unpack(v[i + 16], b);
 #pragma unroll
-        for (int i = 0; i < d; ++i) {
-            const V keep = gf_blend(up, v[i + d], v[i]);
-            const V send = gf_blend(up, v[i], v[i + d]);
-            v[i] = op(keep, gf_shfl_xor(send, d));
+        for (int k = 0; k < B::W; ++k) {
+            const gf_v2u r = __builtin_amdgcn_permlane16_swap(a[k], b[k], false, false);
+            x[k] = r.x;
+            y[k] = r.y;
         }
+        v[i] = op(B::pack(x), B::pack(y));
     }
+    unsigned up8 = (unsigned)(-(int)((lane >> 3) & 1)), up4 = (unsigned)(-(int)((lane >> 2) & 1));
+    unsigned up2 = (unsigned)(-(int)((lane >> 1) & 1)), up1 = (unsigned)(-(int)(lane & 1));
+    asm volatile("" : "+v"(up8), "+v"(up4), "+v"(up2), "+v"(up1));
+    gf_rs_stage<8>(v, up8, op);
+    gf_rs_stage<4>(v, up4, op);
+    gf_rs_stage<2>(v, up2, op);
+    gf_rs_stage<1>(v, up1, op);
     return v[0];
 }
 

@@ -121,6 +121,18 @@ __device__ __forceinline__ void sim_tile(const T* __restrict__ A, const T* __res
     }
 }
 
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so
+// id % 8 labels the XCD.  Giving every XCD a CONTIGUOUS run of tiles (row panel after row panel) keeps
+// its f0 row panel and the f1 column tiles in that XCD's L2 instead of re-fetching them 8 times.
+// Bijective for any tile count (speed only; correctness never depends on placement).
+__device__ __forceinline__ void k1_tile(const K1Args& a, int& bm, int& bn) {
+    const int nt = a.tilesM * a.tilesN, id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3, q = nt >> 3, r = nt & 7;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    bm = t / a.tilesN;
+    bn = t % a.tilesN;
+}
+
 template <bool EXACT>
 __device__ __forceinline__ float k1_exp(float x) {
     if constexpr (EXACT) return expf(x);
@@ -271,7 +283,9 @@ __device__ __forceinline__ void k1_stats_epilogue(const K1Args& a, const v16f (&
 template <typename T>
 __global__ __launch_bounds__(NT) void k1_stats(K1Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int bn = blockIdx.x, bm = blockIdx.y, n = blockIdx.z;
+    const int n = blockIdx.y;
+    int bm, bn;
+    k1_tile(a, bm, bn);
     v16f acc[2][2];
     sim_tile<T>((const T*)a.f0 + (size_t)n * a.L * a.C, (const T*)a.f1 + (size_t)n * a.S * a.C, a.L, a.S, a.C,
                 bm * BM, bn * BN, smem, acc);
@@ -403,7 +417,9 @@ __device__ __forceinline__ void k1_conf_epilogue(const K1Args& a, const v16f (&a
 template <typename T>
 __global__ __launch_bounds__(NT) void k1_conf(K1Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int bn = blockIdx.x, bm = blockIdx.y, n = blockIdx.z;
+    const int n = blockIdx.y;
+    int bm, bn;
+    k1_tile(a, bm, bn);
     v16f acc[2][2];
     sim_tile<T>((const T*)a.f0 + (size_t)n * a.L * a.C, (const T*)a.f1 + (size_t)n * a.S * a.C, a.L, a.S, a.C,
                 bm * BM, bn * BN, smem, acc);
@@ -575,7 +591,7 @@ __global__ __launch_bounds__(1024) void k1_compact(SelArgs a) {
 template <typename T>
 int k1_launch(K1Args a, SelArgs s, void* zero_begin, size_t zero_bytes, hipStream_t st) {
     constexpr bool EXACT = std::is_same<T, float>::value;
-    const dim3 grid(a.tilesN, a.tilesM, a.N);
+    const dim3 grid(a.tilesN * a.tilesM, a.N);
     (void)hipMemsetAsync(zero_begin, 0, zero_bytes, st);   // rowbest, colmax, samplecnt (contiguous)
     void* p0 = gf_prof_begin("k1_stats", st);
     k1_stats<T><<<grid, NT, 2 * STAGE_BYTES, st>>>(a);
