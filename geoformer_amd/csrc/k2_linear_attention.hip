@@ -144,6 +144,148 @@ __global__ __launch_bounds__(256) void la_apply(LaArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// fp16 path: both contractions on the matrix cores.
+//
+//   la16_kv  : per 128-token chunk, per head:  KV[d][v] += sum_tok K[tok][d] V[tok][v]  is an MFMA whose
+//              K dimension is the TOKEN, so the 32-token sub-tiles are written to LDS transposed
+//              ([channel][token], 64-B rows) and both operands become 16-B fragment reads; Ksum comes
+//              from the same A operand against a ones B operand.  V is left unscaled in the fp32 state
+//              (v/S would be an fp16 subnormal); the 1/S scaling is applied when the state is cast to fp16.
+//   la16_apply: computed transposed, out^T[v][tok] = KV^T . Q^T, so the TOKEN sits on the lane: the
+//              numerator rows, the denominator (same MFMA against Ksum replicated over the rows) and the
+//              1/(den+eps) scaling are lane-local; Q fragments are 16-B loads straight from the token row.
+// ---------------------------------------------------------------------------------------------
+constexpr int LT = 32;     // tokens per sub-tile
+
+__device__ __forceinline__ int t_off(int ch, int chunk) { return ch * 64 + ((chunk ^ ((ch >> 2) & 3)) << 4); }   // [ch][32 tok] image
+
+template <int D>
+__global__ __launch_bounds__(256) void la16_kv(LaArgs a) {
+    static_assert(D == 32, "coarse configuration");
+    __shared__ __attribute__((aligned(16))) char kt[256 * 64];
+    __shared__ __attribute__((aligned(16))) char vt[256 * 64];
+    const int chunk = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h2 = lane >> 5, lr = lane & 31, C = a.C;
+    const int s_begin = chunk * CHUNK, s_end = min(a.S, s_begin + CHUNK);
+    const _Float16* kp = (const _Float16*)a.k + (size_t)n * a.S * a.ldk;
+    const _Float16* vp = (const _Float16*)a.v + (size_t)n * a.S * a.ldv;
+    v16f acc[2], ksum[2];                        // this wave's two heads: 2*wave, 2*wave+1
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; ksum[i][r] = 0.f; }
+    const v8h ones{(_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1};
+    for (int s0 = s_begin; s0 < s_end; s0 += LT) {
+        // ---- cooperative load of [32 tok][C] (16 B per thread and pass), transform, transposed LDS write
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int e = p * 256 + tid, tok = e >> 5, c8 = (e & 31) * 8;      // C = 256: 32 chunks per token
+            const int s = s0 + tok;
+            v8h kk = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (s < s_end && (a.kv_mask == nullptr || a.kv_mask[(size_t)n * a.S + s] != 0)) {
+                kk = *reinterpret_cast<const v8h*>(kp + (size_t)s * a.ldk + c8);
+                vv = *reinterpret_cast<const v8h*>(vp + (size_t)s * a.ldv + c8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) kk[i] = (_Float16)elu1((float)kk[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int ch = c8 + i;
+                *reinterpret_cast<_Float16*>(kt + t_off(ch, tok >> 3) + (tok & 7) * 2) = kk[i];
+                *reinterpret_cast<_Float16*>(vt + t_off(ch, tok >> 3) + (tok & 7) * 2) = vv[i];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ch = (2 * wave + i) * D + lr;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const v8h kf = *reinterpret_cast<const v8h*>(kt + t_off(ch, 2 * s2 + h2));
+                const v8h vf = *reinterpret_cast<const v8h*>(vt + t_off(ch, 2 * s2 + h2));
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, vf, acc[i], 0, 0, 0);
+                ksum[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, ones, ksum[i], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    float* dst = (a.nchunks == 1 ? a.kvfinal + (size_t)n * (C * D + C)
+                                 : a.kvpart + ((size_t)n * a.nchunks + chunk) * (C * D + C));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int h = 2 * wave + i;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = gf_acc_row(r, h2);      // rows = d, column = v (lane)
+            dst[lr * C + h * D + d] = acc[i][r];
+            if (lr == 0) dst[C * D + h * D + d] = ksum[i][r];
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void la16_apply(LaArgs a) {
+    static_assert(D == 32, "coarse configuration");
+    __shared__ __attribute__((aligned(16))) _Float16 kvt[8 * 32 * 32];   // [h][v][d]
+    __shared__ __attribute__((aligned(16))) _Float16 ksh[8 * 32];        // [h][d]
+    const int n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5, lr = lane & 31;
+    const int C = a.C;
+    const float* kvf = a.kvfinal + (size_t)n * (C * D + C);
+    // the state is brought to fp16 scaled by 1/S (the reference's "prevent fp16 overflow" scaling, :45):
+    // out = (Q.KV/S) / (Q.Ksum/S + eps/S), identical to (Q.KV/S) * 1/(Q.Ksum + eps) * S
+    const float inv_s = 1.0f / (float)a.S;
+    for (int e = tid; e < C * D; e += 256) {      // kvf element (v, c = h*D + d) at [v*C + c]
+        const int v = e / C, c = e % C;
+        kvt[((c / D) * 32 + v) * 32 + (c % D)] = (_Float16)(kvf[e] * inv_s);
+    }
+    ksh[tid] = (_Float16)(kvf[C * D + tid] * inv_s);
+    __syncthreads();
+    const int tok = blockIdx.x * 128 + wave * 32 + lr;
+    const bool live = tok < a.L;
+    const int tk = live ? tok : a.L - 1;
+    const bool qok = a.q_mask == nullptr || a.q_mask[(size_t)n * a.L + tk] != 0;
+    const _Float16* qp = (const _Float16*)a.q + ((size_t)n * a.L + tk) * a.ldq;
+    _Float16* op = (_Float16*)a.out + ((size_t)n * a.L + tk) * C;
+#pragma unroll 2
+    for (int h = 0; h < 8; ++h) {
+        v16f num, den;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { num[r] = 0.f; den[r] = 0.f; }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            v8h qf = *reinterpret_cast<const v8h*>(qp + h * D + 16 * s2 + 8 * h2);       // B: col = token, k = d
+#pragma unroll
+            for (int i = 0; i < 8; ++i) qf[i] = qok ? (_Float16)elu1((float)qf[i]) : (_Float16)0;
+            const v8h kf = *reinterpret_cast<const v8h*>(kvt + (h * 32 + lr) * 32 + 16 * s2 + 8 * h2);   // A: row = v
+            const v8h sf = *reinterpret_cast<const v8h*>(ksh + h * 32 + 16 * s2 + 8 * h2);              // A: every row = Ksum
+            num = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf, num, 0, 0, 0);
+            den = __builtin_amdgcn_mfma_f32_32x32x16_f16(sf, qf, den, 0, 0, 0);
+        }
+        if (live) {
+            const float z = 1.0f / (den[0] + a.eps * inv_s);  // every row of den holds the token's Q.Ksum / S
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int v0 = 8 * r4 + 4 * h2;                // 4 consecutive v
+                *reinterpret_cast<v4h*>(op + h * D + v0) = v4h{(_Float16)(num[4 * r4] * z), (_Float16)(num[4 * r4 + 1] * z),
+                                                              (_Float16)(num[4 * r4 + 2] * z), (_Float16)(num[4 * r4 + 3] * z)};
+            }
+        }
+    }
+}
+
+int la16_launch(const LaArgs& a, hipStream_t st) {
+    la16_kv<32><<<dim3(a.nchunks, a.N), 256, 0, st>>>(a);
+    if (a.nchunks > 1) {
+        const int len = a.C * a.D + a.C;
+        la_kv_final<<<dim3((len + 255) / 256, a.N), 256, 0, st>>>(a);
+    }
+    la16_apply<32><<<dim3((a.L + 127) / 128, a.N), 256, 0, st>>>(a);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}
+
 template <typename T, int D>
 int la_launch(const LaArgs& a, hipStream_t st) {
     const size_t lds = (size_t)TOK * a.C * sizeof(float);
@@ -187,6 +329,7 @@ extern "C" int gf_linear_attention(const void* q, const void* k, const void* v, 
     a.kvfinal = (float*)workspace;
     a.kvpart = a.kvfinal + (size_t)N * len;
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == GF_F16 && D == 32 && H == 8) return la16_launch(a, st);      // coarse level: matrix-core path
 #define GF_LA(T)                                       \
     (D == 16 ? la_launch<T, 16>(a, st) : D == 32 ? la_launch<T, 32>(a, st) : la_launch<T, 64>(a, st))
     return dtype == GF_F32 ? GF_LA(float) : GF_LA(_Float16);

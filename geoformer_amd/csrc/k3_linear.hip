@@ -154,7 +154,10 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nb][r] = tanhf(acc[nb][r]);
+            for (int r = 0; r < 16; ++r) {
+                if constexpr (std::is_same<T, float>::value) acc[nb][r] = tanhf(acc[nb][r]);
+                else acc[nb][r] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * acc[nb][r]) + 1.0f);   // tanh, ~1e-6 abs
+            }
     } else if constexpr (EPI >= EPI_LN) {
         // nn.LayerNorm over the WROWS channels of the token: two-pass mean / variance in fp32
         float s = 0.f;
