@@ -109,3 +109,34 @@ def test_device_ransac_vs_oracle(precision):
         b = set(zip(ref['b_ids'].tolist(), ref['i_ids'].tolist(), ref['j_ids'].tolist()))
         assert len(a & b) >= 0.97 * max(len(a), len(b))
         close(out['conf_matrix'], ref['conf_matrix'], 0.1, 2e-2)
+
+
+def test_no_coarse_match_branch():
+    """M == 0: FinePreprocess / FineMatching2 early returns (fine_preprocess.py:35-38, fine_matching2.py:34-42)."""
+    case = GI.g10_cases()['g10b_e2e_planted_n2']
+    m = build(0.999999, 0.1)
+    (c0, f0), (c1, f1) = case['feats']
+    with torch.no_grad():
+        out = m.forward_features(to_dev(case['data']), c0.to(DEV), f0.to(DEV), c1.to(DEV), f1.to(DEV))
+    assert out['b_ids'].numel() == 0 and out['mkpts0_c'].shape == (0, 2)
+    assert out['fine_matrix'].shape == (0, 25, 25)
+    assert out['mkpts0_f'].shape == (0, 2) and out['mkpts1_f'].shape == (0, 2) and out['mconf'].numel() == 0
+    assert out['conf_matrix'].shape == (2, 80, 80) and out['dect_conf_matrix'].shape == (2, 80, 80)
+    # no model for any sample -> GeoModule leaves the position-encoded features untouched by the cross layers
+    assert [int(v) for v in out['_geo_dev']['valid']] == [0, 0]
+
+
+@pytest.mark.parametrize('name', ['g10b_e2e_planted_n2', 'g10c_e2e_planted_unequal', 'g10d_e2e_planted_masked'])
+def test_golden_fp16_mode(golden, name):
+    """fp16 storage / fp32 accumulate against the fp32 REFERENCE outputs: the same matches except for a
+    few borderline ones, keypoints of the common matches identical."""
+    G, case = golden(name), GI.g10_cases()[name]
+    m = build(case['coarse_thr'], case['fine_thr'], 'fp16')
+    m.geo_module.homography_fn = None            # device RANSAC
+    (c0, f0), (c1, f1) = case['feats']
+    with torch.no_grad():
+        out = m.forward_features(to_dev(case['data']), c0.to(DEV).half(), f0.to(DEV).half(), c1.to(DEV).half(), f1.to(DEV).half())
+    a = set(zip(out['b_ids'].tolist(), out['i_ids'].tolist(), out['j_ids'].tolist()))
+    b = set(zip(G['out_b_ids'].tolist(), G['out_i_ids'].tolist(), G['out_j_ids'].tolist()))
+    assert len(a & b) >= 0.9 * max(len(a), len(b)), (len(a), len(b), len(a & b))
+    assert out['mkpts0_f'].dtype == torch.float32 and out['conf_matrix'].dtype == torch.float32
