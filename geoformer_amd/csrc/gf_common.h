@@ -208,6 +208,13 @@ __device__ __forceinline__ V gf_reduce_scatter32(V (&v)[32], Op op) {
     return v[0];
 }
 
+// value of lane ^ 16 (the other 16-lane row of the same wave half)
+__device__ __forceinline__ float gf_shfl_xor16(float v) { return __shfl_xor(v, 16, 64); }
+__device__ __forceinline__ unsigned long long gf_shfl_xor16(unsigned long long v) {
+    const unsigned lo = __shfl_xor((unsigned)v, 16, 64), hi = __shfl_xor((unsigned)(v >> 32), 16, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 struct GfMaxF {
     __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); }
 };

@@ -18,6 +18,11 @@
 //   compact k1_compact : ordered compaction (torch.where order) + keypoint arithmetic.
 //
 // HBM roofline: pass B is bound by the conf write (L*S*4 B per sample); everything else is O(L*C).
+// Measured (8 samples of 6400^2, fp16): the same two-128-B-segment store pattern alone reaches 5.6 TB/s
+// (tools/probes/store_pattern.hip); pass B reaches ~3.2 TB/s: ablating the stores or 3 of its 4 K steps
+// removes ~195 us each and the two do not overlap.  A row-panel-persistent variant (f0 rows kept as A
+// fragments in registers, 3x fewer operand bytes) measured the same, so the operand traffic is not the
+// limiter; non-temporal stores (conf is never re-read by this launch) bought 8 %.
 #include <math.h>
 
 #include <type_traits>
@@ -26,10 +31,11 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, NT = 256;
+constexpr int BM = 128, BN = 64, NT = 256;      // workgroup tile; 4 waves stacked along M, each 32 rows x 64 cols
 constexpr int ROWB = 128;                        // bytes per LDS operand row = one K step
-constexpr int STAGE_BYTES = (BM + BN) * ROWB;    // 32 KiB per stage, two stages
+constexpr int STAGE_BYTES = (BM + BN) * ROWB;    // 24 KiB, single stage (the next step's tile waits in registers)
 constexpr float NEG_INF = -INFINITY;
+constexpr float LOG2E = 1.4426950408889634f;
 
 struct K1Args {
     const void* f0;
@@ -51,74 +57,62 @@ struct K1Args {
 };
 
 // ---------------------------------------------------------------------------------------------
-// tile engine: acc[mi][ni] (wave-local 64x64 block = 2x2 MFMA 32x32 tiles) of f0[m0:,:] . f1[n0:,:]^T
-// register-staged double buffering, one barrier per K step; operand rows clamped (masked later).
+// tile engine: acc[ni] = the wave's 32 x 64 block (two MFMA 32x32 tiles) of f0[m0:,:] . f1[n0:,:]^T.
+// 24 KiB of LDS and < 128 VGPRs per lane keep 4 workgroups (16 waves) resident per CU: the epilogue of
+// one overlaps the loads and MFMAs of the others.  Operand rows are clamped; validity is applied later.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ void sim_tile(const T* __restrict__ A, const T* __restrict__ B, int L, int S, int C,
-                                         int m0, int n0, char* smem, v16f (&acc)[2][2]) {
+                                         int m0, int n0, char* smem, v16f (&acc)[2]) {
     using M = Mma32<T>;
     using Frag = typename M::Frag;
     constexpr int EPC = 16 / sizeof(T);
     constexpr int BK = ROWB / sizeof(T);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, lr = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, lr = lane & 31;
     const int srow = tid >> 3, schunk = tid & 7;
-    v4u ra[4], rb[4];   // native vectors: HIP's uint4 (a union-based struct) kept these arrays in scratch
+    v4u ra[4], rb[2];
     const T* ga[4];
-    const T* gb[4];
+    const T* gb[2];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        ga[p] = A + (size_t)min(m0 + srow + 32 * p, L - 1) * C + schunk * EPC;
-        gb[p] = B + (size_t)min(n0 + srow + 32 * p, S - 1) * C + schunk * EPC;
-    }
+    for (int p = 0; p < 4; ++p) ga[p] = A + (size_t)min(m0 + srow + 32 * p, L - 1) * C + schunk * EPC;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int p = 0; p < 2; ++p) gb[p] = B + (size_t)min(n0 + srow + 32 * p, S - 1) * C + schunk * EPC;
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+    for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            ra[p] = *reinterpret_cast<const v4u*>(ga[p] + k0);
-            rb[p] = *reinterpret_cast<const v4u*>(gb[p] + k0);
-        }
-    };
-    auto lstore = [&](int buf) {
-        char* sa = smem + buf * STAGE_BYTES;
-        char* sb = sa + BM * ROWB;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            *reinterpret_cast<v4u*>(sa + gf_lds_off(srow + 32 * p, schunk)) = ra[p];
-            *reinterpret_cast<v4u*>(sb + gf_lds_off(srow + 32 * p, schunk)) = rb[p];
-        }
-    };
+        for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+    char* sa = smem;
+    char* sb = smem + BM * ROWB;
     const int nk = C / BK;
-    gload(0);
-    lstore(0);
-    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) ra[p] = *reinterpret_cast<const v4u*>(ga[p]);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) rb[p] = *reinterpret_cast<const v4u*>(gb[p]);
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * BK);
-        const char* sa = smem + buf * STAGE_BYTES;
-        const char* sb = sa + BM * ROWB;
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<v4u*>(sa + gf_lds_off(srow + 32 * p, schunk)) = ra[p];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) *reinterpret_cast<v4u*>(sb + gf_lds_off(srow + 32 * p, schunk)) = rb[p];
+        __syncthreads();
+        if (kt + 1 < nk) {
+            const int k0 = (kt + 1) * BK;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) ra[p] = *reinterpret_cast<const v4u*>(ga[p] + k0);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) rb[p] = *reinterpret_cast<const v4u*>(gb[p] + k0);
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int chunk = 2 * g + h;
-            Frag a0 = *reinterpret_cast<const Frag*>(sa + gf_lds_off(wm * 64 + lr, chunk));
-            Frag a1 = *reinterpret_cast<const Frag*>(sa + gf_lds_off(wm * 64 + 32 + lr, chunk));
-            Frag b0 = *reinterpret_cast<const Frag*>(sb + gf_lds_off(wn * 64 + lr, chunk));
-            Frag b1 = *reinterpret_cast<const Frag*>(sb + gf_lds_off(wn * 64 + 32 + lr, chunk));
-            M::mma(a0, b0, acc[0][0]);
-            M::mma(a0, b1, acc[0][1]);
-            M::mma(a1, b0, acc[1][0]);
-            M::mma(a1, b1, acc[1][1]);
+            const Frag a0 = *reinterpret_cast<const Frag*>(sa + gf_lds_off(wave * 32 + lr, chunk));
+            const Frag b0 = *reinterpret_cast<const Frag*>(sb + gf_lds_off(lr, chunk));
+            const Frag b1 = *reinterpret_cast<const Frag*>(sb + gf_lds_off(32 + lr, chunk));
+            M::mma(a0, b0, acc[0]);
+            M::mma(a0, b1, acc[1]);
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
-        __syncthreads();
     }
+    __syncthreads();                 // the staging area is reused as scratch by the epilogues
 }
 
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so
@@ -139,29 +133,28 @@ __device__ __forceinline__ float k1_exp(float x) {
     else return __expf(x);
 }
 
-// Per-lane view of the wave's 64x64 block after the MFMAs: validity of its 32 row slots
-// (slot q = mi*16 + r -> row m0 + wm*64 + mi*32 + acc_row(r, h)) and its 2 columns.
+// Per-lane view of the wave's 32x64 block after the MFMAs: slot r (0..15) -> row m0 + wave*32 +
+// acc_row(r, h); column ni -> n0 + ni*32 + (lane & 31).
 struct LaneGeom {
-    unsigned row_in, row_ok;   // bit q: row < L ; mask0 true (or no mask)
+    unsigned row_in, row_ok;   // bit r: row < L ; mask0 true (or no mask)
     unsigned col_in, col_ok;   // bit ni
 };
 
-// Branch-free; the packed words are made opaque so that the compiler keeps them as two VGPRs
-// instead of 64 live lane masks in SGPRs (which spilled thousands of SGPRs).
+// Branch-free; the packed words are made opaque so that the compiler keeps them as VGPRs instead of
+// dozens of live lane masks in SGPRs (which spilled thousands of SGPRs).
 __device__ __forceinline__ LaneGeom k1_geom(const K1Args& a, int n, int m0, int n0) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, lr = lane & 31;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, lr = lane & 31;
     LaneGeom g;
-    const int row0 = m0 + wm * 64, col0 = n0 + wn * 64 + lr;
+    const int row0 = m0 + wave * 32, col0 = n0 + lr;
     g.row_in = 0;
     g.row_ok = 0;
     const bool masked = a.mask0 != nullptr;
 #pragma unroll
-    for (int q = 0; q < 32; ++q) {
-        const int row = row0 + (q >> 4) * 32 + gf_acc_row(q & 15, h);
+    for (int r = 0; r < 16; ++r) {
+        const int row = row0 + gf_acc_row(r, h);
         const unsigned in = row < a.L ? 1u : 0u;
-        g.row_in |= in << q;
-        if (masked) g.row_ok |= (in & (a.mask0[(size_t)n * a.L + min(row, a.L - 1)] != 0 ? 1u : 0u)) << q;
+        g.row_in |= in << r;
+        if (masked) g.row_ok |= (in & (a.mask0[(size_t)n * a.L + min(row, a.L - 1)] != 0 ? 1u : 0u)) << r;
     }
     if (!masked) g.row_ok = g.row_in;
     g.col_in = 0;
@@ -178,115 +171,115 @@ __device__ __forceinline__ LaneGeom k1_geom(const K1Args& a, int n, int m0, int 
     return g;
 }
 
-// sim values of this lane: sv[q][ni]; out-of-range -> -inf (ignored by every reduction),
+// sim values of this lane: sv[ni][r]; out-of-range -> -inf (ignored by every reduction),
 // masked pair -> -1e9 exactly as masked_fill does (coarse_matching.py:123-124).
 // GUARD=false is the interior, unmasked tile: no predicates at all.
 template <bool EXACT, bool GUARD>
-__device__ __forceinline__ void k1_sim_values(const K1Args& a, const LaneGeom& g, const v16f (&acc)[2][2],
-                                              float (&sv)[32][2]) {
+__device__ __forceinline__ void k1_sim_values(const K1Args& a, const LaneGeom& g, const v16f (&acc)[2], float (&sv)[2][16]) {
 #pragma unroll
-    for (int q = 0; q < 32; ++q) {
+    for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const float raw = acc[q >> 4][ni][q & 15];
+        for (int r = 0; r < 16; ++r) {
+            const float raw = acc[ni][r];
             float s;
             if constexpr (EXACT) s = (raw * a.inv_c) / a.temperature;
             else s = raw * a.mult;
             if constexpr (GUARD) {
-                const bool in = ((g.row_in >> q) & (g.col_in >> ni) & 1u) != 0;
-                const bool ok = ((g.row_ok >> q) & (g.col_ok >> ni) & 1u) != 0;
+                const bool in = ((g.row_in >> r) & (g.col_in >> ni) & 1u) != 0;
+                const bool ok = ((g.row_ok >> r) & (g.col_ok >> ni) & 1u) != 0;
                 s = in ? (ok ? s : -1e9f) : NEG_INF;
             }
-            sv[q][ni] = s;
+            sv[ni][r] = s;
         }
-    }
 }
 
 __device__ __forceinline__ bool k1_interior(const K1Args& a, int m0, int n0) {
     return a.mask0 == nullptr && m0 + BM <= a.L && n0 + BN <= a.S;
 }
 
+// reduction over the 64 columns of the wave's block for each of its 16 row slots: the 32 (ni, r) values
+// go through the 32-lane reduce-scatter (lane c ends with slot c = ni*16 + r), lanes c and c^16 then hold
+// the two column halves of row slot r = c & 15
+template <typename V, typename Op>
+__device__ __forceinline__ V k1_row_reduce(V (&v)[32], Op op) {
+    const V x = gf_reduce_scatter32(v, op);
+    return op(x, gf_shfl_xor16(x));
+}
+
 // ---------------------------------------------------------------------------------------------
 // pass A: row / column (max, sum-exp) partials of one tile
 // ---------------------------------------------------------------------------------------------
 template <typename T, bool GUARD>
-__device__ __forceinline__ void k1_stats_epilogue(const K1Args& a, const v16f (&acc)[2][2], char* smem, int n, int bm,
-                                                  int bn) {
+__device__ __forceinline__ void k1_stats_epilogue(const K1Args& a, const v16f (&acc)[2], char* smem, int n, int bm, int bn) {
     constexpr bool EXACT = std::is_same<T, float>::value;
     const int m0 = bm * BM, n0 = bn * BN;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, lr = lane & 31;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, lr = lane & 31;
     LaneGeom g;
     if constexpr (GUARD) g = k1_geom(a, n, m0, n0);
-    float sv[32][2];
+    float sv[2][16];
     k1_sim_values<EXACT, GUARD>(a, g, acc, sv);
-
-    float* scratch = reinterpret_cast<float*>(smem);   // staging buffers are free after the K loop
-    float* rowbc = scratch + wave * 64;                // [4][64]   row maxima broadcast, per wave
-    float2* colx = reinterpret_cast<float2*>(scratch + 256);          // [2(wm)][128] column partials
-    float2* rowx = colx + 256;                                         // [2(wn)][128] row partials
-
-    // ---- columns: lane-local over its 32 rows, then the other lane half
+    float* rowbc = reinterpret_cast<float*>(smem) + wave * 32;             // [4][32] row maxima, per wave
+    float2* colx = reinterpret_cast<float2*>(smem + 512);                   // [4 waves][64] column partials
+    // ---- columns: lane-local over its 16 rows, then the other lane half
     float cm[2], cl[2];
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         float m = NEG_INF;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) m = fmaxf(m, sv[q][ni]);
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, sv[ni][r]);
         m = fmaxf(m, __shfl_xor(m, 32, 64));
         const float ms = (GUARD && m == NEG_INF) ? 0.f : m;
         float l = 0.f;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) l += k1_exp<EXACT>(sv[q][ni] - ms);
+        for (int r = 0; r < 16; ++r) l += k1_exp<EXACT>(sv[ni][r] - ms);
         l += __shfl_xor(l, 32, 64);
         cm[ni] = m;
         cl[ni] = l;
     }
-    // ---- rows: reduce-scatter over the 32 lanes of each half
-    float rq[32];
+    if (h == 0) {
+        colx[wave * 64 + lr] = make_float2(cm[0], cl[0]);
+        colx[wave * 64 + 32 + lr] = make_float2(cm[1], cl[1]);
+    }
+    // ---- rows
+    float v[32];
 #pragma unroll
-    for (int q = 0; q < 32; ++q) rq[q] = fmaxf(sv[q][0], sv[q][1]);
-    const float rmax_mine = gf_reduce_scatter32(rq, GfMaxF());   // lane lr: slot q = lr
-    rowbc[h * 32 + lr] = rmax_mine;
+    for (int q = 0; q < 32; ++q) v[q] = sv[q >> 4][q & 15];
+    const float rmax = k1_row_reduce(v, GfMaxF());             // lanes c, c^16: row slot c & 15
+    if (lr < 16) rowbc[h * 16 + lr] = rmax;
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 32; ++q) {
-        const float m = rowbc[h * 32 + q];
+        const float m = rowbc[h * 16 + (q & 15)];
         const float ms = (GUARD && m == NEG_INF) ? 0.f : m;
-        rq[q] = k1_exp<EXACT>(sv[q][0] - ms) + k1_exp<EXACT>(sv[q][1] - ms);
+        v[q] = k1_exp<EXACT>(sv[q >> 4][q & 15] - ms);
     }
-    const float rsum_mine = gf_reduce_scatter32(rq, GfAddF());
-    // ---- combine the two waves that share rows (wn) / columns (wm) through LDS
-    const int myrow_local = wm * 64 + (lr >> 4) * 32 + gf_acc_row(lr & 15, h);   // slot lr
-    rowx[wn * 128 + myrow_local] = make_float2(rmax_mine, rsum_mine);
-    if (h == 0) {
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) colx[wm * 128 + wn * 64 + ni * 32 + lr] = make_float2(cm[ni], cl[ni]);
+    const float rsum = k1_row_reduce(v, GfAddF());
+    if (lr < 16) {
+        const int row = m0 + wave * 32 + gf_acc_row(lr, h);
+        if (row < a.L) a.rowpart[((size_t)n * a.tilesN + bn) * a.L + row] = make_float2(rmax, rsum);
     }
-    __syncthreads();
+    // ---- combine the four waves' column partials
     const int t = threadIdx.x;
-    const float2* px = (t < 128) ? rowx : colx;
-    const int c = t & 127;
-    const float2 p = px[c], q2 = px[128 + c];
-    const float m = fmaxf(p.x, q2.x);
-    const float ms = (m == NEG_INF) ? 0.f : m;
-    const float l = p.y * k1_exp<EXACT>(p.x - ms) + q2.y * k1_exp<EXACT>(q2.x - ms);
-    if (t < 128) {
-        const int row = m0 + c;
-        if (row < a.L) a.rowpart[((size_t)n * a.tilesN + bn) * a.L + row] = make_float2(m, l);
-    } else {
-        const int col = n0 + c;
+    if (t < 64) {
+        float m = NEG_INF;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) m = fmaxf(m, colx[w * 64 + t].x);
+        const float ms = (m == NEG_INF) ? 0.f : m;
+        float l = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) l += colx[w * 64 + t].y * k1_exp<EXACT>(colx[w * 64 + t].x - ms);
+        const int col = n0 + t;
         if (col < a.S) a.colpart[((size_t)n * a.tilesM + bm) * a.S + col] = make_float2(m, l);
     }
 }
 
 template <typename T>
-__global__ __launch_bounds__(NT) void k1_stats(K1Args a) {
+__global__ __launch_bounds__(NT, 4) void k1_stats(K1Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = blockIdx.y;
     int bm, bn;
     k1_tile(a, bm, bn);
-    v16f acc[2][2];
+    v16f acc[2];
     sim_tile<T>((const T*)a.f0 + (size_t)n * a.L * a.C, (const T*)a.f1 + (size_t)n * a.S * a.C, a.L, a.S, a.C,
                 bm * BM, bn * BN, smem, acc);
     if (k1_interior(a, bm * BM, bn * BN)) k1_stats_epilogue<T, false>(a, acc, smem, n, bm, bn);
@@ -331,106 +324,117 @@ __global__ __launch_bounds__(256) void k1_reduce_stats(K1Args a) {
 // pass B: confidence tile -> HBM, row-best keys, column maxima
 // ---------------------------------------------------------------------------------------------
 template <typename T, bool GUARD, bool DENSE>
-__device__ __forceinline__ void k1_conf_epilogue(const K1Args& a, const v16f (&acc)[2][2], char* smem, int n, int bm,
-                                                 int bn) {
+__device__ __forceinline__ void k1_conf_epilogue(const K1Args& a, const v16f (&acc)[2], char* smem, int n, int bm, int bn) {
     constexpr bool EXACT = std::is_same<T, float>::value;
     const int m0 = bm * BM, n0 = bn * BN;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, lr = lane & 31;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, lr = lane & 31;
     LaneGeom g;
     if constexpr (GUARD) g = k1_geom(a, n, m0, n0);
-    float sv[32][2];
-    k1_sim_values<EXACT, GUARD>(a, g, acc, sv);
-    const int row0 = m0 + wm * 64, col0 = n0 + wn * 64 + lr;
-
-    // row statistics of the tile -> LDS once (a per-slot global load inside the store loop would wait
-    // vmcnt(0), i.e. drain the store queue, 32 times per wave)
+    // row statistics of the tile -> LDS once: EXACT keeps (max, sum); the fast path stores
+    // (-max*log2e, 1/sum) so that conf = exp2(2*s*log2e + A_row + B_col) * (1/sum_row) * (1/sum_col),
+    // ONE exponential per element (= softmax_col * softmax_row up to fp32 rounding)
     float2* rst = reinterpret_cast<float2*>(smem);
     if (threadIdx.x < BM) {
         const float2 st = a.rstat[(size_t)n * a.L + min(m0 + (int)threadIdx.x, a.L - 1)];
-        rst[threadIdx.x] = make_float2(st.x, EXACT ? st.y : __builtin_amdgcn_rcpf(st.y));
+        rst[threadIdx.x] = EXACT ? st : make_float2(-st.x * LOG2E, __builtin_amdgcn_rcpf(st.y));
     }
-    float cmx[2], cden[2];
+    float ca[2], cb[2];
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
-        const int col = GUARD ? min(col0 + ni * 32, a.S - 1) : col0 + ni * 32;
+        const int col = GUARD ? min(n0 + ni * 32 + lr, a.S - 1) : n0 + ni * 32 + lr;
         const float2 st = a.cstat[(size_t)n * a.S + col];
-        cmx[ni] = st.x;
-        cden[ni] = EXACT ? st.y : __builtin_amdgcn_rcpf(st.y);
+        ca[ni] = EXACT ? st.x : -st.x * LOG2E;
+        cb[ni] = EXACT ? st.y : __builtin_amdgcn_rcpf(st.y);
     }
     __syncthreads();
-    unsigned long long key[DENSE ? 32 : 1];
-    unsigned cbest[2] = {0u, 0u};
-    float* cbase = a.conf + (size_t)n * a.L * a.S;
+    const float k2 = 2.0f * a.mult * LOG2E;
+    const int row_base = m0 + __builtin_amdgcn_readfirstlane(wave) * 32;
+    float* cbase = a.conf + ((size_t)n * a.L + row_base) * a.S + n0;
     unsigned long long* rbest = a.rowbest + (size_t)n * a.L;
     unsigned* cmax = a.colmax + (size_t)n * a.S;
+    const int lane_off = 4 * h * a.S + lr;               // 32-bit per-lane part of the store address
+    unsigned long long key[DENSE ? 32 : 1];
+    unsigned cbest[2] = {0u, 0u};
 #pragma unroll
-    for (int q = 0; q < 32; ++q) {
-        const int row = row0 + (q >> 4) * 32 + gf_acc_row(q & 15, h);
-        const float2 st = rst[wm * 64 + (q >> 4) * 32 + gf_acc_row(q & 15, h)];
-        const float rden = st.y;
-        unsigned long long k = 0ull;
+    for (int r = 0; r < 16; ++r) {
+        const float2 st = rst[wave * 32 + gf_acc_row(r, h)];
+        float cf[2];
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-            const float s = sv[q][ni];
-            float pc, pr;
             if constexpr (EXACT) {
-                pc = expf(s - cmx[ni]) / cden[ni];
-                pr = expf(s - st.x) / rden;
+                float s = (acc[ni][r] * a.inv_c) / a.temperature;
+                if constexpr (GUARD) {
+                    const bool ok = ((g.row_ok >> r) & (g.col_ok >> ni) & 1u) != 0;
+                    s = ok ? s : -1e9f;
+                }
+                cf[ni] = (expf(s - ca[ni]) / cb[ni]) * (expf(s - st.x) / st.y);
             } else {
-                pc = __expf(s - cmx[ni]) * cden[ni];
-                pr = __expf(s - st.x) * rden;
+                float e;
+                if constexpr (GUARD) {
+                    const bool ok = ((g.row_ok >> r) & (g.col_ok >> ni) & 1u) != 0;
+                    const float s2 = ok ? acc[ni][r] * k2 : -2e9f * LOG2E;
+                    e = __builtin_amdgcn_exp2f(s2 + (st.x + ca[ni]));
+                } else {
+                    e = __builtin_amdgcn_exp2f(fmaf(acc[ni][r], k2, st.x + ca[ni]));
+                }
+                cf[ni] = e * (st.y * cb[ni]);
             }
-            const float cf = pc * pr;
-            bool in = true;
-            if constexpr (GUARD) in = ((g.row_in >> q) & (g.col_in >> ni) & 1u) != 0;
-            if (in) {
-                const int col = col0 + ni * 32;
-                cbase[(size_t)row * a.S + col] = cf;
-                if (cf > a.thr) {
-                    const unsigned bits = __float_as_uint(cf);
-                    const unsigned long long kk = ((unsigned long long)bits << 32) | (0xFFFFFFFFu - (unsigned)col);
-                    if constexpr (DENSE) {
-                        cbest[ni] = max(cbest[ni], bits);
-                        k = kk > k ? kk : k;
-                    } else {      // rare: at most 1/thr entries of a row (column) can exceed thr
-                        atomicMax(rbest + row, kk);
+        }
+        // the row of slot r: uniform base + compile-time multiple of S; lanes add their 32-bit offset
+        float* rowp = cbase + (size_t)((r & 3) + 8 * (r >> 2)) * a.S;
+        bool in0 = true, in1 = true;
+        if constexpr (GUARD) {
+            in0 = ((g.row_in >> r) & g.col_in & 1u) != 0;
+            in1 = ((g.row_in >> r) & (g.col_in >> 1) & 1u) != 0;
+        }
+        if (in0) __builtin_nontemporal_store(cf[0], rowp + lane_off);
+        if (in1) __builtin_nontemporal_store(cf[1], rowp + lane_off + 32);
+        if constexpr (!DENSE) {
+            // candidates above thr are rare (<= 1/thr per row or column): atomics on them only
+            if (fmaxf(cf[0], cf[1]) > a.thr) {
+                const int row = row_base + gf_acc_row(r, h);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    if (cf[ni] > a.thr && (ni == 0 ? in0 : in1)) {
+                        const int col = n0 + ni * 32 + lr;
+                        const unsigned bits = __float_as_uint(cf[ni]);
+                        atomicMax(rbest + row, ((unsigned long long)bits << 32) | (0xFFFFFFFFu - (unsigned)col));
                         atomicMax(cmax + col, bits);
                     }
                 }
             }
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const bool in = cf[ni] > a.thr && (ni == 0 ? in0 : in1);
+                const unsigned bits = in ? __float_as_uint(cf[ni]) : 0u;
+                cbest[ni] = max(cbest[ni], bits);
+                key[ni * 16 + r] = in ? (((unsigned long long)bits << 32) | (0xFFFFFFFFu - (unsigned)(n0 + ni * 32 + lr))) : 0ull;
+            }
         }
-        if constexpr (DENSE) key[q] = k;
     }
     if constexpr (DENSE) {
-        const unsigned long long kbest = gf_reduce_scatter32(key, GfMaxU64());
-        const int myrow = row0 + (lr >> 4) * 32 + gf_acc_row(lr & 15, h);
-        if (kbest != 0ull) atomicMax(rbest + myrow, kbest);
+        const unsigned long long kbest = k1_row_reduce(key, GfMaxU64());
+        if (lr < 16 && kbest != 0ull) atomicMax(rbest + row_base + gf_acc_row(lr, h), kbest);
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const unsigned c = max(cbest[ni], (unsigned)__shfl_xor((int)cbest[ni], 32, 64));
-            if (h == 0 && c != 0u) atomicMax(cmax + col0 + ni * 32, c);
+            if (h == 0 && c != 0u) atomicMax(cmax + n0 + ni * 32 + lr, c);
         }
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(NT) void k1_conf(K1Args a) {
+template <typename T, bool DENSE>
+__global__ __launch_bounds__(NT, 4) void k1_conf(K1Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = blockIdx.y;
     int bm, bn;
     k1_tile(a, bm, bn);
-    v16f acc[2][2];
+    v16f acc[2];
     sim_tile<T>((const T*)a.f0 + (size_t)n * a.L * a.C, (const T*)a.f1 + (size_t)n * a.S * a.C, a.L, a.S, a.C,
                 bm * BM, bn * BN, smem, acc);
-    const bool interior = k1_interior(a, bm * BM, bn * BN);
-    if (a.dense) {
-        if (interior) k1_conf_epilogue<T, false, true>(a, acc, smem, n, bm, bn);
-        else k1_conf_epilogue<T, true, true>(a, acc, smem, n, bm, bn);
-    } else {
-        if (interior) k1_conf_epilogue<T, false, false>(a, acc, smem, n, bm, bn);
-        else k1_conf_epilogue<T, true, false>(a, acc, smem, n, bm, bn);
-    }
+    if (k1_interior(a, bm * BM, bn * BN)) k1_conf_epilogue<T, false, DENSE>(a, acc, smem, n, bm, bn);
+    else k1_conf_epilogue<T, true, DENSE>(a, acc, smem, n, bm, bn);
 }
 
 struct SelArgs {
@@ -594,12 +598,13 @@ int k1_launch(K1Args a, SelArgs s, void* zero_begin, size_t zero_bytes, hipStrea
     const dim3 grid(a.tilesN * a.tilesM, a.N);
     (void)hipMemsetAsync(zero_begin, 0, zero_bytes, st);   // rowbest, colmax, samplecnt (contiguous)
     void* p0 = gf_prof_begin("k1_stats", st);
-    k1_stats<T><<<grid, NT, 2 * STAGE_BYTES, st>>>(a);
+    k1_stats<T><<<grid, NT, STAGE_BYTES, st>>>(a);
     gf_prof_end("k1_stats", p0, st);
     const int mx = a.L > a.S ? a.L : a.S;
     k1_reduce_stats<EXACT><<<dim3((mx + 31) / 32, 2, a.N), 256, 0, st>>>(a);
     void* p1 = gf_prof_begin("k1_conf", st);
-    k1_conf<T><<<grid, NT, 2 * STAGE_BYTES, st>>>(a);
+    if (a.dense) k1_conf<T, true><<<grid, NT, STAGE_BYTES, st>>>(a);
+    else k1_conf<T, false><<<grid, NT, STAGE_BYTES, st>>>(a);
     gf_prof_end("k1_conf", p1, st);
     k1_colset<<<dim3((a.S + 255) / 256, a.N), 256, 0, st>>>(s);
     k1_select<<<dim3((a.L + 255) / 256, a.N), 256, 0, st>>>(s);
