@@ -220,12 +220,29 @@ def main():
     Ms = [results[i][0] for i in range(args.warmup, args.warmup + args.steps)]
     Mfs = [results[i][1] for i in range(args.warmup, args.warmup + args.steps)]
     out = results[args.warmup + args.steps - 1][2]
+
+    def collect(tag):
+        ms, cnt, work = ctypes.c_double(0), ctypes.c_int(0), ctypes.c_double(0)
+        L.gf_profile_collect(tag, ctypes.byref(ms), ctypes.byref(cnt), ctypes.byref(work))
+        return ms.value, cnt.value, work.value
+    timed = {t: collect(t) for t in (b'k1_conf', b'k1_stats', b'k3_linear')}
+    # Per-kernel durations for the roofline: with several host pipelines the HIP-event span of a launch
+    # also covers kernels of the other streams that share the GPU, so the same steps are replayed on ONE
+    # stream right after the timed region (same inputs, same code, profiling events on) and those
+    # uncontended durations are reported; the in-region averages are kept next to them.
+    if nstreams > 1:
+        for i in range(min(2, args.steps)):
+            step(i)
+        torch.cuda.synchronize()
+        solo = {t: collect(t) for t in (b'k1_conf', b'k1_stats', b'k3_linear')}
+    else:
+        solo = timed
     L.gf_profile_enable(0)
-    tot, cnt = ctypes.c_double(0), ctypes.c_int(0)
-    L.gf_profile_collect(b'k1_conf', ctypes.byref(tot), ctypes.byref(cnt))
-    conf_ms = tot.value / max(cnt.value, 1)
-    tot2, cnt2 = ctypes.c_double(0), ctypes.c_int(0)
-    L.gf_profile_collect(b'k1_stats', ctypes.byref(tot2), ctypes.byref(cnt2))
+    conf_tot_ms, conf_cnt, conf_bytes = solo[b'k1_conf']
+    stats_tot_ms, stats_cnt, stats_flops = solo[b'k1_stats']
+    lin_tot_ms, lin_cnt, lin_flops = solo[b'k3_linear']
+    conf_ms = conf_tot_ms / max(conf_cnt, 1)
+    conf_ms_timed = timed[b'k1_conf'][0] / max(timed[b'k1_conf'][1], 1)
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -239,7 +256,10 @@ def main():
     Lc = (args.size // 8) ** 2
     e = 2 if args.precision == 'fp16' else 4
     algo_bytes = args.batch * (2 * Lc * 256 * e + Lc * Lc * 4)     # per k1_conf launch (170.4 MB/pair-call at e=2)
+    assert conf_cnt == 0 or abs(conf_bytes / conf_cnt - algo_bytes) < 1.0
     achieved = algo_bytes / (conf_ms * 1e-3) / 1e9 if conf_ms > 0 else 0.0
+    mfma_peak = 2500.0 if args.precision == 'fp16' else 157.3      # TFLOP/s dense (MI355X_MICROARCH.md)
+    lin_tflops = lin_flops / (lin_tot_ms * 1e-3) / 1e12 if lin_tot_ms > 0 else 0.0
     traffic = None
     pmc = os.path.join(ROOT, 'profiles', 'k1_conf_pmc_r01.json')
     if os.path.exists(pmc):
@@ -263,9 +283,14 @@ def main():
                    'host_pipelines_per_gpu': nstreams},
         'roofline': {'kernel': 'k1_conf (dual-softmax correlation sweep, conf_matrix write)', 'bound': 'hbm',
                      'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
-                     'traffic': traffic, 'launches': cnt.value, 'avg_launch_ms': conf_ms,
+                     'traffic': traffic, 'launches': conf_cnt, 'avg_launch_ms': conf_ms,
                      'algorithmic_bytes_per_launch': algo_bytes,
-                     'k1_stats_avg_launch_ms': tot2.value / max(cnt2.value, 1)},
+                     'measured': 'HIP events on the launch stream; single-stream replay of the timed steps' if nstreams > 1 else 'HIP events on the launch stream over the timed region',
+                     'avg_launch_ms_in_timed_region': conf_ms_timed},
+        'roofline_mfma': {'kernel': 'k3 linear_kernel (encoder-layer GEMMs with fused epilogues, all launches)', 'bound': 'mfma',
+                          'achieved': lin_tflops, 'peak': mfma_peak, 'unit': 'TFLOP/s', 'frac': lin_tflops / mfma_peak,
+                          'launches': lin_cnt, 'total_ms': lin_tot_ms, 'algorithmic_flops': lin_flops,
+                          'k1_stats_tflops': stats_flops / (stats_tot_ms * 1e-3) / 1e12 if stats_tot_ms > 0 else 0.0},
     }
     if not args.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline(W, args.coarse_thr, args.fine_thr, args.size)

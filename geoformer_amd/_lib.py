@@ -21,7 +21,8 @@ SIGNATURES = {
     'gf_abi_version': (c_int, []),
     'gf_last_error': (ctypes.c_char_p, []),
     'gf_profile_enable': (None, [c_int]),
-    'gf_profile_collect': (c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
+    'gf_profile_collect': (c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int),
+                                   ctypes.POINTER(ctypes.c_double)]),
     'gf_dual_softmax_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'gf_dual_softmax_match': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                       c_float, c_float, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
@@ -38,7 +39,7 @@ SIGNATURES = {
                           c_int, c_void_p]),
     'gf_ransac_workspace_bytes': (c_size_t, [c_int, c_int]),
     'gf_ransac_homography': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_float,
-                                     c_int, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_int, c_uint32, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_size_t, c_void_p]),
     'gf_window_geometry': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

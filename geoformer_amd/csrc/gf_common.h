@@ -36,7 +36,7 @@ void gf_set_error(const char* fmt, ...);
     } while (0)
 
 // optional event timing of single kernels (gf_runtime.hip); no-ops unless gf_profile_enable(1)
-void* gf_prof_begin(const char* tag, hipStream_t st);
+void* gf_prof_begin(const char* tag, hipStream_t st, double work = 0.0);
 void gf_prof_end(const char* tag, void* token, hipStream_t st);
 
 static inline size_t gf_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

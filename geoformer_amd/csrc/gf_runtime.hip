@@ -25,7 +25,7 @@ extern "C" const char* gf_last_error(void) { return g_err; }
 #include <vector>
 
 namespace {
-struct ProfSpan { hipEvent_t a, b; };
+struct ProfSpan { hipEvent_t a, b; double work; };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
 std::map<std::string, std::vector<ProfSpan>> g_prof;
@@ -33,9 +33,10 @@ std::map<std::string, std::vector<ProfSpan>> g_prof;
 
 bool gf_prof_enabled() { return g_prof_on; }
 
-void* gf_prof_begin(const char* tag, hipStream_t st) {
+void* gf_prof_begin(const char* tag, hipStream_t st, double work) {
     if (!g_prof_on) return nullptr;
     ProfSpan sp;
+    sp.work = work;
     if (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess) return nullptr;
     (void)hipEventRecord(sp.a, st);
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -56,22 +57,25 @@ extern "C" void gf_profile_enable(int on) {
     g_prof_on = on != 0;
 }
 
-// Synchronises on the recorded events, returns the summed milliseconds and the span count of `tag`,
-// and clears it.  Returns 0 on success, GF_ERR_INVALID_ARGUMENT when the tag has no spans.
-extern "C" int gf_profile_collect(const char* tag, double* total_ms, int* count) {
+// Synchronises on the recorded events, returns the summed milliseconds, the span count and the summed
+// work units (bytes or flops declared by the launch site) of `tag`, and clears it.
+// Returns 0 on success, GF_ERR_INVALID_ARGUMENT when the tag has no spans.
+extern "C" int gf_profile_collect(const char* tag, double* total_ms, int* count, double* work) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     auto it = g_prof.find(tag);
     if (it == g_prof.end() || it->second.empty()) {
         if (total_ms) *total_ms = 0.0;
         if (count) *count = 0;
+        if (work) *work = 0.0;
         return GF_ERR_INVALID_ARGUMENT;
     }
-    double tot = 0.0;
+    double tot = 0.0, wk = 0.0;
     int n = 0;
     for (auto& sp : it->second) {
         float ms = 0.f;
         if (hipEventSynchronize(sp.b) == hipSuccess && hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
             tot += ms;
+            wk += sp.work;
             ++n;
         }
         (void)hipEventDestroy(sp.a);
@@ -80,5 +84,6 @@ extern "C" int gf_profile_collect(const char* tag, double* total_ms, int* count)
     it->second.clear();
     if (total_ms) *total_ms = tot;
     if (count) *count = n;
+    if (work) *work = wk;
     return GF_OK;
 }

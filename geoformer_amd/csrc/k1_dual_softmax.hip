@@ -597,12 +597,12 @@ int k1_launch(K1Args a, SelArgs s, void* zero_begin, size_t zero_bytes, hipStrea
     constexpr bool EXACT = std::is_same<T, float>::value;
     const dim3 grid(a.tilesN * a.tilesM, a.N);
     (void)hipMemsetAsync(zero_begin, 0, zero_bytes, st);   // rowbest, colmax, samplecnt (contiguous)
-    void* p0 = gf_prof_begin("k1_stats", st);
+    void* p0 = gf_prof_begin("k1_stats", st, 2.0 * a.N * (double)a.L * a.S * a.C);
     k1_stats<T><<<grid, NT, STAGE_BYTES, st>>>(a);
     gf_prof_end("k1_stats", p0, st);
     const int mx = a.L > a.S ? a.L : a.S;
     k1_reduce_stats<EXACT><<<dim3((mx + 31) / 32, 2, a.N), 256, 0, st>>>(a);
-    void* p1 = gf_prof_begin("k1_conf", st);
+    void* p1 = gf_prof_begin("k1_conf", st, (double)a.N * ((double)(a.L + a.S) * a.C * sizeof(T) + (double)a.L * a.S * 4.0));
     if (a.dense) k1_conf<T, true><<<grid, NT, STAGE_BYTES, st>>>(a);
     else k1_conf<T, false><<<grid, NT, STAGE_BYTES, st>>>(a);
     gf_prof_end("k1_conf", p1, st);

@@ -257,6 +257,7 @@ extern "C" int gf_linear(const void* a1, long lda1, int k1, const void* a2, long
     LinArgs a{a1, a2, lda1, lda2, k1, k2, w, bias, rowgroup_bias, rowgroup_rows, ln_gamma, ln_beta, ln_eps, residual,
               ldres, row_flag, flag_rows, out, ldo, M, N};
     hipStream_t st = (hipStream_t)stream;
+    void* pt = gf_prof_begin("k3_linear", st, 2.0 * (double)M * N * (k1 + k2));
     const bool wide = (epilogue >= EPI_LN) ? N == 256 : N % 256 == 0;
     if (dtype == GF_F32) {
         if (wide) lin_launch<float, 8>(a, epilogue, st);
@@ -265,6 +266,7 @@ extern "C" int gf_linear(const void* a1, long lda1, int k1, const void* a2, long
         if (wide) lin_launch<_Float16, 8>(a, epilogue, st);
         else lin_launch<_Float16, 4>(a, epilogue, st);
     }
+    gf_prof_end("k3_linear", pt, st);
     GF_CHECK_LAUNCH();
     return GF_OK;
 }

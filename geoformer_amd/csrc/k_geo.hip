@@ -73,8 +73,8 @@ __global__ void window_geometry(WgArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 struct ImArgs {
-    const int32_t* kp0;      // [cap][2] integer keypoints (from gf_ransac_homography)
-    const int32_t* kp1;
+    const float* kp0;        // [cap][2] integer-valued keypoints (from gf_ransac_homography)
+    const float* kp1;
     const uint8_t* keep;     // [cap]
     const int32_t* counts;   // [1+N]
     int N, L, S, w0, w1, scale;
@@ -92,8 +92,8 @@ __global__ void inlier_scatter(ImArgs a) {
     const int cnt = a.counts[1 + n];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
         if (!a.keep[off + i]) continue;
-        const int x0 = a.kp0[2 * (off + i)], y0 = a.kp0[2 * (off + i) + 1];
-        const int x1 = a.kp1[2 * (off + i)], y1 = a.kp1[2 * (off + i) + 1];
+        const int x0 = (int)a.kp0[2 * (off + i)], y0 = (int)a.kp0[2 * (off + i) + 1];
+        const int x1 = (int)a.kp1[2 * (off + i)], y1 = (int)a.kp1[2 * (off + i) + 1];
         const int c0 = (y0 / a.scale) * a.w0 + x0 / a.scale, c1 = (y1 / a.scale) * a.w1 + x1 / a.scale;
         if (c0 >= 0 && c0 < a.L) a.map0[(size_t)n * a.L + c0] = 1;
         if (c1 >= 0 && c1 < a.S) a.map1[(size_t)n * a.S + c1] = 1;
@@ -244,7 +244,7 @@ extern "C" int gf_window_geometry(const float* H, const int32_t* valid, int N, i
     return GF_OK;
 }
 
-extern "C" int gf_inlier_index(const int32_t* kp0, const int32_t* kp1, const uint8_t* keep, const int32_t* counts,
+extern "C" int gf_inlier_index(const float* kp0, const float* kp1, const uint8_t* keep, const int32_t* counts,
                                int N, int L, int S, int w0, int w1, int scale, uint8_t* map0, uint8_t* map1,
                                int32_t* idx0, int32_t* idx1, int32_t* nidx, void* stream) {
     GF_CHECK_ARG(kp0 && kp1 && keep && counts && map0 && map1 && idx0 && idx1 && nidx, "null pointer");

@@ -26,8 +26,10 @@ struct RsArgs {
     const float* scale1;
     double thr2;
     uint32_t seed;
-    int32_t* kp0;            // [cap][2] integer keypoints (geo_module.py:110-111, 38-43)
-    int32_t* kp1;
+    float* kp0;              // [cap][2] keypoints fed to RANSAC: integer-valued (geo_module.py:110-111, 38-43) or raw
+    float* kp1;
+    int min_points;          // a sample with fewer matches gets no model (GeoModule: 9, i.e. len > 8, geo_module.py:46)
+    int integer_kp;          // 1: the reference's .long() keypoints (GeoModule); 0: sub-pixel keypoints as given (eval)
     double* hyp;             // [N][iters][9]
     int32_t* hyp_cnt;        // [N][iters]  (-1 = invalid hypothesis)
     double* M;               // [N][9]
@@ -104,13 +106,18 @@ __global__ void ransac_keypoints(RsArgs a) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
+            if (!a.integer_kp) {
+                a.kp0[2 * (off + i) + c] = a.mk0[2 * (off + i) + c];
+                a.kp1[2 * (off + i) + c] = a.mk1[2 * (off + i) + c];
+                continue;
+            }
             long k0 = (long)a.mk0[2 * (off + i) + c], k1 = (long)a.mk1[2 * (off + i) + c];
             if (a.scale0) {
                 k0 = (long)((float)k0 / (a.scale * a.scale0[2 * n + c]) * a.scale);
                 k1 = (long)((float)k1 / (a.scale * a.scale1[2 * n + c]) * a.scale);
             }
-            a.kp0[2 * (off + i) + c] = (int32_t)k0;
-            a.kp1[2 * (off + i) + c] = (int32_t)k1;
+            a.kp0[2 * (off + i) + c] = (float)k0;
+            a.kp1[2 * (off + i) + c] = (float)k1;
         }
     }
 }
@@ -122,9 +129,9 @@ __global__ __launch_bounds__(256) void ransac_score(RsArgs a) {
     const int t = blockIdx.x * 4 + wave;
     int off, cnt;
     rs_range(a, n, off, cnt);
-    if (cnt <= 8 || t >= a.iters) return;          // geo_module.py:46 (uniform per block / wave)
-    const int32_t* k0 = a.kp0 + 2 * (size_t)off;
-    const int32_t* k1 = a.kp1 + 2 * (size_t)off;
+    if (cnt < a.min_points || t >= a.iters) return;  // geo_module.py:46 (uniform per block / wave)
+    const float* k0 = a.kp0 + 2 * (size_t)off;
+    const float* k1 = a.kp1 + 2 * (size_t)off;
     if (lane == 0) {
         int idx[4], ok = 1;
         for (int k = 0; k < 4 && ok; ++k) {
@@ -203,11 +210,11 @@ __global__ __launch_bounds__(256) void ransac_final(RsArgs a) {
     int off, cnt;
     rs_range(a, n, off, cnt);
     uint8_t* keep = a.keep + off;
-    const int32_t* k0 = a.kp0 + 2 * (size_t)off;
-    const int32_t* k1 = a.kp1 + 2 * (size_t)off;
+    const float* k0 = a.kp0 + 2 * (size_t)off;
+    const float* k1 = a.kp1 + 2 * (size_t)off;
     // ---- best hypothesis: max count, ties -> smallest t  (key = count * 2^32 + (2^31 - t))
     long long key = -1;
-    if (cnt > 8)
+    if (cnt >= a.min_points)
         for (int i = t; i < a.iters; i += 256) {
             const int c = a.hyp_cnt[(size_t)n * a.iters + i];
             if (c >= 0) {
@@ -329,7 +336,8 @@ extern "C" size_t gf_ransac_workspace_bytes(int N, int iters) {
 
 extern "C" int gf_ransac_homography(const float* mkpts0_c, const float* mkpts1_c, const int32_t* counts, int N,
                                     int capacity, float scale, const float* scale0, const float* scale1,
-                                    float thr, int iters, uint32_t seed, int32_t* kp0, int32_t* kp1, double* M,
+                                    float thr, int iters, uint32_t seed, int min_points, int integer_keypoints, float* kp0,
+                                    float* kp1, double* M,
                                     float* M_f32, float* Minv_f32, int32_t* valid, uint8_t* keep, void* workspace,
                                     size_t workspace_bytes, void* stream) {
     GF_CHECK_ARG(mkpts0_c && mkpts1_c && counts && kp0 && kp1 && M && M_f32 && Minv_f32 && valid && keep, "null pointer");
@@ -342,7 +350,7 @@ extern "C" int gf_ransac_homography(const float* mkpts0_c, const float* mkpts1_c
     RsArgs a;
     a.mk0 = mkpts0_c; a.mk1 = mkpts1_c; a.counts = counts; a.N = N; a.iters = iters; a.scale = scale;
     a.scale0 = scale0; a.scale1 = scale1; a.thr2 = (double)thr * (double)thr; a.seed = seed;
-    a.kp0 = kp0; a.kp1 = kp1;
+    a.kp0 = kp0; a.kp1 = kp1; a.integer_kp = integer_keypoints; a.min_points = min_points < 4 ? 4 : min_points;
     a.hyp = (double*)workspace;
     a.hyp_cnt = (int32_t*)((char*)workspace + gf_align_up((size_t)N * iters * 9 * sizeof(double), 256));
     a.M = M; a.Mf = M_f32; a.Minv = Minv_f32; a.valid = valid; a.keep = keep;

@@ -1,0 +1,185 @@
+"""Caller-side counterpart of the reference's inference / evaluation wrappers:
+
+  * `resize_im`, `load_gray_scale_tensor`   eval_tool/immatch/utils/data_io.py:16-26, :48-62
+  * `GeoFormerMatcher`                      inference.py:12-99 and eval_tool/immatch/modules/geoformer.py:12-99
+                                            (same constructor arguments, `match_pairs` return convention)
+  * `cal_error_auc`, `cal_reproj_dists`, `eval_hpatches`
+                                            eval_tool/immatch/utils/hpatches_helper.py:13-34, :94-317
+
+OpenCV and torchvision are not available offline: images are read with PIL and resized on the device
+with bilinear interpolation (half-pixel centres, no antialiasing - the convention of cv2.resize's default
+INTER_LINEAR); the homography of the HPatches metric is estimated from the fine matches by the device
+RANSAC (`ops.ransac_homography(..., thr=ransac_thres, integer_keypoints=False, min_points=4)`).
+"""
+import glob
+import os
+import time
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .model.cvpr_ds_config import get_default_cfg
+from .model.full_model import GeoFormer
+from .model.geo_config import get_cfg_model
+
+
+def resize_im(wo, ho, imsize=None, dfactor=1, value_to_scale=max, aspan=False):
+    """Target size: scale so that value_to_scale(w, h) == imsize when it exceeds it (or always with
+    aspan), then floor both sides to multiples of dfactor.  Returns (wt, ht, (wo/wt, ho/ht))."""
+    wt, ht = wo, ho
+    if imsize and imsize > 0 and (aspan or value_to_scale(wo, ho) > imsize):
+        s = imsize / value_to_scale(wo, ho)
+        ht, wt = int(round(ho * s)), int(round(wo * s))
+    wt, ht = int(wt // dfactor * dfactor), int(ht // dfactor * dfactor)
+    return wt, ht, (wo / wt, ho / ht)
+
+
+def load_gray_scale_tensor(im_path, device, imsize=None, dfactor=8, value_to_scale=min, aspan=False):
+    """[1,1,H,W] float in [0,1] + (wo/wt, ho/ht); H, W multiples of dfactor."""
+    from PIL import Image
+    im = np.asarray(Image.open(im_path).convert('L'), dtype=np.uint8)
+    ho, wo = im.shape
+    wt, ht, scale = resize_im(wo, ho, imsize=imsize, dfactor=dfactor, value_to_scale=value_to_scale, aspan=aspan)
+    t = torch.from_numpy(im).to(device=device, dtype=torch.float32)[None, None]
+    if (ht, wt) != (ho, wo):
+        t = F.interpolate(t, size=(ht, wt), mode='bilinear', align_corners=False)
+        t = t.round().clamp_(0, 255)          # cv2.resize returns uint8
+    return t / 255.0, scale
+
+
+class GeoFormerMatcher:
+    def __init__(self, imsize, match_threshold, no_match_upscale=False, ckpt=None, device='cuda', precision='fp32'):
+        self.device, self.imsize = device, imsize
+        self.match_threshold, self.no_match_upscale = match_threshold, no_match_upscale
+        conf = get_default_cfg()
+        conf['match_coarse']['thr'] = match_threshold
+        gcfg = get_cfg_model()
+        gcfg['coarse_thr'] = match_threshold
+        gcfg['precision'] = precision
+        self.model = GeoFormer(conf, gcfg)
+        self.ckpt_name = 'random'
+        if ckpt is not None:
+            sd = torch.load(ckpt, map_location='cpu')
+            sd = sd.get('state_dict', sd)
+            self.model.load_state_dict(sd, strict=False)
+            self.ckpt_name = os.path.splitext(os.path.basename(ckpt))[0]
+        self.model = self.model.eval().to(device)
+        self.name = f'GeoFormer_{self.ckpt_name}' + ('_noms' if no_match_upscale else '')
+
+    def load_im(self, im_path):
+        return load_gray_scale_tensor(im_path, self.device, imsize=self.imsize, dfactor=8, value_to_scale=min)
+
+    def match_inputs_(self, gray1, gray2):
+        with torch.no_grad():
+            batch = self.model({'image0': gray1, 'image1': gray2})
+        kpts1, kpts2 = batch['mkpts0_f'].cpu().numpy(), batch['mkpts1_f'].cpu().numpy()
+        scores = batch['mconf'].cpu().numpy()
+        return np.concatenate([kpts1, kpts2], axis=1), kpts1, kpts2, scores
+
+    def match_pairs(self, im1_path, im2_path):
+        gray1, sc1 = self.load_im(im1_path)
+        gray2, sc2 = self.load_im(im2_path)
+        upscale = np.array([sc1 + sc2])
+        matches, kpts1, kpts2, scores = self.match_inputs_(gray1, gray2)
+        if self.no_match_upscale:
+            return matches, kpts1, kpts2, scores, upscale.squeeze(0)
+        return upscale * matches, sc1 * kpts1, sc2 * kpts2, scores
+
+    __call__ = match_pairs
+
+
+# ---------------------------------------------------------------------------------------------
+# HPatches homography metric
+# ---------------------------------------------------------------------------------------------
+def cal_error_auc(errors, thresholds):
+    """Area under the recall-vs-error curve up to each threshold, normalised by the threshold."""
+    errors = np.asarray(errors, dtype=float)
+    if errors.size == 0:
+        return np.zeros(len(thresholds))
+    n = errors.size
+    err = np.concatenate([[0.0], np.sort(errors)])
+    rec = np.arange(n + 1) / n
+    out = []
+    for t in thresholds:
+        k = np.searchsorted(err, t)
+        x = np.concatenate([err[:k], [t]])
+        y = np.concatenate([rec[:k], [rec[k - 1]]])
+        out.append(float(np.sum((y[1:] + y[:-1]) * 0.5 * np.diff(x))) / t)      # trapezoid rule
+    return np.array(out, dtype=float)
+
+
+def cal_reproj_dists(p1s, p2s, homography):
+    p = np.concatenate([p1s, np.ones((len(p1s), 1))], axis=1) @ np.asarray(homography).T
+    return np.sqrt(((p2s - p[:, :2] / p[:, 2:]) ** 2).sum(1))
+
+
+def scale_homography(sw, sh):
+    return np.array([[sw, 0, 0], [0, sh, 0], [0, 0, 1.0]])
+
+
+def estimate_homography(matches, thr, device='cuda'):
+    """RANSAC homography from [n,4] matches on the device; returns (H | None, inlier mask)."""
+    if len(matches) < 4:
+        return None, np.zeros(len(matches), bool)
+    m = torch.as_tensor(matches, dtype=torch.float32, device=device)
+    counts = torch.tensor([len(m), len(m)], dtype=torch.int32, device=device)
+    rs = ops.ransac_homography(m[:, :2].contiguous(), m[:, 2:4].contiguous(), counts, 1, 1.0, thr=thr,
+                               integer_keypoints=False, min_points=4)
+    if int(rs['valid'][0]) == 0:
+        return None, np.zeros(len(matches), bool)
+    return rs['M'][0].cpu().numpy(), rs['keep'][:len(m)].cpu().numpy().astype(bool)
+
+
+def corner_error(H_pred, H_gt, w, h):
+    corners = np.array([[0, 0, 1], [0, h - 1, 1], [w - 1, 0, 1], [w - 1, h - 1, 1.0]])
+    a = corners @ np.asarray(H_gt).T
+    b = corners @ np.asarray(H_pred).T
+    return float(np.mean(np.linalg.norm(a[:, :2] / a[:, 2:] - b[:, :2] / b[:, 2:], axis=1)))
+
+
+def eval_hpatches(matcher, data_root, ransac_thres=3, thres=(1, 3, 5, 10), scale_H=True, max_seqs: Optional[int] = None,
+                  log=print):
+    """Homography-estimation AUC over HPatches sequences (pairs 1 -> 2..6), the protocol of
+    hpatches_helper.eval_hpatches with task='homography', h_solver='cv'."""
+    from PIL import Image
+    seqs = sorted(glob.glob(os.path.join(data_root, '*')))[::-1]
+    if max_seqs:
+        seqs = seqs[:max_seqs]
+    dists = {'a': [], 'i': [], 'v': []}
+    n_matches, times, failed = [], [], 0
+    for seq in seqs:
+        sname = os.path.basename(seq)
+        im1 = os.path.join(seq, '1.ppm')
+        for k in range(2, 7):
+            im2 = os.path.join(seq, f'{k}.ppm')
+            H_gt = np.loadtxt(os.path.join(seq, f'H_1_{k}'))
+            scale = np.ones(4)
+            t0 = time.time()
+            res = matcher(im1, im2)
+            times.append(time.time() - t0)
+            matches = res[0]
+            if scale_H and len(res) > 4:
+                scale = res[4]
+                H_gt = np.linalg.inv(scale_homography(scale[2], scale[3])) @ H_gt @ scale_homography(scale[0], scale[1])
+            n_matches.append(len(matches))
+            H_pred, _ = estimate_homography(matches, ransac_thres, matcher.device)
+            if H_pred is None:
+                d, failed = np.nan, failed + 1
+            else:
+                w, h = Image.open(im1).size
+                d = corner_error(H_pred, H_gt, w / scale[0], h / scale[1])
+            dists['a'].append(d)
+            dists[sname[0] if sname[0] in 'iv' else 'v'].append(d)
+    out = {}
+    for key, ds in dists.items():
+        ds = np.asarray(ds, dtype=float)
+        out['correct_' + key] = np.mean([[float(d <= t) for t in thres] for d in ds], axis=0) if len(ds) else np.zeros(len(thres))
+        out['auc_' + key] = cal_error_auc(ds, thres)
+    out.update(failed=failed, mean_matches=float(np.mean(n_matches)) if n_matches else 0.0,
+               match_time=float(np.mean(times)) if times else 0.0)
+    log(f"Hest Correct: a={out['correct_a']} i={out['correct_i']} v={out['correct_v']}")
+    log(f"Hest AUC: a={out['auc_a']} i={out['auc_i']} v={out['auc_v']}")
+    return out

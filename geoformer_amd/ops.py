@@ -138,13 +138,13 @@ RANSAC_SEED = 0x5EED
 
 
 def ransac_homography(mkpts0_c, mkpts1_c, counts, N, scale, scale0=None, scale1=None, thr=8.0, iters=RANSAC_ITERS,
-                      seed=RANSAC_SEED):
-    """Device RANSAC on the first-pass coarse matches.  Returns dict(kp0, kp1 int32 [cap,2], M fp64 [N,3,3],
+                      seed=RANSAC_SEED, integer_keypoints=True, min_points=9):
+    """Device RANSAC on the first-pass coarse matches.  Returns dict(kp0, kp1 fp32 [cap,2], M fp64 [N,3,3],
     M_f32, Minv_f32 [N,3,3], valid int32 [N], keep uint8 [cap])."""
     _need_cuda(mkpts0_c, mkpts1_c, counts)
     dev = mkpts0_c.device
     cap = mkpts0_c.shape[0]
-    kp = torch.empty(2, max(cap, 1), 2, dtype=torch.int32, device=dev)
+    kp = torch.empty(2, max(cap, 1), 2, dtype=torch.float32, device=dev)
     M = torch.empty(N, 3, 3, dtype=torch.float64, device=dev)
     Mf = torch.empty(2, N, 3, 3, dtype=torch.float32, device=dev)
     valid = torch.empty(N, dtype=torch.int32, device=dev)
@@ -155,7 +155,7 @@ def ransac_homography(mkpts0_c, mkpts1_c, counts, N, scale, scale0=None, scale1=
     nbytes = L_.gf_ransac_workspace_bytes(N, iters)
     ws = _ws.get('ransac', nbytes, dev)
     check(L_.gf_ransac_homography(_p(mkpts0_c), _p(mkpts1_c), _p(counts), N, max(cap, 1), float(scale), _p(s0), _p(s1),
-                                  float(thr), int(iters), int(seed), _p(kp[0]), _p(kp[1]), _p(M), _p(Mf[0]), _p(Mf[1]),
+                                  float(thr), int(iters), int(seed), int(min_points), int(bool(integer_keypoints)), _p(kp[0]), _p(kp[1]), _p(M), _p(Mf[0]), _p(Mf[1]),
                                   _p(valid), _p(keep), _p(ws), ws.numel(), _stream()), 'gf_ransac_homography')
     return {'kp0': kp[0], 'kp1': kp[1], 'M': M, 'M_f32': Mf[0], 'Minv_f32': Mf[1], 'valid': valid, 'keep': keep}
 

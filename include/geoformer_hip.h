@@ -34,9 +34,10 @@ int gf_abi_version(void);
 const char* gf_last_error(void);
 
 /* Optional per-kernel timing with HIP events on the launch stream (used by bench.py's `roofline`).
- * Tags: "k1_stats", "k1_conf".  gf_profile_collect synchronises on the recorded events. */
+ * Tags: "k1_stats" (work = flops), "k1_conf" (work = algorithmic bytes), "k3_linear" (work = flops).
+ * gf_profile_collect synchronises on the recorded events and returns their summed time, count and work. */
 void gf_profile_enable(int on);
-int gf_profile_collect(const char* tag, double* total_ms, int* count);
+int gf_profile_collect(const char* tag, double* total_ms, int* count, double* work);
 
 /* ------------------------------------------------------------------------------------------
  * K1  dual-softmax correlation + mutual-nearest match extraction
@@ -111,15 +112,19 @@ int gf_linear(const void* a1, long lda1, int k1, const void* a2, long lda2, int 
  * filtering of GeoModule.apply_RANSAC (model/geo_module.py:38-52).  OpenCV parity is unpinned;
  * the algorithm is the one stated in oracle/ransac_oracle.c (bit-exact inlier mask).
  *   mkpts0_c/mkpts1_c [cap,2] fp32 and counts int32[1+N] as written by gf_dual_softmax_match;
- *   outputs: kp0/kp1 int32 [cap,2] (the .long() keypoints), M fp64 [N,9], M_f32 / Minv_f32 [N,9]
+ *   min_points: samples with fewer matches get no model (GeoModule passes 9: `len(kp0) > 8`, :46);
+ *   integer_keypoints = 1: keypoints are truncated like the reference's .long() (GeoModule);
+ *   0: sub-pixel keypoints are used as given (homography estimation from fine matches in the
+ *   evaluation harness, eval_tool/immatch/utils/hpatches_helper.py:216);
+ *   outputs: kp0/kp1 fp32 [cap,2] (the keypoints RANSAC saw), M fp64 [N,9], M_f32 / Minv_f32 [N,9]
  *   (the casts of :58 and :67), valid int32 [N] (0 = "M is None"), keep uint8 [cap] (inlier, or 1
  *   for every match of a sample without model: what feeds the occupancy maps of :82-94).
  * ------------------------------------------------------------------------------------------ */
 size_t gf_ransac_workspace_bytes(int N, int iters);
 int gf_ransac_homography(const float* mkpts0_c, const float* mkpts1_c, const int32_t* counts, int N,
                          int capacity, float scale, const float* scale0, const float* scale1, float thr,
-                         int iters, uint32_t seed, int32_t* kp0, int32_t* kp1, double* M, float* M_f32,
-                         float* Minv_f32, int32_t* valid, uint8_t* keep, void* workspace,
+                         int iters, uint32_t seed, int min_points, int integer_keypoints, float* kp0, float* kp1, double* M,
+                         float* M_f32, float* Minv_f32, int32_t* valid, uint8_t* keep, void* workspace,
                          size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -144,7 +149,7 @@ int gf_window_geometry(const float* H, const int32_t* valid, int N, int hq, int 
  *   map0 uint8 [N,L], map1 uint8 [N,S]; idx0 int32 [N,L], idx1 int32 [N,S] ascending cell lists;
  *   nidx int32 [N,2] their lengths.
  * ------------------------------------------------------------------------------------------ */
-int gf_inlier_index(const int32_t* kp0, const int32_t* kp1, const uint8_t* keep, const int32_t* counts, int N,
+int gf_inlier_index(const float* kp0, const float* kp1, const uint8_t* keep, const int32_t* counts, int N,
                     int L, int S, int w0, int w1, int scale, uint8_t* map0, uint8_t* map1, int32_t* idx0,
                     int32_t* idx1, int32_t* nidx, void* stream);
 

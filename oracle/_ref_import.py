@@ -84,6 +84,7 @@ def install_stubs():
     _mod("torchvision")
     _mod("torchvision.transforms")
     _mod("cv2", RANSAC=8, findHomography=_find_homography)
+    _mod("pydegensac")
     sys.modules["kornia"].geometry = sys.modules["kornia.geometry"]
     sys.modules["kornia"].utils = sys.modules["kornia.utils"]
     sys.modules["kornia.geometry"].subpix = sys.modules["kornia.geometry.subpix"]
@@ -113,4 +114,16 @@ def import_reference():
     ns.fine_matching2 = importlib.import_module("model.fine_matching2")
     ns.common_utils = importlib.import_module("utils.common_utils")
     ns.homography = importlib.import_module("utils.homography")
+    return ns
+
+
+def import_eval_helpers():
+    """The pure-numpy/python helpers of the evaluation harness (build container only)."""
+    import importlib
+    install_stubs()
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    ns = types.SimpleNamespace()
+    ns.hpatches_helper = importlib.import_module("eval_tool.immatch.utils.hpatches_helper")
+    ns.data_io = importlib.import_module("eval_tool.immatch.utils.data_io")
     return ns

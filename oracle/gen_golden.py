@@ -317,5 +317,30 @@ def main():
          ransac0_mask=np.packbits(r['ransac0_mask'][:, 0]), ransac0_n=np.array(len(r['ransac0_mask'])))
 
 
+def eval_helpers():
+    """G12: the pure-python helpers of the evaluation harness (cal_error_auc, cal_reproj_dists, resize_im)."""
+    ev = R.import_eval_helpers()
+    rng = np.random.default_rng(121)
+    errs = np.abs(rng.normal(0, 4, 57)); errs[5] = np.nan; errs[11] = 250.0
+    thr = [1, 3, 5, 10]
+    sizes = [(1024, 768), (640, 480), (800, 533), (479, 641), (2000, 1500), (333, 500)]
+    arrs = {'errors': errs, 'thresholds': np.array(thr), 'auc': ev.hpatches_helper.cal_error_auc(errs, thr),
+            'auc_empty': ev.hpatches_helper.cal_error_auc([], thr), 'sizes': np.array(sizes)}
+    Hm = np.array([[1.1, 0.05, -12.0], [-0.03, 0.95, 7.5], [2e-4, -1e-4, 1.0]])
+    p1 = rng.uniform(0, 600, (40, 2)); p2 = rng.uniform(0, 600, (40, 2))
+    arrs.update(H=Hm, p1=p1, p2=p2, reproj=ev.hpatches_helper.cal_reproj_dists(p1, p2, Hm))
+    rs = []
+    for (w, h) in sizes:
+        for imsize, df, f in ((480, 8, min), (640, 8, min), (-1, 8, min), (1024, 16, max)):
+            wt, ht, sc = ev.data_io.resize_im(w, h, imsize=imsize, dfactor=df, value_to_scale=f)
+            rs.append([w, h, imsize, df, 0 if f is min else 1, wt, ht, sc[0], sc[1]])
+    arrs['resize'] = np.array(rs, dtype=np.float64)
+    save('g12_eval_helpers', **arrs)
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'eval':
+        eval_helpers()
+    else:
+        main()
+        eval_helpers()

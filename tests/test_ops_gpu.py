@@ -146,8 +146,8 @@ def test_inlier_index():
     rng = np.random.default_rng(0)
     N, h0, w0, h1, w1 = 3, 9, 12, 7, 10
     cnts = [40, 0, 17]
-    kp0 = np.concatenate([np.stack([rng.integers(0, w0, c) * 8, rng.integers(0, h0, c) * 8], 1) for c in cnts]).astype(np.int32)
-    kp1 = np.concatenate([np.stack([rng.integers(0, w1, c) * 8, rng.integers(0, h1, c) * 8], 1) for c in cnts]).astype(np.int32)
+    kp0 = np.concatenate([np.stack([rng.integers(0, w0, c) * 8, rng.integers(0, h0, c) * 8], 1) for c in cnts]).astype(np.float32)
+    kp1 = np.concatenate([np.stack([rng.integers(0, w1, c) * 8, rng.integers(0, h1, c) * 8], 1) for c in cnts]).astype(np.float32)
     keep = (rng.random(sum(cnts)) > 0.3).astype(np.uint8)
     counts = torch.tensor([sum(cnts)] + cnts, dtype=torch.int32)
     g = ops.inlier_index(torch.from_numpy(kp0).to(DEV), torch.from_numpy(kp1).to(DEV), torch.from_numpy(keep).to(DEV),
@@ -156,8 +156,9 @@ def test_inlier_index():
     for b, c in enumerate(cnts):
         m0 = np.zeros(h0 * w0, bool); m1 = np.zeros(h1 * w1, bool)
         sel = keep[off:off + c].astype(bool)
-        m0[(kp0[off:off + c][sel, 1] // 8) * w0 + kp0[off:off + c][sel, 0] // 8] = True
-        m1[(kp1[off:off + c][sel, 1] // 8) * w1 + kp1[off:off + c][sel, 0] // 8] = True
+        ka, kb = kp0[off:off + c][sel].astype(np.int64), kp1[off:off + c][sel].astype(np.int64)
+        m0[(ka[:, 1] // 8) * w0 + ka[:, 0] // 8] = True
+        m1[(kb[:, 1] // 8) * w1 + kb[:, 0] // 8] = True
         exact(g['map0'][b].bool(), m0); exact(g['map1'][b].bool(), m1)
         k0, k1 = int(g['nidx'][b, 0]), int(g['nidx'][b, 1])
         exact(g['idx0'][b, :k0], np.nonzero(m0)[0]); exact(g['idx1'][b, :k1], np.nonzero(m1)[0])

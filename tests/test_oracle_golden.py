@@ -217,3 +217,15 @@ def test_g11_end_to_end_640_digest(golden, W):
     exact(GI.digest(out['mkpts0_f'], out['mkpts1_f']), G['fine_kpts_digest'])
     close(out['mconf'][:64], G['mconf_head'], 1e-3, 1e-6)
     close(out['conf_matrix'][0, :64].sum(-1), G['conf_rowsum_head'], 1e-3, 1e-6)
+
+
+def test_g12_eval_helpers(golden):
+    """The product's evaluation helpers (pure numpy, run on CPU) against the reference's own."""
+    from geoformer_amd import matcher as MT
+    G = golden('g12_eval_helpers')
+    close(MT.cal_error_auc(G['errors'], list(G['thresholds'])), G['auc'], 1e-12, 1e-12)
+    close(MT.cal_error_auc([], list(G['thresholds'])), G['auc_empty'], 0, 0)
+    close(MT.cal_reproj_dists(G['p1'], G['p2'], G['H']), G['reproj'], 1e-12, 1e-12)
+    for w, h, imsize, df, f, wt, ht, sx, sy in G['resize']:
+        got = MT.resize_im(int(w), int(h), imsize=int(imsize), dfactor=int(df), value_to_scale=min if f == 0 else max)
+        assert got[0] == int(wt) and got[1] == int(ht) and got[2] == (sx, sy), (w, h, imsize, got)
