@@ -17,11 +17,27 @@
 // the activation, the residual and the predicate are then lane-local (one lane-pair exchange for the
 // mean/variance), with no cross-lane reduction tree.  One wave = 32 tokens x (32*NB) channels;
 // workgroup = 4 waves = 128 tokens; LN epilogues need NB*32 == N (whole rows in one wave pair).
+// fp16 kernels are held to 256 registers (two workgroups per CU; the unconstrained build took 330-380
+// and ran one) and transpose their result through LDS for row-contiguous 16-B stores.
 #include <math.h>
 
 #include <type_traits>
 
 #include "gf_common.h"
+
+// -DK3_TRACE=1 records clock64() at the phase boundaries of every workgroup (tools/k3_trace.py reads them).
+#ifndef K3_TRACE
+#define K3_TRACE 0
+#endif
+#if K3_TRACE
+__device__ long long k3_trace[1024 * 4 * 16];
+#define K3_T(slot) do { if (lane == 0 && blockIdx.y == 0 && blockIdx.x < 1024) k3_trace[(blockIdx.x * 4 + wave) * 16 + (slot)] = clock64(); } while (0)
+extern "C" int gf_debug_k3_trace(long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(k3_trace), sizeof(long long) * 1024 * 4 * 16);
+}
+#else
+#define K3_T(slot)
+#endif
 
 namespace {
 
@@ -49,7 +65,7 @@ struct LinArgs {
 };
 
 template <typename T, int NB, int EPI>
-__global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void linear_kernel(LinArgs a) {
     using Mm = Mma32<T>;
     using Frag = typename Mm::Frag;
     constexpr int EPC = 16 / sizeof(T);
@@ -113,11 +129,13 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
         for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
 
     const int nk = K / BK;
+    K3_T(0);
     gload(0);
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();                           // previous step's fragments are consumed
         lstore();
         __syncthreads();
+        K3_T(1 + kt);
         if (kt + 1 < nk) gload((kt + 1) * BK);     // in flight while the MFMAs run
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -130,6 +148,7 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
             }
         }
     }
+    K3_T(10);
     // ---------------- epilogue: lane = token, registers = channels n0 + nb*32 + acc_row(r, h)
     const int token = m0 + wave * 32 + lr;
     const bool live = token < a.M;
@@ -185,36 +204,74 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
                 acc[nb][r] = (acc[nb][r] - mean) * rstd * vec[WROWS + c] + vec[2 * WROWS + c];
             }
     }
-    bool keep = true;
-    if constexpr (EPI == EPI_LN_RES) keep = a.flag == nullptr || a.flag[tk / a.flag_rows] != 0;
-    if (!live) return;
-    T* op = (T*)a.out + (size_t)token * a.ldo + n0;
-    const T* rp = EPI == EPI_LN_RES ? (const T*)a.res + (size_t)token * a.ldres + n0 : nullptr;
+    if constexpr (std::is_same<T, _Float16>::value) {
+        // fp16: transpose through LDS so that global stores (and the residual loads) are 16 B per lane
+        // along the row - 256-B contiguous segments instead of 64 scattered 8-B pieces per instruction.
+        // One 32-token x 128-channel slab per wave at a time (the staging buffers are free now).
+        constexpr int RS = 272;                                          // slab row stride (256 B + pad)
+        K3_T(11);
+        __syncthreads();                                                 // every wave is done with the fragments
+        K3_T(12);
+        char* ot = smem + wave * 32 * RS;
+        const int prow = lane >> 4, pch = lane & 15;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+        for (int hb = 0; hb < NB / 4; ++hb) {
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-            const int c = nb * 32 + 8 * r4 + 4 * h;                     // 4 consecutive channels
-            if (n0 + c >= a.N) continue;
-            v4f v{acc[nb][4 * r4], acc[nb][4 * r4 + 1], acc[nb][4 * r4 + 2], acc[nb][4 * r4 + 3]};
-            if constexpr (EPI == EPI_LN_RES) {
-                v4f x;
-                if constexpr (std::is_same<T, float>::value) x = *reinterpret_cast<const v4f*>(rp + c);
-                else {
-                    const v4h xh = *reinterpret_cast<const v4h*>(rp + c);
-                    x = v4f{(float)xh.x, (float)xh.y, (float)xh.z, (float)xh.w};
+            for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int nb = hb * 4 + q4, c = q4 * 32 + 8 * r4 + 4 * h;
+                    *reinterpret_cast<v4h*>(ot + lr * RS + c * 2) =
+                        v4h{(_Float16)acc[nb][4 * r4], (_Float16)acc[nb][4 * r4 + 1], (_Float16)acc[nb][4 * r4 + 2],
+                            (_Float16)acc[nb][4 * r4 + 3]};
                 }
-                v = keep ? v4f{x.x + v.x, x.y + v.y, x.z + v.z, x.w + v.w} : x;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 4 + prow, tg = m0 + wave * 32 + row, cg = n0 + hb * 128 + pch * 8;
+                if (tg >= a.M || cg >= a.N) continue;
+                v8h v = *reinterpret_cast<const v8h*>(ot + row * RS + pch * 16);
+                if constexpr (EPI == EPI_LN_RES) {
+                    const v8h x = *reinterpret_cast<const v8h*>((const T*)a.res + (size_t)tg * a.ldres + cg);
+                    const bool keep = a.flag == nullptr || a.flag[tg / a.flag_rows] != 0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = keep ? (_Float16)((float)x[i] + (float)v[i]) : x[i];
+                }
+                *reinterpret_cast<v8h*>((T*)a.out + (size_t)tg * a.ldo + cg) = v;
             }
-            if constexpr (std::is_same<T, float>::value) *reinterpret_cast<v4f*>(op + c) = v;
-            else *reinterpret_cast<v4h*>(op + c) = v4h{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            K3_T(13 + hb);
         }
+    } else {
+        bool keep = true;
+        if constexpr (EPI == EPI_LN_RES) keep = a.flag == nullptr || a.flag[tk / a.flag_rows] != 0;
+        if (!live) return;
+        T* op = (T*)a.out + (size_t)token * a.ldo + n0;
+        const T* rp = EPI == EPI_LN_RES ? (const T*)a.res + (size_t)token * a.ldres + n0 : nullptr;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int c = nb * 32 + 8 * r4 + 4 * h;                     // 4 consecutive channels
+                if (n0 + c >= a.N) continue;
+                v4f v{acc[nb][4 * r4], acc[nb][4 * r4 + 1], acc[nb][4 * r4 + 2], acc[nb][4 * r4 + 3]};
+                if constexpr (EPI == EPI_LN_RES) {
+                    const v4f x = *reinterpret_cast<const v4f*>(rp + c);
+                    v = keep ? v4f{x.x + v.x, x.y + v.y, x.z + v.z, x.w + v.w} : x;
+                }
+                *reinterpret_cast<v4f*>(op + c) = v;
+            }
+    }
 }
 
 template <typename T, int NB, int EPI>
 void lin_launch1(const LinArgs& a, hipStream_t st) {
     constexpr int WROWS = 32 * NB;
-    const size_t lds = (size_t)(128 + WROWS) * 128 + 3 * WROWS * sizeof(float);
+    size_t lds = (size_t)(128 + WROWS) * 128 + 3 * WROWS * sizeof(float);
+    if (lds < 4 * 32 * 272) lds = 4 * 32 * 272;                          // fp16 epilogue slabs
     linear_kernel<T, NB, EPI><<<dim3((a.M + 127) / 128, (a.N + WROWS - 1) / WROWS), 256, lds, st>>>(a);
 }
 
@@ -247,7 +304,9 @@ extern "C" int gf_linear(const void* a1, long lda1, int k1, const void* a2, long
     GF_CHECK_ARG(rowgroup_bias == nullptr || rowgroup_rows > 0, "rowgroup_rows must be > 0");
     const int es = dtype == GF_F32 ? 4 : 2;
     GF_CHECK_ARG((lda1 * es) % 16 == 0 && (k2 == 0 || (lda2 * es) % 16 == 0), "operand rows must be 16-byte aligned");
-    GF_CHECK_ARG((ldo * es) % (4 * es) == 0, "ldo must be a multiple of 4");
+    GF_CHECK_ARG((ldo * es) % 16 == 0 && (uintptr_t)out % 16 == 0, "output rows must be 16-byte aligned");
+    GF_CHECK_ARG(residual == nullptr || ((ldres * es) % 16 == 0 && (uintptr_t)residual % 16 == 0),
+                 "residual rows must be 16-byte aligned");
     if (epilogue >= EPI_LN) {
         GF_CHECK_ARG(ln_gamma && ln_beta, "LayerNorm epilogue needs gamma and beta");
         GF_CHECK_ARG(N == 128 || N == 256, "LayerNorm epilogue is built for N = 128 or 256 (whole rows per wave pair)");
