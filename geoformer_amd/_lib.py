@@ -54,6 +54,9 @@ SIGNATURES = {
     'gf_fine_gather': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'gf_bias_act_nhwc': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_int, c_void_p]),
+    'gf_upsample_add_nhwc': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'gf_stem_conv7x7': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'gf_fine_match_workspace_bytes': (c_size_t, [c_int]),
     'gf_fine_match': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p,
                               c_void_p, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

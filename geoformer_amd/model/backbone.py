@@ -3,8 +3,11 @@ SURVEY §2 row 10): only the module tree and parameter names are re-declared so 
 `geoformer.ckpt` loads with the same keys as the reference's ResNetFPN_8_2
 (model/loftr_src/loftr/backbone/resnet_fpn.py:43-118).
 """
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from .. import ops
 
 
 def _conv(cin, cout, k, stride=1):
@@ -60,6 +63,83 @@ class ResNetFPN_8_2(nn.Module):
         c2 = self.layer2_outconv2(c2 + F.interpolate(c3, size=c2.shape[2:], mode='bilinear', align_corners=True))
         c1 = self.layer1_outconv(x1)
         c1 = self.layer1_outconv2(c1 + F.interpolate(c2, size=c1.shape[2:], mode='bilinear', align_corners=True))
+        return [c3, c1]
+
+
+def _fold(conv, bn, dtype):
+    """Eval-mode BatchNorm folded into the convolution: (channels_last weight, fp32 shift or None)."""
+    w = conv.weight.detach().float()
+    b = None
+    if bn is not None:
+        scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + bn.eps)
+        w = w * scale[:, None, None, None]
+        b = (bn.bias.detach().float() - bn.running_mean.float() * scale).contiguous()
+    return w.to(dtype).contiguous(memory_format=torch.channels_last), b
+
+
+class FusedInferenceBackbone:
+    """Inference form of ResNetFPN_8_2 for the fp16 mode: BatchNorm folded into the
+    preceding convolution, channels_last throughout so MIOpen stays on its NHWC kernels, the convolutions
+    called WITHOUT bias, and everything between them - BN shift, ReLU / LeakyReLU, the BasicBlock shortcut
+    add, the two FPN upsample+add merges - done by the two glue kernels of csrc/k_backbone_glue.hip, one
+    read and one write per activation map (the eager sequence made ~50 element-wise passes per call, a
+    third of the backbone's time at batch 16).  Same arithmetic as resnet_fpn.py:85-118 in eval mode up to
+    fp16 rounding points."""
+
+    def __init__(self, bb: 'ResNetFPN_8_2', dtype):
+        self.dtype = dtype
+        self.stem = _fold(bb.conv1, bb.bn1, dtype)
+        # 1 -> 128 channel 7x7 stem: own implicit-GEMM kernel (conv + shift + ReLU, NHWC out); other widths
+        # go through MIOpen like the rest
+        self.stem_hip = None
+        if dtype == torch.float16 and tuple(bb.conv1.weight.shape) == (128, 1, 7, 7) and bb.conv1.stride == (2, 2):
+            self.stem_hip = (_fold(bb.conv1, bb.bn1, torch.float32)[0].contiguous(), self.stem[1])
+        self.blocks = []
+        for layer in (bb.layer1, bb.layer2, bb.layer3):
+            for blk in layer:
+                w1, b1 = _fold(blk.conv1, blk.bn1, dtype)
+                w2, b2 = _fold(blk.conv2, blk.bn2, dtype)
+                wd = None
+                if blk.downsample is not None:
+                    wd, bd = _fold(blk.downsample[0], blk.downsample[1], dtype)
+                    b2 = (b2 + bd).contiguous()
+                self.blocks.append((w1, b1, w2, b2, wd, blk.conv1.stride))
+        self.l3_out = _fold(bb.layer3_outconv, None, dtype)[0]
+        self.l2_out = _fold(bb.layer2_outconv, None, dtype)[0]
+        self.l1_out = _fold(bb.layer1_outconv, None, dtype)[0]
+        self.l2_oc2 = (_fold(bb.layer2_outconv2[0], bb.layer2_outconv2[1], dtype), bb.layer2_outconv2[2].negative_slope,
+                       _fold(bb.layer2_outconv2[3], None, dtype)[0])
+        self.l1_oc2 = (_fold(bb.layer1_outconv2[0], bb.layer1_outconv2[1], dtype), bb.layer1_outconv2[2].negative_slope,
+                       _fold(bb.layer1_outconv2[3], None, dtype)[0])
+
+    @staticmethod
+    def _conv(x, w, stride=1):
+        y = F.conv2d(x, w, None, stride, w.shape[-1] // 2)
+        return y if y.is_contiguous(memory_format=torch.channels_last) else y.contiguous(memory_format=torch.channels_last)
+
+    def _block(self, x, p):
+        w1, b1, w2, b2, wd, stride = p
+        y = ops.bias_act_(self._conv(x, w1, stride), b1, None, ops.ACT_RELU)
+        y = self._conv(y, w2)
+        shortcut = x if wd is None else self._conv(x, wd, stride)
+        return ops.bias_act_(y, b2, shortcut, ops.ACT_RELU)
+
+    def _head(self, x, p):
+        (w0, b0), slope, w3 = p
+        return self._conv(ops.bias_act_(self._conv(x, w0), b0, None, ops.ACT_LEAKY, slope), w3)
+
+    def __call__(self, x):
+        if self.stem_hip is not None:
+            x = ops.stem_conv7x7(x.contiguous(), *self.stem_hip)
+        else:
+            x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
+            x = ops.bias_act_(self._conv(x, self.stem[0], 2), self.stem[1], None, ops.ACT_RELU)
+        x1 = self._block(self._block(x, self.blocks[0]), self.blocks[1])
+        x2 = self._block(self._block(x1, self.blocks[2]), self.blocks[3])
+        x3 = self._block(self._block(x2, self.blocks[4]), self.blocks[5])
+        c3 = self._conv(x3, self.l3_out)
+        c2 = self._head(ops.upsample_add_(self._conv(x2, self.l2_out), c3), self.l2_oc2)
+        c1 = self._head(ops.upsample_add_(self._conv(x1, self.l1_out), c2), self.l1_oc2)
         return [c3, c1]
 
 

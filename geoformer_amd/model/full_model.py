@@ -58,34 +58,18 @@ class GeoFormer(nn.Module):
                 m.invalidate()
 
     def _inference_backbone(self):
-        """fp16 inference copy of the backbone: BatchNorm folded into the preceding convolution
-        (eval-mode algebra), channels-last weights so MIOpen stays on its NHWC kernels.  The fp32 parity
-        mode keeps the unfused module (bit-for-bit the reference's op sequence)."""
+        """fp16 inference form of the backbone (BN folded, channels_last, MIOpen convolutions + HIP glue
+        kernels; model/backbone.py FusedInferenceBackbone).  The fp32 parity mode keeps the unfused module
+        (bit-for-bit the reference's op sequence)."""
         if self._fused[0] is None:
-            import copy
-            from torch.nn.utils.fusion import fuse_conv_bn_eval
-            bb = copy.deepcopy(self.backbone).float().eval()
-
-            def fold(parent, conv_name, bn_name):
-                setattr(parent, conv_name, fuse_conv_bn_eval(getattr(parent, conv_name), getattr(parent, bn_name)))
-                setattr(parent, bn_name, nn.Identity())
-            fold(bb, 'conv1', 'bn1')
-            for layer in (bb.layer1, bb.layer2, bb.layer3):
-                for blk in layer:
-                    fold(blk, 'conv1', 'bn1')
-                    fold(blk, 'conv2', 'bn2')
-                    if blk.downsample is not None:
-                        blk.downsample = nn.Sequential(fuse_conv_bn_eval(blk.downsample[0], blk.downsample[1]), nn.Identity())
-            for seq in (bb.layer2_outconv2, bb.layer1_outconv2):
-                seq[0] = fuse_conv_bn_eval(seq[0], seq[1])
-                seq[1] = nn.Identity()
-            self._fused[0] = bb.to(self.backbone_dtype).to(memory_format=torch.channels_last)
+            from .backbone import FusedInferenceBackbone
+            self._fused[0] = FusedInferenceBackbone(self.backbone, self.backbone_dtype)
         return self._fused[0]
 
     def _backbone(self, x):
         x = x.to(self.backbone_dtype)
         if x.is_cuda and self.backbone_dtype != torch.float32 and not self.training:
-            return self._inference_backbone()(x.contiguous(memory_format=torch.channels_last))
+            return self._inference_backbone()(x)
         return self.backbone(x)
 
     def forward(self, data: Dict[str, torch.Tensor]):

@@ -103,6 +103,54 @@ def pos_encode(x, pe_hwc, out_dtype):
     return out
 
 
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+
+
+def _nhwc(t):
+    if t.dim() != 4 or not t.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError('expected a channels_last [N,C,H,W] tensor')
+    return t
+
+
+def bias_act_(x, bias=None, residual=None, act=ACT_NONE, slope=0.01):
+    """Backbone glue, in place: x <- act(x + bias[c] + residual) on channels_last [N,C,H,W] tensors."""
+    _need_cuda(x)
+    _nhwc(x)
+    if residual is not None and (_nhwc(residual).shape != x.shape or residual.dtype != x.dtype):
+        raise ValueError('residual must match x')
+    N, C, H, W = x.shape
+    check(_lib.lib().gf_bias_act_nhwc(_p(x), _p(bias), _p(residual), _p(x), N * H * W, C, int(act), float(slope), _dt(x),
+                                      _stream()), 'gf_bias_act_nhwc')
+    return x
+
+
+def upsample_add_(hi, lo):
+    """Backbone glue, in place: hi <- hi + bilinear(lo -> hi's size, align_corners=True); channels_last."""
+    _need_cuda(hi, lo)
+    _nhwc(hi), _nhwc(lo)
+    N, C, H, W = hi.shape
+    if lo.shape[:2] != (N, C) or lo.dtype != hi.dtype:
+        raise ValueError('lo must have the batch, channels and dtype of hi')
+    check(_lib.lib().gf_upsample_add_nhwc(_p(lo), _p(hi), _p(hi), N, lo.shape[2], lo.shape[3], H, W, C, _dt(hi),
+                                          _stream()), 'gf_upsample_add_nhwc')
+    return hi
+
+
+def stem_conv7x7(image, weight, shift):
+    """Backbone stem: image [N,1,H,W] (fp32/fp16, contiguous), weight fp32 [128,1,7,7] (BN folded), shift fp32 [128]
+    -> relu(conv 7x7 / stride 2 / pad 3 + shift), fp16 channels_last [N,128,Ho,Wo]."""
+    _need_cuda(image, weight, shift)
+    N, one, H, W = image.shape
+    if one != 1 or not image.is_contiguous():
+        raise ValueError('stem_conv7x7 needs a contiguous [N,1,H,W] image')
+    C = weight.shape[0]
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty(N, C, Ho, Wo, dtype=torch.float16, device=image.device, memory_format=torch.channels_last)
+    check(_lib.lib().gf_stem_conv7x7(_p(image), _dt(image), _p(weight), _p(shift), _p(out), N, H, W, C, _stream()),
+          'gf_stem_conv7x7')
+    return out
+
+
 def _rows(t):
     """[..., C] tensor whose last dim is contiguous -> (tensor, row stride in elements)."""
     if t.stride(-1) != 1:

@@ -192,6 +192,26 @@ int gf_fine_gather(const void* feat_f0, const void* feat_f1, int feat_dtype, con
                    void* win_out, void* ccat_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Backbone glue (fp16 inference backbone; the convolutions themselves stay on PyTorch-ROCm / MIOpen)
+ * replaces the element-wise passes of BasicBlock.forward and the FPN merges
+ *          (model/loftr_src/loftr/backbone/resnet_fpn.py:20-40 bn/relu/shortcut, :92-95 stem,
+ *           :104-105 and :110-111 F.interpolate(..., align_corners=True) + add, :106-115 BN + LeakyReLU)
+ *   channels-last tensors ([pixels, C] in memory), C % 4 == 0, 16-byte aligned, in-place allowed.
+ *   gf_bias_act_nhwc:     out = act(x + bias[c] + residual);  bias fp32 [C] or NULL, residual or NULL;
+ *                         act 0 none, 1 ReLU, 2 LeakyReLU(slope)
+ *   gf_upsample_add_nhwc: out = hi + bilinear(lo -> HxW, align_corners=True);  lo [N,h,w,C], hi/out [N,H,W,C]
+ * ------------------------------------------------------------------------------------------ */
+int gf_bias_act_nhwc(const void* x, const float* bias, const void* residual, void* out, long pixels, int C, int act,
+                     float slope, int dtype, void* stream);
+int gf_upsample_add_nhwc(const void* lo, const void* hi, void* out, int N, int h, int w, int H, int W, int C,
+                         int dtype, void* stream);
+/*   gf_stem_conv7x7:      out[n,oy,ox,c] = relu(sum_{ky,kx} image[n, 2oy-3+ky, 2ox-3+kx] * weight[c,ky,kx] + shift[c])
+ *                         = conv1 (7x7, stride 2, pad 3, 1 input channel) + bn1 (folded) + relu, resnet_fpn.py:60-62, :92;
+ *                         image [N,H,W] fp32 or fp16, weight fp32 [C,7,7], shift fp32 [C], out fp16 [N,Ho,Wo,C], C = 128 */
+int gf_stem_conv7x7(const void* image, int image_dtype, const float* weight, const float* shift, void* out, int N,
+                    int H, int W, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * K8  fine matching
  * replaces FineMatching2.forward + get_fine_match (model/fine_matching2.py:21-126), M > 0 branch
  *   f0, f1 [M,25,C]; fine_matrix fp32 [M,25,25]; compacted mkpts0_f/mkpts1_f [Mf,2], mconf [Mf],

@@ -353,3 +353,76 @@ def test_linear_epilogues(dtype, C):
     ctx = torch.randn((M + 24) // 25, C, generator=g).to(dtype)
     close(ops.linear(d(x), d(w_sq), rowgroup_bias=d(ctx), rowgroup_rows=25),
           F.linear(f(x), f(w_sq)) + f(ctx).repeat_interleave(25, 0)[:M], *tol)
+
+
+# ---------------------------------------------------------------------------------------------
+# backbone glue (fp16 inference backbone): torch fp32 reference of the same op
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('dtype,C', [(torch.float16, 128), (torch.float16, 196), (torch.float32, 196)])
+@pytest.mark.parametrize('act', [0, 1, 2])
+def test_bias_act_vs_torch(dtype, C, act):
+    from geoformer_amd import ops
+    torch.manual_seed(3)
+    x = torch.randn(2, C, 13, 17, device='cuda').to(dtype).contiguous(memory_format=torch.channels_last)
+    r = torch.randn(2, C, 13, 17, device='cuda').to(dtype).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(C, device='cuda')
+    ref = x.float() + b[None, :, None, None] + r.float()
+    ref = [ref, torch.relu(ref), torch.nn.functional.leaky_relu(ref, 0.01)][act]
+    out = ops.bias_act_(x.clone(memory_format=torch.channels_last), b, r, act, 0.01)
+    assert out.is_contiguous(memory_format=torch.channels_last)
+    tol = 1e-6 if dtype == torch.float32 else 2e-3          # one fp16 rounding of an O(1) value
+    assert torch.allclose(out.float(), ref, atol=tol * 4, rtol=tol)
+    # no bias / no residual
+    out2 = ops.bias_act_(x.clone(memory_format=torch.channels_last), None, None, 1)
+    assert torch.equal(out2, torch.relu(x))
+
+
+@pytest.mark.parametrize('dtype,C', [(torch.float16, 256), (torch.float16, 196), (torch.float32, 196)])
+def test_upsample_add_vs_torch(dtype, C):
+    from geoformer_amd import ops
+    torch.manual_seed(4)
+    lo = torch.randn(2, C, 15, 20, device='cuda').to(dtype).contiguous(memory_format=torch.channels_last)
+    hi = torch.randn(2, C, 30, 40, device='cuda').to(dtype).contiguous(memory_format=torch.channels_last)
+    ref = hi.float() + torch.nn.functional.interpolate(lo.float(), size=(30, 40), mode='bilinear', align_corners=True)
+    out = ops.upsample_add_(hi.clone(memory_format=torch.channels_last), lo)
+    tol = 1e-5 if dtype == torch.float32 else 2e-3
+    assert torch.allclose(out.float(), ref, atol=tol * 4, rtol=tol)
+
+
+def test_fused_backbone_vs_module():
+    """fp16 fused inference backbone against the fp32 nn.Module (eval mode, non-trivial BN statistics)."""
+    from geoformer_amd.model.backbone import FusedInferenceBackbone, build_backbone
+    from geoformer_amd.model.cvpr_ds_config import get_default_cfg
+    torch.manual_seed(5)
+    bb = build_backbone(get_default_cfg()).cuda().eval()
+    for m in bb.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.8, 1.2)
+            m.bias.data.normal_(0, 0.1)
+    x = torch.rand(2, 1, 64, 96, device='cuda')
+    with torch.no_grad():
+        c3, c1 = bb(x)
+        f3, f1 = FusedInferenceBackbone(bb, torch.float16)(x)
+    assert f3.shape == c3.shape and f1.shape == c1.shape
+    for f, c in ((f3, c3), (f1, c1)):
+        err = (f.float() - c).abs().max().item() / c.abs().max().item()
+        assert err < 2e-2, err                                  # fp16 weights + activations through 20 convolutions
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+@pytest.mark.parametrize('hw', [(64, 96), (37, 51), (480, 640)])
+def test_stem_conv_vs_torch(dtype, hw):
+    """7x7/2 stem + shift + ReLU against torch's fp32 convolution of the same fp16-rounded operands."""
+    from geoformer_amd import ops
+    torch.manual_seed(6)
+    H, W = hw
+    img = torch.rand(2, 1, H, W, device='cuda').to(dtype)
+    w = torch.randn(128, 1, 7, 7, device='cuda') * 0.2
+    b = torch.randn(128, device='cuda') * 0.1
+    out = ops.stem_conv7x7(img, w, b)
+    ref = torch.relu(torch.nn.functional.conv2d(img.half().float(), w.half().float(), b, 2, 3))
+    assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
+    # fp32 accumulation of exact fp16 products; one fp16 rounding of the result
+    assert torch.allclose(out.float(), ref, atol=2e-3, rtol=2e-3), (out.float() - ref).abs().max().item()
