@@ -20,10 +20,14 @@
 // HBM roofline: pass B is bound by the conf write (L*S*4 B per sample); everything else is O(L*C).
 // Measured (8 samples of 6400^2, fp16): the same two-128-B-segment store pattern alone reaches 5.6 TB/s
 // (tools/probes/store_pattern.hip); pass B reaches ~3.2 TB/s: ablating the stores or 3 of its 4 K steps
-// removes ~195 us each and the two do not overlap.  A row-panel-persistent variant (f0 rows kept as A
-// fragments in registers, 3x fewer operand bytes) measured the same, so the operand traffic is not the
-// limiter; non-temporal stores (conf is never re-read by this launch) bought 8 %.
+// removes ~195 us each and the two do not overlap.  Non-temporal stores (conf is never re-read by this
+// launch) bought 8 %.  The row-panel-persistent form (k1_conf_panel: f0 rows kept as A fragments in
+// registers, f1 tiles prefetched a whole tile ahead, 3x fewer operand bytes) is 3-6 % faster (0.344 ms per
+// 8 pairs); its phase trace (tools/k1_trace.py, -DK1_TRACE=1) shows per tile ~1000 ticks staging, ~2700
+// MFMA + fragment reads, 4000 (thr > 0) to 5200 (dense candidates) epilogue - the epilogue is paced by the
+// HBM write drain (32 KiB per tile per workgroup = ~3500 ticks at the measured 5.6 TB/s store ceiling).
 #include <math.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -437,6 +441,158 @@ __global__ __launch_bounds__(NT, 4) void k1_conf(K1Args a) {
     else k1_conf_epilogue<T, true, DENSE>(a, acc, smem, n, bm, bn);
 }
 
+// ---------------------------------------------------------------------------------------------
+// pass B, row-panel-persistent form (fp16, unmasked, L % 128 == 0, S % 64 == 0): a workgroup keeps its 128
+// f0 rows as MFMA A fragments in REGISTERS (16 k-groups x 4 VGPRs per wave) and walks PANEL_TILES
+// consecutive column tiles; only the 64 x 512-B f1 tile streams through LDS, and the next tile's rows and
+// column statistics are already in flight (registers) while the current tile is multiplied, exponentiated
+// and stored - the global-load latency that a one-tile workgroup exposes 5 times is hidden behind a whole
+// tile of work.  Same k order as sim_tile, so the sim values are bit-identical to pass A's.
+// Units (sample, row panel, run of column tiles) are dealt so that each XCD walks a contiguous range.
+// ---------------------------------------------------------------------------------------------
+constexpr int PANEL_TILES = 10;
+#ifndef K1_TRACE
+#define K1_TRACE 0
+#endif
+#if K1_TRACE
+__device__ long long k1_trace[512 * 4 * 32];
+#define K1_T(slot) do { if (lane == 0 && ui == slot0 + per_xcd && (slot) < 32) k1_trace[(blockIdx.x * 4 + wave) * 32 + (slot)] = clock64(); } while (0)
+#else
+#define K1_T(slot)
+#endif
+constexpr int PANEL_LDS = BN * 512 + BM * 8;      // f1 tile [64][512 B] + row statistics [128] float2
+
+__device__ __forceinline__ int k1p_off(int row, int chunk) { return row * 512 + ((chunk ^ (row & 15)) << 4); }
+
+template <bool DENSE>
+__global__ __launch_bounds__(NT, 2) void k1_conf_panel(K1Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* rst = reinterpret_cast<float2*>(smem + BN * 512);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, lr = lane & 31;
+    const int runs = (a.tilesN + PANEL_TILES - 1) / PANEL_TILES;
+    const int units = a.N * a.tilesM * runs;
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = (nwg + 7 - xcd) >> 3;
+    const int q = units >> 3, rem = units & 7;
+    const int ubeg = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q, ucnt = q + (xcd < rem ? 1 : 0);
+    const float k2 = 2.0f * a.mult * LOG2E;
+    const int srow = tid >> 5, schunk = tid & 31;             // staging: 8 rows x 32 chunks per pass, 8 passes
+    const int slot0 = slot;
+    (void)slot0;
+    for (int ui = slot; ui < ucnt; ui += per_xcd) {
+        const int u = ubeg + ui;
+        K1_T(0);
+        const int run = u % runs, pm = u / runs, bm = pm % a.tilesM, n = pm / a.tilesM;
+        const int m0 = bm * BM, t0 = run * PANEL_TILES, t1 = min(t0 + PANEL_TILES, a.tilesN);
+        const _Float16* A = (const _Float16*)a.f0 + ((size_t)n * a.L + m0 + wave * 32 + lr) * a.C + h * 8;
+        const _Float16* B = (const _Float16*)a.f1 + (size_t)n * a.S * a.C;
+        v8h af[16];
+#pragma unroll
+        for (int kg = 0; kg < 16; ++kg) af[kg] = *reinterpret_cast<const v8h*>(A + kg * 16);
+        __syncthreads();                                      // previous unit's rst readers are done
+        if (tid < BM) {
+            const float2 st = a.rstat[(size_t)n * a.L + m0 + tid];
+            rst[tid] = make_float2(-st.x * LOG2E, __builtin_amdgcn_rcpf(st.y));
+        }
+        v4u rb[8];
+        float2 cs[2];
+        auto prefetch = [&](int bn) {
+            const _Float16* g = B + (size_t)(bn * BN + srow) * a.C + schunk * 8;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) rb[p] = *reinterpret_cast<const v4u*>(g + (size_t)p * 8 * a.C);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) cs[ni] = a.cstat[(size_t)n * a.S + bn * BN + ni * 32 + lr];
+        };
+        prefetch(t0);
+        K1_T(1);
+        const int row_base = m0 + __builtin_amdgcn_readfirstlane(wave) * 32;
+        unsigned long long* rbest = a.rowbest + (size_t)n * a.L;
+        unsigned* cmax = a.colmax + (size_t)n * a.S;
+        const int lane_off = 4 * h * a.S + lr;
+        for (int bn = t0; bn < t1; ++bn) {
+            __syncthreads();                                  // the previous tile's fragments are consumed
+#pragma unroll
+            for (int p = 0; p < 8; ++p) *reinterpret_cast<v4u*>(smem + k1p_off(srow + 8 * p, schunk)) = rb[p];
+            float ca[2], cb[2];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                ca[ni] = -cs[ni].x * LOG2E;
+                cb[ni] = __builtin_amdgcn_rcpf(cs[ni].y);
+            }
+            __syncthreads();
+            K1_T(2 + 4 * (bn - t0));
+            if (bn + 1 < t1) prefetch(bn + 1);                // in flight during this tile's MFMAs and epilogue
+            v16f acc[2];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+#pragma unroll
+            for (int kg = 0; kg < 16; ++kg) {
+                const v8h b0 = *reinterpret_cast<const v8h*>(smem + k1p_off(lr, 2 * kg + h));
+                const v8h b1 = *reinterpret_cast<const v8h*>(smem + k1p_off(32 + lr, 2 * kg + h));
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kg], b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kg], b1, acc[1], 0, 0, 0);
+            }
+            const int n0 = bn * BN;
+            asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][15]));
+            K1_T(3 + 4 * (bn - t0));
+            float* cbase = a.conf + ((size_t)n * a.L + row_base) * a.S + n0;
+            unsigned long long key[DENSE ? 32 : 1];
+            unsigned cbest[2] = {0u, 0u};
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float2 st = rst[wave * 32 + gf_acc_row(r, h)];
+                float cf[2];
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    cf[ni] = __builtin_amdgcn_exp2f(fmaf(acc[ni][r], k2, st.x + ca[ni])) * (st.y * cb[ni]);
+                float* rowp = cbase + (size_t)((r & 3) + 8 * (r >> 2)) * a.S;
+                __builtin_nontemporal_store(cf[0], rowp + lane_off);
+                __builtin_nontemporal_store(cf[1], rowp + lane_off + 32);
+                if constexpr (!DENSE) {
+                    if (fmaxf(cf[0], cf[1]) > a.thr) {
+                        const int row = row_base + gf_acc_row(r, h);
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+                            if (cf[ni] > a.thr) {
+                                const int col = n0 + ni * 32 + lr;
+                                const unsigned bits = __float_as_uint(cf[ni]);
+                                atomicMax(rbest + row, ((unsigned long long)bits << 32) | (0xFFFFFFFFu - (unsigned)col));
+                                atomicMax(cmax + col, bits);
+                            }
+                    }
+                } else {
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        const bool in = cf[ni] > a.thr;
+                        const unsigned bits = in ? __float_as_uint(cf[ni]) : 0u;
+                        cbest[ni] = max(cbest[ni], bits);
+                        key[ni * 16 + r] = in ? (((unsigned long long)bits << 32) | (0xFFFFFFFFu - (unsigned)(n0 + ni * 32 + lr))) : 0ull;
+                    }
+                }
+            }
+            if constexpr (DENSE) {
+                const unsigned long long kbest = k1_row_reduce(key, GfMaxU64());
+                if (lr < 16 && kbest != 0ull) atomicMax(rbest + row_base + gf_acc_row(lr, h), kbest);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const unsigned c = max(cbest[ni], (unsigned)__shfl_xor((int)cbest[ni], 32, 64));
+                    if (h == 0 && c != 0u) atomicMax(cmax + n0 + ni * 32 + lr, c);
+                }
+            }
+            K1_T(4 + 4 * (bn - t0));
+        }
+    }
+}
+
+#if K1_TRACE
+}
+extern "C" int gf_debug_k1_trace(long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(k1_trace), sizeof(long long) * 512 * 4 * 32);
+}
+namespace {
+#endif
+
 struct SelArgs {
     int N, L, S;
     const unsigned long long* rowbest;   // [N][L]
@@ -603,7 +759,13 @@ int k1_launch(K1Args a, SelArgs s, void* zero_begin, size_t zero_bytes, hipStrea
     const int mx = a.L > a.S ? a.L : a.S;
     k1_reduce_stats<EXACT><<<dim3((mx + 31) / 32, 2, a.N), 256, 0, st>>>(a);
     void* p1 = gf_prof_begin("k1_conf", st, (double)a.N * ((double)(a.L + a.S) * a.C * sizeof(T) + (double)a.L * a.S * 4.0));
-    if (a.dense) k1_conf<T, true><<<grid, NT, STAGE_BYTES, st>>>(a);
+    const bool panel = !EXACT && a.mask0 == nullptr && a.L % BM == 0 && a.S % BN == 0 && a.C == 256 && getenv("GF_K1_NOPANEL") == nullptr;
+    if (panel) {
+        const int units = a.N * a.tilesM * ((a.tilesN + PANEL_TILES - 1) / PANEL_TILES);
+        const int wgs = units < 512 ? units : 512;           // two resident workgroups per CU
+        if (a.dense) k1_conf_panel<true><<<wgs, NT, PANEL_LDS, st>>>(a);
+        else k1_conf_panel<false><<<wgs, NT, PANEL_LDS, st>>>(a);
+    } else if (a.dense) k1_conf<T, true><<<grid, NT, STAGE_BYTES, st>>>(a);
     else k1_conf<T, false><<<grid, NT, STAGE_BYTES, st>>>(a);
     gf_prof_end("k1_conf", p1, st);
     k1_colset<<<dim3((a.S + 255) / 256, a.N), 256, 0, st>>>(s);
