@@ -27,6 +27,7 @@ class GeoFormer(nn.Module):
     def __init__(self, loftr_config, geoformer_cfg=default_cfg):
         super().__init__()
         self.config = loftr_config
+        self.geo_cfg = geoformer_cfg
         self.backbone = build_backbone(loftr_config)
         self.loftr_coarse = LocalFeatureTransformer(loftr_config['coarse'])
         self.pos_encoding = PositionEncodingSine(loftr_config['coarse']['d_model'],

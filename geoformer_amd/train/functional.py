@@ -1,0 +1,356 @@
+"""Differentiable (autograd) form of the GeoFormer forward for the training step.
+
+The inference path of this package is forward-only HIP.  Training needs gradients through every block, and
+the backward kernels are not written yet, so the training step runs the SAME arithmetic as
+`model/full_model.py:39-123` in plain torch ops on the model's own parameters (names = state-dict keys) and
+lets autograd differentiate it; the data-dependent, gradient-free pieces keep their device implementations
+(RANSAC homography on the GPU: `ops.ransac_homography`).  Each function cites the reference lines it follows.
+Nothing here is used by `GeoFormer.forward` (inference).
+"""
+import math
+from typing import Callable, Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------- a1 position encoding
+def position_encoding_table(d_model, h, w, temp_bug_fix, device):
+    """position_encoding.py:22-35 (incl. the `//2` precedence quirk of the non-fixed variant)."""
+    ypos = torch.arange(1, h + 1, dtype=torch.float32, device=device).view(1, h, 1).expand(1, h, w)
+    xpos = torch.arange(1, w + 1, dtype=torch.float32, device=device).view(1, 1, w).expand(1, h, w)
+    k2 = torch.arange(0, d_model // 2, 2, device=device).float()
+    if temp_bug_fix:
+        freq = torch.exp(k2 * (-math.log(10000.0) / (d_model // 2)))
+    else:
+        freq = torch.exp(k2 * (-math.log(10000.0) / d_model // 2))
+    freq = freq.view(-1, 1, 1)
+    pe = torch.zeros(d_model, h, w, device=device)
+    pe[0::4] = torch.sin(xpos * freq)
+    pe[1::4] = torch.cos(xpos * freq)
+    pe[2::4] = torch.sin(ypos * freq)
+    pe[3::4] = torch.cos(ypos * freq)
+    return pe
+
+
+def add_pe(x, temp_bug_fix=False):
+    _, c, h, w = x.shape
+    return x + position_encoding_table(c, h, w, temp_bug_fix, x.device)[None]
+
+
+# ----------------------------------------------------------------------------- attention + encoder layers
+def linear_attention(q, k, v, q_mask=None, kv_mask=None, eps=1e-6):
+    """linear_attention.py:21-51."""
+    Q, K = F.elu(q) + 1, F.elu(k) + 1
+    if q_mask is not None:
+        Q = Q * q_mask[:, :, None, None]
+    if kv_mask is not None:
+        K = K * kv_mask[:, :, None, None]
+        v = v * kv_mask[:, :, None, None]
+    s_len = v.size(1)
+    v = v / s_len
+    KV = torch.einsum('nshd,nshv->nhdv', K, v)
+    Z = 1 / (torch.einsum('nlhd,nhd->nlh', Q, K.sum(dim=1)) + eps)
+    return torch.einsum('nlhd,nhdv,nlh->nlhv', Q, KV, Z) * s_len
+
+
+def full_attention(q, k, v, kv_mask=None):
+    """geo_attention.py:53-101: masked logits -1e8 before the 1/sqrt(D) scale, all-masked rows zeroed."""
+    qk = torch.einsum('nlhd,nshd->nlsh', q, k)
+    if kv_mask is not None:
+        qk = qk.masked_fill(~kv_mask[:, None, :, None], -1e8)
+    a = torch.softmax(qk * (1.0 / q.size(3) ** .5), dim=2)
+    out = torch.einsum('nlsh,nshd->nlhd', a, v)
+    if kv_mask is not None:
+        out = out * (kv_mask.sum(-1) != 0)[:, None, None, None].to(out.dtype)
+    return out
+
+
+def encoder_layer(P, prefix, x, source, nhead, kind, x_mask=None, source_mask=None):
+    """loftr_module/transformer.py:37-60 (ReLU, linear attention) / geo_transformer/transformer.py:39-66 (Tanh, full)."""
+    n, _, c = x.shape
+    d = c // nhead
+    q = F.linear(x, P[prefix + 'q_proj.weight']).view(n, -1, nhead, d)
+    k = F.linear(source, P[prefix + 'k_proj.weight']).view(n, -1, nhead, d)
+    v = F.linear(source, P[prefix + 'v_proj.weight']).view(n, -1, nhead, d)
+    msg = linear_attention(q, k, v, x_mask, source_mask) if kind == 'loftr' else full_attention(q, k, v, source_mask)
+    msg = F.linear(msg.reshape(n, -1, c), P[prefix + 'merge.weight'])
+    msg = F.layer_norm(msg, (c,), P[prefix + 'norm1.weight'], P[prefix + 'norm1.bias'])
+    hid = F.linear(torch.cat([x, msg], dim=2), P[prefix + 'mlp.0.weight'])
+    hid = torch.relu(hid) if kind == 'loftr' else torch.tanh(hid)
+    msg = F.linear(hid, P[prefix + 'mlp.2.weight'])
+    msg = F.layer_norm(msg, (c,), P[prefix + 'norm2.weight'], P[prefix + 'norm2.bias'])
+    return x + msg
+
+
+def local_feature_transformer(P, prefix, layer_names, nhead, f0, f1, m0=None, m1=None):
+    """loftr_module/transformer.py:82-104 ('cross': f1 attends to the UPDATED f0)."""
+    for idx, name in enumerate(layer_names):
+        lp = f'{prefix}layers.{idx}.'
+        if name == 'self':
+            f0 = encoder_layer(P, lp, f0, f0, nhead, 'loftr', m0, m0)
+            f1 = encoder_layer(P, lp, f1, f1, nhead, 'loftr', m1, m1)
+        elif name == 'cross':
+            f0 = encoder_layer(P, lp, f0, f1, nhead, 'loftr', m0, m1)
+            f1 = encoder_layer(P, lp, f1, f0, nhead, 'loftr', m1, m0)
+        else:
+            raise KeyError(name)
+    return f0, f1
+
+
+# ----------------------------------------------------------------------------- coarse matching
+def dual_softmax(f0, f1, temperature, m0=None, m1=None):
+    """coarse_matching.py:113-125."""
+    c = f0.shape[-1]
+    sim = torch.einsum('nlc,nsc->nls', f0 / c ** .5, f1 / c ** .5) / temperature
+    if m0 is not None:
+        sim = sim.masked_fill(~(m0[..., None] * m1[:, None]).bool(), -1e9)
+    return F.softmax(sim, 1) * F.softmax(sim, 2)
+
+
+@torch.no_grad()
+def coarse_match(conf, data, thr):
+    """coarse_matching.py:132-212 (border_rm forced to 0; 'dataset_name' -> forced (0,0) match for empty samples)."""
+    mask = conf > thr
+    mask = mask & (conf == conf.max(dim=2, keepdim=True)[0]) & (conf == conf.max(dim=1, keepdim=True)[0])
+    if 'dataset_name' in data:
+        empty = mask.flatten(1).sum(-1) == 0
+        mask[empty, 0, 0] = True
+    mask_v, all_j = mask.max(dim=2)
+    b_ids, i_ids = torch.where(mask_v)
+    j_ids = all_j[b_ids, i_ids]
+    scale = data['hw0_i'][0] / data['hw0_c'][0]
+    scale0 = scale * data['scale0'][b_ids] if 'scale0' in data else scale
+    scale1 = scale * data['scale1'][b_ids] if 'scale1' in data else scale
+    w0c, w1c = int(data['hw0_c'][1]), int(data['hw1_c'][1])
+    mk0 = torch.stack([i_ids % w0c, i_ids // w0c], dim=1) * scale0
+    mk1 = torch.stack([j_ids % w1c, j_ids // w1c], dim=1) * scale1
+    return {'b_ids': b_ids, 'i_ids': i_ids, 'j_ids': j_ids, 'm_bids': b_ids, 'mkpts0_c': mk0, 'mkpts1_c': mk1}
+
+
+# ----------------------------------------------------------------------------- GeoModule
+def _map_keypoints(h, w, scale, device):
+    ys, xs = torch.meshgrid(torch.arange(h // scale, device=device), torch.arange(w // scale, device=device), indexing='ij')
+    return torch.stack([xs.reshape(-1), ys.reshape(-1)], -1) * scale
+
+
+def _warp_points(points, hmat):
+    """utils/homography.py:86-105 for one sample."""
+    homog = torch.cat([points, torch.ones(points.shape[0], 1, device=points.device)], dim=-1)
+    out = torch.bmm(hmat[None].to(homog.dtype), homog[None].permute(0, 2, 1)).permute(0, 2, 1)[0]
+    w = out[:, 2:].clone()
+    w[w == 0] = 1e-6
+    return out[:, :2] / w
+
+
+def _make_windows(kps, img_hw, window_size, scale):
+    """utils/common_utils.py:65-91."""
+    h, w = img_hw
+    r = torch.arange(window_size, device=kps.device) - window_size // 2
+    dy, dx = torch.meshgrid(r, r, indexing='ij')
+    off = torch.stack([dx, dy], -1).float().view(1, window_size * window_size, 2) * scale
+    p = kps[:, None, :] + off
+    oob = (p[..., 0] < 0) | (p[..., 1] < 0) | (p[..., 0] >= w) | (p[..., 1] >= h)
+    return p.masked_fill(oob[..., None], 0).long(), ~oob
+
+
+def _sample_windows(kps, fmap, s):
+    """utils/common_utils.py:166-181: kps [L,ww,2] pixel coords, fmap [C,H,W] -> [L,ww,C]."""
+    cell = (kps.float() // s).long()
+    return fmap[:, cell[..., 1], cell[..., 0]].permute(1, 2, 0)
+
+
+def geo_module(P, cnn0, cnn1, data, geo_cfg, homography_fn: Callable):
+    """model/geo_module.py:23-116 + geo_transformer/transformer.py:89-146.  The geometry (homography, inlier maps,
+    window tables) carries no gradient; the attention layers do.  homography_fn(b, kp0, kp1) -> (M float64 [3,3]
+    tensor | None, inlier mask bool [n])."""
+    n, c, hh0, ww0 = cnn0.shape
+    _, _, hh1, ww1 = cnn1.shape
+    dev = cnn0.device
+    f0 = add_pe(cnn0).flatten(2).transpose(1, 2)
+    f1 = add_pe(cnn1).flatten(2).transpose(1, 2)
+    H0, W0 = data['image0'].shape[2:]
+    H1, W1 = data['image1'].shape[2:]
+    scale = int(data['hw0_i'][0] // data['hw0_c'][0])
+    wsz = geo_cfg['window_size']
+    per_sample_scale = 'scale0' in data
+    win0, win1, msk0, msk1, map0, map1 = [], [], [], [], [], []
+    with torch.no_grad():
+        for b in range(n):
+            sel = data['m_bids'] == b
+            kp0, kp1 = data['mkpts0_c'][sel].long(), data['mkpts1_c'][sel].long()
+            if per_sample_scale:
+                kp0 = (kp0 / (scale * data['scale0'][b]) * scale).long()
+                kp1 = (kp1 / (scale * data['scale1'][b]) * scale).long()
+            M = None
+            if len(kp0) > 8:
+                M, keep = homography_fn(b, kp0, kp1)
+            if M is not None:
+                kp0, kp1 = kp0[keep], kp1[keep]
+                Md = M.to(device=dev, dtype=torch.float64)
+                s0 = scale * data['scale0'][b] if per_sample_scale else scale
+                s1 = scale * data['scale1'][b] if per_sample_scale else scale
+                p1 = _warp_points(_map_keypoints(H0, W0, scale, dev), Md.to(f0.dtype))
+                k1w, m1w = _make_windows(p1, (H1, W1), wsz, s1)
+                p0 = _warp_points(_map_keypoints(H1, W1, scale, dev), torch.inverse(Md[None])[0].to(f0.dtype))
+                k0w, m0w = _make_windows(p0, (H0, W0), wsz, s0)
+                win0.append(k0w); win1.append(k1w); msk0.append(m0w); msk1.append(m1w)
+            else:
+                win0.append(None); win1.append(None); msk0.append(None); msk1.append(None)
+            m0 = torch.zeros(hh0 * ww0, dtype=torch.bool, device=dev)
+            m1 = torch.zeros(hh1 * ww1, dtype=torch.bool, device=dev)
+            m0[(kp0[:, 1] // scale) * ww0 + kp0[:, 0] // scale] = True
+            m1[(kp1[:, 1] // scale) * ww1 + kp1[:, 0] // scale] = True
+            map0.append(m0); map1.append(m1)
+
+    nhead = geo_cfg['nhead']
+    f0 = [f0[b] for b in range(n)]          # per-sample lists: no in-place writes into autograd inputs
+    f1 = [f1[b] for b in range(n)]
+    for idx, name in enumerate(geo_cfg['layer_names']):
+        lp = f'geo_module.des_transformer.layers.{idx}.'
+        if name == 'self':
+            for b in range(n):
+                if map0[b].any():
+                    f0[b] = encoder_layer(P, lp, f0[b][None], f0[b][map0[b]][None], nhead, 'geo')[0]
+                if map1[b].any():
+                    f1[b] = encoder_layer(P, lp, f1[b][None], f1[b][map1[b]][None], nhead, 'geo')[0]
+        elif name == 'cross':
+            g0 = [None if win0[b] is None else _sample_windows(win0[b], f0[b].T.reshape(c, hh0, ww0), scale) for b in range(n)]
+            g1 = [None if win1[b] is None else _sample_windows(win1[b], f1[b].T.reshape(c, hh1, ww1), scale) for b in range(n)]
+            for b in range(n):
+                if g1[b] is None:
+                    continue
+                f0[b] = encoder_layer(P, lp, f0[b][:, None], g1[b], nhead, 'geo', None, msk1[b])[:, 0]
+                f1[b] = encoder_layer(P, lp, f1[b][:, None], g0[b], nhead, 'geo', None, msk0[b])[:, 0]
+        else:
+            raise KeyError(name)
+    return torch.stack(f0), torch.stack(f1)
+
+
+# ----------------------------------------------------------------------------- fine level
+def _fine_windows(feat_f, b_ids, cell_ids, w_c, stride, W):
+    """fine_preprocess.py:41-56 (unfold + gather) without materialising the unfold."""
+    pad = W // 2
+    fp = F.pad(feat_f, (pad, pad, pad, pad))
+    cy, cx = (cell_ids // w_c) * stride, (cell_ids % w_c) * stride
+    r = torch.arange(W, device=feat_f.device)
+    yy = (cy[:, None, None] + r[None, :, None]).expand(-1, W, W)
+    xx = (cx[:, None, None] + r[None, None, :]).expand(-1, W, W)
+    return fp[b_ids[:, None, None], :, yy, xx].reshape(-1, W * W, feat_f.shape[1])
+
+
+def fine_preprocess(P, feat_f0, feat_f1, feat_c0, feat_c1, data, W):
+    """fine_preprocess.py:30-74."""
+    stride = int(data['hw0_f'][0] // data['hw0_c'][0])
+    b, i, j = data['b_ids'], data['i_ids'], data['j_ids']
+    cf = feat_f0.shape[1]
+    if b.shape[0] == 0:
+        e = torch.empty(0, W * W, cf, device=feat_f0.device)
+        return e, e
+    w0 = _fine_windows(feat_f0, b, i, int(data['hw0_c'][1]), stride, W)
+    w1 = _fine_windows(feat_f1, b, j, int(data['hw1_c'][1]), stride, W)
+    cwin = F.linear(torch.cat([feat_c0[b, i], feat_c1[b, j]], 0), P['fine_preprocess.down_proj.weight'],
+                    P['fine_preprocess.down_proj.bias'])
+    both = torch.cat([torch.cat([w0, w1], 0), cwin[:, None].expand(-1, W * W, -1)], -1)
+    both = F.linear(both, P['fine_preprocess.merge_feat.weight'], P['fine_preprocess.merge_feat.bias'])
+    return torch.chunk(both, 2, dim=0)
+
+
+def fine_match(f0, f1, data, temperature, thr):
+    """fine_matching2.py:21-126; `fine_matrix` carries the gradient, the keypoints do not."""
+    M, WW, C = f0.shape
+    if M == 0:
+        return {'fine_matrix': torch.empty(0, WW, WW, device=f0.device), 'mkpts0_f': data['mkpts0_c'],
+                'mkpts1_f': data['mkpts1_c'], 'W': int(math.sqrt(WW))}
+    W = int(math.sqrt(WW))
+    conf = dual_softmax(f0, f1, temperature)
+    with torch.no_grad():
+        mask = conf > thr
+        mask = mask & (conf == conf.max(dim=2, keepdim=True)[0]) & (conf == conf.max(dim=1, keepdim=True)[0])
+        top = conf.reshape(M, -1).argmax(1)
+        onehot = torch.zeros(M, WW * WW, dtype=torch.bool, device=f0.device)
+        onehot[torch.arange(M, device=f0.device), top] = True
+        mask = mask & onehot.view(M, WW, WW)
+        fine_b = data['b_ids'][:, None, None].expand(-1, WW, WW)[mask]
+        mask_v, all_j = mask.max(dim=2)
+        m_ids, i_ids = torch.where(mask_v)
+        j_ids = all_j[m_ids, i_ids]
+        mconf = conf[m_ids, i_ids, j_ids]
+        cscale = data['hw0_i'][0] / data['hw0_c'][0]
+        cscale0 = cscale * data['scale0'][data['b_ids']] if 'scale0' in data else cscale
+        cscale1 = cscale * data['scale1'][data['b_ids']] if 'scale1' in data else cscale
+        c2f = data['hw0_f'][0] / data['hw0_c'][0]
+        c0 = data['mkpts0_c'] / cscale0 * c2f
+        c1 = data['mkpts1_c'] / cscale1 * c2f
+        mk0 = torch.stack([i_ids % W - W // 2, i_ids // W - W // 2], dim=1) + c0[m_ids]
+        mk1 = torch.stack([j_ids % W - W // 2, j_ids // W - W // 2], dim=1) + c1[m_ids]
+        fscale = data['hw0_i'][0] / data['hw0_f'][0]
+        fscale0 = fscale * data['scale0'][fine_b] if 'scale0' in data else fscale
+        fscale1 = fscale * data['scale1'][fine_b] if 'scale1' in data else fscale
+    return {'fine_matrix': conf, 'm_bids': fine_b, 'mkpts0_f': mk0 * fscale0, 'mkpts1_f': mk1 * fscale1, 'mconf': mconf,
+            'W': W}
+
+
+# ----------------------------------------------------------------------------- device RANSAC adaptor
+def device_homography_fn(data, scale):
+    """The forward's `cv2.findHomography` (geo_module.py:47-48) on the GPU: one batched `ops.ransac_homography`
+    call on the first-pass matches; returns the per-sample callback `geo_module` expects."""
+    from .. import ops
+    n = int(data['bs'])
+    counts = torch.zeros(1 + n, dtype=torch.int32, device=data['m_bids'].device)
+    per = torch.bincount(data['m_bids'], minlength=n).to(torch.int32)
+    counts[0] = per.sum()
+    counts[1:] = per
+    rs = ops.ransac_homography(data['mkpts0_c'].float().contiguous(), data['mkpts1_c'].float().contiguous(), counts, n,
+                               float(scale), data.get('scale0'), data.get('scale1'))
+    valid = rs['valid'].cpu()
+    starts = torch.cumsum(per, 0) - per
+
+    def fn(b, kp0, kp1):
+        if int(valid[b]) == 0:
+            return None, None
+        s = int(starts[b])
+        return rs['M'][b], rs['keep'][s:s + len(kp0)].bool()
+    return fn
+
+
+# ----------------------------------------------------------------------------- the forward
+def forward_train(model, data: Dict[str, torch.Tensor], homography_fn: Optional[Callable] = None):
+    """`GeoFormer.forward` (model/full_model.py:39-123) under autograd.  `model` is `geoformer_amd.GeoFormer` in fp32
+    precision; its backbone runs as the nn.Module (train-mode BatchNorm / SyncBatchNorm)."""
+    cfg, gcfg = model.config, model.geo_cfg
+    P = dict(model.named_parameters())
+    img0, img1 = data['image0'], data['image1']
+    n = img0.size(0)
+    data.update({'bs': torch.tensor(n), 'hw0_i': torch.tensor(img0.shape[2:]), 'hw1_i': torch.tensor(img1.shape[2:])})
+    if img0.shape[2:] == img1.shape[2:]:
+        feats_c, feats_f = model.backbone(torch.cat([img0, img1], dim=0))
+        (cnn0, cnn1), (ff0, ff1) = feats_c.split(n), feats_f.split(n)
+    else:
+        (cnn0, ff0), (cnn1, ff1) = model.backbone(img0), model.backbone(img1)
+    data.update({'hw0_c': torch.tensor(cnn0.shape[2:]), 'hw1_c': torch.tensor(cnn1.shape[2:]),
+                 'hw0_f': torch.tensor(ff0.shape[2:]), 'hw1_f': torch.tensor(ff1.shape[2:])})
+    tbf = cfg['coarse']['temp_bug_fix']
+    f0 = add_pe(cnn0, tbf).flatten(2).transpose(1, 2)
+    f1 = add_pe(cnn1, tbf).flatten(2).transpose(1, 2)
+    m0 = m1 = None
+    if 'mask0' in data:
+        m0, m1 = data['mask0'].flatten(-2), data['mask1'].flatten(-2)
+    f0, f1 = local_feature_transformer(P, 'loftr_coarse.', cfg['coarse']['layer_names'], cfg['coarse']['nhead'], f0, f1, m0, m1)
+    temp, thr = cfg['match_coarse']['dsmax_temperature'], cfg['match_coarse']['thr']
+    conf = dual_softmax(f0, f1, temp, m0, m1)
+    data.update(conf_matrix=conf, **coarse_match(conf, data, thr))
+    data['dect_conf_matrix'] = data['conf_matrix']
+    if homography_fn is None:
+        if not cnn0.is_cuda:
+            raise RuntimeError('forward_train on the CPU needs a homography_fn (the device RANSAC is HIP only)')
+        homography_fn = device_homography_fn(data, int(data['hw0_i'][0] // data['hw0_c'][0]))
+    g0, g1 = geo_module(P, cnn0, cnn1, data, gcfg, homography_fn)
+    conf = dual_softmax(g0, g1, temp, m0, m1)
+    data.update(conf_matrix=conf, **coarse_match(conf, data, thr))
+    W = cfg['fine_window_size']
+    u0, u1 = fine_preprocess(P, ff0, ff1, g0, g1, data, W)
+    if u0.size(0) != 0:
+        u0, u1 = local_feature_transformer(P, 'loftr_fine.', cfg['fine']['layer_names'], cfg['fine']['nhead'], u0, u1)
+    data.update(fine_match(u0, u1, data, gcfg['fine_temperature'], gcfg['fine_thr']))
+    return data

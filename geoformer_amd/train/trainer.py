@@ -1,0 +1,162 @@
+"""The training step and its schedule, one process per GPU.
+
+  TrainStep.__call__          lightning/lightning_homo_geoformer.py:64-77 (`_trainval_inference`) + backward + step
+  build_optimizer/scheduler   model/loftr_src/optimizers/__init__.py:5-42
+  warm-up rule                lightning_homo_geoformer.py:45-62 (`optimizer_step`)
+  lr / warm-up scaling        lightning/train_homo_geoformer.py:80-86
+  DDP                         train_homo_geoformer.py:117-125: DDP(find_unused_parameters=True) + SyncBatchNorm,
+                              gradient clipping 0.5 (`TRAINER.GRADIENT_CLIPPING`)
+
+The gradient all-reduce is torch DDP over `torch.distributed` (RCCL on MI355X, gloo in the CPU tests): the
+14.19 M parameters are 56.75 MB of fp32 gradients per step, bucketed at DDP's 25 MB default - two or three
+ring all-reduces per step, far below the xGMI per-link bandwidth, overlapped with the backward.
+"""
+import math
+from typing import Callable, Optional
+
+import torch
+import torch.nn as nn
+
+from .functional import forward_train
+from .loss import GeoLoss
+from .supervision import spvs_coarse, spvs_fine2
+
+DEFAULT_TRAINER_CFG = {       # model/loftr_src/config/default.py:103-165 with the overrides of train_config/loftr_ds_dense.py
+    'canonical_bs': 64, 'canonical_lr': 8e-3, 'optimizer': 'adamw', 'adam_decay': 0., 'adamw_decay': 0.1,
+    'warmup_type': 'linear', 'warmup_ratio': 0.1, 'warmup_step': 1875, 'scheduler': 'MultiStepLR',
+    'scheduler_interval': 'epoch', 'mslr_milestones': [8, 12, 16, 20, 24], 'mslr_gamma': 0.5, 'cosa_tmax': 30,
+    'elr_gamma': 0.999992, 'gradient_clipping': 0.5,
+}
+
+
+def scale_trainer_cfg(cfg, world_size, batch_size):
+    """TRUE_LR / WARMUP_STEP from the canonical values (train_homo_geoformer.py:80-86)."""
+    cfg = dict(DEFAULT_TRAINER_CFG, **(cfg or {}))
+    cfg['world_size'] = world_size
+    cfg['true_batch_size'] = world_size * batch_size
+    cfg['scaling'] = cfg['true_batch_size'] / cfg['canonical_bs']
+    cfg['true_lr'] = cfg['canonical_lr'] * cfg['scaling']
+    cfg['warmup_step'] = math.floor(cfg['warmup_step'] / cfg['scaling'])
+    return cfg
+
+
+def build_optimizer(model, cfg):
+    if cfg['optimizer'] == 'adam':
+        return torch.optim.Adam(model.parameters(), lr=cfg['true_lr'], weight_decay=cfg['adam_decay'])
+    if cfg['optimizer'] == 'adamw':
+        return torch.optim.AdamW(model.parameters(), lr=cfg['true_lr'], weight_decay=cfg['adamw_decay'])
+    raise ValueError(f"TRAINER.OPTIMIZER = {cfg['optimizer']} is not a valid optimizer!")
+
+
+def build_scheduler(cfg, optimizer):
+    name = cfg['scheduler']
+    if name == 'MultiStepLR':
+        return torch.optim.lr_scheduler.MultiStepLR(optimizer, cfg['mslr_milestones'], gamma=cfg['mslr_gamma'])
+    if name == 'CosineAnnealing':
+        return torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, cfg['cosa_tmax'])
+    if name == 'ExponentialLR':
+        return torch.optim.lr_scheduler.ExponentialLR(optimizer, cfg['elr_gamma'])
+    raise NotImplementedError(name)
+
+
+def warmup_lr(cfg, global_step) -> Optional[float]:
+    """lr to force while global_step < warmup_step (linear warm-up), else None."""
+    if global_step >= cfg['warmup_step'] or cfg['warmup_type'] == 'constant':
+        return None
+    if cfg['warmup_type'] != 'linear':
+        raise ValueError(f"Unknown lr warm-up strategy: {cfg['warmup_type']}")
+    base = cfg['warmup_ratio'] * cfg['true_lr']
+    return base + (global_step / cfg['warmup_step']) * abs(cfg['true_lr'] - base)
+
+
+class _Core(nn.Module):
+    """What DDP wraps: supervision -> forward -> fine supervision -> loss, returning the scalar loss."""
+
+    def __init__(self, model, loss, homography_fn=None):
+        super().__init__()
+        self.model, self.loss, self.homography_fn = model, loss, homography_fn
+
+    def forward(self, batch):
+        res = tuple(self.model.config['resolution'])
+        spvs_coarse(batch, res)
+        forward_train(self.model, batch, self.homography_fn)
+        spvs_fine2(batch, res)
+        return self.loss(batch)
+
+
+class TrainStep:
+    """One optimisation step per call; `epoch_end()` advances an epoch-interval scheduler."""
+
+    def __init__(self, model, trainer_cfg=None, loss_cfg=None, batch_size=1, distributed=False, device_ids=None,
+                 homography_fn: Optional[Callable] = None, sparse_spvs=True):
+        world = torch.distributed.get_world_size() if distributed else 1
+        self.cfg = scale_trainer_cfg(trainer_cfg, world, batch_size)
+        if model.precision != 'fp32':
+            raise ValueError("training runs the fp32 parameters: GeoFormer.set_precision('fp32')")
+        model.train()
+        self.model = model
+        core = _Core(model, GeoLoss(loss_cfg, model.config['match_coarse'].get('match_type', 'dual_softmax'), sparse_spvs),
+                     homography_fn)
+        if distributed:
+            if next(model.parameters()).is_cuda:      # torch's SyncBatchNorm is device-only; the gloo/CPU tests keep local BN
+                core = nn.SyncBatchNorm.convert_sync_batchnorm(core)
+            self.model = core.model
+            core = nn.parallel.DistributedDataParallel(core, device_ids=device_ids, find_unused_parameters=True)
+        self.core = core
+        self.optimizer = build_optimizer(self.model, self.cfg)
+        self.scheduler = build_scheduler(self.cfg, self.optimizer)
+        self.global_step = 0
+
+    def __call__(self, batch):
+        loss = self.core(batch)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        if self.cfg['gradient_clipping']:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.cfg['gradient_clipping'])
+        lr = warmup_lr(self.cfg, self.global_step)
+        if lr is not None:
+            for pg in self.optimizer.param_groups:
+                pg['lr'] = lr
+        self.optimizer.step()
+        if self.cfg['scheduler_interval'] == 'step':
+            self.scheduler.step()
+        self.global_step += 1
+        self.model._invalidate()                 # the inference path caches packed weights
+        return loss.detach()
+
+    def epoch_end(self):
+        if self.cfg['scheduler_interval'] == 'epoch':
+            self.scheduler.step()
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic homography pairs (the Oxford-Paris images are not available offline): a smooth random texture and
+# its warp under a random corner-perturbation homography, with the GT matrices the supervision needs
+# ---------------------------------------------------------------------------------------------
+def synthetic_homography_batch(n, hw, seed, device='cpu', max_shift=0.12):
+    H, W = hw
+    g = torch.Generator().manual_seed(seed)
+    base = torch.rand(n, 1, H // 8 + 2, W // 8 + 2, generator=g)
+    img0 = torch.nn.functional.interpolate(base, size=(H, W), mode='bicubic', align_corners=True)
+    img0 = (img0 + 0.15 * torch.rand(n, 1, H, W, generator=g)).clamp(0, 1)
+    src = torch.tensor([[0., 0.], [W - 1., 0.], [W - 1., H - 1.], [0., H - 1.]]).expand(n, 4, 2)
+    dst = src + (torch.rand(n, 4, 2, generator=g) * 2 - 1) * torch.tensor([W, H]) * max_shift
+    A = torch.zeros(n, 8, 8, dtype=torch.float64)
+    bvec = torch.zeros(n, 8, 1, dtype=torch.float64)
+    for k in range(4):
+        x, y = src[:, k, 0].double(), src[:, k, 1].double()
+        u, v = dst[:, k, 0].double(), dst[:, k, 1].double()
+        A[:, 2 * k] = torch.stack([x, y, torch.ones_like(x), torch.zeros_like(x), torch.zeros_like(x), torch.zeros_like(x), -u * x, -u * y], -1)
+        A[:, 2 * k + 1] = torch.stack([torch.zeros_like(x), torch.zeros_like(x), torch.zeros_like(x), x, y, torch.ones_like(x), -v * x, -v * y], -1)
+        bvec[:, 2 * k, 0], bvec[:, 2 * k + 1, 0] = u, v
+    h8 = torch.linalg.solve(A, bvec)[:, :, 0]
+    H01 = torch.cat([h8, torch.ones(n, 1, dtype=torch.float64)], 1).view(n, 3, 3)
+    H10 = torch.linalg.inv(H01)
+    # image1(p) = image0(H10 p): sample image0 at the back-warped pixel grid
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float64), torch.arange(W, dtype=torch.float64), indexing='ij')
+    p = torch.stack([xs, ys, torch.ones_like(xs)], -1).view(1, -1, 3) @ H10.transpose(1, 2)
+    p = p[..., :2] / p[..., 2:]
+    grid = torch.stack([p[..., 0] / (W - 1) * 2 - 1, p[..., 1] / (H - 1) * 2 - 1], -1).view(n, H, W, 2).float()
+    img1 = torch.nn.functional.grid_sample(img0, grid, mode='bilinear', padding_mode='zeros', align_corners=True)
+    return {'image0': img0.to(device), 'image1': img1.to(device), 'H_0to1': H01.float().to(device),
+            'H_1to0': H10.float().to(device), 'dataset_name': ['oxford'] * n, 'pair_names': [f'synthetic{seed}'] * n}

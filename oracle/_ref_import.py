@@ -127,3 +127,16 @@ def import_eval_helpers():
     ns.hpatches_helper = importlib.import_module("eval_tool.immatch.utils.hpatches_helper")
     ns.data_io = importlib.import_module("eval_tool.immatch.utils.data_io")
     return ns
+
+
+def import_training():
+    """Supervision + loss of the training harness (build container only); loguru is absent and only logs."""
+    import importlib
+    install_stubs()
+    _mod("loguru", logger=types.SimpleNamespace(warning=lambda *a, **k: None, info=lambda *a, **k: None))
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    ns = import_reference()
+    ns.supervision = importlib.import_module("model.loftr_src.loftr.utils.supervision")
+    ns.loftr_loss = importlib.import_module("model.loftr_src.losses.loftr_loss")
+    return ns

@@ -192,3 +192,65 @@ def g10_cases():
 def g11_inputs():
     return {'feats': planted_features(1, 80, 80, 80, 80, 111), 'coarse_thr': 0.2, 'fine_thr': 0.1,
             'data': {'image0': torch.zeros(1, 1, 640, 640), 'image1': torch.zeros(1, 1, 640, 640)}}
+
+
+# ------------------------------------------------------------------------------------------ training (f3)
+def _homography(seed, n, hw, amp=6.0):
+    """Mild random homographies: identity + corner-scale perturbation (pixels)."""
+    g = gen(seed)
+    H, W = hw
+    out = []
+    for _ in range(n):
+        m = torch.eye(3)
+        m[:2, :2] += (torch.rand(2, 2, generator=g) - 0.5) * 0.08
+        m[:2, 2] = (torch.rand(2, generator=g) - 0.5) * 2 * amp
+        m[2, :2] = (torch.rand(2, generator=g) - 0.5) * 2e-4
+        out.append(m)
+    return torch.stack(out)
+
+
+def g13_inputs():
+    H01 = _homography(131, 2, (64, 96))
+    base = {'image0': torch.zeros(2, 1, 64, 96), 'image1': torch.zeros(2, 1, 64, 96), 'H_0to1': H01,
+            'H_1to0': torch.inverse(H01), 'dataset_name': ['oxford', 'oxford'], 'pair_names': ['a', 'b']}
+    scaled = dict(base, scale0=torch.tensor([[1.0, 1.0], [1.5, 1.25]]), scale1=torch.tensor([[1.0, 1.0], [1.25, 1.5]]))
+    g = gen(132)
+    M = 7
+    cells0 = torch.randint(0, 8 * 12, (M,), generator=g)
+    mk0 = torch.stack([cells0 % 12, cells0 // 12], 1).float() * 8
+    H1 = H01[:1]
+    w = torch.cat([mk0, torch.ones(M, 1)], 1) @ H1[0].T
+    mk1 = ((w[:, :2] / w[:, 2:]) / 8).round().clamp(min=0) * 8
+    fine = {'image0': torch.zeros(1, 1, 64, 96), 'image1': torch.zeros(1, 1, 64, 96), 'H_0to1': H1, 'H_1to0': torch.inverse(H1),
+            'mkpts0_c': mk0, 'mkpts1_c': mk1, 'b_ids': torch.zeros(M, dtype=torch.long), 'W': torch.tensor(5),
+            'hw0_i': torch.tensor([64, 96]), 'hw0_c': torch.tensor([8, 12]), 'hw0_f': torch.tensor([32, 48]),
+            'dataset_name': ['oxford']}
+    return {'coarse': base, 'coarse_scaled': scaled, 'fine': fine}
+
+
+def g14_inputs():
+    g = gen(141)
+    N, L, S, M = 2, 40, 48, 6
+    conf = torch.rand(N, L, S, generator=g) ** 3
+    dect = torch.rand(N, L, S, generator=g) ** 3
+    gt = torch.zeros(N, L, S)
+    for b in range(N):
+        rows = torch.randperm(L, generator=g)[:11]
+        cols = torch.randperm(S, generator=g)[:11]
+        gt[b, rows, cols] = 1
+    fine = torch.rand(M, 25, 25, generator=g) ** 2
+    fgt = torch.zeros(M, 25, 25, dtype=torch.bool)
+    fgt[torch.arange(4), torch.randint(0, 25, (4,), generator=g), torch.randint(0, 25, (4,), generator=g)] = True
+    m0 = torch.ones(N, 5, 8, dtype=torch.bool); m0[1, 4:] = False
+    m1 = torch.ones(N, 6, 8, dtype=torch.bool); m1[0, :, 6:] = False
+    return {'conf_matrix': conf, 'dect_conf_matrix': dect, 'conf_matrix_gt': gt, 'fine_matrix': fine,
+            'conf_matrix_fine_gt': fgt, 'mask0': m0, 'mask1': m1}
+
+
+def g15_inputs():
+    """One training pair: textured image and its 8-px shift (GT homography = that translation)."""
+    i0, i1 = textured_pair(64, 80, 151)
+    H01 = torch.tensor([[[1., 0., -8.], [0., 1., -8.], [0., 0., 1.]]])
+    return {'coarse_thr': 0.0, 'fine_thr': 0.0,
+            'data': {'image0': i0, 'image1': i1, 'H_0to1': H01, 'H_1to0': torch.inverse(H01), 'dataset_name': ['oxford'],
+                     'pair_names': ['p']}}
