@@ -192,9 +192,9 @@ def main():
         return (time.perf_counter() - t) / 3 / args.batch * 1e3
     bb_ms = backbone_ms_per_pair()
     log(f'backbone {bb_ms:.2f} ms/pair with the shipped MIOpen picks')
-    if not args.tune and args.precision == 'fp16' and bb_ms > 3.4 * (args.size / 640.0) ** 2:
+    if not args.tune and args.precision == 'fp16' and bb_ms > 2.2 * (args.size / 640.0) ** 2:
         # the shipped find-db did not apply (other batch size / MIOpen build): let MIOpen search once
-        log('slower than the tuned reference (2.6 ms/pair): running the MIOpen search (minutes) ...')
+        log('slower than the tuned reference (1.7 ms/pair): running the MIOpen search (minutes) ...')
         torch.backends.cudnn.benchmark = True
         bb_ms = backbone_ms_per_pair()
         log(f'backbone {bb_ms:.2f} ms/pair after the search')

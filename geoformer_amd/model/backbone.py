@@ -66,15 +66,28 @@ class ResNetFPN_8_2(nn.Module):
         return [c3, c1]
 
 
-def _fold(conv, bn, dtype):
-    """Eval-mode BatchNorm folded into the convolution: (channels_last weight, fp32 shift or None)."""
+def _padded(c, multiple):
+    return c if (multiple <= 1 or c == 1 or c % multiple == 0) else (c + multiple - 1) // multiple * multiple
+
+
+def _fold(conv, bn, dtype, pad_multiple=1, pad_out=True):
+    """Eval-mode BatchNorm folded into the convolution: (channels_last weight, fp32 shift or None).
+    With pad_multiple > 1 the input (and, unless pad_out=False, output) channel counts are zero-padded to
+    that multiple: the 196-wide maps of the (128, 196, 256) pyramid become 256-wide maps whose extra
+    channels are identically zero through shift, ReLU / LeakyReLU, shortcut and upsampling."""
     w = conv.weight.detach().float()
     b = None
     if bn is not None:
         scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + bn.eps)
         w = w * scale[:, None, None, None]
-        b = (bn.bias.detach().float() - bn.running_mean.float() * scale).contiguous()
-    return w.to(dtype).contiguous(memory_format=torch.channels_last), b
+        b = bn.bias.detach().float() - bn.running_mean.float() * scale
+    co, ci = w.shape[:2]
+    cop, cip = (_padded(co, pad_multiple) if pad_out else co), _padded(ci, pad_multiple)
+    if (cop, cip) != (co, ci):
+        w = F.pad(w, (0, 0, 0, 0, 0, cip - ci, 0, cop - co))
+        if b is not None:
+            b = F.pad(b, (0, cop - co))
+    return w.to(dtype).contiguous(memory_format=torch.channels_last), (None if b is None else b.contiguous())
 
 
 class FusedInferenceBackbone:
@@ -86,8 +99,9 @@ class FusedInferenceBackbone:
     third of the backbone's time at batch 16).  Same arithmetic as resnet_fpn.py:85-118 in eval mode up to
     fp16 rounding points."""
 
-    def __init__(self, bb: 'ResNetFPN_8_2', dtype):
+    def __init__(self, bb: 'ResNetFPN_8_2', dtype, pad_multiple=32):
         self.dtype = dtype
+        pm = pad_multiple
         self.stem = _fold(bb.conv1, bb.bn1, dtype)
         # 1 -> 128 channel 7x7 stem: own implicit-GEMM kernel (conv + shift + ReLU, NHWC out); other widths
         # go through MIOpen like the rest
@@ -97,20 +111,20 @@ class FusedInferenceBackbone:
         self.blocks = []
         for layer in (bb.layer1, bb.layer2, bb.layer3):
             for blk in layer:
-                w1, b1 = _fold(blk.conv1, blk.bn1, dtype)
-                w2, b2 = _fold(blk.conv2, blk.bn2, dtype)
+                w1, b1 = _fold(blk.conv1, blk.bn1, dtype, pm)
+                w2, b2 = _fold(blk.conv2, blk.bn2, dtype, pm)
                 wd = None
                 if blk.downsample is not None:
-                    wd, bd = _fold(blk.downsample[0], blk.downsample[1], dtype)
+                    wd, bd = _fold(blk.downsample[0], blk.downsample[1], dtype, pm)
                     b2 = (b2 + bd).contiguous()
                 self.blocks.append((w1, b1, w2, b2, wd, blk.conv1.stride))
-        self.l3_out = _fold(bb.layer3_outconv, None, dtype)[0]
-        self.l2_out = _fold(bb.layer2_outconv, None, dtype)[0]
-        self.l1_out = _fold(bb.layer1_outconv, None, dtype)[0]
-        self.l2_oc2 = (_fold(bb.layer2_outconv2[0], bb.layer2_outconv2[1], dtype), bb.layer2_outconv2[2].negative_slope,
-                       _fold(bb.layer2_outconv2[3], None, dtype)[0])
-        self.l1_oc2 = (_fold(bb.layer1_outconv2[0], bb.layer1_outconv2[1], dtype), bb.layer1_outconv2[2].negative_slope,
-                       _fold(bb.layer1_outconv2[3], None, dtype)[0])
+        self.l3_out = _fold(bb.layer3_outconv, None, dtype, pm)[0]
+        self.l2_out = _fold(bb.layer2_outconv, None, dtype, pm)[0]
+        self.l1_out = _fold(bb.layer1_outconv, None, dtype, pm)[0]
+        self.l2_oc2 = (_fold(bb.layer2_outconv2[0], bb.layer2_outconv2[1], dtype, pm), bb.layer2_outconv2[2].negative_slope,
+                       _fold(bb.layer2_outconv2[3], None, dtype, pm)[0])
+        self.l1_oc2 = (_fold(bb.layer1_outconv2[0], bb.layer1_outconv2[1], dtype, pm), bb.layer1_outconv2[2].negative_slope,
+                       _fold(bb.layer1_outconv2[3], None, dtype, pm, pad_out=False)[0])   # the fine map keeps its width
 
     @staticmethod
     def _conv(x, w, stride=1):

@@ -6,6 +6,8 @@ sys.path.insert(0, here)
 os.environ.setdefault('MIOPEN_USER_DB_PATH', os.path.join(here, 'geoformer_amd', 'miopen_db'))
 import torch
 import torch.nn as nn
+torch.backends.cudnn.benchmark = '--tune' in sys.argv
+PAD = int(sys.argv[sys.argv.index('--pad') + 1]) if '--pad' in sys.argv else 32
 from geoformer_amd.model.backbone import FusedInferenceBackbone, build_backbone
 from geoformer_amd.model.cvpr_ds_config import get_default_cfg
 bb = build_backbone(get_default_cfg()).cuda().eval()
@@ -24,7 +26,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'old':
     m = bb.half().to(memory_format=torch.channels_last)
     fb = lambda x: m(x.half().contiguous(memory_format=torch.channels_last))
 else:
-    fb = FusedInferenceBackbone(bb, torch.float16)
+    fb = FusedInferenceBackbone(bb, torch.float16, pad_multiple=PAD)
 x = torch.rand(16, 1, 640, 640, device='cuda')
 with torch.no_grad():
     for _ in range(2):
@@ -33,4 +35,4 @@ with torch.no_grad():
     for _ in range(5):
         fb(x)
     torch.cuda.synchronize()
-print('backbone ms/call %.2f' % ((time.perf_counter() - t) / 5 * 1e3))
+print('pad', PAD, 'tune', torch.backends.cudnn.benchmark, 'backbone ms/call %.2f' % ((time.perf_counter() - t) / 5 * 1e3))
