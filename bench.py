@@ -163,20 +163,39 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
     results = {}
 
-    def worker(w, first, count):
+    # persistent pipeline threads (created once: their thread-local HIP / MIOpen state is warm before the
+    # timed region), fed with (first, count) jobs
+    import queue
+    jobs = [queue.Queue() for _ in range(nstreams)]
+    done = queue.Queue()
+
+    def worker(w):
         torch.cuda.set_device(dev)
         with torch.cuda.stream(streams[w]):
-            for i in range(first + w, first + count, nstreams):
-                out = step(i)
-                results[i] = (len(out['b_ids']), len(out['mkpts0_f']), out)
-        streams[w].synchronize()
+            while True:
+                job = jobs[w].get()
+                if job is None:
+                    return
+                first, count = job
+                try:
+                    for i in range(first + w, first + count, nstreams):
+                        out = step(i)
+                        results[i] = (len(out['b_ids']), len(out['mkpts0_f']), out)
+                    streams[w].synchronize()
+                    done.put(w)
+                except BaseException as e:          # surface a failed step instead of hanging the barrier
+                    done.put(e)
+    pool = [threading.Thread(target=worker, args=(w,), daemon=True) for w in range(nstreams)]
+    for t in pool:
+        t.start()
 
     def run(first, count):
-        ts = [threading.Thread(target=worker, args=(w, first, count)) for w in range(nstreams)]
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join()
+        for w in range(nstreams):
+            jobs[w].put((first, count))
+        for _ in range(nstreams):
+            r = done.get()
+            if isinstance(r, BaseException):
+                raise r
 
     log('model + inputs ready')
 

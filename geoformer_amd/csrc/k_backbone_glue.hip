@@ -35,20 +35,39 @@ template <typename T, int V>
 __global__ __launch_bounds__(256) void bias_act(BaArgs a) {
     typedef typename VecOf<T, V>::type Vec;
     const int cv = a.C / V;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.nvec; i += (long)gridDim.x * 256) {
-        const int c0 = (int)(i % cv) * V;
-        Vec v = __builtin_nontemporal_load(reinterpret_cast<const Vec*>(a.x) + i);
+    const long stride = (long)gridDim.x * 256;
+    const int smod = (int)(stride % cv);
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    int c = (int)(i % cv);                                   // channel-vector of element i, advanced incrementally
+    const Vec* x = reinterpret_cast<const Vec*>(a.x);
+    const Vec* res = reinterpret_cast<const Vec*>(a.res);
+    Vec* out = reinterpret_cast<Vec*>(a.out);
+    for (; i < a.nvec; i += stride) {
+        Vec v = __builtin_nontemporal_load(x + i);
         Vec r;
-        if (a.res) r = __builtin_nontemporal_load(reinterpret_cast<const Vec*>(a.res) + i);
+        if (res) r = __builtin_nontemporal_load(res + i);
+        float bv[V];
+        if (a.bias) {
+#pragma unroll
+            for (int k = 0; k < V; k += 4) {
+                const v4f b4 = *reinterpret_cast<const v4f*>(a.bias + c * V + k);
+                bv[k] = b4.x; bv[k + 1] = b4.y; bv[k + 2] = b4.z; bv[k + 3] = b4.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < V; ++k) bv[k] = 0.f;
+        }
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            float f = (float)v[k] + (a.bias ? a.bias[c0 + k] : 0.f);
-            if (a.res) f += (float)r[k];
+            float f = (float)v[k] + bv[k];
+            if (res) f += (float)r[k];
             if (a.act == ACT_RELU) f = fmaxf(f, 0.f);
             else if (a.act == ACT_LEAKY) f = f > 0.f ? f : f * a.slope;
             v[k] = (T)f;
         }
-        reinterpret_cast<Vec*>(a.out)[i] = v;
+        out[i] = v;
+        c += smod;
+        if (c >= cv) c -= cv;
     }
 }
 
@@ -60,32 +79,30 @@ struct UaArgs {
     float ry, rx;       // (h-1)/(H-1), (w-1)/(W-1)
 };
 
+// grid: x = 256-thread chunks of one output row (W * C/V vectors), y = output row, z = sample
 template <typename T, int V>
 __global__ __launch_bounds__(256) void upsample_add(UaArgs a) {
     typedef typename VecOf<T, V>::type Vec;
-    const int cv = a.C / V;
-    const long total = (long)a.N * a.H * a.W * cv;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % cv);
-        const long p = i / cv;
-        const int x = (int)(p % a.W);
-        const long q = p / a.W;
-        const int y = (int)(q % a.H), n = (int)(q / a.H);
-        const float fy = a.ry * y, fx = a.rx * x;
-        const int y0 = (int)fy, x0 = (int)fx;
-        const int y1 = y0 + (y0 < a.h - 1), x1 = x0 + (x0 < a.w - 1);
-        const float wy1 = fy - y0, wx1 = fx - x0, wy0 = 1.f - wy1, wx0 = 1.f - wx1;
-        const Vec* lo = reinterpret_cast<const Vec*>(a.lo) + (long)n * a.h * a.w * cv + c;
-        const Vec v00 = lo[((long)y0 * a.w + x0) * cv], v01 = lo[((long)y0 * a.w + x1) * cv];
-        const Vec v10 = lo[((long)y1 * a.w + x0) * cv], v11 = lo[((long)y1 * a.w + x1) * cv];
-        Vec o = __builtin_nontemporal_load(reinterpret_cast<const Vec*>(a.hi) + i);
+    const unsigned cv = a.C / V;
+    const unsigned xc = blockIdx.x * 256 + threadIdx.x;
+    if (xc >= (unsigned)a.W * cv) return;
+    const unsigned x = xc / cv, c = xc - x * cv;
+    const int y = blockIdx.y, n = blockIdx.z;
+    const float fy = a.ry * y, fx = a.rx * x;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < a.h - 1), x1 = x0 + (x0 < a.w - 1);
+    const float wy1 = fy - y0, wx1 = fx - x0, wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+    const Vec* lo = reinterpret_cast<const Vec*>(a.lo) + (size_t)n * a.h * a.w * cv + c;
+    const Vec v00 = lo[((size_t)y0 * a.w + x0) * cv], v01 = lo[((size_t)y0 * a.w + x1) * cv];
+    const Vec v10 = lo[((size_t)y1 * a.w + x0) * cv], v11 = lo[((size_t)y1 * a.w + x1) * cv];
+    const size_t i = ((size_t)n * a.H + y) * a.W * cv + xc;
+    Vec o = __builtin_nontemporal_load(reinterpret_cast<const Vec*>(a.hi) + i);
 #pragma unroll
-        for (int k = 0; k < V; ++k) {
-            const float up = wy0 * (wx0 * (float)v00[k] + wx1 * (float)v01[k]) + wy1 * (wx0 * (float)v10[k] + wx1 * (float)v11[k]);
-            o[k] = (T)((float)o[k] + up);
-        }
-        reinterpret_cast<Vec*>(a.out)[i] = o;
+    for (int k = 0; k < V; ++k) {
+        const float up = wy0 * (wx0 * (float)v00[k] + wx1 * (float)v01[k]) + wy1 * (wx0 * (float)v10[k] + wx1 * (float)v11[k]);
+        o[k] = (T)((float)o[k] + up);
     }
+    reinterpret_cast<Vec*>(a.out)[i] = o;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -200,7 +217,8 @@ extern "C" int gf_bias_act_nhwc(const void* x, const float* bias, const void* re
     GF_CHECK_ARG(dtype == GF_F32 || dtype == GF_F16, "dtype must be GF_F32 or GF_F16");
     GF_CHECK_ARG(act >= ACT_NONE && act <= ACT_LEAKY, "unknown activation");
     GF_CHECK_ARG(C % 4 == 0, "C must be a multiple of 4");
-    GF_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)residual % 16 == 0, "tensors must be 16-byte aligned");
+    GF_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)residual % 16 == 0 && (uintptr_t)bias % 16 == 0,
+                 "tensors must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     BaArgs a{x, bias, residual, out, 0, C, act, slope};
     if (dtype == GF_F16 && C % 8 == 0) {
@@ -227,10 +245,12 @@ extern "C" int gf_upsample_add_nhwc(const void* lo, const void* hi, void* out, i
     hipStream_t st = (hipStream_t)stream;
     UaArgs a{lo, hi, out, N, h, w, H, W, C, H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f,
              W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f};
-    const long px = (long)N * H * W;
-    if (dtype == GF_F16 && C % 8 == 0) upsample_add<_Float16, 8><<<glue_blocks(px * C / 8), 256, 0, st>>>(a);
-    else if (dtype == GF_F16) upsample_add<_Float16, 4><<<glue_blocks(px * C / 4), 256, 0, st>>>(a);
-    else upsample_add<float, 4><<<glue_blocks(px * C / 4), 256, 0, st>>>(a);
+    GF_CHECK_ARG(H <= 65535 && N <= 65535, "H and N must fit the launch grid");
+    const int V = (dtype == GF_F16 && C % 8 == 0) ? 8 : 4;
+    const dim3 grid((unsigned)((W * (C / V) + 255) / 256), (unsigned)H, (unsigned)N);
+    if (dtype == GF_F16 && V == 8) upsample_add<_Float16, 8><<<grid, 256, 0, st>>>(a);
+    else if (dtype == GF_F16) upsample_add<_Float16, 4><<<grid, 256, 0, st>>>(a);
+    else upsample_add<float, 4><<<grid, 256, 0, st>>>(a);
     GF_CHECK_LAUNCH();
     return GF_OK;
 }

@@ -29,6 +29,24 @@ __global__ void pe_nhwc(PeArgs a) {
     }
 }
 
+// dense channels-last input, C % 8 == 0: 8 channels per lane, 32-bit index arithmetic
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void pe_nhwc_vec(PeArgs a) {
+    typedef TI VI __attribute__((ext_vector_type(8)));
+    typedef TO VO __attribute__((ext_vector_type(8)));
+    typedef float VF __attribute__((ext_vector_type(8)));
+    const unsigned cv = a.C / 8, hw = (unsigned)a.H * a.W, total = (unsigned)a.N * hw * cv;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const unsigned p = i / cv, c = i - p * cv, q = p % hw;
+        const VI x = reinterpret_cast<const VI*>(a.x)[i];
+        const VF pe = reinterpret_cast<const VF*>(a.pe)[q * cv + c];
+        VO o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = gf_from_float<TO>(gf_to_float(x[k]) + pe[k]);
+        reinterpret_cast<VO*>(a.out)[i] = o;
+    }
+}
+
 // NCHW input (sw == 1): 32 x 32 (position x channel) tile transposed through LDS
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void pe_nchw(PeArgs a) {
@@ -57,7 +75,12 @@ __global__ __launch_bounds__(256) void pe_nchw(PeArgs a) {
 
 template <typename TI, typename TO>
 int pe_launch(const PeArgs& a, hipStream_t st) {
-    if (a.sc == 1) {
+    const long elems = (long)a.N * a.H * a.W * a.C;
+    if (a.sc == 1 && a.C % 8 == 0 && a.sw == a.C && a.sh == (long)a.W * a.C && a.sn == (long)a.H * a.W * a.C && elems < (1l << 34) &&
+        (uintptr_t)a.x % 32 == 0 && (uintptr_t)a.out % 32 == 0 && (uintptr_t)a.pe % 32 == 0) {
+        const long nv = elems / 8;
+        pe_nhwc_vec<TI, TO><<<(int)((nv + 255) / 256 < 4096 ? (nv + 255) / 256 : 4096), 256, 0, st>>>(a);
+    } else if (a.sc == 1) {
         const long total = (long)a.N * a.H * a.W * a.C;
         const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
         pe_nhwc<TI, TO><<<blocks, 256, 0, st>>>(a);
