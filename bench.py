@@ -178,7 +178,7 @@ def main():
                     return
                 first, count = job
                 try:
-                    for i in range(first + w, first + count, nstreams):
+                    for i in (range(first, first + 1) if count == 0 else range(first + w, first + count, nstreams)):
                         out = step(i)
                         results[i] = (len(out['b_ids']), len(out['mkpts0_f']), out)
                     streams[w].synchronize()
@@ -189,7 +189,22 @@ def main():
     for t in pool:
         t.start()
 
+    def run_single(w, i):
+        """One step on pipeline w alone (count == 0 marks it)."""
+        jobs[w].put((i, 0))
+        r = done.get()
+        if isinstance(r, BaseException):
+            raise r
+
+    serial = [False]
+
     def run(first, count):
+        if serial[0]:
+            for i in range(first, first + count):
+                out = step(i)
+                results[i] = (len(out['b_ids']), len(out['mkpts0_f']), out)
+            torch.cuda.synchronize()
+            return
         for w in range(nstreams):
             jobs[w].put((first, count))
         for _ in range(nstreams):
@@ -221,8 +236,24 @@ def main():
     torch.cuda.synchronize()
     torch.cuda.synchronize()
     log('first forward done (MIOpen algorithm lookup / search)')
+    # each pipeline thread owns its MIOpen handle: let every one of them look its convolution algorithms up
+    # ALONE first (concurrent first lookups of the user find-db were seen to leave a handle on slow
+    # fallback picks for the whole process: 3.7x slower steps in ~1 of 10 fresh-box runs)
+    for w in range(nstreams):
+        run_single(w, w)
+    t = time.perf_counter()
+    step(0)
+    torch.cuda.synchronize()
+    t_serial = time.perf_counter() - t
+    t = time.perf_counter()
     run(0, args.warmup)
     torch.cuda.synchronize()
+    t_threads = (time.perf_counter() - t) / max(args.warmup, 1)
+    if nstreams > 1 and args.warmup >= 2 and t_threads > 1.5 * t_serial:
+        log(f'pipelined steps run at {t_threads * 1e3:.1f} ms against {t_serial * 1e3:.1f} ms single-threaded: '
+            f'falling back to one host pipeline')
+        serial[0] = True
+        nstreams = 1
     log('warm-up done')
     if dist is not None:
         dist.barrier()

@@ -149,8 +149,8 @@ __global__ __launch_bounds__(256) void la_apply(LaArgs a) {
 // fp16 path: both contractions on the matrix cores.
 //
 //   la16_kv  : per 128-token chunk, per head:  KV[d][v] += sum_tok K[tok][d] V[tok][v]  is an MFMA whose
-//              K dimension is the TOKEN, so the 32-token sub-tiles are written to LDS transposed
-//              ([channel][token], 64-B rows) and both operands become 16-B fragment reads; Ksum comes
+//              K dimension is the TOKEN: the 32-token sub-tiles go to LDS row-major and the operands are
+//              fetched with the transpose read ds_read_b64_tr_b16 (la16_tr_frag); Ksum comes
 //              from the same A operand against a ones B operand.  V is left unscaled in the fp32 state
 //              (v/S would be an fp16 subnormal); the 1/S scaling is applied when the state is cast to fp16.
 //   la16_apply: computed transposed, out^T[v][tok] = KV^T . Q^T, so the TOKEN sits on the lane: the
@@ -159,13 +159,32 @@ __global__ __launch_bounds__(256) void la_apply(LaArgs a) {
 // ---------------------------------------------------------------------------------------------
 constexpr int LT = 32;     // tokens per sub-tile
 
-__device__ __forceinline__ int t_off(int ch, int chunk) { return ch * 64 + ((chunk ^ ((ch >> 2) & 3)) << 4); }   // [ch][32 tok] image
+
+// [32 tok][576 B] row-major sub-tile image (512 B of channels + 64 B pad): 16-B vector writes, and the
+// token-major MFMA operand is read with the gfx950 transpose read (ds_read_b64_tr_b16: a 16-lane group
+// fetches a 4-token x 16-channel block and each lane receives one channel's 4 tokens).  With the 576-B
+// stride the 16 (token, channel-quad) addresses of both groups of a wave half fall on distinct banks.
+constexpr int TRS = 576;
+typedef short gf_v4s __attribute__((__vector_size__(4 * sizeof(short))));
+
+// operand fragment of one head for the 16-token k-step s2: lane (lr = channel, h2) gets tokens 16*s2 + 8*h2 + 0..7
+__device__ __forceinline__ v8h la16_tr_frag(const char* img, int head_ch0, int s2, int lane) {
+    const int G = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int tok0 = 16 * s2 + 8 * (G >> 1);
+    const char* base = img + (tok0 + q) * TRS + (head_ch0 + 16 * (G & 1) + 4 * p) * 2;
+    typedef __attribute__((address_space(3))) gf_v4s* LP;
+    const gf_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LP)(base));
+    const gf_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LP)(base + 4 * TRS));
+    typedef short v8s __attribute__((__vector_size__(8 * sizeof(short))));
+    const v8s both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(v8h, both);
+}
 
 template <int D>
 __global__ __launch_bounds__(256) void la16_kv(LaArgs a) {
     static_assert(D == 32, "coarse configuration");
-    __shared__ __attribute__((aligned(16))) char kt[256 * 64];
-    __shared__ __attribute__((aligned(16))) char vt[256 * 64];
+    __shared__ __attribute__((aligned(16))) char kt[LT * TRS];
+    __shared__ __attribute__((aligned(16))) char vt[LT * TRS];
     const int chunk = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h2 = lane >> 5, lr = lane & 31, C = a.C;
     const int s_begin = chunk * CHUNK, s_end = min(a.S, s_begin + CHUNK);
@@ -177,34 +196,42 @@ __global__ __launch_bounds__(256) void la16_kv(LaArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; ksum[i][r] = 0.f; }
     const v8h ones{(_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1};
-    for (int s0 = s_begin; s0 < s_end; s0 += LT) {
-        // ---- cooperative load of [32 tok][C] (16 B per thread and pass), transform, transposed LDS write
+    const v8h zero{0, 0, 0, 0, 0, 0, 0, 0};
+    v8h rk[4], rv[4];                            // the next sub-tile, in flight while this one is multiplied
+    auto fetch = [&](int s0) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int e = p * 256 + tid, tok = e >> 5, c8 = (e & 31) * 8;      // C = 256: 32 chunks per token
             const int s = s0 + tok;
-            v8h kk = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
+            rk[p] = zero;
+            rv[p] = zero;
             if (s < s_end && (a.kv_mask == nullptr || a.kv_mask[(size_t)n * a.S + s] != 0)) {
-                kk = *reinterpret_cast<const v8h*>(kp + (size_t)s * a.ldk + c8);
-                vv = *reinterpret_cast<const v8h*>(vp + (size_t)s * a.ldv + c8);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) kk[i] = (_Float16)elu1((float)kk[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int ch = c8 + i;
-                *reinterpret_cast<_Float16*>(kt + t_off(ch, tok >> 3) + (tok & 7) * 2) = kk[i];
-                *reinterpret_cast<_Float16*>(vt + t_off(ch, tok >> 3) + (tok & 7) * 2) = vv[i];
+                rk[p] = *reinterpret_cast<const v8h*>(kp + (size_t)s * a.ldk + c8);
+                rv[p] = *reinterpret_cast<const v8h*>(vp + (size_t)s * a.ldv + c8);
             }
         }
+    };
+    fetch(s_begin);
+    for (int s0 = s_begin; s0 < s_end; s0 += LT) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int e = p * 256 + tid, tok = e >> 5, c8 = (e & 31) * 8;
+            const bool ok = s0 + tok < s_end && (a.kv_mask == nullptr || a.kv_mask[(size_t)n * a.S + s0 + tok] != 0);
+            v8h kk = rk[p];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) kk[i] = ok ? (_Float16)elu1((float)kk[i]) : (_Float16)0;
+            *reinterpret_cast<v8h*>(kt + tok * TRS + c8 * 2) = kk;
+            *reinterpret_cast<v8h*>(vt + tok * TRS + c8 * 2) = rv[p];
+        }
         __syncthreads();
+        if (s0 + LT < s_end) fetch(s0 + LT);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int ch = (2 * wave + i) * D + lr;
+            const int ch0 = (2 * wave + i) * D;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const v8h kf = *reinterpret_cast<const v8h*>(kt + t_off(ch, 2 * s2 + h2));
-                const v8h vf = *reinterpret_cast<const v8h*>(vt + t_off(ch, 2 * s2 + h2));
+                const v8h kf = la16_tr_frag(kt, ch0, s2, lane);
+                const v8h vf = la16_tr_frag(vt, ch0, s2, lane);
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, vf, acc[i], 0, 0, 0);
                 ksum[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, ones, ksum[i], 0, 0, 0);
             }
