@@ -24,10 +24,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # MIOpen's convolution search results for the bench shapes are shipped with the repo (plain-text user
-# find-db for gfx950), so warm-up looks the algorithms up instead of re-running a multi-minute search
-os.environ.setdefault('MIOPEN_USER_DB_PATH', os.path.join(ROOT, 'geoformer_amd', 'miopen_db'))
-# compiled MIOpen kernels are cached next to it (git-ignored build artefact, like the .so)
-os.environ.setdefault('MIOPEN_CUSTOM_CACHE_DIR', os.path.join(ROOT, 'geoformer_amd', 'miopen_db', 'cache'))
+# find-db for gfx950), so warm-up looks the algorithms up instead of re-running a multi-minute search; every
+# process works on its own copy (geoformer_amd/miopen.py)
+from geoformer_amd import miopen as gf_miopen  # noqa: E402
+gf_miopen.use_shipped_find_db()
 
 import torch  # noqa: E402
 
@@ -230,6 +230,7 @@ def main():
         # the shipped find-db did not apply (other batch size / MIOpen build): let MIOpen search once
         log('slower than the tuned reference (1.7 ms/pair): running the MIOpen search (minutes) ...')
         torch.backends.cudnn.benchmark = True
+        args.tune = True
         bb_ms = backbone_ms_per_pair()
         log(f'backbone {bb_ms:.2f} ms/pair after the search')
     step(0)                          # single-threaded first pass: fills the weight / table caches
@@ -345,6 +346,8 @@ def main():
     if not args.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline(W, args.coarse_thr, args.fine_thr, args.size)
     print(json.dumps(res), flush=True)
+    if args.tune and rank == 0 and 'GEOFORMER_KEEP_SHIPPED_DB' not in os.environ:
+        gf_miopen.save_find_db()             # a search ran: keep its picks for the next process
     if dist is not None:
         dist.destroy_process_group()
 

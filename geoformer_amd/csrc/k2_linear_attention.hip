@@ -255,8 +255,10 @@ __global__ __launch_bounds__(256) void la16_kv(LaArgs a) {
 template <int D>
 __global__ __launch_bounds__(256) void la16_apply(LaArgs a) {
     static_assert(D == 32, "coarse configuration");
+    constexpr int RS = 272;                                              // slab row: 4 heads x 64 B + pad
     __shared__ __attribute__((aligned(16))) _Float16 kvt[8 * 32 * 32];   // [h][v][d]
     __shared__ __attribute__((aligned(16))) _Float16 ksh[8 * 32];        // [h][d]
+    __shared__ __attribute__((aligned(16))) char qs[4 * 32 * RS];        // per wave: 32 tokens x 4 heads of Q, then of out
     const int n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5, lr = lane & 31;
     const int C = a.C;
     const float* kvf = a.kvfinal + (size_t)n * (C * D + C);
@@ -269,36 +271,59 @@ __global__ __launch_bounds__(256) void la16_apply(LaArgs a) {
     }
     ksh[tid] = (_Float16)(kvf[C * D + tid] * inv_s);
     __syncthreads();
-    const int tok = blockIdx.x * 128 + wave * 32 + lr;
-    const bool live = tok < a.L;
-    const int tk = live ? tok : a.L - 1;
-    const bool qok = a.q_mask == nullptr || a.q_mask[(size_t)n * a.L + tk] != 0;
-    const _Float16* qp = (const _Float16*)a.q + ((size_t)n * a.L + tk) * a.ldq;
-    _Float16* op = (_Float16*)a.out + ((size_t)n * a.L + tk) * C;
-#pragma unroll 2
-    for (int h = 0; h < 8; ++h) {
-        v16f num, den;
+    // Q rows come in with 16-B-per-lane row-contiguous loads (4 heads = 256 B per token at a time) through a
+    // wave-private LDS slab; the MFMA B fragments are 16-B row reads of it; the result overwrites the head's
+    // own 64 bytes and leaves with the same row-contiguous pattern.
+    char* qt = qs + wave * 32 * RS;
+    const int tok0 = blockIdx.x * 128 + wave * 32;
+    const int prow = lane >> 4, pch = lane & 15;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { num[r] = 0.f; den[r] = 0.f; }
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 4 + prow, tok = min(tok0 + row, a.L - 1);
+            const bool qok = a.q_mask == nullptr || a.q_mask[(size_t)n * a.L + tok] != 0;
+            v8h qv = *reinterpret_cast<const v8h*>((const _Float16*)a.q + ((size_t)n * a.L + tok) * a.ldq + half * 128 + pch * 8);
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            v8h qf = *reinterpret_cast<const v8h*>(qp + h * D + 16 * s2 + 8 * h2);       // B: col = token, k = d
-#pragma unroll
-            for (int i = 0; i < 8; ++i) qf[i] = qok ? (_Float16)elu1((float)qf[i]) : (_Float16)0;
-            const v8h kf = *reinterpret_cast<const v8h*>(kvt + (h * 32 + lr) * 32 + 16 * s2 + 8 * h2);   // A: row = v
-            const v8h sf = *reinterpret_cast<const v8h*>(ksh + h * 32 + 16 * s2 + 8 * h2);              // A: every row = Ksum
-            num = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf, num, 0, 0, 0);
-            den = __builtin_amdgcn_mfma_f32_32x32x16_f16(sf, qf, den, 0, 0, 0);
+            for (int i = 0; i < 8; ++i) qv[i] = qok ? (_Float16)elu1((float)qv[i]) : (_Float16)0;
+            *reinterpret_cast<v8h*>(qt + row * RS + pch * 16) = qv;
         }
-        if (live) {
-            const float z = 1.0f / (den[0] + a.eps * inv_s);  // every row of den holds the token's Q.Ksum / S
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int v0 = 8 * r4 + 4 * h2;                // 4 consecutive v
-                *reinterpret_cast<v4h*>(op + h * D + v0) = v4h{(_Float16)(num[4 * r4] * z), (_Float16)(num[4 * r4 + 1] * z),
-                                                              (_Float16)(num[4 * r4 + 2] * z), (_Float16)(num[4 * r4 + 3] * z)};
+        for (int hh = 0; hh < 4; ++hh) {
+            const int h = half * 4 + hh;
+            v16f num, den;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { num[r] = 0.f; den[r] = 0.f; }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const v8h qf = *reinterpret_cast<const v8h*>(qt + lr * RS + (hh * 4 + 2 * s2 + h2) * 16);   // B: col = token, k = d
+                const v8h kf = *reinterpret_cast<const v8h*>(kvt + (h * 32 + lr) * 32 + 16 * s2 + 8 * h2);   // A: row = v
+                const v8h sf = *reinterpret_cast<const v8h*>(ksh + h * 32 + 16 * s2 + 8 * h2);              // A: every row = Ksum
+                num = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf, num, 0, 0, 0);
+                den = __builtin_amdgcn_mfma_f32_32x32x16_f16(sf, qf, den, 0, 0, 0);
             }
+            const float z = 1.0f / (den[0] + a.eps * inv_s);     // every row of den holds the token's Q.Ksum / S
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                *reinterpret_cast<v4h*>(qt + lr * RS + (hh * 32 + 8 * r4 + 4 * h2) * 2) =
+                    v4h{(_Float16)(num[4 * r4] * z), (_Float16)(num[4 * r4 + 1] * z), (_Float16)(num[4 * r4 + 2] * z),
+                        (_Float16)(num[4 * r4 + 3] * z)};
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 4 + prow, tok = tok0 + row;
+            if (tok < a.L)
+                *reinterpret_cast<v8h*>((_Float16*)a.out + ((size_t)n * a.L + tok) * C + half * 128 + pch * 8) =
+                    *reinterpret_cast<const v8h*>(qt + row * RS + pch * 16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

@@ -52,6 +52,8 @@ def load_gray_scale_tensor(im_path, device, imsize=None, dfactor=8, value_to_sca
 
 class GeoFormerMatcher:
     def __init__(self, imsize, match_threshold, no_match_upscale=False, ckpt=None, device='cuda', precision='fp32'):
+        from . import miopen
+        miopen.use_shipped_find_db()              # no-op if the caller configured MIOpen already
         self.device, self.imsize = device, imsize
         self.match_threshold, self.no_match_upscale = match_threshold, no_match_upscale
         conf = get_default_cfg()

@@ -3,7 +3,8 @@
 import os, sys, time
 here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, here)
-os.environ.setdefault('MIOPEN_USER_DB_PATH', os.path.join(here, 'geoformer_amd', 'miopen_db'))
+from geoformer_amd import miopen as gf_miopen
+gf_miopen.use_shipped_find_db()
 import torch
 import torch.nn as nn
 torch.backends.cudnn.benchmark = '--tune' in sys.argv
@@ -35,4 +36,6 @@ with torch.no_grad():
     for _ in range(5):
         fb(x)
     torch.cuda.synchronize()
+if '--tune' in sys.argv:
+    gf_miopen.save_find_db()
 print('pad', PAD, 'tune', torch.backends.cudnn.benchmark, 'backbone ms/call %.2f' % ((time.perf_counter() - t) / 5 * 1e3))
