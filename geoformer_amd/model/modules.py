@@ -100,7 +100,7 @@ class LoFTREncoderLayer(nn.Module):
         c = self.d_model
         return kv[..., :c], kv[..., c:]
 
-    def finish(self, x, message, row_flag=None, flag_rows=0):
+    def finish(self, x, message, row_flag=None, flag_rows=0, out=None):
         """x + norm2(mlp([x, norm1(merge(message))])) in three K3 launches: merge+LN, mlp.0 on the
         two-part operand (no concat) + activation, mlp.2+LN+residual.  row_flag (int32 per `flag_rows`
         rows) == 0 leaves x unchanged - GeoTransformer's per-sample 'layer skipped' cases."""
@@ -109,9 +109,10 @@ class LoFTREncoderLayer(nn.Module):
         message = ops.linear(message, w['merge'], epilogue=ops.EPI_LN, ln=w['n1'], eps=self.norm1.eps)
         hid = ops.linear(x, w['w1'], a2=message, epilogue=act)
         return ops.linear(hid, w['w2'], epilogue=ops.EPI_LN_RES, ln=w['n2'], eps=self.norm2.eps, residual=x,
-                          row_flag=row_flag, flag_rows=flag_rows)
+                          row_flag=row_flag, flag_rows=flag_rows, out=out)
 
-    def forward(self, x, source, x_mask: Optional[torch.Tensor] = None, source_mask: Optional[torch.Tensor] = None):
+    def forward(self, x, source, x_mask: Optional[torch.Tensor] = None, source_mask: Optional[torch.Tensor] = None,
+                out: Optional[torch.Tensor] = None):
         """x [N,L,C], source [N,S,C] -> [N,L,C]  (linear-attention flavour; the geometry-guided flavours
         are driven by GeoTransformer, which owns the token lists / windows)."""
         if self.attention_kind != 'linear':
@@ -119,7 +120,7 @@ class LoFTREncoderLayer(nn.Module):
         q = self.project_q(x)
         k, v = self.project_kv(source)
         message = ops.linear_attention(q, k, v, self.nhead, x_mask, source_mask)
-        return self.finish(x, message)
+        return self.finish(x, message, out=out)
 
 
 class LocalFeatureTransformer(nn.Module):
@@ -140,22 +141,30 @@ class LocalFeatureTransformer(nn.Module):
     def forward(self, feat0, feat1, mask0: Optional[torch.Tensor] = None, mask1: Optional[torch.Tensor] = None):
         assert self.d_model == feat0.size(2), 'the feature number of src and transformer must be equal'
         same = feat0.shape == feat1.shape
+        n = feat0.shape[0]
+        # same-shape pairs live in ONE [2N, L, C] buffer: self layers run both images in one batched launch set
+        # (same weights, independent rows) and cross layers write their halves in place of a concat
+        both = torch.cat([feat0, feat1], 0) if same else None
+        mboth = torch.cat([mask0, mask1], 0) if (same and mask0 is not None) else None
         for layer, name in zip(self.layers, self.layer_names):
             if name == 'self':
-                if same:      # both images through one batched launch set (same weights, independent rows)
-                    both = torch.cat([feat0, feat1], 0)
-                    m = None if mask0 is None else torch.cat([mask0, mask1], 0)
-                    both = layer(both, both, m, m)
-                    feat0, feat1 = both[:feat0.shape[0]], both[feat0.shape[0]:]
+                if same:
+                    both = layer(both, both, mboth, mboth)
                 else:
                     feat0 = layer(feat0, feat0, mask0, mask0)
                     feat1 = layer(feat1, feat1, mask1, mask1)
             elif name == 'cross':  # feat1 attends to the UPDATED feat0 (transformer.py:99-100)
-                feat0 = layer(feat0, feat1, mask0, mask1)
-                feat1 = layer(feat1, feat0, mask1, mask0)
+                if same:
+                    nxt = torch.empty_like(both)
+                    layer(both[:n], both[n:], mask0, mask1, out=nxt[:n])
+                    layer(both[n:], nxt[:n], mask1, mask0, out=nxt[n:])
+                    both = nxt
+                else:
+                    feat0 = layer(feat0, feat1, mask0, mask1)
+                    feat1 = layer(feat1, feat0, mask1, mask0)
             else:
                 raise KeyError
-        return feat0, feat1
+        return (both[:n], both[n:]) if same else (feat0, feat1)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -222,10 +231,12 @@ class GeoTransformer(nn.Module):
         n, L, S = feat0.shape[0], feat0.shape[1], feat1.shape[1]
         same = feat0.shape == feat1.shape
         nk = geo['nidx']
+        if same:                     # one [2N, L, C] buffer, as in LocalFeatureTransformer
+            both = torch.cat([feat0, feat1], 0)
+            feat0, feat1 = both[:n], both[n:]
         for layer, name in zip(self.layers, self.layer_names):
             if name == 'self':       # keys/values = tokens at inlier cells; a sample without any keeps its features
                 if same:
-                    both = torch.cat([feat0, feat1], 0)
                     k, v = layer.project_kv(both)
                     msg = ops.self_attention_gathered(layer.project_q(both), k, v, geo['idx_both'], geo['nidx_both'],
                                                       self.nhead)
@@ -245,8 +256,15 @@ class GeoTransformer(nn.Module):
                 k1, v1 = layer.project_kv(feat1)
                 m0 = ops.window_cross_attention(layer.project_q(feat0), k1, v1, geo['win1'], geo['valid'], self.nhead)
                 m1 = ops.window_cross_attention(layer.project_q(feat1), k0, v0, geo['win0'], geo['valid'], self.nhead)
-                feat0 = layer.finish(feat0, m0, geo['valid'], L)
-                feat1 = layer.finish(feat1, m1, geo['valid'], S)
+                if same:
+                    nxt = torch.empty_like(both)
+                    layer.finish(feat0, m0, geo['valid'], L, out=nxt[:n])
+                    layer.finish(feat1, m1, geo['valid'], S, out=nxt[n:])
+                    both = nxt
+                    feat0, feat1 = both[:n], both[n:]
+                else:
+                    feat0 = layer.finish(feat0, m0, geo['valid'], L)
+                    feat1 = layer.finish(feat1, m1, geo['valid'], S)
             else:
                 raise KeyError
         return feat0, feat1

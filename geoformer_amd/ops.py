@@ -349,7 +349,7 @@ def _rows2d(t):
 
 
 def linear(a1, w, a2=None, bias=None, rowgroup_bias=None, rowgroup_rows=0, epilogue=EPI_NONE, ln=None, eps=1e-5,
-           residual=None, row_flag=None, flag_rows=0):
+           residual=None, row_flag=None, flag_rows=0, out=None):
     """K3.  out[..., n] = epi([a1|a2] @ w.T + bias + rowgroup_bias); see include/geoformer_hip.h (gf_linear).
     ln = (gamma fp32 [N], beta fp32 [N]) for the LayerNorm epilogues."""
     _need_cuda(a1, w)
@@ -361,7 +361,10 @@ def linear(a1, w, a2=None, bias=None, rowgroup_bias=None, rowgroup_rows=0, epilo
         k2 = a2.shape[-1]
     N = w.shape[0]
     M = a1.numel() // k1
-    out = torch.empty(*a1.shape[:-1], N, dtype=a1.dtype, device=a1.device)
+    if out is None:
+        out = torch.empty(*a1.shape[:-1], N, dtype=a1.dtype, device=a1.device)
+    elif out.shape != (*a1.shape[:-1], N) or out.dtype != a1.dtype or not out.is_contiguous():
+        raise ValueError('out must be a contiguous tensor of the result shape and dtype')
     res, ldres = (None, 0) if residual is None else _rows2d(residual)
     g, b = (None, None) if ln is None else ln
     check(_lib.lib().gf_linear(_p(a1), lda1, k1, _p(a2), lda2, k2, _p(w), _p(bias), _p(rowgroup_bias), int(rowgroup_rows),
