@@ -1,0 +1,19 @@
+"""Where the autograd training step spends its time (torch profiler, top ops by device time)."""
+import sys, time, torch
+sys.path.insert(0, '.')
+from geoformer_amd import miopen; miopen.use_shipped_find_db()
+from geoformer_amd.model.cvpr_ds_config import get_default_cfg
+from geoformer_amd.model.full_model import GeoFormer
+from geoformer_amd.model.geo_config import get_cfg_model
+from geoformer_amd.weights import deterministic_init_
+from geoformer_amd.train import TrainStep, synthetic_homography_batch
+g = get_cfg_model(); g.update(coarse_thr=0.0, fine_thr=0.0, precision='fp32')
+model = deterministic_init_(GeoFormer(get_default_cfg(), g)).cuda()
+step = TrainStep(model, batch_size=2)
+for it in range(3):
+    t = time.perf_counter(); step(synthetic_homography_batch(2, (480, 640), seed=it, device='cuda')); torch.cuda.synchronize()
+    print('step', it, '%.2f s' % (time.perf_counter() - t), flush=True)
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    step(synthetic_homography_batch(2, (480, 640), seed=9, device='cuda')); torch.cuda.synchronize()
+print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=25, max_name_column_width=50))
