@@ -27,7 +27,6 @@
 // MFMA + fragment reads, 4000 (thr > 0) to 5200 (dense candidates) epilogue - the epilogue is paced by the
 // HBM write drain (32 KiB per tile per workgroup = ~3500 ticks at the measured 5.6 TB/s store ceiling).
 #include <math.h>
-#include <stdlib.h>
 
 #include <type_traits>
 
@@ -759,7 +758,7 @@ int k1_launch(K1Args a, SelArgs s, void* zero_begin, size_t zero_bytes, hipStrea
     const int mx = a.L > a.S ? a.L : a.S;
     k1_reduce_stats<EXACT><<<dim3((mx + 31) / 32, 2, a.N), 256, 0, st>>>(a);
     void* p1 = gf_prof_begin("k1_conf", st, (double)a.N * ((double)(a.L + a.S) * a.C * sizeof(T) + (double)a.L * a.S * 4.0));
-    const bool panel = !EXACT && a.mask0 == nullptr && a.L % BM == 0 && a.S % BN == 0 && a.C == 256 && getenv("GF_K1_NOPANEL") == nullptr;
+    const bool panel = !EXACT && a.mask0 == nullptr && a.L % BM == 0 && a.S % BN == 0 && a.C == 256;
     if (panel) {
         const int units = a.N * a.tilesM * ((a.tilesN + PANEL_TILES - 1) / PANEL_TILES);
         const int wgs = units < 512 ? units : 512;           // two resident workgroups per CU

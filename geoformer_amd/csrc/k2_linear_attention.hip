@@ -338,9 +338,105 @@ int la16_launch(const LaArgs& a, hipStream_t st) {
     return GF_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// short sequences (S, L <= CHUNK: the fine level has 25-token windows and ~2M of them): the whole
+// attention of one sample in ONE workgroup - the D x D state goes from the KV phase to the apply phase
+// through LDS instead of a global round trip and two more launches.  Same summation order as
+// la_kv_partial / la_apply with one chunk, so the results are bit-identical to that path.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(256) void la_small(LaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* row = reinterpret_cast<float*>(smem);                 // [TOK][C] staging (V rows, then Q rows)
+    float* kvs = row + TOK * a.C;                                // [C][D]: element (c = h*D + d, v)
+    float* kss = kvs + a.C * D;                                  // [C]
+    const int n = blockIdx.x, t = threadIdx.x, C = a.C;
+    const int h0 = (t / D) * D, vi = t % D;
+    const T* kp = (const T*)a.k + (size_t)n * a.S * a.ldk;
+    const T* vp = (const T*)a.v + (size_t)n * a.S * a.ldv;
+    const float slen = (float)a.S;
+    float acc[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) acc[i] = 0.f;
+    float ksum = 0.f;
+    for (int s0 = 0; s0 < a.S; s0 += TOK) {
+        float kk[TOK];
+#pragma unroll
+        for (int j = 0; j < TOK; ++j) {
+            const int s = s0 + j;
+            float kv = 0.f, vv = 0.f;
+            if (s < a.S && (a.kv_mask == nullptr || a.kv_mask[(size_t)n * a.S + s] != 0)) {
+                kv = elu1(gf_to_float(kp[(size_t)s * a.ldk + t]));
+                vv = gf_to_float(vp[(size_t)s * a.ldv + t]) / slen;
+            }
+            kk[j] = kv;
+            row[j * C + t] = vv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TOK; ++j) {
+            const float kv = kk[j];
+            ksum += kv;
+            const v4f* vr = reinterpret_cast<const v4f*>(row + j * C + h0);
+#pragma unroll
+            for (int i = 0; i < D / 4; ++i) {
+                const v4f x = vr[i];
+                acc[4 * i + 0] += kv * x.x;
+                acc[4 * i + 1] += kv * x.y;
+                acc[4 * i + 2] += kv * x.z;
+                acc[4 * i + 3] += kv * x.w;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) kvs[t * D + i] = acc[i];
+    kss[t] = ksum;
+    __syncthreads();
+    float kv[D], ks[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        kv[d] = kvs[(h0 + d) * D + vi];      // KV[h][d][v]
+        ks[d] = kss[h0 + d];
+    }
+    const T* qp = (const T*)a.q + (size_t)n * a.L * a.ldq;
+    T* op = (T*)a.out + (size_t)n * a.L * C;
+    for (int l0 = 0; l0 < a.L; l0 += TOK) {
+#pragma unroll
+        for (int j = 0; j < TOK; ++j) {
+            const int l = l0 + j;
+            float qv = 0.f;
+            if (l < a.L && (a.q_mask == nullptr || a.q_mask[(size_t)n * a.L + l] != 0))
+                qv = elu1(gf_to_float(qp[(size_t)l * a.ldq + t]));
+            row[j * C + t] = qv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TOK; ++j) {
+            const int l = l0 + j;
+            const v4f* qr = reinterpret_cast<const v4f*>(row + j * C + h0);
+            float num = 0.f, den = 0.f;
+#pragma unroll
+            for (int i = 0; i < D / 4; ++i) {
+                const v4f x = qr[i];
+                num += x.x * kv[4 * i] + x.y * kv[4 * i + 1] + x.z * kv[4 * i + 2] + x.w * kv[4 * i + 3];
+                den += x.x * ks[4 * i] + x.y * ks[4 * i + 1] + x.z * ks[4 * i + 2] + x.w * ks[4 * i + 3];
+            }
+            const float z = 1.0f / (den + a.eps);
+            if (l < a.L) op[(size_t)l * C + t] = gf_from_float<T>(num * z * slen);
+        }
+        __syncthreads();
+    }
+}
+
 template <typename T, int D>
 int la_launch(const LaArgs& a, hipStream_t st) {
     const size_t lds = (size_t)TOK * a.C * sizeof(float);
+    if (a.S <= CHUNK && a.L <= CHUNK) {
+        la_small<T, D><<<a.N, a.C, lds + (size_t)a.C * (D + 1) * sizeof(float), st>>>(a);
+        GF_CHECK_LAUNCH();
+        return GF_OK;
+    }
     la_kv_partial<T, D><<<dim3(a.nchunks, a.N), a.C, lds, st>>>(a);
     if (a.nchunks > 1) {
         const int len = a.C * a.D + a.C;
