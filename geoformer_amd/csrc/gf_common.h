@@ -12,6 +12,7 @@ typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef _Float16 v4h __attribute__((ext_vector_type(4)));
 typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef short gf_v4s __attribute__((__vector_size__(4 * sizeof(short))));   // result of ds_read_b64_tr_b16
 
 // ---------------------------------------------------------------------------------------------
 // error plumbing: every extern "C" entry returns 0 or a negative code and never throws

@@ -804,6 +804,233 @@ K1Workspace k1_carve(void* ws, int N, int L, int S) {
     return w;
 }
 
+// =============================================================================================
+// Training: the sparse-supervision focal loss on the dual-softmax confidence and its backward,
+// WITHOUT materialising conf or dS.  With p_ij = softmax_col(S)_ij * softmax_row(S)_ij and the loss a sum
+// over the ground-truth positives (i, j) of l(p_ij)  (loftr_loss.py:246-270, coarse_matching.py:113-125):
+//     d log p_ij / dS_kl = 2 d_ik d_jl - d_jl A_kl - d_ik B_kl,   A = softmax over rows, B = softmax over columns
+//     dS = 2 G - A o (1 gc^T) - B o (gr 1^T),   g_ij = dL/dlog p_ij,  gr_k = sum_j g_kj,  gc_l = sum_i g_il
+//     dF0 = mult * dS . F1,   dF1 = mult * dS^T . F0                    (S = mult * F0 . F1^T)
+// k1_grad_panel computes one side's dense part: a workgroup keeps 128 rows of `fa` as MFMA fragments in
+// registers (as k1_conf_panel), streams the other side's 64-row tiles through LDS, recomputes the similarity
+// tile TRANSPOSED (lane = its panel row, registers = the tile's rows), turns it into
+// W = exp(S - m_a)(g_a / l_a) + exp(S - m_b)(g_b / l_b) in registers and feeds it - accumulator as B operand,
+// no data movement - to a second MFMA against the tile read column-wise (ds_read_b64_tr_b16), accumulating
+// dFa^T for its 128 rows over the whole sweep.  W is scaled into fp16 range by 8192 / max|g|.
+// =============================================================================================
+struct GrArgs {
+    const _Float16* fa;      // [N][La][256] panel side
+    const _Float16* fb;      // [N][Lb][256] streamed side
+    const float2* sa;        // [N][La] (max, sumexp) of the softmax that normalises over the OTHER side's index
+    const float2* sb;        // [N][Lb]
+    const float* ga;         // [N][La] g summed per panel row
+    const float* gb;         // [N][Lb]
+    const unsigned* gmax;    // bits of max |g| (device)
+    float mult;
+    float* dfa;              // [N][La][256] fp32, written (not accumulated)
+    int N, La, Lb, tilesA, tilesB;
+};
+
+__global__ __launch_bounds__(NT, 1) void k1_grad_panel(GrArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* bst = reinterpret_cast<float2*>(smem + BN * 512);             // [64] streamed-side (c, w)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, lr = lane & 31;
+    const int bm = blockIdx.x % a.tilesA, n = blockIdx.x / a.tilesA, m0 = bm * BM;
+    const int srow = tid >> 5, schunk = tid & 31;
+    const float gmax = __uint_as_float(*a.gmax);
+    const float sw = gmax > 0.f ? 8192.0f / gmax : 0.f;                   // W * sw fits fp16 comfortably
+    const float k2 = a.mult * LOG2E;
+    const _Float16* A = a.fa + ((size_t)n * a.La + m0 + wave * 32 + lr) * 256 + h * 8;
+    const _Float16* B = a.fb + (size_t)n * a.Lb * 256;
+    v8h af[16];
+#pragma unroll
+    for (int kg = 0; kg < 16; ++kg) af[kg] = *reinterpret_cast<const v8h*>(A + kg * 16);
+    // this lane's panel row: -m*log2e and g/l scaled
+    const int krow = m0 + wave * 32 + lr;
+    const float2 sta = a.sa[(size_t)n * a.La + krow];
+    const float ra = -sta.x * LOG2E, wa = a.ga[(size_t)n * a.La + krow] * __builtin_amdgcn_rcpf(sta.y) * sw;
+    v16f dacc[8];
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dacc[cb][r] = 0.f;
+    v4u rb[8];
+    float2 cs = make_float2(0.f, 0.f);
+    auto prefetch = [&](int bn) {
+        const _Float16* g = B + (size_t)(bn * BN + srow) * 256 + schunk * 8;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) rb[p] = *reinterpret_cast<const v4u*>(g + (size_t)p * 8 * 256);
+        if (tid < BN) {
+            const float2 st = a.sb[(size_t)n * a.Lb + bn * BN + tid];
+            cs = make_float2(-st.x * LOG2E, a.gb[(size_t)n * a.Lb + bn * BN + tid] * __builtin_amdgcn_rcpf(st.y) * sw);
+        }
+    };
+    prefetch(0);
+    typedef __attribute__((address_space(3))) gf_v4s* LP;
+    for (int bn = 0; bn < a.tilesB; ++bn) {
+        __syncthreads();                                   // the previous tile is consumed
+#pragma unroll
+        for (int p = 0; p < 8; ++p) *reinterpret_cast<v4u*>(smem + k1p_off(srow + 8 * p, schunk)) = rb[p];
+        if (tid < BN) bst[tid] = cs;
+        __syncthreads();
+        if (bn + 1 < a.tilesB) prefetch(bn + 1);
+        // ---- similarity tile, transposed: D[row = tile row l][col = panel row k]
+        v16f acc[2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+#pragma unroll
+        for (int kg = 0; kg < 16; ++kg) {
+            const v8h b0 = *reinterpret_cast<const v8h*>(smem + k1p_off(lr, 2 * kg + h));
+            const v8h b1 = *reinterpret_cast<const v8h*>(smem + k1p_off(32 + lr, 2 * kg + h));
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, af[kg], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, af[kg], acc[1], 0, 0, 0);
+        }
+        // ---- W^T in registers (fp16), then dFa^T[c][k] += sum_l Fb[l][c] W[l][k]
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {                   // 16 tile rows per k-group
+            const int ni = gg >> 1, r0 = 8 * (gg & 1);
+            v8h wf;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int l0 = ni * 32 + 8 * ((r0 >> 2) + q) + 4 * h;       // rows of registers r0+4q .. r0+4q+3
+                const v4f s01 = *reinterpret_cast<const v4f*>(bst + l0);
+                const v4f s23 = *reinterpret_cast<const v4f*>(bst + l0 + 2);
+                const float cbv[4] = {s01.x, s01.z, s23.x, s23.z}, wbv[4] = {s01.y, s01.w, s23.y, s23.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float s2 = acc[ni][r0 + 4 * q + j] * k2;
+                    const float w = __builtin_amdgcn_exp2f(s2 + ra) * wa + __builtin_amdgcn_exp2f(s2 + cbv[j]) * wbv[j];
+                    wf[4 * q + j] = (_Float16)w;
+                }
+            }
+            const int G = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
+            const int lrow = gg * 16 + 4 * (G >> 1) + q4;                   // + 8 for the second read
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+                const int ch = cb * 32 + 16 * (G & 1) + 4 * p4;             // 4 channels this lane addresses
+                const int chunk = ch >> 3, sub = (ch & 7) * 2;
+                const gf_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LP)(smem + k1p_off(lrow, chunk) + sub));
+                const gf_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LP)(smem + k1p_off(lrow + 8, chunk) + sub));
+                typedef short v8s __attribute__((__vector_size__(8 * sizeof(short))));
+                const v8s both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                dacc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, both), wf, dacc[cb], 0, 0, 0);
+            }
+        }
+    }
+    // ---- dFa = -(mult / sw) * accumulated; lane = panel row, registers = channels
+    const float fin = sw > 0.f ? -a.mult / sw : 0.f;
+    float* op = a.dfa + ((size_t)n * a.La + krow) * 256;
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int c = cb * 32 + 8 * r4 + 4 * h;
+            *reinterpret_cast<v4f*>(op + c) = v4f{dacc[cb][4 * r4] * fin, dacc[cb][4 * r4 + 1] * fin, dacc[cb][4 * r4 + 2] * fin,
+                                                  dacc[cb][4 * r4 + 3] * fin};
+        }
+}
+
+struct PosArgs {
+    const _Float16* f0;
+    const _Float16* f1;
+    const float2* rstat;
+    const float2* cstat;
+    const int64_t* pb;
+    const int64_t* pi;
+    const int64_t* pj;
+    const float* pw;         // per-positive weight or null
+    float* conf;             // [P] p_ij
+    float* loss;             // [P] focal term (weighted)
+    float* grad;             // [P] dL_k / dlog p_k (weighted, unscaled)
+    float* gr;               // [N][L]
+    float* gc;               // [N][S]
+    unsigned* gmax;
+    float* d0;               // dF0 / dF1 for the sparse 2G term
+    float* d1;
+    int P, L, S;
+    float mult, alpha, gamma, scale;
+};
+
+// one wave per positive: p = exp(s - mr)/lr * exp(s - mc)/lc, focal term and its derivative
+__global__ __launch_bounds__(256) void k1_pos_loss(PosArgs a) {
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k >= a.P) return;
+    const int b = (int)a.pb[k], i = (int)a.pi[k], j = (int)a.pj[k];
+    const v4h x = *reinterpret_cast<const v4h*>(a.f0 + ((size_t)b * a.L + i) * 256 + lane * 4);
+    const v4h y = *reinterpret_cast<const v4h*>(a.f1 + ((size_t)b * a.S + j) * 256 + lane * 4);
+    float d = (float)x.x * (float)y.x + (float)x.y * (float)y.y + (float)x.z * (float)y.z + (float)x.w * (float)y.w;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+    if (lane != 0) return;
+    const float s = d * a.mult;
+    const float2 r = a.rstat[(size_t)b * a.L + i], c = a.cstat[(size_t)b * a.S + j];
+    const float p = (__expf(s - r.x) / r.y) * (__expf(s - c.x) / c.y);
+    const float w = a.pw ? a.pw[k] : 1.0f;
+    const float pc = fminf(fmaxf(p, 1e-6f), 1.0f - 1e-6f);              // torch.clamp(conf, 1e-6, 1 - 1e-6)
+    const float om = 1.0f - pc, lg = __logf(pc), pw_ = powf(om, a.gamma);
+    a.conf[k] = p;
+    a.loss[k] = -a.alpha * pw_ * lg * w;
+    // d/dp of -alpha (1-p)^gamma log p, zero where the clamp is active; times p = d/dlog p
+    const float dldp = (p > 1e-6f && p < 1.0f - 1e-6f) ? a.alpha * (a.gamma * powf(om, a.gamma - 1.0f) * lg - pw_ / pc) * w : 0.f;
+    a.grad[k] = dldp * pc;
+}
+
+// g_k * scale -> row / column sums and the running max |g|
+__global__ void k1_pos_scatter(PosArgs a) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.P) return;
+    const int b = (int)a.pb[k], i = (int)a.pi[k], j = (int)a.pj[k];
+    const float g = a.grad[k] * a.scale;
+    atomicAdd(a.gr + (size_t)b * a.L + i, g);
+    atomicAdd(a.gc + (size_t)b * a.S + j, g);
+    atomicMax(a.gmax, __float_as_uint(fabsf(g)));
+}
+
+// the sparse 2G term: dF0[i] += 2 g mult F1[j], dF1[j] += 2 g mult F0[i]
+__global__ __launch_bounds__(256) void k1_pos_grad(PosArgs a) {
+    const int k = blockIdx.x, t = threadIdx.x;
+    const int b = (int)a.pb[k], i = (int)a.pi[k], j = (int)a.pj[k];
+    const float g2 = 2.0f * a.grad[k] * a.scale * a.mult;
+    atomicAdd(a.d0 + ((size_t)b * a.L + i) * 256 + t, g2 * (float)a.f1[((size_t)b * a.S + j) * 256 + t]);
+    atomicAdd(a.d1 + ((size_t)b * a.S + j) * 256 + t, g2 * (float)a.f0[((size_t)b * a.L + i) * 256 + t]);
+}
+
+__global__ void k1_cast_f16(const float* x, _Float16* y, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const v4f v = reinterpret_cast<const v4f*>(x)[i];
+        reinterpret_cast<v4h*>(y)[i] = v4h{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    }
+}
+
+struct LossWs {
+    _Float16 *f0h, *f1h;
+    float2 *rowpart, *colpart, *rstat, *cstat;
+    float *gr, *gc;
+    unsigned* gmax;
+    size_t zero_off, zero_bytes, bytes;
+};
+
+LossWs loss_carve(void* ws, int N, int L, int S) {
+    const int tilesM = (L + BM - 1) / BM, tilesN = (S + BN - 1) / BN;
+    GfCarver c(ws);
+    LossWs w;
+    w.f0h = c.take<_Float16>((size_t)N * L * 256);
+    w.f1h = c.take<_Float16>((size_t)N * S * 256);
+    w.rowpart = c.take<float2>((size_t)N * tilesN * L);
+    w.colpart = c.take<float2>((size_t)N * tilesM * S);
+    w.rstat = c.take<float2>((size_t)N * L);
+    w.cstat = c.take<float2>((size_t)N * S);
+    w.zero_off = c.used();
+    w.gr = c.take<float>((size_t)N * L);
+    w.gc = c.take<float>((size_t)N * S);
+    w.gmax = c.take<unsigned>(1);
+    w.zero_bytes = c.used() - w.zero_off;
+    w.bytes = c.used();
+    return w;
+}
+
 }   // namespace
 
 extern "C" size_t gf_dual_softmax_workspace_bytes(int N, int L, int S) {
@@ -849,4 +1076,89 @@ extern "C" int gf_dual_softmax_match(const void* f0, const void* f1, int dtype, 
     hipStream_t st = (hipStream_t)stream;
     return dtype == GF_F32 ? k1_launch<float>(a, s, w.rowbest, w.zero_bytes, st)
                            : k1_launch<_Float16>(a, s, w.rowbest, w.zero_bytes, st);
+}
+
+extern "C" size_t gf_coarse_loss_workspace_bytes(int N, int L, int S) {
+    if (N <= 0 || L <= 0 || S <= 0) return 0;
+    return loss_carve(nullptr, N, L, S).bytes;
+}
+
+static int coarse_loss_check(const char* fn, int N, int L, int S, int C, int P, void* workspace, size_t workspace_bytes) {
+    if (!(N > 0 && L > 0 && S > 0 && P > 0)) { gf_set_error("%s: empty problem", fn); return GF_ERR_INVALID_ARGUMENT; }
+    if (C != 256 || L % BM != 0 || S % BN != 0) {
+        gf_set_error("%s: built for C = 256, L %% 128 == 0, S %% 64 == 0 (the coarse level)", fn);
+        return GF_ERR_INVALID_ARGUMENT;
+    }
+    if (workspace == nullptr || workspace_bytes < gf_coarse_loss_workspace_bytes(N, L, S)) {
+        gf_set_error("%s: workspace too small", fn);
+        return GF_ERR_WORKSPACE;
+    }
+    return GF_OK;
+}
+
+extern "C" int gf_coarse_loss_forward(const void* f0, const void* f1, int dtype, int N, int L, int S, int C,
+                                      float temperature, const int64_t* pos_b, const int64_t* pos_i, const int64_t* pos_j,
+                                      int P, const float* pos_weight, float alpha, float gamma, float* pos_conf,
+                                      float* pos_loss, float* pos_grad, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+    GF_CHECK_ARG(f0 && f1 && pos_b && pos_i && pos_j && pos_conf && pos_loss && pos_grad, "null pointer");
+    GF_CHECK_ARG(dtype == GF_F32 || dtype == GF_F16, "dtype must be GF_F32 or GF_F16");
+    GF_CHECK_ARG(temperature > 0.f, "bad temperature");
+    const int rc = coarse_loss_check("gf_coarse_loss_forward", N, L, S, C, P, workspace, workspace_bytes);
+    if (rc != GF_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const LossWs w = loss_carve(workspace, N, L, S);
+    if (dtype == GF_F32) {
+        k1_cast_f16<<<2048, 256, 0, st>>>((const float*)f0, w.f0h, (size_t)N * L * 64);
+        k1_cast_f16<<<2048, 256, 0, st>>>((const float*)f1, w.f1h, (size_t)N * S * 64);
+    } else {
+        (void)hipMemcpyAsync(w.f0h, f0, (size_t)N * L * 512, hipMemcpyDeviceToDevice, st);
+        (void)hipMemcpyAsync(w.f1h, f1, (size_t)N * S * 512, hipMemcpyDeviceToDevice, st);
+    }
+    K1Args a{};
+    a.f0 = w.f0h; a.f1 = w.f1h; a.N = N; a.L = L; a.S = S; a.C = C;
+    a.inv_c = 1.0f / (float)C; a.temperature = temperature; a.mult = (1.0f / (float)C) / temperature;
+    a.tilesM = L / BM; a.tilesN = S / BN;
+    a.rowpart = w.rowpart; a.colpart = w.colpart; a.rstat = w.rstat; a.cstat = w.cstat;
+    k1_stats<_Float16><<<dim3(a.tilesN * a.tilesM, N), NT, STAGE_BYTES, st>>>(a);
+    const int mx = L > S ? L : S;
+    k1_reduce_stats<false><<<dim3((mx + 31) / 32, 2, N), 256, 0, st>>>(a);
+    PosArgs p{};
+    p.f0 = w.f0h; p.f1 = w.f1h; p.rstat = w.rstat; p.cstat = w.cstat; p.pb = pos_b; p.pi = pos_i; p.pj = pos_j;
+    p.pw = pos_weight; p.conf = pos_conf; p.loss = pos_loss; p.grad = pos_grad; p.P = P; p.L = L; p.S = S;
+    p.mult = a.mult; p.alpha = alpha; p.gamma = gamma;
+    k1_pos_loss<<<(P + 3) / 4, 256, 0, st>>>(p);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}
+
+extern "C" int gf_coarse_loss_backward(int N, int L, int S, int C, float temperature, const int64_t* pos_b,
+                                       const int64_t* pos_i, const int64_t* pos_j, int P, const float* pos_grad,
+                                       float scale, float* d_f0, float* d_f1, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+    GF_CHECK_ARG(pos_b && pos_i && pos_j && pos_grad && d_f0 && d_f1, "null pointer");
+    const int rc = coarse_loss_check("gf_coarse_loss_backward", N, L, S, C, P, workspace, workspace_bytes);
+    if (rc != GF_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const LossWs w = loss_carve(workspace, N, L, S);
+    (void)hipMemsetAsync((char*)workspace + w.zero_off, 0, w.zero_bytes, st);
+    PosArgs p{};
+    p.f0 = w.f0h; p.f1 = w.f1h; p.pb = pos_b; p.pi = pos_i; p.pj = pos_j; p.grad = const_cast<float*>(pos_grad);
+    p.gr = w.gr; p.gc = w.gc; p.gmax = w.gmax; p.d0 = d_f0; p.d1 = d_f1; p.P = P; p.L = L; p.S = S;
+    p.mult = (1.0f / (float)C) / temperature; p.scale = scale;
+    k1_pos_scatter<<<(P + 255) / 256, 256, 0, st>>>(p);
+    GrArgs g{};
+    g.gmax = w.gmax; g.mult = p.mult; g.N = N;
+    // dF0: panel = f0 rows (row statistics, gr), streamed = f1 rows (column statistics, gc)
+    g.fa = w.f0h; g.fb = w.f1h; g.sa = w.rstat; g.sb = w.cstat; g.ga = w.gr; g.gb = w.gc; g.dfa = d_f0;
+    g.La = L; g.Lb = S; g.tilesA = L / BM; g.tilesB = S / BN;
+    k1_grad_panel<<<N * g.tilesA, NT, PANEL_LDS, st>>>(g);
+    // dF1: roles swapped (S must then tile by 128 and L by 64)
+    GF_CHECK_ARG(S % BM == 0 && L % BN == 0, "S must be a multiple of 128 too");
+    g.fa = w.f1h; g.fb = w.f0h; g.sa = w.cstat; g.sb = w.rstat; g.ga = w.gc; g.gb = w.gr; g.dfa = d_f1;
+    g.La = S; g.Lb = L; g.tilesA = S / BM; g.tilesB = L / BN;
+    k1_grad_panel<<<N * g.tilesA, NT, PANEL_LDS, st>>>(g);
+    k1_pos_grad<<<P, 256, 0, st>>>(p);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
 }

@@ -165,7 +165,6 @@ constexpr int LT = 32;     // tokens per sub-tile
 // fetches a 4-token x 16-channel block and each lane receives one channel's 4 tokens).  With the 576-B
 // stride the 16 (token, channel-quad) addresses of both groups of a wave half fall on distinct banks.
 constexpr int TRS = 576;
-typedef short gf_v4s __attribute__((__vector_size__(4 * sizeof(short))));
 
 // operand fragment of one head for the 16-token k-step s2: lane (lr = channel, h2) gets tokens 16*s2 + 8*h2 + 0..7
 __device__ __forceinline__ v8h la16_tr_frag(const char* img, int head_ch0, int s2, int lane) {

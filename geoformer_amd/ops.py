@@ -371,3 +371,50 @@ def linear(a1, w, a2=None, bias=None, rowgroup_bias=None, rowgroup_rows=0, epilo
                                int(epilogue), _p(g), _p(b), float(eps), _p(res), ldres, _p(row_flag), int(flag_rows), _p(out),
                                N, _dt(a1), M, N, _stream()), 'gf_linear')
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# training: fused dual-softmax focal loss (forward + backward in HIP, nothing L x S is materialised)
+# ---------------------------------------------------------------------------------------------
+class CoarseFocalLoss(torch.autograd.Function):
+    """sum_k -alpha (1 - p_k)^gamma log p_k * w_k over the positives k = (b, i, j), p = the dual-softmax confidence
+    of (f0, f1) at temperature `temperature` (loftr_loss.py:246-270 on coarse_matching.py:113-125).  Returns
+    (loss_sum, p [P]); gradients flow to f0 and f1 only."""
+
+    @staticmethod
+    def forward(ctx, f0, f1, pos_b, pos_i, pos_j, temperature, alpha, gamma, weight):
+        _need_cuda(f0, f1, pos_b)
+        N, L, C = f0.shape
+        S = f1.shape[1]
+        P = pos_b.numel()
+        f0c, f1c = _contig(f0), _contig(f1)
+        if f0c.dtype not in _DTYPES or f1c.dtype != f0c.dtype:
+            raise ValueError('f0/f1 must both be fp32 or fp16')
+        L_ = _lib.lib()
+        ws = torch.empty(L_.gf_coarse_loss_workspace_bytes(N, L, S), dtype=torch.uint8, device=f0.device)
+        conf = torch.empty(P, dtype=torch.float32, device=f0.device)
+        loss, grad = torch.empty_like(conf), torch.empty_like(conf)
+        pb, pi, pj = _contig(pos_b.long()), _contig(pos_i.long()), _contig(pos_j.long())
+        w = None if weight is None else _contig(weight.float())
+        check(L_.gf_coarse_loss_forward(_p(f0c), _p(f1c), _dt(f0c), N, L, S, C, float(temperature), _p(pb), _p(pi), _p(pj), P, _p(w),
+                                        float(alpha), float(gamma), _p(conf), _p(loss), _p(grad), _p(ws), ws.numel(), _stream()),
+              'gf_coarse_loss_forward')
+        ctx.save_for_backward(pb, pi, pj, grad, ws)
+        ctx.meta = (N, L, S, C, float(temperature), f0.dtype)
+        ctx.mark_non_differentiable(conf)
+        return loss.sum(), conf
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_conf):
+        pb, pi, pj, grad, ws = ctx.saved_tensors
+        N, L, S, C, temperature, dtype = ctx.meta
+        d0 = torch.empty(N, L, C, dtype=torch.float32, device=grad.device)
+        d1 = torch.empty(N, S, C, dtype=torch.float32, device=grad.device)
+        check(_lib.lib().gf_coarse_loss_backward(N, L, S, C, temperature, _p(pb), _p(pi), _p(pj), pb.numel(), _p(grad),
+                                                 float(g_loss), _p(d0), _p(d1), _p(ws), ws.numel(), _stream()),
+              'gf_coarse_loss_backward')
+        return d0.to(dtype), d1.to(dtype), None, None, None, None, None, None, None
+
+
+def coarse_focal_loss(f0, f1, pos_b, pos_i, pos_j, temperature, alpha=0.25, gamma=2.0, weight=None):
+    return CoarseFocalLoss.apply(f0, f1, pos_b, pos_i, pos_j, temperature, alpha, gamma, weight)

@@ -74,11 +74,20 @@ class GeoLoss(nn.Module):
             return (data['mask0'].flatten(-2)[..., None] * data['mask1'].flatten(-2)[:, None]).float()
         return None
 
+    def fused_params(self):
+        """(alpha, gamma) if this loss is the configuration the fused HIP coarse loss implements, else None."""
+        return (self.cfg['focal_alpha'], self.cfg['focal_gamma']) if (self.cfg['coarse_type'] == 'focal' and self.sparse_spvs) else None
+
     def forward(self, data):
         """loftr_loss.py:353-395: loss = (loss_c + loss_d)*coarse_weight + loss_f*fine_weight."""
-        w = self.compute_c_weight(data)
-        loss_c = self.compute_coarse_loss(data['conf_matrix'], data['conf_matrix_gt'], weight=w)
-        loss_d = self.compute_coarse_loss(data['dect_conf_matrix'], data['conf_matrix_gt'], weight=w)
+        if 'loss_c_fused' in data:               # forward_train(..., fused_coarse_loss=...): HIP loss terms (sum, count)
+            (sc, nc), (sd, nd) = data['loss_c_fused'], data['loss_d_fused']
+            has_gt = float(data.get('spv_num_gt', 1) > 0)
+            loss_c, loss_d = self.c_pos_w * has_gt * sc / nc, self.c_pos_w * has_gt * sd / nd
+        else:
+            w = self.compute_c_weight(data)
+            loss_c = self.compute_coarse_loss(data['conf_matrix'], data['conf_matrix_gt'], weight=w)
+            loss_d = self.compute_coarse_loss(data['dect_conf_matrix'], data['conf_matrix_gt'], weight=w)
         loss = (loss_c + loss_d) * self.cfg['coarse_weight']
         loss_f = self.compute_fine_loss(data['fine_matrix'], data['conf_matrix_fine_gt'])
         loss = loss + loss_f * self.cfg['fine_weight']

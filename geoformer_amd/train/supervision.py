@@ -91,6 +91,7 @@ def spvs_coarse(data, resolution=(8, 2)):
     b_ids, i_ids = torch.where(correct)
     j_ids = nearest_index1[b_ids, i_ids]
     conf_gt[b_ids, i_ids, j_ids] = 1
+    data['spv_num_gt'] = int(len(b_ids))                   # before the dummy below (the loss terms need the real count)
     if len(b_ids) == 0:                                     # keeps the fine level alive; does not touch its loss
         b_ids = i_ids = j_ids = torch.zeros(1, dtype=torch.long, device=device)
     data.update(conf_matrix_gt=conf_gt, spv_b_ids=b_ids, spv_i_ids=i_ids, spv_j_ids=j_ids, spv_w_pt0_i=w_pt0_i,

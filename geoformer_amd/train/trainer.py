@@ -17,7 +17,7 @@ from typing import Callable, Optional
 import torch
 import torch.nn as nn
 
-from .functional import forward_train
+from .functional import forward_train, fused_coarse_loss_applicable
 from .loss import GeoLoss
 from .supervision import spvs_coarse, spvs_fine2
 
@@ -72,14 +72,15 @@ def warmup_lr(cfg, global_step) -> Optional[float]:
 class _Core(nn.Module):
     """What DDP wraps: supervision -> forward -> fine supervision -> loss, returning the scalar loss."""
 
-    def __init__(self, model, loss, homography_fn=None):
+    def __init__(self, model, loss, homography_fn=None, fused=True):
         super().__init__()
-        self.model, self.loss, self.homography_fn = model, loss, homography_fn
+        self.model, self.loss, self.homography_fn, self.fused = model, loss, homography_fn, fused
 
     def forward(self, batch):
         res = tuple(self.model.config['resolution'])
         spvs_coarse(batch, res)
-        forward_train(self.model, batch, self.homography_fn)
+        fused = self.loss.fused_params() if (self.fused and fused_coarse_loss_applicable(self.model, batch)) else None
+        forward_train(self.model, batch, self.homography_fn, fused_coarse_loss=fused)
         spvs_fine2(batch, res)
         return self.loss(batch)
 
@@ -88,7 +89,7 @@ class TrainStep:
     """One optimisation step per call; `epoch_end()` advances an epoch-interval scheduler."""
 
     def __init__(self, model, trainer_cfg=None, loss_cfg=None, batch_size=1, distributed=False, device_ids=None,
-                 homography_fn: Optional[Callable] = None, sparse_spvs=True):
+                 homography_fn: Optional[Callable] = None, sparse_spvs=True, fused_coarse_loss=True):
         world = torch.distributed.get_world_size() if distributed else 1
         self.cfg = scale_trainer_cfg(trainer_cfg, world, batch_size)
         if model.precision != 'fp32':
@@ -96,7 +97,7 @@ class TrainStep:
         model.train()
         self.model = model
         core = _Core(model, GeoLoss(loss_cfg, model.config['match_coarse'].get('match_type', 'dual_softmax'), sparse_spvs),
-                     homography_fn)
+                     homography_fn, fused_coarse_loss)
         if distributed:
             if next(model.parameters()).is_cuda:      # torch's SyncBatchNorm is device-only; the gloo/CPU tests keep local BN
                 core = nn.SyncBatchNorm.convert_sync_batchnorm(core)

@@ -36,3 +36,78 @@ def test_train_steps_reduce_loss_and_refresh_inference():
     ref = O.geoformer_forward(W, {'image0': pair['image0'].cpu(), 'image1': pair['image1'].cpu()}, None,
                               dict(O.default_geo_config(), coarse_thr=0.0, fine_thr=0.0), make_homography_fn())
     torch.testing.assert_close(out['dect_conf_matrix'].cpu(), ref['dect_conf_matrix'], rtol=5e-3, atol=1e-7)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+@pytest.mark.parametrize('weighted', [False, True])
+def test_fused_coarse_focal_loss_matches_autograd(dtype, weighted):
+    """gf_coarse_loss_forward/backward against torch autograd on the same fp16-rounded features (fp32 math):
+    loss and per-positive confidences to 2e-3, gradients to 2e-2 (fp16 MFMA operands, fp32 accumulation)."""
+    from geoformer_amd import ops
+    torch.manual_seed(11)
+    N, L, S, C, T = 2, 256, 384, 256, 0.1
+    # planted but noisy correspondences: confidences of the positives spread over (0, 1), i.e. a state in which the
+    # gradient is not the near-cancellation of its dense and sparse parts (at p -> 1 those two are equal and opposite
+    # and ANY rounding of either dominates their difference)
+    base = torch.randn(N, max(L, S), C, device='cuda') * 0.75
+    f0 = base[:, :L].clone()
+    perm = torch.stack([torch.randperm(S, device='cuda') for _ in range(N)])
+    f1 = torch.gather(base[:, :S], 1, perm[..., None].expand(-1, -1, C)) + 0.6 * torch.randn(N, S, C, device='cuda')
+    f0, f1 = f0.to(dtype), f1.to(dtype)
+    # positives: every third row of f0, matched to where its feature went (when it exists), unique rows and columns
+    inv = torch.argsort(perm, dim=1)
+    pb = torch.arange(N, device='cuda').repeat_interleave(L // 3)
+    pi = torch.arange(0, L - 2, 3, device='cuda').repeat(N)[:pb.numel()]
+    pj = inv[pb, pi]
+    w = torch.rand(pb.numel(), device='cuda') + 0.5 if weighted else None
+
+    a0 = f0.detach().half().float().requires_grad_(True)
+    a1 = f1.detach().half().float().requires_grad_(True)
+    sim = torch.einsum('nlc,nsc->nls', a0 / C ** .5, a1 / C ** .5) / T
+    conf = torch.softmax(sim, 1) * torch.softmax(sim, 2)
+    p = torch.clamp(conf, 1e-6, 1 - 1e-6)[pb, pi, pj]
+    terms = -0.25 * (1 - p) ** 2.0 * p.log()
+    ref = (terms * w).sum() if weighted else terms.sum()
+    (ref * 0.37).backward()
+
+    h0, h1 = f0.detach().clone().requires_grad_(True), f1.detach().clone().requires_grad_(True)
+    loss, pk = ops.coarse_focal_loss(h0, h1, pb, pi, pj, T, 0.25, 2.0, w)
+    (loss * 0.37).backward()
+    assert 0.02 < float(pk.median()) < 0.98, float(pk.median())
+    torch.testing.assert_close(pk, conf[pb, pi, pj].detach(), rtol=2e-3, atol=1e-7)
+    torch.testing.assert_close(loss.detach(), ref.detach(), rtol=2e-3, atol=1e-6)
+    for got, want in ((h0.grad.float(), a0.grad), (h1.grad.float(), a1.grad)):
+        rel = (got - want).norm() / want.norm()
+        assert rel < 2e-2, float(rel)
+        assert (got - want).abs().max() < 3e-2 * want.abs().max()
+
+
+def test_train_step_fused_loss_equals_autograd_path():
+    """Same batch, same weights: the step with the fused HIP coarse loss against the step that differentiates the
+    materialised confidence matrices (loss terms to 2e-3, parameter gradients to 3e-2 in norm)."""
+    from geoformer_amd.model.cvpr_ds_config import get_default_cfg
+    from geoformer_amd.model.full_model import GeoFormer
+    from geoformer_amd.model.geo_config import get_cfg_model
+    from geoformer_amd.train import GeoLoss, forward_train, spvs_coarse, spvs_fine2, synthetic_homography_batch
+    g = get_cfg_model()
+    g.update(coarse_thr=0.0, fine_thr=0.0, precision='fp32')
+    model = GeoFormer(get_default_cfg(), g)
+    sd = model.state_dict(); O.closed_form_fill(sd); model.load_state_dict(sd)
+    model.cuda().train()
+    loss_fn = GeoLoss()
+    grads, scalars = [], []
+    for fused in (None, loss_fn.fused_params()):
+        batch = synthetic_homography_batch(2, (128, 256), seed=21, device='cuda')      # 16 x 32 = 512 coarse cells
+        spvs_coarse(batch)
+        forward_train(model, batch, fused_coarse_loss=fused)
+        spvs_fine2(batch)
+        model.zero_grad(set_to_none=True)
+        loss_fn(batch).backward()
+        scalars.append({k: float(v) for k, v in batch['loss_scalars'].items()})
+        grads.append({n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+        assert ('loss_c_fused' in batch) == (fused is not None)
+    for k in ('loss_c', 'loss_d', 'loss'):
+        assert scalars[1][k] == pytest.approx(scalars[0][k], rel=2e-3), (k, scalars)
+    num = sum(((grads[1][n] - grads[0][n]) ** 2).sum() for n in grads[0])
+    den = sum((grads[0][n] ** 2).sum() for n in grads[0])
+    assert float(torch.sqrt(num / den)) < 3e-2

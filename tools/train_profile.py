@@ -1,5 +1,8 @@
-"""Where the autograd training step spends its time (torch profiler, top ops by device time)."""
+"""Where the training step spends its time (torch profiler, top ops by device time).
+   python tools/train_profile.py [H W] [--no-fused] [--no-prof]"""
 import sys, time, torch
+HW = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 and sys.argv[1].isdigit() else (480, 640)
+FUSED = '--no-fused' not in sys.argv
 sys.path.insert(0, '.')
 from geoformer_amd import miopen; miopen.use_shipped_find_db()
 from geoformer_amd.model.cvpr_ds_config import get_default_cfg
@@ -9,11 +12,13 @@ from geoformer_amd.weights import deterministic_init_
 from geoformer_amd.train import TrainStep, synthetic_homography_batch
 g = get_cfg_model(); g.update(coarse_thr=0.0, fine_thr=0.0, precision='fp32')
 model = deterministic_init_(GeoFormer(get_default_cfg(), g)).cuda()
-step = TrainStep(model, batch_size=2)
-for it in range(3):
-    t = time.perf_counter(); step(synthetic_homography_batch(2, (480, 640), seed=it, device='cuda')); torch.cuda.synchronize()
-    print('step', it, '%.2f s' % (time.perf_counter() - t), flush=True)
+step = TrainStep(model, batch_size=2, fused_coarse_loss=FUSED)
+for it in range(4):
+    t = time.perf_counter(); step(synthetic_homography_batch(2, HW, seed=it, device='cuda')); torch.cuda.synchronize()
+    print('step', it, '%.3f s' % (time.perf_counter() - t), 'fused' if FUSED else 'autograd', HW, flush=True)
+if '--no-prof' in sys.argv:
+    sys.exit(0)
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
-    step(synthetic_homography_batch(2, (480, 640), seed=9, device='cuda')); torch.cuda.synchronize()
+    step(synthetic_homography_batch(2, HW, seed=9, device='cuda')); torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=25, max_name_column_width=50))
