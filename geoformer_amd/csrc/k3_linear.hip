@@ -41,7 +41,7 @@ extern "C" int gf_debug_k3_trace(long long* out) {
 
 namespace {
 
-enum { EPI_NONE = 0, EPI_RELU = 1, EPI_TANH = 2, EPI_LN = 3, EPI_LN_RES = 4 };
+enum { EPI_NONE = 0, EPI_RELU = 1, EPI_TANH = 2, EPI_LN = 3, EPI_LN_RES = 4, EPI_UPADD = 5 };
 
 struct LinArgs {
     const void* a1;
@@ -62,6 +62,11 @@ struct LinArgs {
     void* out;
     long ldo;
     int M, N;
+    // EPI_UPADD (the FPN merge fused into the 1x1 lateral convolution): rows are the pixels of [n][H][W] maps and
+    // out += bilinear(lo -> H x W, align_corners=True), lo = [n][h][w][N] of T
+    const void* up_lo;
+    int up_h, up_w, up_H, up_W;
+    float up_ry, up_rx;
 };
 
 template <typename T, int NB, int EPI>
@@ -83,7 +88,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void linear_kernel(Lin
 
     if (tid < WROWS) {
         vec[tid] = (a.bias && n0 + tid < a.N) ? a.bias[n0 + tid] : 0.f;
-        if constexpr (EPI >= EPI_LN) {
+        if constexpr (EPI == EPI_LN || EPI == EPI_LN_RES) {
             vec[WROWS + tid] = a.gamma[n0 + tid];
             vec[2 * WROWS + tid] = a.beta[n0 + tid];
         }
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void linear_kernel(Lin
                 if constexpr (std::is_same<T, float>::value) acc[nb][r] = tanhf(acc[nb][r]);
                 else acc[nb][r] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * acc[nb][r]) + 1.0f);   // tanh, ~1e-6 abs
             }
-    } else if constexpr (EPI >= EPI_LN) {
+    } else if constexpr (EPI == EPI_LN || EPI == EPI_LN_RES) {
         // nn.LayerNorm over the WROWS channels of the token: two-pass mean / variance in fp32
         float s = 0.f;
 #pragma unroll
@@ -233,6 +238,23 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void linear_kernel(Lin
                 const int row = it * 4 + prow, tg = m0 + wave * 32 + row, cg = n0 + hb * 128 + pch * 8;
                 if (tg >= a.M || cg >= a.N) continue;
                 v8h v = *reinterpret_cast<const v8h*>(ot + row * RS + pch * 16);
+                if constexpr (EPI == EPI_UPADD) {
+                    const unsigned px = (unsigned)tg % (unsigned)a.up_W, q = (unsigned)tg / (unsigned)a.up_W;
+                    const unsigned py = q % (unsigned)a.up_H, pn = q / (unsigned)a.up_H;
+                    const float fy = a.up_ry * py, fx = a.up_rx * px;
+                    const int y0 = (int)fy, x0 = (int)fx;
+                    const int y1 = y0 + (y0 < a.up_h - 1), x1 = x0 + (x0 < a.up_w - 1);
+                    const float wy1 = fy - y0, wx1 = fx - x0, wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+                    const T* lo = (const T*)a.up_lo + (size_t)pn * a.up_h * a.up_w * a.N + cg;
+                    const v8h v00 = *reinterpret_cast<const v8h*>(lo + ((size_t)y0 * a.up_w + x0) * a.N);
+                    const v8h v01 = *reinterpret_cast<const v8h*>(lo + ((size_t)y0 * a.up_w + x1) * a.N);
+                    const v8h v10 = *reinterpret_cast<const v8h*>(lo + ((size_t)y1 * a.up_w + x0) * a.N);
+                    const v8h v11 = *reinterpret_cast<const v8h*>(lo + ((size_t)y1 * a.up_w + x1) * a.N);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        v[i] = (_Float16)((float)v[i] + wy0 * (wx0 * (float)v00[i] + wx1 * (float)v01[i]) +
+                                          wy1 * (wx0 * (float)v10[i] + wx1 * (float)v11[i]));
+                }
                 if constexpr (EPI == EPI_LN_RES) {
                     const v8h x = *reinterpret_cast<const v8h*>((const T*)a.res + (size_t)tg * a.ldres + cg);
                     const bool keep = a.flag == nullptr || a.flag[tg / a.flag_rows] != 0;
@@ -282,7 +304,10 @@ void lin_launch(const LinArgs& a, int epi, hipStream_t st) {
         case EPI_RELU: lin_launch1<T, NB, EPI_RELU>(a, st); break;
         case EPI_TANH: lin_launch1<T, NB, EPI_TANH>(a, st); break;
         case EPI_LN: lin_launch1<T, NB, EPI_LN>(a, st); break;
-        default: lin_launch1<T, NB, EPI_LN_RES>(a, st); break;
+        case EPI_LN_RES: lin_launch1<T, NB, EPI_LN_RES>(a, st); break;
+        default:
+            if constexpr (std::is_same<T, _Float16>::value) lin_launch1<T, NB, EPI_UPADD>(a, st);
+            break;
     }
 }
 
@@ -325,6 +350,30 @@ extern "C" int gf_linear(const void* a1, long lda1, int k1, const void* a2, long
         if (wide) lin_launch<_Float16, 8>(a, epilogue, st);
         else lin_launch<_Float16, 4>(a, epilogue, st);
     }
+    gf_prof_end("k3_linear", pt, st);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}
+
+// backbone glue: 1x1 lateral convolution of the FPN with the top-down merge fused into its epilogue
+//   out[n,y,x,:] = w . x[n,y,x,:] + bilinear(lo -> HxW, align_corners=True)[n,y,x,:]
+extern "C" int gf_conv1x1_upsample_add_nhwc(const void* x, const void* w, const void* lo, void* out, int N, int h, int wl,
+                                            int H, int W, int Cin, int Cout, int dtype, void* stream) {
+    GF_CHECK_ARG(x && w && lo && out, "null pointer");
+    GF_CHECK_ARG(N > 0 && h > 0 && wl > 0 && H > 0 && W > 0, "empty problem");
+    GF_CHECK_ARG(dtype == GF_F16, "built for fp16 maps (the inference backbone)");
+    GF_CHECK_ARG(Cin % 64 == 0 && Cout % 32 == 0, "Cin must be a multiple of 64, Cout of 32");
+    GF_CHECK_ARG((long)N * H * W < (1l << 31), "too many pixels");
+    GF_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)lo % 16 == 0, "tensors must be 16-byte aligned");
+    LinArgs a{};
+    a.a1 = x; a.lda1 = Cin; a.k1 = Cin; a.w = w; a.out = out; a.ldo = Cout; a.M = N * H * W; a.N = Cout;
+    a.up_lo = lo; a.up_h = h; a.up_w = wl; a.up_H = H; a.up_W = W;
+    a.up_ry = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    a.up_rx = W > 1 ? (float)(wl - 1) / (float)(W - 1) : 0.f;
+    hipStream_t st = (hipStream_t)stream;
+    void* pt = gf_prof_begin("k3_linear", st, 2.0 * (double)a.M * Cout * Cin);
+    if (Cout % 256 == 0) lin_launch<_Float16, 8>(a, EPI_UPADD, st);
+    else lin_launch<_Float16, 4>(a, EPI_UPADD, st);
     gf_prof_end("k3_linear", pt, st);
     GF_CHECK_LAUNCH();
     return GF_OK;

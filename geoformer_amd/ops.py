@@ -136,6 +136,22 @@ def upsample_add_(hi, lo):
     return hi
 
 
+def conv1x1_upsample_add(x, weight, lo):
+    """Backbone glue: 1x1 convolution of channels_last x [N,Cin,H,W] with weight [Cout,Cin(,1,1)] plus the bilinear
+    (align_corners=True) upsampling of channels_last lo [N,Cout,h,w], in one K3 launch -> channels_last [N,Cout,H,W]."""
+    _need_cuda(x, weight, lo)
+    _nhwc(x), _nhwc(lo)
+    N, Cin, H, W = x.shape
+    Cout = weight.shape[0]
+    w2 = _contig(weight.reshape(Cout, Cin))
+    if lo.shape[:2] != (N, Cout) or lo.dtype != x.dtype or w2.dtype != x.dtype:
+        raise ValueError('lo must be [N, Cout, h, w] of the dtype of x and weight')
+    out = torch.empty(N, Cout, H, W, dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    check(_lib.lib().gf_conv1x1_upsample_add_nhwc(_p(x), _p(w2), _p(lo), _p(out), N, lo.shape[2], lo.shape[3], H, W, Cin, Cout,
+                                                  _dt(x), _stream()), 'gf_conv1x1_upsample_add_nhwc')
+    return out
+
+
 def stem_conv7x7(image, weight, shift):
     """Backbone stem: image [N,1,H,W] (fp32/fp16, contiguous), weight fp32 [128,1,7,7] (BN folded), shift fp32 [128]
     -> relu(conv 7x7 / stride 2 / pad 3 + shift), fp16 channels_last [N,128,Ho,Wo]."""

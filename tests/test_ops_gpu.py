@@ -426,3 +426,16 @@ def test_stem_conv_vs_torch(dtype, hw):
     assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
     # fp32 accumulation of exact fp16 products; one fp16 rounding of the result
     assert torch.allclose(out.float(), ref, atol=2e-3, rtol=2e-3), (out.float() - ref).abs().max().item()
+
+
+def test_conv1x1_upsample_add_vs_torch():
+    from geoformer_amd import ops
+    torch.manual_seed(7)
+    x = torch.randn(2, 128, 30, 44, device='cuda').half().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(224, 128, 1, 1, device='cuda') * 0.1).half()
+    lo = torch.randn(2, 224, 15, 22, device='cuda').half().contiguous(memory_format=torch.channels_last)
+    out = ops.conv1x1_upsample_add(x, w, lo)
+    ref = torch.nn.functional.conv2d(x.float(), w.float()) + torch.nn.functional.interpolate(
+        lo.float(), size=(30, 44), mode='bilinear', align_corners=True)
+    assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
+    assert torch.allclose(out.float(), ref, atol=1e-2, rtol=4e-3), (out.float() - ref).abs().max().item()   # two fp16 roundings
