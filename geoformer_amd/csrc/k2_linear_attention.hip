@@ -10,6 +10,8 @@
 // One thread per channel c = h*D + d; C = H*D <= 256.
 #include <math.h>
 
+#include <type_traits>
+
 #include "gf_common.h"
 
 namespace {
@@ -32,6 +34,14 @@ struct LaArgs {
 
 // F.elu(x) + 1 evaluated like torch: expm1 first, then the add
 __device__ __forceinline__ float elu1(float x) { return (x > 0.f ? x : expm1f(x)) + 1.0f; }
+// fp16 path: elu(x) + 1 = exp(x) for x <= 0; the hardware exponential is exact to fp16 rounding and ~20 VALU
+// instructions cheaper than expm1f (which made la16_kv VALU-bound: 32 of them per thread and sub-tile)
+__device__ __forceinline__ float elu1_fast(float x) { return x > 0.f ? x + 1.0f : __expf(x); }
+template <typename T>
+__device__ __forceinline__ float elu1_t(float x) {          // parity (fp32) mode keeps torch's evaluation
+    if constexpr (std::is_same<T, float>::value) return elu1(x);
+    else return elu1_fast(x);
+}
 
 template <typename T, int D>
 __global__ __launch_bounds__(256) void la_kv_partial(LaArgs a) {
@@ -56,7 +66,7 @@ __global__ __launch_bounds__(256) void la_kv_partial(LaArgs a) {
             if (s < s_end) {
                 const bool ok = a.kv_mask == nullptr || a.kv_mask[(size_t)n * a.S + s] != 0;
                 if (ok) {
-                    kv = elu1(gf_to_float(kp[(size_t)s * a.ldk + t]));
+                    kv = elu1_t<T>(gf_to_float(kp[(size_t)s * a.ldk + t]));
                     vv = gf_to_float(vp[(size_t)s * a.ldv + t]) / slen;   // values / v_length (:45)
                 }
             }
@@ -121,7 +131,7 @@ __global__ __launch_bounds__(256) void la_apply(LaArgs a) {
             float qv = 0.f;
             if (l < l_end) {
                 const bool ok = a.q_mask == nullptr || a.q_mask[(size_t)n * a.L + l] != 0;
-                if (ok) qv = elu1(gf_to_float(qp[(size_t)l * a.ldq + t]));
+                if (ok) qv = elu1_t<T>(gf_to_float(qp[(size_t)l * a.ldq + t]));
             }
             qrow[j * C + t] = qv;
         }
@@ -218,7 +228,7 @@ __global__ __launch_bounds__(256) void la16_kv(LaArgs a) {
             const bool ok = s0 + tok < s_end && (a.kv_mask == nullptr || a.kv_mask[(size_t)n * a.S + s0 + tok] != 0);
             v8h kk = rk[p];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) kk[i] = ok ? (_Float16)elu1((float)kk[i]) : (_Float16)0;
+            for (int i = 0; i < 8; ++i) kk[i] = ok ? (_Float16)elu1_fast((float)kk[i]) : (_Float16)0;
             *reinterpret_cast<v8h*>(kt + tok * TRS + c8 * 2) = kk;
             *reinterpret_cast<v8h*>(vt + tok * TRS + c8 * 2) = rv[p];
         }
@@ -284,7 +294,7 @@ __global__ __launch_bounds__(256) void la16_apply(LaArgs a) {
             const bool qok = a.q_mask == nullptr || a.q_mask[(size_t)n * a.L + tok] != 0;
             v8h qv = *reinterpret_cast<const v8h*>((const _Float16*)a.q + ((size_t)n * a.L + tok) * a.ldq + half * 128 + pch * 8);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) qv[i] = qok ? (_Float16)elu1((float)qv[i]) : (_Float16)0;
+            for (int i = 0; i < 8; ++i) qv[i] = qok ? (_Float16)elu1_fast((float)qv[i]) : (_Float16)0;
             *reinterpret_cast<v8h*>(qt + row * RS + pch * 16) = qv;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -365,7 +375,7 @@ __global__ __launch_bounds__(256) void la_small(LaArgs a) {
             const int s = s0 + j;
             float kv = 0.f, vv = 0.f;
             if (s < a.S && (a.kv_mask == nullptr || a.kv_mask[(size_t)n * a.S + s] != 0)) {
-                kv = elu1(gf_to_float(kp[(size_t)s * a.ldk + t]));
+                kv = elu1_t<T>(gf_to_float(kp[(size_t)s * a.ldk + t]));
                 vv = gf_to_float(vp[(size_t)s * a.ldv + t]) / slen;
             }
             kk[j] = kv;
@@ -406,7 +416,7 @@ __global__ __launch_bounds__(256) void la_small(LaArgs a) {
             const int l = l0 + j;
             float qv = 0.f;
             if (l < a.L && (a.q_mask == nullptr || a.q_mask[(size_t)n * a.L + l] != 0))
-                qv = elu1(gf_to_float(qp[(size_t)l * a.ldq + t]));
+                qv = elu1_t<T>(gf_to_float(qp[(size_t)l * a.ldq + t]));
             row[j * C + t] = qv;
         }
         __syncthreads();
