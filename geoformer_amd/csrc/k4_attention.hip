@@ -160,11 +160,12 @@ __global__ __launch_bounds__(256) void attn_self(AtArgs a) {
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float mnew = fmaxf(m, tmax);          // finite: every tile holds at least one real key
-        const float alpha = expf(m - mnew);
+        constexpr bool FAST = !std::is_same<T, float>::value;          // fp16 mode: hardware exponential
+        const float alpha = FAST ? __expf(m - mnew) : expf(m - mnew);
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            x[r] = expf(x[r] - mnew);
+            x[r] = FAST ? __expf(x[r] - mnew) : expf(x[r] - mnew);
             psum += x[r];
         }
         l = l * alpha + psum;

@@ -14,6 +14,8 @@
 //                                  gather-then-project because k_proj/v_proj are bias-free linear maps).
 #include <math.h>
 
+#include <type_traits>
+
 #include "gf_common.h"
 
 namespace {
@@ -211,18 +213,20 @@ __global__ __launch_bounds__(256) void window_cross_attention(CaArgs a) {
         logit[k] = s * a.softmax_temp;
         mx = fmaxf(mx, logit[k]);
     }
+    constexpr bool FAST = !std::is_same<T, float>::value;     // fp16 mode: hardware exp / reciprocal
     float den = 0.f;
 #pragma unroll
     for (int k = 0; k < WW; ++k) {
-        logit[k] = expf(logit[k] - mx);
+        logit[k] = FAST ? __expf(logit[k] - mx) : expf(logit[k] - mx);
         den += logit[k];
     }
+    const float rden = __builtin_amdgcn_rcpf(den);
     v4f acc{0.f, 0.f, 0.f, 0.f};
     if (any) {
 #pragma unroll
         for (int k = 0; k < WW; ++k) {
             if (cell[k] >= 0) {            // masked keys have weight exp(-1.25e7 - mx) == 0 whenever any key is valid
-                const float p = logit[k] / den;
+                const float p = FAST ? logit[k] * rden : logit[k] / den;
                 const v4f vv = load4<T>(vb + (size_t)cell[k] * a.ldv);
                 acc.x += p * vv.x; acc.y += p * vv.y; acc.z += p * vv.z; acc.w += p * vv.w;
             }
