@@ -20,6 +20,7 @@ c_long, c_uint32 = ctypes.c_long, ctypes.c_uint32
 SIGNATURES = {
     'gf_abi_version': (c_int, []),
     'gf_last_error': (ctypes.c_char_p, []),
+    'gf_profile_filter': (None, [ctypes.c_char_p]),
     'gf_profile_enable': (None, [c_int]),
     'gf_profile_collect': (c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int),
                                    ctypes.POINTER(ctypes.c_double)]),

@@ -28,18 +28,33 @@ namespace {
 struct ProfSpan { hipEvent_t a, b; double work; };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
+std::string g_prof_filter;                              // empty = every tag
 std::map<std::string, std::vector<ProfSpan>> g_prof;
+std::vector<hipEvent_t> g_prof_pool;                    // recycled events (creating two per launch is not free)
+
+hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) {
+        hipEvent_t e = g_prof_pool.back();
+        g_prof_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+}
 }   // namespace
 
 bool gf_prof_enabled() { return g_prof_on; }
 
 void* gf_prof_begin(const char* tag, hipStream_t st, double work) {
     if (!g_prof_on) return nullptr;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_filter.empty() && g_prof_filter != tag) return nullptr;
     ProfSpan sp;
     sp.work = work;
-    if (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess) return nullptr;
+    sp.a = prof_event();
+    sp.b = prof_event();
+    if (!sp.a || !sp.b) return nullptr;
     (void)hipEventRecord(sp.a, st);
-    std::lock_guard<std::mutex> lk(g_prof_mu);
     auto& v = g_prof[tag];
     v.push_back(sp);
     return (void*)(uintptr_t)v.size();
@@ -55,6 +70,11 @@ void gf_prof_end(const char* tag, void* token, hipStream_t st) {
 extern "C" void gf_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_on = on != 0;
+}
+
+extern "C" void gf_profile_filter(const char* tag) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_filter = tag ? tag : "";
 }
 
 // Synchronises on the recorded events, returns the summed milliseconds, the span count and the summed
@@ -78,8 +98,8 @@ extern "C" int gf_profile_collect(const char* tag, double* total_ms, int* count,
             wk += sp.work;
             ++n;
         }
-        (void)hipEventDestroy(sp.a);
-        (void)hipEventDestroy(sp.b);
+        g_prof_pool.push_back(sp.a);
+        g_prof_pool.push_back(sp.b);
     }
     it->second.clear();
     if (total_ms) *total_ms = tot;

@@ -220,15 +220,16 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void linear_kernel(Lin
         char* ot = smem + wave * 32 * RS;
         const int prow = lane >> 4, pch = lane & 15;
 #pragma unroll
-        for (int hb = 0; hb < NB / 4; ++hb) {
+        for (int hb = 0; hb < (NB + 3) / 4; ++hb) {
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4)
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const int nb = hb * 4 + q4, c = q4 * 32 + 8 * r4 + 4 * h;
-                    *reinterpret_cast<v4h*>(ot + lr * RS + c * 2) =
-                        v4h{(_Float16)acc[nb][4 * r4], (_Float16)acc[nb][4 * r4 + 1], (_Float16)acc[nb][4 * r4 + 2],
-                            (_Float16)acc[nb][4 * r4 + 3]};
+                    if (nb < NB)                                         // NB = 7: the last slab holds three blocks
+                        *reinterpret_cast<v4h*>(ot + lr * RS + c * 2) =
+                            v4h{(_Float16)acc[nb][4 * r4], (_Float16)acc[nb][4 * r4 + 1], (_Float16)acc[nb][4 * r4 + 2],
+                                (_Float16)acc[nb][4 * r4 + 3]};
                 }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -304,10 +305,7 @@ void lin_launch(const LinArgs& a, int epi, hipStream_t st) {
         case EPI_RELU: lin_launch1<T, NB, EPI_RELU>(a, st); break;
         case EPI_TANH: lin_launch1<T, NB, EPI_TANH>(a, st); break;
         case EPI_LN: lin_launch1<T, NB, EPI_LN>(a, st); break;
-        case EPI_LN_RES: lin_launch1<T, NB, EPI_LN_RES>(a, st); break;
-        default:
-            if constexpr (std::is_same<T, _Float16>::value) lin_launch1<T, NB, EPI_UPADD>(a, st);
-            break;
+        default: lin_launch1<T, NB, EPI_LN_RES>(a, st); break;
     }
 }
 
@@ -372,8 +370,8 @@ extern "C" int gf_conv1x1_upsample_add_nhwc(const void* x, const void* w, const 
     a.up_rx = W > 1 ? (float)(wl - 1) / (float)(W - 1) : 0.f;
     hipStream_t st = (hipStream_t)stream;
     void* pt = gf_prof_begin("k3_linear", st, 2.0 * (double)a.M * Cout * Cin);
-    if (Cout % 256 == 0) lin_launch<_Float16, 8>(a, EPI_UPADD, st);
-    else lin_launch<_Float16, 4>(a, EPI_UPADD, st);
+    if (Cout == 224) lin_launch1<_Float16, 7, EPI_UPADD>(a, st);          // the padded pyramid width: one column tile
+    else lin_launch1<_Float16, 4, EPI_UPADD>(a, st);
     gf_prof_end("k3_linear", pt, st);
     GF_CHECK_LAUNCH();
     return GF_OK;

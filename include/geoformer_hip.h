@@ -37,6 +37,7 @@ const char* gf_last_error(void);
  * Tags: "k1_stats" (work = flops), "k1_conf" (work = algorithmic bytes), "k3_linear" (work = flops).
  * gf_profile_collect synchronises on the recorded events and returns their summed time, count and work. */
 void gf_profile_enable(int on);
+void gf_profile_filter(const char* tag);   /* record only this tag (NULL: all): keeps the event count inside a timed region small */
 int gf_profile_collect(const char* tag, double* total_ms, int* count, double* work);
 
 /* ------------------------------------------------------------------------------------------
