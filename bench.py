@@ -350,7 +350,7 @@ def main():
                           'launches': lin_cnt, 'total_ms': lin_tot_ms, 'algorithmic_flops': lin_flops,
                           'k1_stats_tflops': stats_flops / (stats_tot_ms * 1e-3) / 1e12 if stats_tot_ms > 0 else 0.0},
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:          # reported on rank 0 at N = 1 only
         res['cpu_baseline'] = cpu_baseline(W, args.coarse_thr, args.fine_thr, args.size)
     print(json.dumps(res), flush=True)
     if args.tune and rank == 0 and 'GEOFORMER_KEEP_SHIPPED_DB' not in os.environ:
