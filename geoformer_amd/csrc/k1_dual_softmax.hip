@@ -507,6 +507,14 @@ __global__ __launch_bounds__(NT, 2) void k1_conf_panel(K1Args a) {
         unsigned long long* rbest = a.rowbest + (size_t)n * a.L;
         unsigned* cmax = a.colmax + (size_t)n * a.S;
         const int lane_off = 4 * h * a.S + lr;
+        // DENSE (thr ~ 0, every element is a candidate): the best (value, column) of each of the lane's 16 rows is
+        // carried in registers over the whole run of tiles and reduced across lanes ONCE per run (a strict > keeps
+        // the earliest column on ties: tiles, and ni within a tile, come in increasing column order)
+        unsigned runv[DENSE ? 16 : 1], runc[DENSE ? 16 : 1];
+        if constexpr (DENSE) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { runv[r] = 0u; runc[r] = 0u; }
+        }
         for (int bn = t0; bn < t1; ++bn) {
             __syncthreads();                                  // the previous tile's fragments are consumed
 #pragma unroll
@@ -536,7 +544,6 @@ __global__ __launch_bounds__(NT, 2) void k1_conf_panel(K1Args a) {
             asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][15]));
             K1_T(3 + 4 * (bn - t0));
             float* cbase = a.conf + ((size_t)n * a.L + row_base) * a.S + n0;
-            unsigned long long key[DENSE ? 32 : 1];
             unsigned cbest[2] = {0u, 0u};
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -561,18 +568,18 @@ __global__ __launch_bounds__(NT, 2) void k1_conf_panel(K1Args a) {
                             }
                     }
                 } else {
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
-                        const bool in = cf[ni] > a.thr;
-                        const unsigned bits = in ? __float_as_uint(cf[ni]) : 0u;
-                        cbest[ni] = max(cbest[ni], bits);
-                        key[ni * 16 + r] = in ? (((unsigned long long)bits << 32) | (0xFFFFFFFFu - (unsigned)(n0 + ni * 32 + lr))) : 0ull;
-                    }
+                    const unsigned b0 = cf[0] > a.thr ? __float_as_uint(cf[0]) : 0u;
+                    const unsigned b1 = cf[1] > a.thr ? __float_as_uint(cf[1]) : 0u;
+                    cbest[0] = max(cbest[0], b0);
+                    cbest[1] = max(cbest[1], b1);
+                    const bool second = b1 > b0;                      // ni = 1 is the later column: only a strict win
+                    const unsigned bv = second ? b1 : b0, bc = (unsigned)(n0 + lr) + (second ? 32u : 0u);
+                    const bool better = bv > runv[r];
+                    runv[r] = better ? bv : runv[r];
+                    runc[r] = better ? bc : runc[r];
                 }
             }
             if constexpr (DENSE) {
-                const unsigned long long kbest = k1_row_reduce(key, GfMaxU64());
-                if (lr < 16 && kbest != 0ull) atomicMax(rbest + row_base + gf_acc_row(lr, h), kbest);
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
                     const unsigned c = max(cbest[ni], (unsigned)__shfl_xor((int)cbest[ni], 32, 64));
@@ -580,6 +587,16 @@ __global__ __launch_bounds__(NT, 2) void k1_conf_panel(K1Args a) {
                 }
             }
             K1_T(4 + 4 * (bn - t0));
+        }
+        if constexpr (DENSE) {
+            unsigned long long key[32];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                key[r] = runv[r] ? (((unsigned long long)runv[r] << 32) | (0xFFFFFFFFu - runc[r])) : 0ull;
+                key[16 + r] = 0ull;
+            }
+            const unsigned long long kbest = k1_row_reduce(key, GfMaxU64());
+            if (lr < 16 && kbest != 0ull) atomicMax(rbest + row_base + gf_acc_row(lr, h), kbest);
         }
     }
 }
