@@ -552,9 +552,12 @@ __global__ __launch_bounds__(NT, 2) void k1_conf_panel(K1Args a) {
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
                     cf[ni] = __builtin_amdgcn_exp2f(fmaf(acc[ni][r], k2, st.x + ca[ni])) * (st.y * cb[ni]);
+                // one v_permlane32_swap puts a row's 64 columns on the 64 lanes: each store instruction then writes
+                // 256 contiguous bytes of ONE row (instead of 128 B of two rows 4 apart)
                 float* rowp = cbase + (size_t)((r & 3) + 8 * (r >> 2)) * a.S;
-                __builtin_nontemporal_store(cf[0], rowp + lane_off);
-                __builtin_nontemporal_store(cf[1], rowp + lane_off + 32);
+                const gf_v2u sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(cf[0]), __float_as_uint(cf[1]), false, false);
+                __builtin_nontemporal_store(__uint_as_float(sw.x), rowp + lane);
+                __builtin_nontemporal_store(__uint_as_float(sw.y), rowp + 4 * a.S + lane);
                 if constexpr (!DENSE) {
                     if (fmaxf(cf[0], cf[1]) > a.thr) {
                         const int row = row_base + gf_acc_row(r, h);
