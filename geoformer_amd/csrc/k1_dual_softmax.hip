@@ -541,7 +541,9 @@ __global__ __launch_bounds__(NT, 2) void k1_conf_panel(K1Args a) {
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kg], b1, acc[1], 0, 0, 0);
             }
             const int n0 = bn * BN;
-            asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][15]));
+#if K1_TRACE
+            asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][15]));      // the stamp below waits for the MFMAs
+#endif
             K1_T(3 + 4 * (bn - t0));
             float* cbase = a.conf + ((size_t)n * a.L + row_base) * a.S + n0;
             unsigned cbest[2] = {0u, 0u};
