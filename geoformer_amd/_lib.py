@@ -30,9 +30,9 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_size_t, c_void_p]),
     'gf_coarse_loss_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
-    'gf_coarse_loss_forward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
+    'gf_coarse_loss_forward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
                                         c_int, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    'gf_coarse_loss_backward': (c_int, [c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float,
+    'gf_coarse_loss_backward': (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float,
                                          c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'gf_pos_encode': (c_int, [c_void_p, c_int, c_long, c_long, c_long, c_long, c_void_p, c_void_p, c_int, c_int, c_int,
                               c_int, c_int, c_void_p]),

@@ -847,15 +847,19 @@ struct GrArgs {
     const float2* sb;        // [N][Lb]
     const float* ga;         // [N][La] g summed per panel row
     const float* gb;         // [N][Lb]
+    const uint8_t* ma;       // [N][La] padding masks (0 = padded) or null; a pair with a padded member has sim = -1e9
+    const uint8_t* mb;       // [N][Lb]   (coarse_matching.py:123-124) and therefore weight 0
     const unsigned* gmax;    // bits of max |g| (device)
     float mult;
     float* dfa;              // [N][La][256] fp32, written (not accumulated)
     int N, La, Lb, tilesA, tilesB;
 };
 
+template <bool MASKED>
 __global__ __launch_bounds__(NT, 1) void k1_grad_panel(GrArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* bst = reinterpret_cast<float2*>(smem + BN * 512);             // [64] streamed-side (c, w)
+    float* bmk = reinterpret_cast<float*>(smem + BN * 512 + BN * 8);      // [64] streamed-side mask (1 / 0)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, lr = lane & 31;
     const int bm = blockIdx.x % a.tilesA, n = blockIdx.x / a.tilesA, m0 = bm * BM;
     const int srow = tid >> 5, schunk = tid & 31;
@@ -870,7 +874,11 @@ __global__ __launch_bounds__(NT, 1) void k1_grad_panel(GrArgs a) {
     // this lane's panel row: -m*log2e and g/l scaled
     const int krow = m0 + wave * 32 + lr;
     const float2 sta = a.sa[(size_t)n * a.La + krow];
-    const float ra = -sta.x * LOG2E, wa = a.ga[(size_t)n * a.La + krow] * __builtin_amdgcn_rcpf(sta.y) * sw;
+    const float ka = (a.ma == nullptr || a.ma[(size_t)n * a.La + krow] != 0) ? 1.0f : 0.0f;
+    // a padded row's statistics are those of a row of -1e9 fills: give it an offset that sends its exponentials to 0
+    // (its weight is 0 as well); with masks every exponent is also capped, because a padded member's raw similarity
+    // is not bounded by the maxima taken over the unpadded ones and inf * 0 would poison the sum
+    const float ra = ka != 0.f ? -sta.x * LOG2E : -30000.f, wa = a.ga[(size_t)n * a.La + krow] * __builtin_amdgcn_rcpf(sta.y) * sw * ka;
     v16f dacc[8];
 #pragma unroll
     for (int cb = 0; cb < 8; ++cb)
@@ -878,13 +886,16 @@ __global__ __launch_bounds__(NT, 1) void k1_grad_panel(GrArgs a) {
         for (int r = 0; r < 16; ++r) dacc[cb][r] = 0.f;
     v4u rb[8];
     float2 cs = make_float2(0.f, 0.f);
+    float cm = 1.f;
     auto prefetch = [&](int bn) {
         const _Float16* g = B + (size_t)(bn * BN + srow) * 256 + schunk * 8;
 #pragma unroll
         for (int p = 0; p < 8; ++p) rb[p] = *reinterpret_cast<const v4u*>(g + (size_t)p * 8 * 256);
         if (tid < BN) {
-            const float2 st = a.sb[(size_t)n * a.Lb + bn * BN + tid];
-            cs = make_float2(-st.x * LOG2E, a.gb[(size_t)n * a.Lb + bn * BN + tid] * __builtin_amdgcn_rcpf(st.y) * sw);
+            const size_t l = (size_t)n * a.Lb + bn * BN + tid;
+            const float2 st = a.sb[l];
+            cm = (a.mb == nullptr || a.mb[l] != 0) ? 1.0f : 0.0f;
+            cs = make_float2(cm != 0.f ? -st.x * LOG2E : -30000.f, a.gb[l] * __builtin_amdgcn_rcpf(st.y) * sw * cm);
         }
     };
     prefetch(0);
@@ -893,7 +904,10 @@ __global__ __launch_bounds__(NT, 1) void k1_grad_panel(GrArgs a) {
         __syncthreads();                                   // the previous tile is consumed
 #pragma unroll
         for (int p = 0; p < 8; ++p) *reinterpret_cast<v4u*>(smem + k1p_off(srow + 8 * p, schunk)) = rb[p];
-        if (tid < BN) bst[tid] = cs;
+        if (tid < BN) {
+            bst[tid] = cs;
+            bmk[tid] = cm;
+        }
         __syncthreads();
         if (bn + 1 < a.tilesB) prefetch(bn + 1);
         // ---- similarity tile, transposed: D[row = tile row l][col = panel row k]
@@ -920,10 +934,15 @@ __global__ __launch_bounds__(NT, 1) void k1_grad_panel(GrArgs a) {
                 const v4f s01 = *reinterpret_cast<const v4f*>(bst + l0);
                 const v4f s23 = *reinterpret_cast<const v4f*>(bst + l0 + 2);
                 const float cbv[4] = {s01.x, s01.z, s23.x, s23.z}, wbv[4] = {s01.y, s01.w, s23.y, s23.w};
+                const v4f mk = *reinterpret_cast<const v4f*>(bmk + l0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float s2 = acc[ni][r0 + 4 * q + j] * k2;
-                    const float w = __builtin_amdgcn_exp2f(s2 + ra) * wa + __builtin_amdgcn_exp2f(s2 + cbv[j]) * wbv[j];
+                    // a padded member on either side zeroes the pair: wa carries the panel row's mask, wbv the
+                    // streamed row's, and the cross terms take the other side's
+                    float e1 = s2 + ra, e2 = s2 + cbv[j];
+                    if constexpr (MASKED) { e1 = fminf(e1, 64.f); e2 = fminf(e2, 64.f); }
+                    const float w = __builtin_amdgcn_exp2f(e1) * (wa * mk[j]) + __builtin_amdgcn_exp2f(e2) * (wbv[j] * ka);
                     wf[4 * q + j] = (_Float16)w;
                 }
             }
@@ -1119,13 +1138,14 @@ static int coarse_loss_check(const char* fn, int N, int L, int S, int C, int P, 
 }
 
 extern "C" int gf_coarse_loss_forward(const void* f0, const void* f1, int dtype, int N, int L, int S, int C,
-                                      float temperature, const int64_t* pos_b, const int64_t* pos_i, const int64_t* pos_j,
+                                      const uint8_t* mask0, const uint8_t* mask1, float temperature, const int64_t* pos_b, const int64_t* pos_i, const int64_t* pos_j,
                                       int P, const float* pos_weight, float alpha, float gamma, float* pos_conf,
                                       float* pos_loss, float* pos_grad, void* workspace, size_t workspace_bytes,
                                       void* stream) {
     GF_CHECK_ARG(f0 && f1 && pos_b && pos_i && pos_j && pos_conf && pos_loss && pos_grad, "null pointer");
     GF_CHECK_ARG(dtype == GF_F32 || dtype == GF_F16, "dtype must be GF_F32 or GF_F16");
     GF_CHECK_ARG(temperature > 0.f, "bad temperature");
+    GF_CHECK_ARG((mask0 == nullptr) == (mask1 == nullptr), "mask0/mask1 must both be set or both be NULL");
     const int rc = coarse_loss_check("gf_coarse_loss_forward", N, L, S, C, P, workspace, workspace_bytes);
     if (rc != GF_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -1139,6 +1159,7 @@ extern "C" int gf_coarse_loss_forward(const void* f0, const void* f1, int dtype,
     }
     K1Args a{};
     a.f0 = w.f0h; a.f1 = w.f1h; a.N = N; a.L = L; a.S = S; a.C = C;
+    a.mask0 = mask0; a.mask1 = mask1;
     a.inv_c = 1.0f / (float)C; a.temperature = temperature; a.mult = (1.0f / (float)C) / temperature;
     a.tilesM = L / BM; a.tilesN = S / BN;
     a.rowpart = w.rowpart; a.colpart = w.colpart; a.rstat = w.rstat; a.cstat = w.cstat;
@@ -1154,7 +1175,8 @@ extern "C" int gf_coarse_loss_forward(const void* f0, const void* f1, int dtype,
     return GF_OK;
 }
 
-extern "C" int gf_coarse_loss_backward(int N, int L, int S, int C, float temperature, const int64_t* pos_b,
+extern "C" int gf_coarse_loss_backward(int N, int L, int S, int C, const uint8_t* mask0, const uint8_t* mask1,
+                                       float temperature, const int64_t* pos_b,
                                        const int64_t* pos_i, const int64_t* pos_j, int P, const float* pos_grad,
                                        float scale, float* d_f0, float* d_f1, void* workspace, size_t workspace_bytes,
                                        void* stream) {
@@ -1173,13 +1195,17 @@ extern "C" int gf_coarse_loss_backward(int N, int L, int S, int C, float tempera
     g.gmax = w.gmax; g.mult = p.mult; g.N = N;
     // dF0: panel = f0 rows (row statistics, gr), streamed = f1 rows (column statistics, gc)
     g.fa = w.f0h; g.fb = w.f1h; g.sa = w.rstat; g.sb = w.cstat; g.ga = w.gr; g.gb = w.gc; g.dfa = d_f0;
+    g.ma = mask0; g.mb = mask1;
     g.La = L; g.Lb = S; g.tilesA = L / BM; g.tilesB = S / BN;
-    k1_grad_panel<<<N * g.tilesA, NT, PANEL_LDS, st>>>(g);
+    if (mask0) k1_grad_panel<true><<<N * g.tilesA, NT, PANEL_LDS + BN * 4, st>>>(g);
+    else k1_grad_panel<false><<<N * g.tilesA, NT, PANEL_LDS + BN * 4, st>>>(g);
     // dF1: roles swapped (S must then tile by 128 and L by 64)
     GF_CHECK_ARG(S % BM == 0 && L % BN == 0, "S must be a multiple of 128 too");
     g.fa = w.f1h; g.fb = w.f0h; g.sa = w.cstat; g.sb = w.rstat; g.ga = w.gc; g.gb = w.gr; g.dfa = d_f1;
+    g.ma = mask1; g.mb = mask0;
     g.La = S; g.Lb = L; g.tilesA = S / BM; g.tilesB = L / BN;
-    k1_grad_panel<<<N * g.tilesA, NT, PANEL_LDS, st>>>(g);
+    if (mask0) k1_grad_panel<true><<<N * g.tilesA, NT, PANEL_LDS + BN * 4, st>>>(g);
+    else k1_grad_panel<false><<<N * g.tilesA, NT, PANEL_LDS + BN * 4, st>>>(g);
     k1_pos_grad<<<P, 256, 0, st>>>(p);
     GF_CHECK_LAUNCH();
     return GF_OK;

@@ -398,7 +398,7 @@ class CoarseFocalLoss(torch.autograd.Function):
     (loss_sum, p [P]); gradients flow to f0 and f1 only."""
 
     @staticmethod
-    def forward(ctx, f0, f1, pos_b, pos_i, pos_j, temperature, alpha, gamma, weight):
+    def forward(ctx, f0, f1, pos_b, pos_i, pos_j, temperature, alpha, gamma, weight, mask0=None, mask1=None):
         _need_cuda(f0, f1, pos_b)
         N, L, C = f0.shape
         S = f1.shape[1]
@@ -412,7 +412,10 @@ class CoarseFocalLoss(torch.autograd.Function):
         loss, grad = torch.empty_like(conf), torch.empty_like(conf)
         pb, pi, pj = _contig(pos_b.long()), _contig(pos_i.long()), _contig(pos_j.long())
         w = None if weight is None else _contig(weight.float())
-        check(L_.gf_coarse_loss_forward(_p(f0c), _p(f1c), _dt(f0c), N, L, S, C, float(temperature), _p(pb), _p(pi), _p(pj), P, _p(w),
+        m0 = None if mask0 is None else _contig(mask0.reshape(N, L).to(torch.uint8))
+        m1 = None if mask1 is None else _contig(mask1.reshape(N, S).to(torch.uint8))
+        ctx.masks = (m0, m1)
+        check(L_.gf_coarse_loss_forward(_p(f0c), _p(f1c), _dt(f0c), N, L, S, C, _p(m0), _p(m1), float(temperature), _p(pb), _p(pi), _p(pj), P, _p(w),
                                         float(alpha), float(gamma), _p(conf), _p(loss), _p(grad), _p(ws), ws.numel(), _stream()),
               'gf_coarse_loss_forward')
         ctx.save_for_backward(pb, pi, pj, grad, ws)
@@ -426,11 +429,12 @@ class CoarseFocalLoss(torch.autograd.Function):
         N, L, S, C, temperature, dtype = ctx.meta
         d0 = torch.empty(N, L, C, dtype=torch.float32, device=grad.device)
         d1 = torch.empty(N, S, C, dtype=torch.float32, device=grad.device)
-        check(_lib.lib().gf_coarse_loss_backward(N, L, S, C, temperature, _p(pb), _p(pi), _p(pj), pb.numel(), _p(grad),
+        m0, m1 = ctx.masks
+        check(_lib.lib().gf_coarse_loss_backward(N, L, S, C, _p(m0), _p(m1), temperature, _p(pb), _p(pi), _p(pj), pb.numel(), _p(grad),
                                                  float(g_loss), _p(d0), _p(d1), _p(ws), ws.numel(), _stream()),
               'gf_coarse_loss_backward')
-        return d0.to(dtype), d1.to(dtype), None, None, None, None, None, None, None
+        return d0.to(dtype), d1.to(dtype), None, None, None, None, None, None, None, None, None
 
 
-def coarse_focal_loss(f0, f1, pos_b, pos_i, pos_j, temperature, alpha=0.25, gamma=2.0, weight=None):
-    return CoarseFocalLoss.apply(f0, f1, pos_b, pos_i, pos_j, temperature, alpha, gamma, weight)
+def coarse_focal_loss(f0, f1, pos_b, pos_i, pos_j, temperature, alpha=0.25, gamma=2.0, weight=None, mask0=None, mask1=None):
+    return CoarseFocalLoss.apply(f0, f1, pos_b, pos_i, pos_j, temperature, alpha, gamma, weight, mask0, mask1)

@@ -315,21 +315,22 @@ def device_homography_fn(data, scale):
 
 
 # ----------------------------------------------------------------------------- the forward
-def _fused_coarse_stage(f0, f1, data, temp, thr, focal):
+def _fused_coarse_stage(f0, f1, data, temp, thr, focal, m0=None, m1=None):
     """One coarse-matching stage of the training forward on the HIP path: matches from K1 (no gradient), and the
     sparse-supervision focal term + its gradient from the fused loss kernels (ops.coarse_focal_loss), so that no
     L x S tensor enters the autograd graph.  Returns (conf_matrix without grad, match dict, (loss_sum, count))."""
     from .. import ops
     scale = float(data['hw0_i'][0]) / float(data['hw0_c'][0])
-    r = ops.dual_softmax_match(f0.detach(), f1.detach(), temp, thr, data['hw0_c'], data['hw1_c'], scale,
+    r = ops.dual_softmax_match(f0.detach(), f1.detach(), temp, thr, data['hw0_c'], data['hw1_c'], scale, mask0=m0, mask1=m1,
                                scale0=data.get('scale0'), scale1=data.get('scale1'), force_one='dataset_name' in data)
     m = int(r['counts'][0])
     match = {k: r[k][:m] for k in ('b_ids', 'i_ids', 'j_ids', 'mkpts0_c', 'mkpts1_c')}
     match['m_bids'] = match['b_ids']
     n_gt = data['spv_num_gt']
     if n_gt > 0:
-        loss_sum, _ = ops.coarse_focal_loss(f0, f1, data['spv_b_ids'], data['spv_i_ids'], data['spv_j_ids'], temp,
-                                            focal[0], focal[1])
+        pb, pi, pj = data['spv_b_ids'], data['spv_i_ids'], data['spv_j_ids']
+        w = None if m0 is None else (m0[pb, pi] * m1[pb, pj]).float()      # GeoLoss.compute_c_weight at the positives
+        loss_sum, _ = ops.coarse_focal_loss(f0, f1, pb, pi, pj, temp, focal[0], focal[1], w, m0, m1)
     else:                                       # loftr_loss.py:220-224: a dummy positive with zero weight
         loss_sum = f0.sum() * 0.0
     return r['conf_matrix'], match, (loss_sum, max(n_gt, 1))
@@ -337,10 +338,10 @@ def _fused_coarse_stage(f0, f1, data, temp, thr, focal):
 
 def fused_coarse_loss_applicable(model, data):
     """The fused HIP loss covers the training configuration of the reference: dual-softmax, sparse supervision, focal
-    loss, no padding masks, coarse grids that tile (L, S multiples of 128, C = 256)."""
+    loss (padding masks included), coarse grids that tile (L, S multiples of 128, C = 256)."""
     h0, w0 = data['image0'].shape[2] // 8, data['image0'].shape[3] // 8
     h1, w1 = data['image1'].shape[2] // 8, data['image1'].shape[3] // 8
-    return (data['image0'].is_cuda and 'mask0' not in data and model.config['coarse']['d_model'] == 256
+    return (data['image0'].is_cuda and model.config['coarse']['d_model'] == 256
             and (h0 * w0) % 128 == 0 and (h1 * w1) % 128 == 0 and 'spv_num_gt' in data)
 
 
@@ -372,7 +373,7 @@ def forward_train(model, data: Dict[str, torch.Tensor], homography_fn: Optional[
     f0, f1 = local_feature_transformer(P, 'loftr_coarse.', cfg['coarse']['layer_names'], cfg['coarse']['nhead'], f0, f1, m0, m1)
     temp, thr = cfg['match_coarse']['dsmax_temperature'], cfg['match_coarse']['thr']
     if fused_coarse_loss is not None:
-        conf, match, data['loss_d_fused'] = _fused_coarse_stage(f0, f1, data, temp, thr, fused_coarse_loss)
+        conf, match, data['loss_d_fused'] = _fused_coarse_stage(f0, f1, data, temp, thr, fused_coarse_loss, m0, m1)
         data.update(conf_matrix=conf, **match)
     else:
         conf = dual_softmax(f0, f1, temp, m0, m1)
@@ -384,7 +385,7 @@ def forward_train(model, data: Dict[str, torch.Tensor], homography_fn: Optional[
         homography_fn = device_homography_fn(data, int(data['hw0_i'][0] // data['hw0_c'][0]))
     g0, g1 = geo_module(P, cnn0, cnn1, data, gcfg, homography_fn)
     if fused_coarse_loss is not None:
-        conf, match, data['loss_c_fused'] = _fused_coarse_stage(g0, g1, data, temp, thr, fused_coarse_loss)
+        conf, match, data['loss_c_fused'] = _fused_coarse_stage(g0, g1, data, temp, thr, fused_coarse_loss, m0, m1)
         data.update(conf_matrix=conf, **match)
     else:
         conf = dual_softmax(g0, g1, temp, m0, m1)

@@ -72,7 +72,8 @@ int gf_dual_softmax_match(const void* f0, const void* f1, int dtype, int N, int 
  *          GeoLoss.compute_coarse_loss, focal / sparse_spvs / dual_softmax branch (loftr_loss.py:246-270), and the
  *          autograd backward through both.  Neither conf nor its gradient is materialised.
  *   f0 [N,L,256], f1 [N,S,256] (GF_F32 or GF_F16; the arithmetic is fp16 operands / fp32 accumulation),
- *   positives (pos_b, pos_i, pos_j)[P] = torch.where(conf_matrix_gt == 1), optional per-positive weight.
+ *   positives (pos_b, pos_i, pos_j)[P] = torch.where(conf_matrix_gt == 1), optional per-positive weight,
+ *   optional padding masks uint8 [N,L] / [N,S] (pairs with a padded member: sim = -1e9, coarse_matching.py:123-124).
  *   forward:  pos_conf[k] = conf[b,i,j], pos_loss[k] = -alpha (1-p)^gamma log p * w  (p clamped to [1e-6, 1-1e-6]),
  *             pos_grad[k] = d pos_loss[k] / d log p.   loss_c = c_pos_w * mean_k pos_loss[k] is formed by the caller.
  *   backward: d_f0 [N,L,256], d_f1 [N,S,256] fp32 (overwritten) for  loss = scale * sum_k pos_loss[k];
@@ -80,11 +81,12 @@ int gf_dual_softmax_match(const void* f0, const void* f1, int dtype, int N, int 
  *   L and S multiples of 128, C = 256.
  * ------------------------------------------------------------------------------------------ */
 size_t gf_coarse_loss_workspace_bytes(int N, int L, int S);
-int gf_coarse_loss_forward(const void* f0, const void* f1, int dtype, int N, int L, int S, int C, float temperature,
-                           const int64_t* pos_b, const int64_t* pos_i, const int64_t* pos_j, int P,
+int gf_coarse_loss_forward(const void* f0, const void* f1, int dtype, int N, int L, int S, int C, const uint8_t* mask0,
+                           const uint8_t* mask1, float temperature, const int64_t* pos_b, const int64_t* pos_i, const int64_t* pos_j, int P,
                            const float* pos_weight, float alpha, float gamma, float* pos_conf, float* pos_loss,
                            float* pos_grad, void* workspace, size_t workspace_bytes, void* stream);
-int gf_coarse_loss_backward(int N, int L, int S, int C, float temperature, const int64_t* pos_b, const int64_t* pos_i,
+int gf_coarse_loss_backward(int N, int L, int S, int C, const uint8_t* mask0, const uint8_t* mask1, float temperature,
+                            const int64_t* pos_b, const int64_t* pos_i,
                             const int64_t* pos_j, int P, const float* pos_grad, float scale, float* d_f0, float* d_f1,
                             void* workspace, size_t workspace_bytes, void* stream);
 

@@ -39,8 +39,8 @@ def test_train_steps_reduce_loss_and_refresh_inference():
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
-@pytest.mark.parametrize('weighted', [False, True])
-def test_fused_coarse_focal_loss_matches_autograd(dtype, weighted):
+@pytest.mark.parametrize('weighted,masked', [(False, False), (True, False), (True, True)])
+def test_fused_coarse_focal_loss_matches_autograd(dtype, weighted, masked):
     """gf_coarse_loss_forward/backward against torch autograd on the same fp16-rounded features (fp32 math):
     loss and per-positive confidences to 2e-3, gradients to 2e-2 (fp16 MFMA operands, fp32 accumulation)."""
     from geoformer_amd import ops
@@ -60,10 +60,18 @@ def test_fused_coarse_focal_loss_matches_autograd(dtype, weighted):
     pi = torch.arange(0, L - 2, 3, device='cuda').repeat(N)[:pb.numel()]
     pj = inv[pb, pi]
     w = torch.rand(pb.numel(), device='cuda') + 0.5 if weighted else None
+    m0 = m1 = None
+    if masked:                      # zero-padded borders: the last rows of image0's grid, a block of image1's
+        m0 = torch.ones(N, L, dtype=torch.bool, device='cuda'); m0[:, L - 40:] = False
+        m1 = torch.ones(N, S, dtype=torch.bool, device='cuda'); m1[0, 100:170] = False; m1[1, :33] = False
+        keep = m0[pb, pi] & m1[pb, pj]
+        pb, pi, pj, w = pb[keep], pi[keep], pj[keep], w[keep]
 
     a0 = f0.detach().half().float().requires_grad_(True)
     a1 = f1.detach().half().float().requires_grad_(True)
     sim = torch.einsum('nlc,nsc->nls', a0 / C ** .5, a1 / C ** .5) / T
+    if masked:
+        sim = sim.masked_fill(~(m0[..., None] & m1[:, None]), -1e9)
     conf = torch.softmax(sim, 1) * torch.softmax(sim, 2)
     p = torch.clamp(conf, 1e-6, 1 - 1e-6)[pb, pi, pj]
     terms = -0.25 * (1 - p) ** 2.0 * p.log()
@@ -71,7 +79,7 @@ def test_fused_coarse_focal_loss_matches_autograd(dtype, weighted):
     (ref * 0.37).backward()
 
     h0, h1 = f0.detach().clone().requires_grad_(True), f1.detach().clone().requires_grad_(True)
-    loss, pk = ops.coarse_focal_loss(h0, h1, pb, pi, pj, T, 0.25, 2.0, w)
+    loss, pk = ops.coarse_focal_loss(h0, h1, pb, pi, pj, T, 0.25, 2.0, w, m0, m1)
     (loss * 0.37).backward()
     assert 0.02 < float(pk.median()) < 0.98, float(pk.median())
     torch.testing.assert_close(pk, conf[pb, pi, pj].detach(), rtol=2e-3, atol=1e-7)
@@ -82,7 +90,8 @@ def test_fused_coarse_focal_loss_matches_autograd(dtype, weighted):
         assert (got - want).abs().max() < 3e-2 * want.abs().max()
 
 
-def test_train_step_fused_loss_equals_autograd_path():
+@pytest.mark.parametrize('masked', [False, True])
+def test_train_step_fused_loss_equals_autograd_path(masked):
     """Same batch, same weights: the step with the fused HIP coarse loss against the step that differentiates the
     materialised confidence matrices (loss terms to 2e-3, parameter gradients to 3e-2 in norm)."""
     from geoformer_amd.model.cvpr_ds_config import get_default_cfg
@@ -98,6 +107,9 @@ def test_train_step_fused_loss_equals_autograd_path():
     grads, scalars = [], []
     for fused in (None, loss_fn.fused_params()):
         batch = synthetic_homography_batch(2, (128, 256), seed=21, device='cuda')      # 16 x 32 = 512 coarse cells
+        if masked:                  # MegaDepth-style zero padding: bottom rows of image0, right columns of image1
+            batch['mask0'] = torch.ones(2, 16, 32, dtype=torch.bool, device='cuda'); batch['mask0'][:, 13:] = False
+            batch['mask1'] = torch.ones(2, 16, 32, dtype=torch.bool, device='cuda'); batch['mask1'][:, :, 27:] = False
         spvs_coarse(batch)
         forward_train(model, batch, fused_coarse_loss=fused)
         spvs_fine2(batch)
