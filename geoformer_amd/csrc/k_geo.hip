@@ -197,20 +197,31 @@ __global__ __launch_bounds__(256) void window_cross_attention(CaArgs a) {
     const T* vb = (const T*)a.vmap + (size_t)n * a.S * a.ldv + lane * 4;
     float logit[WW];
     int cell[WW];
+#pragma unroll
+    for (int k = 0; k < WW; ++k) cell[k] = win[k];
+    // branch-free gathers: a masked key reads row 0 and is overridden afterwards, so the 25 row loads are issued
+    // back to back and the 16-lane DPP reductions of different keys interleave (the per-key branches had serialised
+    // load -> 4 dependent DPP adds -> next key, with two wait states in front of every DPP read)
+    float dot[WW];
+#pragma unroll
+    for (int k = 0; k < WW; ++k) {
+        const v4f kv = load4<T>(kb + (unsigned)max(cell[k], 0) * (unsigned)a.ldk);     // 32-bit offsets: S * ld < 2^32
+        dot[k] = q.x * kv.x + q.y * kv.y + q.z * kv.z + q.w * kv.w;
+    }
+#pragma unroll
+    for (int k = 0; k < WW; ++k) dot[k] = dpp_add<0xB1>(dot[k]);     // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int k = 0; k < WW; ++k) dot[k] = dpp_add<0x4E>(dot[k]);     // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int k = 0; k < WW; ++k) dot[k] = dpp_add<0x141>(dot[k]);    // row_half_mirror
+#pragma unroll
+    for (int k = 0; k < WW; ++k) dot[k] = dpp_add<0x140>(dot[k]);    // row_mirror
     float mx = -INFINITY;
     bool any = false;
 #pragma unroll
     for (int k = 0; k < WW; ++k) {
-        cell[k] = win[k];
-        float s;
-        if (cell[k] >= 0) {
-            const v4f kv = load4<T>(kb + (size_t)cell[k] * a.ldk);
-            s = row16_sum(q.x * kv.x + q.y * kv.y + q.z * kv.z + q.w * kv.w);
-            any = true;
-        } else {
-            s = -1e8f;                      // masked_fill BEFORE the temperature (geo_attention.py:83,92)
-        }
-        logit[k] = s * a.softmax_temp;
+        any = any || cell[k] >= 0;
+        logit[k] = (cell[k] >= 0 ? dot[k] : -1e8f) * a.softmax_temp;   // masked_fill BEFORE the temperature (geo_attention.py:83,92)
         mx = fmaxf(mx, logit[k]);
     }
     constexpr bool FAST = !std::is_same<T, float>::value;     // fp16 mode: hardware exp / reciprocal
@@ -225,11 +236,10 @@ __global__ __launch_bounds__(256) void window_cross_attention(CaArgs a) {
     if (any) {
 #pragma unroll
         for (int k = 0; k < WW; ++k) {
-            if (cell[k] >= 0) {            // masked keys have weight exp(-1.25e7 - mx) == 0 whenever any key is valid
-                const float p = FAST ? logit[k] * rden : logit[k] / den;
-                const v4f vv = load4<T>(vb + (size_t)cell[k] * a.ldv);
-                acc.x += p * vv.x; acc.y += p * vv.y; acc.z += p * vv.z; acc.w += p * vv.w;
-            }
+            // masked keys have weight exp(-1.25e7 - mx) == 0 whenever any key is valid: their (row 0) values add 0
+            const float p = cell[k] >= 0 ? (FAST ? logit[k] * rden : logit[k] / den) : 0.f;
+            const v4f vv = load4<T>(vb + (unsigned)max(cell[k], 0) * (unsigned)a.ldv);
+            acc.x += p * vv.x; acc.y += p * vv.y; acc.z += p * vv.z; acc.w += p * vv.w;
         }
     }                                       // no valid key: the row is zeroed (geo_attention.py:98-100)
     store4<T>(out, acc);
@@ -269,6 +279,7 @@ extern "C" int gf_window_cross_attention(const void* q, const void* kmap, const 
     GF_CHECK_ARG(q && kmap && vmap && win && out, "null pointer");
     GF_CHECK_ARG(N > 0 && L > 0 && S > 0, "empty problem");
     GF_CHECK_ARG(H == 4 && D == 64 && WW == 25, "built for nhead=4, head dim 64, 5x5 windows (geo_config.py:12,16)");
+    GF_CHECK_ARG((double)S * (double)(ldk > ldv ? ldk : ldv) < 4294967296.0, "key map too large for 32-bit row offsets");
     GF_CHECK_ARG(dtype == GF_F32 || dtype == GF_F16, "dtype must be GF_F32 or GF_F16");
     CaArgs a{q, kmap, vmap, ldq, ldk, ldv, win, valid, out, N, L, S, WW, 1.0f / sqrtf((float)D)};
     const dim3 grid((L + 3) / 4, N);
