@@ -36,7 +36,11 @@ struct LaArgs {
 __device__ __forceinline__ float elu1(float x) { return (x > 0.f ? x : expm1f(x)) + 1.0f; }
 // fp16 path: elu(x) + 1 = exp(x) for x <= 0; the hardware exponential is exact to fp16 rounding and ~20 VALU
 // instructions cheaper than expm1f (which made la16_kv VALU-bound: 32 of them per thread and sub-tile)
-__device__ __forceinline__ float elu1_fast(float x) { return x > 0.f ? x + 1.0f : __expf(x); }
+// (both sides are evaluated and selected: a conditional exponential compiles to a divergent branch per element)
+__device__ __forceinline__ float elu1_fast(float x) {
+    const float e = __expf(fminf(x, 0.f));
+    return x > 0.f ? x + 1.0f : e;
+}
 template <typename T>
 __device__ __forceinline__ float elu1_t(float x) {          // parity (fp32) mode keeps torch's evaluation
     if constexpr (std::is_same<T, float>::value) return elu1(x);
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(256) void la16_apply(LaArgs a) {
                 num = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf, num, 0, 0, 0);
                 den = __builtin_amdgcn_mfma_f32_32x32x16_f16(sf, qf, den, 0, 0, 0);
             }
-            const float z = 1.0f / (den[0] + a.eps * inv_s);     // every row of den holds the token's Q.Ksum / S
+            const float z = __builtin_amdgcn_rcpf(den[0] + a.eps * inv_s);     // every row of den holds the token's Q.Ksum / S
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4)
                 *reinterpret_cast<v4h*>(qt + lr * RS + (hh * 32 + 8 * r4 + 4 * h2) * 2) =
