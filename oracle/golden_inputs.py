@@ -254,3 +254,23 @@ def g15_inputs():
     return {'coarse_thr': 0.0, 'fine_thr': 0.0,
             'data': {'image0': i0, 'image1': i1, 'H_0to1': H01, 'H_1to0': torch.inverse(H01), 'dataset_name': ['oxford'],
                      'pair_names': ['p']}}
+
+
+def g16_inputs():
+    """Depth + pose supervision (MegaDepth / ScanNet branch): two views of a slanted plane with a known relative pose."""
+    g = gen(161)
+    N, H, W = 2, 64, 96
+    K = torch.tensor([[[80., 0., 48.], [0., 80., 32.], [0., 0., 1.]]]).repeat(N, 1, 1)
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing='ij')
+    depth0 = (4.0 + 0.01 * xs + 0.02 * ys)[None].repeat(N, 1, 1) + 0.05 * torch.rand(N, H, W, generator=g)
+    depth0[:, :3, :5] = 0                                              # holes
+    T = torch.eye(4)[None].repeat(N, 1, 1)
+    ang = torch.tensor([0.03, -0.05])
+    T[:, 0, 0] = torch.cos(ang); T[:, 0, 2] = torch.sin(ang); T[:, 2, 0] = -torch.sin(ang); T[:, 2, 2] = torch.cos(ang)
+    T[:, :3, 3] = torch.tensor([[0.15, -0.05, 0.1], [-0.2, 0.03, -0.05]])
+    Tinv = torch.inverse(T)
+    depth1 = (4.1 + 0.012 * xs + 0.018 * ys)[None].repeat(N, 1, 1) + 0.05 * torch.rand(N, H, W, generator=g)
+    kpts = torch.rand(N, 50, 2, generator=g) * torch.tensor([W - 1.0, H - 1.0])
+    coarse = {'image0': torch.zeros(N, 1, H, W), 'image1': torch.zeros(N, 1, H, W), 'depth0': depth0, 'depth1': depth1,
+              'T_0to1': T, 'T_1to0': Tinv, 'K0': K, 'K1': K.clone(), 'dataset_name': ['megadepth'] * N, 'pair_names': ['a', 'b']}
+    return {'kpts': kpts, 'coarse': coarse}
