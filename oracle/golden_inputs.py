@@ -273,4 +273,12 @@ def g16_inputs():
     kpts = torch.rand(N, 50, 2, generator=g) * torch.tensor([W - 1.0, H - 1.0])
     coarse = {'image0': torch.zeros(N, 1, H, W), 'image1': torch.zeros(N, 1, H, W), 'depth0': depth0, 'depth1': depth1,
               'T_0to1': T, 'T_1to0': Tinv, 'K0': K, 'K1': K.clone(), 'dataset_name': ['megadepth'] * N, 'pair_names': ['a', 'b']}
-    return {'kpts': kpts, 'coarse': coarse}
+    M = 9
+    cells0 = torch.randint(12, 8 * 12 - 12, (M,), generator=g)
+    mk0 = torch.stack([cells0 % 12, cells0 // 12], 1).float() * 8
+    mk1 = (mk0 + torch.tensor([8., 0.])).clamp(max=88)
+    fine = {'image0': torch.zeros(1, 1, H, W), 'image1': torch.zeros(1, 1, H, W), 'depth0': depth0[:1], 'depth1': depth1[:1],
+            'T_0to1': T[:1], 'T_1to0': Tinv[:1], 'K0': K[:1], 'K1': K[:1].clone(), 'mkpts0_c': mk0, 'mkpts1_c': mk1,
+            'b_ids': torch.zeros(M, dtype=torch.long), 'W': torch.tensor(5), 'hw0_i': torch.tensor([H, W]),
+            'hw0_c': torch.tensor([H // 8, W // 8]), 'hw0_f': torch.tensor([H // 2, W // 2]), 'dataset_name': ['megadepth']}
+    return {'kpts': kpts, 'coarse': coarse, 'fine': fine}
