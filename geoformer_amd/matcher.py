@@ -40,7 +40,7 @@ def resize_im(wo, ho, imsize=None, dfactor=1, value_to_scale=max, aspan=False):
 def load_gray_scale_tensor(im_path, device, imsize=None, dfactor=8, value_to_scale=min, aspan=False):
     """[1,1,H,W] float in [0,1] + (wo/wt, ho/ht); H, W multiples of dfactor."""
     from PIL import Image
-    im = np.asarray(Image.open(im_path).convert('L'), dtype=np.uint8)
+    im = np.array(Image.open(im_path).convert('L'), dtype=np.uint8)        # a writable copy (torch.from_numpy)
     ho, wo = im.shape
     wt, ht, scale = resize_im(wo, ho, imsize=imsize, dfactor=dfactor, value_to_scale=value_to_scale, aspan=aspan)
     t = torch.from_numpy(im).to(device=device, dtype=torch.float32)[None, None]
@@ -191,3 +191,39 @@ def eval_hpatches(matcher, data_root, ransac_thres=3, thres=(1, 3, 5, 10), scale
     log(f"Hest Correct: a={out['correct_a']} i={out['correct_i']} v={out['correct_v']}")
     log(f"Hest AUC: a={out['auc_a']} i={out['auc_i']} v={out['auc_v']}")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# command line: the counterparts of `python inference.py` and `python eval_Hpatches.py`
+#   python -m geoformer_amd.matcher match im1 im2 [--ckpt saved_ckpt/geoformer.ckpt] [--out matches.npz]
+#   python -m geoformer_amd.matcher hpatches /path/to/hpatches-sequences-release [--ckpt ...]
+# ---------------------------------------------------------------------------------------------
+def main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(prog='python -m geoformer_amd.matcher')
+    sub = ap.add_subparsers(dest='cmd', required=True)
+    m = sub.add_parser('match', help='match one image pair (inference.py)')
+    m.add_argument('im1'), m.add_argument('im2'), m.add_argument('--out', default=None)
+    h = sub.add_parser('hpatches', help='homography AUC over HPatches sequences (eval_Hpatches.py)')
+    h.add_argument('root'), h.add_argument('--max-seqs', type=int, default=None)
+    h.add_argument('--ransac-thres', type=float, default=3.0)
+    for p in (m, h):
+        p.add_argument('--ckpt', default=None)
+        p.add_argument('--imsize', type=int, default=640)            # inference.py:107 / eval_Hpatches.py defaults
+        p.add_argument('--match-threshold', type=float, default=0.2)
+        p.add_argument('--no-match-upscale', action='store_true')
+        p.add_argument('--precision', choices=('fp32', 'fp16'), default='fp16')
+    args = ap.parse_args(argv)
+    matcher = GeoFormerMatcher(args.imsize, args.match_threshold, args.no_match_upscale, args.ckpt, precision=args.precision)
+    if args.cmd == 'match':
+        res = matcher(args.im1, args.im2)
+        print(f'{matcher.name}: {len(res[0])} matches')
+        if args.out:
+            np.savez(args.out, matches=res[0], kpts1=res[1], kpts2=res[2], scores=res[3])
+    else:
+        out = eval_hpatches(matcher, args.root, ransac_thres=args.ransac_thres, max_seqs=args.max_seqs)
+        print({k: (v.tolist() if hasattr(v, 'tolist') else v) for k, v in out.items()})
+
+
+if __name__ == '__main__':
+    main()

@@ -57,3 +57,17 @@ def test_matcher_and_hpatches_protocol(tmp_path):
     out = MT.eval_hpatches(m, root, log=lambda s: None)
     assert len(out['auc_a']) == 4 and len(out['auc_i']) == 4 and len(out['auc_v']) == 4
     assert 0 <= out['failed'] <= 10 and out['match_time'] > 0
+
+
+def test_command_line(tmp_path, capsys):
+    """`python -m geoformer_amd.matcher match|hpatches` (inference.py / eval_Hpatches.py counterparts)."""
+    from geoformer_amd import matcher as MT
+    root = str(tmp_path / 'hp')
+    _write_seq(root, 'v_cli', np.array([[1., 0, 2], [0, 1, 1], [0, 0, 1]]), 3)
+    out = str(tmp_path / 'm.npz')
+    MT.main(['match', os.path.join(root, 'v_cli', '1.ppm'), os.path.join(root, 'v_cli', '2.ppm'), '--imsize', '160',
+             '--match-threshold', '0.0', '--out', out])
+    z = np.load(out)
+    assert z['matches'].shape[1] == 4 and len(z['scores']) == len(z['matches'])
+    MT.main(['hpatches', root, '--imsize', '160', '--match-threshold', '0.0', '--max-seqs', '1'])
+    assert 'auc_a' in capsys.readouterr().out
