@@ -15,7 +15,8 @@
 // The product is computed TRANSPOSED (MFMA A-operand = weight rows, B-operand = token rows) so that the
 // accumulator layout has the TOKEN on the lane and its channels in registers: LayerNorm statistics,
 // the activation, the residual and the predicate are then lane-local (one lane-pair exchange for the
-// mean/variance), with no cross-lane reduction tree.  One wave = 32 tokens x (32*NB) channels;
+// mean/variance), with no cross-lane reduction tree.  One wave = 32 tokens x (32*NB) channels (the fp16 plain /
+// ReLU / Tanh epilogues on 256-wide tiles use the 2 x 2 wave tiling of linear_kernel_w2: 64 tokens x 128 channels);
 // workgroup = 4 waves = 128 tokens; LN epilogues need NB*32 == N (whole rows in one wave pair).
 // fp16 kernels are held to 256 registers (two workgroups per CU; the unconstrained build took 330-380
 // and ran one) and transpose their result through LDS for row-contiguous 16-B stores.
@@ -302,6 +303,123 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void linear_kernel(Lin
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 2 x 2 wave tiling (fp16, 256-channel column tiles, epilogues without LayerNorm): a wave owns 64 tokens x 128
+// channels instead of 32 x 256.  Same 128 accumulator registers, but a k-group now needs 2 token + 4 weight
+// fragments for its 8 MFMAs instead of 1 + 8: a third less LDS read traffic in the K loop, which is LDS-bound.
+// ---------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void linear_kernel_w2(LinArgs a) {
+    using T = _Float16;
+    using Frag = v8h;
+    constexpr int EPC = 8, BK = 64, WROWS = 256, ROWS = 128 + WROWS, NLD = ROWS * 8 / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* st = smem;
+    char* sw = smem + 128 * 128;
+    float* vec = reinterpret_cast<float*>(smem + ROWS * 128);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, lr = lane & 31;
+    const int tm = wave >> 1, tn = wave & 1;
+    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * WROWS;
+    const int K = a.k1 + a.k2;
+    if (tid < WROWS) vec[tid] = (a.bias && n0 + tid < a.N) ? a.bias[n0 + tid] : 0.f;
+    const T* src[NLD];
+    int dst[NLD];
+    bool isa[NLD];
+#pragma unroll
+    for (int p = 0; p < NLD; ++p) {
+        const int e = p * 256 + tid, row = e >> 3, c = e & 7;
+        isa[p] = row < 128;
+        if (isa[p]) {
+            src[p] = nullptr;
+            dst[p] = gf_lds_off(row, c);
+        } else {
+            const int wr = row - 128;
+            src[p] = (const T*)a.w + (size_t)min(n0 + wr, a.N - 1) * K + c * EPC;
+            dst[p] = 128 * 128 + gf_lds_off(wr, c);
+        }
+    }
+    v4u regs[NLD];
+    auto gload = [&](int k0) {
+        const bool first = k0 < a.k1;
+        const T* ab = (const T*)(first ? a.a1 : a.a2);
+        const long ld = first ? a.lda1 : a.lda2;
+        const int kk = first ? k0 : k0 - a.k1;
+#pragma unroll
+        for (int p = 0; p < NLD; ++p) {
+            const int e = p * 256 + tid, row = e >> 3, c = e & 7;
+            const T* g = isa[p] ? ab + (size_t)min(m0 + row, a.M - 1) * ld + kk + c * EPC : src[p] + k0;
+            regs[p] = *reinterpret_cast<const v4u*>(g);
+        }
+    };
+    v16f acc[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][nb][r] = 0.f;
+    const int nk = K / BK;
+    gload(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < NLD; ++p) *reinterpret_cast<v4u*>(smem + dst[p]) = regs[p];
+        __syncthreads();
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int chunk = 2 * g + h;
+            const Frag t0 = *reinterpret_cast<const Frag*>(st + gf_lds_off(tm * 64 + lr, chunk));
+            const Frag t1 = *reinterpret_cast<const Frag*>(st + gf_lds_off(tm * 64 + 32 + lr, chunk));
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const Frag wf = *reinterpret_cast<const Frag*>(sw + gf_lds_off(tn * 128 + nb * 32 + lr, chunk));
+                acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, t0, acc[0][nb], 0, 0, 0);
+                acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, t1, acc[1][nb], 0, 0, 0);
+            }
+        }
+    }
+    // epilogue: lane = token (m0 + tm*64 + t*32 + lr), registers = channels n0 + tn*128 + nb*32 + acc_row(r, h)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[t][nb][r] + vec[tn * 128 + nb * 32 + gf_acc_row(r, h)];
+                if constexpr (EPI == EPI_RELU) v = fmaxf(v, 0.f);
+                else if constexpr (EPI == EPI_TANH) v = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * v) + 1.0f);
+                acc[t][nb][r] = v;
+            }
+    constexpr int RS = 272;
+    __syncthreads();                                     // every wave is done with the fragments
+    char* ot = smem + wave * 32 * RS;
+    const int prow = lane >> 4, pch = lane & 15;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int c = nb * 32 + 8 * r4 + 4 * h;
+                *reinterpret_cast<v4h*>(ot + lr * RS + c * 2) =
+                    v4h{(_Float16)acc[t][nb][4 * r4], (_Float16)acc[t][nb][4 * r4 + 1], (_Float16)acc[t][nb][4 * r4 + 2],
+                        (_Float16)acc[t][nb][4 * r4 + 3]};
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 4 + prow, tg = m0 + tm * 64 + t * 32 + row, cg = n0 + tn * 128 + pch * 8;
+            if (tg >= a.M || cg >= a.N) continue;
+            *reinterpret_cast<v8h*>((T*)a.out + (size_t)tg * a.ldo + cg) = *reinterpret_cast<const v8h*>(ot + row * RS + pch * 16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 template <typename T, int NB, int EPI>
 void lin_launch1(const LinArgs& a, hipStream_t st) {
     constexpr int WROWS = 32 * NB;
@@ -353,7 +471,13 @@ extern "C" int gf_linear(const void* a1, long lda1, int k1, const void* a2, long
     hipStream_t st = (hipStream_t)stream;
     void* pt = gf_prof_begin("k3_linear", st, 2.0 * (double)M * N * (k1 + k2));
     const bool wide = (epilogue >= EPI_LN) ? N == 256 : N % 256 == 0;
-    if (dtype == GF_F32) {
+    if (dtype == GF_F16 && wide && epilogue <= EPI_TANH && rowgroup_bias == nullptr) {
+        const size_t lds = (size_t)(128 + 256) * 128 + 256 * sizeof(float);
+        const dim3 grid((M + 127) / 128, (N + 255) / 256);
+        if (epilogue == EPI_NONE) linear_kernel_w2<EPI_NONE><<<grid, 256, lds, st>>>(a);
+        else if (epilogue == EPI_RELU) linear_kernel_w2<EPI_RELU><<<grid, 256, lds, st>>>(a);
+        else linear_kernel_w2<EPI_TANH><<<grid, 256, lds, st>>>(a);
+    } else if (dtype == GF_F32) {
         if (wide) lin_launch<float, 8>(a, epilogue, st);
         else lin_launch<float, 4>(a, epilogue, st);
     } else {
