@@ -97,8 +97,10 @@ def test_low_threshold_dense_path(thr):
     np.testing.assert_allclose(out['mconf'].numpy(), ref['mconf'].numpy(), rtol=1e-4, atol=1e-12)
 
 
-def test_full_size_properties():
-    """BASELINE size (L=S=6400, fp16 features): size-independent properties of the dual-softmax -
+@pytest.mark.parametrize('thr', [0.2, 0.0])
+def test_full_size_properties(thr):
+    """BASELINE size (L=S=6400, fp16 features; the row-panel-persistent pass B, sparse candidates at thr = 0.2 and the
+    dense-candidate variant bench.py runs at thr = 0): size-independent properties of the dual-softmax -
     row/column sums of sqrt-factors, mutual-nearest consistency, ordering, planted recovery."""
     from geoformer_amd import ops
     N, L, S, C = 2, 6400, 6400, 256
@@ -106,7 +108,7 @@ def test_full_size_properties():
     f0 = torch.randn(N, L, C, generator=g) * 1.3
     perm = torch.stack([torch.randperm(S, generator=g) for _ in range(N)])
     f1 = torch.stack([f0[b][perm[b]] for b in range(N)]) + 0.4 * torch.randn(N, S, C, generator=g)
-    out = ops.dual_softmax_match(f0.cuda().half(), f1.cuda().half(), 0.1, 0.2, (80, 80), (80, 80), 8.0)
+    out = ops.dual_softmax_match(f0.cuda().half(), f1.cuda().half(), 0.1, thr, (80, 80), (80, 80), 8.0)
     torch.cuda.synchronize()
     M = int(out['counts'][0])
     conf = out['conf_matrix']
@@ -121,7 +123,7 @@ def test_full_size_properties():
     # every reported match is the maximum of its row and column and exceeds thr
     assert torch.equal(conf[b, i].argmax(-1), j)
     assert torch.equal(conf[b, :, j].argmax(0) if False else conf.transpose(1, 2)[b, j].argmax(-1), i)
-    assert torch.all(out['mconf'][:M] > 0.2) and torch.equal(out['mconf'][:M], conf[b, i, j])
+    assert torch.all(out['mconf'][:M] > thr) and torch.equal(out['mconf'][:M], conf[b, i, j])
     # conf <= 1 and each row / column of conf sums to <= 1 (product of two probabilities)
     assert float(conf.max()) <= 1.0 + 1e-5
     assert float(conf.sum(-1).max()) <= 1.0 + 1e-4 and float(conf.sum(-2).max()) <= 1.0 + 1e-4
