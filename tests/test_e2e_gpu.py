@@ -140,3 +140,18 @@ def test_golden_fp16_mode(golden, name):
     b = set(zip(G['out_b_ids'].tolist(), G['out_i_ids'].tolist(), G['out_j_ids'].tolist()))
     assert len(a & b) >= 0.9 * max(len(a), len(b)), (len(a), len(b), len(a & b))
     assert out['mkpts0_f'].dtype == torch.float32 and out['conf_matrix'].dtype == torch.float32
+
+
+def test_640_fp16_mode_against_reference(golden):
+    """BASELINE size in the fast mode (panel K1, MFMA K2, tiled K3, device RANSAC): the coarse matches against the
+    REFERENCE's fp32 run (recorded homography replaced by the device RANSAC, fp16 storage): >= 95 % common."""
+    G, case = golden('g11_e2e_640_digest'), GI.g11_inputs()
+    m = build(case['coarse_thr'], case['fine_thr'], 'fp16')
+    m.geo_module.homography_fn = None
+    (c0, f0), (c1, f1) = case['feats']
+    with torch.no_grad():
+        out = m.forward_features(to_dev(case['data']), c0.to(DEV).half(), f0.to(DEV).half(), c1.to(DEV).half(), f1.to(DEV).half())
+    a = set(zip(out['i_ids'].tolist(), out['j_ids'].tolist()))
+    b = set(zip(G['i_ids'].astype(np.int64).tolist(), G['j_ids'].astype(np.int64).tolist()))
+    assert len(b) == int(G['M']) and len(a & b) >= 0.95 * max(len(a), len(b)), (len(a), len(b), len(a & b))
+    assert abs(len(out['mkpts0_f']) - int(G['Mf'])) <= 0.05 * int(G['Mf'])
