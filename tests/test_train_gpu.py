@@ -123,3 +123,30 @@ def test_train_step_fused_loss_equals_autograd_path(masked):
     num = sum(((grads[1][n] - grads[0][n]) ** 2).sum() for n in grads[0])
     den = sum((grads[0][n] ** 2).sum() for n in grads[0])
     assert float(torch.sqrt(num / den)) < 3e-2
+
+
+def test_fused_coarse_focal_loss_full_size():
+    """The coarse level's real size (one pair, L = S = 6400): fused HIP loss against autograd."""
+    from geoformer_amd import ops
+    torch.manual_seed(12)
+    N, L, S, C, T = 1, 6400, 6400, 256, 0.1
+    f0 = torch.randn(N, L, C, device='cuda') * 0.75
+    perm = torch.randperm(S, device='cuda')[None]
+    f1 = (f0[:, perm[0]] + 0.6 * torch.randn(N, S, C, device='cuda')).half()
+    f0 = f0.half()
+    inv = torch.argsort(perm, dim=1)
+    pi = torch.arange(0, L, 2, device='cuda')
+    pb = torch.zeros_like(pi)
+    pj = inv[0, pi]
+    a0, a1 = f0.float().requires_grad_(True), f1.float().requires_grad_(True)
+    sim = torch.einsum('nlc,nsc->nls', a0 / C ** .5, a1 / C ** .5) / T
+    conf = torch.softmax(sim, 1) * torch.softmax(sim, 2)
+    p = torch.clamp(conf, 1e-6, 1 - 1e-6)[pb, pi, pj]
+    ref = (-0.25 * (1 - p) ** 2.0 * p.log()).mean()
+    ref.backward()
+    h0, h1 = f0.clone().requires_grad_(True), f1.clone().requires_grad_(True)
+    loss, pk = ops.coarse_focal_loss(h0, h1, pb, pi, pj, T)
+    (loss / pi.numel()).backward()
+    torch.testing.assert_close(loss.detach() / pi.numel(), ref.detach(), rtol=2e-3, atol=1e-7)
+    for got, want in ((h0.grad.float(), a0.grad), (h1.grad.float(), a1.grad)):
+        assert float((got - want).norm() / want.norm()) < 2e-2
