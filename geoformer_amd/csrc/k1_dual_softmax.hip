@@ -48,7 +48,8 @@ struct K1Args {
     const uint8_t* mask1;
     float inv_c, temperature, mult;   // sim = acc*inv_c/temperature (exact) or acc*mult (fast)
     int tilesM, tilesN;
-    float2* rowpart;   // [N][tilesN][L]  (max, sumexp)
+    int rowparts;      // number of row partials per row: tilesN (tile form) or the number of tile runs (panel form)
+    float2* rowpart;   // [N][rowparts][L]  (max, sumexp)
     float2* colpart;   // [N][tilesM][S]
     float2* rstat;     // [N][L]  (max, sum)
     float2* cstat;     // [N][S]
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(256) void k1_reduce_stats(K1Args a) {
     __shared__ float2 sh[8][32];
     const int n = blockIdx.z;
     const bool rows = blockIdx.y == 0;
-    const int len = rows ? a.L : a.S, np = rows ? a.tilesN : a.tilesM;
+    const int len = rows ? a.L : a.S, np = rows ? a.rowparts : a.tilesM;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + tx;
     if (blockIdx.x * 32 >= len) return;
@@ -606,6 +607,111 @@ __global__ __launch_bounds__(NT, 2) void k1_conf_panel(K1Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// pass A in the same row-panel-persistent form: the f0 panel lives in registers, f1 tiles stream through LDS one tile
+// ahead, and - the point - the ROW statistics stay in the lane that owns the row slot for the whole run of tiles
+// (online max / rescaled sum per slot, 3 exponentials per slot and tile) and cross the lanes once per run instead
+// of two 32-lane reduce-scatters per tile.  Column statistics are lane-local per tile as before.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT, 2) void k1_stats_panel(K1Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* colx = reinterpret_cast<float2*>(smem + BN * 512);            // [4 waves][64] column partials of the tile
+    float* rowbc = reinterpret_cast<float*>(smem + BN * 512 + 4 * 64 * 8);  // [4 waves][32] row maxima of the run
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, lr = lane & 31;
+    const int runs = (a.tilesN + PANEL_TILES - 1) / PANEL_TILES;
+    const int units = a.N * a.tilesM * runs;
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = (nwg + 7 - xcd) >> 3;
+    const int q8 = units >> 3, rem = units & 7;
+    const int ubeg = xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8, ucnt = q8 + (xcd < rem ? 1 : 0);
+    const int srow = tid >> 5, schunk = tid & 31;
+    for (int ui = slot; ui < ucnt; ui += per_xcd) {
+        const int u = ubeg + ui;
+        const int run = u % runs, pm = u / runs, bm = pm % a.tilesM, n = pm / a.tilesM;
+        const int m0 = bm * BM, t0 = run * PANEL_TILES, t1 = min(t0 + PANEL_TILES, a.tilesN);
+        const _Float16* A = (const _Float16*)a.f0 + ((size_t)n * a.L + m0 + wave * 32 + lr) * a.C + h * 8;
+        const _Float16* B = (const _Float16*)a.f1 + (size_t)n * a.S * a.C;
+        v8h af[16];
+#pragma unroll
+        for (int kg = 0; kg < 16; ++kg) af[kg] = *reinterpret_cast<const v8h*>(A + kg * 16);
+        v4u rb[8];
+        auto prefetch = [&](int bn) {
+            const _Float16* g = B + (size_t)(bn * BN + srow) * a.C + schunk * 8;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) rb[p] = *reinterpret_cast<const v4u*>(g + (size_t)p * 8 * a.C);
+        };
+        prefetch(t0);
+        float rm[16], rs[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { rm[r] = NEG_INF; rs[r] = 0.f; }
+        for (int bn = t0; bn < t1; ++bn) {
+            __syncthreads();                                  // previous tile: fragments consumed, colx combined
+#pragma unroll
+            for (int p = 0; p < 8; ++p) *reinterpret_cast<v4u*>(smem + k1p_off(srow + 8 * p, schunk)) = rb[p];
+            __syncthreads();
+            if (bn + 1 < t1) prefetch(bn + 1);
+            v16f acc[2];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+#pragma unroll
+            for (int kg = 0; kg < 16; ++kg) {
+                const v8h b0 = *reinterpret_cast<const v8h*>(smem + k1p_off(lr, 2 * kg + h));
+                const v8h b1 = *reinterpret_cast<const v8h*>(smem + k1p_off(32 + lr, 2 * kg + h));
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kg], b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kg], b1, acc[1], 0, 0, 0);
+            }
+            // ---- columns (lane = column): max and sum over this wave's 32 rows
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                float m = NEG_INF;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[ni][r]);
+                m = fmaxf(m, __shfl_xor(m, 32, 64)) * a.mult;
+                float l = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) l += __expf(fmaf(acc[ni][r], a.mult, -m));
+                l += __shfl_xor(l, 32, 64);
+                if (h == 0) colx[wave * 64 + ni * 32 + lr] = make_float2(m, l);
+            }
+            // ---- rows (register slot = row): online (max, sum) over the run's columns held by this lane
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float s0 = acc[0][r] * a.mult, s1 = acc[1][r] * a.mult;
+                const float mn = fmaxf(rm[r], fmaxf(s0, s1));
+                rs[r] = rs[r] * __expf(rm[r] - mn) + __expf(s0 - mn) + __expf(s1 - mn);
+                rm[r] = mn;
+            }
+            __syncthreads();
+            if (tid < 64) {                                   // combine the four waves' column partials
+                float m = NEG_INF;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) m = fmaxf(m, colx[w * 64 + tid].x);
+                float l = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) l += colx[w * 64 + tid].y * __expf(colx[w * 64 + tid].x - m);
+                a.colpart[((size_t)n * a.tilesM + bm) * a.S + bn * BN + tid] = make_float2(m, l);
+            }
+        }
+        // ---- end of the run: row maxima across the lanes, sums rescaled to them, sums across the lanes
+        float v[32];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { v[q] = rm[q]; v[16 + q] = NEG_INF; }
+        const float rmax = k1_row_reduce(v, GfMaxF());
+        if (lr < 16) rowbc[wave * 32 + h * 16 + lr] = rmax;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            v[q] = rs[q] * __expf(rm[q] - rowbc[wave * 32 + h * 16 + q]);
+            v[16 + q] = 0.f;
+        }
+        const float rsum = k1_row_reduce(v, GfAddF());
+        if (lr < 16) a.rowpart[((size_t)n * runs + run) * a.L + m0 + wave * 32 + gf_acc_row(lr, h)] = make_float2(rmax, rsum);
+    }
+}
+
 #if K1_TRACE
 }
 extern "C" int gf_debug_k1_trace(long long* out) {
@@ -774,16 +880,18 @@ int k1_launch(K1Args a, SelArgs s, void* zero_begin, size_t zero_bytes, hipStrea
     constexpr bool EXACT = std::is_same<T, float>::value;
     const dim3 grid(a.tilesN * a.tilesM, a.N);
     (void)hipMemsetAsync(zero_begin, 0, zero_bytes, st);   // rowbest, colmax, samplecnt (contiguous)
+    const bool panel = !EXACT && a.mask0 == nullptr && a.L % BM == 0 && a.S % BN == 0 && a.C == 256;
+    const int runs = (a.tilesN + PANEL_TILES - 1) / PANEL_TILES;
+    const int units = a.N * a.tilesM * runs, wgs = units < 512 ? units : 512;    // two resident workgroups per CU
+    a.rowparts = panel ? runs : a.tilesN;
     void* p0 = gf_prof_begin("k1_stats", st, 2.0 * a.N * (double)a.L * a.S * a.C);
-    k1_stats<T><<<grid, NT, STAGE_BYTES, st>>>(a);
+    if (panel) k1_stats_panel<<<wgs, NT, PANEL_LDS + 2048, st>>>(a);
+    else k1_stats<T><<<grid, NT, STAGE_BYTES, st>>>(a);
     gf_prof_end("k1_stats", p0, st);
     const int mx = a.L > a.S ? a.L : a.S;
     k1_reduce_stats<EXACT><<<dim3((mx + 31) / 32, 2, a.N), 256, 0, st>>>(a);
     void* p1 = gf_prof_begin("k1_conf", st, (double)a.N * ((double)(a.L + a.S) * a.C * sizeof(T) + (double)a.L * a.S * 4.0));
-    const bool panel = !EXACT && a.mask0 == nullptr && a.L % BM == 0 && a.S % BN == 0 && a.C == 256;
     if (panel) {
-        const int units = a.N * a.tilesM * ((a.tilesN + PANEL_TILES - 1) / PANEL_TILES);
-        const int wgs = units < 512 ? units : 512;           // two resident workgroups per CU
         if (a.dense) k1_conf_panel<true><<<wgs, NT, PANEL_LDS, st>>>(a);
         else k1_conf_panel<false><<<wgs, NT, PANEL_LDS, st>>>(a);
     } else if (a.dense) k1_conf<T, true><<<grid, NT, STAGE_BYTES, st>>>(a);
@@ -1161,7 +1269,7 @@ extern "C" int gf_coarse_loss_forward(const void* f0, const void* f1, int dtype,
     a.f0 = w.f0h; a.f1 = w.f1h; a.N = N; a.L = L; a.S = S; a.C = C;
     a.mask0 = mask0; a.mask1 = mask1;
     a.inv_c = 1.0f / (float)C; a.temperature = temperature; a.mult = (1.0f / (float)C) / temperature;
-    a.tilesM = L / BM; a.tilesN = S / BN;
+    a.tilesM = L / BM; a.tilesN = S / BN; a.rowparts = a.tilesN;
     a.rowpart = w.rowpart; a.colpart = w.colpart; a.rstat = w.rstat; a.cstat = w.cstat;
     k1_stats<_Float16><<<dim3(a.tilesN * a.tilesM, N), NT, STAGE_BYTES, st>>>(a);
     const int mx = L > S ? L : S;
