@@ -1269,9 +1269,16 @@ extern "C" int gf_coarse_loss_forward(const void* f0, const void* f1, int dtype,
     a.f0 = w.f0h; a.f1 = w.f1h; a.N = N; a.L = L; a.S = S; a.C = C;
     a.mask0 = mask0; a.mask1 = mask1;
     a.inv_c = 1.0f / (float)C; a.temperature = temperature; a.mult = (1.0f / (float)C) / temperature;
-    a.tilesM = L / BM; a.tilesN = S / BN; a.rowparts = a.tilesN;
+    a.tilesM = L / BM; a.tilesN = S / BN;
     a.rowpart = w.rowpart; a.colpart = w.colpart; a.rstat = w.rstat; a.cstat = w.cstat;
-    k1_stats<_Float16><<<dim3(a.tilesN * a.tilesM, N), NT, STAGE_BYTES, st>>>(a);
+    if (mask0 == nullptr) {                                   // panel form (needs no masks)
+        const int runs = (a.tilesN + PANEL_TILES - 1) / PANEL_TILES, units = N * a.tilesM * runs;
+        a.rowparts = runs;
+        k1_stats_panel<<<units < 512 ? units : 512, NT, PANEL_LDS + 2048, st>>>(a);
+    } else {
+        a.rowparts = a.tilesN;
+        k1_stats<_Float16><<<dim3(a.tilesN * a.tilesM, N), NT, STAGE_BYTES, st>>>(a);
+    }
     const int mx = L > S ? L : S;
     k1_reduce_stats<false><<<dim3((mx + 31) / 32, 2, N), 256, 0, st>>>(a);
     PosArgs p{};
