@@ -3,14 +3,19 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--precision fp16|fp32]
 
-Workload (BASELINE.json configs[4], "batched inference, synthetic 640x640 pairs, fp16 features"):
-every rank owns its static shard of the pair list and runs `steps` batches of `batch` pairs through
-the FULL forward (ResNet-FPN backbone on PyTorch-ROCm + the HIP matching path); there is no data-path
-collective (pairs are independent), so scaling is weak: per-GPU work is fixed as N grows.
-Inputs are resident in HBM before the timed region.  Weights: deterministic closed-form fill of the
-reference architecture (no checkpoint offline); thresholds 0 so that matches flow through every stage,
-as in the reference CPU measurement of BASELINE.md section 2 - M (coarse matches) and K (inlier cells)
-are reported because cost scales with them.
+Workload (BASELINE.json configs[4], "batched inference, 1024 synthetic 640x640 pairs, fp16 features, 8 GPUs
+embarrassingly-parallel shard"): the pair list (seeds 0 .. N*K*B-1) is cut into contiguous per-rank blocks
+(`geoformer_amd.shard.shard_bounds`, the reference's own habit: homodataset/HomoDataset.py:40-45) and every rank
+runs `steps` batches of `batch` pairs of its block through the FULL forward (ResNet-FPN backbone on PyTorch-ROCm +
+the HIP matching path).  There is no data-path collective (pairs are independent), so scaling is weak: per-GPU
+work is fixed as N grows.  Inputs are resident in HBM before the timed region.  Weights: deterministic
+closed-form fill of the reference architecture (no checkpoint offline); thresholds 0 so that matches flow through
+every stage, as in the reference CPU measurement of BASELINE.md section 2 - M (coarse matches) and K (inlier
+cells) are reported because cost scales with them.
+
+Launching: `--gpus N` (N > 1) without a launcher starts the N ranks ITSELF (fresh child processes, before anything
+in the parent touches the GPU), waits for them and relays rank 0's line; under `python -m torch.distributed.run`
+(RANK / LOCAL_RANK / WORLD_SIZE in the environment) it is one of the ranks.  `--gpus` must equal the world size.
 
 One JSON line on rank 0 (see README / DESIGN.md for the fields).
 """
@@ -18,30 +23,144 @@ import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# MIOpen's convolution search results for the bench shapes are shipped with the repo (plain-text user
-# find-db for gfx950), so warm-up looks the algorithms up instead of re-running a multi-minute search; every
-# process works on its own copy (geoformer_amd/miopen.py)
-from geoformer_amd import miopen as gf_miopen  # noqa: E402
-gf_miopen.use_shipped_find_db()
-
-import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+MFMA_PEAK_TFLOPS = {'fp16': 2500.0, 'fp32': 157.3}     # dense, same table
+
+# kernel families that carry HIP events in libgeoformer_hip.so (gf_prof_begin tags): what the declared work unit
+# is, which roofline bounds the family, and whether it belongs to the matching path (the north_star's hot path)
+ROOFLINE_TAGS = [
+    # tag,                   bound,  hot path, description
+    ('enc_layer',            'mfma', True,  'fused encoder layer (projections + attention apply + merge/LN + MLP/LN + residual)'),
+    ('enc_kv_state',         'mfma', True,  'fused k/v projection + linear-attention state'),
+    ('k3_linear',            'mfma', True,  'K3 linear_kernel family (encoder-layer / fine-level GEMMs with fused epilogues)'),
+    ('k1_stats',             'mfma', True,  'K1 pass A (similarity tile statistics)'),
+    ('k1_conf',              'hbm',  True,  'K1 pass B (dual-softmax correlation sweep, conf_matrix write)'),
+    ('k2_linear_attention',  'hbm',  True,  'K2 linear attention (state + apply)'),
+    ('k5_window_attention',  'hbm',  True,  'K5 windowed cross attention (L2 gather)'),
+    ('bias_act',             'hbm',  False, 'backbone glue: shift + shortcut + activation stream'),
+]
 
 
-def synth_pairs(batch, seed, size=640, device='cpu'):
-    """bench-pair(seed): low-frequency texture + pixel noise; image1 = image0 under a random homography
-    (corner perturbation <= 32 px).  SURVEY section 8d."""
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=8, help='pairs per GPU per step')
+    ap.add_argument('--size', type=int, default=640)
+    ap.add_argument('--precision', default='fp16', choices=['fp16', 'fp32'])
+    ap.add_argument('--pairs', default='homography', choices=['homography', 'shift'],
+                    help="image1 = image0 under a random homography (default), or shifted by one coarse cell (the pair of "
+                         "the reference's CPU measurement, BASELINE.md section 2: ~2400 coarse matches per pair)")
+    ap.add_argument('--coarse-thr', type=float, default=0.0)
+    ap.add_argument('--fine-thr', type=float, default=0.0)
+    ap.add_argument('--streams', type=int, default=2, help='concurrent forward pipelines (host threads, one HIP stream each)')
+    ap.add_argument('--tune', action='store_true', help='let MIOpen search its convolution algorithms (minutes)')
+    ap.add_argument('--save-db', action='store_true', help='with --tune: copy the searched find-db over geoformer_amd/miopen_db')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the nominal-load and fp32 parity-mode side measurements')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='launcher / rendezvous / shard plan only, on CPU over gloo (what tests/test_bench_launcher.py runs)')
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# launcher: --gpus N without RANK/WORLD_SIZE in the environment
+# ---------------------------------------------------------------------------------------------------------------
+def spawn_ranks(args, argv):
+    """Starts N fresh child processes of this script (one per GPU) and relays rank 0's JSON line.  Nothing in this
+    parent initialises the GPU.  Returns the exit code: 0 only if every rank exited 0 and the line says n_gpus == N."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), GEOFORMER_BENCH_CHILD='1')
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if any(codes):
+        print(f'bench.py: ranks exited with {codes}', file=sys.stderr)
+        return 1
+    try:
+        line = json.loads([ln for ln in out0.splitlines() if ln.startswith('{')][-1])
+    except (IndexError, ValueError):
+        print('bench.py: rank 0 printed no JSON line', file=sys.stderr)
+        return 1
+    if line.get('n_gpus') != args.gpus:
+        print(f"bench.py: {line.get('n_gpus')} ranks joined, {args.gpus} requested", file=sys.stderr)
+        return 1
+    return 0
+
+
+def dist_env(args):
+    rank, local, world = (int(os.environ.get(k, d)) for k, d in (('RANK', 0), ('LOCAL_RANK', 0), ('WORLD_SIZE', 1)))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: pass --gpus equal to the number of ranks '
+                         f'(or drop the launcher and let bench.py start them)')
+    return rank, local, world
+
+
+def dry_run(args):
+    """The distributed skeleton without a GPU: rendezvous over gloo, the shard plan, the barrier-bracketed timed
+    region and the MAX all-reduce of its duration - everything bench.py does around the forward passes."""
+    import torch
+    import torch.distributed as dist
+    from geoformer_amd.shard import shard_bounds
+    rank, _, world = dist_env(args)
+    if world > 1:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    total = args.steps * args.batch * world
+    lo, hi = shard_bounds(total, world, rank)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (1 + rank))                         # rank-dependent 'work': the MAX must come from the last rank
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    plan = [None] * world
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_gather_object(plan, (rank, lo, hi))
+    else:
+        plan = [(rank, lo, hi)]
+    if rank == 0:
+        print(json.dumps({'metric': 'image-pairs/sec (640x640)', 'value': 0.0, 'unit': 'image-pairs/s', 'n_gpus': world,
+                          'steps': args.steps, 'warmup': args.warmup, 'dry_run': True, 'elapsed_max_s': float(t[0]),
+                          'shard_plan': plan, 'scaling': 'weak'}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# workload
+# ---------------------------------------------------------------------------------------------------------------
+def synth_pairs(batch, seed, size=640, device='cpu', kind='homography'):
+    """bench-pair(seed): low-frequency texture + pixel noise; image1 = image0 under a random homography (corner
+    perturbation <= 32 px) or, kind='shift', shifted by one coarse cell (8 px) in x and y (the
+    pair of the reference's own CPU timing)."""
+    import torch
     g = torch.Generator().manual_seed(seed)
     base = torch.rand(batch, 1, size // 8 + 2, size // 8 + 2, generator=g)
     img = torch.nn.functional.interpolate(base, size=(size + 16, size + 16), mode='bicubic', align_corners=True)
     img = (img + 0.15 * torch.rand(batch, 1, size + 16, size + 16, generator=g)).clamp(0, 1)
     image0 = img[:, :, 8:8 + size, 8:8 + size].contiguous()
+    if kind == 'shift':
+        return image0.to(device), img[:, :, 16:16 + size, 16:16 + size].contiguous().to(device)
     # projective warp through a sampling grid: corners move by up to +-32 px
     src = torch.tensor([[-1., -1.], [1., -1.], [-1., 1.], [1., 1.]])
     dst = src[None] + (torch.rand(batch, 4, 2, generator=g) - 0.5) * (2 * 64.0 / size)
@@ -75,11 +194,12 @@ def build_model(precision, coarse_thr, fine_thr, device):
     return m.to(device), W
 
 
-def cpu_baseline(W, coarse_thr, fine_thr, size, seconds_budget=25.0):
+def cpu_baseline(W, coarse_thr, fine_thr, size, kind, seconds_budget=25.0):
     """The oracle (a PyTorch-CPU port of the reference's forward) on the host cores, same workload,
     a bounded sample of pairs.  torch's intra-op pool is capped at 32 threads: on the 256-thread hosts
     of the GPU boxes more threads make these medium-sized ops slower, not faster (measured 164 s/pair
     with all 256)."""
+    import torch
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import geoformer_oracle as O
     import ransac_oracle as RO
@@ -89,7 +209,7 @@ def cpu_baseline(W, coarse_thr, fine_thr, size, seconds_budget=25.0):
     cfg.update(coarse_thr=coarse_thr, fine_thr=fine_thr)
 
     def one(seed, sz):
-        i0, i1 = synth_pairs(1, seed, sz)
+        i0, i1 = synth_pairs(1, seed, sz, kind=kind)
         t = time.perf_counter()
         with torch.no_grad():
             out = O.geoformer_forward(W, {'image0': i0, 'image1': i1}, None, cfg, RO.make_homography_fn())
@@ -105,26 +225,136 @@ def cpu_baseline(W, coarse_thr, fine_thr, size, seconds_budget=25.0):
                       f'the reference forward incl. backbone and RANSAC), {per_pair:.2f} s/pair, M={M} on the last pair'}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=8, help='pairs per GPU per step')
-    ap.add_argument('--size', type=int, default=640)
-    ap.add_argument('--precision', default='fp16', choices=['fp16', 'fp32'])
-    ap.add_argument('--coarse-thr', type=float, default=0.0)
-    ap.add_argument('--fine-thr', type=float, default=0.0)
-    ap.add_argument('--streams', type=int, default=2, help='concurrent forward pipelines (host threads, one HIP stream each)')
-    ap.add_argument('--tune', action='store_true', help='let MIOpen search its convolution algorithms (minutes) and extend the shipped find-db')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    args = ap.parse_args()
+class Pipelines:
+    """`nstreams` persistent host threads, each with its own HIP stream, taking the steps round-robin: while one
+    forward waits on its two host syncs (match counts) or runs small latency-bound kernels (RANSAC, compaction) the
+    other keeps the GPU fed.  All K timed steps are executed inside the timed region."""
 
-    rank = int(os.environ.get('RANK', 0))
-    local = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    def __init__(self, step_fn, nstreams, dev):
+        import queue
+        import threading
+        import torch
+        self.torch, self.step_fn, self.n, self.dev = torch, step_fn, nstreams, dev
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+        self.jobs = [queue.Queue() for _ in range(nstreams)]
+        self.done = queue.Queue()
+        self.results = {}
+        self.serial = False
+        self.pool = [threading.Thread(target=self._worker, args=(w,), daemon=True) for w in range(nstreams)]
+        for t in self.pool:
+            t.start()
+
+    def _record(self, i, out):
+        # keep the counts and the small geometry summary only: holding every step's output (two 1.3 GB confidence
+        # matrices each) made the timed steps hipMalloc fresh memory - up to 3.5x the step time on a fresh box
+        self.results[i] = (len(out['b_ids']), len(out['mkpts0_f']), out.get('_geo_dev', {}).get('nidx'))
+
+    def _worker(self, w):
+        torch = self.torch
+        torch.cuda.set_device(self.dev)
+        with torch.cuda.stream(self.streams[w]):
+            while True:
+                job = self.jobs[w].get()
+                if job is None:
+                    return
+                first, count = job
+                try:
+                    for i in (range(first, first + 1) if count == 0 else range(first + w, first + count, self.n)):
+                        out = self.step_fn(i)
+                        self._record(i, out)
+                        del out
+                    self.streams[w].synchronize()
+                    self.done.put(w)
+                except BaseException as e:          # surface a failed step instead of hanging the barrier
+                    self.done.put(e)
+
+    def run_single(self, w, i):
+        self.jobs[w].put((i, 0))
+        r = self.done.get()
+        if isinstance(r, BaseException):
+            raise r
+
+    def run(self, first, count):
+        if self.serial:
+            for i in range(first, first + count):
+                out = self.step_fn(i)
+                self._record(i, out)
+                del out
+            self.torch.cuda.synchronize()
+            return
+        for w in range(self.n):
+            self.jobs[w].put((first, count))
+        for _ in range(self.n):
+            r = self.done.get()
+            if isinstance(r, BaseException):
+                raise r
+
+    def close(self):
+        for q in self.jobs:
+            q.put(None)
+
+
+def measure(model, batches, steps, warmup, nstreams, dev, dist, log, profile_tag=None, L=None):
+    """W untimed + K timed steps of `model` over the resident `batches`; returns (elapsed_s, pipelines)."""
+    import torch
+    nres = len(batches)
+
+    def step(i):
+        i0, i1 = batches[i % nres]
+        with torch.no_grad():
+            return model({'image0': i0, 'image1': i1})
+    pipes = Pipelines(step, max(1, min(nstreams, steps)), dev)
+    step(0)                          # single-threaded first pass: fills the weight / table caches
+    torch.cuda.synchronize()
+    # each pipeline thread owns its MIOpen handle: let every one of them look its convolution algorithms up ALONE
+    # first (concurrent first lookups of the user find-db were seen to leave a handle on slow fallback picks for
+    # the whole process: 3.7x slower steps in ~1 of 10 fresh-box runs)
+    for w in range(pipes.n):
+        pipes.run_single(w, w)
+    t = time.perf_counter()
+    step(0)
+    torch.cuda.synchronize()
+    t_serial = time.perf_counter() - t
+    t = time.perf_counter()
+    pipes.run(0, warmup)
+    torch.cuda.synchronize()
+    t_threads = (time.perf_counter() - t) / max(warmup, 1)
+    if pipes.n > 1 and warmup >= 2 and t_threads > 1.5 * t_serial:
+        log(f'pipelined steps run at {t_threads * 1e3:.1f} ms against {t_serial * 1e3:.1f} ms single-threaded: '
+            f'falling back to one host pipeline')
+        pipes.serial = True
+    if dist is not None:
+        dist.barrier()
+    if profile_tag is not None:
+        # inside the timed region only ONE kernel family carries HIP events (two launches per step); event pairs
+        # around all ~110 profiled launches per step were seen to slow a whole run 3.5x on some boxes
+        L.gf_profile_filter(profile_tag)
+        L.gf_profile_enable(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pipes.run(warmup, steps)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, pipes, step
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args, argv))
+    if args.dry_run:
+        return dry_run(args)
+    rank, local, world = dist_env(args)
+
+    # MIOpen's convolution search results for the bench shapes are shipped with the repo (plain-text user find-db
+    # for gfx950), so warm-up looks the algorithms up instead of re-running a multi-minute search; every process
+    # works on its own copy (geoformer_amd/miopen.py) and the shipped files are only rewritten by --tune --save-db
+    from geoformer_amd import miopen as gf_miopen
+    gf_miopen.use_shipped_find_db()
+    import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -132,12 +362,9 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
-
-    # MIOpen: the repo ships the user find-db (geoformer_amd/miopen_db) holding the tuned convolution picks
-    # for the bench shapes, so immediate mode finds them without a search (4 s start-up instead of minutes,
-    # same speed).  --tune re-runs the search (and extends the db) for other batch sizes.
     torch.backends.cudnn.benchmark = args.tune
     from geoformer_amd import _lib
+    from geoformer_amd.shard import shard_bounds
     L = _lib.lib()
     tlog = time.perf_counter()
 
@@ -145,78 +372,16 @@ def main():
         if rank == 0:
             print(f'[bench +{time.perf_counter() - tlog:6.1f}s] {msg}', file=sys.stderr, flush=True)
     model, W = build_model(args.precision, args.coarse_thr, args.fine_thr, dev)
-    # static shard: rank r owns pairs [r*steps*batch, (r+1)*steps*batch); a few distinct batches are
-    # kept resident and cycled so that HBM holds the inputs before the timed region starts
+    # static shard: the job is the pair list 0 .. world*steps*batch-1; this rank owns the contiguous block
+    # [lo, hi).  A few distinct batches of the block are kept resident and cycled so that HBM holds the inputs
+    # before the timed region starts.
+    lo, hi = shard_bounds(world * args.steps * args.batch, world, rank)
+    assert hi - lo == args.steps * args.batch
     nres = min(args.steps, 4)
-    batches = [synth_pairs(args.batch, seed=rank * 100003 + i, size=args.size, device=dev) for i in range(nres)]
 
-    def step(i):
-        i0, i1 = batches[i % nres]
-        with torch.no_grad():
-            return model({'image0': i0, 'image1': i1})
-
-    # `streams` host threads, each with its own HIP stream, take the steps round-robin: while one forward
-    # waits on its two host syncs (match counts) or runs small latency-bound kernels (RANSAC, compaction),
-    # the other keeps the GPU fed.  All of the K timed steps are still executed inside the timed region.
-    import threading
-    nstreams = max(1, min(args.streams, args.steps))
-    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
-    results = {}
-
-    # persistent pipeline threads (created once: their thread-local HIP / MIOpen state is warm before the
-    # timed region), fed with (first, count) jobs
-    import queue
-    jobs = [queue.Queue() for _ in range(nstreams)]
-    done = queue.Queue()
-
-    def worker(w):
-        torch.cuda.set_device(dev)
-        with torch.cuda.stream(streams[w]):
-            while True:
-                job = jobs[w].get()
-                if job is None:
-                    return
-                first, count = job
-                try:
-                    for i in (range(first, first + 1) if count == 0 else range(first + w, first + count, nstreams)):
-                        out = step(i)
-                        # keep the counts and the small geometry summary only: holding every step's output (two
-                        # 1.3 GB confidence matrices each) made the timed steps hipMalloc fresh memory, which on
-                        # a freshly started GPU box cost up to 3.5x the step time
-                        results[i] = (len(out['b_ids']), len(out['mkpts0_f']), out.get('_geo_dev', {}).get('nidx'))
-                        del out
-                    streams[w].synchronize()
-                    done.put(w)
-                except BaseException as e:          # surface a failed step instead of hanging the barrier
-                    done.put(e)
-    pool = [threading.Thread(target=worker, args=(w,), daemon=True) for w in range(nstreams)]
-    for t in pool:
-        t.start()
-
-    def run_single(w, i):
-        """One step on pipeline w alone (count == 0 marks it)."""
-        jobs[w].put((i, 0))
-        r = done.get()
-        if isinstance(r, BaseException):
-            raise r
-
-    serial = [False]
-
-    def run(first, count):
-        if serial[0]:
-            for i in range(first, first + count):
-                out = step(i)
-                results[i] = (len(out['b_ids']), len(out['mkpts0_f']), out.get('_geo_dev', {}).get('nidx'))
-                del out
-            torch.cuda.synchronize()
-            return
-        for w in range(nstreams):
-            jobs[w].put((first, count))
-        for _ in range(nstreams):
-            r = done.get()
-            if isinstance(r, BaseException):
-                raise r
-
+    def resident(kind):
+        return [synth_pairs(args.batch, seed=lo + i * args.batch, size=args.size, device=dev, kind=kind) for i in range(nres)]
+    batches = resident(args.pairs)
     log('model + inputs ready')
 
     def backbone_ms_per_pair():
@@ -232,81 +397,47 @@ def main():
     bb_ms = backbone_ms_per_pair()
     log(f'backbone {bb_ms:.2f} ms/pair with the shipped MIOpen picks')
     if not args.tune and args.precision == 'fp16' and bb_ms > 2.2 * (args.size / 640.0) ** 2:
-        # the shipped find-db did not apply (other batch size / MIOpen build): let MIOpen search once
+        # the shipped find-db did not apply (other batch size / MIOpen build): let MIOpen search once; the result
+        # stays in this process's private db copy
         log('slower than the tuned reference (1.7 ms/pair): running the MIOpen search (minutes) ...')
         torch.backends.cudnn.benchmark = True
-        args.tune = True
         bb_ms = backbone_ms_per_pair()
         log(f'backbone {bb_ms:.2f} ms/pair after the search')
-    step(0)                          # single-threaded first pass: fills the weight / table caches
-    torch.cuda.synchronize()
-    torch.cuda.synchronize()
-    log('first forward done (MIOpen algorithm lookup / search)')
-    # each pipeline thread owns its MIOpen handle: let every one of them look its convolution algorithms up
-    # ALONE first (concurrent first lookups of the user find-db were seen to leave a handle on slow
-    # fallback picks for the whole process: 3.7x slower steps in ~1 of 10 fresh-box runs)
-    for w in range(nstreams):
-        run_single(w, w)
-    t = time.perf_counter()
-    step(0)
-    torch.cuda.synchronize()
-    t_serial = time.perf_counter() - t
-    t = time.perf_counter()
-    run(0, args.warmup)
-    torch.cuda.synchronize()
-    t_threads = (time.perf_counter() - t) / max(args.warmup, 1)
-    if nstreams > 1 and args.warmup >= 2 and t_threads > 1.5 * t_serial:
-        log(f'pipelined steps run at {t_threads * 1e3:.1f} ms against {t_serial * 1e3:.1f} ms single-threaded: '
-            f'falling back to one host pipeline')
-        serial[0] = True
-        nstreams = 1
-    log('warm-up done')
-    if dist is not None:
-        dist.barrier()
-    # inside the timed region only the roofline kernel carries HIP events (two launches per step); event pairs
-    # around all ~110 profiled launches per step were seen to slow a whole run 3.5x on some boxes
-    L.gf_profile_filter(b'k1_conf')
-    L.gf_profile_enable(1)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.warmup, args.steps)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+
+    elapsed, pipes, step = measure(model, batches, args.steps, args.warmup, args.streams, dev, dist, log, b'k1_conf', L)
     log('timed region done')
-    Ms = [results[i][0] for i in range(args.warmup, args.warmup + args.steps)]
-    Mfs = [results[i][1] for i in range(args.warmup, args.warmup + args.steps)]
-    nidx = results[args.warmup + args.steps - 1][2]
+    nstreams = 1 if pipes.serial else pipes.n
+    res_rows = [pipes.results[i] for i in range(args.warmup, args.warmup + args.steps)]
+    Ms, Mfs = [r[0] for r in res_rows], [r[1] for r in res_rows]
+    nidx = res_rows[-1][2]
 
     def collect(tag):
         ms, cnt, work = ctypes.c_double(0), ctypes.c_int(0), ctypes.c_double(0)
-        L.gf_profile_collect(tag, ctypes.byref(ms), ctypes.byref(cnt), ctypes.byref(work))
+        L.gf_profile_collect(tag.encode(), ctypes.byref(ms), ctypes.byref(cnt), ctypes.byref(work))
         return ms.value, cnt.value, work.value
-    timed = {b'k1_conf': collect(b'k1_conf')}
+    timed_conf = collect('k1_conf')
     L.gf_profile_filter(None)
-    # Per-kernel durations for the roofline: with several host pipelines the HIP-event span of a launch
-    # also covers kernels of the other streams that share the GPU, so the same steps are replayed on ONE
-    # stream right after the timed region (same inputs, same code, profiling events on) and those
-    # uncontended durations are reported; the in-region averages are kept next to them.
-    for i in range(min(2, args.steps)):
+    # Per-kernel durations for the roofline entries: with several host pipelines the HIP-event span of a launch
+    # also covers kernels of the other streams that share the GPU, so the same steps are replayed on ONE stream
+    # right after the timed region (same inputs, same code, profiling events on every tagged launch) and those
+    # uncontended durations are reported - they are what `rocprofv3 --kernel-trace -- python3 bench.py --streams 1`
+    # (profiles/) shows per kernel.  k1_conf's in-region average is kept next to it.
+    replay_steps = min(2, args.steps)
+    for i in range(replay_steps):
         step(i)
     torch.cuda.synchronize()
-    solo = {t: collect(t) for t in (b'k1_conf', b'k1_stats', b'k3_linear')}
-    if nstreams == 1:
-        solo[b'k1_conf'] = timed[b'k1_conf']            # one pipeline: the in-region spans are uncontended already
+    solo = {tag: collect(tag) for tag, _, _, _ in ROOFLINE_TAGS}
     L.gf_profile_enable(0)
-    conf_tot_ms, conf_cnt, conf_bytes = solo[b'k1_conf']
-    stats_tot_ms, stats_cnt, stats_flops = solo[b'k1_stats']
-    lin_tot_ms, lin_cnt, lin_flops = solo[b'k3_linear']
-    conf_ms = conf_tot_ms / max(conf_cnt, 1)
-    conf_ms_timed = timed[b'k1_conf'][0] / max(timed[b'k1_conf'][1], 1)
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
+        rows = [None] * world
+        dist.all_gather_object(rows, (sum(Ms), sum(Mfs), len(Ms)))
+    else:
+        rows = [(sum(Ms), sum(Mfs), len(Ms))]
     if rank != 0:
+        pipes.close()
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -315,48 +446,100 @@ def main():
     Lc = (args.size // 8) ** 2
     e = 2 if args.precision == 'fp16' else 4
     algo_bytes = args.batch * (2 * Lc * 256 * e + Lc * Lc * 4)     # per k1_conf launch (170.4 MB/pair-call at e=2)
-    assert conf_cnt == 0 or abs(conf_bytes / conf_cnt - algo_bytes) < 1.0
-    achieved = algo_bytes / (conf_ms * 1e-3) / 1e9 if conf_ms > 0 else 0.0
-    mfma_peak = 2500.0 if args.precision == 'fp16' else 157.3      # TFLOP/s dense (MI355X_MICROARCH.md)
-    lin_tflops = lin_flops / (lin_tot_ms * 1e-3) / 1e12 if lin_tot_ms > 0 else 0.0
-    traffic = None
-    pmc = os.path.join(ROOT, 'profiles', 'k1_conf_pmc_r01.json')
-    if os.path.exists(pmc):
+    if solo['k1_conf'][1]:
+        assert abs(solo['k1_conf'][2] / solo['k1_conf'][1] - algo_bytes) < 1.0
+    pmc = {}
+    pmc_file = os.path.join(ROOT, 'profiles', 'r02_pmc_per_tag.json')
+    if os.path.exists(pmc_file):
         try:
-            traffic = json.load(open(pmc)).get('hbm_bytes_per_launch_batch%d' % args.batch)
+            pmc = json.load(open(pmc_file))
         except Exception:
-            traffic = None
+            pmc = {}
+    entries = []
+    for tag, bound, hot, what in ROOFLINE_TAGS:
+        tot_ms, cnt, work = solo[tag]
+        if cnt == 0 or tot_ms <= 0:
+            continue
+        peak = HBM_PEAK_GBPS if bound == 'hbm' else MFMA_PEAK_TFLOPS[args.precision]
+        ach = work / (tot_ms * 1e-3) / (1e9 if bound == 'hbm' else 1e12)
+        p = pmc.get(tag, {})
+        entries.append({'kernel': f'{tag}: {what}', 'tag': tag, 'bound': bound, 'hot_path': hot, 'achieved': ach, 'peak': peak,
+                        'unit': 'GB/s' if bound == 'hbm' else 'TFLOP/s', 'frac': ach / peak,
+                        'traffic': p.get('hbm_bytes_per_launch'), 'mfma_util_pmc': p.get('mfma_util'),
+                        'launches': cnt, 'launches_per_step': cnt / replay_steps, 'avg_launch_ms': tot_ms / cnt,
+                        'total_ms_per_step': tot_ms / replay_steps,
+                        ('algorithmic_bytes_per_launch' if bound == 'hbm' else 'algorithmic_flops_per_launch'): work / cnt})
+    hot_entries = [x for x in entries if x['hot_path']]
+    dominant = dict(max(hot_entries, key=lambda x: x['total_ms_per_step'])) if hot_entries else {}
+    dominant['measured'] = ('HIP events on the launch stream; single-stream replay of the timed steps (equals the kernel '
+                            'durations of a --streams 1 rocprofv3 trace, profiles/)')
+    if timed_conf[1]:
+        for x in entries:
+            if x['tag'] == 'k1_conf':
+                x['avg_launch_ms_in_timed_region'] = timed_conf[0] / timed_conf[1]
     K = int(nidx[:, 0].float().mean()) if nidx is not None else None
+    tot_M, tot_Mf, tot_steps = (sum(r[k] for r in rows) for k in range(3))
     res = {
         'metric': 'image-pairs/sec (640x640)', 'value': pairs / elapsed, 'unit': 'image-pairs/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f16' if args.precision == 'fp16' else 'f32', 'data': 'synthetic',
-        'config': {'workload': f'batched inference, synthetic {args.size}x{args.size} pairs (BASELINE configs[4] shard), '
-                               f'full forward incl. ResNet-FPN backbone; closed-form random-init weights; '
-                               f'coarse_thr={args.coarse_thr} fine_thr={args.fine_thr}',
+        'config': {'workload': f'batched inference, synthetic {args.size}x{args.size} pairs (BASELINE configs[4]: static shard of the '
+                               f'pair list, {args.steps * args.batch} pairs per GPU), image1 = {args.pairs} of image0, full forward '
+                               f'incl. ResNet-FPN backbone; closed-form random-init weights; coarse_thr={args.coarse_thr} '
+                               f'fine_thr={args.fine_thr}',
                    'pairs_per_gpu_per_step': args.batch, 'global_pairs_per_step': args.batch * world,
-                   'coarse_matches_per_pair': sum(Ms) / len(Ms) / args.batch, 'fine_matches_per_pair': sum(Mfs) / len(Mfs) / args.batch,
+                   'coarse_matches_per_pair': tot_M / tot_steps / args.batch, 'fine_matches_per_pair': tot_Mf / tot_steps / args.batch,
                    'inlier_cells_per_pair': K, 'parallelism': f'pair-shard x{world} (no collective)',
                    'host_pipelines_per_gpu': nstreams},
-        'roofline': {'kernel': 'k1_conf (dual-softmax correlation sweep, conf_matrix write)', 'bound': 'hbm',
-                     'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
-                     'traffic': traffic, 'launches': conf_cnt, 'avg_launch_ms': conf_ms,
-                     'algorithmic_bytes_per_launch': algo_bytes,
-                     'measured': 'HIP events on the launch stream; single-stream replay of the timed steps' if nstreams > 1 else 'HIP events on the launch stream over the timed region',
-                     'avg_launch_ms_in_timed_region': conf_ms_timed},
-        'roofline_mfma': {'kernel': 'k3 linear_kernel (encoder-layer GEMMs with fused epilogues, all launches)', 'bound': 'mfma',
-                          'achieved': lin_tflops, 'peak': mfma_peak, 'unit': 'TFLOP/s', 'frac': lin_tflops / mfma_peak,
-                          'launches': lin_cnt, 'total_ms': lin_tot_ms, 'algorithmic_flops': lin_flops,
-                          'k1_stats_tflops': stats_flops / (stats_tot_ms * 1e-3) / 1e12 if stats_tot_ms > 0 else 0.0},
+        'roofline': dominant,
+        'roofline_kernels': entries,
     }
+    pipes.close()
+    if world == 1 and not args.no_extras:
+        res['side_measurements'] = side_measurements(args, model, dev, log, L)
     if not args.no_cpu_baseline and world == 1:          # reported on rank 0 at N = 1 only
-        res['cpu_baseline'] = cpu_baseline(W, args.coarse_thr, args.fine_thr, args.size)
+        res['cpu_baseline'] = cpu_baseline(W, args.coarse_thr, args.fine_thr, args.size, args.pairs)
     print(json.dumps(res), flush=True)
-    if args.tune and rank == 0 and 'GEOFORMER_KEEP_SHIPPED_DB' not in os.environ:
-        gf_miopen.save_find_db()             # a search ran: keep its picks for the next process
+    if args.tune and args.save_db:
+        gf_miopen.save_find_db()             # an explicit search: keep its picks for the next process
     if dist is not None:
         dist.destroy_process_group()
+
+
+def side_measurements(args, model, dev, log, L):
+    """Two more throughput figures of the same job, N = 1 only (they are not `value`):
+      nominal_load   image1 = image0 shifted by one coarse cell, the pair of the reference's own CPU timing
+                     (BASELINE.md section 2): thousands of coarse matches and hundreds of inlier cells per pair, i.e. the
+                     load SURVEY section 8 sizes the path for (M ~ 2000), where K4 / K7 / K8 / loftr_fine carry real work;
+      parity_mode    the fp32 mode in which coarse indices are bit-exact against the reference's golden vectors."""
+    out = {}
+    steps = max(4, min(args.steps, 100))
+    shift = [synth_pairs(args.batch, seed=50000 + i * args.batch, size=args.size, device=dev, kind='shift') for i in range(4)]
+    el, p, _ = measure(model, shift, steps, 3, args.streams, dev, None, log)
+    rr = [p.results[i] for i in range(3, 3 + steps)]
+    p.close()
+    nidx = rr[-1][2]
+    out['nominal_load'] = {'value': steps * args.batch / el, 'unit': 'image-pairs/s', 'steps': steps, 'ms_per_step': 1e3 * el / steps,
+                           'pairs': 'shift by one coarse cell (BASELINE.md section 2)', 'dtype': 'f16' if args.precision == 'fp16' else 'f32',
+                           'coarse_matches_per_pair': sum(r[0] for r in rr) / len(rr) / args.batch,
+                           'fine_matches_per_pair': sum(r[1] for r in rr) / len(rr) / args.batch,
+                           'inlier_cells_per_pair': int(nidx[:, 0].float().mean()) if nidx is not None else None}
+    log(f"nominal load: {out['nominal_load']['value']:.1f} pairs/s at M = {out['nominal_load']['coarse_matches_per_pair']:.0f}")
+    if args.precision == 'fp16':
+        import torch
+        m32, _ = build_model('fp32', args.coarse_thr, args.fine_thr, dev)
+        homo = [synth_pairs(args.batch, seed=i * args.batch, size=args.size, device=dev, kind=args.pairs) for i in range(2)]
+        s32 = max(4, min(args.steps, 10))
+        el, p, _ = measure(m32, homo, s32, 2, 1, dev, None, log)
+        p.close()
+        out['parity_mode'] = {'value': s32 * args.batch / el, 'unit': 'image-pairs/s', 'steps': s32, 'ms_per_step': 1e3 * el / s32,
+                              'dtype': 'f32', 'note': 'fp32 storage and exact-fp32 MFMA (v_mfma_f32_32x32x2_f32); unfused fp32 backbone, '
+                                                      'MIOpen immediate mode'}
+        del m32
+        torch.cuda.empty_cache()
+        log(f"parity mode (fp32): {out['parity_mode']['value']:.1f} pairs/s")
+    return out
 
 
 if __name__ == '__main__':

@@ -33,13 +33,17 @@ SIGNATURES = {
     'gf_coarse_loss_forward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
                                         c_int, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'gf_coarse_loss_backward': (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float,
-                                         c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'gf_pos_encode': (c_int, [c_void_p, c_int, c_long, c_long, c_long, c_long, c_void_p, c_void_p, c_int, c_int, c_int,
                               c_int, c_int, c_void_p]),
     'gf_linear_attention_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'gf_linear_attention': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_long,
                                     c_long, c_long, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_size_t,
                                     c_void_p]),
+    'gf_encoder_kv_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'gf_encoder_kv_state': (c_int, [c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'gf_encoder_layer': (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_int, c_void_p, c_float, c_void_p, c_void_p, c_float,
+                                 c_float, c_int, c_void_p, c_int, c_void_p, c_long, c_int, c_int, c_int, c_void_p]),
     'gf_linear': (c_int, [c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                           c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p, c_int, c_void_p, c_long, c_int, c_int,
                           c_int, c_void_p]),

@@ -30,6 +30,7 @@ std::mutex g_prof_mu;
 bool g_prof_on = false;
 std::string g_prof_filter;                              // empty = every tag
 std::map<std::string, std::vector<ProfSpan>> g_prof;
+uint32_t g_prof_gen = 1;                                // bumped by every collect: tokens of older spans go stale
 std::vector<hipEvent_t> g_prof_pool;                    // recycled events (creating two per launch is not free)
 
 hipEvent_t prof_event() {
@@ -57,14 +58,19 @@ void* gf_prof_begin(const char* tag, hipStream_t st, double work) {
     (void)hipEventRecord(sp.a, st);
     auto& v = g_prof[tag];
     v.push_back(sp);
-    return (void*)(uintptr_t)v.size();
+    return (void*)(((uintptr_t)g_prof_gen << 32) | (uintptr_t)v.size());      // generation | 1-based index
 }
 
 void gf_prof_end(const char* tag, void* token, hipStream_t st) {
     if (!token) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
+    // a collect between begin and end (another host thread) emptied the vector: the token's generation no longer
+    // matches and the span is dropped instead of indexing past the end
+    const uintptr_t t = (uintptr_t)token, idx = t & 0xffffffffu;
+    if ((uint32_t)(t >> 32) != g_prof_gen) return;
     auto& v = g_prof[tag];
-    (void)hipEventRecord(v[(uintptr_t)token - 1].b, st);
+    if (idx == 0 || idx > v.size()) return;
+    (void)hipEventRecord(v[idx - 1].b, st);
 }
 
 extern "C" void gf_profile_enable(int on) {
@@ -102,6 +108,7 @@ extern "C" int gf_profile_collect(const char* tag, double* total_ms, int* count,
         g_prof_pool.push_back(sp.b);
     }
     it->second.clear();
+    ++g_prof_gen;
     if (total_ms) *total_ms = tot;
     if (count) *count = n;
     if (work) *work = wk;

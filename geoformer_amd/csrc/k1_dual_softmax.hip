@@ -1100,6 +1100,7 @@ struct PosArgs {
     float* d1;
     int P, L, S;
     float mult, alpha, gamma, scale;
+    const float* scale_dev;  // optional device scalar multiplied into `scale` (the upstream gradient of the loss sum)
 };
 
 // one wave per positive: p = exp(s - mr)/lr * exp(s - mc)/lc, focal term and its derivative
@@ -1131,7 +1132,7 @@ __global__ void k1_pos_scatter(PosArgs a) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.P) return;
     const int b = (int)a.pb[k], i = (int)a.pi[k], j = (int)a.pj[k];
-    const float g = a.grad[k] * a.scale;
+    const float g = a.grad[k] * (a.scale_dev ? a.scale * a.scale_dev[0] : a.scale);
     atomicAdd(a.gr + (size_t)b * a.L + i, g);
     atomicAdd(a.gc + (size_t)b * a.S + j, g);
     atomicMax(a.gmax, __float_as_uint(fabsf(g)));
@@ -1141,7 +1142,7 @@ __global__ void k1_pos_scatter(PosArgs a) {
 __global__ __launch_bounds__(256) void k1_pos_grad(PosArgs a) {
     const int k = blockIdx.x, t = threadIdx.x;
     const int b = (int)a.pb[k], i = (int)a.pi[k], j = (int)a.pj[k];
-    const float g2 = 2.0f * a.grad[k] * a.scale * a.mult;
+    const float g2 = 2.0f * a.grad[k] * (a.scale_dev ? a.scale * a.scale_dev[0] : a.scale) * a.mult;
     atomicAdd(a.d0 + ((size_t)b * a.L + i) * 256 + t, g2 * (float)a.f1[((size_t)b * a.S + j) * 256 + t]);
     atomicAdd(a.d1 + ((size_t)b * a.S + j) * 256 + t, g2 * (float)a.f0[((size_t)b * a.L + i) * 256 + t]);
 }
@@ -1293,18 +1294,19 @@ extern "C" int gf_coarse_loss_forward(const void* f0, const void* f1, int dtype,
 extern "C" int gf_coarse_loss_backward(int N, int L, int S, int C, const uint8_t* mask0, const uint8_t* mask1,
                                        float temperature, const int64_t* pos_b,
                                        const int64_t* pos_i, const int64_t* pos_j, int P, const float* pos_grad,
-                                       float scale, float* d_f0, float* d_f1, void* workspace, size_t workspace_bytes,
-                                       void* stream) {
+                                       float scale, const float* scale_dev, float* d_f0, float* d_f1, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
     GF_CHECK_ARG(pos_b && pos_i && pos_j && pos_grad && d_f0 && d_f1, "null pointer");
     const int rc = coarse_loss_check("gf_coarse_loss_backward", N, L, S, C, P, workspace, workspace_bytes);
     if (rc != GF_OK) return rc;
+    GF_CHECK_ARG(S % BM == 0 && L % BN == 0, "S must be a multiple of 128 too");     // before anything is enqueued
     hipStream_t st = (hipStream_t)stream;
     const LossWs w = loss_carve(workspace, N, L, S);
     (void)hipMemsetAsync((char*)workspace + w.zero_off, 0, w.zero_bytes, st);
     PosArgs p{};
     p.f0 = w.f0h; p.f1 = w.f1h; p.pb = pos_b; p.pi = pos_i; p.pj = pos_j; p.grad = const_cast<float*>(pos_grad);
     p.gr = w.gr; p.gc = w.gc; p.gmax = w.gmax; p.d0 = d_f0; p.d1 = d_f1; p.P = P; p.L = L; p.S = S;
-    p.mult = (1.0f / (float)C) / temperature; p.scale = scale;
+    p.mult = (1.0f / (float)C) / temperature; p.scale = scale; p.scale_dev = scale_dev;
     k1_pos_scatter<<<(P + 255) / 256, 256, 0, st>>>(p);
     GrArgs g{};
     g.gmax = w.gmax; g.mult = p.mult; g.N = N;
@@ -1314,8 +1316,7 @@ extern "C" int gf_coarse_loss_backward(int N, int L, int S, int C, const uint8_t
     g.La = L; g.Lb = S; g.tilesA = L / BM; g.tilesB = S / BN;
     if (mask0) k1_grad_panel<true><<<N * g.tilesA, NT, PANEL_LDS + BN * 4, st>>>(g);
     else k1_grad_panel<false><<<N * g.tilesA, NT, PANEL_LDS + BN * 4, st>>>(g);
-    // dF1: roles swapped (S must then tile by 128 and L by 64)
-    GF_CHECK_ARG(S % BM == 0 && L % BN == 0, "S must be a multiple of 128 too");
+    // dF1: roles swapped (S must then tile by 128 and L by 64: checked above)
     g.fa = w.f1h; g.fb = w.f0h; g.sa = w.cstat; g.sb = w.rstat; g.ga = w.gc; g.gb = w.gr; g.dfa = d_f1;
     g.ma = mask1; g.mb = mask0;
     g.La = S; g.Lb = L; g.tilesA = S / BM; g.tilesB = L / BN;

@@ -490,9 +490,16 @@ extern "C" int gf_linear_attention(const void* q, const void* k, const void* v, 
     a.kvfinal = (float*)workspace;
     a.kvpart = a.kvfinal + (size_t)N * len;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == GF_F16 && D == 32 && H == 8) return la16_launch(a, st);      // coarse level: matrix-core path
+    // algorithmic bytes: q, k, v read once, the message written once
+    void* pt = gf_prof_begin("k2_linear_attention", st, (double)N * (2.0 * L + 2.0 * S) * a.C * (dtype == GF_F32 ? 4 : 2));
+    int rc;
+    if (dtype == GF_F16 && D == 32 && H == 8) rc = la16_launch(a, st);      // coarse level: matrix-core path
+    else {
 #define GF_LA(T)                                       \
     (D == 16 ? la_launch<T, 16>(a, st) : D == 32 ? la_launch<T, 32>(a, st) : la_launch<T, 64>(a, st))
-    return dtype == GF_F32 ? GF_LA(float) : GF_LA(_Float16);
+        rc = dtype == GF_F32 ? GF_LA(float) : GF_LA(_Float16);
 #undef GF_LA
+    }
+    gf_prof_end("k2_linear_attention", pt, st);
+    return rc;
 }

@@ -1,0 +1,712 @@
+// K6: the encoder layer as TWO launches that touch HBM three times per token (read source, read x, write out) -
+// the algorithmic minimum of SURVEY 8d - instead of the eight launches / ~19 token-row transfers of the
+// K3 + K2 chain.  16-bit storage modes only (fp16 / bf16 operands, fp32 accumulation and statistics); the fp32 parity
+// mode keeps the unfused kernels.
+//
+// Replaces LoFTREncoderLayer.forward (model/loftr_src/loftr/loftr_module/transformer.py:37-60, ReLU, linear
+// attention of linear_attention.py:21-51) and the part of its Geo twin after the attention
+// (model/geo_transformer/transformer.py:56-66, Tanh):
+//
+//   enc_kv_state   k, v = W_k src, W_v src ; KV[n,h] = sum_s phi(k_s)^T v_s ; Ksum[n,h] = sum_s phi(k_s)
+//                  per 128-token tile -> one fp32 partial state per tile ; enc_kv_reduce sums the tiles of an image.
+//                  k and v never exist in HBM.
+//   enc_layer      q = W_q x ; msg = phi(q) KV / (phi(q).Ksum + eps)            (ATTN: linear attention)
+//                  or msg = attention output read from HBM                        (Geo layers: K4 / K5 made it)
+//                  m = LN1(W_m msg) ; hid = act(W_1 [x | m]) ; out = x + LN2(W_2 hid)
+//
+// One workgroup = 4 waves = 128 tokens, one wave per SIMD with the whole 512-register file; a wave owns 32 tokens
+// for the entire chain.  Products are computed transposed (MFMA A = 32 weight rows, B = 32 tokens), so a result
+// tile has the token on the lane and 32 channels in 16 registers per lane half - and that IS the B operand of
+// the next product (contraction over channels = over the tile's row index): 8 registers are packed to 16 bits
+// per 16-deep k-step and the next weight's A fragment is stored with the matching k order
+// (c = 32t + 16s + 8(j>>2) + 4h + (j&3) for element j of lane half h).  Activations therefore never pass through
+// LDS between the five GEMMs; LayerNorm, phi, the activation and the residual are lane-local.
+//
+// Weights are pre-packed on the host (geoformer_amd/fused.py) into the exact sequence of 1-KiB MFMA A fragments
+// the kernel consumes (`wstream`), 32 fragments = one 32-KiB block; every workgroup streams the same 1 MiB per
+// layer from L2 into a two-block LDS ring with LDS-DMA (global_load_lds_dwordx4: the fragment order makes the
+// LDS image lane-linear, so fragment reads are conflict-free ds_read_b128), one barrier per block of 32 MFMAs
+// per wave.  The token tile x stays in LDS for the whole kernel (B operand of the q and mlp.0 products, residual).
+#include <math.h>
+
+#include <type_traits>
+
+#include "gf_common.h"
+
+// -DK6_TRACE=1 records s_memtime at the phase boundaries of every workgroup (tools/k6_trace.py reads them); a
+// diagnostic build only: the stamps serialise the wave, so only the SHARES of the phases are meaningful.
+#ifndef K6_TRACE
+#define K6_TRACE 0
+#endif
+#if K6_TRACE
+__device__ long long k6_trace[4096 * 4 * 16];
+#define K6_T(slot) do { if (lane == 0 && blockIdx.x < 4096) k6_trace[(blockIdx.x * 4 + wave) * 16 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int gf_debug_k6_trace(long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(k6_trace), sizeof(long long) * 4096 * 4 * 16);
+}
+#else
+#define K6_T(slot)
+#endif
+
+namespace {
+
+constexpr int C = 256, D = 32, NH = 8;            // coarse level: d_model 256, 8 heads of 32
+constexpr int TM = 128;                           // tokens per workgroup
+constexpr int WBLK = 32768, FRAG = 1024;          // one weight block = 32 fragments of 64 lanes x 16 B
+constexpr int X_OFF = 0;                          // [4 k-chunks][128 rows][128 B], chunk-swizzled (gf_lds_off)
+constexpr int W_OFF = 65536;                      // two weight blocks
+constexpr int KV_OFF = W_OFF + 2 * WBLK;          // [8 heads][2 k-steps][64 lanes][16 B]: KV/S as 16-bit A fragments
+constexpr int KS_OFF = KV_OFF + NH * 2 * FRAG;    // [256] float: Ksum/S rounded to the storage type
+constexpr int VEC_OFF = KS_OFF + C * 4;           // gamma1 | beta1 | gamma2 | beta2, [4][256] float
+constexpr int LDS_BYTES = VEC_OFF + 4 * C * 4;    // 152,576 B
+constexpr int SLAB_RS = 272;                      // epilogue slab row stride (256 B + pad)
+
+struct EncArgs {
+    const void* x;          // [N*L][ldx] tokens
+    long ldx;
+    const void* msg;        // [N*L][ldm] attention output (ATTN = false)
+    long ldm;
+    const float* kvfinal;   // [N][C*D + C] fp32: KV as [c][v] then Ksum[c]   (ATTN = true)
+    const uint8_t* q_mask;  // [N*L] or null: masked query rows -> phi(q) = 0 (linear_attention.py:35-36)
+    const void* wstream;    // packed fragments (see fused.py)
+    const float* ln;        // gamma1 | beta1 | gamma2 | beta2
+    float eps1, eps2, attn_eps;
+    void* out;
+    long ldo;
+    int N, L, S, tiles;     // tiles = ceil(L / 128) per image
+    const int32_t* flag;    // [N*L / flag_rows] or null: 0 -> out = x (GeoTransformer's "layer skipped")
+    int flag_rows;
+    // enc_kv_state
+    const uint8_t* kv_mask; // [N*S] or null
+    float* part;            // [N][tiles][C*D + C]
+};
+
+template <typename T>
+__device__ __forceinline__ typename Mma32<T>::Frag pack8(float a0, float a1, float a2, float a3, float a4, float a5, float a6,
+                                                          float a7) {
+    typename Mma32<T>::Frag f;
+    f[0] = gf_from_float<T>(a0); f[1] = gf_from_float<T>(a1); f[2] = gf_from_float<T>(a2); f[3] = gf_from_float<T>(a3);
+    f[4] = gf_from_float<T>(a4); f[5] = gf_from_float<T>(a5); f[6] = gf_from_float<T>(a6); f[7] = gf_from_float<T>(a7);
+    return f;
+}
+// registers 8s .. 8s+7 of an accumulator tile as the operand of k-step s of the next product
+template <typename T>
+__device__ __forceinline__ typename Mma32<T>::Frag pack_step(const v16f& a, int s) {
+    return s == 0 ? pack8<T>(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7])
+                  : pack8<T>(a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15]);
+}
+// elu(x) + 1 (linear_attention.py:33-34) = max(x, 0) + exp(min(x, 0)): x + 1 for x > 0 (exp(0) = 1 exactly), exp(x)
+// otherwise - branch-free (a conditional exponential compiles to a divergent branch per element), hardware exponential
+__device__ __forceinline__ float phi(float x) { return fmaxf(x, 0.f) + __builtin_amdgcn_exp2f(fminf(x, 0.f) * 1.44269504088896341f); }
+template <typename T>
+__device__ __forceinline__ float rnd(float x) { return gf_to_float(gf_from_float<T>(x)); }   // round to the storage type
+
+// one weight block (32 fragments) from the stream into ring slot (b & 1): wave w moves fragments 8w .. 8w+7
+__device__ __forceinline__ void dma_block(const char* wstream, char* smem, int b, int wave, int lane) {
+    char* dst = smem + W_OFF + (b & 1) * WBLK + wave * 8 * FRAG;
+    const char* src = wstream + (size_t)b * WBLK + wave * 8 * FRAG + lane * 16;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * FRAG),
+                                         (__attribute__((address_space(3))) void*)(dst + i * FRAG), 16, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);        // the requests go out before the block's MFMAs, not in between them
+}
+// the next block has landed (every wave waits for its own DMA) and every wave is done reading the current one
+__device__ __forceinline__ void ring_turn() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+// The weight stream is consumed in STEPS of 8 fragments (8 KiB, 8 MFMAs per wave); a block is 4 steps.  The
+// fragments of step i+1 are requested from LDS BEFORE the MFMAs of step i are issued (one wave per SIMD: nothing
+// else hides the LDS latency; left to itself the compiler reads each fragment right in front of the MFMA that needs it),
+// fenced with sched_barrier so the order survives the scheduler.  The ring turns before the LAST step of a block:
+// by then block b+1 has landed and every wave holds block b's last fragments in registers, so block b+2 can be
+// requested into b's slot while 8 MFMAs of block b are still to run.
+struct Ring {
+    const char* ws;
+    char* smem;
+    int wave, lane, blk, nblk;
+};
+template <typename Frag>
+__device__ __forceinline__ void load_step(const Ring& g, Frag (&f)[8], int b, int st) {
+    const char* p = g.smem + W_OFF + (b & 1) * WBLK + st * 8 * FRAG + g.lane * 16;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = *reinterpret_cast<const Frag*>(p + i * FRAG);
+}
+// to be called before the MFMAs of step `st` (0..3) of block g.blk: requests the fragments of the following step
+template <typename Frag>
+__device__ __forceinline__ void fetch_next(Ring& g, Frag (&nx)[8], int st) {
+    // the current step's fragments were requested a whole step (8 MFMAs) ago: retiring them here is free, and it keeps
+    // the outstanding LDS reads below the 4-bit lgkmcnt range (with 18 in flight the compiler falls back to
+    // lgkmcnt(0) AFTER the new requests, exposing their full latency on every second step)
+    __builtin_amdgcn_s_waitcnt(0xC07F);                               // lgkmcnt(0) only
+    if (st == 3) {
+        ring_turn();
+        if (g.blk + 2 < g.nblk) dma_block(g.ws, g.smem, g.blk + 2, g.wave, g.lane);
+        if (g.blk + 1 < g.nblk) load_step(g, nx, g.blk + 1, 0);
+        ++g.blk;
+    } else {
+        load_step(g, nx, g.blk, st + 1);
+    }
+}
+// Scheduling of one step (placed after its 8 MFMAs): alternate MFMA / LDS read so that the requests of the next
+// step's fragments ride in the issue slots between this step's MFMAs (an MFMA holds the issue port for 8 of its 32
+// cycles) instead of in front of them, then close the region.  EXTRA = operand fragments read besides the 8 weights.
+template <int EXTRA>
+__device__ __forceinline__ void step_schedule() {
+    // the reads go out in the first half of the step (two per MFMA gap) so that they have at least four MFMAs
+    // (128 cycles) to land before the next step retires them
+    if constexpr (EXTRA > 0) __builtin_amdgcn_sched_group_barrier(0x100, EXTRA, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // two DS reads
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// x tile -> LDS: [kc][row][128 B] with the 16-B chunk index XORed with (row>>1)&7 (conflict-free ds_read_b128)
+template <typename T>
+__device__ __forceinline__ void load_tile(const T* base, long ld, int row0, int rows_valid, char* smem, int off, int tid) {
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const int e = p * 256 + tid, row = e >> 5, c32 = e & 31;
+        const int r = min(row0 + row, rows_valid - 1);
+        const v4u v = *reinterpret_cast<const v4u*>(base + (size_t)r * ld + c32 * 8);
+        *reinterpret_cast<v4u*>(smem + off + (c32 >> 3) * 16384 + gf_lds_off(row, c32 & 7)) = v;
+    }
+}
+
+template <typename T, int ACT, bool ATTN>
+__global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
+    using Mm = Mma32<T>;
+    using Frag = typename Mm::Frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5, lr = lane & 31;
+    const int n = blockIdx.x / a.tiles, tile = blockIdx.x - n * a.tiles;
+    const int t0 = tile * TM;                                         // first token of the tile inside image n
+    const T* xg = (const T*)a.x + (size_t)n * a.L * a.ldx;
+    const char* ws = (const char*)a.wstream;
+    constexpr int NBLK = ATTN ? 32 : 28;
+    float* vec = reinterpret_cast<float*>(smem + VEC_OFF);
+    K6_T(0);
+    dma_block(ws, smem, 0, wave, lane);
+    load_tile<T>(xg, a.ldx, t0, a.L, smem, X_OFF, tid);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vec[i * C + tid] = a.ln[i * C + tid];
+    if constexpr (ATTN) {
+        // KV / S and Ksum / S of image n in the storage type (the reference's "prevent fp16 overflow" scaling,
+        // linear_attention.py:45-49: out = (Q.KV/S) / (Q.Ksum/S + eps/S)), KV as A fragments in the k order of a
+        // packed accumulator: lane (v = lr, h2), element j  <->  d = 16s + 8(j>>2) + 4 h2 + (j&3)
+        const float* kvf = a.kvfinal + (size_t)n * (C * D + C);
+        const float inv_s = 1.0f / (float)a.S;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int slot = p * 256 + tid, ln = slot & 63, hs = slot >> 6, hh = hs >> 1, s = hs & 1;
+            const float* src = kvf + (size_t)(hh * D + 16 * s + 4 * (ln >> 5)) * D + (ln & 31);       // KV[c = (hh, d)][v]
+            *reinterpret_cast<Frag*>(smem + KV_OFF + hs * FRAG + ln * 16) =
+                pack8<T>(src[0] * inv_s, src[D] * inv_s, src[2 * D] * inv_s, src[3 * D] * inv_s, src[8 * D] * inv_s, src[9 * D] * inv_s,
+                         src[10 * D] * inv_s, src[11 * D] * inv_s);
+        }
+        reinterpret_cast<float*>(smem + KS_OFF)[tid] = rnd<T>(kvf[C * D + tid] * inv_s);
+    }
+    Frag mfrag[8][2];                      // the B operand of the merge product, then of the second half of mlp.0
+    if constexpr (!ATTN) {
+        // the attention output of K4 / K5 comes from HBM: stage the 128 x 256 tile row-contiguously in the (still
+        // empty) second ring slot + the KV area ... it is 64 KiB, the ring is 64 KiB, block 0 is in slot 0: use the
+        // x-tile layout at W_OFF + WBLK is too small, so the tile goes through in two 64-token halves
+        const T* mg = (const T*)a.msg + (size_t)n * a.L * a.ldm;
+        __syncthreads();                   // nothing pending on slot 1; slot 0 holds block 0 (DMA may still be in flight: different bytes)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            // 64 rows x 512 B = 32 KiB into slot 1, image [kc][64 rows][128 B]
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int e = p * 256 + tid, row = e >> 5, c32 = e & 31;
+                const int r = min(t0 + half * 64 + row, a.L - 1);
+                const v4u v = *reinterpret_cast<const v4u*>(mg + (size_t)r * a.ldm + c32 * 8);
+                *reinterpret_cast<v4u*>(smem + W_OFF + WBLK + (c32 >> 3) * 8192 + gf_lds_off(row, c32 & 7)) = v;
+            }
+            __syncthreads();
+            if ((wave >> 1) == half) {     // waves 0,1 own rows 0..63, waves 2,3 rows 64..127
+                const int row = (wave & 1) * 32 + lr;
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        // channels 32t + 16s + 4h2 + {0..3} and + 8: two 8-byte pieces of chunk (32t + 16s) / 8 and the next
+                        const int c0 = 32 * t + 16 * s + 4 * h2, ch = c0 >> 3;           // c0 % 8 is 0 or 4
+                        const char* p0 = smem + W_OFF + WBLK + (ch >> 3) * 8192 + gf_lds_off(row, ch & 7) + (c0 & 7) * 2;
+                        const char* p1 = smem + W_OFF + WBLK + ((ch + 1) >> 3) * 8192 + gf_lds_off(row, (ch + 1) & 7) + (c0 & 7) * 2;
+                        typedef short v4s __attribute__((ext_vector_type(4)));
+                        typedef short v8s __attribute__((ext_vector_type(8)));
+                        const v4s lo = *reinterpret_cast<const v4s*>(p0), hi = *reinterpret_cast<const v4s*>(p1);
+                        const v8s both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        mfrag[t][s] = __builtin_bit_cast(Frag, both);
+                    }
+            }
+            __syncthreads();
+        }
+    }
+    // blocks 0 and 1 are requested; the first turn waits for block 0 only (the 8 youngest requests are block 1's)
+    dma_block(ws, smem, 1, wave, lane);
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    K6_T(1);
+    const int tok = t0 + wave * 32 + lr;                              // this lane's token (accumulator column)
+    const char* xrow = smem + X_OFF;
+    const int myrow = wave * 32 + lr;
+    Ring ring{ws, smem, wave, lane, 0, NBLK};
+    Frag fa[8], fb[8];                                                // fragments of the current / next step, alternating
+    load_step(ring, fa, 0, 0);
+    // token-tile operand of 16-deep k-step ks (0..15)
+    auto xfrag = [&](int ks) { return *reinterpret_cast<const Frag*>(xrow + (ks >> 2) * 16384 + gf_lds_off(myrow, 2 * (ks & 3) + h2)); };
+
+    if constexpr (ATTN) {
+        // ---------------- q = W_q x : 16 steps (k-step ks = step, tiles nb = 0..7)
+        v16f q[8];
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) q[nb][r] = 0.f;
+        Frag tf = xfrag(0);
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            Frag (&cur)[8] = (st & 1) ? fb : fa;
+            Frag (&nxt)[8] = (st & 1) ? fa : fb;
+            __builtin_amdgcn_s_waitcnt(0xC07F);                        // see fetch_next: retire the current step's reads first
+            const Frag tn = xfrag(st < 15 ? st + 1 : 15);
+            fetch_next(ring, nxt, st & 3);
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) Mm::mma(cur[nb], tf, q[nb]);
+            step_schedule<1>();
+            tf = tn;
+        }
+        K6_T(2);
+        // ---------------- linear attention per head: tile h of q is head h (32 channels)
+        const float qmul = (a.q_mask == nullptr || a.q_mask[(size_t)n * a.L + min(tok, a.L - 1)] != 0) ? 1.f : 0.f;
+        const float eps_s = a.attn_eps / (float)a.S;
+        const float* ks = reinterpret_cast<const float*>(smem + KS_OFF);
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) {
+            float pq[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pq[r] = rnd<T>(phi(q[hh][r]) * qmul);
+            float den = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {                               // rows 8g + 4 h2 + {0..3} of the head
+                const v4f k4 = *reinterpret_cast<const v4f*>(ks + hh * D + 8 * g + 4 * h2);
+                den += pq[4 * g] * k4.x + pq[4 * g + 1] * k4.y + pq[4 * g + 2] * k4.z + pq[4 * g + 3] * k4.w;
+            }
+            den += __shfl_xor(den, 32, 64);
+            v16f num;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) num[r] = 0.f;
+            const Frag p0 = pack8<T>(pq[0], pq[1], pq[2], pq[3], pq[4], pq[5], pq[6], pq[7]);
+            const Frag p1 = pack8<T>(pq[8], pq[9], pq[10], pq[11], pq[12], pq[13], pq[14], pq[15]);
+            Mm::mma(*reinterpret_cast<const Frag*>(smem + KV_OFF + (hh * 2) * FRAG + lane * 16), p0, num);
+            Mm::mma(*reinterpret_cast<const Frag*>(smem + KV_OFF + (hh * 2 + 1) * FRAG + lane * 16), p1, num);
+            const float z = __builtin_amdgcn_rcpf(den + eps_s);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) num[r] *= z;
+            mfrag[hh][0] = pack_step<T>(num, 0);
+            mfrag[hh][1] = pack_step<T>(num, 1);
+        }
+    }
+
+    K6_T(3);
+    // ---------------- m = LN1(W_m msg) : 16 steps, operand (tile t = step / 2, k-step s = step % 2) from registers
+    v16f m[8];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m[nb][r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+        Frag (&cur)[8] = (st & 1) ? fb : fa;
+        Frag (&nxt)[8] = (st & 1) ? fa : fb;
+        fetch_next(ring, nxt, st & 3);
+        const Frag bf = mfrag[st >> 1][st & 1];
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) Mm::mma(cur[nb], bf, m[nb]);
+        step_schedule<0>();
+    }
+    // nn.LayerNorm over the 256 channels of the lane's token, statistics in fp32; the other lane half holds the other
+    // 128 channels.  One pass over the accumulators (they live in AGPRs: every use is a register move): sum and sum of
+    // squares, var = E[x^2] - mean^2 (|x| = O(1) after a 256..512-deep product of O(1) operands: no cancellation issue).
+    auto ln_stats = [&](const v16f (&t)[8], float eps, float& mean, float& rstd) {
+        float s = 0.f, qd = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = t[nb][r];
+                s += v;
+                qd = fmaf(v, v, qd);
+            }
+        s += __shfl_xor(s, 32, 64);
+        qd += __shfl_xor(qd, 32, 64);
+        mean = s * (1.0f / C);
+        rstd = 1.0f / sqrtf(fmaxf(qd - s * mean, 0.f) * (1.0f / C) + eps);
+    };
+    // the four normalised values of registers 4g .. 4g+3 of tile nb (channels nb*32 + 8g + 4 h2 + {0..3})
+    auto ln_apply = [&](const v16f& t, int nb, int g, const float* gamma, const float* beta, float mean, float rstd) {
+        const int c = nb * 32 + 8 * g + 4 * h2;
+        const v4f ga = *reinterpret_cast<const v4f*>(gamma + c), be = *reinterpret_cast<const v4f*>(beta + c);
+        return v4f{(t[4 * g] - mean) * rstd * ga.x + be.x, (t[4 * g + 1] - mean) * rstd * ga.y + be.y,
+                   (t[4 * g + 2] - mean) * rstd * ga.z + be.z, (t[4 * g + 3] - mean) * rstd * ga.w + be.w};
+    };
+    K6_T(4);
+    {
+        float mean, rstd;
+        ln_stats(m, a.eps1, mean, rstd);
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+                const v4f lo = ln_apply(m[nb], nb, 2 * sx, vec, vec + C, mean, rstd), hi = ln_apply(m[nb], nb, 2 * sx + 1, vec, vec + C, mean, rstd);
+                mfrag[nb][sx] = pack8<T>(lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w);
+            }
+    }
+
+    K6_T(5);
+    // ---------------- hid = act(W_1 [x | m]) in four 128-wide slices, each consumed at once by out += W_2[:, slice] hid
+    // per slice 24 steps: 8 (x half: tiles hb = 0..3 x k-steps 2j, 2j+1) + 8 (m half: tile j of m) + 8 (W_2: tiles nb, k-step u)
+    v16f o[8];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[nb][r] = 0.f;
+#pragma unroll 1
+    for (int sl = 0; sl < 4; ++sl) {
+        v16f hd[4];
+#pragma unroll
+        for (int hb = 0; hb < 4; ++hb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hd[hb][r] = 0.f;
+        if (sl == 1) K6_T(6);
+        Frag t0f = xfrag(0), t1f = xfrag(1);
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            Frag (&cur)[8] = (st & 1) ? fb : fa;
+            Frag (&nxt)[8] = (st & 1) ? fa : fb;
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            const Frag n0 = xfrag(st < 7 ? 2 * st + 2 : 14), n1 = xfrag(st < 7 ? 2 * st + 3 : 15);
+            fetch_next(ring, nxt, st & 3);
+#pragma unroll
+            for (int hb = 0; hb < 4; ++hb) Mm::mma(cur[hb], t0f, hd[hb]);
+#pragma unroll
+            for (int hb = 0; hb < 4; ++hb) Mm::mma(cur[4 + hb], t1f, hd[hb]);
+            step_schedule<2>();
+            t0f = n0;
+            t1f = n1;
+        }
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            Frag (&cur)[8] = (st & 1) ? fb : fa;
+            Frag (&nxt)[8] = (st & 1) ? fa : fb;
+            fetch_next(ring, nxt, st & 3);
+#pragma unroll
+            for (int hb = 0; hb < 4; ++hb) Mm::mma(cur[hb], mfrag[st][0], hd[hb]);
+#pragma unroll
+            for (int hb = 0; hb < 4; ++hb) Mm::mma(cur[4 + hb], mfrag[st][1], hd[hb]);
+            step_schedule<0>();
+        }
+        Frag hfrag[4][2];
+#pragma unroll
+        for (int hb = 0; hb < 4; ++hb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if constexpr (ACT == 0) hd[hb][r] = fmaxf(hd[hb][r], 0.f);
+                else hd[hb][r] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * hd[hb][r]) + 1.0f);     // tanh, ~1e-6 abs
+            }
+            hfrag[hb][0] = pack_step<T>(hd[hb], 0);
+            hfrag[hb][1] = pack_step<T>(hd[hb], 1);
+        }
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {                                // out += W_2[:, 128 sl + 16 st .. + 15] hid
+            Frag (&cur)[8] = (st & 1) ? fb : fa;
+            Frag (&nxt)[8] = (st & 1) ? fa : fb;
+            fetch_next(ring, nxt, st & 3);
+            const Frag bf = hfrag[st >> 1][st & 1];
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) Mm::mma(cur[nb], bf, o[nb]);
+            step_schedule<0>();
+        }
+    }
+
+    K6_T(7);
+    // ---------------- out = x + LN2(.) (one rounding), per-sample skip predicate, row-contiguous stores through a slab
+    float mean2, rstd2;
+    ln_stats(o, a.eps2, mean2, rstd2);
+    K6_T(8);
+    // the predicate is per sample (flag_rows is a multiple of L in every caller): read it once, wave-uniformly
+    const bool keep = a.flag == nullptr || __builtin_amdgcn_readfirstlane(a.flag[((size_t)n * a.L + t0) / a.flag_rows]) != 0;
+    char* ot = smem + W_OFF + wave * 32 * SLAB_RS;                      // the ring is idle now (every wave passed the last turn)
+    const int prow = lane >> 4, pch = lane & 15;
+    T* og = (T*)a.out + (size_t)n * a.L * a.ldo;
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nb = hb * 4 + q4, c = nb * 32 + 8 * g + 4 * h2, ch = c >> 3;
+                typedef T v4t __attribute__((ext_vector_type(4)));
+                const v4t xv = *reinterpret_cast<const v4t*>(xrow + (ch >> 3) * 16384 + gf_lds_off(myrow, ch & 7) + (c & 7) * 2);
+                v4t ov = xv;
+                if (keep) {                                             // uniform over the workgroup: a tile belongs to one sample
+                    const v4f y = ln_apply(o[nb], nb, g, vec + 2 * C, vec + 3 * C, mean2, rstd2);
+                    ov[0] = gf_from_float<T>(gf_to_float(xv[0]) + y.x);
+                    ov[1] = gf_from_float<T>(gf_to_float(xv[1]) + y.y);
+                    ov[2] = gf_from_float<T>(gf_to_float(xv[2]) + y.z);
+                    ov[3] = gf_from_float<T>(gf_to_float(xv[3]) + y.w);
+                }
+                *reinterpret_cast<v4t*>(ot + lr * SLAB_RS + (q4 * 32 + 8 * g + 4 * h2) * 2) = ov;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 4 + prow, tg = t0 + wave * 32 + row;
+            if (tg < a.L)
+                *reinterpret_cast<v4u*>(og + (size_t)tg * a.ldo + hb * 128 + pch * 8) = *reinterpret_cast<const v4u*>(ot + row * SLAB_RS + pch * 16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    K6_T(9);
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// enc_kv_state: k, v projections of a 128-token source tile and its linear-attention state, in registers.
+// Here the products are NOT transposed (A = 32 token rows from the LDS tile, B = 32 weight rows): the result has
+// the channel on the lane and the tokens in registers, so the state KV[d][v] = sum_tok phi(k)[tok][d] v[tok][v] - a
+// contraction over the tiles' ROW index - takes both accumulators as MFMA operands directly (phi(k) as A gives
+// phi(k)^T . v).  Stream: the four 64-deep blocks of W_k, then the four of W_v.
+// -------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 1) void enc_kv_state(EncArgs a) {
+    using Mm = Mma32<T>;
+    using Frag = typename Mm::Frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5, lr = lane & 31;
+    const int n = blockIdx.x / a.tiles, tile = blockIdx.x - n * a.tiles;
+    const int t0 = tile * TM;
+    const T* xg = (const T*)a.x + (size_t)n * a.S * a.ldx;
+    const char* ws = (const char*)a.wstream;
+    constexpr int NBLK = 8;
+    K6_T(0);
+    dma_block(ws, smem, 0, wave, lane);
+    load_tile<T>(xg, a.ldx, t0, a.S, smem, X_OFF, tid);
+    // validity of the wave's 32 tokens as a bit mask (tail of the image, padding mask of linear_attention.py:37-39)
+    const int mytok = t0 + wave * 32 + lr;
+    const bool ok = mytok < a.S && (a.kv_mask == nullptr || a.kv_mask[(size_t)n * a.S + min(mytok, a.S - 1)] != 0);
+    const unsigned valid = (unsigned)__ballot(ok && h2 == 0);
+    dma_block(ws, smem, 1, wave, lane);
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");      // block 0 and the tile; block 1 stays in flight
+    __builtin_amdgcn_s_barrier();
+    K6_T(1);
+    const int myrow = wave * 32 + lr;
+    Ring ring{ws, smem, wave, lane, 0, NBLK};
+    Frag fa[8], fb[8];
+    load_step(ring, fa, 0, 0);
+    auto xfrag = [&](int ks) { return *reinterpret_cast<const Frag*>(smem + X_OFF + (ks >> 2) * 16384 + gf_lds_off(myrow, 2 * (ks & 3) + h2)); };
+    auto project = [&](v16f (&acc)[8]) {                               // acc = src tile x W^T: 16 steps (k-step = step)
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+        Frag tf = xfrag(0);
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            Frag (&cur)[8] = (st & 1) ? fb : fa;
+            Frag (&nxt)[8] = (st & 1) ? fa : fb;
+            __builtin_amdgcn_s_waitcnt(0xC07F);                        // see fetch_next: retire the current step's reads first
+            const Frag tn = xfrag(st < 15 ? st + 1 : 15);
+            fetch_next(ring, nxt, st & 3);
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) Mm::mma(tf, cur[nb], acc[nb]);
+            step_schedule<1>();
+            tf = tn;
+        }
+    };
+    // phi(k) first (its accumulators are packed to 16-bit operands and released), then v: 128 accumulators at a time
+    Frag kf[8][2];
+    float ksum[8];
+    float vm[16];                                                       // 1 / 0 per accumulator row (token) of this lane half
+#pragma unroll
+    for (int r = 0; r < 16; ++r) vm[r] = ((valid >> gf_acc_row(r, h2)) & 1u) ? 1.f : 0.f;
+    {
+        v16f k[8];
+        project(k);
+        K6_T(2);
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = phi(k[hh][r]) * vm[r];
+                k[hh][r] = p;                                           // rounded when packed as the MFMA operand
+                s += p;                                                 // Ksum adds the fp32 values
+            }
+            ksum[hh] = s + __shfl_xor(s, 32, 64);                     // lane lr = channel d
+            kf[hh][0] = pack_step<T>(k[hh], 0);
+            kf[hh][1] = pack_step<T>(k[hh], 1);
+        }
+    }
+    // state of the wave's 32 tokens: head h = channel tile h; rows = d, lane = v
+    v16f kv[8];
+    {
+        v16f v[8];
+        K6_T(3);
+        project(v);
+        K6_T(4);
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) kv[hh][r] = 0.f;
+            Mm::mma(kf[hh][0], pack_step<T>(v[hh], 0), kv[hh]);
+            Mm::mma(kf[hh][1], pack_step<T>(v[hh], 1), kv[hh]);
+        }
+    }
+    K6_T(5);
+    // sum of the four waves (tree through LDS: 3 -> 1 and 2 -> 0, then 1 -> 0), then one partial per tile
+    float* red = reinterpret_cast<float*>(smem);                       // [2][8][16][64] + [2][8][64] floats = 68 KiB
+    auto put = [&](int slot) {
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((slot * 8 + hh) * 16 + r) * 64 + lane] = kv[hh][r];
+            red[2 * 8 * 16 * 64 + (slot * 8 + hh) * 64 + lane] = ksum[hh];
+        }
+    };
+    auto get = [&](int slot) {
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) kv[hh][r] += red[((slot * 8 + hh) * 16 + r) * 64 + lane];
+            ksum[hh] += red[2 * 8 * 16 * 64 + (slot * 8 + hh) * 64 + lane];
+        }
+    };
+    __syncthreads();
+    if (wave >= 2) put(wave - 2);
+    __syncthreads();
+    if (wave < 2) get(wave);
+    __syncthreads();
+    if (wave == 1) put(0);
+    __syncthreads();
+    K6_T(6);
+    if (wave == 0) {
+        get(0);
+        float* dst = a.part + ((size_t)n * a.tiles + tile) * (C * D + C);
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(size_t)(hh * D + gf_acc_row(r, h2)) * D + lr] = kv[hh][r];      // [c][v]: 128-B runs
+            if (h2 == 0) dst[C * D + hh * D + lr] = ksum[hh];
+        }
+    }
+    K6_T(7);
+}
+
+__global__ void enc_kv_reduce(const float* part, float* fin, int tiles, int len) {
+    const int n = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    const float* p = part + (size_t)n * tiles * len + i;
+    float s = 0.f;
+    for (int c = 0; c < tiles; ++c) s += p[(size_t)c * len];
+    fin[(size_t)n * len + i] = s;
+}
+
+template <typename T>
+int enc_launch(const EncArgs& a, int act, bool attn, hipStream_t st) {
+    const dim3 grid(a.N * a.tiles);
+    if (attn) {
+        if (act == 0) enc_layer<T, 0, true><<<grid, 256, LDS_BYTES, st>>>(a);
+        else enc_layer<T, 1, true><<<grid, 256, LDS_BYTES, st>>>(a);
+    } else {
+        if (act == 0) enc_layer<T, 0, false><<<grid, 256, LDS_BYTES, st>>>(a);
+        else enc_layer<T, 1, false><<<grid, 256, LDS_BYTES, st>>>(a);
+    }
+    return 0;
+}
+
+bool enc_attr_done = false;
+template <typename K>
+void enc_allow_lds(K kern) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); }
+void enc_init() {
+    if (enc_attr_done) return;
+    enc_allow_lds(enc_layer<_Float16, 0, true>); enc_allow_lds(enc_layer<_Float16, 1, true>);
+    enc_allow_lds(enc_layer<_Float16, 0, false>); enc_allow_lds(enc_layer<_Float16, 1, false>);
+    enc_allow_lds(enc_kv_state<_Float16>);
+    enc_attr_done = true;
+}
+
+}   // namespace
+
+extern "C" size_t gf_encoder_kv_workspace_bytes(int N, int S) {
+    if (N <= 0 || S <= 0) return 0;
+    const size_t tiles = (S + TM - 1) / TM, len = (size_t)C * D + C;
+    return gf_align_up(sizeof(float) * N * tiles * len, 256);
+}
+
+// k/v projection + linear-attention state of `src` [N, S, 256]: kv_state [N][256*32 + 256] fp32 (KV as [c][v], then Ksum)
+extern "C" int gf_encoder_kv_state(const void* src, long ld, int dtype, int N, int S, const uint8_t* kv_mask,
+                                   const void* wstream_kv, float* kv_state, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+    GF_CHECK_ARG(src && wstream_kv && kv_state, "null pointer");
+    GF_CHECK_ARG(N > 0 && S > 0, "empty problem");
+    GF_CHECK_ARG(dtype == GF_F16, "the fused encoder kernels are built for 16-bit storage (GF_F16)");
+    GF_CHECK_ARG((ld * 2) % 16 == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)wstream_kv % 16 == 0, "operands must be 16-byte aligned");
+    if (workspace == nullptr || workspace_bytes < gf_encoder_kv_workspace_bytes(N, S)) {
+        gf_set_error("gf_encoder_kv_state: workspace too small");
+        return GF_ERR_WORKSPACE;
+    }
+    enc_init();
+    EncArgs a{};
+    a.x = src; a.ldx = ld; a.N = N; a.L = S; a.S = S; a.tiles = (S + TM - 1) / TM; a.kv_mask = kv_mask; a.wstream = wstream_kv;
+    a.part = (float*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    const int len = C * D + C;
+    void* pt = gf_prof_begin("enc_kv_state", st, 2.0 * N * (double)S * C * (2.0 * C + 2.0 * D));
+    enc_kv_state<_Float16><<<N * a.tiles, 256, W_OFF + 2 * WBLK + 8192, st>>>(a);
+    enc_kv_reduce<<<dim3((len + 255) / 256, N), 256, 0, st>>>(a.part, kv_state, a.tiles, len);
+    gf_prof_end("enc_kv_state", pt, st);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}
+
+// the encoder layer after (attn = 0) or including (attn = 1) the attention; see the header for the arguments
+extern "C" int gf_encoder_layer(const void* x, long ldx, const void* msg, long ldm, const float* kv_state, int S,
+                                const uint8_t* q_mask, float attn_eps, const void* wstream, const float* ln_params, float eps1,
+                                float eps2, int activation, const int32_t* row_flag, int flag_rows, void* out, long ldo, int dtype,
+                                int N, int L, void* stream) {
+    GF_CHECK_ARG(x && wstream && ln_params && out, "null pointer");
+    GF_CHECK_ARG((msg != nullptr) != (kv_state != nullptr), "exactly one of msg (attention output) and kv_state (linear attention) is given");
+    GF_CHECK_ARG(N > 0 && L > 0 && (kv_state == nullptr || S > 0), "empty problem");
+    GF_CHECK_ARG(dtype == GF_F16, "the fused encoder kernels are built for 16-bit storage (GF_F16)");
+    GF_CHECK_ARG(activation == 0 || activation == 1, "activation: 0 = ReLU, 1 = Tanh");
+    GF_CHECK_ARG((ldx * 2) % 16 == 0 && (ldo * 2) % 16 == 0 && (msg == nullptr || (ldm * 2) % 16 == 0), "rows must be 16-byte aligned");
+    GF_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)msg % 16 == 0 && (uintptr_t)wstream % 16 == 0,
+                 "tensors must be 16-byte aligned");
+    GF_CHECK_ARG(row_flag == nullptr || flag_rows > 0, "flag_rows must be > 0");
+    enc_init();
+    EncArgs a{};
+    a.x = x; a.ldx = ldx; a.msg = msg; a.ldm = ldm; a.kvfinal = kv_state; a.q_mask = q_mask; a.wstream = wstream; a.ln = ln_params;
+    a.eps1 = eps1; a.eps2 = eps2; a.attn_eps = attn_eps; a.out = out; a.ldo = ldo; a.N = N; a.L = L; a.S = S > 0 ? S : 1;
+    a.tiles = (L + TM - 1) / TM; a.flag = row_flag; a.flag_rows = flag_rows;
+    hipStream_t st = (hipStream_t)stream;
+    const bool attn = kv_state != nullptr;
+    // flops per token: [q 2C^2 + apply 2C(D+1)] + merge 2C^2 + mlp.0 2(2C)(2C) + mlp.2 2(2C)C
+    const double per_tok = (attn ? 2.0 * C * C + 2.0 * C * (D + 1) : 0.0) + 2.0 * C * C + 8.0 * C * C + 4.0 * C * C;
+    void* pt = gf_prof_begin("enc_layer", st, per_tok * N * (double)L);
+    enc_launch<_Float16>(a, activation, attn, st);
+    gf_prof_end("enc_layer", pt, st);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}

@@ -221,6 +221,7 @@ extern "C" int gf_bias_act_nhwc(const void* x, const float* bias, const void* re
                  "tensors must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     BaArgs a{x, bias, residual, out, 0, C, act, slope};
+    void* pt = gf_prof_begin("bias_act", st, (double)pixels * C * (dtype == GF_F32 ? 4 : 2) * (residual ? 3.0 : 2.0));
     if (dtype == GF_F16 && C % 8 == 0) {
         a.nvec = pixels * C / 8;
         bias_act<_Float16, 8><<<glue_blocks(a.nvec), 256, 0, st>>>(a);
@@ -231,6 +232,7 @@ extern "C" int gf_bias_act_nhwc(const void* x, const float* bias, const void* re
         a.nvec = pixels * C / 4;
         bias_act<float, 4><<<glue_blocks(a.nvec), 256, 0, st>>>(a);
     }
+    gf_prof_end("bias_act", pt, st);
     GF_CHECK_LAUNCH();
     return GF_OK;
 }

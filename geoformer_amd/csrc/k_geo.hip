@@ -284,8 +284,11 @@ extern "C" int gf_window_cross_attention(const void* q, const void* kmap, const 
     CaArgs a{q, kmap, vmap, ldq, ldk, ldv, win, valid, out, N, L, S, WW, 1.0f / sqrtf((float)D)};
     const dim3 grid((L + 3) / 4, N);
     hipStream_t st = (hipStream_t)stream;
+    // algorithmic bytes: q read, out written, each projected key / value map read once (served from L2 after that)
+    void* pt = gf_prof_begin("k5_window_attention", st, (double)N * (2.0 * L + 2.0 * S) * H * D * (dtype == GF_F32 ? 4 : 2));
     if (dtype == GF_F32) window_cross_attention<float, 25><<<grid, 256, 0, st>>>(a);
     else window_cross_attention<_Float16, 25><<<grid, 256, 0, st>>>(a);
+    gf_prof_end("k5_window_attention", pt, st);
     GF_CHECK_LAUNCH();
     return GF_OK;
 }

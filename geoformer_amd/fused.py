@@ -1,0 +1,114 @@
+"""Host side of the fused encoder-layer kernels (csrc/k6_encoder_fused.hip): weight pre-packing and the two ops.
+
+The kernels consume weights as a linear stream of 1-KiB MFMA A fragments (64 lanes x 8 sixteen-bit elements) in
+exactly the order the kernel multiplies them, 32 fragments per 32-KiB block.  Two fragment orders exist:
+
+  standard   element j of lane l = W[32 nb + (l & 31)][16 ks + 8 (l >> 5) + j]
+             (the other operand comes from the token tile in LDS, natural k order)
+  permuted   element j of lane l = W[32 nb + (l & 31)][32 t + 16 s + 8 (j >> 2) + 4 (l >> 5) + (j & 3)],  ks = 2 t + s
+             (the other operand is a packed accumulator tile: its k order is the accumulator's row order)
+
+Packing happens once per layer and dtype (cached by the modules), with plain torch gathers.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check
+from .ops import _DTYPES, _contig, _dt, _need_cuda, _p, _rows2d, _stream, _ws
+
+_IDX = {}
+
+
+def _frag_index(order, device):
+    """[ks, lane, j] -> k offset inside the 16-deep k-step ... returned as the absolute k = f(ks, lane, j) table builder."""
+    key = (order, str(device))
+    if key not in _IDX:
+        lane = torch.arange(64, device=device)[:, None]
+        j = torch.arange(8, device=device)[None, :]
+        h = lane >> 5
+        if order == 'std':
+            koff = 8 * h + j                                        # within a 16-deep step
+        else:
+            koff = 8 * (j >> 2) + 4 * h + (j & 3)
+        _IDX[key] = (koff, (lane & 31).expand(64, 8))
+    return _IDX[key]
+
+
+def fragments(w, order):
+    """w [N, K] -> [N/32, K/16, 64, 8]: fragment (nb, ks) of the chosen order."""
+    N, K = w.shape
+    koff, row = _frag_index(order, w.device)
+    nb = torch.arange(N // 32, device=w.device)[:, None, None, None]
+    ks = torch.arange(K // 16, device=w.device)[None, :, None, None]
+    return w[(32 * nb + row[None, None]), (16 * ks + koff[None, None])]
+
+
+def _steps(f, tiles, ksteps):
+    """f [NB, KS, 64, 8] -> stream piece: for each k-step in `ksteps` (a list of lists: the k-steps of one 8-fragment
+    step) the fragments of the tiles `tiles`, k-step-major inside the step."""
+    return torch.cat([f[tiles, ks].reshape(-1) for group in ksteps for ks in group])
+
+
+def pack_layer_stream(wq, wm, w1, w2):
+    """Stream of gf_encoder_layer, in steps of 8 fragments (4 steps = one 32-KiB block):
+       [W_q: 16 steps (k-step ks: tiles 0..7)] + W_m: 16 steps (permuted order) + per 128-wide hidden slice sl
+       { W_1[:, :256]: 8 steps (k-steps 2j, 2j+1 x tiles 4sl..4sl+3), W_1[:, 256:]: 8 steps (same, permuted),
+         W_2[:, slice]: 8 steps (k-step u: tiles 0..7, permuted) }.   wq may be None (attention computed elsewhere)."""
+    c = wm.shape[0]
+    parts = []
+    all8 = torch.arange(8, device=wm.device)
+    if wq is not None:
+        parts.append(_steps(fragments(wq, 'std'), all8, [[ks] for ks in range(16)]))
+    parts.append(_steps(fragments(wm, 'perm'), all8, [[ks] for ks in range(16)]))
+    f1x, f1m = fragments(w1[:, :c], 'std'), fragments(w1[:, c:], 'perm')   # [16, 16, 64, 8]
+    pairs = [[2 * j, 2 * j + 1] for j in range(8)]
+    for sl in range(4):
+        tiles = torch.arange(4 * sl, 4 * sl + 4, device=wm.device)
+        parts.append(_steps(f1x, tiles, pairs))
+        parts.append(_steps(f1m, tiles, pairs))
+        parts.append(_steps(fragments(w2[:, 128 * sl:128 * sl + 128], 'perm'), all8, [[u] for u in range(8)]))
+    return torch.cat(parts).contiguous()
+
+
+def pack_kv_stream(wk, wv):
+    """Stream of gf_encoder_kv_state: W_k in 16 steps (k-step ks: tiles 0..7), then W_v."""
+    all8 = torch.arange(8, device=wk.device)
+    return torch.cat([_steps(fragments(w, 'std'), all8, [[ks] for ks in range(16)]) for w in (wk, wv)]).contiguous()
+
+
+def encoder_kv_state(src, wstream_kv, kv_mask=None):
+    """src [N, S, 256] (16-bit) -> kv_state fp32 [N, 256*32 + 256]."""
+    _need_cuda(src, wstream_kv)
+    N, S, C = src.shape
+    if C != 256:
+        raise ValueError('the fused encoder kernels are built for d_model = 256')
+    src, ld = _rows2d(src)
+    L_ = _lib.lib()
+    ws = _ws.get('k6', L_.gf_encoder_kv_workspace_bytes(N, S), src.device)
+    out = torch.empty(N, C * 32 + C, dtype=torch.float32, device=src.device)
+    km = None if kv_mask is None else _contig(kv_mask.reshape(N, S).to(torch.uint8))
+    check(L_.gf_encoder_kv_state(_p(src), ld, _dt(src), N, S, _p(km), _p(wstream_kv), _p(out), _p(ws), ws.numel(), _stream()),
+          'gf_encoder_kv_state')
+    return out
+
+
+def encoder_layer(x, wstream, ln_params, eps1, eps2, activation, msg=None, kv_state=None, source_len=0, q_mask=None,
+                  attn_eps=1e-6, row_flag=None, flag_rows=0, out=None):
+    """x [N, L, 256] -> out [N, L, 256]; give either `msg` (attention output) or `kv_state` (+ source_len)."""
+    _need_cuda(x, wstream, ln_params)
+    N, L, C = x.shape
+    x, ldx = _rows2d(x)
+    ldm = 0
+    if msg is not None:
+        msg, ldm = _rows2d(msg)
+    if out is None:
+        out = torch.empty(N, L, C, dtype=x.dtype, device=x.device)
+    elif out.shape != (N, L, C) or out.dtype != x.dtype or not out.is_contiguous():
+        raise ValueError('out must be a contiguous tensor of the result shape and dtype')
+    qm = None if q_mask is None else _contig(q_mask.reshape(N, L).to(torch.uint8))
+    check(_lib.lib().gf_encoder_layer(_p(x), ldx, _p(msg), ldm, _p(kv_state), int(source_len), _p(qm), float(attn_eps), _p(wstream),
+                                      _p(ln_params), float(eps1), float(eps2), int(activation), _p(row_flag), int(flag_rows), _p(out), C,
+                                      _dt(x), N, L, _stream()), 'gf_encoder_layer')
+    return out

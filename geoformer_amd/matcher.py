@@ -148,46 +148,59 @@ def corner_error(H_pred, H_gt, w, h):
     return float(np.mean(np.linalg.norm(a[:, :2] / a[:, 2:] - b[:, :2] / b[:, 2:], axis=1)))
 
 
-def eval_hpatches(matcher, data_root, ransac_thres=3, thres=(1, 3, 5, 10), scale_H=True, max_seqs: Optional[int] = None,
-                  log=print):
-    """Homography-estimation AUC over HPatches sequences (pairs 1 -> 2..6), the protocol of
-    hpatches_helper.eval_hpatches with task='homography', h_solver='cv'."""
-    from PIL import Image
+def hpatches_pairs(data_root, max_seqs: Optional[int] = None):
+    """The protocol's pair list: every sequence (reverse lexical order, as hpatches_helper.eval_hpatches walks
+    them), image 1 against images 2..6 -> [(sequence name, im1, im2, H_1_k path)]."""
     seqs = sorted(glob.glob(os.path.join(data_root, '*')))[::-1]
     if max_seqs:
         seqs = seqs[:max_seqs]
-    dists = {'a': [], 'i': [], 'v': []}
-    n_matches, times, failed = [], [], 0
-    for seq in seqs:
-        sname = os.path.basename(seq)
-        im1 = os.path.join(seq, '1.ppm')
-        for k in range(2, 7):
-            im2 = os.path.join(seq, f'{k}.ppm')
-            H_gt = np.loadtxt(os.path.join(seq, f'H_1_{k}'))
+    return [(os.path.basename(seq), os.path.join(seq, '1.ppm'), os.path.join(seq, f'{k}.ppm'), os.path.join(seq, f'H_1_{k}'))
+            for seq in seqs for k in range(2, 7)]
+
+
+def eval_hpatches(matcher, data_root, ransac_thres=3, thres=(1, 3, 5, 10), scale_H=True, max_seqs: Optional[int] = None,
+                  log=print):
+    """Homography-estimation AUC over HPatches sequences (pairs 1 -> 2..6), the protocol of
+    hpatches_helper.eval_hpatches with task='homography', h_solver='cv'.
+
+    Pairs are independent: under torch.distributed (one process per GPU) the pair list is cut into contiguous
+    per-rank blocks by `shard.run_sharded` and every rank ends up with the summaries of ALL pairs, so the metric
+    is identical on every rank and to a single-process run."""
+    from PIL import Image
+    from .shard import run_sharded
+
+    def match_block(block):
+        out = []
+        for sname, im1, im2, hfile in block:
+            H_gt = np.loadtxt(hfile)
             scale = np.ones(4)
             t0 = time.time()
             res = matcher(im1, im2)
-            times.append(time.time() - t0)
+            dt = time.time() - t0
             matches = res[0]
-            if scale_H and len(res) > 4:
+            if scale_H and len(res) > 4:       # matches stay in resized coordinates: move the GT homography there
                 scale = res[4]
                 H_gt = np.linalg.inv(scale_homography(scale[2], scale[3])) @ H_gt @ scale_homography(scale[0], scale[1])
-            n_matches.append(len(matches))
             H_pred, _ = estimate_homography(matches, ransac_thres, matcher.device)
             if H_pred is None:
-                d, failed = np.nan, failed + 1
+                d = float('nan')
             else:
                 w, h = Image.open(im1).size
                 d = corner_error(H_pred, H_gt, w / scale[0], h / scale[1])
-            dists['a'].append(d)
-            dists[sname[0] if sname[0] in 'iv' else 'v'].append(d)
+            out.append((sname, d, len(matches), dt))
+        return out
+    rows = run_sharded(hpatches_pairs(data_root, max_seqs), match_block, batch=5)
+    dists = {'a': [], 'i': [], 'v': []}
+    for sname, d, _, _ in rows:
+        dists['a'].append(d)
+        dists[sname[0] if sname[0] in 'iv' else 'v'].append(d)
     out = {}
     for key, ds in dists.items():
         ds = np.asarray(ds, dtype=float)
         out['correct_' + key] = np.mean([[float(d <= t) for t in thres] for d in ds], axis=0) if len(ds) else np.zeros(len(thres))
         out['auc_' + key] = cal_error_auc(ds, thres)
-    out.update(failed=failed, mean_matches=float(np.mean(n_matches)) if n_matches else 0.0,
-               match_time=float(np.mean(times)) if times else 0.0)
+    out.update(failed=int(sum(np.isnan(r[1]) for r in rows)), mean_matches=float(np.mean([r[2] for r in rows])) if rows else 0.0,
+               match_time=float(np.mean([r[3] for r in rows])) if rows else 0.0, pairs=len(rows))
     log(f"Hest Correct: a={out['correct_a']} i={out['correct_i']} v={out['correct_v']}")
     log(f"Hest AUC: a={out['auc_a']} i={out['auc_i']} v={out['auc_v']}")
     return out
@@ -199,30 +212,51 @@ def eval_hpatches(matcher, data_root, ransac_thres=3, thres=(1, 3, 5, 10), scale
 #   python -m geoformer_amd.matcher hpatches /path/to/hpatches-sequences-release [--ckpt ...]
 # ---------------------------------------------------------------------------------------------
 def main(argv=None):
+    """Defaults follow the reference per sub-command: `match` = inference.py:107 (imsize 640, matches scaled back to the
+    original images); `hpatches` = eval_configs/geoformer.yml:7-11 with eval_Hpatches.py:96-100 (imsize 480, match
+    threshold 0.2, no_match_upscale True -> the ground-truth homography is moved into resized coordinates, RANSAC
+    threshold 3).  Under `python -m torch.distributed.run --nproc-per-node N -m geoformer_amd.matcher hpatches ...` the
+    pair list is sharded over the N GPUs (shard.run_sharded)."""
     import argparse
     ap = argparse.ArgumentParser(prog='python -m geoformer_amd.matcher')
     sub = ap.add_subparsers(dest='cmd', required=True)
     m = sub.add_parser('match', help='match one image pair (inference.py)')
     m.add_argument('im1'), m.add_argument('im2'), m.add_argument('--out', default=None)
+    m.add_argument('--imsize', type=int, default=640)
+    m.add_argument('--no-match-upscale', action='store_true')
     h = sub.add_parser('hpatches', help='homography AUC over HPatches sequences (eval_Hpatches.py)')
     h.add_argument('root'), h.add_argument('--max-seqs', type=int, default=None)
     h.add_argument('--ransac-thres', type=float, default=3.0)
+    h.add_argument('--imsize', type=int, default=480)
+    h.add_argument('--match-upscale', dest='no_match_upscale', action='store_false',
+                   help='scale matches back to the original images instead of moving the GT homography (reference: off)')
+    h.set_defaults(no_match_upscale=True)
     for p in (m, h):
         p.add_argument('--ckpt', default=None)
-        p.add_argument('--imsize', type=int, default=640)            # inference.py:107 / eval_Hpatches.py defaults
         p.add_argument('--match-threshold', type=float, default=0.2)
-        p.add_argument('--no-match-upscale', action='store_true')
-        p.add_argument('--precision', choices=('fp32', 'fp16'), default='fp16')
+        p.add_argument('--precision', choices=('fp32', 'fp16'), default='fp16',
+                       help="fp16 = the fast mode (fp16 storage, fp32 accumulation); fp32 = the reference's arithmetic")
     args = ap.parse_args(argv)
-    matcher = GeoFormerMatcher(args.imsize, args.match_threshold, args.no_match_upscale, args.ckpt, precision=args.precision)
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        torch.cuda.set_device(local)
+        torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
+    matcher = GeoFormerMatcher(args.imsize, args.match_threshold, args.no_match_upscale, args.ckpt, device=f'cuda:{local}',
+                               precision=args.precision)
     if args.cmd == 'match':
         res = matcher(args.im1, args.im2)
         print(f'{matcher.name}: {len(res[0])} matches')
         if args.out:
             np.savez(args.out, matches=res[0], kpts1=res[1], kpts2=res[2], scores=res[3])
     else:
-        out = eval_hpatches(matcher, args.root, ransac_thres=args.ransac_thres, max_seqs=args.max_seqs)
-        print({k: (v.tolist() if hasattr(v, 'tolist') else v) for k, v in out.items()})
+        quiet = int(os.environ.get('RANK', '0')) != 0
+        out = eval_hpatches(matcher, args.root, ransac_thres=args.ransac_thres, max_seqs=args.max_seqs,
+                            scale_H=matcher.no_match_upscale, log=(lambda s: None) if quiet else print)
+        if not quiet:
+            print({k: (v.tolist() if hasattr(v, 'tolist') else v) for k, v in out.items()})
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':

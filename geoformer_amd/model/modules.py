@@ -11,7 +11,7 @@ from typing import Dict, Optional
 
 import torch
 import torch.nn as nn
-from .. import ops
+from .. import fused, ops
 
 
 # ---------------------------------------------------------------------------------------------
@@ -86,8 +86,21 @@ class LoFTREncoderLayer(nn.Module):
                  'w2': self.mlp[2].weight.detach().to(dtype).contiguous(),
                  'n1': (self.norm1.weight.detach().to(f32).contiguous(), self.norm1.bias.detach().to(f32).contiguous()),
                  'n2': (self.norm2.weight.detach().to(f32).contiguous(), self.norm2.bias.detach().to(f32).contiguous())}
+            if self.fusable(dtype):
+                # K6: the weights as the fragment streams the fused kernels consume (fused.py), packed once
+                c = self.d_model
+                w['ln'] = torch.cat([w['n1'][0], w['n1'][1], w['n2'][0], w['n2'][1]]).contiguous()
+                w['stream_finish'] = fused.pack_layer_stream(None, w['merge'], w['w1'], w['w2'])
+                if self.attention_kind == 'linear':
+                    w['stream'] = fused.pack_layer_stream(w['q'], w['merge'], w['w1'], w['w2'])
+                    w['stream_kv'] = fused.pack_kv_stream(w['kv'][:c], w['kv'][c:])
             self._cache[dtype] = w
         return w
+
+    def fusable(self, dtype):
+        """The fused two-launch form (csrc/k6_encoder_fused.hip) exists for 16-bit storage at d_model 256, with
+        8 heads of 32 when the layer's own (linear) attention is part of it."""
+        return dtype != torch.float32 and self.d_model == 256 and (self.attention_kind != 'linear' or self.nhead == 8)
 
     def invalidate(self):
         self._cache = {}
@@ -105,6 +118,10 @@ class LoFTREncoderLayer(nn.Module):
         two-part operand (no concat) + activation, mlp.2+LN+residual.  row_flag (int32 per `flag_rows`
         rows) == 0 leaves x unchanged - GeoTransformer's per-sample 'layer skipped' cases."""
         w = self.weights(x.dtype)
+        if self.fusable(x.dtype):
+            return fused.encoder_layer(x, w['stream_finish'], w['ln'], self.norm1.eps, self.norm2.eps,
+                                       0 if self.activation == 'relu' else 1, msg=message, row_flag=row_flag,
+                                       flag_rows=flag_rows, out=out)
         act = ops.EPI_RELU if self.activation == 'relu' else ops.EPI_TANH
         message = ops.linear(message, w['merge'], epilogue=ops.EPI_LN, ln=w['n1'], eps=self.norm1.eps)
         hid = ops.linear(x, w['w1'], a2=message, epilogue=act)
@@ -117,6 +134,13 @@ class LoFTREncoderLayer(nn.Module):
         are driven by GeoTransformer, which owns the token lists / windows)."""
         if self.attention_kind != 'linear':
             raise NotImplementedError('full attention layers are driven by GeoTransformer')
+        if self.fusable(x.dtype):
+            # two launches, three token-row transfers: source -> state (k, v never reach HBM), x -> out
+            w = self.weights(x.dtype)
+            state = fused.encoder_kv_state(source, w['stream_kv'], source_mask)
+            return fused.encoder_layer(x, w['stream'], w['ln'], self.norm1.eps, self.norm2.eps,
+                                       0 if self.activation == 'relu' else 1, kv_state=state, source_len=source.shape[1],
+                                       q_mask=x_mask, out=out)
         q = self.project_q(x)
         k, v = self.project_kv(source)
         message = ops.linear_attention(q, k, v, self.nhead, x_mask, source_mask)

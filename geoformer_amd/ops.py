@@ -430,8 +430,9 @@ class CoarseFocalLoss(torch.autograd.Function):
         d0 = torch.empty(N, L, C, dtype=torch.float32, device=grad.device)
         d1 = torch.empty(N, S, C, dtype=torch.float32, device=grad.device)
         m0, m1 = ctx.masks
+        gl = _contig(g_loss.detach().reshape(1).to(device=grad.device, dtype=torch.float32))   # stays on the device: no host sync
         check(_lib.lib().gf_coarse_loss_backward(N, L, S, C, _p(m0), _p(m1), temperature, _p(pb), _p(pi), _p(pj), pb.numel(), _p(grad),
-                                                 float(g_loss), _p(d0), _p(d1), _p(ws), ws.numel(), _stream()),
+                                                 1.0, _p(gl), _p(d0), _p(d1), _p(ws), ws.numel(), _stream()),
               'gf_coarse_loss_backward')
         return d0.to(dtype), d1.to(dtype), None, None, None, None, None, None, None, None, None
 

@@ -16,7 +16,7 @@ import time
 import torch
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--batch', type=int, default=4, help='pairs per GPU (reference: 32 over 8 GPUs)')
@@ -25,14 +25,20 @@ def main():
     ap.add_argument('--ckpt', default=None, help='initial state dict (geoformer.ckpt)')
     ap.add_argument('--save', default=None)
     ap.add_argument('--coarse-thr', type=float, default=0.2)
-    args = ap.parse_args()
+    ap.add_argument('--fused-coarse-loss', action='store_true',
+                    help='coarse focal losses through the HIP kernels (fp16 operands; tolerances in TrainStep.__doc__)')
+    ap.add_argument('--force-ddp', action='store_true', help='wrap in DDP/SyncBatchNorm even at world size 1')
+    args = ap.parse_args(argv)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank, local = int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
-        torch.distributed.init_process_group('nccl', rank=rank, world_size=world)
+    ddp = world > 1 or args.force_ddp
+    if ddp:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from ..model.cvpr_ds_config import get_default_cfg
     from ..model.full_model import GeoFormer
@@ -48,7 +54,7 @@ def main():
     else:
         deterministic_init_(model)
     model.to(dev)
-    step = TrainStep(model, batch_size=args.batch, distributed=world > 1, device_ids=[local] if world > 1 else None)
+    step = TrainStep(model, batch_size=args.batch, distributed=ddp, fused_coarse_loss=args.fused_coarse_loss)
     t0 = t1 = time.perf_counter()
     for it in range(args.steps):
         if it == 1:                               # the first step carries MIOpen's algorithm search
@@ -70,8 +76,9 @@ def main():
         print(f'{args.steps} steps in {now - t0:.1f} s; {rate:.2f} pairs/s over {world} GPU(s) after the first step')
         if args.save:
             torch.save({'state_dict': step.model.state_dict()}, args.save)
-    if world > 1:
+    if ddp:
         torch.distributed.destroy_process_group()
+    return float(loss)
 
 
 if __name__ == '__main__':

@@ -86,10 +86,22 @@ class _Core(nn.Module):
 
 
 class TrainStep:
-    """One optimisation step per call; `epoch_end()` advances an epoch-interval scheduler."""
+    """One optimisation step per call; `epoch_end()` advances an epoch-interval scheduler.
+
+    `step(batch)` mutates `batch` exactly like the reference's `_trainval_inference` (supervision, forward outputs,
+    `loss`, `loss_scalars`): the DDP wrapper is built WITHOUT `device_ids` - the module lives on one device and the
+    inputs are created there - because with `device_ids` DDP rebuilds every input dict on the way in and the caller's
+    `batch` would never see what the forward wrote.
+
+    `fused_coarse_loss=False` (default) is the parity configuration: both coarse losses are differentiated by autograd
+    on materialised fp32 confidence matrices, like the reference.  `True` switches the two coarse losses to the HIP
+    kernels `gf_coarse_loss_forward/backward`, which compute in fp16 operands / fp32 accumulation: loss value and `p`
+    agree with fp32 autograd on the SAME (fp16-rounded) features to 2e-3, the feature gradients to 2e-2 in norm
+    (tests/test_train_gpu.py); against un-rounded fp32 features the loss agrees to 5e-3 and the gradients to 5e-2 in
+    norm, also for confident matches (p > 0.95), where the gradient itself is small."""
 
     def __init__(self, model, trainer_cfg=None, loss_cfg=None, batch_size=1, distributed=False, device_ids=None,
-                 homography_fn: Optional[Callable] = None, sparse_spvs=True, fused_coarse_loss=True):
+                 homography_fn: Optional[Callable] = None, sparse_spvs=True, fused_coarse_loss=False):
         world = torch.distributed.get_world_size() if distributed else 1
         self.cfg = scale_trainer_cfg(trainer_cfg, world, batch_size)
         if model.precision != 'fp32':
@@ -102,7 +114,10 @@ class TrainStep:
             if next(model.parameters()).is_cuda:      # torch's SyncBatchNorm is device-only; the gloo/CPU tests keep local BN
                 core = nn.SyncBatchNorm.convert_sync_batchnorm(core)
             self.model = core.model
-            core = nn.parallel.DistributedDataParallel(core, device_ids=device_ids, find_unused_parameters=True)
+            if device_ids is not None:
+                raise ValueError('TrainStep builds DDP without device_ids (see the class docstring): call '
+                                 'torch.cuda.set_device(local_rank) and move the model there instead')
+            core = nn.parallel.DistributedDataParallel(core, find_unused_parameters=True)
         self.core = core
         self.optimizer = build_optimizer(self.model, self.cfg)
         self.scheduler = build_scheduler(self.cfg, self.optimizer)
@@ -110,6 +125,8 @@ class TrainStep:
 
     def __call__(self, batch):
         loss = self.core(batch)
+        if 'loss_scalars' not in batch:          # the wrapper handed the forward a copy of the batch
+            raise RuntimeError('the training forward did not write into the caller\'s batch')
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         if self.cfg['gradient_clipping']:

@@ -76,7 +76,9 @@ int gf_dual_softmax_match(const void* f0, const void* f1, int dtype, int N, int 
  *   optional padding masks uint8 [N,L] / [N,S] (pairs with a padded member: sim = -1e9, coarse_matching.py:123-124).
  *   forward:  pos_conf[k] = conf[b,i,j], pos_loss[k] = -alpha (1-p)^gamma log p * w  (p clamped to [1e-6, 1-1e-6]),
  *             pos_grad[k] = d pos_loss[k] / d log p.   loss_c = c_pos_w * mean_k pos_loss[k] is formed by the caller.
- *   backward: d_f0 [N,L,256], d_f1 [N,S,256] fp32 (overwritten) for  loss = scale * sum_k pos_loss[k];
+ *   backward: d_f0 [N,L,256], d_f1 [N,S,256] fp32 (overwritten) for  loss = scale * scale_dev[0] * sum_k pos_loss[k]
+ *             (scale_dev: optional DEVICE scalar, NULL = 1; lets autograd hand the upstream gradient over without a
+ *             host synchronisation);
  *             the workspace of the forward call must be passed unchanged (fp16 features and softmax statistics).
  *   L and S multiples of 128, C = 256.
  * ------------------------------------------------------------------------------------------ */
@@ -87,8 +89,8 @@ int gf_coarse_loss_forward(const void* f0, const void* f1, int dtype, int N, int
                            float* pos_grad, void* workspace, size_t workspace_bytes, void* stream);
 int gf_coarse_loss_backward(int N, int L, int S, int C, const uint8_t* mask0, const uint8_t* mask1, float temperature,
                             const int64_t* pos_b, const int64_t* pos_i,
-                            const int64_t* pos_j, int P, const float* pos_grad, float scale, float* d_f0, float* d_f1,
-                            void* workspace, size_t workspace_bytes, void* stream);
+                            const int64_t* pos_j, int P, const float* pos_grad, float scale, const float* scale_dev,
+                            float* d_f0, float* d_f1, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * a1  position encoding add + flatten
@@ -110,6 +112,33 @@ size_t gf_linear_attention_workspace_bytes(int N, int S, int H, int D);
 int gf_linear_attention(const void* q, const void* k, const void* v, int dtype, int N, int L, int S, int H,
                         int D, long ldq, long ldk, long ldv, const uint8_t* q_mask, const uint8_t* kv_mask,
                         float eps, void* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K6  the encoder layer in two launches (16-bit storage modes)
+ * replaces LoFTREncoderLayer.forward as a whole (model/loftr_src/loftr/loftr_module/transformer.py:37-60 with
+ *          LinearAttention.forward, linear_attention.py:21-51) and the part of the Geo layer after its attention
+ *          (model/geo_transformer/transformer.py:56-66); d_model 256, 8 heads of 32 (linear attention).
+ *   gf_encoder_kv_state: kv_state[n] = { KV[c][v] = sum_s phi(k)[s,c] v[s, head(c)*32 + v],  Ksum[c] = sum_s phi(k)[s,c] },
+ *          k = W_k src, v = W_v src, phi = elu + 1, masked / out-of-range rows excluded; fp32 [N][256*32 + 256]
+ *          (KV from the 16-bit rounded phi(k) and v, Ksum from the fp32 phi(k)).
+ *          wstream_kv = W_k and W_v packed by geoformer_amd/fused.py:pack_kv_stream (256 KiB).
+ *   gf_encoder_layer: out = x + LN2(W_2 act(W_1 [x | LN1(W_m msg)])) with
+ *          msg = phi(W_q x) KV / (phi(W_q x) . Ksum + attn_eps)       when kv_state is given (S = source length), or
+ *          msg = the given attention output [N*L, 256]                 when msg is given;
+ *          wstream = fused.py:pack_layer_stream (1 MiB with W_q, 896 KiB without); ln_params = gamma1|beta1|gamma2|beta2
+ *          fp32 [4][256]; activation 0 = ReLU, 1 = Tanh; row_flag / flag_rows as in gf_linear (0 -> out = x).
+ *   Rounding points (what oracle/geoformer_oracle.py's storage mode mirrors): every MFMA operand is rounded to the
+ *   storage type (phi(q), phi(k), v, KV/S, Ksum/S, msg, LN1 output, hidden activations); accumulation, LayerNorm,
+ *   phi, the activation and the residual sum are fp32; out is rounded once.
+ * ------------------------------------------------------------------------------------------ */
+size_t gf_encoder_kv_workspace_bytes(int N, int S);
+int gf_encoder_kv_state(const void* src, long ld, int dtype, int N, int S, const uint8_t* kv_mask,
+                        const void* wstream_kv, float* kv_state, void* workspace, size_t workspace_bytes,
+                        void* stream);
+int gf_encoder_layer(const void* x, long ldx, const void* msg, long ldm, const float* kv_state, int S,
+                     const uint8_t* q_mask, float attn_eps, const void* wstream, const float* ln_params, float eps1,
+                     float eps2, int activation, const int32_t* row_flag, int flag_rows, void* out, long ldo, int dtype,
+                     int N, int L, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K3  encoder-layer linears with fused epilogues

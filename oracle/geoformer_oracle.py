@@ -159,6 +159,95 @@ def encoder_layer(P: Dict[str, torch.Tensor], prefix: str, x, source, nhead: int
 
 
 # --------------------------------------------------------------------------------------
+# 16-bit STORAGE MODE of the encoder layers.  The product's fast modes keep tensors in fp16 (or bf16) and
+# accumulate in fp32; the functions below restate the same reference arithmetic with a round trip through
+# the storage type at exactly the points where the HIP kernels round (include/geoformer_hip.h, K6 / K3 / K2):
+#   'fused'   csrc/k6_encoder_fused.hip (coarse LoFTR layers; the part of a Geo layer after its attention):
+#             every MFMA operand is rounded (phi(q), phi(k), v, KV/S, Ksum/S, msg, LN1 output, hidden
+#             activations), everything else is fp32, the output x + LN2(.) is rounded once;
+#   'chain'   the K3 + K2 kernel chain (fine level): every tensor a kernel writes is rounded (q, k, v, message,
+#             LN1 output, hidden activations, LN2 output, and then the residual sum once more).
+# `st` is the storage dtype.  Not a new algorithm: with st = torch.float32 both reduce to encoder_layer above.
+# --------------------------------------------------------------------------------------
+
+
+def rt(x: torch.Tensor, st) -> torch.Tensor:
+    """Round trip through the storage type."""
+    return x if st is None or st == torch.float32 else x.to(st).float()
+
+
+def _phi(x):
+    """elu(x) + 1 as the kernels evaluate it: x + 1 for x > 0, exp(x) otherwise."""
+    return torch.where(x > 0, x + 1, torch.exp(torch.clamp(x, max=0)))
+
+
+def linear_attention_fused(q, k, v, st, q_mask=None, kv_mask=None, eps: float = 1e-6):
+    """q [N,L,H,D], k, v [N,S,H,D] un-rounded fp32 projections -> message [N,L,H,D] (rounded)."""
+    s_len = v.size(1)
+    inv_s = torch.tensor(1.0, dtype=torch.float32) / float(s_len)
+    Kf = _phi(k)                                     # fp32: Ksum is not an MFMA operand, it adds the unrounded values
+    if kv_mask is not None:
+        Kf = Kf * kv_mask[:, :, None, None]
+    Q, K, V = rt(_phi(q), st), rt(Kf, st), rt(v, st)
+    if q_mask is not None:
+        Q = Q * q_mask[:, :, None, None]
+    KV = rt(torch.einsum('nshd,nshv->nhdv', K, V) * inv_s, st)
+    Ks = rt(Kf.sum(dim=1) * inv_s, st)
+    num = torch.einsum('nlhd,nhdv->nlhv', Q, KV)
+    den = torch.einsum('nlhd,nhd->nlh', Q, Ks) + torch.tensor(eps, dtype=torch.float32) / float(s_len)
+    return rt(num * (1.0 / den)[..., None], st)
+
+
+def _finish_fused(P, prefix, x, msg, kind, st):
+    """x, msg [N,L,C] (rounded) -> x + LN2(W_2 act(W_1 [x | LN1(W_m msg)]))."""
+    c = x.shape[-1]
+    W = lambda name: rt(P[prefix + name], st)                                    # noqa: E731
+    m = F.linear(msg, W('merge.weight'))
+    m = rt(F.layer_norm(m, (c,), P[prefix + 'norm1.weight'], P[prefix + 'norm1.bias']), st)
+    hid = F.linear(torch.cat([x, m], dim=2), W('mlp.0.weight'))
+    hid = rt(torch.relu(hid) if kind == 'loftr' else torch.tanh(hid), st)
+    o = F.layer_norm(F.linear(hid, W('mlp.2.weight')), (c,), P[prefix + 'norm2.weight'], P[prefix + 'norm2.bias'])
+    return rt(x + o, st)
+
+
+def encoder_layer_fused(P, prefix, x, source, nhead, st, x_mask=None, source_mask=None):
+    """LoFTR (linear attention, ReLU) layer in the 'fused' storage mode; x, source already rounded."""
+    n, _, c = x.shape
+    d = c // nhead
+    W = lambda name: rt(P[prefix + name], st)                                    # noqa: E731
+    q = F.linear(x, W('q_proj.weight')).view(n, -1, nhead, d)
+    k = F.linear(source, W('k_proj.weight')).view(n, -1, nhead, d)
+    v = F.linear(source, W('v_proj.weight')).view(n, -1, nhead, d)
+    msg = linear_attention_fused(q, k, v, st, x_mask, source_mask).reshape(n, -1, c)
+    return _finish_fused(P, prefix, x, msg, 'loftr', st)
+
+
+def encoder_layer_chain(P, prefix, x, source, nhead, st, x_mask=None, source_mask=None):
+    """LoFTR layer in the 'chain' storage mode (K3 linears + K2 attention of short sequences, the fine level):
+    la_small evaluates phi, the state and the normaliser in fp32 from the stored q, k, v."""
+    n, _, c = x.shape
+    d = c // nhead
+    W = lambda name: rt(P[prefix + name], st)                                    # noqa: E731
+    q = rt(F.linear(x, W('q_proj.weight')), st).view(n, -1, nhead, d)
+    k = rt(F.linear(source, W('k_proj.weight')), st).view(n, -1, nhead, d)
+    v = rt(F.linear(source, W('v_proj.weight')), st).view(n, -1, nhead, d)
+    Q, K = _phi(q), _phi(k)
+    if x_mask is not None:
+        Q = Q * x_mask[:, :, None, None]
+    if source_mask is not None:
+        K = K * source_mask[:, :, None, None]
+        v = v * source_mask[:, :, None, None]
+    s_len = v.size(1)
+    KV = torch.einsum('nshd,nshv->nhdv', K, v / s_len)
+    Z = 1 / (torch.einsum('nlhd,nhd->nlh', Q, K.sum(dim=1)) + 1e-6)
+    msg = rt(torch.einsum('nlhd,nhdv,nlh->nlhv', Q, KV, Z) * s_len, st).reshape(n, -1, c)
+    m = rt(F.layer_norm(F.linear(msg, W('merge.weight')), (c,), P[prefix + 'norm1.weight'], P[prefix + 'norm1.bias']), st)
+    hid = rt(torch.relu(F.linear(torch.cat([x, m], dim=2), W('mlp.0.weight'))), st)
+    o = rt(F.layer_norm(F.linear(hid, W('mlp.2.weight')), (c,), P[prefix + 'norm2.weight'], P[prefix + 'norm2.bias']), st)
+    return rt(x + o, st)
+
+
+# --------------------------------------------------------------------------------------
 # a4  LoFTR layer schedule   (loftr_module/transformer.py:82-104)
 # --------------------------------------------------------------------------------------
 

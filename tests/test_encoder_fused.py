@@ -1,0 +1,141 @@
+"""The fused encoder-layer kernels (csrc/k6_encoder_fused.hip, geoformer_amd/fused.py).
+
+CPU: the two weight-fragment orders of fused.fragments against their definition.
+GPU: gf_encoder_kv_state / gf_encoder_layer against the oracle's 'fused' storage mode (the reference's arithmetic
+with a round trip through fp16 at the kernels' rounding points) on the same inputs: kv state to 1e-3, layer outputs
+equal to two fp16 ulp (see _ulp_close)."""
+import numpy as np
+import pytest
+import torch
+
+import geoformer_oracle as O
+
+DEV = 'cuda:0'
+PFX = 'loftr_coarse.layers.2.'
+GPFX = 'geo_module.des_transformer.layers.1.'
+
+
+def test_fragment_orders():
+    from geoformer_amd.fused import fragments, pack_kv_stream, pack_layer_stream
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(64, 96, generator=g)
+    fs, fp = fragments(w, 'std'), fragments(w, 'perm')
+    assert fs.shape == (2, 6, 64, 8) and fp.shape == (2, 6, 64, 8)
+    for nb in range(2):
+        for ks in range(6):
+            for lane in (0, 5, 31, 32, 47, 63):
+                for j in range(8):
+                    r, h = lane & 31, lane >> 5
+                    assert fs[nb, ks, lane, j] == w[32 * nb + r, 16 * ks + 8 * h + j]
+                    t, s = ks >> 1, ks & 1
+                    assert fp[nb, ks, lane, j] == w[32 * nb + r, 32 * t + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)]
+    c = 256
+    wq, wm, w1, w2 = (torch.randn(c, c, generator=g), torch.randn(c, c, generator=g), torch.randn(2 * c, 2 * c, generator=g),
+                      torch.randn(c, 2 * c, generator=g))
+    assert pack_layer_stream(wq, wm, w1, w2).numel() == 32 * 32 * 64 * 8          # 32 blocks of 32 fragments: 1 MiB in fp16
+    assert pack_layer_stream(None, wm, w1, w2).numel() == 28 * 32 * 64 * 8
+    assert pack_kv_stream(wq, wm).numel() == 8 * 32 * 64 * 8
+    # every weight element appears exactly once in the stream
+    s = pack_layer_stream(wq, wm, w1, w2)
+    assert torch.equal(torch.sort(s)[0], torch.sort(torch.cat([wq.flatten(), wm.flatten(), w1.flatten(), w2.flatten()]))[0])
+
+
+def _layer(prefix, attention, activation, nhead):
+    from geoformer_amd.model.modules import LoFTREncoderLayer
+    W = O.make_weights()
+    m = LoFTREncoderLayer(256, nhead, attention, activation)
+    m.load_state_dict({k[len(prefix):]: v for k, v in W.items() if k.startswith(prefix)})
+    return m.to(DEV), W
+
+
+def _ulp_close(got, want, what):
+    """fp16 outputs of a chain of five rounded GEMM stages: the two sides sum in different orders, so a value that sits
+    within ~1e-7 of a rounding boundary lands on the other fp16 neighbour, and every such flip perturbs the whole
+    next layer by a fraction of an ulp - exact equality is not attainable; agreement is to 2 ulp, with a mean
+    difference far below one ulp."""
+    got, want = got.float().cpu(), want.float()
+    torch.testing.assert_close(got, want, rtol=4e-3, atol=4e-3, msg=lambda m: f'{what}: {m}')
+    assert float((got - want).abs().mean()) < 3e-4, what
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('masked', [False, True])
+def test_kv_state_vs_oracle(masked):
+    from geoformer_amd import fused
+    layer, W = _layer(PFX, 'linear', 'relu', 8)
+    g = torch.Generator().manual_seed(5)
+    N, S = 2, 300                                           # 3 tiles per image, the last one ragged
+    src = O.rt(torch.randn(N, S, 256, generator=g) * 0.8, torch.float16)
+    km = None
+    if masked:
+        km = torch.ones(N, S, dtype=torch.bool); km[0, 250:] = False; km[1, 10:40] = False
+    st = torch.float16
+    k = torch.nn.functional.linear(src, O.rt(W[PFX + 'k_proj.weight'], st)).view(N, S, 8, 32)
+    v = torch.nn.functional.linear(src, O.rt(W[PFX + 'v_proj.weight'], st)).view(N, S, 8, 32)
+    Kf = O._phi(k)
+    if masked:
+        Kf = Kf * km[:, :, None, None]
+    K, V = O.rt(Kf, st), O.rt(v, st)
+    KV = torch.einsum('nshd,nshv->nhdv', K, V).reshape(N, 256, 32)          # [c = h*32 + d][v]
+    ref = torch.cat([KV.reshape(N, -1), Kf.sum(1).reshape(N, 256)], 1)
+    w = layer.weights(torch.float16)
+    got = fused.encoder_kv_state(src.to(DEV).half(), w['stream_kv'], None if km is None else km.to(DEV)).cpu()
+    torch.testing.assert_close(got, ref, rtol=1e-3, atol=1e-3 * float(ref.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('L,S,masked', [(256, 256, False), (300, 200, False), (200, 300, True)])
+def test_linear_attention_layer_vs_oracle(L, S, masked):
+    layer, W = _layer(PFX, 'linear', 'relu', 8)
+    g = torch.Generator().manual_seed(7)
+    N, st = 2, torch.float16
+    x = O.rt(torch.randn(N, L, 256, generator=g) * 0.7, st)
+    src = O.rt(torch.randn(N, S, 256, generator=g) * 0.7, st)
+    xm = sm = None
+    if masked:
+        xm = torch.ones(N, L, dtype=torch.bool); xm[1, 150:] = False
+        sm = torch.ones(N, S, dtype=torch.bool); sm[0, 280:] = False; sm[1, :17] = False
+    ref = O.encoder_layer_fused(W, PFX, x, src, 8, st, xm, sm)
+    with torch.no_grad():
+        got = layer(x.to(DEV).half(), src.to(DEV).half(), None if xm is None else xm.to(DEV), None if sm is None else sm.to(DEV))
+    assert got.dtype == torch.float16
+    _ulp_close(got, ref, f'layer L={L} S={S}')
+
+
+@pytest.mark.gpu
+def test_finish_vs_oracle_tanh_and_skip_flags():
+    """The Geo form: attention output given, Tanh MLP, per-sample 'layer skipped' predicate."""
+    layer, W = _layer(GPFX, 'full', 'tanh', 4)
+    g = torch.Generator().manual_seed(9)
+    N, L, st = 3, 200, torch.float16
+    x = O.rt(torch.randn(N, L, 256, generator=g) * 0.7, st)
+    msg = O.rt(torch.randn(N, L, 256, generator=g) * 0.5, st)
+    flag = torch.tensor([1, 0, 5], dtype=torch.int32)
+    ref = O._finish_fused(W, GPFX, x, msg, 'geo', st)
+    ref[1] = x[1]
+    with torch.no_grad():
+        got = layer.finish(x.to(DEV).half(), msg.to(DEV).half(), flag.to(DEV), L)
+    _ulp_close(got, ref, 'finish tanh')
+    assert torch.equal(got[1].cpu(), x[1].half())           # a skipped sample is copied bit for bit
+
+
+@pytest.mark.gpu
+def test_full_size_layer_against_unfused_chain():
+    """L = S = 6400 (the 640x640 grid), 4 images: the fused layer against the K3 + K2 kernel chain it replaces (both
+    fp16 storage; they round at different points, so agreement is to fp16 resolution, not bitwise)."""
+    from geoformer_amd import ops
+    layer, _ = _layer(PFX, 'linear', 'relu', 8)
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(4, 6400, 256, generator=g) * 0.7).to(DEV).half()
+    src = (torch.randn(4, 6400, 256, generator=g) * 0.7).to(DEV).half()
+    with torch.no_grad():
+        got = layer(x, src)
+        w = layer.weights(torch.float16)
+        q = ops.linear(x, w['q'])
+        kv = ops.linear(src, w['kv'])
+        msg = ops.linear_attention(q, kv[..., :256], kv[..., 256:], 8)
+        msg = ops.linear(msg, w['merge'], epilogue=ops.EPI_LN, ln=w['n1'], eps=layer.norm1.eps)
+        hid = ops.linear(x, w['w1'], a2=msg, epilogue=ops.EPI_RELU)
+        want = ops.linear(hid, w['w2'], epilogue=ops.EPI_LN_RES, ln=w['n2'], eps=layer.norm2.eps, residual=x)
+    torch.testing.assert_close(got.float(), want.float(), rtol=1e-2, atol=1e-2)
+    assert float((got.float() - want.float()).abs().mean()) < 1e-3
