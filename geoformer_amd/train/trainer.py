@@ -97,8 +97,8 @@ class TrainStep:
     on materialised fp32 confidence matrices, like the reference.  `True` switches the two coarse losses to the HIP
     kernels `gf_coarse_loss_forward/backward`, which compute in fp16 operands / fp32 accumulation: loss value and `p`
     agree with fp32 autograd on the SAME (fp16-rounded) features to 2e-3, the feature gradients to 2e-2 in norm
-    (tests/test_train_gpu.py); against un-rounded fp32 features the loss agrees to 5e-3 and the gradients to 5e-2 in
-    norm, also for confident matches (p > 0.95), where the gradient itself is small."""
+    (tests/test_train_gpu.py); against un-rounded fp32 features the loss agrees to 2e-3 and the gradients to 1e-2 in
+    norm (measured 3e-4 / 2e-3), also for confident matches (p > 0.95), where the gradient itself is small."""
 
     def __init__(self, model, trainer_cfg=None, loss_cfg=None, batch_size=1, distributed=False, device_ids=None,
                  homography_fn: Optional[Callable] = None, sparse_spvs=True, fused_coarse_loss=False):

@@ -5,7 +5,8 @@ and bench.py's `cpu_baseline` leg may import this module; the product package
 (geoformer_amd/) never does and fails loudly without its HIP library.
 
 What it is: a plain-PyTorch fp32 restatement (CPU) of the reference's forward
-pass, written from the behaviour of the files cited per function (paths are
+pass (plus, further down, the same arithmetic with the product's 16-bit storage
+round trips: geoformer_forward_storage), written from the behaviour of the files cited per function (paths are
 relative to the reference checkout).  It is functional: weights come in as a
 flat dict keyed by the reference's state-dict names.
 
@@ -602,6 +603,190 @@ def geoformer_forward(P, data, loftr_cfg=None, geo_cfg=None, homography_fn: Call
                                            loftr_cfg['fine']['nhead'], u0, u1)
     if record is not None:
         record.update(fine_f0=u0, fine_f1=u1)
+    data.update(fine_match(u0, u1, data, geo_cfg['fine_temperature'], geo_cfg['fine_thr']))
+    return data
+
+
+# --------------------------------------------------------------------------------------
+# a16 in 16-bit STORAGE MODE: the same forward with the round trips of the product's fast modes (fp16 / bf16
+# storage, fp32 accumulation) at the points where its kernels round.  Used by the end-to-end parity tests of those
+# modes: coarse indices are then compared bit for bit, not by overlap with the fp32 run.
+#   position encoding      out = rt(x + pe)                                       (k_pos_encode.hip)
+#   coarse LoFTR layers    encoder_layer_fused                                    (k6_encoder_fused.hip)
+#   dual softmax           fp32 arithmetic on the rounded features                (k1_dual_softmax.hip)
+#   Geo layers             q, k, v = rt(W x) (K3); self: flash attention over 32-key tiles with the probabilities
+#                          rounded for the P.V product (k4_attention.hip); cross: fp32 softmax over the 25 window keys
+#                          (k_geo.hip); message rounded; rest = _finish_fused
+#   fine level             FinePreprocess linears rounded per kernel (K3), loftr_fine = encoder_layer_chain,
+#                          FineMatching2 in fp32 on the rounded features (k_fine.hip)
+# --------------------------------------------------------------------------------------
+
+
+def _flash_self_attention(q, k, v, st, tile: int = 32):
+    """q [L,H,D], k, v [K,H,D] (rounded) -> [L,H,D]: online softmax over key tiles exactly as attn_self runs it - running
+    maximum per query, probabilities exp(s - m_running) rounded to the storage type for the P.V product while their
+    sum stays fp32, rescale by exp(m_old - m_new) per tile, one division at the end."""
+    L, H, D = q.shape
+    K = k.shape[0]
+    temp = 1.0 / D ** .5
+    m = torch.full((L, H), float('-inf'))
+    l = torch.zeros(L, H)
+    o = torch.zeros(L, H, D)
+    for t0 in range(0, K, tile):
+        kt, vt = k[t0:t0 + tile], v[t0:t0 + tile]
+        x = torch.einsum('lhd,shd->lhs', q, kt) * temp
+        mnew = torch.maximum(m, x.max(dim=2)[0])
+        alpha = torch.exp(m - mnew)
+        p = torch.exp(x - mnew[..., None])
+        l = l * alpha + p.sum(dim=2)
+        o = o * alpha[..., None] + torch.einsum('lhs,shd->lhd', rt(p, st), vt)
+        m = mnew
+    return rt(o / l[..., None], st)
+
+
+def _geo_layer_storage(P, prefix, x, source, nhead, st, kv_mask=None, flash=False):
+    """Geo encoder layer: x [n,L,C], source [n,S,C] (rounded)."""
+    n, _, c = x.shape
+    d = c // nhead
+    W = lambda name: rt(P[prefix + name], st)                                    # noqa: E731
+    q = rt(F.linear(x, W('q_proj.weight')), st).view(n, -1, nhead, d)
+    k = rt(F.linear(source, W('k_proj.weight')), st).view(n, -1, nhead, d)
+    v = rt(F.linear(source, W('v_proj.weight')), st).view(n, -1, nhead, d)
+    if flash:
+        msg = torch.stack([_flash_self_attention(q[i], k[i], v[i], st) for i in range(n)])
+    else:
+        msg = rt(full_attention(q, k, v, None, kv_mask), st)
+    return _finish_fused(P, prefix, x, msg.reshape(n, -1, c), 'geo', st)
+
+
+def geo_module_storage(P, f0, f1, hw0, hw1, data, geo_cfg, homography_fn: Callable, st):
+    """geo_module above with f0/f1 = the rounded position-encoded maps [N,L,C] / [N,S,C]."""
+    n, _, c = f0.shape
+    (hh0, ww0), (hh1, ww1) = hw0, hw1
+    H0, W0 = data['image0'].shape[2:]
+    H1, W1 = data['image1'].shape[2:]
+    scale = int(data['hw0_i'][0] // data['hw0_c'][0])
+    wsz = geo_cfg['window_size']
+    per_sample_scale = 'scale0' in data
+    win0, win1, msk0, msk1 = [], [], [], []
+    map0 = torch.zeros(n, hh0 * ww0, dtype=torch.bool)
+    map1 = torch.zeros(n, hh1 * ww1, dtype=torch.bool)
+    for b in range(n):
+        sel = data['m_bids'] == b
+        kp0, kp1 = data['mkpts0_c'][sel].long(), data['mkpts1_c'][sel].long()
+        if per_sample_scale:
+            kp0 = (kp0 / (scale * data['scale0'][b]) * scale).long()
+            kp1 = (kp1 / (scale * data['scale1'][b]) * scale).long()
+        M = None
+        if len(kp0) > 8:
+            M, inl = homography_fn(kp0.numpy(), kp1.numpy())
+        if M is not None:
+            keep = torch.from_numpy(inl[:, 0] == 1)
+            kp0, kp1 = kp0[keep], kp1[keep]
+            Md = torch.from_numpy(M)
+            s0 = scale * data['scale0'][b] if per_sample_scale else scale
+            s1 = scale * data['scale1'][b] if per_sample_scale else scale
+            p1 = warp_points(map_keypoints(H0, W0, scale), Md.to(torch.float32))
+            k1w, m1w = make_windows(p1, (H1, W1), wsz, s1)
+            p0 = warp_points(map_keypoints(H1, W1, scale), torch.inverse(Md[None])[0].to(torch.float32))
+            k0w, m0w = make_windows(p0, (H0, W0), wsz, s0)
+            win0.append(k0w); win1.append(k1w); msk0.append(m0w); msk1.append(m1w)
+        else:
+            win0.append(None); win1.append(None); msk0.append(None); msk1.append(None)
+        map0[b, (kp0[:, 1] // scale) * ww0 + kp0[:, 0] // scale] = True
+        map1[b, (kp1[:, 1] // scale) * ww1 + kp1[:, 0] // scale] = True
+    nhead = geo_cfg['nhead']
+    f0, f1 = f0.clone(), f1.clone()
+    for idx, name in enumerate(geo_cfg['layer_names']):
+        lp = f'geo_module.des_transformer.layers.{idx}.'
+        if name == 'self':
+            for b in range(n):
+                if map0[b].any():
+                    f0[b] = _geo_layer_storage(P, lp, f0[b][None], f0[b][map0[b]][None], nhead, st, flash=True)[0]
+                if map1[b].any():
+                    f1[b] = _geo_layer_storage(P, lp, f1[b][None], f1[b][map1[b]][None], nhead, st, flash=True)[0]
+        else:
+            g0 = [None if win0[b] is None else sample_windows(win0[b], f0[b].T.reshape(c, hh0, ww0), scale) for b in range(n)]
+            g1 = [None if win1[b] is None else sample_windows(win1[b], f1[b].T.reshape(c, hh1, ww1), scale) for b in range(n)]
+            for b in range(n):
+                if g1[b] is None:
+                    continue
+                f0[b] = _geo_layer_storage(P, lp, f0[b][:, None], g1[b], nhead, st, kv_mask=msk1[b])[:, 0]
+                f1[b] = _geo_layer_storage(P, lp, f1[b][:, None], g0[b], nhead, st, kv_mask=msk0[b])[:, 0]
+    return f0, f1
+
+
+def fine_preprocess_storage(P, feat_f0, feat_f1, feat_c0, feat_c1, data, st, W: int = 5):
+    """fine_preprocess above as the product evaluates it: merge_feat(cat([win, down_proj(c)])) = W_win win + ctx with
+    ctx = W_ctx down_proj(c) + b computed once per match; every linear's output is rounded."""
+    stride = int(data['hw0_f'][0] // data['hw0_c'][0])
+    b, i, j = data['b_ids'], data['i_ids'], data['j_ids']
+    cf = feat_f0.shape[1]
+    if b.shape[0] == 0:
+        return torch.empty(0, W * W, cf), torch.empty(0, W * W, cf)
+    win = torch.cat([fine_windows(feat_f0, b, i, int(data['hw0_c'][1]), stride, W),
+                     fine_windows(feat_f1, b, j, int(data['hw1_c'][1]), stride, W)], 0)
+    ccat = torch.cat([feat_c0[b, i], feat_c1[b, j]], 0)
+    mw = rt(P['fine_preprocess.merge_feat.weight'], st)
+    down = rt(F.linear(ccat, rt(P['fine_preprocess.down_proj.weight'], st), P['fine_preprocess.down_proj.bias']), st)
+    ctx = rt(F.linear(down, mw[:, cf:], P['fine_preprocess.merge_feat.bias']), st)
+    both = rt(F.linear(win, mw[:, :cf]) + ctx[:, None], st)
+    return torch.chunk(both, 2, dim=0)
+
+
+def geoformer_forward_storage(P, data, st, loftr_cfg=None, geo_cfg=None, homography_fn: Callable = None, feats=None,
+                              record: Optional[dict] = None):
+    """geoformer_forward in the 16-bit storage mode `st` (torch.float16 / torch.bfloat16), from backbone features
+    `feats` = ((c0, f0), (c1, f1)) - the backbone (MIOpen) is outside the HIP path, its outputs are the inputs here."""
+    loftr_cfg = loftr_cfg or default_loftr_config()
+    geo_cfg = geo_cfg or default_geo_config()
+    thr, temp = geo_cfg['coarse_thr'], loftr_cfg['match_coarse']['dsmax_temperature']
+    img0, img1 = data['image0'], data['image1']
+    data.update(bs=torch.tensor(img0.size(0)), hw0_i=torch.tensor(img0.shape[2:]), hw1_i=torch.tensor(img1.shape[2:]))
+    (c0, ff0), (c1, ff1) = [(rt(c, st), rt(f, st)) for c, f in feats]
+    data.update(hw0_c=torch.tensor(c0.shape[2:]), hw1_c=torch.tensor(c1.shape[2:]),
+                hw0_f=torch.tensor(ff0.shape[2:]), hw1_f=torch.tensor(ff1.shape[2:]))
+    tbf = loftr_cfg['coarse']['temp_bug_fix']
+    pe0 = rt(add_position_encoding(c0, tbf), st).flatten(2).transpose(1, 2).contiguous()
+    pe1 = rt(add_position_encoding(c1, tbf), st).flatten(2).transpose(1, 2).contiguous()
+    m0 = m1 = None
+    if 'mask0' in data:
+        m0, m1 = data['mask0'].flatten(-2), data['mask1'].flatten(-2)
+    f0, f1 = pe0, pe1
+    for idx, name in enumerate(loftr_cfg['coarse']['layer_names']):
+        lp = f'loftr_coarse.layers.{idx}.'
+        nh = loftr_cfg['coarse']['nhead']
+        if name == 'self':
+            f0 = encoder_layer_fused(P, lp, f0, f0, nh, st, m0, m0)
+            f1 = encoder_layer_fused(P, lp, f1, f1, nh, st, m1, m1)
+        else:
+            f0 = encoder_layer_fused(P, lp, f0, f1, nh, st, m0, m1)
+            f1 = encoder_layer_fused(P, lp, f1, f0, nh, st, m1, m0)
+    conf = dual_softmax(f0, f1, temp, m0, m1)
+    data['conf_matrix'] = conf
+    data.update(coarse_match(conf, data, thr))
+    data['dect_conf_matrix'] = data['conf_matrix']
+    if tbf:
+        raise NotImplementedError('storage mode assumes the GeoModule shares the position-encoded maps (temp_bug_fix False)')
+    g0, g1 = geo_module_storage(P, pe0, pe1, tuple(c0.shape[2:]), tuple(c1.shape[2:]), data, geo_cfg, homography_fn, st)
+    conf = dual_softmax(g0, g1, temp, m0, m1)
+    data['conf_matrix'] = conf
+    data.update(coarse_match(conf, data, thr))
+    W = loftr_cfg['fine_window_size']
+    data['W'] = torch.tensor(W)
+    u0, u1 = fine_preprocess_storage(P, ff0, ff1, g0, g1, data, st, W)
+    if u0.size(0) != 0:
+        nh = loftr_cfg['fine']['nhead']
+        for idx, name in enumerate(loftr_cfg['fine']['layer_names']):
+            lp = f'loftr_fine.layers.{idx}.'
+            if name == 'self':
+                u0 = encoder_layer_chain(P, lp, u0, u0, nh, st)
+                u1 = encoder_layer_chain(P, lp, u1, u1, nh, st)
+            else:
+                u0 = encoder_layer_chain(P, lp, u0, u1, nh, st)
+                u1 = encoder_layer_chain(P, lp, u1, u0, nh, st)
+    if record is not None:
+        record.update(loftr_f0=f0, loftr_f1=f1, geo_f0=g0, geo_f1=g1, fine_f0=u0, fine_f1=u1)
     data.update(fine_match(u0, u1, data, geo_cfg['fine_temperature'], geo_cfg['fine_thr']))
     return data
 

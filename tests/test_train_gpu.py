@@ -150,3 +150,127 @@ def test_fused_coarse_focal_loss_full_size():
     torch.testing.assert_close(loss.detach() / pi.numel(), ref.detach(), rtol=2e-3, atol=1e-7)
     for got, want in ((h0.grad.float(), a0.grad), (h1.grad.float(), a1.grad)):
         assert float((got - want).norm() / want.norm()) < 2e-2
+
+
+def test_run_loop_under_ddp_on_the_gpu():
+    """`python -m geoformer_amd.train.run --force-ddp`: the training CLI with its model wrapped in DDP + SyncBatchNorm over
+    RCCL (world size 1 on the one GPU of the test box), a fresh child process.  The loop reads batch['loss_scalars'],
+    batch['b_ids'], batch['conf_matrix_gt'] after every step: with DDP handing the forward a COPY of the batch (the
+    `device_ids` behaviour) rank 0 died right here."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
+    env.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29541', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, '-m', 'geoformer_amd.train.run', '--steps', '2', '--batch', '2', '--size', '64', '80',
+                        '--coarse-thr', '0.0', '--force-ddp'], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('step')]
+    assert len(lines) == 2 and 'matches' in lines[1] and 'gt' in lines[1], r.stdout
+
+
+def test_fused_coarse_loss_vs_fp32_autograd_incl_confident_matches():
+    """The opt-in fused HIP coarse loss against autograd on the ORIGINAL fp32 features (not rounded to fp16 first), in two
+    regimes: noisy correspondences (p spread over (0,1)) and confident ones (median p > 0.95, where the sparse and dense
+    gradient terms nearly cancel).  Tolerances = the ones TrainStep's docstring states: loss 2e-3, gradients 1e-2 in norm."""
+    from geoformer_amd import ops
+    torch.manual_seed(23)
+    N, L, S, C, T = 2, 256, 256, 256, 0.1
+    for noise, lo, hi in ((3.0, 0.02, 0.95), (0.12, 0.95, 1.0)):
+        base = torch.randn(N, L, C, device='cuda')
+        perm = torch.stack([torch.randperm(S, device='cuda') for _ in range(N)])
+        f0 = base.clone()
+        f1 = torch.gather(base, 1, perm[..., None].expand(-1, -1, C)) + noise * torch.randn(N, S, C, device='cuda')
+        inv = torch.argsort(perm, dim=1)
+        pb = torch.arange(N, device='cuda').repeat_interleave(L // 2)
+        pi = torch.arange(0, L, 2, device='cuda').repeat(N)
+        pj = inv[pb, pi]
+        a0, a1 = f0.clone().requires_grad_(True), f1.clone().requires_grad_(True)
+        sim = torch.einsum('nlc,nsc->nls', a0 / C ** .5, a1 / C ** .5) / T
+        conf = torch.softmax(sim, 1) * torch.softmax(sim, 2)
+        p = torch.clamp(conf, 1e-6, 1 - 1e-6)[pb, pi, pj]
+        ref = (-0.25 * (1 - p) ** 2.0 * p.log()).sum()
+        ref.backward()
+        h0, h1 = f0.clone().requires_grad_(True), f1.clone().requires_grad_(True)
+        loss, pk = ops.coarse_focal_loss(h0, h1, pb, pi, pj, T, 0.25, 2.0)
+        loss.backward()
+        med = float(pk.median())
+        assert lo < med < hi, (noise, med)
+        rel_loss = abs(float(loss) - float(ref)) / abs(float(ref))
+        rels = [float((g.float() - w).norm() / w.norm()) for g, w in ((h0.grad, a0.grad), (h1.grad, a1.grad))]
+        print(f'noise {noise}: median p {med:.3f}, loss rel {rel_loss:.2e}, grad rel {rels[0]:.2e} {rels[1]:.2e}, |grad| {float(a0.grad.norm()):.3e}')
+        assert rel_loss < 2e-3, (noise, rel_loss)
+        assert max(rels) < 1e-2, (noise, rels)
+
+
+def _megadepth_style_batch(device):
+    """Two textured pairs related by a known pose + depth, zero-padded (masks), with per-image scales: the keys
+    lightning_depth_geoformer.py:87-99 feeds (image*, depth*, T_*, K*, scale*, mask*, dataset_name)."""
+    import golden_inputs as GI
+    N, H, W = 2, 128, 160
+    # image1 = image0 shifted by one coarse cell: decisive mutual-nearest matches, so that the CPU and the GPU leg
+    # (whose fp32 sums differ in the last bits) make the same discrete choices
+    pairs = [GI.textured_pair(H, W, 311 + k) for k in range(N)]
+    b = {'image0': torch.cat([p[0] for p in pairs]), 'image1': torch.cat([p[1] for p in pairs])}
+    scale0 = torch.tensor([[1.0, 1.0], [1.25, 1.5]])
+    scale1 = torch.tensor([[1.5, 1.25], [1.0, 1.0]])
+    Hd, Wd = 2 * H, 2 * W                                            # depth maps at the ORIGINAL resolution (scale <= 2)
+    ys, xs = torch.meshgrid(torch.arange(Hd, dtype=torch.float32), torch.arange(Wd, dtype=torch.float32), indexing='ij')
+    depth0 = (6.0 + 0.004 * xs + 0.006 * ys)[None].repeat(N, 1, 1)
+    depth1 = (6.1 + 0.004 * xs + 0.006 * ys)[None].repeat(N, 1, 1)
+    K = torch.tensor([[[180., 0., 100.], [0., 180., 80.], [0., 0., 1.]]]).repeat(N, 1, 1)
+    T = torch.eye(4)[None].repeat(N, 1, 1)
+    T[:, :3, 3] = torch.tensor([[-0.27, -0.27, 0.0], [-0.2, 0.1, -0.05]])     # sample 0: ~ the 8 px shift at depth 6, f = 180
+    mask0 = torch.ones(N, H // 8, W // 8, dtype=torch.bool); mask0[0, 13:] = False
+    mask1 = torch.ones(N, H // 8, W // 8, dtype=torch.bool); mask1[1, :, 17:] = False
+    out = {'image0': b['image0'], 'image1': b['image1'], 'depth0': depth0, 'depth1': depth1, 'T_0to1': T, 'T_1to0': torch.inverse(T),
+           'K0': K, 'K1': K.clone(), 'scale0': scale0, 'scale1': scale1, 'mask0': mask0, 'mask1': mask1}
+    out = {k: v.to(device) for k, v in out.items()}
+    out.update(dataset_name=['megadepth'] * N, pair_names=['a', 'b'])
+    return out
+
+
+def test_megadepth_style_train_step_matches_cpu_step():
+    """BASELINE configs[3] step at N = 2 (depth + pose supervision incl. the per-sample fine labels, padding masks,
+    per-image scales in the GeoModule - SURVEY App. A.8): the GPU step (device RANSAC) against the same step on the CPU
+    (C statement of the RANSAC), same weights: supervision identical, matches equal up to a few boundary cases, loss terms
+    within 2e-3."""
+    import ransac_oracle as RO
+    from geoformer_amd.model.cvpr_ds_config import get_default_cfg
+    from geoformer_amd.model.full_model import GeoFormer
+    from geoformer_amd.model.geo_config import get_cfg_model
+    from geoformer_amd.train import GeoLoss, forward_train, spvs_coarse, spvs_fine2
+
+    def hfn(b, kp0, kp1):
+        M, mask = RO.find_homography(kp0.cpu().numpy().astype(np.float64), kp1.cpu().numpy().astype(np.float64))
+        return (None, None) if M is None else (torch.from_numpy(M), torch.from_numpy(mask[:, 0] == 1))
+    res = {}
+    for dev in ('cpu', 'cuda'):
+        g = get_cfg_model()
+        g.update(coarse_thr=0.0, fine_thr=0.0, precision='fp32')
+        model = GeoFormer(get_default_cfg(), g)
+        sd = model.state_dict(); O.closed_form_fill(sd); model.load_state_dict(sd)
+        model.to(dev).train()
+        batch = _megadepth_style_batch(dev)
+        spvs_coarse(batch)
+        forward_train(model, batch, hfn if dev == 'cpu' else None)
+        spvs_fine2(batch)
+        GeoLoss()(batch)
+        batch['loss'].backward()
+        res[dev] = batch
+    c, g = res['cpu'], res['cuda']
+    assert int(c['conf_matrix_gt'].sum()) > 50 and torch.equal(c['conf_matrix_gt'], g['conf_matrix_gt'].cpu())
+    for k in ('spv_b_ids', 'spv_i_ids', 'spv_j_ids'):
+        assert torch.equal(c[k], g[k].cpu()), k
+    a = set(zip(c['b_ids'].tolist(), c['i_ids'].tolist(), c['j_ids'].tolist()))
+    b = set(zip(g['b_ids'].tolist(), g['i_ids'].tolist(), g['j_ids'].tolist()))
+    assert len(a) > 30 and len(a & b) >= 0.97 * max(len(a), len(b)), (len(a), len(b), len(a & b))
+    print(f'megadepth-style step: {len(a)} / {len(b)} matches (cpu / gpu), {len(a & b)} common; '
+          f"loss cpu {float(c['loss_scalars']['loss']):.5f} gpu {float(g['loss_scalars']['loss']):.5f}")
+    assert sorted(set(g['b_ids'].tolist())) == [0, 1]
+    for k in ('loss_c', 'loss_d', 'loss'):
+        assert float(g['loss_scalars'][k]) == pytest.approx(float(c['loss_scalars'][k]), rel=2e-3), k
+    if a == b:
+        assert float(g['loss_scalars']['loss_f']) == pytest.approx(float(c['loss_scalars']['loss_f']), rel=2e-3)
+        assert int(c['conf_matrix_fine_gt'].sum()) == int(g['conf_matrix_fine_gt'].sum())
