@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput bench of the GeoFormer matching path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--precision fp16|fp32]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--precision fp16|bf16|fp32]
 
 Workload (BASELINE.json configs[4], "batched inference, 1024 synthetic 640x640 pairs, fp16 features, 8 GPUs
 embarrassingly-parallel shard"): the pair list (seeds 0 .. N*K*B-1) is cut into contiguous per-rank blocks
@@ -32,7 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
-MFMA_PEAK_TFLOPS = {'fp16': 2500.0, 'fp32': 157.3}     # dense, same table
+MFMA_PEAK_TFLOPS = {'fp16': 2500.0, 'bf16': 2500.0, 'fp32': 157.3}     # dense, same table
 
 # kernel families that carry HIP events in libgeoformer_hip.so (gf_prof_begin tags): what the declared work unit
 # is, which roofline bounds the family, and whether it belongs to the matching path (the north_star's hot path)
@@ -56,7 +56,7 @@ def parse_args(argv=None):
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=8, help='pairs per GPU per step')
     ap.add_argument('--size', type=int, default=640)
-    ap.add_argument('--precision', default='fp16', choices=['fp16', 'fp32'])
+    ap.add_argument('--precision', default='fp16', choices=['fp16', 'bf16', 'fp32'])
     ap.add_argument('--pairs', default='homography', choices=['homography', 'shift'],
                     help="image1 = image0 under a random homography (default), or shifted by one coarse cell (the pair of "
                          "the reference's CPU measurement, BASELINE.md section 2: ~2400 coarse matches per pair)")
@@ -396,7 +396,7 @@ def main(argv=None):
         return (time.perf_counter() - t) / 3 / args.batch * 1e3
     bb_ms = backbone_ms_per_pair()
     log(f'backbone {bb_ms:.2f} ms/pair with the shipped MIOpen picks')
-    if not args.tune and args.precision == 'fp16' and bb_ms > 2.2 * (args.size / 640.0) ** 2:
+    if not args.tune and args.precision != 'fp32' and bb_ms > 2.2 * (args.size / 640.0) ** 2:
         # the shipped find-db did not apply (other batch size / MIOpen build): let MIOpen search once; the result
         # stays in this process's private db copy
         log('slower than the tuned reference (1.7 ms/pair): running the MIOpen search (minutes) ...')
@@ -444,7 +444,7 @@ def main(argv=None):
 
     pairs = args.batch * args.steps * world
     Lc = (args.size // 8) ** 2
-    e = 2 if args.precision == 'fp16' else 4
+    e = 4 if args.precision == 'fp32' else 2
     algo_bytes = args.batch * (2 * Lc * 256 * e + Lc * Lc * 4)     # per k1_conf launch (170.4 MB/pair-call at e=2)
     if solo['k1_conf'][1]:
         assert abs(solo['k1_conf'][2] / solo['k1_conf'][1] - algo_bytes) < 1.0
@@ -483,7 +483,7 @@ def main(argv=None):
         'metric': 'image-pairs/sec (640x640)', 'value': pairs / elapsed, 'unit': 'image-pairs/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f16' if args.precision == 'fp16' else 'f32', 'data': 'synthetic',
+        'dtype': {'fp16': 'f16', 'bf16': 'bf16', 'fp32': 'f32'}[args.precision], 'data': 'synthetic',
         'config': {'workload': f'batched inference, synthetic {args.size}x{args.size} pairs (BASELINE configs[4]: static shard of the '
                                f'pair list, {args.steps * args.batch} pairs per GPU), image1 = {args.pairs} of image0, full forward '
                                f'incl. ResNet-FPN backbone; closed-form random-init weights; coarse_thr={args.coarse_thr} '
@@ -521,12 +521,12 @@ def side_measurements(args, model, dev, log, L):
     p.close()
     nidx = rr[-1][2]
     out['nominal_load'] = {'value': steps * args.batch / el, 'unit': 'image-pairs/s', 'steps': steps, 'ms_per_step': 1e3 * el / steps,
-                           'pairs': 'shift by one coarse cell (BASELINE.md section 2)', 'dtype': 'f16' if args.precision == 'fp16' else 'f32',
+                           'pairs': 'shift by one coarse cell (BASELINE.md section 2)', 'dtype': {'fp16': 'f16', 'bf16': 'bf16', 'fp32': 'f32'}[args.precision],
                            'coarse_matches_per_pair': sum(r[0] for r in rr) / len(rr) / args.batch,
                            'fine_matches_per_pair': sum(r[1] for r in rr) / len(rr) / args.batch,
                            'inlier_cells_per_pair': int(nidx[:, 0].float().mean()) if nidx is not None else None}
     log(f"nominal load: {out['nominal_load']['value']:.1f} pairs/s at M = {out['nominal_load']['coarse_matches_per_pair']:.0f}")
-    if args.precision == 'fp16':
+    if args.precision != 'fp32':
         import torch
         m32, _ = build_model('fp32', args.coarse_thr, args.fine_thr, dev)
         homo = [synth_pairs(args.batch, seed=i * args.batch, size=args.size, device=dev, kind=args.pairs) for i in range(2)]

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgeoformer_hip.so')
 
-GF_F32, GF_F16 = 0, 1
+GF_F32, GF_F16, GF_BF16 = 0, 1, 2
 
 c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 c_long, c_uint32 = ctypes.c_long, ctypes.c_uint32

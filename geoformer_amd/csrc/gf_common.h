@@ -12,6 +12,11 @@ typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef _Float16 v4h __attribute__((ext_vector_type(4)));
 typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef __bf16 gf_bf16;                                                     // bfloat16 storage (GF_BF16)
+typedef gf_bf16 v8b __attribute__((ext_vector_type(8)));
+typedef gf_bf16 v4b __attribute__((ext_vector_type(4)));
+template <typename T, int N>
+using gf_vec = T __attribute__((ext_vector_type(N)));                        // N elements of a storage type
 typedef short gf_v4s __attribute__((__vector_size__(4 * sizeof(short))));   // result of ds_read_b64_tr_b16
 
 // ---------------------------------------------------------------------------------------------
@@ -72,15 +77,23 @@ struct ElemTraits<_Float16> {
     static constexpr int kDtype = GF_F16;
     static constexpr int kPer16B = 8;
 };
+template <>
+struct ElemTraits<gf_bf16> {
+    static constexpr int kDtype = GF_BF16;
+    static constexpr int kPer16B = 8;
+};
 
 __device__ __forceinline__ float gf_to_float(float x) { return x; }
 __device__ __forceinline__ float gf_to_float(_Float16 x) { return (float)x; }
+__device__ __forceinline__ float gf_to_float(gf_bf16 x) { return (float)x; }
 template <typename T>
 __device__ __forceinline__ T gf_from_float(float x);
 template <>
 __device__ __forceinline__ float gf_from_float<float>(float x) { return x; }
 template <>
 __device__ __forceinline__ _Float16 gf_from_float<_Float16>(float x) { return (_Float16)x; }
+template <>
+__device__ __forceinline__ gf_bf16 gf_from_float<gf_bf16>(float x) { return (gf_bf16)x; }       // round to nearest even (v_cvt_pk_bf16_f32)
 
 // ---------------------------------------------------------------------------------------------
 // MFMA 32x32 wrappers.  One "k-group" = the K range covered by one 16-byte fragment per lane:
@@ -109,6 +122,15 @@ struct Mma32<_Float16> {
     static constexpr int kGroup = 16;
     static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, v16f& c) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+template <>
+struct Mma32<gf_bf16> {
+    using Frag = v8b;
+    static constexpr int kGroup = 16;
+    static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, v16f& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
 };
 

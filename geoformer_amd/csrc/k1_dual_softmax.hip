@@ -464,8 +464,9 @@ constexpr int PANEL_LDS = BN * 512 + BM * 8;      // f1 tile [64][512 B] + row s
 
 __device__ __forceinline__ int k1p_off(int row, int chunk) { return row * 512 + ((chunk ^ (row & 15)) << 4); }
 
-template <bool DENSE>
+template <typename H, bool DENSE>
 __global__ __launch_bounds__(NT, 2) void k1_conf_panel(K1Args a) {
+    using V8 = gf_vec<H, 8>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* rst = reinterpret_cast<float2*>(smem + BN * 512);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, lr = lane & 31;
@@ -483,11 +484,11 @@ __global__ __launch_bounds__(NT, 2) void k1_conf_panel(K1Args a) {
         K1_T(0);
         const int run = u % runs, pm = u / runs, bm = pm % a.tilesM, n = pm / a.tilesM;
         const int m0 = bm * BM, t0 = run * PANEL_TILES, t1 = min(t0 + PANEL_TILES, a.tilesN);
-        const _Float16* A = (const _Float16*)a.f0 + ((size_t)n * a.L + m0 + wave * 32 + lr) * a.C + h * 8;
-        const _Float16* B = (const _Float16*)a.f1 + (size_t)n * a.S * a.C;
-        v8h af[16];
+        const H* A = (const H*)a.f0 + ((size_t)n * a.L + m0 + wave * 32 + lr) * a.C + h * 8;
+        const H* B = (const H*)a.f1 + (size_t)n * a.S * a.C;
+        V8 af[16];
 #pragma unroll
-        for (int kg = 0; kg < 16; ++kg) af[kg] = *reinterpret_cast<const v8h*>(A + kg * 16);
+        for (int kg = 0; kg < 16; ++kg) af[kg] = *reinterpret_cast<const V8*>(A + kg * 16);
         __syncthreads();                                      // previous unit's rst readers are done
         if (tid < BM) {
             const float2 st = a.rstat[(size_t)n * a.L + m0 + tid];
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(NT, 2) void k1_conf_panel(K1Args a) {
         v4u rb[8];
         float2 cs[2];
         auto prefetch = [&](int bn) {
-            const _Float16* g = B + (size_t)(bn * BN + srow) * a.C + schunk * 8;
+            const H* g = B + (size_t)(bn * BN + srow) * a.C + schunk * 8;
 #pragma unroll
             for (int p = 0; p < 8; ++p) rb[p] = *reinterpret_cast<const v4u*>(g + (size_t)p * 8 * a.C);
 #pragma unroll
@@ -536,10 +537,10 @@ __global__ __launch_bounds__(NT, 2) void k1_conf_panel(K1Args a) {
                 for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
 #pragma unroll
             for (int kg = 0; kg < 16; ++kg) {
-                const v8h b0 = *reinterpret_cast<const v8h*>(smem + k1p_off(lr, 2 * kg + h));
-                const v8h b1 = *reinterpret_cast<const v8h*>(smem + k1p_off(32 + lr, 2 * kg + h));
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kg], b0, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kg], b1, acc[1], 0, 0, 0);
+                const V8 b0 = *reinterpret_cast<const V8*>(smem + k1p_off(lr, 2 * kg + h));
+                const V8 b1 = *reinterpret_cast<const V8*>(smem + k1p_off(32 + lr, 2 * kg + h));
+                Mma32<H>::mma(af[kg], b0, acc[0]);
+                Mma32<H>::mma(af[kg], b1, acc[1]);
             }
             const int n0 = bn * BN;
 #if K1_TRACE
@@ -613,7 +614,9 @@ __global__ __launch_bounds__(NT, 2) void k1_conf_panel(K1Args a) {
 // (online max / rescaled sum per slot, 3 exponentials per slot and tile) and cross the lanes once per run instead
 // of two 32-lane reduce-scatters per tile.  Column statistics are lane-local per tile as before.
 // ---------------------------------------------------------------------------------------------
+template <typename H>
 __global__ __launch_bounds__(NT, 2) void k1_stats_panel(K1Args a) {
+    using V8 = gf_vec<H, 8>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* colx = reinterpret_cast<float2*>(smem + BN * 512);            // [4 waves][64] column partials of the tile
     float* rowbc = reinterpret_cast<float*>(smem + BN * 512 + 4 * 64 * 8);  // [4 waves][32] row maxima of the run
@@ -628,14 +631,14 @@ __global__ __launch_bounds__(NT, 2) void k1_stats_panel(K1Args a) {
         const int u = ubeg + ui;
         const int run = u % runs, pm = u / runs, bm = pm % a.tilesM, n = pm / a.tilesM;
         const int m0 = bm * BM, t0 = run * PANEL_TILES, t1 = min(t0 + PANEL_TILES, a.tilesN);
-        const _Float16* A = (const _Float16*)a.f0 + ((size_t)n * a.L + m0 + wave * 32 + lr) * a.C + h * 8;
-        const _Float16* B = (const _Float16*)a.f1 + (size_t)n * a.S * a.C;
-        v8h af[16];
+        const H* A = (const H*)a.f0 + ((size_t)n * a.L + m0 + wave * 32 + lr) * a.C + h * 8;
+        const H* B = (const H*)a.f1 + (size_t)n * a.S * a.C;
+        V8 af[16];
 #pragma unroll
-        for (int kg = 0; kg < 16; ++kg) af[kg] = *reinterpret_cast<const v8h*>(A + kg * 16);
+        for (int kg = 0; kg < 16; ++kg) af[kg] = *reinterpret_cast<const V8*>(A + kg * 16);
         v4u rb[8];
         auto prefetch = [&](int bn) {
-            const _Float16* g = B + (size_t)(bn * BN + srow) * a.C + schunk * 8;
+            const H* g = B + (size_t)(bn * BN + srow) * a.C + schunk * 8;
 #pragma unroll
             for (int p = 0; p < 8; ++p) rb[p] = *reinterpret_cast<const v4u*>(g + (size_t)p * 8 * a.C);
         };
@@ -656,10 +659,10 @@ __global__ __launch_bounds__(NT, 2) void k1_stats_panel(K1Args a) {
                 for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
 #pragma unroll
             for (int kg = 0; kg < 16; ++kg) {
-                const v8h b0 = *reinterpret_cast<const v8h*>(smem + k1p_off(lr, 2 * kg + h));
-                const v8h b1 = *reinterpret_cast<const v8h*>(smem + k1p_off(32 + lr, 2 * kg + h));
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kg], b0, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kg], b1, acc[1], 0, 0, 0);
+                const V8 b0 = *reinterpret_cast<const V8*>(smem + k1p_off(lr, 2 * kg + h));
+                const V8 b1 = *reinterpret_cast<const V8*>(smem + k1p_off(32 + lr, 2 * kg + h));
+                Mma32<H>::mma(af[kg], b0, acc[0]);
+                Mma32<H>::mma(af[kg], b1, acc[1]);
             }
             // ---- columns (lane = column): max and sum over this wave's 32 rows
 #pragma unroll
@@ -885,15 +888,25 @@ int k1_launch(K1Args a, SelArgs s, void* zero_begin, size_t zero_bytes, hipStrea
     const int units = a.N * a.tilesM * runs, wgs = units < 512 ? units : 512;    // two resident workgroups per CU
     a.rowparts = panel ? runs : a.tilesN;
     void* p0 = gf_prof_begin("k1_stats", st, 2.0 * a.N * (double)a.L * a.S * a.C);
-    if (panel) k1_stats_panel<<<wgs, NT, PANEL_LDS + 2048, st>>>(a);
-    else k1_stats<T><<<grid, NT, STAGE_BYTES, st>>>(a);
+    if constexpr (!EXACT) {
+        if (panel) k1_stats_panel<T><<<wgs, NT, PANEL_LDS + 2048, st>>>(a);
+        else k1_stats<T><<<grid, NT, STAGE_BYTES, st>>>(a);
+    } else {
+        k1_stats<T><<<grid, NT, STAGE_BYTES, st>>>(a);
+    }
     gf_prof_end("k1_stats", p0, st);
     const int mx = a.L > a.S ? a.L : a.S;
     k1_reduce_stats<EXACT><<<dim3((mx + 31) / 32, 2, a.N), 256, 0, st>>>(a);
     void* p1 = gf_prof_begin("k1_conf", st, (double)a.N * ((double)(a.L + a.S) * a.C * sizeof(T) + (double)a.L * a.S * 4.0));
-    if (panel) {
-        if (a.dense) k1_conf_panel<true><<<wgs, NT, PANEL_LDS, st>>>(a);
-        else k1_conf_panel<false><<<wgs, NT, PANEL_LDS, st>>>(a);
+    bool done = false;
+    if constexpr (!EXACT) {
+        if (panel) {
+            if (a.dense) k1_conf_panel<T, true><<<wgs, NT, PANEL_LDS, st>>>(a);
+            else k1_conf_panel<T, false><<<wgs, NT, PANEL_LDS, st>>>(a);
+            done = true;
+        }
+    }
+    if (done) {
     } else if (a.dense) k1_conf<T, true><<<grid, NT, STAGE_BYTES, st>>>(a);
     else k1_conf<T, false><<<grid, NT, STAGE_BYTES, st>>>(a);
     gf_prof_end("k1_conf", p1, st);
@@ -1196,7 +1209,7 @@ extern "C" int gf_dual_softmax_match(const void* f0, const void* f1, int dtype, 
                                      int32_t* counts, void* workspace, size_t workspace_bytes, void* stream) {
     GF_CHECK_ARG(f0 && f1 && conf && b_ids && i_ids && j_ids && mconf && mkpts0_c && mkpts1_c && counts, "null pointer");
     GF_CHECK_ARG(N > 0 && L > 0 && S > 0, "empty problem");
-    GF_CHECK_ARG(dtype == GF_F32 || dtype == GF_F16, "dtype must be GF_F32 or GF_F16");
+    GF_CHECK_ARG(dtype >= GF_F32 && dtype <= GF_BF16, "bad dtype");
     GF_CHECK_ARG(C > 0 && C % (dtype == GF_F32 ? 32 : 64) == 0, "C must be a multiple of 32 (f32) / 64 (f16)");
     GF_CHECK_ARG((mask0 == nullptr) == (mask1 == nullptr), "mask0/mask1 must both be set or both be NULL");
     GF_CHECK_ARG(temperature > 0.f && w0c > 0 && w1c > 0, "bad temperature / grid width");
@@ -1225,7 +1238,8 @@ extern "C" int gf_dual_softmax_match(const void* f0, const void* f1, int dtype, 
     s.counts = counts;
     hipStream_t st = (hipStream_t)stream;
     return dtype == GF_F32 ? k1_launch<float>(a, s, w.rowbest, w.zero_bytes, st)
-                           : k1_launch<_Float16>(a, s, w.rowbest, w.zero_bytes, st);
+                           : dtype == GF_F16 ? k1_launch<_Float16>(a, s, w.rowbest, w.zero_bytes, st)
+                                             : k1_launch<gf_bf16>(a, s, w.rowbest, w.zero_bytes, st);
 }
 
 extern "C" size_t gf_coarse_loss_workspace_bytes(int N, int L, int S) {
@@ -1275,7 +1289,7 @@ extern "C" int gf_coarse_loss_forward(const void* f0, const void* f1, int dtype,
     if (mask0 == nullptr) {                                   // panel form (needs no masks)
         const int runs = (a.tilesN + PANEL_TILES - 1) / PANEL_TILES, units = N * a.tilesM * runs;
         a.rowparts = runs;
-        k1_stats_panel<<<units < 512 ? units : 512, NT, PANEL_LDS + 2048, st>>>(a);
+        k1_stats_panel<_Float16><<<units < 512 ? units : 512, NT, PANEL_LDS + 2048, st>>>(a);
     } else {
         a.rowparts = a.tilesN;
         k1_stats<_Float16><<<dim3(a.tilesN * a.tilesM, N), NT, STAGE_BYTES, st>>>(a);

@@ -181,7 +181,8 @@ constexpr int LT = 32;     // tokens per sub-tile
 constexpr int TRS = 576;
 
 // operand fragment of one head for the 16-token k-step s2: lane (lr = channel, h2) gets tokens 16*s2 + 8*h2 + 0..7
-__device__ __forceinline__ v8h la16_tr_frag(const char* img, int head_ch0, int s2, int lane) {
+template <typename H>
+__device__ __forceinline__ gf_vec<H, 8> la16_tr_frag(const char* img, int head_ch0, int s2, int lane) {
     const int G = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
     const int tok0 = 16 * s2 + 8 * (G >> 1);
     const char* base = img + (tok0 + q) * TRS + (head_ch0 + 16 * (G & 1) + 4 * p) * 2;
@@ -190,27 +191,28 @@ __device__ __forceinline__ v8h la16_tr_frag(const char* img, int head_ch0, int s
     const gf_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LP)(base + 4 * TRS));
     typedef short v8s __attribute__((__vector_size__(8 * sizeof(short))));
     const v8s both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(v8h, both);
+    return __builtin_bit_cast(gf_vec<H, 8>, both);
 }
 
-template <int D>
+template <typename H, int D>
 __global__ __launch_bounds__(256) void la16_kv(LaArgs a) {
+    using V8 = gf_vec<H, 8>;
     static_assert(D == 32, "coarse configuration");
     __shared__ __attribute__((aligned(16))) char kt[LT * TRS];
     __shared__ __attribute__((aligned(16))) char vt[LT * TRS];
     const int chunk = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h2 = lane >> 5, lr = lane & 31, C = a.C;
     const int s_begin = chunk * CHUNK, s_end = min(a.S, s_begin + CHUNK);
-    const _Float16* kp = (const _Float16*)a.k + (size_t)n * a.S * a.ldk;
-    const _Float16* vp = (const _Float16*)a.v + (size_t)n * a.S * a.ldv;
+    const H* kp = (const H*)a.k + (size_t)n * a.S * a.ldk;
+    const H* vp = (const H*)a.v + (size_t)n * a.S * a.ldv;
     v16f acc[2], ksum[2];                        // this wave's two heads: 2*wave, 2*wave+1
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; ksum[i][r] = 0.f; }
-    const v8h ones{(_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1};
-    const v8h zero{0, 0, 0, 0, 0, 0, 0, 0};
-    v8h rk[4], rv[4];                            // the next sub-tile, in flight while this one is multiplied
+    const V8 ones{(H)1, (H)1, (H)1, (H)1, (H)1, (H)1, (H)1, (H)1};
+    const V8 zero{(H)0, (H)0, (H)0, (H)0, (H)0, (H)0, (H)0, (H)0};
+    V8 rk[4], rv[4];                            // the next sub-tile, in flight while this one is multiplied
     auto fetch = [&](int s0) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -219,8 +221,8 @@ __global__ __launch_bounds__(256) void la16_kv(LaArgs a) {
             rk[p] = zero;
             rv[p] = zero;
             if (s < s_end && (a.kv_mask == nullptr || a.kv_mask[(size_t)n * a.S + s] != 0)) {
-                rk[p] = *reinterpret_cast<const v8h*>(kp + (size_t)s * a.ldk + c8);
-                rv[p] = *reinterpret_cast<const v8h*>(vp + (size_t)s * a.ldv + c8);
+                rk[p] = *reinterpret_cast<const V8*>(kp + (size_t)s * a.ldk + c8);
+                rv[p] = *reinterpret_cast<const V8*>(vp + (size_t)s * a.ldv + c8);
             }
         }
     };
@@ -230,11 +232,11 @@ __global__ __launch_bounds__(256) void la16_kv(LaArgs a) {
         for (int p = 0; p < 4; ++p) {
             const int e = p * 256 + tid, tok = e >> 5, c8 = (e & 31) * 8;
             const bool ok = s0 + tok < s_end && (a.kv_mask == nullptr || a.kv_mask[(size_t)n * a.S + s0 + tok] != 0);
-            v8h kk = rk[p];
+            V8 kk = rk[p];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) kk[i] = ok ? (_Float16)elu1_fast((float)kk[i]) : (_Float16)0;
-            *reinterpret_cast<v8h*>(kt + tok * TRS + c8 * 2) = kk;
-            *reinterpret_cast<v8h*>(vt + tok * TRS + c8 * 2) = rv[p];
+            for (int i = 0; i < 8; ++i) kk[i] = ok ? (H)elu1_fast((float)kk[i]) : (H)0;
+            *reinterpret_cast<V8*>(kt + tok * TRS + c8 * 2) = kk;
+            *reinterpret_cast<V8*>(vt + tok * TRS + c8 * 2) = rv[p];
         }
         __syncthreads();
         if (s0 + LT < s_end) fetch(s0 + LT);
@@ -243,10 +245,10 @@ __global__ __launch_bounds__(256) void la16_kv(LaArgs a) {
             const int ch0 = (2 * wave + i) * D;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const v8h kf = la16_tr_frag(kt, ch0, s2, lane);
-                const v8h vf = la16_tr_frag(vt, ch0, s2, lane);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, vf, acc[i], 0, 0, 0);
-                ksum[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, ones, ksum[i], 0, 0, 0);
+                const V8 kf = la16_tr_frag<H>(kt, ch0, s2, lane);
+                const V8 vf = la16_tr_frag<H>(vt, ch0, s2, lane);
+                Mma32<H>::mma(kf, vf, acc[i]);
+                Mma32<H>::mma(kf, ones, ksum[i]);
             }
         }
         __syncthreads();
@@ -265,12 +267,14 @@ __global__ __launch_bounds__(256) void la16_kv(LaArgs a) {
     }
 }
 
-template <int D>
+template <typename H, int D>
 __global__ __launch_bounds__(256) void la16_apply(LaArgs a) {
+    using V8 = gf_vec<H, 8>;
+    using V4 = gf_vec<H, 4>;
     static_assert(D == 32, "coarse configuration");
     constexpr int RS = 272;                                              // slab row: 4 heads x 64 B + pad
-    __shared__ __attribute__((aligned(16))) _Float16 kvt[8 * 32 * 32];   // [h][v][d]
-    __shared__ __attribute__((aligned(16))) _Float16 ksh[8 * 32];        // [h][d]
+    __shared__ __attribute__((aligned(16))) H kvt[8 * 32 * 32];   // [h][v][d]
+    __shared__ __attribute__((aligned(16))) H ksh[8 * 32];        // [h][d]
     __shared__ __attribute__((aligned(16))) char qs[4 * 32 * RS];        // per wave: 32 tokens x 4 heads of Q, then of out
     const int n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5, lr = lane & 31;
     const int C = a.C;
@@ -280,9 +284,9 @@ __global__ __launch_bounds__(256) void la16_apply(LaArgs a) {
     const float inv_s = 1.0f / (float)a.S;
     for (int e = tid; e < C * D; e += 256) {      // kvf element (v, c = h*D + d) at [v*C + c]
         const int v = e / C, c = e % C;
-        kvt[((c / D) * 32 + v) * 32 + (c % D)] = (_Float16)(kvf[e] * inv_s);
+        kvt[((c / D) * 32 + v) * 32 + (c % D)] = (H)(kvf[e] * inv_s);
     }
-    ksh[tid] = (_Float16)(kvf[C * D + tid] * inv_s);
+    ksh[tid] = (H)(kvf[C * D + tid] * inv_s);
     __syncthreads();
     // Q rows come in with 16-B-per-lane row-contiguous loads (4 heads = 256 B per token at a time) through a
     // wave-private LDS slab; the MFMA B fragments are 16-B row reads of it; the result overwrites the head's
@@ -296,10 +300,10 @@ __global__ __launch_bounds__(256) void la16_apply(LaArgs a) {
         for (int it = 0; it < 8; ++it) {
             const int row = it * 4 + prow, tok = min(tok0 + row, a.L - 1);
             const bool qok = a.q_mask == nullptr || a.q_mask[(size_t)n * a.L + tok] != 0;
-            v8h qv = *reinterpret_cast<const v8h*>((const _Float16*)a.q + ((size_t)n * a.L + tok) * a.ldq + half * 128 + pch * 8);
+            V8 qv = *reinterpret_cast<const V8*>((const H*)a.q + ((size_t)n * a.L + tok) * a.ldq + half * 128 + pch * 8);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) qv[i] = qok ? (_Float16)elu1_fast((float)qv[i]) : (_Float16)0;
-            *reinterpret_cast<v8h*>(qt + row * RS + pch * 16) = qv;
+            for (int i = 0; i < 8; ++i) qv[i] = qok ? (H)elu1_fast((float)qv[i]) : (H)0;
+            *reinterpret_cast<V8*>(qt + row * RS + pch * 16) = qv;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -312,18 +316,17 @@ __global__ __launch_bounds__(256) void la16_apply(LaArgs a) {
             for (int r = 0; r < 16; ++r) { num[r] = 0.f; den[r] = 0.f; }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const v8h qf = *reinterpret_cast<const v8h*>(qt + lr * RS + (hh * 4 + 2 * s2 + h2) * 16);   // B: col = token, k = d
-                const v8h kf = *reinterpret_cast<const v8h*>(kvt + (h * 32 + lr) * 32 + 16 * s2 + 8 * h2);   // A: row = v
-                const v8h sf = *reinterpret_cast<const v8h*>(ksh + h * 32 + 16 * s2 + 8 * h2);              // A: every row = Ksum
-                num = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf, num, 0, 0, 0);
-                den = __builtin_amdgcn_mfma_f32_32x32x16_f16(sf, qf, den, 0, 0, 0);
+                const V8 qf = *reinterpret_cast<const V8*>(qt + lr * RS + (hh * 4 + 2 * s2 + h2) * 16);   // B: col = token, k = d
+                const V8 kf = *reinterpret_cast<const V8*>(kvt + (h * 32 + lr) * 32 + 16 * s2 + 8 * h2);   // A: row = v
+                const V8 sf = *reinterpret_cast<const V8*>(ksh + h * 32 + 16 * s2 + 8 * h2);              // A: every row = Ksum
+                Mma32<H>::mma(kf, qf, num);
+                Mma32<H>::mma(sf, qf, den);
             }
             const float z = __builtin_amdgcn_rcpf(den[0] + a.eps * inv_s);     // every row of den holds the token's Q.Ksum / S
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4)
-                *reinterpret_cast<v4h*>(qt + lr * RS + (hh * 32 + 8 * r4 + 4 * h2) * 2) =
-                    v4h{(_Float16)(num[4 * r4] * z), (_Float16)(num[4 * r4 + 1] * z), (_Float16)(num[4 * r4 + 2] * z),
-                        (_Float16)(num[4 * r4 + 3] * z)};
+                *reinterpret_cast<V4*>(qt + lr * RS + (hh * 32 + 8 * r4 + 4 * h2) * 2) =
+                    V4{(H)(num[4 * r4] * z), (H)(num[4 * r4 + 1] * z), (H)(num[4 * r4 + 2] * z), (H)(num[4 * r4 + 3] * z)};
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -332,21 +335,22 @@ __global__ __launch_bounds__(256) void la16_apply(LaArgs a) {
         for (int it = 0; it < 8; ++it) {
             const int row = it * 4 + prow, tok = tok0 + row;
             if (tok < a.L)
-                *reinterpret_cast<v8h*>((_Float16*)a.out + ((size_t)n * a.L + tok) * C + half * 128 + pch * 8) =
-                    *reinterpret_cast<const v8h*>(qt + row * RS + pch * 16);
+                *reinterpret_cast<V8*>((H*)a.out + ((size_t)n * a.L + tok) * C + half * 128 + pch * 8) =
+                    *reinterpret_cast<const V8*>(qt + row * RS + pch * 16);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
 }
 
+template <typename H>
 int la16_launch(const LaArgs& a, hipStream_t st) {
-    la16_kv<32><<<dim3(a.nchunks, a.N), 256, 0, st>>>(a);
+    la16_kv<H, 32><<<dim3(a.nchunks, a.N), 256, 0, st>>>(a);
     if (a.nchunks > 1) {
         const int len = a.C * a.D + a.C;
         la_kv_final<<<dim3((len + 255) / 256, a.N), 256, 0, st>>>(a);
     }
-    la16_apply<32><<<dim3((a.L + 127) / 128, a.N), 256, 0, st>>>(a);
+    la16_apply<H, 32><<<dim3((a.L + 127) / 128, a.N), 256, 0, st>>>(a);
     GF_CHECK_LAUNCH();
     return GF_OK;
 }
@@ -475,7 +479,7 @@ extern "C" int gf_linear_attention(const void* q, const void* k, const void* v, 
                                    size_t workspace_bytes, void* stream) {
     GF_CHECK_ARG(q && k && v && out, "null pointer");
     GF_CHECK_ARG(N > 0 && L > 0 && S > 0, "empty problem");
-    GF_CHECK_ARG(dtype == GF_F32 || dtype == GF_F16, "dtype must be GF_F32 or GF_F16");
+    GF_CHECK_ARG(dtype >= GF_F32 && dtype <= GF_BF16, "bad dtype");
     GF_CHECK_ARG((D == 16 || D == 32 || D == 64) && H * D <= 256 && (H * D) % 64 == 0, "need D in {16,32,64}, H*D in {64,128,192,256}");
     GF_CHECK_ARG(ldq >= H * D && ldk >= H * D && ldv >= H * D, "row strides smaller than H*D");
     if (workspace == nullptr || workspace_bytes < gf_linear_attention_workspace_bytes(N, S, H, D)) {
@@ -493,11 +497,12 @@ extern "C" int gf_linear_attention(const void* q, const void* k, const void* v, 
     // algorithmic bytes: q, k, v read once, the message written once
     void* pt = gf_prof_begin("k2_linear_attention", st, (double)N * (2.0 * L + 2.0 * S) * a.C * (dtype == GF_F32 ? 4 : 2));
     int rc;
-    if (dtype == GF_F16 && D == 32 && H == 8) rc = la16_launch(a, st);      // coarse level: matrix-core path
+    if (dtype == GF_F16 && D == 32 && H == 8) rc = la16_launch<_Float16>(a, st);      // coarse level: matrix-core path
+    else if (dtype == GF_BF16 && D == 32 && H == 8) rc = la16_launch<gf_bf16>(a, st);
     else {
 #define GF_LA(T)                                       \
     (D == 16 ? la_launch<T, 16>(a, st) : D == 32 ? la_launch<T, 32>(a, st) : la_launch<T, 64>(a, st))
-        rc = dtype == GF_F32 ? GF_LA(float) : GF_LA(_Float16);
+        rc = dtype == GF_F32 ? GF_LA(float) : dtype == GF_F16 ? GF_LA(_Float16) : GF_LA(gf_bf16);
 #undef GF_LA
     }
     gf_prof_end("k2_linear_attention", pt, st);

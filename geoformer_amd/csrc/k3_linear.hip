@@ -210,7 +210,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void linear_kernel(Lin
                 acc[nb][r] = (acc[nb][r] - mean) * rstd * vec[WROWS + c] + vec[2 * WROWS + c];
             }
     }
-    if constexpr (std::is_same<T, _Float16>::value) {
+    if constexpr (!std::is_same<T, float>::value) {
+        using V4 = gf_vec<T, 4>;
+        using V8 = gf_vec<T, 8>;
         // fp16: transpose through LDS so that global stores (and the residual loads) are 16 B per lane
         // along the row - 256-B contiguous segments instead of 64 scattered 8-B pieces per instruction.
         // One 32-token x 128-channel slab per wave at a time (the staging buffers are free now).
@@ -236,9 +238,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void linear_kernel(Lin
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const int nb = hb * 4 + q4, c = q4 * 32 + 8 * r4 + 4 * h;
                     if (nb < NB)                                         // NB = 7: the last slab holds three blocks
-                        *reinterpret_cast<v4h*>(ot + lr * RS + c * 2) =
-                            v4h{(_Float16)acc[nb][4 * r4], (_Float16)acc[nb][4 * r4 + 1], (_Float16)acc[nb][4 * r4 + 2],
-                                (_Float16)acc[nb][4 * r4 + 3]};
+                        *reinterpret_cast<V4*>(ot + lr * RS + c * 2) =
+                            V4{(T)acc[nb][4 * r4], (T)acc[nb][4 * r4 + 1], (T)acc[nb][4 * r4 + 2], (T)acc[nb][4 * r4 + 3]};
                 }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void linear_kernel(Lin
             for (int it = 0; it < 8; ++it) {
                 const int row = it * 4 + prow, tg = m0 + wave * 32 + row, cg = n0 + hb * 128 + pch * 8;
                 if (tg >= a.M || cg >= a.N) continue;
-                v8h v = *reinterpret_cast<const v8h*>(ot + row * RS + pch * 16);
+                V8 v = *reinterpret_cast<const V8*>(ot + row * RS + pch * 16);
                 if constexpr (EPI == EPI_UPADD) {
                     // pixel of this row: the wave's first row is decoded once (uniform), rows step along x with wrap
                     int px = upx + row, py = upy, pn = upn;
@@ -260,22 +261,22 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void linear_kernel(Lin
                     const int y1 = y0 + (y0 < a.up_h - 1), x1 = x0 + (x0 < a.up_w - 1);
                     const float wy1 = fy - y0, wx1 = fx - x0, wy0 = 1.f - wy1, wx0 = 1.f - wx1;
                     const T* lo = (const T*)a.up_lo + (size_t)pn * a.up_h * a.up_w * a.N + cg;
-                    const v8h v00 = *reinterpret_cast<const v8h*>(lo + ((size_t)y0 * a.up_w + x0) * a.N);
-                    const v8h v01 = *reinterpret_cast<const v8h*>(lo + ((size_t)y0 * a.up_w + x1) * a.N);
-                    const v8h v10 = *reinterpret_cast<const v8h*>(lo + ((size_t)y1 * a.up_w + x0) * a.N);
-                    const v8h v11 = *reinterpret_cast<const v8h*>(lo + ((size_t)y1 * a.up_w + x1) * a.N);
+                    const V8 v00 = *reinterpret_cast<const V8*>(lo + ((size_t)y0 * a.up_w + x0) * a.N);
+                    const V8 v01 = *reinterpret_cast<const V8*>(lo + ((size_t)y0 * a.up_w + x1) * a.N);
+                    const V8 v10 = *reinterpret_cast<const V8*>(lo + ((size_t)y1 * a.up_w + x0) * a.N);
+                    const V8 v11 = *reinterpret_cast<const V8*>(lo + ((size_t)y1 * a.up_w + x1) * a.N);
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
-                        v[i] = (_Float16)((float)v[i] + wy0 * (wx0 * (float)v00[i] + wx1 * (float)v01[i]) +
+                        v[i] = (T)((float)v[i] + wy0 * (wx0 * (float)v00[i] + wx1 * (float)v01[i]) +
                                           wy1 * (wx0 * (float)v10[i] + wx1 * (float)v11[i]));
                 }
                 if constexpr (EPI == EPI_LN_RES) {
-                    const v8h x = *reinterpret_cast<const v8h*>((const T*)a.res + (size_t)tg * a.ldres + cg);
+                    const V8 x = *reinterpret_cast<const V8*>((const T*)a.res + (size_t)tg * a.ldres + cg);
                     const bool keep = a.flag == nullptr || a.flag[tg / a.flag_rows] != 0;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = keep ? (_Float16)((float)x[i] + (float)v[i]) : x[i];
+                    for (int i = 0; i < 8; ++i) v[i] = keep ? (T)((float)x[i] + (float)v[i]) : x[i];
                 }
-                *reinterpret_cast<v8h*>((T*)a.out + (size_t)tg * a.ldo + cg) = v;
+                *reinterpret_cast<V8*>((T*)a.out + (size_t)tg * a.ldo + cg) = v;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -308,10 +309,11 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void linear_kernel(Lin
 // channels instead of 32 x 256.  Same 128 accumulator registers, but a k-group now needs 2 token + 4 weight
 // fragments for its 8 MFMAs instead of 1 + 8: a third less LDS read traffic in the K loop, which is LDS-bound.
 // ---------------------------------------------------------------------------------------------
-template <int EPI>
+template <typename T, int EPI>
 __global__ __launch_bounds__(256, 2) void linear_kernel_w2(LinArgs a) {
-    using T = _Float16;
-    using Frag = v8h;
+    using Frag = typename Mma32<T>::Frag;
+    using V4 = gf_vec<T, 4>;
+    using V8 = gf_vec<T, 8>;
     constexpr int EPC = 8, BK = 64, WROWS = 256, ROWS = 128 + WROWS, NLD = ROWS * 8 / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* st = smem;
@@ -374,8 +376,8 @@ __global__ __launch_bounds__(256, 2) void linear_kernel_w2(LinArgs a) {
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
                 const Frag wf = *reinterpret_cast<const Frag*>(sw + gf_lds_off(tn * 128 + nb * 32 + lr, chunk));
-                acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, t0, acc[0][nb], 0, 0, 0);
-                acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, t1, acc[1][nb], 0, 0, 0);
+                Mma32<T>::mma(wf, t0, acc[0][nb]);
+                Mma32<T>::mma(wf, t1, acc[1][nb]);
             }
         }
     }
@@ -402,9 +404,8 @@ __global__ __launch_bounds__(256, 2) void linear_kernel_w2(LinArgs a) {
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const int c = nb * 32 + 8 * r4 + 4 * h;
-                *reinterpret_cast<v4h*>(ot + lr * RS + c * 2) =
-                    v4h{(_Float16)acc[t][nb][4 * r4], (_Float16)acc[t][nb][4 * r4 + 1], (_Float16)acc[t][nb][4 * r4 + 2],
-                        (_Float16)acc[t][nb][4 * r4 + 3]};
+                *reinterpret_cast<V4*>(ot + lr * RS + c * 2) =
+                    V4{(T)acc[t][nb][4 * r4], (T)acc[t][nb][4 * r4 + 1], (T)acc[t][nb][4 * r4 + 2], (T)acc[t][nb][4 * r4 + 3]};
             }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel_w2(LinArgs a) {
         for (int it = 0; it < 8; ++it) {
             const int row = it * 4 + prow, tg = m0 + tm * 64 + t * 32 + row, cg = n0 + tn * 128 + pch * 8;
             if (tg >= a.M || cg >= a.N) continue;
-            *reinterpret_cast<v8h*>((T*)a.out + (size_t)tg * a.ldo + cg) = *reinterpret_cast<const v8h*>(ot + row * RS + pch * 16);
+            *reinterpret_cast<V8*>((T*)a.out + (size_t)tg * a.ldo + cg) = *reinterpret_cast<const V8*>(ot + row * RS + pch * 16);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -448,7 +449,7 @@ extern "C" int gf_linear(const void* a1, long lda1, int k1, const void* a2, long
                          int N, void* stream) {
     GF_CHECK_ARG(a1 && w && out, "null pointer");
     GF_CHECK_ARG(M > 0 && N > 0 && k1 > 0 && k2 >= 0, "bad sizes");
-    GF_CHECK_ARG(dtype == GF_F32 || dtype == GF_F16, "dtype must be GF_F32 or GF_F16");
+    GF_CHECK_ARG(dtype >= GF_F32 && dtype <= GF_BF16, "bad dtype");
     const int bk = dtype == GF_F32 ? 32 : 64;
     GF_CHECK_ARG(k1 % bk == 0 && k2 % bk == 0, "k1 and k2 must be multiples of 32 (f32) / 64 (f16)");
     GF_CHECK_ARG(k2 == 0 || a2 != nullptr, "a2 missing");
@@ -471,18 +472,27 @@ extern "C" int gf_linear(const void* a1, long lda1, int k1, const void* a2, long
     hipStream_t st = (hipStream_t)stream;
     void* pt = gf_prof_begin("k3_linear", st, 2.0 * (double)M * N * (k1 + k2));
     const bool wide = (epilogue >= EPI_LN) ? N == 256 : N % 256 == 0;
-    if (dtype == GF_F16 && wide && epilogue <= EPI_TANH && rowgroup_bias == nullptr) {
+    if (dtype != GF_F32 && wide && epilogue <= EPI_TANH && rowgroup_bias == nullptr) {
         const size_t lds = (size_t)(128 + 256) * 128 + 256 * sizeof(float);
         const dim3 grid((M + 127) / 128, (N + 255) / 256);
-        if (epilogue == EPI_NONE) linear_kernel_w2<EPI_NONE><<<grid, 256, lds, st>>>(a);
-        else if (epilogue == EPI_RELU) linear_kernel_w2<EPI_RELU><<<grid, 256, lds, st>>>(a);
-        else linear_kernel_w2<EPI_TANH><<<grid, 256, lds, st>>>(a);
+#define GF_W2(T)                                                                   \
+    do {                                                                           \
+        if (epilogue == EPI_NONE) linear_kernel_w2<T, EPI_NONE><<<grid, 256, lds, st>>>(a);       \
+        else if (epilogue == EPI_RELU) linear_kernel_w2<T, EPI_RELU><<<grid, 256, lds, st>>>(a);  \
+        else linear_kernel_w2<T, EPI_TANH><<<grid, 256, lds, st>>>(a);                            \
+    } while (0)
+        if (dtype == GF_F16) GF_W2(_Float16);
+        else GF_W2(gf_bf16);
+#undef GF_W2
     } else if (dtype == GF_F32) {
         if (wide) lin_launch<float, 8>(a, epilogue, st);
         else lin_launch<float, 4>(a, epilogue, st);
-    } else {
+    } else if (dtype == GF_F16) {
         if (wide) lin_launch<_Float16, 8>(a, epilogue, st);
         else lin_launch<_Float16, 4>(a, epilogue, st);
+    } else {
+        if (wide) lin_launch<gf_bf16, 8>(a, epilogue, st);
+        else lin_launch<gf_bf16, 4>(a, epilogue, st);
     }
     gf_prof_end("k3_linear", pt, st);
     GF_CHECK_LAUNCH();
@@ -495,7 +505,7 @@ extern "C" int gf_conv1x1_upsample_add_nhwc(const void* x, const void* w, const 
                                             int H, int W, int Cin, int Cout, int dtype, void* stream) {
     GF_CHECK_ARG(x && w && lo && out, "null pointer");
     GF_CHECK_ARG(N > 0 && h > 0 && wl > 0 && H > 0 && W > 0, "empty problem");
-    GF_CHECK_ARG(dtype == GF_F16, "built for fp16 maps (the inference backbone)");
+    GF_CHECK_ARG(dtype == GF_F16 || dtype == GF_BF16, "built for 16-bit maps (the inference backbone)");
     GF_CHECK_ARG(Cin % 64 == 0 && Cout % 32 == 0, "Cin must be a multiple of 64, Cout of 32");
     GF_CHECK_ARG((long)N * H * W < (1l << 31), "too many pixels");
     GF_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)lo % 16 == 0, "tensors must be 16-byte aligned");
@@ -508,7 +518,8 @@ extern "C" int gf_conv1x1_upsample_add_nhwc(const void* x, const void* w, const 
     void* pt = gf_prof_begin("k3_linear", st, 2.0 * (double)a.M * Cout * Cin);
     // 128-wide column tiles (152 registers, three waves per SIMD): with K = 128 the kernel is all epilogue, and
     // a single 224-wide tile (NB = 7, two waves per SIMD) measured slower (607 vs 529 us) despite reading x once
-    lin_launch1<_Float16, 4, EPI_UPADD>(a, st);
+    if (dtype == GF_F16) lin_launch1<_Float16, 4, EPI_UPADD>(a, st);
+    else lin_launch1<gf_bf16, 4, EPI_UPADD>(a, st);
     gf_prof_end("k3_linear", pt, st);
     GF_CHECK_LAUNCH();
     return GF_OK;

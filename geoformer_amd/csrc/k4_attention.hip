@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void attn_gather_kv(AtArgs a) {
             vc[(size_t)p * CC + t] = ok ? vm[(size_t)tok * a.ldv + t] : 0.f;
         }
     } else {
-        _Float16 vt[KT];
+        T vt[KT];
 #pragma unroll
         for (int p = 0; p < KT; ++p) {
             const bool ok = p0 + p < K;
@@ -71,10 +71,11 @@ __global__ __launch_bounds__(256) void attn_gather_kv(AtArgs a) {
             kc[(size_t)p * CC + t] = ok ? km[(size_t)tok * a.ldk + t] : (T)0;
             vt[vt_pos(p)] = ok ? vm[(size_t)tok * a.ldv + t] : (T)0;
         }
-        v8h* dst = reinterpret_cast<v8h*>((T*)a.vc + ((size_t)n * CC + t) * a.Kpad + p0);
+        using V8 = gf_vec<T, 8>;
+        V8* dst = reinterpret_cast<V8*>((T*)a.vc + ((size_t)n * CC + t) * a.Kpad + p0);
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            dst[c] = v8h{vt[8 * c], vt[8 * c + 1], vt[8 * c + 2], vt[8 * c + 3], vt[8 * c + 4], vt[8 * c + 5], vt[8 * c + 6], vt[8 * c + 7]};
+            dst[c] = V8{vt[8 * c], vt[8 * c + 1], vt[8 * c + 2], vt[8 * c + 3], vt[8 * c + 4], vt[8 * c + 5], vt[8 * c + 6], vt[8 * c + 7]};
     }
 }
 
@@ -185,12 +186,12 @@ __global__ __launch_bounds__(256) void attn_self(AtArgs a) {
         } else {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const v8h pf{(_Float16)x[8 * s2], (_Float16)x[8 * s2 + 1], (_Float16)x[8 * s2 + 2], (_Float16)x[8 * s2 + 3],
-                             (_Float16)x[8 * s2 + 4], (_Float16)x[8 * s2 + 5], (_Float16)x[8 * s2 + 6], (_Float16)x[8 * s2 + 7]};
+                const Frag pf{(T)x[8 * s2], (T)x[8 * s2 + 1], (T)x[8 * s2 + 2], (T)x[8 * s2 + 3],
+                              (T)x[8 * s2 + 4], (T)x[8 * s2 + 5], (T)x[8 * s2 + 6], (T)x[8 * s2 + 7]};
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    const v8h vf = *reinterpret_cast<const v8h*>(vs + vt_off(head * HD + b * 32 + lr, 2 * s2 + h));
-                    o[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[b], 0, 0, 0);
+                    const Frag vf = *reinterpret_cast<const Frag*>(vs + vt_off(head * HD + b * 32 + lr, 2 * s2 + h));
+                    M::mma(vf, pf, o[b]);
                 }
             }
         }
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void attn_self(AtArgs a) {
                 const int d = b * 32 + 8 * r4 + 4 * h;
                 const v4f v{o[b][4 * r4] * inv, o[b][4 * r4 + 1] * inv, o[b][4 * r4 + 2] * inv, o[b][4 * r4 + 3] * inv};
                 if constexpr (F32) *reinterpret_cast<v4f*>(op + d) = v;
-                else *reinterpret_cast<v4h*>(op + d) = v4h{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                else *reinterpret_cast<gf_vec<T, 4>*>(op + d) = gf_vec<T, 4>{(T)v.x, (T)v.y, (T)v.z, (T)v.w};
             }
     }
 }
@@ -227,7 +228,7 @@ extern "C" int gf_self_attention_gathered(const void* q, const void* kmap, const
     GF_CHECK_ARG(q && kmap && vmap && idx && nkeys && out, "null pointer");
     GF_CHECK_ARG(N > 0 && L > 0, "empty problem");
     GF_CHECK_ARG(H == NH && D == HD, "built for nhead=4, head dim 64 (geo_config.py:12, d_model 256)");
-    GF_CHECK_ARG(dtype == GF_F32 || dtype == GF_F16, "dtype must be GF_F32 or GF_F16");
+    GF_CHECK_ARG(dtype >= GF_F32 && dtype <= GF_BF16, "bad dtype");
     if (workspace == nullptr || workspace_bytes < gf_self_attention_workspace_bytes(N, L, dtype)) {
         gf_set_error("gf_self_attention_gathered: workspace too small");
         return GF_ERR_WORKSPACE;
@@ -245,9 +246,12 @@ extern "C" int gf_self_attention_gathered(const void* q, const void* kmap, const
     if (dtype == GF_F32) {
         attn_gather_kv<float><<<ggrid, 256, 0, st>>>(a);
         attn_self<float><<<agrid, 256, 2 * KT * CC * 4, st>>>(a);
-    } else {
+    } else if (dtype == GF_F16) {
         attn_gather_kv<_Float16><<<ggrid, 256, 0, st>>>(a);
         attn_self<_Float16><<<agrid, 256, 2 * KT * CC * 2, st>>>(a);
+    } else {
+        attn_gather_kv<gf_bf16><<<ggrid, 256, 0, st>>>(a);
+        attn_self<gf_bf16><<<agrid, 256, 2 * KT * CC * 2, st>>>(a);
     }
     GF_CHECK_LAUNCH();
     return GF_OK;

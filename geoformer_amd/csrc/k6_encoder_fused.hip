@@ -644,6 +644,9 @@ void enc_init() {
     enc_allow_lds(enc_layer<_Float16, 0, true>); enc_allow_lds(enc_layer<_Float16, 1, true>);
     enc_allow_lds(enc_layer<_Float16, 0, false>); enc_allow_lds(enc_layer<_Float16, 1, false>);
     enc_allow_lds(enc_kv_state<_Float16>);
+    enc_allow_lds(enc_layer<gf_bf16, 0, true>); enc_allow_lds(enc_layer<gf_bf16, 1, true>);
+    enc_allow_lds(enc_layer<gf_bf16, 0, false>); enc_allow_lds(enc_layer<gf_bf16, 1, false>);
+    enc_allow_lds(enc_kv_state<gf_bf16>);
     enc_attr_done = true;
 }
 
@@ -661,7 +664,7 @@ extern "C" int gf_encoder_kv_state(const void* src, long ld, int dtype, int N, i
                                    void* stream) {
     GF_CHECK_ARG(src && wstream_kv && kv_state, "null pointer");
     GF_CHECK_ARG(N > 0 && S > 0, "empty problem");
-    GF_CHECK_ARG(dtype == GF_F16, "the fused encoder kernels are built for 16-bit storage (GF_F16)");
+    GF_CHECK_ARG(dtype == GF_F16 || dtype == GF_BF16, "the fused encoder kernels are built for 16-bit storage (GF_F16 / GF_BF16)");
     GF_CHECK_ARG((ld * 2) % 16 == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)wstream_kv % 16 == 0, "operands must be 16-byte aligned");
     if (workspace == nullptr || workspace_bytes < gf_encoder_kv_workspace_bytes(N, S)) {
         gf_set_error("gf_encoder_kv_state: workspace too small");
@@ -674,7 +677,8 @@ extern "C" int gf_encoder_kv_state(const void* src, long ld, int dtype, int N, i
     hipStream_t st = (hipStream_t)stream;
     const int len = C * D + C;
     void* pt = gf_prof_begin("enc_kv_state", st, 2.0 * N * (double)S * C * (2.0 * C + 2.0 * D));
-    enc_kv_state<_Float16><<<N * a.tiles, 256, W_OFF + 2 * WBLK + 8192, st>>>(a);
+    if (dtype == GF_F16) enc_kv_state<_Float16><<<N * a.tiles, 256, W_OFF + 2 * WBLK + 8192, st>>>(a);
+    else enc_kv_state<gf_bf16><<<N * a.tiles, 256, W_OFF + 2 * WBLK + 8192, st>>>(a);
     enc_kv_reduce<<<dim3((len + 255) / 256, N), 256, 0, st>>>(a.part, kv_state, a.tiles, len);
     gf_prof_end("enc_kv_state", pt, st);
     GF_CHECK_LAUNCH();
@@ -689,7 +693,7 @@ extern "C" int gf_encoder_layer(const void* x, long ldx, const void* msg, long l
     GF_CHECK_ARG(x && wstream && ln_params && out, "null pointer");
     GF_CHECK_ARG((msg != nullptr) != (kv_state != nullptr), "exactly one of msg (attention output) and kv_state (linear attention) is given");
     GF_CHECK_ARG(N > 0 && L > 0 && (kv_state == nullptr || S > 0), "empty problem");
-    GF_CHECK_ARG(dtype == GF_F16, "the fused encoder kernels are built for 16-bit storage (GF_F16)");
+    GF_CHECK_ARG(dtype == GF_F16 || dtype == GF_BF16, "the fused encoder kernels are built for 16-bit storage (GF_F16 / GF_BF16)");
     GF_CHECK_ARG(activation == 0 || activation == 1, "activation: 0 = ReLU, 1 = Tanh");
     GF_CHECK_ARG((ldx * 2) % 16 == 0 && (ldo * 2) % 16 == 0 && (msg == nullptr || (ldm * 2) % 16 == 0), "rows must be 16-byte aligned");
     GF_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)msg % 16 == 0 && (uintptr_t)wstream % 16 == 0,
@@ -705,7 +709,8 @@ extern "C" int gf_encoder_layer(const void* x, long ldx, const void* msg, long l
     // flops per token: [q 2C^2 + apply 2C(D+1)] + merge 2C^2 + mlp.0 2(2C)(2C) + mlp.2 2(2C)C
     const double per_tok = (attn ? 2.0 * C * C + 2.0 * C * (D + 1) : 0.0) + 2.0 * C * C + 8.0 * C * C + 4.0 * C * C;
     void* pt = gf_prof_begin("enc_layer", st, per_tok * N * (double)L);
-    enc_launch<_Float16>(a, activation, attn, st);
+    if (dtype == GF_F16) enc_launch<_Float16>(a, activation, attn, st);
+    else enc_launch<gf_bf16>(a, activation, attn, st);
     gf_prof_end("enc_layer", pt, st);
     GF_CHECK_LAUNCH();
     return GF_OK;

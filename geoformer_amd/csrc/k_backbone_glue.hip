@@ -19,6 +19,8 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2 };
 template <typename T, int V> struct VecOf;
 template <> struct VecOf<_Float16, 8> { typedef v8h type; };
 template <> struct VecOf<_Float16, 4> { typedef v4h type; };
+template <> struct VecOf<gf_bf16, 8> { typedef v8b type; };
+template <> struct VecOf<gf_bf16, 4> { typedef v4b type; };
 template <> struct VecOf<float, 4> { typedef v4f type; };
 
 struct BaArgs {
@@ -214,7 +216,7 @@ extern "C" int gf_bias_act_nhwc(const void* x, const float* bias, const void* re
                                 int act, float slope, int dtype, void* stream) {
     GF_CHECK_ARG(x && out, "null pointer");
     GF_CHECK_ARG(pixels > 0 && C > 0, "empty problem");
-    GF_CHECK_ARG(dtype == GF_F32 || dtype == GF_F16, "dtype must be GF_F32 or GF_F16");
+    GF_CHECK_ARG(dtype >= GF_F32 && dtype <= GF_BF16, "bad dtype");
     GF_CHECK_ARG(act >= ACT_NONE && act <= ACT_LEAKY, "unknown activation");
     GF_CHECK_ARG(C % 4 == 0, "C must be a multiple of 4");
     GF_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)residual % 16 == 0 && (uintptr_t)bias % 16 == 0,
@@ -228,6 +230,12 @@ extern "C" int gf_bias_act_nhwc(const void* x, const float* bias, const void* re
     } else if (dtype == GF_F16) {
         a.nvec = pixels * C / 4;
         bias_act<_Float16, 4><<<glue_blocks(a.nvec), 256, 0, st>>>(a);
+    } else if (dtype == GF_BF16 && C % 8 == 0) {
+        a.nvec = pixels * C / 8;
+        bias_act<gf_bf16, 8><<<glue_blocks(a.nvec), 256, 0, st>>>(a);
+    } else if (dtype == GF_BF16) {
+        a.nvec = pixels * C / 4;
+        bias_act<gf_bf16, 4><<<glue_blocks(a.nvec), 256, 0, st>>>(a);
     } else {
         a.nvec = pixels * C / 4;
         bias_act<float, 4><<<glue_blocks(a.nvec), 256, 0, st>>>(a);
@@ -241,17 +249,19 @@ extern "C" int gf_upsample_add_nhwc(const void* lo, const void* hi, void* out, i
                                     int dtype, void* stream) {
     GF_CHECK_ARG(lo && hi && out, "null pointer");
     GF_CHECK_ARG(N > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0, "empty problem");
-    GF_CHECK_ARG(dtype == GF_F32 || dtype == GF_F16, "dtype must be GF_F32 or GF_F16");
+    GF_CHECK_ARG(dtype >= GF_F32 && dtype <= GF_BF16, "bad dtype");
     GF_CHECK_ARG(C % 4 == 0, "C must be a multiple of 4");
     GF_CHECK_ARG((uintptr_t)lo % 16 == 0 && (uintptr_t)hi % 16 == 0 && (uintptr_t)out % 16 == 0, "tensors must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     UaArgs a{lo, hi, out, N, h, w, H, W, C, H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f,
              W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f};
     GF_CHECK_ARG(H <= 65535 && N <= 65535, "H and N must fit the launch grid");
-    const int V = (dtype == GF_F16 && C % 8 == 0) ? 8 : 4;
+    const int V = (dtype != GF_F32 && C % 8 == 0) ? 8 : 4;
     const dim3 grid((unsigned)((W * (C / V) + 255) / 256), (unsigned)H, (unsigned)N);
     if (dtype == GF_F16 && V == 8) upsample_add<_Float16, 8><<<grid, 256, 0, st>>>(a);
     else if (dtype == GF_F16) upsample_add<_Float16, 4><<<grid, 256, 0, st>>>(a);
+    else if (dtype == GF_BF16 && V == 8) upsample_add<gf_bf16, 8><<<grid, 256, 0, st>>>(a);
+    else if (dtype == GF_BF16) upsample_add<gf_bf16, 4><<<grid, 256, 0, st>>>(a);
     else upsample_add<float, 4><<<grid, 256, 0, st>>>(a);
     GF_CHECK_LAUNCH();
     return GF_OK;

@@ -199,13 +199,17 @@ extern "C" int gf_fine_gather(const void* feat_f0, const void* feat_f1, int feat
     GF_CHECK_ARG(feat_f0 && feat_f1 && strides0 && strides1 && feat_c0 && feat_c1 && b_ids && i_ids && j_ids && win_out && ccat_out, "null pointer");
     GF_CHECK_ARG(M > 0, "M must be > 0 (the M == 0 early return of fine_preprocess.py:35-38 is the caller's)");
     GF_CHECK_ARG(C > 0 && C <= 256 && window > 0 && stride > 0 && w0c > 0 && w1c > 0, "bad sizes");
-    GF_CHECK_ARG((feat_dtype == GF_F32 || feat_dtype == GF_F16) && (dtype == GF_F32 || dtype == GF_F16), "bad dtype");
+    GF_CHECK_ARG(feat_dtype >= GF_F32 && feat_dtype <= GF_BF16 && dtype >= GF_F32 && dtype <= GF_BF16, "bad dtype");
+    GF_CHECK_ARG(feat_dtype == GF_F32 || dtype == GF_F32 || feat_dtype == dtype, "fp16 <-> bf16 conversion is not built");
     FgArgs a{feat_f0, feat_f1, strides0[0], strides0[1], strides0[2], strides0[3], strides1[0], strides1[1], strides1[2],
              strides1[3], H0, W0, H1, W1, C, feat_c0, feat_c1, L, S, CC, b_ids, i_ids, j_ids, M, w0c, w1c, stride, window,
              win_out, ccat_out};
     hipStream_t st = (hipStream_t)stream;
-    if (feat_dtype == GF_F32) return dtype == GF_F32 ? fg_launch<float, float>(a, st) : fg_launch<float, _Float16>(a, st);
-    return dtype == GF_F32 ? fg_launch<_Float16, float>(a, st) : fg_launch<_Float16, _Float16>(a, st);
+    if (feat_dtype == GF_F32)
+        return dtype == GF_F32 ? fg_launch<float, float>(a, st)
+                               : dtype == GF_F16 ? fg_launch<float, _Float16>(a, st) : fg_launch<float, gf_bf16>(a, st);
+    if (feat_dtype == GF_F16) return dtype == GF_F32 ? fg_launch<_Float16, float>(a, st) : fg_launch<_Float16, _Float16>(a, st);
+    return dtype == GF_F32 ? fg_launch<gf_bf16, float>(a, st) : fg_launch<gf_bf16, gf_bf16>(a, st);
 }
 
 extern "C" size_t gf_fine_match_workspace_bytes(int M) {
@@ -221,7 +225,7 @@ extern "C" int gf_fine_match(const void* f0, const void* f1, int dtype, int M, i
     GF_CHECK_ARG(f0 && f1 && b_ids && mkpts0_c && mkpts1_c && fine_matrix && mkpts0_f && mkpts1_f && mconf && m_bids && count, "null pointer");
     GF_CHECK_ARG(M > 0, "M must be > 0 (the M == 0 early return of fine_matching2.py:34-42 is the caller's)");
     GF_CHECK_ARG(WWin == WW && C > 0 && C <= 128, "built for 5x5 windows and C <= 128");
-    GF_CHECK_ARG(dtype == GF_F32 || dtype == GF_F16, "dtype must be GF_F32 or GF_F16");
+    GF_CHECK_ARG(dtype >= GF_F32 && dtype <= GF_BF16, "bad dtype");
     if (workspace == nullptr || workspace_bytes < gf_fine_match_workspace_bytes(M)) {
         gf_set_error("gf_fine_match: workspace too small");
         return GF_ERR_WORKSPACE;
@@ -237,7 +241,8 @@ extern "C" int gf_fine_match(const void* f0, const void* f1, int dtype, int M, i
     hipStream_t st = (hipStream_t)stream;
     (void)hipMemsetAsync(a.chunk_cnt, 0, (size_t)a.chunks * sizeof(int32_t), st);
     if (dtype == GF_F32) fine_match<float><<<M, 256, 0, st>>>(a);
-    else fine_match<_Float16><<<M, 256, 0, st>>>(a);
+    else if (dtype == GF_F16) fine_match<_Float16><<<M, 256, 0, st>>>(a);
+    else fine_match<gf_bf16><<<M, 256, 0, st>>>(a);
     fine_compact<<<a.chunks, 1024, 0, st>>>(a);
     GF_CHECK_LAUNCH();
     return GF_OK;

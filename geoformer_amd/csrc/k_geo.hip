@@ -180,6 +180,15 @@ template <>
 __device__ __forceinline__ void store4<_Float16>(_Float16* p, v4f v) {
     *reinterpret_cast<v4h*>(p) = v4h{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
 }
+template <>
+__device__ __forceinline__ v4f load4<gf_bf16>(const gf_bf16* p) {
+    const v4b h = *reinterpret_cast<const v4b*>(p);
+    return v4f{(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+}
+template <>
+__device__ __forceinline__ void store4<gf_bf16>(gf_bf16* p, v4f v) {
+    *reinterpret_cast<v4b*>(p) = v4b{(gf_bf16)v.x, (gf_bf16)v.y, (gf_bf16)v.z, (gf_bf16)v.w};
+}
 
 template <typename T, int WW>
 __global__ __launch_bounds__(256) void window_cross_attention(CaArgs a) {
@@ -280,14 +289,15 @@ extern "C" int gf_window_cross_attention(const void* q, const void* kmap, const 
     GF_CHECK_ARG(N > 0 && L > 0 && S > 0, "empty problem");
     GF_CHECK_ARG(H == 4 && D == 64 && WW == 25, "built for nhead=4, head dim 64, 5x5 windows (geo_config.py:12,16)");
     GF_CHECK_ARG((double)S * (double)(ldk > ldv ? ldk : ldv) < 4294967296.0, "key map too large for 32-bit row offsets");
-    GF_CHECK_ARG(dtype == GF_F32 || dtype == GF_F16, "dtype must be GF_F32 or GF_F16");
+    GF_CHECK_ARG(dtype >= GF_F32 && dtype <= GF_BF16, "bad dtype");
     CaArgs a{q, kmap, vmap, ldq, ldk, ldv, win, valid, out, N, L, S, WW, 1.0f / sqrtf((float)D)};
     const dim3 grid((L + 3) / 4, N);
     hipStream_t st = (hipStream_t)stream;
     // algorithmic bytes: q read, out written, each projected key / value map read once (served from L2 after that)
     void* pt = gf_prof_begin("k5_window_attention", st, (double)N * (2.0 * L + 2.0 * S) * H * D * (dtype == GF_F32 ? 4 : 2));
     if (dtype == GF_F32) window_cross_attention<float, 25><<<grid, 256, 0, st>>>(a);
-    else window_cross_attention<_Float16, 25><<<grid, 256, 0, st>>>(a);
+    else if (dtype == GF_F16) window_cross_attention<_Float16, 25><<<grid, 256, 0, st>>>(a);
+    else window_cross_attention<gf_bf16, 25><<<grid, 256, 0, st>>>(a);
     gf_prof_end("k5_window_attention", pt, st);
     GF_CHECK_LAUNCH();
     return GF_OK;

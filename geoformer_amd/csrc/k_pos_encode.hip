@@ -97,9 +97,13 @@ extern "C" int gf_pos_encode(const void* x, int x_dtype, long sn, long sc, long 
                              void* out, int out_dtype, int N, int C, int H, int W, void* stream) {
     GF_CHECK_ARG(x && pe && out, "null pointer");
     GF_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0, "empty problem");
-    GF_CHECK_ARG((x_dtype == GF_F32 || x_dtype == GF_F16) && (out_dtype == GF_F32 || out_dtype == GF_F16), "bad dtype");
+    GF_CHECK_ARG(x_dtype >= GF_F32 && x_dtype <= GF_BF16 && out_dtype >= GF_F32 && out_dtype <= GF_BF16, "bad dtype");
+    GF_CHECK_ARG(x_dtype == GF_F32 || out_dtype == GF_F32 || x_dtype == out_dtype, "fp16 <-> bf16 conversion is not built");
     PeArgs a{x, sn, sc, sh, sw, pe, out, N, C, H, W};
     hipStream_t st = (hipStream_t)stream;
-    if (x_dtype == GF_F32) return out_dtype == GF_F32 ? pe_launch<float, float>(a, st) : pe_launch<float, _Float16>(a, st);
-    return out_dtype == GF_F32 ? pe_launch<_Float16, float>(a, st) : pe_launch<_Float16, _Float16>(a, st);
+    if (x_dtype == GF_F32)
+        return out_dtype == GF_F32 ? pe_launch<float, float>(a, st)
+                                   : out_dtype == GF_F16 ? pe_launch<float, _Float16>(a, st) : pe_launch<float, gf_bf16>(a, st);
+    if (x_dtype == GF_F16) return out_dtype == GF_F32 ? pe_launch<_Float16, float>(a, st) : pe_launch<_Float16, _Float16>(a, st);
+    return out_dtype == GF_F32 ? pe_launch<gf_bf16, float>(a, st) : pe_launch<gf_bf16, gf_bf16>(a, st);
 }

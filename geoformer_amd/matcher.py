@@ -234,8 +234,9 @@ def main(argv=None):
     for p in (m, h):
         p.add_argument('--ckpt', default=None)
         p.add_argument('--match-threshold', type=float, default=0.2)
-        p.add_argument('--precision', choices=('fp32', 'fp16'), default='fp16',
-                       help="fp16 = the fast mode (fp16 storage, fp32 accumulation); fp32 = the reference's arithmetic")
+        p.add_argument('--precision', choices=('fp32', 'fp16', 'bf16'), default='fp16',
+                       help="fp16 / bf16 = the fast modes (16-bit storage, fp32 accumulation; bf16 = BASELINE configs[1]'s wording); "
+                            "fp32 = the reference's arithmetic")
     args = ap.parse_args(argv)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))

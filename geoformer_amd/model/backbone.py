@@ -153,7 +153,7 @@ class FusedInferenceBackbone:
         x3 = self._block(self._block(x2, self.blocks[4]), self.blocks[5])
         c3 = self._conv(x3, self.l3_out)
         c2 = self._head(ops.upsample_add_(self._conv(x2, self.l2_out), c3), self.l2_oc2)
-        if self.l1_out.shape[1] % 64 == 0 and self.dtype == torch.float16:      # lateral 1x1 + merge in one K3 launch
+        if self.l1_out.shape[1] % 64 == 0 and self.dtype != torch.float32:      # lateral 1x1 + merge in one K3 launch
             c1 = self._head(ops.conv1x1_upsample_add(x1, self.l1_out, c2), self.l1_oc2)
         else:
             c1 = self._head(ops.upsample_add_(self._conv(x1, self.l1_out), c2), self.l1_oc2)

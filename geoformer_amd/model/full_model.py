@@ -20,7 +20,7 @@ from .geo_config import default_cfg
 from .modules import (CoarseMatching, FineMatching2, FinePreprocess, GeoModule, LocalFeatureTransformer,
                       PositionEncodingSine, materialize_matches)
 
-_PRECISIONS = {'fp32': torch.float32, 'fp16': torch.float16}
+_PRECISIONS = {'fp32': torch.float32, 'fp16': torch.float16, 'bf16': torch.bfloat16}
 
 
 class GeoFormer(nn.Module):
@@ -41,7 +41,7 @@ class GeoFormer(nn.Module):
         self._fused = [None]     # holder list: keeps the folded inference copy out of the module tree / state dict
         self.set_precision(geoformer_cfg.get('precision', 'fp32'))
 
-    # -- precision of the matching path: 'fp32' (parity mode) or 'fp16' (fp16 storage, fp32 accumulate)
+    # -- precision of the matching path: 'fp32' (parity mode), 'fp16' or 'bf16' (16-bit storage, fp32 accumulate)
     def set_precision(self, precision: str, backbone_dtype: Optional[torch.dtype] = None):
         if precision not in _PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")

@@ -8,16 +8,16 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import GF_F16, GF_F32, check
+from ._lib import GF_BF16, GF_F16, GF_F32, check
 
-_DTYPES = {torch.float32: GF_F32, torch.float16: GF_F16}
+_DTYPES = {torch.float32: GF_F32, torch.float16: GF_F16, torch.bfloat16: GF_BF16}
 
 
 def _dt(t):
     try:
         return _DTYPES[t.dtype]
     except KeyError:
-        raise TypeError(f'geoformer_amd kernels take float32 or float16 tensors, got {t.dtype}') from None
+        raise TypeError(f'geoformer_amd kernels take float32, float16 or bfloat16 tensors, got {t.dtype}') from None
 
 
 def _p(t):

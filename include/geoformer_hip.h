@@ -13,7 +13,7 @@
  *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*), never
  *     synchronises, never allocates; safe to capture in a hipGraph;
  *   - returns 0 (GF_OK) or a negative gf_status; gf_last_error() gives the message;
- *   - dtype: GF_F32 (parity mode, exact-fp32 MFMA) or GF_F16 (fp16 storage, fp32 accumulate);
+ *   - dtype: GF_F32 (parity mode, exact-fp32 MFMA), GF_F16 or GF_BF16 (16-bit storage, fp32 accumulate);
  *   - data-dependent sizes (match counts) are produced in device memory; entry points that
  *     consume them read them from device memory too, so no host round trip is forced.
  */
@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 typedef enum { GF_OK = 0, GF_ERR_INVALID_ARGUMENT = -1, GF_ERR_WORKSPACE = -2, GF_ERR_LAUNCH = -3 } gf_status;
-typedef enum { GF_F32 = 0, GF_F16 = 1 } gf_dtype;
+typedef enum { GF_F32 = 0, GF_F16 = 1, GF_BF16 = 2 } gf_dtype;
 
 int gf_abi_version(void);
 const char* gf_last_error(void);

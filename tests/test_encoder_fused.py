@@ -48,28 +48,29 @@ def _layer(prefix, attention, activation, nhead):
     return m.to(DEV), W
 
 
-def _ulp_close(got, want, what):
+def _ulp_close(got, want, what, st=torch.float16):
     """fp16 outputs of a chain of five rounded GEMM stages: the two sides sum in different orders, so a value that sits
     within ~1e-7 of a rounding boundary lands on the other fp16 neighbour, and every such flip perturbs the whole
     next layer by a fraction of an ulp - exact equality is not attainable; agreement is to 2 ulp, with a mean
     difference far below one ulp."""
     got, want = got.float().cpu(), want.float()
-    torch.testing.assert_close(got, want, rtol=4e-3, atol=4e-3, msg=lambda m: f'{what}: {m}')
-    assert float((got - want).abs().mean()) < 3e-4, what
+    k = 1 if st == torch.float16 else 8                      # bf16: 8 significant bits against 11
+    torch.testing.assert_close(got, want, rtol=4e-3 * k, atol=4e-3 * k, msg=lambda m: f'{what}: {m}')
+    assert float((got - want).abs().mean()) < 3e-4 * k, what
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('st', [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('masked', [False, True])
-def test_kv_state_vs_oracle(masked):
+def test_kv_state_vs_oracle(masked, st):
     from geoformer_amd import fused
     layer, W = _layer(PFX, 'linear', 'relu', 8)
     g = torch.Generator().manual_seed(5)
     N, S = 2, 300                                           # 3 tiles per image, the last one ragged
-    src = O.rt(torch.randn(N, S, 256, generator=g) * 0.8, torch.float16)
+    src = O.rt(torch.randn(N, S, 256, generator=g) * 0.8, st)
     km = None
     if masked:
         km = torch.ones(N, S, dtype=torch.bool); km[0, 250:] = False; km[1, 10:40] = False
-    st = torch.float16
     k = torch.nn.functional.linear(src, O.rt(W[PFX + 'k_proj.weight'], st)).view(N, S, 8, 32)
     v = torch.nn.functional.linear(src, O.rt(W[PFX + 'v_proj.weight'], st)).view(N, S, 8, 32)
     Kf = O._phi(k)
@@ -78,17 +79,19 @@ def test_kv_state_vs_oracle(masked):
     K, V = O.rt(Kf, st), O.rt(v, st)
     KV = torch.einsum('nshd,nshv->nhdv', K, V).reshape(N, 256, 32)          # [c = h*32 + d][v]
     ref = torch.cat([KV.reshape(N, -1), Kf.sum(1).reshape(N, 256)], 1)
-    w = layer.weights(torch.float16)
-    got = fused.encoder_kv_state(src.to(DEV).half(), w['stream_kv'], None if km is None else km.to(DEV)).cpu()
-    torch.testing.assert_close(got, ref, rtol=1e-3, atol=1e-3 * float(ref.abs().max()))
+    w = layer.weights(st)
+    got = fused.encoder_kv_state(src.to(DEV).to(st), w['stream_kv'], None if km is None else km.to(DEV)).cpu()
+    tol = 1e-3 if st == torch.float16 else 8e-3
+    torch.testing.assert_close(got, ref, rtol=tol, atol=tol * float(ref.abs().max()))
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('st', [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('L,S,masked', [(256, 256, False), (300, 200, False), (200, 300, True)])
-def test_linear_attention_layer_vs_oracle(L, S, masked):
+def test_linear_attention_layer_vs_oracle(L, S, masked, st):
     layer, W = _layer(PFX, 'linear', 'relu', 8)
     g = torch.Generator().manual_seed(7)
-    N, st = 2, torch.float16
+    N = 2
     x = O.rt(torch.randn(N, L, 256, generator=g) * 0.7, st)
     src = O.rt(torch.randn(N, S, 256, generator=g) * 0.7, st)
     xm = sm = None
@@ -97,26 +100,27 @@ def test_linear_attention_layer_vs_oracle(L, S, masked):
         sm = torch.ones(N, S, dtype=torch.bool); sm[0, 280:] = False; sm[1, :17] = False
     ref = O.encoder_layer_fused(W, PFX, x, src, 8, st, xm, sm)
     with torch.no_grad():
-        got = layer(x.to(DEV).half(), src.to(DEV).half(), None if xm is None else xm.to(DEV), None if sm is None else sm.to(DEV))
-    assert got.dtype == torch.float16
-    _ulp_close(got, ref, f'layer L={L} S={S}')
+        got = layer(x.to(DEV).to(st), src.to(DEV).to(st), None if xm is None else xm.to(DEV), None if sm is None else sm.to(DEV))
+    assert got.dtype == st
+    _ulp_close(got, ref, f'layer L={L} S={S}', st)
 
 
 @pytest.mark.gpu
-def test_finish_vs_oracle_tanh_and_skip_flags():
+@pytest.mark.parametrize('st', [torch.float16, torch.bfloat16])
+def test_finish_vs_oracle_tanh_and_skip_flags(st):
     """The Geo form: attention output given, Tanh MLP, per-sample 'layer skipped' predicate."""
     layer, W = _layer(GPFX, 'full', 'tanh', 4)
     g = torch.Generator().manual_seed(9)
-    N, L, st = 3, 200, torch.float16
+    N, L = 3, 200
     x = O.rt(torch.randn(N, L, 256, generator=g) * 0.7, st)
     msg = O.rt(torch.randn(N, L, 256, generator=g) * 0.5, st)
     flag = torch.tensor([1, 0, 5], dtype=torch.int32)
     ref = O._finish_fused(W, GPFX, x, msg, 'geo', st)
     ref[1] = x[1]
     with torch.no_grad():
-        got = layer.finish(x.to(DEV).half(), msg.to(DEV).half(), flag.to(DEV), L)
-    _ulp_close(got, ref, 'finish tanh')
-    assert torch.equal(got[1].cpu(), x[1].half())           # a skipped sample is copied bit for bit
+        got = layer.finish(x.to(DEV).to(st), msg.to(DEV).to(st), flag.to(DEV), L)
+    _ulp_close(got, ref, 'finish tanh', st)
+    assert torch.equal(got[1].cpu(), x[1].to(st))           # a skipped sample is copied bit for bit
 
 
 @pytest.mark.gpu

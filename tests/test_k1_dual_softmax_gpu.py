@@ -60,7 +60,7 @@ def _planted(N, L, S, C, seed, noise=0.35, scale=1.3):
     return f0, f1
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('shape', [(1, 300, 500, 256), (2, 1200, 1184, 256), (1, 4800, 4560, 256)])
 def test_vs_oracle_ragged(shape, dtype):
     """Ragged sizes (not multiples of the 128 tile), oracle run on the SAME rounded inputs."""

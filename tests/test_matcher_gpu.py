@@ -1,6 +1,10 @@
 """Caller-side wrappers on the GPU: image loading/resizing, match_pairs return
 conventions, device RANSAC on sub-pixel matches, HPatches-protocol evaluation loop on a synthetic
-two-sequence dataset."""
+two-sequence dataset.
+
+The resize itself (PIL read + bilinear, half-pixel centres) is NOT pinned against cv2.resize: OpenCV is absent from the
+build container, so no table of its outputs can be produced here; what is pinned is everything downstream of the
+resized tensors."""
 import os
 
 import numpy as np
@@ -71,3 +75,47 @@ def test_command_line(tmp_path, capsys):
     assert z['matches'].shape[1] == 4 and len(z['scores']) == len(z['matches'])
     MT.main(['hpatches', root, '--imsize', '160', '--match-threshold', '0.0', '--max-seqs', '1'])
     assert 'auc_a' in capsys.readouterr().out
+
+
+def test_match_pairs_against_oracle_on_the_same_resized_tensors(tmp_path):
+    """match_pairs' numbers, not just its shapes: the matcher (fp32 mode, oracle weights) on two image files of different
+    sizes against the oracle run on the SAME resized tensors (`load_im`'s output): keypoints of the common matches equal,
+    `upscale` = the two resize ratios in (w0, h0, w1, h1) order, and the upscaled form = ratios x the resized form
+    (eval_tool/immatch/modules/geoformer.py:40-75: a swapped scale[0..3] or a wrong keypoint scale fails here)."""
+    import sys
+    from PIL import Image
+    import geoformer_oracle as O
+    import golden_inputs as GI
+    import ransac_oracle as RO
+    from geoformer_amd import matcher as MT
+    i0, i1 = GI.textured_pair(168, 200, 77)
+    big = torch.nn.functional.interpolate(i1, size=(210, 280), mode='bilinear', align_corners=False)    # other size and aspect
+    p0, p1 = str(tmp_path / 'a.png'), str(tmp_path / 'b.png')
+    Image.fromarray((i0[0, 0] * 255).round().byte().numpy()).save(p0)
+    Image.fromarray((big[0, 0] * 255).round().byte().numpy()).save(p1)
+    W = O.make_weights()
+
+    def make(noms):
+        m = MT.GeoFormerMatcher(imsize=160, match_threshold=0.0, no_match_upscale=noms, precision='fp32')
+        m.model.load_state_dict({k: v.clone() for k, v in W.items()})
+        m.model.fine_matching.thr = 0.0
+        return m
+    m = make(True)
+    g0, s0 = m.load_im(p0)
+    g1, s1 = m.load_im(p1)
+    assert tuple(g0.shape) == (1, 1, 160, 184) and tuple(g1.shape) == (1, 1, 160, 208)         # shorter side -> 160, floored to x8
+    assert s0 == (200 / 184, 168 / 160) and s1 == (280 / 208, 210 / 160)
+    matches, k0, k1, scores, upscale = m.match_pairs(p0, p1)
+    np.testing.assert_allclose(upscale, np.array(s0 + s1))
+    cfg = dict(O.default_geo_config(), coarse_thr=0.0, fine_thr=0.0)
+    ref = O.geoformer_forward(W, {'image0': g0.cpu(), 'image1': g1.cpu()}, None, cfg, RO.make_homography_fn())
+    want = {tuple(np.round(r, 3)) for r in torch.cat([ref['mkpts0_f'], ref['mkpts1_f']], 1).numpy().tolist()}
+    got = {tuple(np.round(r, 3)) for r in matches.tolist()}
+    assert len(want) > 50 and len(got & want) >= 0.9 * max(len(got), len(want)), (len(got), len(want), len(got & want))
+    np.testing.assert_array_equal(matches[:, :2], k0); np.testing.assert_array_equal(matches[:, 2:], k1)
+    assert len(scores) == len(matches) and float(scores.min()) >= 0 and float(scores.max()) <= 1
+    # the other return convention: keypoints scaled back to the original images
+    up, u0, u1, sc = make(False).match_pairs(p0, p1)
+    np.testing.assert_allclose(up, matches * np.array(s0 + s1)[None], rtol=1e-6)
+    np.testing.assert_allclose(u0, k0 * np.array(s0)[None], rtol=1e-6); np.testing.assert_allclose(u1, k1 * np.array(s1)[None], rtol=1e-6)
+    assert float(u0[:, 0].max()) <= 200 and float(u1[:, 0].max()) <= 280 and float(u1[:, 0].max()) > 208 * 0.9

@@ -13,6 +13,12 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
+def _tol(dtype, f32, f16):
+    """(rtol, atol) per storage type: bf16 keeps 8 significant bits against fp16's 11."""
+    return f32 if dtype == torch.float32 else f16 if dtype == torch.float16 else (8 * f16[0], 8 * f16[1])
+
+
+
 def close(a, b, rtol, atol):
     a = a.detach().double().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
     b = b.detach().double().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
@@ -63,7 +69,7 @@ def test_linear_attention_golden_fp32(golden):
     close(run(I['qf'], I['kf'], I['vf']), G['out_fine'], 2e-5, 2e-6)
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
 def test_linear_attention_coarse_shape(dtype):
     """Coarse-level shape (L = S = 6400, H 8, D 32), strided k/v views as produced by the fused kv GEMM."""
     from geoformer_amd import ops
@@ -74,7 +80,7 @@ def test_linear_attention_coarse_shape(dtype):
     out = ops.linear_attention(q.to(DEV), kv.to(DEV)[..., :256], kv.to(DEV)[..., 256:], H)
     ref = O.linear_attention(q.float().view(N, L, H, D), kv.float()[..., :256].reshape(N, S, H, D),
                              kv.float()[..., 256:].reshape(N, S, H, D)).reshape(N, L, -1)
-    tol = (1e-4, 1e-5) if dtype == torch.float32 else (2e-3, 2e-3)
+    tol = _tol(dtype, (1e-4, 1e-5), (2e-3, 2e-3))
     close(out, ref, *tol)
 
 
@@ -166,7 +172,7 @@ def test_inlier_index():
 
 
 # ------------------------------------------------------------------ K4
-@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
 def test_self_attention_gathered(dtype):
     from geoformer_amd import ops
     g = torch.Generator().manual_seed(4)
@@ -179,7 +185,7 @@ def test_self_attention_gathered(dtype):
         idx[b, :nk[b]] = torch.sort(torch.randperm(L, generator=g)[:nk[b]])[0].int()
     nkeys = torch.tensor(nk, dtype=torch.int32)
     out = ops.self_attention_gathered(q.to(DEV), kv.to(DEV)[..., :C], kv.to(DEV)[..., C:], idx.to(DEV), nkeys.to(DEV), H)
-    tol = (1e-4, 1e-5) if dtype == torch.float32 else (4e-3, 4e-3)
+    tol = _tol(dtype, (1e-4, 1e-5), (4e-3, 4e-3))
     for b in range(N):
         if nk[b] == 0:
             assert float(out[b].abs().max()) == 0.0
@@ -191,7 +197,7 @@ def test_self_attention_gathered(dtype):
 
 
 # ------------------------------------------------------------------ K5
-@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
 def test_window_cross_attention(dtype):
     from geoformer_amd import ops
     g = torch.Generator().manual_seed(5)
@@ -204,7 +210,7 @@ def test_window_cross_attention(dtype):
     win[1, 8, 1:] = -1
     valid = torch.tensor([1, 1], dtype=torch.int32)
     out = ops.window_cross_attention(q.to(DEV), kv.to(DEV)[..., :C], kv.to(DEV)[..., C:], win.to(DEV), valid.to(DEV), H)
-    tol = (1e-4, 1e-5) if dtype == torch.float32 else (4e-3, 4e-3)
+    tol = _tol(dtype, (1e-4, 1e-5), (4e-3, 4e-3))
     for b in range(N):
         cell = win[b].clamp(min=0).long()
         ks, vs = kv[b, :, :C].float()[cell], kv[b, :, C:].float()[cell]          # [L, 25, C]
@@ -312,7 +318,7 @@ def test_geo_module_golden(golden, tag):
 
 
 # ------------------------------------------------------------------ K3
-@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('C', [256, 128])
 def test_linear_epilogues(dtype, C):
     """gf_linear against the same ops in plain PyTorch fp32 on the same (rounded) inputs."""
@@ -329,7 +335,7 @@ def test_linear_epilogues(dtype, C):
     bias = 0.1 * torch.randn(C, generator=g)
     d = lambda t: t.to(DEV)
     f = lambda t: t.float()
-    tol = (2e-4, 2e-5) if dtype == torch.float32 else (5e-3, 5e-3)
+    tol = _tol(dtype, (2e-4, 2e-5), (5e-3, 5e-3))
     # plain, strided input view (as the k|v split produces) and bias
     wide = torch.randn(M, 2 * C, generator=g).to(dtype)
     close(ops.linear(d(wide)[:, C:], d(w_sq), bias=d(bias)), F.linear(f(wide)[:, C:], f(w_sq), bias), *tol)
@@ -358,7 +364,7 @@ def test_linear_epilogues(dtype, C):
 # ---------------------------------------------------------------------------------------------
 # backbone glue (fp16 inference backbone): torch fp32 reference of the same op
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('dtype,C', [(torch.float16, 128), (torch.float16, 196), (torch.float32, 196)])
+@pytest.mark.parametrize('dtype,C', [(torch.float16, 128), (torch.float16, 196), (torch.float32, 196), (torch.bfloat16, 224)])
 @pytest.mark.parametrize('act', [0, 1, 2])
 def test_bias_act_vs_torch(dtype, C, act):
     from geoformer_amd import ops
@@ -370,14 +376,14 @@ def test_bias_act_vs_torch(dtype, C, act):
     ref = [ref, torch.relu(ref), torch.nn.functional.leaky_relu(ref, 0.01)][act]
     out = ops.bias_act_(x.clone(memory_format=torch.channels_last), b, r, act, 0.01)
     assert out.is_contiguous(memory_format=torch.channels_last)
-    tol = 1e-6 if dtype == torch.float32 else 2e-3          # one fp16 rounding of an O(1) value
+    tol = {torch.float32: 1e-6, torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dtype]          # one rounding of an O(1) value
     assert torch.allclose(out.float(), ref, atol=tol * 4, rtol=tol)
     # no bias / no residual
     out2 = ops.bias_act_(x.clone(memory_format=torch.channels_last), None, None, 1)
     assert torch.equal(out2, torch.relu(x))
 
 
-@pytest.mark.parametrize('dtype,C', [(torch.float16, 256), (torch.float16, 196), (torch.float32, 196)])
+@pytest.mark.parametrize('dtype,C', [(torch.float16, 256), (torch.float16, 196), (torch.float32, 196), (torch.bfloat16, 224)])
 def test_upsample_add_vs_torch(dtype, C):
     from geoformer_amd import ops
     torch.manual_seed(4)
@@ -385,12 +391,13 @@ def test_upsample_add_vs_torch(dtype, C):
     hi = torch.randn(2, C, 30, 40, device='cuda').to(dtype).contiguous(memory_format=torch.channels_last)
     ref = hi.float() + torch.nn.functional.interpolate(lo.float(), size=(30, 40), mode='bilinear', align_corners=True)
     out = ops.upsample_add_(hi.clone(memory_format=torch.channels_last), lo)
-    tol = 1e-5 if dtype == torch.float32 else 2e-3
+    tol = {torch.float32: 1e-5, torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dtype]
     assert torch.allclose(out.float(), ref, atol=tol * 4, rtol=tol)
 
 
-def test_fused_backbone_vs_module():
-    """fp16 fused inference backbone against the fp32 nn.Module (eval mode, non-trivial BN statistics)."""
+@pytest.mark.parametrize('dtype,bound', [(torch.float16, 2e-2), (torch.bfloat16, 1e-1)])
+def test_fused_backbone_vs_module(dtype, bound):
+    """16-bit fused inference backbone against the fp32 nn.Module (eval mode, non-trivial BN statistics)."""
     from geoformer_amd.model.backbone import FusedInferenceBackbone, build_backbone
     from geoformer_amd.model.cvpr_ds_config import get_default_cfg
     torch.manual_seed(5)
@@ -404,11 +411,11 @@ def test_fused_backbone_vs_module():
     x = torch.rand(2, 1, 64, 96, device='cuda')
     with torch.no_grad():
         c3, c1 = bb(x)
-        f3, f1 = FusedInferenceBackbone(bb, torch.float16)(x)
+        f3, f1 = FusedInferenceBackbone(bb, dtype)(x)
     assert f3.shape == c3.shape and f1.shape == c1.shape
     for f, c in ((f3, c3), (f1, c1)):
         err = (f.float() - c).abs().max().item() / c.abs().max().item()
-        assert err < 2e-2, err                                  # fp16 weights + activations through 20 convolutions
+        assert err < bound, err                                 # 16-bit weights + activations through 20 convolutions
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16])

@@ -14,7 +14,7 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $ROOT
-BENCH="python3 bench.py --streams 1 --no-cpu-baseline $*"
+BENCH="python3 bench.py --streams 1 --no-cpu-baseline --no-extras $*"
 echo "== kernel trace: $BENCH"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o run -- $BENCH --steps 10 --warmup 3 > $OUT/${TAG}_trace.json 2> $OUT/${TAG}_trace.err
 echo "rc=$?"
@@ -32,6 +32,6 @@ echo "rc=$?"
 # keep the merged-back payload small: only the per-kernel csv files are needed
 find $OUT/${TAG}_trace $OUT/${TAG}_pmc_sq $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write -type f ! -name '*.csv' -delete 2>/dev/null
 python3 tools/prof_summary.py $OUT/${TAG}_trace > $OUT/${TAG}_trace_summary.txt 2>&1
-python3 tools/pmc_roofline.py $OUT $TAG > $OUT/${TAG}_pmc_summary.txt 2>&1
+python3 tools/pmc_roofline.py $OUT $TAG --tags $OUT/${TAG}_pmc_per_tag.json > $OUT/${TAG}_pmc_summary.txt 2>&1
 tail -5 $OUT/${TAG}_trace.err
 cat $OUT/${TAG}_trace.json | tail -1 | cut -c1-600

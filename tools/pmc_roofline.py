@@ -19,10 +19,59 @@ import re
 import sys
 
 
+_DEMANGLED = {}
+
+
 def family(name):
+    """Kernel family = the function name without namespace, return type and argument list; template arguments kept
+    (`linear_kernel<_Float16, 8, 4>`); mangled names (rocprofv3 leaves some) go through c++filt."""
+    if name.startswith('_Z'):
+        if name not in _DEMANGLED:
+            import subprocess
+            try:
+                _DEMANGLED[name] = subprocess.run(['c++filt', name], capture_output=True, text=True).stdout.strip() or name
+            except OSError:
+                _DEMANGLED[name] = name
+        name = _DEMANGLED[name]
+        m = re.match(r'^_ZN12_GLOBAL__N_1(\d+)', name)
+        if m:      # c++filt does not know _Float16 (DF16_): decode `name<template args>` of our own kernels by hand
+            n = int(m.group(1))
+            ident, rest = name[m.end():m.end() + n], name[m.end() + n:]
+            args = []
+            if rest.startswith('I'):
+                for tok in re.findall(r'DF16_|DF16b|Li\d+E|Lb\dE|f', rest[1:rest.index('EE') + 1] if 'EE' in rest else rest[1:]):
+                    args.append({'DF16_': '_Float16', 'DF16b': '__bf16', 'f': 'float'}.get(tok) or
+                                (tok[2:-1] if tok.startswith('Li') else ('true' if tok == 'Lb1E' else 'false')))
+            name = ident + ('<' + ', '.join(args) + '>' if args else '')
     name = re.sub(r'\(anonymous namespace\)::', '', name)
     name = re.sub(r'^void ', '', name)
-    return name.split('(')[0][:64]
+    depth, out = 0, []
+    for ch in name:                      # cut at the '(' that opens the argument list (template args may hold parentheses)
+        if ch == '<':
+            depth += 1
+        elif ch == '>':
+            depth -= 1
+        elif ch == '(' and depth == 0:
+            break
+        out.append(ch)
+    return ''.join(out)[:72]
+
+
+# bench.py's roofline tags -> the kernel families a tagged call launches (substring match on the family name)
+TAG_FAMILIES = {
+    'enc_layer': ['enc_layer<'],
+    'enc_kv_state': ['enc_kv_state<', 'enc_kv_reduce'],
+    'k3_linear': ['linear_kernel'],
+    'k1_stats': ['k1_stats'],
+    'k1_conf': ['k1_conf'],
+    'k2_linear_attention': ['la16_', 'la_kv_', 'la_apply', 'la_small'],
+    'k5_window_attention': ['window_cross_attention'],
+    'bias_act': ['bias_act<'],
+}
+# the family whose call count equals the number of tagged calls
+TAG_PRIMARY = {'enc_layer': 'enc_layer<', 'enc_kv_state': 'enc_kv_state<', 'k3_linear': 'linear_kernel', 'k1_stats': 'k1_stats',
+               'k1_conf': 'k1_conf', 'k2_linear_attention': ('la16_apply', 'la_apply', 'la_small'), 'k5_window_attention': 'window_cross_attention',
+               'bias_act': 'bias_act<'}
 
 
 def counters(d):
@@ -75,8 +124,31 @@ def main():
         hb = r.get('hbm_bytes', float('nan'))
         print(f'{r["kernel"][:44]:44s} {r["calls"]:5d} {r["avg_us"]:8.1f} {r["share"] * 100:5.1f}% {r.get("mfma_insts", float("nan")):11.0f} '
               f'{mu:17.3f} {hb / 1e6:9.1f} {hb / (r["avg_us"] * 1e-6) / 1e9:7.0f}')
+    # per bench.py tag: PMC HBM bytes per tagged call and MFMA utilisation (SQ_VALU_MFMA_BUSY_CYCLES summed over the
+    # 1024 SIMDs / (GRBM_GUI_ACTIVE per XCD x 1024): the gfx9 MfmaUtil expression of rocprofv3's counter definitions)
+    per_tag = {}
+    print()
+    print(f'{"tag":22s} {"calls":>6s} {"avg_us":>8s} {"HBM MB/call":>12s} {"GB/s":>7s} {"mfma_util":>9s}')
+    for tag, pats in TAG_FAMILIES.items():
+        fam = [r for r in rows if any(p in r['kernel'] for p in pats)]
+        if not fam:
+            continue
+        prim = TAG_PRIMARY[tag]
+        prim = prim if isinstance(prim, tuple) else (prim,)
+        calls = sum(r['calls'] for r in fam if any(p in r['kernel'] for p in prim)) or 1
+        t_us = sum(r['calls'] * r['avg_us'] for r in fam)
+        hbm = sum(r['calls'] * r['hbm_bytes'] for r in fam if 'hbm_bytes' in r)
+        mb = sum(r['calls'] * r.get('mfma_busy_cycles', 0.0) for r in fam)
+        ga = sum(r['calls'] * r.get('gui_active', 0.0) for r in fam)
+        util = mb / (ga / 8.0 * 1024.0) if ga else None
+        per_tag[tag] = {'calls': calls, 'avg_us_per_call': t_us / calls, 'hbm_bytes_per_launch': hbm / calls if hbm else None,
+                        'mfma_util': util, 'families': sorted({r['kernel'] for r in fam})}
+        print(f'{tag:22s} {calls:6d} {t_us / calls:8.1f} {hbm / calls / 1e6:12.1f} {hbm / max(t_us, 1e-9) * 1e-3:7.0f} '
+              f'{(util if util is not None else float("nan")):9.3f}')
     if '--json' in sys.argv:
         json.dump(rows, open(sys.argv[sys.argv.index('--json') + 1], 'w'), indent=1)
+    if '--tags' in sys.argv:
+        json.dump(per_tag, open(sys.argv[sys.argv.index('--tags') + 1], 'w'), indent=1)
 
 
 if __name__ == '__main__':
