@@ -57,14 +57,16 @@ def parse_args(argv=None):
     ap.add_argument('--batch', type=int, default=8, help='pairs per GPU per step')
     ap.add_argument('--size', type=int, default=640)
     ap.add_argument('--precision', default='fp16', choices=['fp16', 'bf16', 'fp32'])
-    ap.add_argument('--pairs', default='homography', choices=['homography', 'shift'],
+    ap.add_argument('--pairs', default='homography', choices=['homography', 'shift', 'planted'],
                     help="image1 = image0 under a random homography (default), or shifted by one coarse cell (the pair of "
-                         "the reference's CPU measurement, BASELINE.md section 2: ~2400 coarse matches per pair)")
+                         "the reference's CPU measurement, BASELINE.md section 2), or 'planted': the nominal-load workload of the "
+                         "side measurement as the main one (planted-correspondence feature maps, thresholds 0.2 / 0.1)")
     ap.add_argument('--coarse-thr', type=float, default=0.0)
     ap.add_argument('--fine-thr', type=float, default=0.0)
     ap.add_argument('--streams', type=int, default=2, help='concurrent forward pipelines (host threads, one HIP stream each)')
     ap.add_argument('--tune', action='store_true', help='let MIOpen search its convolution algorithms (minutes)')
     ap.add_argument('--save-db', action='store_true', help='with --tune: copy the searched find-db over geoformer_amd/miopen_db')
+    ap.add_argument('--graphs', action='store_true', help='replay the static part of the forward from a captured hipGraph (GeoFormer.enable_graphs)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the nominal-load and fp32 parity-mode side measurements')
     ap.add_argument('--dry-run', action='store_true',
@@ -294,15 +296,37 @@ class Pipelines:
             q.put(None)
 
 
-def measure(model, batches, steps, warmup, nstreams, dev, dist, log, profile_tag=None, L=None):
-    """W untimed + K timed steps of `model` over the resident `batches`; returns (elapsed_s, pipelines)."""
+def planted_features(batch, seed, grid=80, noise=0.35, device='cpu', dtype=None):
+    """Stand-in backbone outputs with planted correspondences (the construction of the parity fixtures, restated): the
+    coarse and fine maps of image 1 are those of image 0 shifted by one coarse cell plus noise, so that the matching
+    path runs at its nominal load (thousands of coarse matches at the reference's coarse_thr = 0.2,
+    as many inlier cells) whatever the weights are."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    h = grid + 1
+    big = torch.randn(batch, 256, h, h, generator=g) * 0.5
+    bigf = torch.randn(batch, 128, 4 * h, 4 * h, generator=g)
+    c0, f0 = big[:, :, :grid, :grid], bigf[:, :, :4 * grid, :4 * grid]
+    c1 = big[:, :, 1:, 1:] + noise * torch.randn(batch, 256, grid, grid, generator=g)
+    f1 = bigf[:, :, 4:, 4:] + noise * torch.randn(batch, 128, 4 * grid, 4 * grid, generator=g)
+    # channels_last, like the maps the backbone emits (the fine-window gather reads 256-byte channel rows)
+    return tuple(t.to(device=device, dtype=dtype).contiguous(memory_format=torch.channels_last) for t in (c0, f0, c1, f1))
+
+
+def measure(model, batches, steps, warmup, nstreams, dev, dist, log, profile_tag=None, L=None, planted=None):
+    """W untimed + K timed steps of `model` over the resident `batches`; returns (elapsed_s, pipelines, step_fn).
+    planted = per-batch (c0, f0, c1, f1): the backbone still runs on the images (its cost stays in the step) but the
+    matching path is fed the planted feature maps."""
     import torch
     nres = len(batches)
 
     def step(i):
         i0, i1 = batches[i % nres]
         with torch.no_grad():
-            return model({'image0': i0, 'image1': i1})
+            if planted is None:
+                return model({'image0': i0, 'image1': i1})
+            model._backbone(torch.cat([i0, i1], dim=0))
+            return model.forward_features({'image0': i0, 'image1': i1}, *planted[i % nres])
     pipes = Pipelines(step, max(1, min(nstreams, steps)), dev)
     step(0)                          # single-threaded first pass: fills the weight / table caches
     torch.cuda.synchronize()
@@ -371,7 +395,11 @@ def main(argv=None):
     def log(msg):
         if rank == 0:
             print(f'[bench +{time.perf_counter() - tlog:6.1f}s] {msg}', file=sys.stderr, flush=True)
+    if args.pairs == 'planted' and args.coarse_thr == 0.0 and args.fine_thr == 0.0:
+        args.coarse_thr, args.fine_thr = 0.2, 0.1          # the reference's thresholds (geo_config.py:13,15)
     model, W = build_model(args.precision, args.coarse_thr, args.fine_thr, dev)
+    if args.graphs:
+        model.enable_graphs()
     # static shard: the job is the pair list 0 .. world*steps*batch-1; this rank owns the contiguous block
     # [lo, hi).  A few distinct batches of the block are kept resident and cycled so that HBM holds the inputs
     # before the timed region starts.
@@ -381,7 +409,12 @@ def main(argv=None):
 
     def resident(kind):
         return [synth_pairs(args.batch, seed=lo + i * args.batch, size=args.size, device=dev, kind=kind) for i in range(nres)]
-    batches = resident(args.pairs)
+    planted = None
+    if args.pairs == 'planted':
+        batches = resident('shift')
+        planted = [planted_features(args.batch, 60000 + lo + i, args.size // 8, device=dev, dtype=model.compute_dtype) for i in range(nres)]
+    else:
+        batches = resident(args.pairs)
     log('model + inputs ready')
 
     def backbone_ms_per_pair():
@@ -404,7 +437,7 @@ def main(argv=None):
         bb_ms = backbone_ms_per_pair()
         log(f'backbone {bb_ms:.2f} ms/pair after the search')
 
-    elapsed, pipes, step = measure(model, batches, args.steps, args.warmup, args.streams, dev, dist, log, b'k1_conf', L)
+    elapsed, pipes, step = measure(model, batches, args.steps, args.warmup, args.streams, dev, dist, log, b'k1_conf', L, planted)
     log('timed region done')
     nstreams = 1 if pipes.serial else pipes.n
     res_rows = [pipes.results[i] for i in range(args.warmup, args.warmup + args.steps)]
@@ -499,7 +532,7 @@ def main(argv=None):
     if world == 1 and not args.no_extras:
         res['side_measurements'] = side_measurements(args, model, dev, log, L)
     if not args.no_cpu_baseline and world == 1:          # reported on rank 0 at N = 1 only
-        res['cpu_baseline'] = cpu_baseline(W, args.coarse_thr, args.fine_thr, args.size, args.pairs)
+        res['cpu_baseline'] = cpu_baseline(W, args.coarse_thr, args.fine_thr, args.size, 'shift' if args.pairs == 'planted' else args.pairs)
     print(json.dumps(res), flush=True)
     if args.tune and args.save_db:
         gf_miopen.save_find_db()             # an explicit search: keep its picks for the next process
@@ -509,25 +542,33 @@ def main(argv=None):
 
 def side_measurements(args, model, dev, log, L):
     """Two more throughput figures of the same job, N = 1 only (they are not `value`):
-      nominal_load   image1 = image0 shifted by one coarse cell, the pair of the reference's own CPU timing
-                     (BASELINE.md section 2): thousands of coarse matches and hundreds of inlier cells per pair, i.e. the
-                     load SURVEY section 8 sizes the path for (M ~ 2000), where K4 / K7 / K8 / loftr_fine carry real work;
+      nominal_load   the load SURVEY section 8 sizes the path for (M ~ 2000 coarse matches, K ~ 1000+ inlier cells per pair at
+                     the reference's thresholds), where K4 / K7 / K8 / loftr_fine carry real work: random-init weights
+                     cannot produce it from images, so the matching path is fed planted-correspondence feature maps
+                     while the backbone still runs on the images;
       parity_mode    the fp32 mode in which coarse indices are bit-exact against the reference's golden vectors."""
+    import torch
     out = {}
     steps = max(4, min(args.steps, 100))
-    shift = [synth_pairs(args.batch, seed=50000 + i * args.batch, size=args.size, device=dev, kind='shift') for i in range(4)]
-    el, p, _ = measure(model, shift, steps, 3, args.streams, dev, None, log)
+    mn, _ = build_model(args.precision, 0.2, 0.1, dev)                  # the reference's thresholds (geo_config.py:13,15)
+    imgs = [synth_pairs(args.batch, seed=50000 + i * args.batch, size=args.size, device=dev, kind='shift') for i in range(2)]
+    feats = [planted_features(args.batch, 60000 + i, args.size // 8, device=dev, dtype=mn.compute_dtype) for i in range(2)]
+    el, p, _ = measure(mn, imgs, steps, 3, args.streams, dev, None, log, planted=feats)
     rr = [p.results[i] for i in range(3, 3 + steps)]
     p.close()
     nidx = rr[-1][2]
     out['nominal_load'] = {'value': steps * args.batch / el, 'unit': 'image-pairs/s', 'steps': steps, 'ms_per_step': 1e3 * el / steps,
-                           'pairs': 'shift by one coarse cell (BASELINE.md section 2)', 'dtype': {'fp16': 'f16', 'bf16': 'bf16', 'fp32': 'f32'}[args.precision],
+                           'pairs': 'backbone on the images + matching path on planted-correspondence feature maps (shift by one '
+                                    'coarse cell + noise), coarse_thr 0.2, fine_thr 0.1',
+                           'dtype': {'fp16': 'f16', 'bf16': 'bf16', 'fp32': 'f32'}[args.precision],
                            'coarse_matches_per_pair': sum(r[0] for r in rr) / len(rr) / args.batch,
                            'fine_matches_per_pair': sum(r[1] for r in rr) / len(rr) / args.batch,
                            'inlier_cells_per_pair': int(nidx[:, 0].float().mean()) if nidx is not None else None}
-    log(f"nominal load: {out['nominal_load']['value']:.1f} pairs/s at M = {out['nominal_load']['coarse_matches_per_pair']:.0f}")
+    del mn, feats
+    torch.cuda.empty_cache()
+    log(f"nominal load: {out['nominal_load']['value']:.1f} pairs/s at M = {out['nominal_load']['coarse_matches_per_pair']:.0f}, "
+        f"K = {out['nominal_load']['inlier_cells_per_pair']}")
     if args.precision != 'fp32':
-        import torch
         m32, _ = build_model('fp32', args.coarse_thr, args.fine_thr, dev)
         homo = [synth_pairs(args.batch, seed=i * args.batch, size=args.size, device=dev, kind=args.pairs) for i in range(2)]
         s32 = max(4, min(args.steps, 10))

@@ -73,10 +73,51 @@ class GeoFormer(nn.Module):
             return self._inference_backbone()(x)
         return self.backbone(x)
 
+    # -- hipGraph replay of the static part.  Everything before the first host synchronisation has
+    # data-independent launches (the device RANSAC and the device-side counts keep it that way), so per (shapes, stream)
+    # it is captured once with torch.cuda.graph - MIOpen convolutions and the library's own launches alike - and
+    # replayed on inputs copied into the capture's static buffers.  On one GPU the eager path is already GPU-bound
+    # (17.15 ms eager vs 17.13 ms replayed per 8 pairs), so this is OFF by default; it takes ~250 launches per batch
+    # off the host, which matters when one host feeds many GPUs.
+    def enable_graphs(self, on: bool = True):
+        self._graphs = {} if on else None
+        return self
+
+    def _forward_graphed(self, data):
+        img0, img1 = data['image0'], data['image1']
+        key = (tuple(img0.shape), tuple(img1.shape), img0.dtype, torch.cuda.current_stream().cuda_stream)
+        entry = self._graphs.get(key)
+        if entry is None:
+            # warm-up ON the stream the capture will use: MIOpen keeps a handle (and its algorithm picks / workspaces) per
+            # stream and this library a workspace per stream - their first use must not fall inside the capture
+            cur, side = torch.cuda.current_stream(), torch.cuda.Stream()
+            s0, s1 = img0.clone(), img1.clone()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self.forward_static({'image0': s0, 'image1': s1})
+            side.synchronize()
+            g = torch.cuda.CUDAGraph()
+            cap = {'image0': s0, 'image1': s1}
+            with torch.cuda.graph(g, stream=side):
+                self.forward_static(cap)
+            entry = self._graphs[key] = (g, s0, s1, cap, side)
+        g, s0, s1, cap = entry[:4]
+        s0.copy_(img0)
+        s1.copy_(img1)
+        g.replay()
+        data.update({k: v for k, v in cap.items() if k not in ('image0', 'image1')})
+        data['_static'] = dict(cap['_static'])                   # the tensors are the capture's static outputs: consumed below
+        data['_backbone_feats'] = tuple(cap['_static'][k] for k in ('feat_c0', 'feat_f0', 'feat_c1', 'feat_f1'))
+        return self.forward_dynamic(data)
+
     def forward(self, data: Dict[str, torch.Tensor]):
         img0, img1 = data['image0'], data['image1']
         if not img0.is_cuda:
             raise RuntimeError('geoformer_amd.GeoFormer runs on an MI355X (CUDA/HIP device) only; there is no CPU path')
+        if (getattr(self, '_graphs', None) is not None and not self.training and 'mask0' not in data and 'scale0' not in data
+                and self.geo_module.homography_fn is None):
+            return self._forward_graphed(data)
         data.update({'bs': torch.tensor(img0.size(0)), 'hw0_i': torch.tensor(img0.shape[2:]),
                      'hw1_i': torch.tensor(img1.shape[2:])})
         n = img0.size(0)
@@ -88,7 +129,33 @@ class GeoFormer(nn.Module):
             (feat_c0, feat_f0), (feat_c1, feat_f1) = self._backbone(img0), self._backbone(img1)
         return self.forward_features(data, feat_c0, feat_f0, feat_c1, feat_f1)
 
-    def forward_features(self, data, feat_c0, feat_f0, feat_c1, feat_f1):
+    def forward_static(self, data):
+        """The part of the forward whose launches do not depend on data: backbone -> ... -> second coarse matching, with
+        the match arrays at capacity and their counts on the device.  No host synchronisation: it can be captured into a
+        hipGraph (torch.cuda.graph) and replayed; `forward_dynamic` finishes the forward from its result."""
+        img0, img1 = data['image0'], data['image1']
+        data.update({'bs': torch.tensor(img0.size(0)), 'hw0_i': torch.tensor(img0.shape[2:]), 'hw1_i': torch.tensor(img1.shape[2:])})
+        n = img0.size(0)
+        if img0.shape[2:] == img1.shape[2:]:
+            feats_c, feats_f = self._backbone(torch.cat([img0, img1], dim=0))
+            (feat_c0, feat_c1), (feat_f0, feat_f1) = feats_c.split(n), feats_f.split(n)
+        else:
+            (feat_c0, feat_f0), (feat_c1, feat_f1) = self._backbone(img0), self._backbone(img1)
+        return self.forward_features(data, feat_c0, feat_f0, feat_c1, feat_f1, static_only=True)
+
+    def forward_dynamic(self, data):
+        """Host sync #1 (number of coarse matches), fine level, fine matching (host sync #2)."""
+        st = data.pop('_static')
+        data.update(materialize_matches(st['raw']))
+        f0u, f1u = self.fine_preprocess(st['feat_f0'], st['feat_f1'], st['geo0'], st['geo1'], data)
+        if f0u.size(0) != 0:
+            f0u, f1u = self.loftr_fine(f0u, f1u)
+        self.fine_matching(f0u, f1u, data)
+        data['_feat_dev'] = {'loftr_f0': st['feat0'], 'loftr_f1': st['feat1'], 'geo_f0': st['geo0'], 'geo_f1': st['geo1'],
+                             'fine_f0': f0u, 'fine_f1': f1u}
+        return data
+
+    def forward_features(self, data, feat_c0, feat_f0, feat_c1, feat_f1, static_only=False):
         """Everything after the backbone.  Public so that parity tests and benchmarks can drive the
         matching path with given feature maps ([N,256,h,w] coarse, [N,128,4h,4w] fine)."""
         dt = self.compute_dtype
@@ -110,15 +177,12 @@ class GeoFormer(nn.Module):
         same_pe = self.pos_encoding.temp_bug_fix == self.geo_module.pos_encoding.temp_bug_fix
         geo0, geo1 = self.geo_module(feat_c0, feat_c1, data, pe0 if same_pe else None, pe1 if same_pe else None, dt)
         raw = self.coarse_matching(geo0, geo1, data, mask_c0=mask_c0, mask_c1=mask_c1, lazy=True)
-        data.update(materialize_matches(raw))                      # host sync #1: M
-        # 4. fine level
-        f0u, f1u = self.fine_preprocess(feat_f0, feat_f1, geo0, geo1, data)
-        if f0u.size(0) != 0:
-            f0u, f1u = self.loftr_fine(f0u, f1u)
-        # 5. fine matching                                         # host sync #2: Mf
-        self.fine_matching(f0u, f1u, data)
-        data['_feat_dev'] = {'loftr_f0': feat0, 'loftr_f1': feat1, 'geo_f0': geo0, 'geo_f1': geo1, 'fine_f0': f0u, 'fine_f1': f1u}
-        return data
+        data['_static'] = {'raw': raw, 'feat_c0': feat_c0, 'feat_c1': feat_c1, 'feat_f0': feat_f0, 'feat_f1': feat_f1, 'geo0': geo0, 'geo1': geo1,
+                           'feat0': feat0, 'feat1': feat1}
+        if static_only:
+            return data
+        # 4. host sync #1 (M), fine level, 5. fine matching (host sync #2: Mf)
+        return self.forward_dynamic(data)
 
     def load_state_dict(self, state_dict, *args, **kwargs):
         for k in list(state_dict.keys()):

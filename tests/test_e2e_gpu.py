@@ -291,3 +291,31 @@ def test_bf16_mode_vs_storage_oracle(golden, name):
     G = golden(name)
     g = set(zip(G['out_b_ids'].tolist(), G['out_i_ids'].tolist(), G['out_j_ids'].tolist()))
     assert len(a & g) >= 0.8 * max(len(a), len(g)), (len(a), len(g), len(a & g))
+
+
+def test_graph_replay_equals_eager():
+    """GeoFormer.enable_graphs(): the static part (backbone .. second coarse matching) replayed from a captured hipGraph
+    against the eager matching path on the replay's own backbone features, bit for bit, also on a second, different input
+    (static-buffer reuse).  (The backbone itself is compared to fp16 resolution only: MIOpen may pick another convolution
+    algorithm under capture for shapes outside the shipped find-db - 1-ulp different feature maps.)"""
+    from geoformer_amd import miopen
+    miopen.use_shipped_find_db()
+    m = build(0.0, 0.0, 'fp16')
+    pairs = [[t.to(DEV) for t in GI.textured_pair(128, 160, 900 + k)] for k in range(2)]
+    keys = ('b_ids', 'i_ids', 'j_ids', 'mkpts0_f', 'mkpts1_f', 'mconf', 'conf_matrix', 'dect_conf_matrix')
+    with torch.no_grad():
+        m.enable_graphs()
+        graphed = []
+        for i0, i1 in pairs:
+            out = m({'image0': i0, 'image1': i1})
+            graphed.append(({k: out[k].clone() for k in keys}, tuple(t.clone() for t in out['_backbone_feats'])))
+        assert len(m._graphs) == 1
+        m.enable_graphs(False)
+        for (i0, i1), (got, feats) in zip(pairs, graphed):
+            ref = m.forward_features({'image0': i0, 'image1': i1}, *feats)
+            assert len(ref['b_ids']) > 10
+            for k in keys:
+                assert torch.equal(got[k], ref[k]), k
+            c0_eager = m._backbone(torch.cat([i0, i1], 0))[0][:1]
+            assert float((c0_eager.float() - feats[0].float()).abs().max()) < 0.05 * float(c0_eager.float().abs().max())
+    assert not torch.equal(graphed[0][0]['conf_matrix'], graphed[1][0]['conf_matrix'])
