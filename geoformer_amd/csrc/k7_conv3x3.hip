@@ -1,0 +1,403 @@
+// K7: 3x3 / stride 1 / pad 1 convolution of channels-last 16-bit maps with the BatchNorm shift, the BasicBlock
+// shortcut and the activation in its epilogue - the backbone's dominant shapes (SURVEY 8f rank 4:
+// model/loftr_src/loftr/backbone/resnet_fpn.py:9-40 BasicBlock, :60-83 the FPN heads), as an implicit GEMM on the
+// matrix cores:   out[n,y,x,:] = act( sum_{ky,kx} W[:, :, ky, kx] . x[n, y+ky-1, x+kx-1, :] + shift + shortcut[n,y,x,:] )
+//
+// Same machinery as K6 (k6_encoder_fused.hip): one wave per SIMD, products transposed (MFMA A = 32 output channels,
+// B = 32 pixels, so a pixel's channels sit in one lane's registers), weights pre-packed on the host into the exact
+// sequence of 1-KiB MFMA A fragments the kernel consumes and streamed from L2 through a two-block LDS ring by LDS-DMA;
+// the fragments of step i+1 (weights AND pixels) are requested before the MFMAs of step i.
+//   workgroup = 4 waves = an 8-row x 32-column pixel tile of one image; a wave owns two rows (two 32-pixel blocks):
+//               every weight fragment feeds two MFMAs, 2 x COUT/32 accumulator tiles per wave (outputs wider than 128
+//               channels: 4-row tiles, one row per wave);
+//   K loop     = input channels in chunks of 32 (two 16-deep k-steps) x 9 taps: one STEP = (chunk, tap, k-step) =
+//               COUT/32 weight fragments, PB pixel fragments, PB x COUT/32 MFMAs; a weight block = 6 steps, so the ring
+//               turns at fixed places of a chunk (steps 5, 11, 17);
+//   pixels     = per chunk the halo patch of the tile (64 B per pixel) sits in LDS, double-buffered: the next chunk's
+//               (or the next tile's first) patch arrives by LDS-DMA while the current one is multiplied; pixels outside
+//               the image are read from a page of zeros (per-lane DMA source address); the 16-byte slot index is XORed
+//               with (pixel >> 2) & 3 on the source side so that the fragment reads of 32 consecutive pixels spread
+//               over the LDS banks;
+//   persistent = min(tiles, 256) workgroups walk the tiles (25 rounds at 16 x 320 x 320); the ring and the patch
+//               buffers run on across tiles (the next tile's first blocks and patch are requested during the last
+//               chunk), and the epilogue is wave-private: no workgroup barrier besides the ring turns;
+//   epilogue   = the shortcut rows are fetched into registers at the start of the last chunk; accumulators -> a
+//               wave-private LDS slab (pixel-major) -> + shift + shortcut -> activation -> 16-byte NHWC stores that
+//               nobody waits for.
+#include <type_traits>
+
+#include "gf_common.h"
+
+namespace {
+
+constexpr int TW = 32, PW = TW + 2;               // tile / halo-patch width
+constexpr int C7_FRAG = 1024;
+constexpr int P_OFF = 0;                          // two patches
+enum { C7_NONE = 0, C7_RELU = 1, C7_LEAKY = 2 };
+
+struct ConvArgs {
+    const void* x;          // [N][H][W][CIN]
+    const void* wstream;    // packed fragments (fused.py:pack_conv3x3_stream)
+    const float* shift;     // [COUT] or null
+    const void* res;        // [N][H][W][COUT] or null
+    void* out;              // [N][H][W][COUT]
+    const void* zeros;      // >= 64 bytes of zeros (source of out-of-image pixels)
+    int N, H, W, act;
+    float slope;
+    int tiles_x, tiles_y, ntiles;
+};
+
+template <int NT>
+struct ConvGeo {
+    // output widths up to 128 channels: a wave owns two 32-pixel rows (every weight fragment feeds two MFMAs, 2 x NT
+    // accumulator tiles); wider outputs: one row per wave (the accumulators of two would not fit the register file)
+    static constexpr int PB = NT <= 4 ? 2 : 1;
+    static constexpr int TH = 4 * PB, PH = TH + 2;                // tile / halo-patch height
+    static constexpr int PIECES = (PH * PW + 15) / 16;            // DMA pieces of 16 pixels x 64 B
+    static constexpr int PATCH_BYTES = PIECES * 1024;
+    static constexpr int W7_OFF = 2 * PATCH_BYTES;                // two weight blocks behind the two patches
+    static constexpr int BLOCK_STEPS = 6;                         // a third of a chunk's 18 steps
+    static constexpr int FR = BLOCK_STEPS * NT;                   // fragments per block
+    static constexpr int WBLK = FR * C7_FRAG;                     // 24 / 42 / 48 KiB
+    static constexpr int SLAB_OFF = W7_OFF + 2 * WBLK;
+    static constexpr int RS = 128 * 2 + 16;                       // slab row: up to 128 channels of a pixel + 16 B
+    static constexpr int SHIFT_OFF = SLAB_OFF + 4 * 32 * RS;      // one 32-pixel slab per wave
+    static constexpr int LDS = SHIFT_OFF + NT * 32 * 4;
+};
+
+// request weight block b of the stream into ring slot `slot`; the waves share its fragments round-robin
+template <int NT>
+__device__ __forceinline__ void conv_dma_block(const char* ws, char* smem, int b, int slot, int wave, int lane) {
+    using G = ConvGeo<NT>;
+    char* dst = smem + G::W7_OFF + slot * G::WBLK;
+    const char* src = ws + (size_t)b * G::WBLK + lane * 16;
+#pragma unroll
+    for (int i = 0; i < (G::FR + 3) / 4; ++i) {
+        const int f = wave + 4 * i;
+        if (f < G::FR)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * C7_FRAG),
+                                             (__attribute__((address_space(3))) void*)(dst + f * C7_FRAG), 16, 0, 0);
+    }
+}
+
+// request the halo patch of (tile, channel chunk c) into patch buffer `buf`: pieces of 16 pixels x 64 B over the 4 waves
+template <typename T, int CIN, int NT>
+__device__ __forceinline__ void conv_dma_patch(const ConvArgs& a, char* smem, int buf, int n, int y0, int x0, int c, int wave, int lane) {
+    using G = ConvGeo<NT>;
+    const T* xg = (const T*)a.x;
+    char* dst = smem + P_OFF + buf * G::PATCH_BYTES;
+#pragma unroll
+    for (int i = 0; i < (G::PIECES + 3) / 4; ++i) {
+        const int piece = wave + 4 * i;
+        if (piece < G::PIECES) {
+            const int q = piece * 16 + (lane >> 2), slot = (lane & 3) ^ ((q >> 2) & 3);
+            const int pr = q / PW, pc = q - pr * PW;
+            const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+            const bool in = q < G::PH * PW && y >= 0 && y < a.H && x >= 0 && x < a.W;
+            const char* src = in ? (const char*)(xg + (((size_t)n * a.H + y) * a.W + x) * CIN + 32 * c + 8 * slot) : (const char*)a.zeros + (lane & 3) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+        }
+    }
+}
+
+// -DK7_TRACE=1 records s_memtime at the phase boundaries of the first 8 tiles of every wave (tools/k7_trace.py)
+#ifndef K7_TRACE
+#define K7_TRACE 0
+#endif
+#ifdef K7_EXP_NOSTORE
+#define K7_STORE_OK (a.slope == 12345.f)
+#else
+#define K7_STORE_OK true
+#endif
+#if K7_TRACE
+__device__ long long k7_trace[256 * 8 * 4 * 16];
+#define K7_T(slot) do { if (lane == 0 && it < 8) k7_trace[((blockIdx.x * 8 + it) * 4 + wave) * 16 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define K7_T(slot)
+#endif
+
+template <typename T, int CIN, int COUT>
+__global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a) {
+    using Mm = Mma32<T>;
+    using Frag = typename Mm::Frag;
+    using G = ConvGeo<COUT / 32>;
+    using V4 = gf_vec<T, 4>;
+    using V8 = gf_vec<T, 8>;
+    constexpr int NT = COUT / 32, NCH = CIN / 32, NBLK = NCH * 3;
+    constexpr int PB = G::PB, TH = G::TH, RS = G::RS;
+    constexpr int NSTORE = PB * 2 * NT;                             // 16-byte output stores per lane and tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5, lr = lane & 31;
+    const char* ws = (const char*)a.wstream;
+    float* shiftv = reinterpret_cast<float*>(smem + G::SHIFT_OFF);
+    for (int i = tid; i < COUT; i += 256) shiftv[i] = a.shift ? a.shift[i] : 0.f;
+
+    auto decode = [&](int t, int& n, int& y0, int& x0) {
+        const int per = a.tiles_x * a.tiles_y;
+        n = t / per;
+        const int r = t - n * per, ty = r / a.tiles_x;
+        y0 = ty * TH;
+        x0 = (r - ty * a.tiles_x) * TW;
+    };
+    // byte offset (k-step 0) of this lane's pixel fragment in patch row PB wave + r, column shift kx; k-step 1 = ^ 32
+    int xaddr[PB + 2][3];
+#pragma unroll
+    for (int r = 0; r < PB + 2; ++r)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int q = (PB * wave + r) * PW + lr + kx;
+            xaddr[r][kx] = q * 64 + ((h2 ^ ((q >> 2) & 3)) << 4);
+        }
+    Frag wa[NT], wb[NT], xa[PB], xb[PB];
+    auto load_w = [&](Frag (&f)[NT], int slot, int s) {            // weight fragments of step s of the block in `slot`
+        const char* p = smem + G::W7_OFF + slot * G::WBLK + s * NT * C7_FRAG + lane * 16;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) f[t] = *reinterpret_cast<const Frag*>(p + t * C7_FRAG);
+    };
+    auto load_x = [&](Frag (&f)[PB], int buf, int ts) {            // pixel fragments of (tap, k-step) = ts of the chunk in `buf`
+        const int tap = ts >> 1, ky = tap / 3, kx = tap - 3 * ky;
+        const char* p = smem + P_OFF + buf * G::PATCH_BYTES;
+#pragma unroll
+        for (int b = 0; b < PB; ++b) f[b] = *reinterpret_cast<const Frag*>(p + (xaddr[b + ky][kx] ^ ((ts & 1) << 5)));
+    };
+
+    int pbuf = 0, wslot = 0;                                        // patch buffer / ring slot being multiplied
+    {
+        int n, y0, x0;
+        decode(blockIdx.x, n, y0, x0);
+        conv_dma_patch<T, CIN, NT>(a, smem, 0, n, y0, x0, 0, wave, lane);
+        conv_dma_block<NT>(ws, smem, 0, 0, wave, lane);
+        conv_dma_block<NT>(ws, smem, 1, 1, wave, lane);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        load_w(wa, 0, 0);
+        load_x(xa, 0, 0);
+    }
+    [[maybe_unused]] int it = -1;
+    bool prev_full = false;                                         // previous tile of this workgroup: all its stores issued?
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        int n, y0, x0;
+        decode(tile, n, y0, x0);
+        const int nxt_tile = tile + gridDim.x;
+        const bool has_next = nxt_tile < a.ntiles;
+        ++it;
+        K7_T(0);
+        v16f acc[PB][NT];
+        // accumulators start at the shift of their channel: 32 t + 8 (r / 4) + 4 h2 + (r % 4)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 sh = *reinterpret_cast<const float4*>(shiftv + 32 * t + 8 * g + 4 * h2);
+#pragma unroll
+                for (int b = 0; b < PB; ++b) {
+                    acc[b][t][4 * g] = sh.x;
+                    acc[b][t][4 * g + 1] = sh.y;
+                    acc[b][t][4 * g + 2] = sh.z;
+                    acc[b][t][4 * g + 3] = sh.w;
+                }
+            }
+        // shortcut rows of this lane's epilogue chunks (fetched at the start of the last channel chunk)
+        V8 rres[PB][16];
+        const T* rg = (const T*)a.res;
+        T* og = (T*)a.out;
+        // the epilogue runs in passes of 4 accumulator tiles (128 channels; the last pass of 224 channels: 3); in pass t0,
+        // a lane's chunk jj is slab chunk e = lane + 64 jj -> pixel e / cpr, 16-byte channel chunk e % cpr (cpr = 4 nt)
+        auto pass_tiles = [](int t0) { return NT - t0 < 4 ? NT - t0 : 4; };
+
+#pragma unroll 1
+        for (int c = 0; c < NCH; ++c) {
+            if (c == NCH - 1 && rg) {
+#pragma unroll
+                for (int b = 0; b < PB; ++b) {
+                    const int y = y0 + PB * wave + b;
+#pragma unroll
+                    for (int t0 = 0; t0 < NT; t0 += 4)
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj)
+                            if (jj < 2 * pass_tiles(t0)) {
+                                const int cpr = 4 * pass_tiles(t0), e = lane + 64 * jj, px = e / cpr, cc = e - px * cpr, x = x0 + px;
+                                V8 v;
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) v[i] = (T)0.f;
+                                if (y < a.H && x < a.W)
+                                    v = *reinterpret_cast<const V8*>(rg + (((size_t)n * a.H + y) * a.W + x) * COUT + (t0 * 4 + cc) * 8);
+                                rres[b][(t0 / 4) * 8 + jj] = v;
+                            }
+                }
+            }
+#pragma unroll
+            for (int ts = 0; ts < 18; ++ts) {                       // (tap, k-step) of this chunk
+                Frag (&cw)[NT] = (ts & 1) ? wb : wa;
+                Frag (&nw)[NT] = (ts & 1) ? wa : wb;
+                Frag (&cx)[PB] = (ts & 1) ? xb : xa;
+                Frag (&nx)[PB] = (ts & 1) ? xa : xb;
+                __builtin_amdgcn_s_waitcnt(0xC07F);                 // this step's fragments (requested a step ago) are in registers
+                if (ts % 6 == 5) {
+                    // ring turn before the last step of a block: the next block (and a patch requested a turn ago) has
+                    // landed, every wave holds this block's last fragments in registers: its slot takes the block after next
+                    // (the first turn of a tile only needs the block requested before the previous tile's epilogue: its
+                    // NSTORE output stores - all issued when that tile lay inside the image - may stay in flight)
+                    if (ts == 5 && c == 0) K7_T(12);
+                    if (ts == 5 && c == 0 && prev_full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (ts == 5 && c == 0) K7_T(13);
+                    __builtin_amdgcn_s_barrier();
+                    if (ts == 5 && c == 0) K7_T(14);
+                    const int nb = c * 3 + ts / 6 + 2;
+                    if (nb < NBLK) conv_dma_block<NT>(ws, smem, nb, wslot, wave, lane);
+                    else if (has_next) conv_dma_block<NT>(ws, smem, nb - NBLK, wslot, wave, lane);
+                    if (ts == 5) {
+                        // first turn of the chunk: every wave is past the previous chunk, its patch buffer is free
+                        if (c + 1 < NCH) conv_dma_patch<T, CIN, NT>(a, smem, pbuf ^ 1, n, y0, x0, c + 1, wave, lane);
+                        else if (has_next) {
+                            int n2, y2, x2;
+                            decode(nxt_tile, n2, y2, x2);
+                            conv_dma_patch<T, CIN, NT>(a, smem, pbuf ^ 1, n2, y2, x2, 0, wave, lane);
+                        }
+                    }
+                    wslot ^= 1;
+                    if (ts == 5 && c == 0) K7_T(15);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // next step's fragments (after the last step of a tile: the next tile's first, or stale bytes nobody uses)
+                load_w(nw, wslot, (ts + 1) % 6);
+                load_x(nx, ts == 17 ? pbuf ^ 1 : pbuf, (ts + 1) % 18);
+#pragma unroll
+                for (int b = 0; b < PB; ++b)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) Mm::mma(cw[t], cx[b], acc[b][t]);
+                // issue order: two reads, then one read behind each of the first MFMAs (left alone the compiler sinks the
+                // reads behind the step's last MFMA and the next step waits out the whole LDS latency)
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                for (int i = 0; i < NT + PB - 2; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, NT * PB - (NT + PB - 2), 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            pbuf ^= 1;
+            K7_T(2 + c);
+        }
+        // ---------------- epilogue (wave-private): T(acc) -> slab [pixel][128 channels] -> + shift + shortcut -> act -> NHWC
+        K7_T(10);
+        char* slab = smem + G::SLAB_OFF + wave * 32 * RS;
+        // act(f) = max(f, 0) ReLU; else max(f, k f) with k = the slope (0 <= slope <= 1) LeakyReLU, 1 none: uniform per chunk
+        const bool relu = a.act == C7_RELU;
+        const float neg_k = a.act == C7_LEAKY ? a.slope : 1.f;
+#pragma unroll
+        for (int b = 0; b < PB; ++b) {
+            const int y = y0 + PB * wave + b;
+#pragma unroll
+            for (int t0 = 0; t0 < NT; t0 += 4) {
+                const int nt = pass_tiles(t0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (t < nt)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            *reinterpret_cast<V4*>(slab + lr * RS + (t * 32 + 8 * g + 4 * h2) * 2) =
+                                V4{(T)acc[b][t0 + t][4 * g], (T)acc[b][t0 + t][4 * g + 1], (T)acc[b][t0 + t][4 * g + 2], (T)acc[b][t0 + t][4 * g + 3]};
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    if (jj < 2 * nt) {
+                        const int cpr = 4 * nt, e = lane + 64 * jj, px = e / cpr, cc = e - px * cpr, x = x0 + px, ch8 = t0 * 4 + cc;
+                        const V8 v = *reinterpret_cast<const V8*>(slab + px * RS + cc * 16);
+                        float f[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+                        if (rg) {
+                            const V8 r = rres[b][(t0 / 4) * 8 + jj];
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) f[i] += (float)r[i];
+                        }
+                        V8 o;
+                        if (relu) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) o[i] = (T)fmaxf(f[i], 0.f);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) o[i] = (T)fmaxf(f[i], f[i] * neg_k);
+                        }
+                        if (y < a.H && x < a.W && K7_STORE_OK) *reinterpret_cast<V8*>(og + (((size_t)n * a.H + y) * a.W + x) * COUT + ch8 * 8) = o;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        prev_full = y0 + TH <= a.H && x0 + TW <= a.W;
+        K7_T(11);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
+#if K7_TRACE
+}
+extern "C" int gf_debug_k7_trace(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(k7_trace), sizeof(k7_trace)) == hipSuccess ? 0 : -1;
+}
+namespace {
+#endif
+
+template <typename T, int CIN, int COUT>
+int conv_launch(const ConvArgs& a, hipStream_t st) {
+    constexpr int NT = COUT / 32;
+    constexpr int lds = ConvGeo<NT>::LDS;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_kernel<T, CIN, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr = true;
+    }
+    conv3x3_kernel<T, CIN, COUT><<<a.ntiles < 256 ? a.ntiles : 256, 256, lds, st>>>(a);
+    return 0;
+}
+
+template <typename T>
+int conv_dispatch(const ConvArgs& a, int cin, int cout, hipStream_t st) {
+    if (cin == 128 && cout == 128) return conv_launch<T, 128, 128>(a, st);
+    if (cin == 224 && cout == 224) return conv_launch<T, 224, 224>(a, st);
+    if (cin == 224 && cout == 128) return conv_launch<T, 224, 128>(a, st);
+    if (cin == 256 && cout == 256) return conv_launch<T, 256, 256>(a, st);
+    if (cin == 256 && cout == 224) return conv_launch<T, 256, 224>(a, st);
+    return -1;
+}
+
+}   // namespace
+
+// 1 if gf_conv3x3_nhwc has a kernel for these channel counts
+extern "C" int gf_conv3x3_supported(int cin, int cout) {
+    return (cin == 128 && cout == 128) || (cin == 224 && (cout == 224 || cout == 128)) || (cin == 256 && (cout == 256 || cout == 224));
+}
+
+// out = act(conv3x3(x, w) + shift + residual), channels-last 16-bit maps; wstream = fused.py:pack_conv3x3_stream(w);
+// zeros = >= 64 bytes of device memory holding zeros (the source of out-of-image pixels)
+extern "C" int gf_conv3x3_nhwc(const void* x, const void* wstream, const float* shift, const void* residual, void* out,
+                               const void* zeros, int N, int H, int W, int cin, int cout, int act, float slope, int dtype,
+                               void* stream) {
+    GF_CHECK_ARG(x && wstream && out && zeros, "null pointer");
+    GF_CHECK_ARG(N > 0 && H > 0 && W > 0, "empty problem");
+    GF_CHECK_ARG(dtype == GF_F16 || dtype == GF_BF16, "built for 16-bit maps");
+    GF_CHECK_ARG(gf_conv3x3_supported(cin, cout), "no kernel for these channel counts (see gf_conv3x3_supported)");
+    GF_CHECK_ARG(act >= C7_NONE && act <= C7_LEAKY, "unknown activation");
+    GF_CHECK_ARG(act != C7_LEAKY || (slope >= 0.f && slope <= 1.f), "LeakyReLU slope must lie in [0, 1]");
+    GF_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)residual % 16 == 0 && (uintptr_t)wstream % 16 == 0 &&
+                     (uintptr_t)zeros % 16 == 0, "tensors must be 16-byte aligned");
+    const int th = cout <= 128 ? 8 : 4;                             // ConvGeo<NT>::TH
+    ConvArgs a{x, wstream, shift, residual, out, zeros, N, H, W, act, slope, (W + TW - 1) / TW, (H + th - 1) / th, 0};
+    GF_CHECK_ARG((long)N * a.tiles_x * a.tiles_y < (1l << 31), "too many tiles");
+    a.ntiles = N * a.tiles_x * a.tiles_y;
+    hipStream_t st = (hipStream_t)stream;
+    void* pt = gf_prof_begin("conv3x3", st, 2.0 * N * (double)H * W * cin * cout * 9.0);
+    const int rc = dtype == GF_F16 ? conv_dispatch<_Float16>(a, cin, cout, st) : conv_dispatch<gf_bf16>(a, cin, cout, st);
+    gf_prof_end("conv3x3", pt, st);
+    GF_CHECK_ARG(rc == 0, "dispatch failed");
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}

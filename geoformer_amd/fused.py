@@ -112,3 +112,52 @@ def encoder_layer(x, wstream, ln_params, eps1, eps2, activation, msg=None, kv_st
                                       _p(ln_params), float(eps1), float(eps2), int(activation), _p(row_flag), int(flag_rows), _p(out), C,
                                       _dt(x), N, L, _stream()), 'gf_encoder_layer')
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# K7: 3x3 convolution with fused epilogue (csrc/k7_conv3x3.hip)
+# ---------------------------------------------------------------------------------------------------------------
+_ZEROS = {}
+
+
+def pack_conv3x3_stream(w):
+    """w [Cout, Cin, 3, 3] (BatchNorm already folded, 16-bit) -> the fragment stream of gf_conv3x3_nhwc: for each 32-channel
+    input chunk c, tap t = 3 ky + kx and 16-deep k-step s the Cout/32 standard-order fragments of W[:, 32c + 16s ..., ky, kx];
+    zero-padded to whole weight blocks (8 steps for Cout <= 128, else 4)."""
+    cout, cin = w.shape[:2]
+    nt = cout // 32
+    wt = w.reshape(cout, cin, 9)
+    parts = []
+    for c in range(cin // 32):
+        for t in range(9):
+            f = fragments(wt[:, 32 * c:32 * c + 32, t].contiguous(), 'std')            # [nt, 2, 64, 8]
+            for s in range(2):
+                parts.append(f[:, s].reshape(-1))
+    stream = torch.cat(parts)
+    block = (8 if nt <= 4 else 4) * nt * 512                                          # elements per weight block
+    pad = (-stream.numel()) % block
+    if pad:
+        stream = torch.cat([stream, stream.new_zeros(pad)])
+    return stream.contiguous()
+
+
+def conv3x3_supported(cin, cout):
+    return bool(_lib.lib().gf_conv3x3_supported(int(cin), int(cout)))
+
+
+def conv3x3(x, wstream, cout, shift=None, residual=None, act=0, slope=0.01):
+    """x channels_last [N, Cin, H, W] (16-bit) -> channels_last [N, cout, H, W] = act(conv3x3(x) + shift + residual)."""
+    _need_cuda(x, wstream)
+    if x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError('conv3x3 expects a channels_last [N, C, H, W] tensor')
+    N, cin, H, W = x.shape
+    out = torch.empty(N, cout, H, W, dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    if residual is not None and (residual.shape != out.shape or residual.dtype != x.dtype or
+                                 not residual.is_contiguous(memory_format=torch.channels_last)):
+        raise ValueError('residual must be a channels_last tensor of the output shape and dtype')
+    z = _ZEROS.get(x.device)
+    if z is None:
+        z = _ZEROS[x.device] = torch.zeros(256, dtype=torch.uint8, device=x.device)
+    check(_lib.lib().gf_conv3x3_nhwc(_p(x), _p(wstream), _p(shift), _p(residual), _p(out), _p(z), N, H, W, cin, cout, int(act),
+                                     float(slope), _dt(x), _stream()), 'gf_conv3x3_nhwc')
+    return out

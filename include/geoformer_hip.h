@@ -141,6 +141,22 @@ int gf_encoder_layer(const void* x, long ldx, const void* msg, long ldm, const f
                      int N, int L, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K7  3x3 / stride 1 / pad 1 convolution of channels-last 16-bit maps with a fused epilogue (backbone)
+ * replaces conv3x3 + BatchNorm(eval) [+ shortcut] + ReLU / LeakyReLU of BasicBlock.forward and of the FPN heads
+ *          (model/loftr_src/loftr/backbone/resnet_fpn.py:9-40, :60-83, :100-116), BatchNorm folded into the weights
+ *   out[n,y,x,:] = act( sum_{ky,kx} w[:, :, ky, kx] . x[n, y+ky-1, x+kx-1, :] + shift + residual[n,y,x,:] )
+ *   x [N,H,W,cin], out / residual [N,H,W,cout] (GF_F16 or GF_BF16); the convolution result is rounded to the storage
+ *   type before shift / residual / activation (the rounding points of a separate convolution followed by
+ *   gf_bias_act_nhwc); act: 0 none, 1 ReLU, 2 LeakyReLU(slope); shift fp32 [cout] or NULL; residual or NULL;
+ *   wstream = geoformer_amd/fused.py:pack_conv3x3_stream(w); zeros = >= 64 bytes of zeroed device memory.
+ *   Channel counts: gf_conv3x3_supported(cin, cout).
+ * ------------------------------------------------------------------------------------------ */
+int gf_conv3x3_supported(int cin, int cout);
+int gf_conv3x3_nhwc(const void* x, const void* wstream, const float* shift, const void* residual, void* out,
+                    const void* zeros, int N, int H, int W, int cin, int cout, int act, float slope, int dtype,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * K3  encoder-layer linears with fused epilogues
  * replaces the nn.Linear / LayerNorm / activation / concat / residual sequence of
  * LoFTREncoderLayer.forward (model/loftr_src/loftr/loftr_module/transformer.py:45-60 and
