@@ -47,54 +47,64 @@ struct ConvArgs {
     int tiles_x, tiles_y, ntiles;
 };
 
-template <int NT>
+template <int NT, int NW>
 struct ConvGeo {
     // output widths up to 128 channels: a wave owns two 32-pixel rows (every weight fragment feeds two MFMAs, 2 x NT
-    // accumulator tiles); wider outputs: one row per wave (the accumulators of two would not fit the register file)
+    // accumulator tiles); wider outputs: one row per wave (the accumulators of two would not fit the register file).
+    // NW = 4 waves (one per SIMD, 512 registers each) or 8 (two per SIMD, 256 each: one wave's issue gaps - DMA requests,
+    // ring turns, the epilogue - are filled by the other's MFMAs).
     static constexpr int PB = NT <= 4 ? 2 : 1;
-    static constexpr int TH = 4 * PB, PH = TH + 2;                // tile / halo-patch height
+    static constexpr int TH = NW * PB, PH = TH + 2;               // tile / halo-patch height
     static constexpr int PIECES = (PH * PW + 15) / 16;            // DMA pieces of 16 pixels x 64 B
     static constexpr int PATCH_BYTES = PIECES * 1024;
     static constexpr int W7_OFF = 2 * PATCH_BYTES;                // two weight blocks behind the two patches
-    static constexpr int BLOCK_STEPS = 6;                         // a third of a chunk's 18 steps
+    static constexpr int BLOCK_STEPS = NW == 8 ? 3 : 6;          // a sixth / a third of a chunk's 18 steps
     static constexpr int FR = BLOCK_STEPS * NT;                   // fragments per block
-    static constexpr int WBLK = FR * C7_FRAG;                     // 24 / 42 / 48 KiB
+    static constexpr int WBLK = FR * C7_FRAG;
     static constexpr int SLAB_OFF = W7_OFF + 2 * WBLK;
-    static constexpr int RS = 128 * 2 + 16;                       // slab row: up to 128 channels of a pixel + 16 B
-    static constexpr int SHIFT_OFF = SLAB_OFF + 4 * 32 * RS;      // one 32-pixel slab per wave
+    static constexpr int SP = NW == 4 ? 4 : 2;                    // accumulator tiles per epilogue pass
+    static constexpr int RS = SP * 64 + 16;                       // slab row: SP x 32 channels of a pixel + 16 B
+    static constexpr int SHIFT_OFF = SLAB_OFF + NW * 32 * RS;     // one 32-pixel slab per wave
     static constexpr int LDS = SHIFT_OFF + NT * 32 * 4;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
 // request weight block b of the stream into ring slot `slot`; the waves share its fragments round-robin
-template <int NT>
+template <int NT, int NW>
 __device__ __forceinline__ void conv_dma_block(const char* ws, char* smem, int b, int slot, int wave, int lane) {
-    using G = ConvGeo<NT>;
+    using G = ConvGeo<NT, NW>;
+    asm volatile("" : "+v"(lane));      // (as in conv_dma_patch)
     char* dst = smem + G::W7_OFF + slot * G::WBLK;
     const char* src = ws + (size_t)b * G::WBLK + lane * 16;
 #pragma unroll
-    for (int i = 0; i < (G::FR + 3) / 4; ++i) {
-        const int f = wave + 4 * i;
+    for (int i = 0; i < (G::FR + NW - 1) / NW; ++i) {
+        const int f = wave + NW * i;
         if (f < G::FR)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * C7_FRAG),
                                              (__attribute__((address_space(3))) void*)(dst + f * C7_FRAG), 16, 0, 0);
     }
 }
 
-// request the halo patch of (tile, channel chunk c) into patch buffer `buf`: pieces of 16 pixels x 64 B over the 4 waves
-template <typename T, int CIN, int NT>
+// request the halo patch of (tile, channel chunk c) into patch buffer `buf`: pieces of 16 pixels x 64 B over the waves
+template <typename T, int CIN, int NT, int NW>
 __device__ __forceinline__ void conv_dma_patch(const ConvArgs& a, char* smem, int buf, int n, int y0, int x0, int c, int wave, int lane) {
-    using G = ConvGeo<NT>;
-    const T* xg = (const T*)a.x;
+    using G = ConvGeo<NT, NW>;
+    asm volatile("" : "+v"(lane));      // recompute the per-lane source addresses here: hoisted out of the K loop they cost
+                                        // live registers per piece, and a spilled one a vmcnt(0) reload between requests
+    const char* xg = (const char*)a.x;
     char* dst = smem + P_OFF + buf * G::PATCH_BYTES;
+    // element offset of patch pixel (0, 0), channel 32 c (may be negative; 32-bit: the entry point bounds the tensor)
+    const int sbase = ((n * a.H + y0 - 1) * a.W + x0 - 1) * CIN + 32 * c;
+    const char* zsrc = (const char*)a.zeros + (lane & 3) * 16;
 #pragma unroll
-    for (int i = 0; i < (G::PIECES + 3) / 4; ++i) {
-        const int piece = wave + 4 * i;
+    for (int i = 0; i < (G::PIECES + NW - 1) / NW; ++i) {
+        const int piece = wave + NW * i;
         if (piece < G::PIECES) {
             const int q = piece * 16 + (lane >> 2), slot = (lane & 3) ^ ((q >> 2) & 3);
             const int pr = q / PW, pc = q - pr * PW;
-            const int y = y0 - 1 + pr, x = x0 - 1 + pc;
-            const bool in = q < G::PH * PW && y >= 0 && y < a.H && x >= 0 && x < a.W;
-            const char* src = in ? (const char*)(xg + (((size_t)n * a.H + y) * a.W + x) * CIN + 32 * c + 8 * slot) : (const char*)a.zeros + (lane & 3) * 16;
+            const bool in = (unsigned)(y0 - 1 + pr) < (unsigned)a.H && (unsigned)(x0 - 1 + pc) < (unsigned)a.W && q < G::PH * PW;
+            const int off = sbase + (pr * a.W + pc) * CIN + 8 * slot;
+            const char* src = in ? xg + (size_t)(unsigned)off * sizeof(T) : zsrc;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
         }
@@ -111,27 +121,28 @@ __device__ __forceinline__ void conv_dma_patch(const ConvArgs& a, char* smem, in
 #define K7_STORE_OK true
 #endif
 #if K7_TRACE
-__device__ long long k7_trace[256 * 8 * 4 * 16];
-#define K7_T(slot) do { if (lane == 0 && it < 8) k7_trace[((blockIdx.x * 8 + it) * 4 + wave) * 16 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+__device__ long long k7_trace[256 * 8 * 8 * 16];
+#define K7_T(slot) do { if (lane == 0 && it < 8) k7_trace[((blockIdx.x * 8 + it) * 8 + wave) * 16 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define K7_T(slot)
 #endif
 
-template <typename T, int CIN, int COUT>
-__global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a) {
+template <typename T, int CIN, int COUT, int NW>
+__global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
     using Mm = Mma32<T>;
     using Frag = typename Mm::Frag;
-    using G = ConvGeo<COUT / 32>;
+    using G = ConvGeo<COUT / 32, NW>;
     using V4 = gf_vec<T, 4>;
     using V8 = gf_vec<T, 8>;
-    constexpr int NT = COUT / 32, NCH = CIN / 32, NBLK = NCH * 3;
-    constexpr int PB = G::PB, TH = G::TH, RS = G::RS;
+    constexpr int NT = COUT / 32, NCH = CIN / 32, BS = G::BLOCK_STEPS, BPC = 18 / BS, NBLK = NCH * BPC;
+    constexpr int PB = G::PB, TH = G::TH, RS = G::RS, SP = G::SP;
+    constexpr bool PRE_RES = NW == 4;                               // shortcut rows prefetched into registers (room for them)
     constexpr int NSTORE = PB * 2 * NT;                             // 16-byte output stores per lane and tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5, lr = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h2 = lane >> 5, lr = lane & 31;
     const char* ws = (const char*)a.wstream;
     float* shiftv = reinterpret_cast<float*>(smem + G::SHIFT_OFF);
-    for (int i = tid; i < COUT; i += 256) shiftv[i] = a.shift ? a.shift[i] : 0.f;
+    for (int i = tid; i < COUT; i += NW * 64) shiftv[i] = a.shift ? a.shift[i] : 0.f;
 
     auto decode = [&](int t, int& n, int& y0, int& x0) {
         const int per = a.tiles_x * a.tiles_y;
@@ -166,9 +177,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a) {
     {
         int n, y0, x0;
         decode(blockIdx.x, n, y0, x0);
-        conv_dma_patch<T, CIN, NT>(a, smem, 0, n, y0, x0, 0, wave, lane);
-        conv_dma_block<NT>(ws, smem, 0, 0, wave, lane);
-        conv_dma_block<NT>(ws, smem, 1, 1, wave, lane);
+        conv_dma_patch<T, CIN, NT, NW>(a, smem, 0, n, y0, x0, 0, wave, lane);
+        conv_dma_block<NT, NW>(ws, smem, 0, 0, wave, lane);
+        conv_dma_block<NT, NW>(ws, smem, 1, 1, wave, lane);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
         load_w(wa, 0, 0);
@@ -199,23 +210,23 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a) {
                 }
             }
         // shortcut rows of this lane's epilogue chunks (fetched at the start of the last channel chunk)
-        V8 rres[PB][16];
+        V8 rres[PB][PRE_RES ? 16 : 1];
         const T* rg = (const T*)a.res;
         T* og = (T*)a.out;
-        // the epilogue runs in passes of 4 accumulator tiles (128 channels; the last pass of 224 channels: 3); in pass t0,
+        // the epilogue runs in passes of SP accumulator tiles (the last pass of 224 channels: one fewer); in pass t0,
         // a lane's chunk jj is slab chunk e = lane + 64 jj -> pixel e / cpr, 16-byte channel chunk e % cpr (cpr = 4 nt)
-        auto pass_tiles = [](int t0) { return NT - t0 < 4 ? NT - t0 : 4; };
+        auto pass_tiles = [](int t0) { return NT - t0 < SP ? NT - t0 : SP; };
 
 #pragma unroll 1
         for (int c = 0; c < NCH; ++c) {
-            if (c == NCH - 1 && rg) {
+            if (PRE_RES && c == NCH - 1 && rg) {
 #pragma unroll
                 for (int b = 0; b < PB; ++b) {
                     const int y = y0 + PB * wave + b;
 #pragma unroll
-                    for (int t0 = 0; t0 < NT; t0 += 4)
+                    for (int t0 = 0; t0 < NT; t0 += SP)
 #pragma unroll
-                        for (int jj = 0; jj < 8; ++jj)
+                        for (int jj = 0; jj < 2 * SP; ++jj)
                             if (jj < 2 * pass_tiles(t0)) {
                                 const int cpr = 4 * pass_tiles(t0), e = lane + 64 * jj, px = e / cpr, cc = e - px * cpr, x = x0 + px;
                                 V8 v;
@@ -223,7 +234,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a) {
                                 for (int i = 0; i < 8; ++i) v[i] = (T)0.f;
                                 if (y < a.H && x < a.W)
                                     v = *reinterpret_cast<const V8*>(rg + (((size_t)n * a.H + y) * a.W + x) * COUT + (t0 * 4 + cc) * 8);
-                                rres[b][(t0 / 4) * 8 + jj] = v;
+                                rres[b][PRE_RES ? (t0 / SP) * 2 * SP + jj : 0] = v;
                             }
                 }
             }
@@ -234,35 +245,35 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a) {
                 Frag (&cx)[PB] = (ts & 1) ? xb : xa;
                 Frag (&nx)[PB] = (ts & 1) ? xa : xb;
                 __builtin_amdgcn_s_waitcnt(0xC07F);                 // this step's fragments (requested a step ago) are in registers
-                if (ts % 6 == 5) {
+                if (ts % BS == BS - 1) {
                     // ring turn before the last step of a block: the next block (and a patch requested a turn ago) has
                     // landed, every wave holds this block's last fragments in registers: its slot takes the block after next
                     // (the first turn of a tile only needs the block requested before the previous tile's epilogue: its
                     // NSTORE output stores - all issued when that tile lay inside the image - may stay in flight)
-                    if (ts == 5 && c == 0) K7_T(12);
-                    if (ts == 5 && c == 0 && prev_full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
+                    if (ts == BS - 1 && c == 0) K7_T(12);
+                    if (ts == BS - 1 && c == 0 && prev_full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (ts == 5 && c == 0) K7_T(13);
+                    if (ts == BS - 1 && c == 0) K7_T(13);
                     __builtin_amdgcn_s_barrier();
-                    if (ts == 5 && c == 0) K7_T(14);
-                    const int nb = c * 3 + ts / 6 + 2;
-                    if (nb < NBLK) conv_dma_block<NT>(ws, smem, nb, wslot, wave, lane);
-                    else if (has_next) conv_dma_block<NT>(ws, smem, nb - NBLK, wslot, wave, lane);
-                    if (ts == 5) {
+                    if (ts == BS - 1 && c == 0) K7_T(14);
+                    const int nb = c * BPC + ts / BS + 2;
+                    if (nb < NBLK) conv_dma_block<NT, NW>(ws, smem, nb, wslot, wave, lane);
+                    else if (has_next) conv_dma_block<NT, NW>(ws, smem, nb - NBLK, wslot, wave, lane);
+                    if (ts == BS - 1) {
                         // first turn of the chunk: every wave is past the previous chunk, its patch buffer is free
-                        if (c + 1 < NCH) conv_dma_patch<T, CIN, NT>(a, smem, pbuf ^ 1, n, y0, x0, c + 1, wave, lane);
+                        if (c + 1 < NCH) conv_dma_patch<T, CIN, NT, NW>(a, smem, pbuf ^ 1, n, y0, x0, c + 1, wave, lane);
                         else if (has_next) {
                             int n2, y2, x2;
                             decode(nxt_tile, n2, y2, x2);
-                            conv_dma_patch<T, CIN, NT>(a, smem, pbuf ^ 1, n2, y2, x2, 0, wave, lane);
+                            conv_dma_patch<T, CIN, NT, NW>(a, smem, pbuf ^ 1, n2, y2, x2, 0, wave, lane);
                         }
                     }
                     wslot ^= 1;
-                    if (ts == 5 && c == 0) K7_T(15);
+                    if (ts == BS - 1 && c == 0) K7_T(15);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // next step's fragments (after the last step of a tile: the next tile's first, or stale bytes nobody uses)
-                load_w(nw, wslot, (ts + 1) % 6);
+                load_w(nw, wslot, (ts + 1) % BS);
                 load_x(nx, ts == 17 ? pbuf ^ 1 : pbuf, (ts + 1) % 18);
 #pragma unroll
                 for (int b = 0; b < PB; ++b)
@@ -292,10 +303,22 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a) {
         for (int b = 0; b < PB; ++b) {
             const int y = y0 + PB * wave + b;
 #pragma unroll
-            for (int t0 = 0; t0 < NT; t0 += 4) {
-                const int nt = pass_tiles(t0);
+            for (int t0 = 0; t0 < NT; t0 += SP) {
+                const int nt = pass_tiles(t0), cpr = 4 * nt;
+                V8 rl[2 * SP];                                      // shortcut rows of this pass when they were not prefetched
+                if (!PRE_RES && rg) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                    for (int jj = 0; jj < 2 * SP; ++jj)
+                        if (jj < 2 * nt) {
+                            const int e = lane + 64 * jj, px = e / cpr, cc = e - px * cpr, x = x0 + px;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) rl[jj][i] = (T)0.f;
+                            if (y < a.H && x < a.W)
+                                rl[jj] = *reinterpret_cast<const V8*>(rg + (((size_t)n * a.H + y) * a.W + x) * COUT + (t0 * 4 + cc) * 8);
+                        }
+                }
+#pragma unroll
+                for (int t = 0; t < SP; ++t)
                     if (t < nt)
 #pragma unroll
                         for (int g = 0; g < 4; ++g)
@@ -305,15 +328,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a) {
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
+                for (int jj = 0; jj < 2 * SP; ++jj) {
                     if (jj < 2 * nt) {
-                        const int cpr = 4 * nt, e = lane + 64 * jj, px = e / cpr, cc = e - px * cpr, x = x0 + px, ch8 = t0 * 4 + cc;
+                        const int e = lane + 64 * jj, px = e / cpr, cc = e - px * cpr, x = x0 + px, ch8 = t0 * 4 + cc;
                         const V8 v = *reinterpret_cast<const V8*>(slab + px * RS + cc * 16);
                         float f[8];
 #pragma unroll
                         for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
                         if (rg) {
-                            const V8 r = rres[b][(t0 / 4) * 8 + jj];
+                            const V8 r = PRE_RES ? rres[b][PRE_RES ? (t0 / SP) * 2 * SP + jj : 0] : rl[jj];
 #pragma unroll
                             for (int i = 0; i < 8; ++i) f[i] += (float)r[i];
                         }
@@ -346,26 +369,37 @@ extern "C" int gf_debug_k7_trace(long long* out) {
 namespace {
 #endif
 
-template <typename T, int CIN, int COUT>
-int conv_launch(const ConvArgs& a, hipStream_t st) {
-    constexpr int NT = COUT / 32;
-    constexpr int lds = ConvGeo<NT>::LDS;
+template <typename T, int CIN, int COUT, int NW>
+int conv_launch(ConvArgs a, hipStream_t st) {
+    using G = ConvGeo<COUT / 32, NW>;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_kernel<T, CIN, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)conv3x3_kernel<T, CIN, COUT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
         attr = true;
     }
-    conv3x3_kernel<T, CIN, COUT><<<a.ntiles < 256 ? a.ntiles : 256, 256, lds, st>>>(a);
+    a.tiles_x = (a.W + TW - 1) / TW;
+    a.tiles_y = (a.H + G::TH - 1) / G::TH;
+    const long nt = (long)a.N * a.tiles_x * a.tiles_y;
+    if (nt >= (1l << 31)) return -2;
+    a.ntiles = (int)nt;
+    conv3x3_kernel<T, CIN, COUT, NW><<<a.ntiles < 256 ? a.ntiles : 256, NW * 64, G::LDS, st>>>(a);
     return 0;
+}
+
+// 8 waves per workgroup: measured 1.1-1.3x faster than 4 at every shape (tools/k7_time.py); the 4-wave form stays
+// instantiable (conv_launch<..., 4>) for experiments
+template <typename T, int CIN, int COUT>
+int conv_launch_w(const ConvArgs& a, hipStream_t st) {
+    return conv_launch<T, CIN, COUT, 8>(a, st);
 }
 
 template <typename T>
 int conv_dispatch(const ConvArgs& a, int cin, int cout, hipStream_t st) {
-    if (cin == 128 && cout == 128) return conv_launch<T, 128, 128>(a, st);
-    if (cin == 224 && cout == 224) return conv_launch<T, 224, 224>(a, st);
-    if (cin == 224 && cout == 128) return conv_launch<T, 224, 128>(a, st);
-    if (cin == 256 && cout == 256) return conv_launch<T, 256, 256>(a, st);
-    if (cin == 256 && cout == 224) return conv_launch<T, 256, 224>(a, st);
+    if (cin == 128 && cout == 128) return conv_launch_w<T, 128, 128>(a, st);
+    if (cin == 224 && cout == 224) return conv_launch_w<T, 224, 224>(a, st);
+    if (cin == 224 && cout == 128) return conv_launch_w<T, 224, 128>(a, st);
+    if (cin == 256 && cout == 256) return conv_launch_w<T, 256, 256>(a, st);
+    if (cin == 256 && cout == 224) return conv_launch_w<T, 256, 224>(a, st);
     return -1;
 }
 
@@ -389,10 +423,8 @@ extern "C" int gf_conv3x3_nhwc(const void* x, const void* wstream, const float* 
     GF_CHECK_ARG(act != C7_LEAKY || (slope >= 0.f && slope <= 1.f), "LeakyReLU slope must lie in [0, 1]");
     GF_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)residual % 16 == 0 && (uintptr_t)wstream % 16 == 0 &&
                      (uintptr_t)zeros % 16 == 0, "tensors must be 16-byte aligned");
-    const int th = cout <= 128 ? 8 : 4;                             // ConvGeo<NT>::TH
-    ConvArgs a{x, wstream, shift, residual, out, zeros, N, H, W, act, slope, (W + TW - 1) / TW, (H + th - 1) / th, 0};
-    GF_CHECK_ARG((long)N * a.tiles_x * a.tiles_y < (1l << 31), "too many tiles");
-    a.ntiles = N * a.tiles_x * a.tiles_y;
+    GF_CHECK_ARG((long)N * H * W * (cin > cout ? cin : cout) < (1l << 31), "maps of 2^31 elements or more are not supported");
+    ConvArgs a{x, wstream, shift, residual, out, zeros, N, H, W, act, slope, 0, 0, 0};
     hipStream_t st = (hipStream_t)stream;
     void* pt = gf_prof_begin("conv3x3", st, 2.0 * N * (double)H * W * cin * cout * 9.0);
     const int rc = dtype == GF_F16 ? conv_dispatch<_Float16>(a, cin, cout, st) : conv_dispatch<gf_bf16>(a, cin, cout, st);

@@ -122,8 +122,8 @@ _ZEROS = {}
 
 def pack_conv3x3_stream(w):
     """w [Cout, Cin, 3, 3] (BatchNorm already folded, 16-bit) -> the fragment stream of gf_conv3x3_nhwc: for each 32-channel
-    input chunk c, tap t = 3 ky + kx and 16-deep k-step s the Cout/32 standard-order fragments of W[:, 32c + 16s ..., ky, kx];
-    zero-padded to whole weight blocks (8 steps for Cout <= 128, else 4)."""
+    input chunk c, tap t = 3 ky + kx and 16-deep k-step s the Cout/32 standard-order fragments of W[:, 32c + 16s ..., ky, kx]
+    (18 steps per chunk; the kernel's weight blocks are 3 or 6 consecutive steps)."""
     cout, cin = w.shape[:2]
     nt = cout // 32
     wt = w.reshape(cout, cin, 9)
@@ -133,12 +133,7 @@ def pack_conv3x3_stream(w):
             f = fragments(wt[:, 32 * c:32 * c + 32, t].contiguous(), 'std')            # [nt, 2, 64, 8]
             for s in range(2):
                 parts.append(f[:, s].reshape(-1))
-    stream = torch.cat(parts)
-    block = (8 if nt <= 4 else 4) * nt * 512                                          # elements per weight block
-    pad = (-stream.numel()) % block
-    if pad:
-        stream = torch.cat([stream, stream.new_zeros(pad)])
-    return stream.contiguous()
+    return torch.cat(parts).contiguous()
 
 
 def conv3x3_supported(cin, cout):

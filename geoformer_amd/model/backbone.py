@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import ops
+from .. import fused, ops
 
 
 def _conv(cin, cout, k, stride=1):
@@ -91,13 +91,13 @@ def _fold(conv, bn, dtype, pad_multiple=1, pad_out=True):
 
 
 class FusedInferenceBackbone:
-    """Inference form of ResNetFPN_8_2 for the fp16 mode: BatchNorm folded into the
-    preceding convolution, channels_last throughout so MIOpen stays on its NHWC kernels, the convolutions
-    called WITHOUT bias, and everything between them - BN shift, ReLU / LeakyReLU, the BasicBlock shortcut
-    add, the two FPN upsample+add merges - done by the two glue kernels of csrc/k_backbone_glue.hip, one
-    read and one write per activation map (the eager sequence made ~50 element-wise passes per call, a
-    third of the backbone's time at batch 16).  Same arithmetic as resnet_fpn.py:85-118 in eval mode up to
-    fp16 rounding points."""
+    """Inference form of ResNetFPN_8_2 for the 16-bit modes: BatchNorm folded into the
+    preceding convolution, channels_last throughout.  The 3x3 / stride-1 convolutions (13 of the 17, >90 % of
+    the backbone's FLOPs) run on K7 (csrc/k7_conv3x3.hip) with the BN shift, the BasicBlock shortcut add and
+    ReLU / LeakyReLU in the kernel's epilogue; the three stride-2 convolutions, the 1x1 laterals and the
+    downsample shortcuts go through MIOpen (NHWC, called WITHOUT bias) with the glue kernels of
+    csrc/k_backbone_glue.hip in between (one read and one write per activation map); the stem is its own
+    kernel.  Same arithmetic as resnet_fpn.py:85-118 in eval mode up to fp16 rounding points."""
 
     def __init__(self, bb: 'ResNetFPN_8_2', dtype, pad_multiple=32):
         self.dtype = dtype
@@ -117,7 +117,7 @@ class FusedInferenceBackbone:
                 if blk.downsample is not None:
                     wd, bd = _fold(blk.downsample[0], blk.downsample[1], dtype, pm)
                     b2 = (b2 + bd).contiguous()
-                self.blocks.append((w1, b1, w2, b2, wd, blk.conv1.stride))
+                self.blocks.append((w1, b1, w2, b2, wd, blk.conv1.stride, self._stream(w1, blk.conv1.stride), self._stream(w2)))
         self.l3_out = _fold(bb.layer3_outconv, None, dtype, pm)[0]
         self.l2_out = _fold(bb.layer2_outconv, None, dtype, pm)[0]
         self.l1_out = _fold(bb.layer1_outconv, None, dtype, pm)[0]
@@ -125,22 +125,41 @@ class FusedInferenceBackbone:
                        _fold(bb.layer2_outconv2[3], None, dtype, pm)[0])
         self.l1_oc2 = (_fold(bb.layer1_outconv2[0], bb.layer1_outconv2[1], dtype, pm), bb.layer1_outconv2[2].negative_slope,
                        _fold(bb.layer1_outconv2[3], None, dtype, pm, pad_out=False)[0])   # the fine map keeps its width
+        self.l2_oc2 += (self._stream(self.l2_oc2[0][0]), self._stream(self.l2_oc2[2]))
+        self.l1_oc2 += (self._stream(self.l1_oc2[0][0]), self._stream(self.l1_oc2[2]))
 
     @staticmethod
     def _conv(x, w, stride=1):
         y = F.conv2d(x, w, None, stride, w.shape[-1] // 2)
         return y if y.is_contiguous(memory_format=torch.channels_last) else y.contiguous(memory_format=torch.channels_last)
 
+    def _stream(self, w, stride=(1, 1)):
+        """K7 fragment stream of a 3x3 / stride-1 convolution whose widths gf_conv3x3_nhwc is built for (16-bit modes), else None
+        (the convolution then goes through MIOpen + the glue kernel)."""
+        if self.dtype == torch.float32 or tuple(w.shape[2:]) != (3, 3) or tuple(stride) != (1, 1):
+            return None
+        if not fused.conv3x3_supported(w.shape[1], w.shape[0]):
+            return None
+        return fused.pack_conv3x3_stream(w)
+
+    def _conv3(self, x, w, ws, shift, shortcut, act, slope=0.01, stride=1):
+        """act(conv(x, w) + shift + shortcut): one K7 launch when a stream exists."""
+        if ws is not None:
+            return fused.conv3x3(x, ws, w.shape[0], shift, shortcut, act, slope)
+        y = self._conv(x, w, stride)
+        if shift is None and shortcut is None and act == ops.ACT_NONE:
+            return y
+        return ops.bias_act_(y, shift, shortcut, act, slope)
+
     def _block(self, x, p):
-        w1, b1, w2, b2, wd, stride = p
-        y = ops.bias_act_(self._conv(x, w1, stride), b1, None, ops.ACT_RELU)
-        y = self._conv(y, w2)
+        w1, b1, w2, b2, wd, stride, s1, s2 = p
+        y = self._conv3(x, w1, s1, b1, None, ops.ACT_RELU, stride=stride)
         shortcut = x if wd is None else self._conv(x, wd, stride)
-        return ops.bias_act_(y, b2, shortcut, ops.ACT_RELU)
+        return self._conv3(y, w2, s2, b2, shortcut, ops.ACT_RELU)
 
     def _head(self, x, p):
-        (w0, b0), slope, w3 = p
-        return self._conv(ops.bias_act_(self._conv(x, w0), b0, None, ops.ACT_LEAKY, slope), w3)
+        (w0, b0), slope, w3, s0, s3 = p
+        return self._conv3(self._conv3(x, w0, s0, b0, None, ops.ACT_LEAKY, slope), w3, s3, None, None, ops.ACT_NONE)
 
     def __call__(self, x):
         if self.stem_hip is not None:

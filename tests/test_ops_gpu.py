@@ -418,6 +418,57 @@ def test_fused_backbone_vs_module(dtype, bound):
         assert err < bound, err                                 # 16-bit weights + activations through 20 convolutions
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('cin,cout,hw,act,use_res,use_shift', [
+    (128, 128, (64, 96), 'relu', True, True),        # BasicBlock conv2: shift + shortcut + ReLU, whole tiles
+    (128, 128, (37, 70), 'relu', False, True),       # ragged in both directions, several tiles per workgroup round
+    (224, 224, (23, 33), 'leaky', False, True),      # FPN head conv0: shift + LeakyReLU (one row per wave form)
+    (224, 128, (40, 40), 'none', False, False),      # FPN head conv3: plain convolution
+    (256, 256, (10, 10), 'relu', True, True),        # image smaller than a tile
+    (256, 224, (20, 28), 'none', True, False),
+    (128, 128, (1, 1), 'relu', True, True),          # single pixel: everything but the centre tap reads the zero page
+])
+def test_conv3x3_vs_torch(dtype, cin, cout, hw, act, use_res, use_shift):
+    """K7 (gf_conv3x3_nhwc) against torch's fp32 convolution of the same 16-bit operands + shift + shortcut + activation.
+    Tolerance: the result is rounded to the storage type twice (accumulator + shift -> slab; + shortcut, activation ->
+    output), each by at most half an ulp of the value rounded."""
+    from geoformer_amd import fused, ops
+    torch.manual_seed(cin + cout + hw[0])
+    N, (H, W) = 3, hw
+    x = torch.randn(N, cin, H, W, device='cuda').to(dtype).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, 3, 3, device='cuda') * (1.5 / (3 * cin ** 0.5))).to(dtype)
+    shift = torch.randn(cout, device='cuda') if use_shift else None
+    res = torch.randn(N, cout, H, W, device='cuda').to(dtype).contiguous(memory_format=torch.channels_last) if use_res else None
+    assert fused.conv3x3_supported(cin, cout)
+    ws = fused.pack_conv3x3_stream(w)
+    code = {'none': ops.ACT_NONE, 'relu': ops.ACT_RELU, 'leaky': ops.ACT_LEAKY}[act]
+    out = fused.conv3x3(x, ws, cout, shift, res, code, 0.1)
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), None, 1, 1)
+    if use_shift:
+        ref = ref + shift[None, :, None, None]
+    pre = ref                                        # the value the slab rounds (before the shortcut is added)
+    if use_res:
+        ref = ref + res.float()
+    ref = {'none': lambda t: t, 'relu': torch.relu, 'leaky': lambda t: torch.nn.functional.leaky_relu(t, 0.1)}[act](ref)
+    assert out.shape == ref.shape and out.dtype == dtype and out.is_contiguous(memory_format=torch.channels_last)
+    ulp = 2.0 ** (-10 if dtype == torch.float16 else -7)
+    err = (out.float() - ref).abs()
+    assert float((err / torch.maximum(pre.abs(), ref.abs()).clamp_min(1.0)).max()) < 1.1 * ulp, float(err.max())
+    # a second call (persistent workgroups leave nothing behind) gives the same bits
+    assert torch.equal(out, fused.conv3x3(x, ws, cout, shift, res, code, 0.1))
+
+
+def test_conv3x3_rejects_unsupported():
+    from geoformer_amd import fused, _lib
+    assert not fused.conv3x3_supported(64, 64)
+    x = torch.zeros(1, 64, 8, 8, device='cuda', dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+    with pytest.raises(_lib.GeoFormerHipError):
+        fused.conv3x3(x, torch.zeros(64 * 64 * 9, device='cuda', dtype=torch.float16), 64)
+    x = torch.zeros(1, 128, 8, 8, device='cuda', dtype=torch.float16)          # NCHW: refused on the host side
+    with pytest.raises(ValueError):
+        fused.conv3x3(x, torch.zeros(128 * 128 * 9, device='cuda', dtype=torch.float16), 128)
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
 @pytest.mark.parametrize('hw', [(64, 96), (37, 51), (480, 640)])
 def test_stem_conv_vs_torch(dtype, hw):

@@ -18,14 +18,14 @@ for res in (z, None):
     for _ in range(3):
         fused.conv3x3(x, ws, CO, b, res, ops.ACT_RELU)
     torch.cuda.synchronize()
-    buf = np.zeros(256 * 8 * 4 * 16, dtype=np.int64)
+    buf = np.zeros(256 * 8 * 8 * 16, dtype=np.int64)
     fn(buf.ctypes.data_as(ctypes.c_void_p))
-    T4 = buf.reshape(256, 8, 4, 16)
+    T4 = buf.reshape(256, 8, 8, 16)
     t = T4[:, :, 0]
     nch = CI // 32
     cols = [0, 1] + list(range(2, 2 + nch)) + [10, 11]
     print(f'{CI}->{CO} {H}x{H} residual={res is not None}: slots {cols}')
-    for w in range(4):
+    for w in range(8):
         d = T4[:, 4, w, [12, 13, 14, 15, 2, 10, 11]] - T4[:, 4, 0, :1]
         print(f'  tile 4 wave {w}: turn0 reached/vm-waited/barrier passed/dma issued, chunk0 done, epilogue start, end:', np.median(d, axis=0).astype(int).tolist())
     for it in (0, 1, 4, 7):
