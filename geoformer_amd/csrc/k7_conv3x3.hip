@@ -182,8 +182,6 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
         conv_dma_block<NT, NW>(ws, smem, 1, 1, wave, lane);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
-        load_w(wa, 0, 0);
-        load_x(xa, 0, 0);
     }
     [[maybe_unused]] int it = -1;
     bool prev_full = false;                                         // previous tile of this workgroup: all its stores issued?
@@ -194,13 +192,17 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
         const bool has_next = nxt_tile < a.ntiles;
         ++it;
         K7_T(0);
+        load_w(wa, wslot, 0);               // block 0 and the patch of chunk 0 landed before the previous tile's last turn
+        load_x(xa, pbuf, 0);
         v16f acc[PB][NT];
         // accumulators start at the shift of their channel: 32 t + 8 (r / 4) + 4 h2 + (r % 4)
+        int il = lane;
+        asm volatile("" : "+v"(il));
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 sh = *reinterpret_cast<const float4*>(shiftv + 32 * t + 8 * g + 4 * h2);
+                const float4 sh = *reinterpret_cast<const float4*>(shiftv + 32 * t + 8 * g + 4 * (il >> 5));
 #pragma unroll
                 for (int b = 0; b < PB; ++b) {
                     acc[b][t][4 * g] = sh.x;
@@ -272,9 +274,11 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
                     if (ts == BS - 1 && c == 0) K7_T(15);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                // next step's fragments (after the last step of a tile: the next tile's first, or stale bytes nobody uses)
-                load_w(nw, wslot, (ts + 1) % BS);
-                load_x(nx, ts == 17 ? pbuf ^ 1 : pbuf, (ts + 1) % 18);
+                // next step's fragments (a tile's first ones are read at its start: held across the epilogue they spill)
+                if (ts < 17 || c + 1 < NCH) {
+                    load_w(nw, wslot, (ts + 1) % BS);
+                    load_x(nx, ts == 17 ? pbuf ^ 1 : pbuf, (ts + 1) % 18);
+                }
 #pragma unroll
                 for (int b = 0; b < PB; ++b)
 #pragma unroll
@@ -297,50 +301,77 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
         K7_T(10);
         char* slab = smem + G::SLAB_OFF + wave * 32 * RS;
         // act(f) = max(f, 0) ReLU; else max(f, k f) with k = the slope (0 <= slope <= 1) LeakyReLU, 1 none: uniform per chunk
-        const bool relu = a.act == C7_RELU;
-        const float neg_k = a.act == C7_LEAKY ? a.slope : 1.f;
+        const bool relu = a.act == C7_RELU, leaky = a.act == C7_LEAKY;
+        const float neg_k = leaky ? a.slope : 1.f;
+        // passes p = (pixel block b, tile group t0); the shortcut rows of pass p + 1 are requested before pass p is worked on
+        constexpr int PPB = (NT + SP - 1) / SP, NPASS = PB * PPB;
+        int el = lane;                      // (recompute the lane's slab / pixel offsets per tile: kept across the K loop they spill)
+        asm volatile("" : "+v"(el));
+        V8 rl[2][2 * SP];
 #pragma unroll
-        for (int b = 0; b < PB; ++b) {
-            const int y = y0 + PB * wave + b;
+        for (int i = 0; i < 2 * 2 * SP; ++i)                       // (defined on every path: otherwise carried from tile to tile)
 #pragma unroll
-            for (int t0 = 0; t0 < NT; t0 += SP) {
-                const int nt = pass_tiles(t0), cpr = 4 * nt;
-                V8 rl[2 * SP];                                      // shortcut rows of this pass when they were not prefetched
-                if (!PRE_RES && rg) {
+            for (int k = 0; k < 8; ++k) rl[i / (2 * SP)][i % (2 * SP)][k] = (T)0.f;
+        auto load_res = [&](V8 (&dstv)[2 * SP], int p) {
+            const int b = p / PPB, t0 = (p % PPB) * SP, nt = pass_tiles(t0), cpr = 4 * nt, y = y0 + PB * wave + b;
 #pragma unroll
-                    for (int jj = 0; jj < 2 * SP; ++jj)
-                        if (jj < 2 * nt) {
-                            const int e = lane + 64 * jj, px = e / cpr, cc = e - px * cpr, x = x0 + px;
+            for (int jj = 0; jj < 2 * SP; ++jj)
+                if (jj < 2 * nt) {
+                    const int e = el + 64 * jj, px = e / cpr, cc = e - px * cpr, x = x0 + px;
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) rl[jj][i] = (T)0.f;
-                            if (y < a.H && x < a.W)
-                                rl[jj] = *reinterpret_cast<const V8*>(rg + (((size_t)n * a.H + y) * a.W + x) * COUT + (t0 * 4 + cc) * 8);
-                        }
+                    for (int i = 0; i < 8; ++i) dstv[jj][i] = (T)0.f;
+                    if (y < a.H && x < a.W)
+                        dstv[jj] = *reinterpret_cast<const V8*>(rg + (((size_t)n * a.H + y) * a.W + x) * COUT + (t0 * 4 + cc) * 8);
                 }
+        };
+        // the accumulators are packed to the storage type first: half the registers, room for the shortcut rows
+        V4 pk[PB][NT][4];
 #pragma unroll
-                for (int t = 0; t < SP; ++t)
-                    if (t < nt)
+        for (int b = 0; b < PB; ++b)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            *reinterpret_cast<V4*>(slab + lr * RS + (t * 32 + 8 * g + 4 * h2) * 2) =
-                                V4{(T)acc[b][t0 + t][4 * g], (T)acc[b][t0 + t][4 * g + 1], (T)acc[b][t0 + t][4 * g + 2], (T)acc[b][t0 + t][4 * g + 3]};
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int jj = 0; jj < 2 * SP; ++jj) {
-                    if (jj < 2 * nt) {
-                        const int e = lane + 64 * jj, px = e / cpr, cc = e - px * cpr, x = x0 + px, ch8 = t0 * 4 + cc;
-                        const V8 v = *reinterpret_cast<const V8*>(slab + px * RS + cc * 16);
+                for (int g = 0; g < 4; ++g)
+                    pk[b][t][g] = V4{(T)acc[b][t][4 * g], (T)acc[b][t][4 * g + 1], (T)acc[b][t][4 * g + 2], (T)acc[b][t][4 * g + 3]};
+        __builtin_amdgcn_sched_barrier(0);
+        if (!PRE_RES && rg) load_res(rl[0], 0);
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            const int b = p / PPB, t0 = (p % PPB) * SP, nt = pass_tiles(t0), cpr = 4 * nt, y = y0 + PB * wave + b;
+            if (!PRE_RES && rg && p + 1 < NPASS) load_res(rl[(p + 1) & 1], p + 1);
+#pragma unroll
+            for (int t = 0; t < SP; ++t)
+                if (t < nt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<V4*>(slab + (el & 31) * RS + (t * 32 + 8 * g + 4 * (el >> 5)) * 2) = pk[b][t0 + t][g];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int jj = 0; jj < 2 * SP; ++jj) {
+                if (jj < 2 * nt) {
+                    const int e = el + 64 * jj, px = e / cpr, cc = e - px * cpr, x = x0 + px, ch8 = t0 * 4 + cc;
+                    const V8 v = *reinterpret_cast<const V8*>(slab + px * RS + cc * 16);
+                    V8 o;
+                    if constexpr (std::is_same<T, _Float16>::value) {
+                        // packed half arithmetic: the sum of two halves rounded to half is what the fp32 route gives
+                        // (up to a double rounding when the exponents are > 13 apart), max is exact
+                        if (!leaky) {
+                            o = v;
+                            if (rg) o = o + (PRE_RES ? rres[b][PRE_RES ? (t0 / SP) * 2 * SP + jj : 0] : rl[p & 1][jj]);
+                            if (relu) o = __builtin_elementwise_max(o, V8{0, 0, 0, 0, 0, 0, 0, 0});
+                        }
+                    }
+                    if (!std::is_same<T, _Float16>::value || leaky) {
                         float f[8];
 #pragma unroll
                         for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
                         if (rg) {
-                            const V8 r = PRE_RES ? rres[b][PRE_RES ? (t0 / SP) * 2 * SP + jj : 0] : rl[jj];
+                            const V8 r = PRE_RES ? rres[b][PRE_RES ? (t0 / SP) * 2 * SP + jj : 0] : rl[p & 1][jj];
 #pragma unroll
                             for (int i = 0; i < 8; ++i) f[i] += (float)r[i];
                         }
-                        V8 o;
                         if (relu) {
 #pragma unroll
                             for (int i = 0; i < 8; ++i) o[i] = (T)fmaxf(f[i], 0.f);
@@ -348,12 +379,12 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
                             for (int i = 0; i < 8; ++i) o[i] = (T)fmaxf(f[i], f[i] * neg_k);
                         }
-                        if (y < a.H && x < a.W && K7_STORE_OK) *reinterpret_cast<V8*>(og + (((size_t)n * a.H + y) * a.W + x) * COUT + ch8 * 8) = o;
                     }
+                    if (y < a.H && x < a.W && K7_STORE_OK) *reinterpret_cast<V8*>(og + (((size_t)n * a.H + y) * a.W + x) * COUT + ch8 * 8) = o;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
         prev_full = y0 + TH <= a.H && x0 + TW <= a.W;
         K7_T(11);

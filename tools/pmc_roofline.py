@@ -67,11 +67,12 @@ TAG_FAMILIES = {
     'k2_linear_attention': ['la16_', 'la_kv_', 'la_apply', 'la_small'],
     'k5_window_attention': ['window_cross_attention'],
     'bias_act': ['bias_act<'],
+    'conv3x3': ['conv3x3_kernel'],
 }
 # the family whose call count equals the number of tagged calls
 TAG_PRIMARY = {'enc_layer': 'enc_layer<', 'enc_kv_state': 'enc_kv_state<', 'k3_linear': 'linear_kernel', 'k1_stats': 'k1_stats',
                'k1_conf': 'k1_conf', 'k2_linear_attention': ('la16_apply', 'la_apply', 'la_small'), 'k5_window_attention': 'window_cross_attention',
-               'bias_act': 'bias_act<'}
+               'bias_act': 'bias_act<', 'conv3x3': 'conv3x3_kernel'}
 
 
 def counters(d):
