@@ -136,7 +136,6 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
     using V8 = gf_vec<T, 8>;
     constexpr int NT = COUT / 32, NCH = CIN / 32, BS = G::BLOCK_STEPS, BPC = 18 / BS, NBLK = NCH * BPC;
     constexpr int PB = G::PB, TH = G::TH, RS = G::RS, SP = G::SP;
-    constexpr bool PRE_RES = NW == 4;                               // shortcut rows prefetched into registers (room for them)
     constexpr int NSTORE = PB * 2 * NT;                             // 16-byte output stores per lane and tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h2 = lane >> 5, lr = lane & 31;
@@ -211,8 +210,6 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
                     acc[b][t][4 * g + 3] = sh.w;
                 }
             }
-        // shortcut rows of this lane's epilogue chunks (fetched at the start of the last channel chunk)
-        V8 rres[PB][PRE_RES ? 16 : 1];
         const T* rg = (const T*)a.res;
         T* og = (T*)a.out;
         // the epilogue runs in passes of SP accumulator tiles (the last pass of 224 channels: one fewer); in pass t0,
@@ -221,25 +218,6 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
 
 #pragma unroll 1
         for (int c = 0; c < NCH; ++c) {
-            if (PRE_RES && c == NCH - 1 && rg) {
-#pragma unroll
-                for (int b = 0; b < PB; ++b) {
-                    const int y = y0 + PB * wave + b;
-#pragma unroll
-                    for (int t0 = 0; t0 < NT; t0 += SP)
-#pragma unroll
-                        for (int jj = 0; jj < 2 * SP; ++jj)
-                            if (jj < 2 * pass_tiles(t0)) {
-                                const int cpr = 4 * pass_tiles(t0), e = lane + 64 * jj, px = e / cpr, cc = e - px * cpr, x = x0 + px;
-                                V8 v;
-#pragma unroll
-                                for (int i = 0; i < 8; ++i) v[i] = (T)0.f;
-                                if (y < a.H && x < a.W)
-                                    v = *reinterpret_cast<const V8*>(rg + (((size_t)n * a.H + y) * a.W + x) * COUT + (t0 * 4 + cc) * 8);
-                                rres[b][PRE_RES ? (t0 / SP) * 2 * SP + jj : 0] = v;
-                            }
-                }
-            }
 #pragma unroll
             for (int ts = 0; ts < 18; ++ts) {                       // (tap, k-step) of this chunk
                 Frag (&cw)[NT] = (ts & 1) ? wb : wa;
@@ -297,96 +275,114 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
             pbuf ^= 1;
             K7_T(2 + c);
         }
-        // ---------------- epilogue (wave-private): T(acc) -> slab [pixel][128 channels] -> + shift + shortcut -> act -> NHWC
+        // ---------------- epilogue (wave-private): T(acc) -> slab [pixel][SP x 32 channels] -> + shortcut -> act -> NHWC
         K7_T(10);
-        char* slab = smem + G::SLAB_OFF + wave * 32 * RS;
-        // act(f) = max(f, 0) ReLU; else max(f, k f) with k = the slope (0 <= slope <= 1) LeakyReLU, 1 none: uniform per chunk
-        const bool relu = a.act == C7_RELU, leaky = a.act == C7_LEAKY;
-        const float neg_k = leaky ? a.slope : 1.f;
-        // passes p = (pixel block b, tile group t0); the shortcut rows of pass p + 1 are requested before pass p is worked on
-        constexpr int PPB = (NT + SP - 1) / SP, NPASS = PB * PPB;
-        int el = lane;                      // (recompute the lane's slab / pixel offsets per tile: kept across the K loop they spill)
-        asm volatile("" : "+v"(el));
-        V8 rl[2][2 * SP];
+        const bool full = y0 + TH <= a.H && x0 + TW <= a.W;
+        // one straight-line body per (shortcut?, activation form, tile inside the image?): with these as run-time branches
+        // inside the passes every join waits for vmcnt(0), i.e. for the previous pass's stores to come back
+        auto epilogue = [&](auto has_res_c, auto mode_c, auto full_c) {
+            constexpr bool HAS_RES = decltype(has_res_c)::value, FULL = decltype(full_c)::value;
+            constexpr int MODE = decltype(mode_c)::value;       // 0 packed-half ReLU, 1 packed-half none, 2 fp32 ReLU, 3 fp32 max(f, k f)
+            char* slab = smem + G::SLAB_OFF + wave * 32 * RS;
+            const float neg_k = a.act == C7_LEAKY ? a.slope : 1.f;
+            constexpr int PPB = (NT + SP - 1) / SP, NPASS = PB * PPB;     // passes p = (pixel block b, tile group t0)
+            int el = lane;                  // (recompute the lane's slab / pixel offsets per tile: kept across the K loop they spill)
+            asm volatile("" : "+v"(el));
+            // two rows per wave: the accumulators are packed to the storage type first (half the registers: room for the
+            // shortcut rows); one row per wave: converted as they are written (there the packed copy is what spills)
+            constexpr bool PACK_FIRST = PB == 2;
+            V4 pk[PACK_FIRST ? PB : 1][PACK_FIRST ? NT : 1][4];
+            if constexpr (PACK_FIRST) {
 #pragma unroll
-        for (int i = 0; i < 2 * 2 * SP; ++i)                       // (defined on every path: otherwise carried from tile to tile)
+                for (int b = 0; b < PB; ++b)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) rl[i / (2 * SP)][i % (2 * SP)][k] = (T)0.f;
-        auto load_res = [&](V8 (&dstv)[2 * SP], int p) {
-            const int b = p / PPB, t0 = (p % PPB) * SP, nt = pass_tiles(t0), cpr = 4 * nt, y = y0 + PB * wave + b;
+                    for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int jj = 0; jj < 2 * SP; ++jj)
-                if (jj < 2 * nt) {
-                    const int e = el + 64 * jj, px = e / cpr, cc = e - px * cpr, x = x0 + px;
+                        for (int g = 0; g < 4; ++g)
+                            pk[b][t][g] = V4{(T)acc[b][t][4 * g], (T)acc[b][t][4 * g + 1], (T)acc[b][t][4 * g + 2], (T)acc[b][t][4 * g + 3]};
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // every shortcut row is requested before the first output store: a load waited for behind a store (the memory
+            // counter is in issue order) would expose the store's round trip once per pass
+            V8 rl[HAS_RES ? NPASS : 1][2 * SP];
+            if constexpr (HAS_RES) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) dstv[jj][i] = (T)0.f;
-                    if (y < a.H && x < a.W)
-                        dstv[jj] = *reinterpret_cast<const V8*>(rg + (((size_t)n * a.H + y) * a.W + x) * COUT + (t0 * 4 + cc) * 8);
-                }
-        };
-        // the accumulators are packed to the storage type first: half the registers, room for the shortcut rows
-        V4 pk[PB][NT][4];
+                for (int p = 0; p < NPASS; ++p) {
+                    const int b = p / PPB, t0 = (p % PPB) * SP, nt = pass_tiles(t0), cpr = 4 * nt, y = y0 + PB * wave + b;
 #pragma unroll
-        for (int b = 0; b < PB; ++b)
+                    for (int jj = 0; jj < 2 * SP; ++jj)
+                        if (jj < 2 * nt) {
+                            const int e = el + 64 * jj, px = e / cpr, cc = e - px * cpr, x = x0 + px;
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    pk[b][t][g] = V4{(T)acc[b][t][4 * g], (T)acc[b][t][4 * g + 1], (T)acc[b][t][4 * g + 2], (T)acc[b][t][4 * g + 3]};
-        __builtin_amdgcn_sched_barrier(0);
-        if (!PRE_RES && rg) load_res(rl[0], 0);
-#pragma unroll
-        for (int p = 0; p < NPASS; ++p) {
-            const int b = p / PPB, t0 = (p % PPB) * SP, nt = pass_tiles(t0), cpr = 4 * nt, y = y0 + PB * wave + b;
-            if (!PRE_RES && rg && p + 1 < NPASS) load_res(rl[(p + 1) & 1], p + 1);
-#pragma unroll
-            for (int t = 0; t < SP; ++t)
-                if (t < nt)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        *reinterpret_cast<V4*>(slab + (el & 31) * RS + (t * 32 + 8 * g + 4 * (el >> 5)) * 2) = pk[b][t0 + t][g];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int jj = 0; jj < 2 * SP; ++jj) {
-                if (jj < 2 * nt) {
-                    const int e = el + 64 * jj, px = e / cpr, cc = e - px * cpr, x = x0 + px, ch8 = t0 * 4 + cc;
-                    const V8 v = *reinterpret_cast<const V8*>(slab + px * RS + cc * 16);
-                    V8 o;
-                    if constexpr (std::is_same<T, _Float16>::value) {
-                        // packed half arithmetic: the sum of two halves rounded to half is what the fp32 route gives
-                        // (up to a double rounding when the exponents are > 13 apart), max is exact
-                        if (!leaky) {
-                            o = v;
-                            if (rg) o = o + (PRE_RES ? rres[b][PRE_RES ? (t0 / SP) * 2 * SP + jj : 0] : rl[p & 1][jj]);
-                            if (relu) o = __builtin_elementwise_max(o, V8{0, 0, 0, 0, 0, 0, 0, 0});
+                            for (int i = 0; i < 8; ++i) rl[p][jj][i] = (T)0.f;
+                            if (FULL || (y < a.H && x < a.W))
+                                rl[p][jj] = *reinterpret_cast<const V8*>(rg + (((size_t)n * a.H + y) * a.W + x) * COUT + (t0 * 4 + cc) * 8);
                         }
-                    }
-                    if (!std::is_same<T, _Float16>::value || leaky) {
-                        float f[8];
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
-                        if (rg) {
-                            const V8 r = PRE_RES ? rres[b][PRE_RES ? (t0 / SP) * 2 * SP + jj : 0] : rl[p & 1][jj];
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) f[i] += (float)r[i];
-                        }
-                        if (relu) {
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) o[i] = (T)fmaxf(f[i], 0.f);
-                        } else {
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) o[i] = (T)fmaxf(f[i], f[i] * neg_k);
-                        }
-                    }
-                    if (y < a.H && x < a.W && K7_STORE_OK) *reinterpret_cast<V8*>(og + (((size_t)n * a.H + y) * a.W + x) * COUT + ch8 * 8) = o;
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) {
+                const int b = p / PPB, t0 = (p % PPB) * SP, nt = pass_tiles(t0), cpr = 4 * nt, y = y0 + PB * wave + b;
+#pragma unroll
+                for (int t = 0; t < SP; ++t)
+                    if (t < nt)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            *reinterpret_cast<V4*>(slab + (el & 31) * RS + (t * 32 + 8 * g + 4 * (el >> 5)) * 2) =
+                                PACK_FIRST ? pk[PACK_FIRST ? b : 0][PACK_FIRST ? t0 + t : 0][g]
+                                           : V4{(T)acc[b][t0 + t][4 * g], (T)acc[b][t0 + t][4 * g + 1], (T)acc[b][t0 + t][4 * g + 2], (T)acc[b][t0 + t][4 * g + 3]};
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int jj = 0; jj < 2 * SP; ++jj) {
+                    if (jj < 2 * nt) {
+                        const int e = el + 64 * jj, px = e / cpr, cc = e - px * cpr, x = x0 + px, ch8 = t0 * 4 + cc;
+                        const V8 v = *reinterpret_cast<const V8*>(slab + px * RS + cc * 16);
+                        V8 o;
+                        if constexpr (MODE <= 1) {
+                            // packed half arithmetic: the sum of two halves rounded to half is what the fp32 route gives
+                            // (up to a double rounding when the exponents are > 13 apart), max is exact
+                            o = v;
+                            if constexpr (HAS_RES) o = o + rl[p][jj];
+                            if constexpr (MODE == 0) o = __builtin_elementwise_max(o, V8{0, 0, 0, 0, 0, 0, 0, 0});
+                        } else {
+                            float f[8];
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+                            if constexpr (HAS_RES) {
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) f[i] += (float)rl[p][jj][i];
+                            }
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) o[i] = (T)(MODE == 2 ? fmaxf(f[i], 0.f) : fmaxf(f[i], f[i] * neg_k));
+                        }
+                        if ((FULL || (y < a.H && x < a.W)) && K7_STORE_OK)
+                            *reinterpret_cast<V8*>(og + (((size_t)n * a.H + y) * a.W + x) * COUT + ch8 * 8) = o;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        };
+        using std::integral_constant;
+        auto by_tile = [&](auto has_res_c, auto mode_c) {
+            if (full) epilogue(has_res_c, mode_c, integral_constant<bool, true>{});
+            else epilogue(has_res_c, mode_c, integral_constant<bool, false>{});
+        };
+        auto by_res = [&](auto mode_c) {
+            if (rg) by_tile(integral_constant<bool, true>{}, mode_c);
+            else by_tile(integral_constant<bool, false>{}, mode_c);
+        };
+        if constexpr (std::is_same<T, _Float16>::value) {
+            if (a.act == C7_RELU) by_res(integral_constant<int, 0>{});
+            else if (a.act == C7_NONE) by_res(integral_constant<int, 1>{});
+            else by_res(integral_constant<int, 3>{});
+        } else {
+            if (a.act == C7_RELU) by_res(integral_constant<int, 2>{});
+            else by_res(integral_constant<int, 3>{});
         }
-        prev_full = y0 + TH <= a.H && x0 + TW <= a.W;
+        prev_full = full;
         K7_T(11);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
