@@ -46,7 +46,7 @@ ROOFLINE_TAGS = [
     ('k2_linear_attention',  'hbm',  True,  'K2 linear attention (state + apply)'),
     ('k5_window_attention',  'hbm',  True,  'K5 windowed cross attention (L2 gather)'),
     ('bias_act',             'hbm',  False, 'backbone glue: shift + shortcut + activation stream'),
-    ('conv3x3',              'mfma', False, 'K7 3x3 convolution of the backbone (BN shift + shortcut + activation in the epilogue; SURVEY 8f rank 4)'),
+    ('conv3x3',              'mfma', False, 'K10 3x3 convolution of the backbone (BN shift + shortcut + activation in the epilogue; SURVEY 8f rank 4)'),
 ]
 
 

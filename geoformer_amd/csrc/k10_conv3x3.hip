@@ -1,9 +1,9 @@
-// K7: 3x3 / stride 1 / pad 1 convolution of channels-last 16-bit maps with the BatchNorm shift, the BasicBlock
+// K10: 3x3 / stride 1 / pad 1 convolution of channels-last 16-bit maps with the BatchNorm shift, the BasicBlock
 // shortcut and the activation in its epilogue - the backbone's dominant shapes (SURVEY 8f rank 4:
 // model/loftr_src/loftr/backbone/resnet_fpn.py:9-40 BasicBlock, :60-83 the FPN heads), as an implicit GEMM on the
 // matrix cores:   out[n,y,x,:] = act( sum_{ky,kx} W[:, :, ky, kx] . x[n, y+ky-1, x+kx-1, :] + shift + shortcut[n,y,x,:] )
 //
-// Same machinery as K6 (k6_encoder_fused.hip): one wave per SIMD, products transposed (MFMA A = 32 output channels,
+// Same machinery as K9 (k9_encoder_fused.hip): one wave per SIMD, products transposed (MFMA A = 32 output channels,
 // B = 32 pixels, so a pixel's channels sit in one lane's registers), weights pre-packed on the host into the exact
 // sequence of 1-KiB MFMA A fragments the kernel consumes and streamed from L2 through a two-block LDS ring by LDS-DMA;
 // the fragments of step i+1 (weights AND pixels) are requested before the MFMAs of step i.
@@ -31,9 +31,9 @@
 namespace {
 
 constexpr int TW = 32, PW = TW + 2;               // tile / halo-patch width
-constexpr int C7_FRAG = 1024;
+constexpr int C10_FRAG = 1024;
 constexpr int P_OFF = 0;                          // two patches
-enum { C7_NONE = 0, C7_RELU = 1, C7_LEAKY = 2 };
+enum { C10_NONE = 0, C10_RELU = 1, C10_LEAKY = 2 };
 
 struct ConvArgs {
     const void* x;          // [N][H][W][CIN]
@@ -57,11 +57,11 @@ struct ConvGeo {
     static constexpr int TH = NW * PB, PH = TH + 2;               // tile / halo-patch height
     static constexpr int PIECES = (PH * PW + 15) / 16;            // DMA pieces of 16 pixels x 64 B
     static constexpr int PATCH_BYTES = PIECES * 1024;
-    static constexpr int W7_OFF = 2 * PATCH_BYTES;                // two weight blocks behind the two patches
+    static constexpr int W10_OFF = 2 * PATCH_BYTES;                // two weight blocks behind the two patches
     static constexpr int BLOCK_STEPS = NW == 8 ? 3 : 6;          // a sixth / a third of a chunk's 18 steps
     static constexpr int FR = BLOCK_STEPS * NT;                   // fragments per block
-    static constexpr int WBLK = FR * C7_FRAG;
-    static constexpr int SLAB_OFF = W7_OFF + 2 * WBLK;
+    static constexpr int WBLK = FR * C10_FRAG;
+    static constexpr int SLAB_OFF = W10_OFF + 2 * WBLK;
     static constexpr int SP = NW == 4 ? 4 : 2;                    // accumulator tiles per epilogue pass
     static constexpr int RS = SP * 64 + 16;                       // slab row: SP x 32 channels of a pixel + 16 B
     static constexpr int SHIFT_OFF = SLAB_OFF + NW * 32 * RS;     // one 32-pixel slab per wave
@@ -74,14 +74,14 @@ template <int NT, int NW>
 __device__ __forceinline__ void conv_dma_block(const char* ws, char* smem, int b, int slot, int wave, int lane) {
     using G = ConvGeo<NT, NW>;
     asm volatile("" : "+v"(lane));      // (as in conv_dma_patch)
-    char* dst = smem + G::W7_OFF + slot * G::WBLK;
+    char* dst = smem + G::W10_OFF + slot * G::WBLK;
     const char* src = ws + (size_t)b * G::WBLK + lane * 16;
 #pragma unroll
     for (int i = 0; i < (G::FR + NW - 1) / NW; ++i) {
         const int f = wave + NW * i;
         if (f < G::FR)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * C7_FRAG),
-                                             (__attribute__((address_space(3))) void*)(dst + f * C7_FRAG), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * C10_FRAG),
+                                             (__attribute__((address_space(3))) void*)(dst + f * C10_FRAG), 16, 0, 0);
     }
 }
 
@@ -111,20 +111,20 @@ __device__ __forceinline__ void conv_dma_patch(const ConvArgs& a, char* smem, in
     }
 }
 
-// -DK7_TRACE=1 records s_memtime at the phase boundaries of the first 8 tiles of every wave (tools/k7_trace.py)
-#ifndef K7_TRACE
-#define K7_TRACE 0
+// -DK10_TRACE=1 records s_memtime at the phase boundaries of the first 8 tiles of every wave (tools/k10_trace.py)
+#ifndef K10_TRACE
+#define K10_TRACE 0
 #endif
-#ifdef K7_EXP_NOSTORE
-#define K7_STORE_OK (a.slope == 12345.f)
+#ifdef K10_EXP_NOSTORE
+#define K10_STORE_OK (a.slope == 12345.f)
 #else
-#define K7_STORE_OK true
+#define K10_STORE_OK true
 #endif
-#if K7_TRACE
-__device__ long long k7_trace[256 * 8 * 8 * 16];
-#define K7_T(slot) do { if (lane == 0 && it < 8) k7_trace[((blockIdx.x * 8 + it) * 8 + wave) * 16 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#if K10_TRACE
+__device__ long long k10_trace[256 * 8 * 8 * 16];
+#define K10_T(slot) do { if (lane == 0 && it < 8) k10_trace[((blockIdx.x * 8 + it) * 8 + wave) * 16 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
-#define K7_T(slot)
+#define K10_T(slot)
 #endif
 
 template <typename T, int CIN, int COUT, int NW>
@@ -161,9 +161,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
         }
     Frag wa[NT], wb[NT], xa[PB], xb[PB];
     auto load_w = [&](Frag (&f)[NT], int slot, int s) {            // weight fragments of step s of the block in `slot`
-        const char* p = smem + G::W7_OFF + slot * G::WBLK + s * NT * C7_FRAG + lane * 16;
+        const char* p = smem + G::W10_OFF + slot * G::WBLK + s * NT * C10_FRAG + lane * 16;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) f[t] = *reinterpret_cast<const Frag*>(p + t * C7_FRAG);
+        for (int t = 0; t < NT; ++t) f[t] = *reinterpret_cast<const Frag*>(p + t * C10_FRAG);
     };
     auto load_x = [&](Frag (&f)[PB], int buf, int ts) {            // pixel fragments of (tap, k-step) = ts of the chunk in `buf`
         const int tap = ts >> 1, ky = tap / 3, kx = tap - 3 * ky;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
         const int nxt_tile = tile + gridDim.x;
         const bool has_next = nxt_tile < a.ntiles;
         ++it;
-        K7_T(0);
+        K10_T(0);
         load_w(wa, wslot, 0);               // block 0 and the patch of chunk 0 landed before the previous tile's last turn
         load_x(xa, pbuf, 0);
         v16f acc[PB][NT];
@@ -230,12 +230,12 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
                     // landed, every wave holds this block's last fragments in registers: its slot takes the block after next
                     // (the first turn of a tile only needs the block requested before the previous tile's epilogue: its
                     // NSTORE output stores - all issued when that tile lay inside the image - may stay in flight)
-                    if (ts == BS - 1 && c == 0) K7_T(12);
+                    if (ts == BS - 1 && c == 0) K10_T(12);
                     if (ts == BS - 1 && c == 0 && prev_full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (ts == BS - 1 && c == 0) K7_T(13);
+                    if (ts == BS - 1 && c == 0) K10_T(13);
                     __builtin_amdgcn_s_barrier();
-                    if (ts == BS - 1 && c == 0) K7_T(14);
+                    if (ts == BS - 1 && c == 0) K10_T(14);
                     const int nb = c * BPC + ts / BS + 2;
                     if (nb < NBLK) conv_dma_block<NT, NW>(ws, smem, nb, wslot, wave, lane);
                     else if (has_next) conv_dma_block<NT, NW>(ws, smem, nb - NBLK, wslot, wave, lane);
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
                         }
                     }
                     wslot ^= 1;
-                    if (ts == BS - 1 && c == 0) K7_T(15);
+                    if (ts == BS - 1 && c == 0) K10_T(15);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // next step's fragments (a tile's first ones are read at its start: held across the epilogue they spill)
@@ -273,10 +273,10 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             pbuf ^= 1;
-            K7_T(2 + c);
+            K10_T(2 + c);
         }
         // ---------------- epilogue (wave-private): T(acc) -> slab [pixel][SP x 32 channels] -> + shortcut -> act -> NHWC
-        K7_T(10);
+        K10_T(10);
         const bool full = y0 + TH <= a.H && x0 + TW <= a.W;
         // one straight-line body per (shortcut?, activation form, tile inside the image?): with these as run-time branches
         // inside the passes every join waits for vmcnt(0), i.e. for the previous pass's stores to come back
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
             constexpr bool HAS_RES = decltype(has_res_c)::value, FULL = decltype(full_c)::value;
             constexpr int MODE = decltype(mode_c)::value;       // 0 packed-half ReLU, 1 packed-half none, 2 fp32 ReLU, 3 fp32 max(f, k f)
             char* slab = smem + G::SLAB_OFF + wave * 32 * RS;
-            const float neg_k = a.act == C7_LEAKY ? a.slope : 1.f;
+            const float neg_k = a.act == C10_LEAKY ? a.slope : 1.f;
             constexpr int PPB = (NT + SP - 1) / SP, NPASS = PB * PPB;     // passes p = (pixel block b, tile group t0)
             int el = lane;                  // (recompute the lane's slab / pixel offsets per tile: kept across the K loop they spill)
             asm volatile("" : "+v"(el));
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
                             for (int i = 0; i < 8; ++i) o[i] = (T)(MODE == 2 ? fmaxf(f[i], 0.f) : fmaxf(f[i], f[i] * neg_k));
                         }
-                        if ((FULL || (y < a.H && x < a.W)) && K7_STORE_OK)
+                        if ((FULL || (y < a.H && x < a.W)) && K10_STORE_OK)
                             *reinterpret_cast<V8*>(og + (((size_t)n * a.H + y) * a.W + x) * COUT + ch8 * 8) = o;
                     }
                 }
@@ -375,23 +375,23 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
             else by_tile(integral_constant<bool, false>{}, mode_c);
         };
         if constexpr (std::is_same<T, _Float16>::value) {
-            if (a.act == C7_RELU) by_res(integral_constant<int, 0>{});
-            else if (a.act == C7_NONE) by_res(integral_constant<int, 1>{});
+            if (a.act == C10_RELU) by_res(integral_constant<int, 0>{});
+            else if (a.act == C10_NONE) by_res(integral_constant<int, 1>{});
             else by_res(integral_constant<int, 3>{});
         } else {
-            if (a.act == C7_RELU) by_res(integral_constant<int, 2>{});
+            if (a.act == C10_RELU) by_res(integral_constant<int, 2>{});
             else by_res(integral_constant<int, 3>{});
         }
         prev_full = full;
-        K7_T(11);
+        K10_T(11);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
-#if K7_TRACE
+#if K10_TRACE
 }
-extern "C" int gf_debug_k7_trace(long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(k7_trace), sizeof(k7_trace)) == hipSuccess ? 0 : -1;
+extern "C" int gf_debug_k10_trace(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(k10_trace), sizeof(k10_trace)) == hipSuccess ? 0 : -1;
 }
 namespace {
 #endif
@@ -413,7 +413,7 @@ int conv_launch(ConvArgs a, hipStream_t st) {
     return 0;
 }
 
-// 8 waves per workgroup: measured 1.1-1.3x faster than 4 at every shape (tools/k7_time.py); the 4-wave form stays
+// 8 waves per workgroup: measured 1.1-1.3x faster than 4 at every shape (tools/k10_time.py); the 4-wave form stays
 // instantiable (conv_launch<..., 4>) for experiments
 template <typename T, int CIN, int COUT>
 int conv_launch_w(const ConvArgs& a, hipStream_t st) {
@@ -446,8 +446,8 @@ extern "C" int gf_conv3x3_nhwc(const void* x, const void* wstream, const float* 
     GF_CHECK_ARG(N > 0 && H > 0 && W > 0, "empty problem");
     GF_CHECK_ARG(dtype == GF_F16 || dtype == GF_BF16, "built for 16-bit maps");
     GF_CHECK_ARG(gf_conv3x3_supported(cin, cout), "no kernel for these channel counts (see gf_conv3x3_supported)");
-    GF_CHECK_ARG(act >= C7_NONE && act <= C7_LEAKY, "unknown activation");
-    GF_CHECK_ARG(act != C7_LEAKY || (slope >= 0.f && slope <= 1.f), "LeakyReLU slope must lie in [0, 1]");
+    GF_CHECK_ARG(act >= C10_NONE && act <= C10_LEAKY, "unknown activation");
+    GF_CHECK_ARG(act != C10_LEAKY || (slope >= 0.f && slope <= 1.f), "LeakyReLU slope must lie in [0, 1]");
     GF_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)residual % 16 == 0 && (uintptr_t)wstream % 16 == 0 &&
                      (uintptr_t)zeros % 16 == 0, "tensors must be 16-byte aligned");
     GF_CHECK_ARG((long)N * H * W * (cin > cout ? cin : cout) < (1l << 31), "maps of 2^31 elements or more are not supported");

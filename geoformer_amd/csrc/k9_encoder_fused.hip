@@ -1,4 +1,4 @@
-// K6: the encoder layer as TWO launches that touch HBM three times per token (read source, read x, write out) -
+// K9: the encoder layer as TWO launches that touch HBM three times per token (read source, read x, write out) -
 // the algorithmic minimum of SURVEY 8d - instead of the eight launches / ~19 token-row transfers of the
 // K3 + K2 chain.  16-bit storage modes only (fp16 / bf16 operands, fp32 accumulation and statistics); the fp32 parity
 // mode keeps the unfused kernels.
@@ -33,19 +33,19 @@
 
 #include "gf_common.h"
 
-// -DK6_TRACE=1 records s_memtime at the phase boundaries of every workgroup (tools/k6_trace.py reads them); a
+// -DK9_TRACE=1 records s_memtime at the phase boundaries of every workgroup (tools/k9_trace.py reads them); a
 // diagnostic build only: the stamps serialise the wave, so only the SHARES of the phases are meaningful.
-#ifndef K6_TRACE
-#define K6_TRACE 0
+#ifndef K9_TRACE
+#define K9_TRACE 0
 #endif
-#if K6_TRACE
-__device__ long long k6_trace[4096 * 4 * 16];
-#define K6_T(slot) do { if (lane == 0 && blockIdx.x < 4096) k6_trace[(blockIdx.x * 4 + wave) * 16 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-extern "C" int gf_debug_k6_trace(long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(k6_trace), sizeof(long long) * 4096 * 4 * 16);
+#if K9_TRACE
+__device__ long long k9_trace[4096 * 4 * 16];
+#define K9_T(slot) do { if (lane == 0 && blockIdx.x < 4096) k9_trace[(blockIdx.x * 4 + wave) * 16 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int gf_debug_k9_trace(long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(k9_trace), sizeof(long long) * 4096 * 4 * 16);
 }
 #else
-#define K6_T(slot)
+#define K9_T(slot)
 #endif
 
 namespace {
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
     const char* ws = (const char*)a.wstream;
     constexpr int NBLK = ATTN ? 32 : 28;
     float* vec = reinterpret_cast<float*>(smem + VEC_OFF);
-    K6_T(0);
+    K9_T(0);
     dma_block(ws, smem, 0, wave, lane);
     load_tile<T>(xg, a.ldx, t0, a.L, smem, X_OFF, tid);
 #pragma unroll
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
     asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    K6_T(1);
+    K9_T(1);
     const int tok = t0 + wave * 32 + lr;                              // this lane's token (accumulator column)
     const char* xrow = smem + X_OFF;
     const int myrow = wave * 32 + lr;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
             step_schedule<1>();
             tf = tn;
         }
-        K6_T(2);
+        K9_T(2);
         // ---------------- linear attention per head: tile h of q is head h (32 channels)
         const float qmul = (a.q_mask == nullptr || a.q_mask[(size_t)n * a.L + min(tok, a.L - 1)] != 0) ? 1.f : 0.f;
         const float eps_s = a.attn_eps / (float)a.S;
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
         }
     }
 
-    K6_T(3);
+    K9_T(3);
     // ---------------- m = LN1(W_m msg) : 16 steps, operand (tile t = step / 2, k-step s = step % 2) from registers
     v16f m[8];
 #pragma unroll
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
         return v4f{(t[4 * g] - mean) * rstd * ga.x + be.x, (t[4 * g + 1] - mean) * rstd * ga.y + be.y,
                    (t[4 * g + 2] - mean) * rstd * ga.z + be.z, (t[4 * g + 3] - mean) * rstd * ga.w + be.w};
     };
-    K6_T(4);
+    K9_T(4);
     {
         float mean, rstd;
         ln_stats(m, a.eps1, mean, rstd);
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
             }
     }
 
-    K6_T(5);
+    K9_T(5);
     // ---------------- hid = act(W_1 [x | m]) in four 128-wide slices, each consumed at once by out += W_2[:, slice] hid
     // per slice 24 steps: 8 (x half: tiles hb = 0..3 x k-steps 2j, 2j+1) + 8 (m half: tile j of m) + 8 (W_2: tiles nb, k-step u)
     v16f o[8];
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
         for (int hb = 0; hb < 4; ++hb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) hd[hb][r] = 0.f;
-        if (sl == 1) K6_T(6);
+        if (sl == 1) K9_T(6);
         Frag t0f = xfrag(0), t1f = xfrag(1);
 #pragma unroll
         for (int st = 0; st < 8; ++st) {
@@ -438,11 +438,11 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
         }
     }
 
-    K6_T(7);
+    K9_T(7);
     // ---------------- out = x + LN2(.) (one rounding), per-sample skip predicate, row-contiguous stores through a slab
     float mean2, rstd2;
     ln_stats(o, a.eps2, mean2, rstd2);
-    K6_T(8);
+    K9_T(8);
     // the predicate is per sample (flag_rows is a multiple of L in every caller): read it once, wave-uniformly
     const bool keep = a.flag == nullptr || __builtin_amdgcn_readfirstlane(a.flag[((size_t)n * a.L + t0) / a.flag_rows]) != 0;
     char* ot = smem + W_OFF + wave * 32 * SLAB_RS;                      // the ring is idle now (every wave passed the last turn)
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    K6_T(9);
+    K9_T(9);
 }
 
 // -------------------------------------------------------------------------------------------------------------
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256, 1) void enc_kv_state(EncArgs a) {
     const T* xg = (const T*)a.x + (size_t)n * a.S * a.ldx;
     const char* ws = (const char*)a.wstream;
     constexpr int NBLK = 8;
-    K6_T(0);
+    K9_T(0);
     dma_block(ws, smem, 0, wave, lane);
     load_tile<T>(xg, a.ldx, t0, a.S, smem, X_OFF, tid);
     // validity of the wave's 32 tokens as a bit mask (tail of the image, padding mask of linear_attention.py:37-39)
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(256, 1) void enc_kv_state(EncArgs a) {
     dma_block(ws, smem, 1, wave, lane);
     asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");      // block 0 and the tile; block 1 stays in flight
     __builtin_amdgcn_s_barrier();
-    K6_T(1);
+    K9_T(1);
     const int myrow = wave * 32 + lr;
     Ring ring{ws, smem, wave, lane, 0, NBLK};
     Frag fa[8], fb[8];
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256, 1) void enc_kv_state(EncArgs a) {
     {
         v16f k[8];
         project(k);
-        K6_T(2);
+        K9_T(2);
 #pragma unroll
         for (int hh = 0; hh < 8; ++hh) {
             float s = 0.f;
@@ -563,9 +563,9 @@ __global__ __launch_bounds__(256, 1) void enc_kv_state(EncArgs a) {
     v16f kv[8];
     {
         v16f v[8];
-        K6_T(3);
+        K9_T(3);
         project(v);
-        K6_T(4);
+        K9_T(4);
 #pragma unroll
         for (int hh = 0; hh < 8; ++hh) {
 #pragma unroll
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256, 1) void enc_kv_state(EncArgs a) {
             Mm::mma(kf[hh][1], pack_step<T>(v[hh], 1), kv[hh]);
         }
     }
-    K6_T(5);
+    K9_T(5);
     // sum of the four waves (tree through LDS: 3 -> 1 and 2 -> 0, then 1 -> 0), then one partial per tile
     float* red = reinterpret_cast<float*>(smem);                       // [2][8][16][64] + [2][8][64] floats = 68 KiB
     auto put = [&](int slot) {
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256, 1) void enc_kv_state(EncArgs a) {
     __syncthreads();
     if (wave == 1) put(0);
     __syncthreads();
-    K6_T(6);
+    K9_T(6);
     if (wave == 0) {
         get(0);
         float* dst = a.part + ((size_t)n * a.tiles + tile) * (C * D + C);
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256, 1) void enc_kv_state(EncArgs a) {
             if (h2 == 0) dst[C * D + hh * D + lr] = ksum[hh];
         }
     }
-    K6_T(7);
+    K9_T(7);
 }
 
 __global__ void enc_kv_reduce(const float* part, float* fin, int tiles, int len) {

@@ -1,4 +1,4 @@
-"""Host side of the fused encoder-layer kernels (csrc/k6_encoder_fused.hip): weight pre-packing and the two ops.
+"""Host side of the fused encoder-layer kernels (csrc/k9_encoder_fused.hip): weight pre-packing and the two ops.
 
 The kernels consume weights as a linear stream of 1-KiB MFMA A fragments (64 lanes x 8 sixteen-bit elements) in
 exactly the order the kernel multiplies them, 32 fragments per 32-KiB block.  Two fragment orders exist:
@@ -115,7 +115,7 @@ def encoder_layer(x, wstream, ln_params, eps1, eps2, activation, msg=None, kv_st
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# K7: 3x3 convolution with fused epilogue (csrc/k7_conv3x3.hip)
+# K10: 3x3 convolution with fused epilogue (csrc/k10_conv3x3.hip)
 # ---------------------------------------------------------------------------------------------------------------
 _ZEROS = {}
 

@@ -93,7 +93,7 @@ def _fold(conv, bn, dtype, pad_multiple=1, pad_out=True):
 class FusedInferenceBackbone:
     """Inference form of ResNetFPN_8_2 for the 16-bit modes: BatchNorm folded into the
     preceding convolution, channels_last throughout.  The 3x3 / stride-1 convolutions (13 of the 17, >90 % of
-    the backbone's FLOPs) run on K7 (csrc/k7_conv3x3.hip) with the BN shift, the BasicBlock shortcut add and
+    the backbone's FLOPs) run on K10 (csrc/k10_conv3x3.hip) with the BN shift, the BasicBlock shortcut add and
     ReLU / LeakyReLU in the kernel's epilogue; the three stride-2 convolutions, the 1x1 laterals and the
     downsample shortcuts go through MIOpen (NHWC, called WITHOUT bias) with the glue kernels of
     csrc/k_backbone_glue.hip in between (one read and one write per activation map); the stem is its own
@@ -134,7 +134,7 @@ class FusedInferenceBackbone:
         return y if y.is_contiguous(memory_format=torch.channels_last) else y.contiguous(memory_format=torch.channels_last)
 
     def _stream(self, w, stride=(1, 1)):
-        """K7 fragment stream of a 3x3 / stride-1 convolution whose widths gf_conv3x3_nhwc is built for (16-bit modes), else None
+        """K10 fragment stream of a 3x3 / stride-1 convolution whose widths gf_conv3x3_nhwc is built for (16-bit modes), else None
         (the convolution then goes through MIOpen + the glue kernel)."""
         if self.dtype == torch.float32 or tuple(w.shape[2:]) != (3, 3) or tuple(stride) != (1, 1):
             return None
@@ -143,7 +143,7 @@ class FusedInferenceBackbone:
         return fused.pack_conv3x3_stream(w)
 
     def _conv3(self, x, w, ws, shift, shortcut, act, slope=0.01, stride=1):
-        """act(conv(x, w) + shift + shortcut): one K7 launch when a stream exists."""
+        """act(conv(x, w) + shift + shortcut): one K10 launch when a stream exists."""
         if ws is not None:
             return fused.conv3x3(x, ws, w.shape[0], shift, shortcut, act, slope)
         y = self._conv(x, w, stride)

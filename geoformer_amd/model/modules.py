@@ -87,7 +87,7 @@ class LoFTREncoderLayer(nn.Module):
                  'n1': (self.norm1.weight.detach().to(f32).contiguous(), self.norm1.bias.detach().to(f32).contiguous()),
                  'n2': (self.norm2.weight.detach().to(f32).contiguous(), self.norm2.bias.detach().to(f32).contiguous())}
             if self.fusable(dtype):
-                # K6: the weights as the fragment streams the fused kernels consume (fused.py), packed once
+                # K9: the weights as the fragment streams the fused kernels consume (fused.py), packed once
                 c = self.d_model
                 w['ln'] = torch.cat([w['n1'][0], w['n1'][1], w['n2'][0], w['n2'][1]]).contiguous()
                 w['stream_finish'] = fused.pack_layer_stream(None, w['merge'], w['w1'], w['w2'])
@@ -98,7 +98,7 @@ class LoFTREncoderLayer(nn.Module):
         return w
 
     def fusable(self, dtype):
-        """The fused two-launch form (csrc/k6_encoder_fused.hip) exists for 16-bit storage at d_model 256, with
+        """The fused two-launch form (csrc/k9_encoder_fused.hip) exists for 16-bit storage at d_model 256, with
         8 heads of 32 when the layer's own (linear) attention is part of it."""
         return dtype != torch.float32 and self.d_model == 256 and (self.attention_kind != 'linear' or self.nhead == 8)
 

@@ -114,7 +114,7 @@ int gf_linear_attention(const void* q, const void* k, const void* v, int dtype, 
                         float eps, void* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * K6  the encoder layer in two launches (16-bit storage modes)
+ * K9  the encoder layer in two launches (16-bit storage modes)
  * replaces LoFTREncoderLayer.forward as a whole (model/loftr_src/loftr/loftr_module/transformer.py:37-60 with
  *          LinearAttention.forward, linear_attention.py:21-51) and the part of the Geo layer after its attention
  *          (model/geo_transformer/transformer.py:56-66); d_model 256, 8 heads of 32 (linear attention).
@@ -141,13 +141,14 @@ int gf_encoder_layer(const void* x, long ldx, const void* msg, long ldm, const f
                      int N, int L, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * K7  3x3 / stride 1 / pad 1 convolution of channels-last 16-bit maps with a fused epilogue (backbone)
+ * K10 3x3 / stride 1 / pad 1 convolution of channels-last 16-bit maps with a fused epilogue (backbone)
  * replaces conv3x3 + BatchNorm(eval) [+ shortcut] + ReLU / LeakyReLU of BasicBlock.forward and of the FPN heads
  *          (model/loftr_src/loftr/backbone/resnet_fpn.py:9-40, :60-83, :100-116), BatchNorm folded into the weights
  *   out[n,y,x,:] = act( sum_{ky,kx} w[:, :, ky, kx] . x[n, y+ky-1, x+kx-1, :] + shift + residual[n,y,x,:] )
- *   x [N,H,W,cin], out / residual [N,H,W,cout] (GF_F16 or GF_BF16); the convolution result is rounded to the storage
- *   type before shift / residual / activation (the rounding points of a separate convolution followed by
- *   gf_bias_act_nhwc); act: 0 none, 1 ReLU, 2 LeakyReLU(slope); shift fp32 [cout] or NULL; residual or NULL;
+ *   x [N,H,W,cin], out / residual [N,H,W,cout] (GF_F16 or GF_BF16); fp32 accumulation starting from the shift; the sum is
+ *   rounded to the storage type once before the residual is added and once at the output (a separate convolution
+ *   followed by gf_bias_act_nhwc rounds twice as well); act: 0 none, 1 ReLU, 2 LeakyReLU(slope in [0,1]);
+ *   shift fp32 [cout] or NULL; residual or NULL; maps must hold fewer than 2^31 elements;
  *   wstream = geoformer_amd/fused.py:pack_conv3x3_stream(w); zeros = >= 64 bytes of zeroed device memory.
  *   Channel counts: gf_conv3x3_supported(cin, cout).
  * ------------------------------------------------------------------------------------------ */

@@ -162,8 +162,8 @@ def encoder_layer(P: Dict[str, torch.Tensor], prefix: str, x, source, nhead: int
 # --------------------------------------------------------------------------------------
 # 16-bit STORAGE MODE of the encoder layers.  The product's fast modes keep tensors in fp16 (or bf16) and
 # accumulate in fp32; the functions below restate the same reference arithmetic with a round trip through
-# the storage type at exactly the points where the HIP kernels round (include/geoformer_hip.h, K6 / K3 / K2):
-#   'fused'   csrc/k6_encoder_fused.hip (coarse LoFTR layers; the part of a Geo layer after its attention):
+# the storage type at exactly the points where the HIP kernels round (include/geoformer_hip.h, K9 / K3 / K2):
+#   'fused'   csrc/k9_encoder_fused.hip (coarse LoFTR layers; the part of a Geo layer after its attention):
 #             every MFMA operand is rounded (phi(q), phi(k), v, KV/S, Ksum/S, msg, LN1 output, hidden
 #             activations), everything else is fp32, the output x + LN2(.) is rounded once;
 #   'chain'   the K3 + K2 kernel chain (fine level): every tensor a kernel writes is rounded (q, k, v, message,
@@ -612,7 +612,7 @@ def geoformer_forward(P, data, loftr_cfg=None, geo_cfg=None, homography_fn: Call
 # storage, fp32 accumulation) at the points where its kernels round.  Used by the end-to-end parity tests of those
 # modes: coarse indices are then compared bit for bit, not by overlap with the fp32 run.
 #   position encoding      out = rt(x + pe)                                       (k_pos_encode.hip)
-#   coarse LoFTR layers    encoder_layer_fused                                    (k6_encoder_fused.hip)
+#   coarse LoFTR layers    encoder_layer_fused                                    (k9_encoder_fused.hip)
 #   dual softmax           fp32 arithmetic on the rounded features                (k1_dual_softmax.hip)
 #   Geo layers             q, k, v = rt(W x) (K3); self: flash attention over 32-key tiles with the probabilities
 #                          rounded for the P.V product (k4_attention.hip); cross: fp32 softmax over the 25 window keys

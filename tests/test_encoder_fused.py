@@ -1,4 +1,4 @@
-"""The fused encoder-layer kernels (csrc/k6_encoder_fused.hip, geoformer_amd/fused.py).
+"""The fused encoder-layer kernels (csrc/k9_encoder_fused.hip, geoformer_amd/fused.py).
 
 CPU: the two weight-fragment orders of fused.fragments against their definition.
 GPU: gf_encoder_kv_state / gf_encoder_layer against the oracle's 'fused' storage mode (the reference's arithmetic

@@ -429,7 +429,7 @@ def test_fused_backbone_vs_module(dtype, bound):
     (128, 128, (1, 1), 'relu', True, True),          # single pixel: everything but the centre tap reads the zero page
 ])
 def test_conv3x3_vs_torch(dtype, cin, cout, hw, act, use_res, use_shift):
-    """K7 (gf_conv3x3_nhwc) against torch's fp32 convolution of the same 16-bit operands + shift + shortcut + activation.
+    """K10 (gf_conv3x3_nhwc) against torch's fp32 convolution of the same 16-bit operands + shift + shortcut + activation.
     Tolerance: the result is rounded to the storage type twice (accumulator + shift -> slab; + shortcut, activation ->
     output), each by at most half an ulp of the value rounded."""
     from geoformer_amd import fused, ops

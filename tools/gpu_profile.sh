@@ -33,5 +33,10 @@ echo "rc=$?"
 find $OUT/${TAG}_trace $OUT/${TAG}_pmc_sq $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write -type f ! -name '*.csv' -delete 2>/dev/null
 python3 tools/prof_summary.py $OUT/${TAG}_trace > $OUT/${TAG}_trace_summary.txt 2>&1
 python3 tools/pmc_roofline.py $OUT $TAG --tags $OUT/${TAG}_pmc_per_tag.json > $OUT/${TAG}_pmc_summary.txt 2>&1
+# the raw per-dispatch counter csvs are ~30 MB per pass (gpurun merges back at most 64 MiB): keep them only on request
+if [ -z "${KEEP_RAW:-}" ]; then
+    rm -rf $OUT/${TAG}_pmc_sq $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write
+    find $OUT/${TAG}_trace -type f ! -name '*kernel_stats.csv' -delete 2>/dev/null
+fi
 tail -5 $OUT/${TAG}_trace.err
 cat $OUT/${TAG}_trace.json | tail -1 | cut -c1-600

@@ -1,5 +1,5 @@
-"""K7 (gf_conv3x3_nhwc) against MIOpen conv + gf_bias_act at the backbone's 3x3 shapes: correctness and time.
-python tools/k7_time.py [fp16|bf16]"""
+"""K10 (gf_conv3x3_nhwc) against MIOpen conv + gf_bias_act at the backbone's 3x3 shapes: correctness and time.
+python tools/k10_time.py [fp16|bf16]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -42,5 +42,5 @@ for (N, CI, CO, H, W) in ((2, 128, 128, 37, 70), (16, 128, 128, 320, 320), (16, 
     t_sep = timeit(lambda: ops.bias_act_(F.conv2d(x, wcl, None, 1, 1), b, z, ops.ACT_RELU))
     t_conv = timeit(lambda: F.conv2d(x, wcl, None, 1, 1))
     fl = 2.0 * N * H * W * CI * CO * 9
-    print(f'{N}x{CI}->{CO}x{H}x{W}: err {err:.3g} / plain {err0:.3g} | K7 {t_k7:.3f} ms ({fl / t_k7 / 1e9:.0f} TFLOP/s) | '
+    print(f'{N}x{CI}->{CO}x{H}x{W}: err {err:.3g} / plain {err0:.3g} | K10 {t_k7:.3f} ms ({fl / t_k7 / 1e9:.0f} TFLOP/s) | '
           f'MIOpen conv {t_conv:.3f} + bias_act = {t_sep:.3f} ms', flush=True)

@@ -1,6 +1,6 @@
-"""Phase timeline of gf_conv3x3_nhwc (needs HIPCC_EXTRA='-DK7_TRACE=1' python -m geoformer_amd.build): median s_memtime
+"""Phase timeline of gf_conv3x3_nhwc (needs HIPCC_EXTRA='-DK10_TRACE=1' python -m geoformer_amd.build): median s_memtime
 offsets (10 ns ticks) per tile: 0 tile start | 1 first block + patch landed | 2.. chunk c done | 10 epilogue start | 11 tile done.
-python tools/k7_trace.py [cin cout H]"""
+python tools/k10_trace.py [cin cout H]"""
 import sys, os, ctypes
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,7 +13,7 @@ w = torch.randn(CO, CI, 3, 3, device='cuda', dtype=torch.float16) * 0.03
 z = torch.randn(N, CO, H, H, device='cuda', dtype=torch.float16).contiguous(memory_format=torch.channels_last)
 b = torch.randn(CO, device='cuda')
 ws = fused.pack_conv3x3_stream(w)
-fn = ctypes.CDLL(_lib.LIB_PATH).gf_debug_k7_trace
+fn = ctypes.CDLL(_lib.LIB_PATH).gf_debug_k10_trace
 for res in (z, None):
     for _ in range(3):
         fused.conv3x3(x, ws, CO, b, res, ops.ACT_RELU)

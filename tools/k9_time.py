@@ -1,4 +1,4 @@
-"""Times the fused encoder kernels at the bench shapes: python tools/k6_time.py [images] [reps]
+"""Times the fused encoder kernels at the bench shapes: python tools/k9_time.py [images] [reps]
 (16 images of 80x80 tokens = one coarse 'self' layer call of an 8-pair batch)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,4 @@
-"""Phase timeline of the fused encoder kernels (needs a -DK6_TRACE=1 build: HIPCC_EXTRA='-DK6_TRACE=1' is honoured by
+"""Phase timeline of the fused encoder kernels (needs a -DK9_TRACE=1 build: HIPCC_EXTRA='-DK9_TRACE=1' is honoured by
 geoformer_amd/build.py).  Prints the median s_memtime offsets (100 MHz ticks x clock ratio: raw counter units) of the
 phase boundaries per workgroup, for enc_layer and enc_kv_state at 16 images of 80x80 tokens."""
 import sys, os, ctypes
@@ -16,7 +16,7 @@ layer.load_state_dict({k[len(pfx):]: v for k, v in W.items() if k.startswith(pfx
 layer = layer.cuda()
 x = (torch.randn(N, L, 256, device='cuda') * 0.7).half()
 w = layer.weights(torch.float16)
-fn = ctypes.CDLL(_lib.LIB_PATH).gf_debug_k6_trace
+fn = ctypes.CDLL(_lib.LIB_PATH).gf_debug_k9_trace
 
 
 def grab():
