@@ -28,6 +28,7 @@
 // HBM write drain (32 KiB per tile per workgroup = ~3500 ticks at the measured 5.6 TB/s store ceiling).
 #include <math.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "gf_common.h"
@@ -609,6 +610,190 @@ __global__ __launch_bounds__(NT, 2) void k1_conf_panel(K1Args a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// pass B, pipelined panel form (the default): as k1_conf_panel, but
+//   * the f1 tiles arrive by LDS-DMA (global_load_lds, swizzle applied on the source side) into TWO LDS buffers - no
+//     staging registers, no ds_write pass, one barrier per tile;
+//   * the run's column statistics sit in LDS (read once per unit);
+//   * the 32 MFMAs of tile t+1 are interleaved with the exponentials / stores of tile t (two accumulator sets): the
+//     store stream of a workgroup no longer pauses for its own K loop.
+// The DMA of tile t+1 is waited for with a counted vmcnt: the 32 row-segment stores issued behind it stay in flight.
+// Same k order as sim_tile: bit-identical sim values.  Both softmax normalisations are folded into the exponent.
+// Measured at 8 pairs (tools/k1_time.py): 385 -> 336 us sparse candidates, 406 -> 385 us dense (bench: 343 -> 334 us).
+// What bounds it now is NOT the store stream: with the conf stores compiled out the kernel still takes 308 us (sparse) /
+// 341 us (dense), without the exponentials 323 / 353 us - it is paced by the instruction issue of its epilogue (add, fma,
+// exp, lane swap, candidate bookkeeping per element) sharing the SIMDs with the 32 MFMAs per tile, at two waves per SIMD.
+// ---------------------------------------------------------------------------------------------
+constexpr int PIPE_LDS = 2 * BN * 512 + BM * 8 + PANEL_TILES * BN * 8;
+
+template <typename H, bool DENSE>
+__global__ __launch_bounds__(NT, 2) void k1_conf_pipe(K1Args a) {
+    using V8 = gf_vec<H, 8>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* rst = reinterpret_cast<float*>(smem + 2 * BN * 512);              // per row:    -max log2(e) - log2(sum)
+    float* cst = reinterpret_cast<float*>(smem + 2 * BN * 512 + BM * 8);     // per column of the run, likewise
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, lr = lane & 31;
+    const int runs = (a.tilesN + PANEL_TILES - 1) / PANEL_TILES;
+    const int units = a.N * a.tilesM * runs;
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = (nwg + 7 - xcd) >> 3;
+    const int q = units >> 3, rem = units & 7;
+    const int ubeg = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q, ucnt = q + (xcd < rem ? 1 : 0);
+    const float k2 = 2.0f * a.mult * LOG2E;
+    for (int ui = slot; ui < ucnt; ui += per_xcd) {
+        const int u = ubeg + ui;
+        const int run = u % runs, pm = u / runs, bm = pm % a.tilesM, n = pm / a.tilesM;
+        const int m0 = bm * BM, t0 = run * PANEL_TILES, t1 = min(t0 + PANEL_TILES, a.tilesN);
+        const H* A = (const H*)a.f0 + ((size_t)n * a.L + m0 + wave * 32 + lr) * a.C + h * 8;
+        const char* B = (const char*)((const H*)a.f1 + (size_t)n * a.S * a.C);
+        V8 af[16];
+#pragma unroll
+        for (int kg = 0; kg < 16; ++kg) af[kg] = *reinterpret_cast<const V8*>(A + kg * 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (also drains the previous unit's stores: the counted waits below start clean)
+        __syncthreads();                                      // previous unit's readers of rst / cst / the tile buffers are done
+        // tile bn -> buffer `buf`: 32 pieces of 2 rows x 512 B, 8 per wave; LDS slot j of row r holds chunk j ^ (r & 15)
+        auto dma = [&](int bn, int buf) {
+            int dl = lane;
+            asm volatile("" : "+v"(dl));                     // per-piece source addresses recomputed here, not kept across the tile loop
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int p = wave * 8 + i, row = 2 * p + (dl >> 5), j = dl & 31;
+                const char* src = B + ((size_t)(bn * BN + row) * a.C + ((j ^ (row & 15)) << 3)) * sizeof(H);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(smem + buf * (BN * 512) + p * 1024), 16, 0, 0);
+            }
+        };
+        dma(t0, 0);
+        if (tid < BM) {
+            const float2 st = a.rstat[(size_t)n * a.L + m0 + tid];
+            rst[tid] = -st.x * LOG2E - __builtin_amdgcn_logf(st.y);       // v_log_f32 = log2: exp2(.. + rst) = e^{-max} / sum
+        }
+        for (int i = tid; i < (t1 - t0) * BN; i += NT) {
+            const float2 cs = a.cstat[(size_t)n * a.S + t0 * BN + i];
+            cst[i] = -cs.x * LOG2E - __builtin_amdgcn_logf(cs.y);
+        }
+        const int row_base = m0 + wave * 32;
+        unsigned long long* rbest = a.rowbest + (size_t)n * a.L;
+        unsigned* cmax = a.colmax + (size_t)n * a.S;
+        unsigned runv[DENSE ? 16 : 1], runc[DENSE ? 16 : 1];
+        if constexpr (DENSE) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { runv[r] = 0u; runc[r] = 0u; }
+        }
+        // one row (register r of both column halves) of the epilogue of tile `bn`
+        // conf = exp2(2 sim log2e + rst[row] + cst[col]): both softmax normalisations folded into the exponent (one add,
+        // one fma and one exponential per element; the two products with 1/sum are gone)
+        float ca[2];
+        unsigned cbest[2];
+        const unsigned thr_bits = __float_as_uint(fmaxf(a.thr, 0.f));
+        auto epi_begin = [&](int bn) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                ca[ni] = cst[(bn - t0) * BN + ni * 32 + lr];
+                cbest[ni] = 0u;
+            }
+        };
+        auto epi_row = [&](const v16f (&acc)[2], int bn, int r) {
+            const int n0 = bn * BN;
+            const float st = rst[wave * 32 + gf_acc_row(r, h)];
+            float cf[2];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) cf[ni] = __builtin_amdgcn_exp2f(fmaf(acc[ni][r], k2, st + ca[ni]));
+            float* rowp = a.conf + ((size_t)n * a.L + row_base + (r & 3) + 8 * (r >> 2)) * a.S + n0;
+            const gf_v2u sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(cf[0]), __float_as_uint(cf[1]), false, false);
+            __builtin_nontemporal_store(__uint_as_float(sw.x), rowp + lane);
+            __builtin_nontemporal_store(__uint_as_float(sw.y), rowp + 4 * a.S + lane);
+            if constexpr (!DENSE) {
+                if (fmaxf(cf[0], cf[1]) > a.thr) {
+                    const int row = row_base + gf_acc_row(r, h);
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        if (cf[ni] > a.thr) {
+                            const int col = n0 + ni * 32 + lr;
+                            const unsigned bits = __float_as_uint(cf[ni]);
+                            atomicMax(rbest + row, ((unsigned long long)bits << 32) | (0xFFFFFFFFu - (unsigned)col));
+                            atomicMax(cmax + col, bits);
+                        }
+                }
+            } else {
+                // (conf >= 0: its bits order like its value; the threshold is applied once, to the maxima)
+                const unsigned b0 = __float_as_uint(cf[0]), b1 = __float_as_uint(cf[1]);
+                cbest[0] = max(cbest[0], b0);
+                cbest[1] = max(cbest[1], b1);
+                const bool second = b1 > b0;                          // ni = 1 is the later column: only a strict win
+                const unsigned bv = second ? b1 : b0, bc = (unsigned)(n0 + lr) + (second ? 32u : 0u);
+                const bool better = bv > runv[r];
+                runv[r] = better ? bv : runv[r];
+                runc[r] = better ? bc : runc[r];
+            }
+        };
+        auto epi_end = [&](int bn) {
+            if constexpr (DENSE) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const unsigned c = max(cbest[ni], (unsigned)__shfl_xor((int)cbest[ni], 32, 64));
+                    if (h == 0 && c > thr_bits) atomicMax(cmax + bn * BN + ni * 32 + lr, c);
+                }
+            }
+        };
+        v16f prev[2], cur[2];
+        for (int bn = t0; bn <= t1; ++bn) {
+            const bool mma = bn < t1, epi = bn > t0;
+            if (mma) {
+                // tile bn has landed: everything issued behind its DMA (the previous iteration's 32 row stores, and
+                // possibly candidate atomics) may stay in flight; the very first tile of a unit has nothing behind it
+                if (bn == t0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            }
+            __syncthreads();                                  // ... for every wave; and every wave is done with tile bn-1's buffer
+            if (bn + 1 < t1) dma(bn + 1, (bn + 1 - t0) & 1);
+            const char* tb = smem + ((bn - t0) & 1) * (BN * 512);
+            if (epi) epi_begin(bn - 1);
+            if (mma) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cur[ni][r] = 0.f;
+            }
+            if (mma && epi) {
+#pragma unroll
+                for (int kg = 0; kg < 16; ++kg) {
+                    const V8 b0 = *reinterpret_cast<const V8*>(tb + k1p_off(lr, 2 * kg + h));
+                    const V8 b1 = *reinterpret_cast<const V8*>(tb + k1p_off(32 + lr, 2 * kg + h));
+                    Mma32<H>::mma(af[kg], b0, cur[0]);
+                    Mma32<H>::mma(af[kg], b1, cur[1]);
+                    epi_row(prev, bn - 1, kg);
+                }
+            } else if (mma) {
+#pragma unroll
+                for (int kg = 0; kg < 16; ++kg) {
+                    const V8 b0 = *reinterpret_cast<const V8*>(tb + k1p_off(lr, 2 * kg + h));
+                    const V8 b1 = *reinterpret_cast<const V8*>(tb + k1p_off(32 + lr, 2 * kg + h));
+                    Mma32<H>::mma(af[kg], b0, cur[0]);
+                    Mma32<H>::mma(af[kg], b1, cur[1]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) epi_row(prev, bn - 1, r);
+            }
+            if (epi) epi_end(bn - 1);
+            if (mma) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) prev[ni] = cur[ni];
+            }
+        }
+        if constexpr (DENSE) {
+            unsigned long long key[32];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                key[r] = runv[r] > thr_bits ? (((unsigned long long)runv[r] << 32) | (0xFFFFFFFFu - runc[r])) : 0ull;
+                key[16 + r] = 0ull;
+            }
+            const unsigned long long kbest = k1_row_reduce(key, GfMaxU64());
+            if (lr < 16 && kbest != 0ull) atomicMax(rbest + row_base + gf_acc_row(lr, h), kbest);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // pass A in the same row-panel-persistent form: the f0 panel lives in registers, f1 tiles stream through LDS one tile
 // ahead, and - the point - the ROW statistics stay in the lane that owns the row slot for the whole run of tiles
 // (online max / rescaled sum per slot, 3 exponentials per slot and tile) and cross the lanes once per run instead
@@ -901,8 +1086,19 @@ int k1_launch(K1Args a, SelArgs s, void* zero_begin, size_t zero_bytes, hipStrea
     bool done = false;
     if constexpr (!EXACT) {
         if (panel) {
-            if (a.dense) k1_conf_panel<T, true><<<wgs, NT, PANEL_LDS, st>>>(a);
-            else k1_conf_panel<T, false><<<wgs, NT, PANEL_LDS, st>>>(a);
+            // GF_K1_CONF=panel selects the unpipelined panel form (A/B measurements, tools/k1_trace.py)
+            static const bool old_form = [] { const char* e = getenv("GF_K1_CONF"); return e && e[0] == 'p'; }();
+            static bool attr = false;
+            if (!attr) {
+                (void)hipFuncSetAttribute((const void*)k1_conf_pipe<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS);
+                (void)hipFuncSetAttribute((const void*)k1_conf_pipe<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS);
+                attr = true;
+            }
+            if (old_form) {
+                if (a.dense) k1_conf_panel<T, true><<<wgs, NT, PANEL_LDS, st>>>(a);
+                else k1_conf_panel<T, false><<<wgs, NT, PANEL_LDS, st>>>(a);
+            } else if (a.dense) k1_conf_pipe<T, true><<<wgs, NT, PIPE_LDS, st>>>(a);
+            else k1_conf_pipe<T, false><<<wgs, NT, PIPE_LDS, st>>>(a);
             done = true;
         }
     }

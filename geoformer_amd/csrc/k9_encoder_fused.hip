@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
     using Mm = Mma32<T>;
     using Frag = typename Mm::Frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5, lr = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h2 = lane >> 5, lr = lane & 31;
     const int n = blockIdx.x / a.tiles, tile = blockIdx.x - n * a.tiles;
     const int t0 = tile * TM;                                         // first token of the tile inside image n
     const T* xg = (const T*)a.x + (size_t)n * a.L * a.ldx;
@@ -446,38 +446,56 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
     // the predicate is per sample (flag_rows is a multiple of L in every caller): read it once, wave-uniformly
     const bool keep = a.flag == nullptr || __builtin_amdgcn_readfirstlane(a.flag[((size_t)n * a.L + t0) / a.flag_rows]) != 0;
     char* ot = smem + W_OFF + wave * 32 * SLAB_RS;                      // the ring is idle now (every wave passed the last turn)
-    const int prow = lane >> 4, pch = lane & 15;
     T* og = (T*)a.out + (size_t)n * a.L * a.ldo;
+    // one straight-line body per (layer kept?, tile inside the sequence?): as run-time branches inside the loops every join
+    // costs a conservative wait on the stores of the first channel half
+    auto finish = [&](auto keep_c, auto full_c) {
+        constexpr bool KEEP = decltype(keep_c)::value, FULL = decltype(full_c)::value;
+        int el = lane;
+        asm volatile("" : "+v"(el));                                    // slab / row offsets recomputed here, not carried through the layer
+        const int erow = wave * 32 + (el & 31), eh2 = el >> 5, prow = el >> 4, pch = el & 15;
 #pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
+        for (int hb = 0; hb < 2; ++hb) {
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4)
+            for (int q4 = 0; q4 < 4; ++q4)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nb = hb * 4 + q4, c = nb * 32 + 8 * g + 4 * h2, ch = c >> 3;
-                typedef T v4t __attribute__((ext_vector_type(4)));
-                const v4t xv = *reinterpret_cast<const v4t*>(xrow + (ch >> 3) * 16384 + gf_lds_off(myrow, ch & 7) + (c & 7) * 2);
-                v4t ov = xv;
-                if (keep) {                                             // uniform over the workgroup: a tile belongs to one sample
-                    const v4f y = ln_apply(o[nb], nb, g, vec + 2 * C, vec + 3 * C, mean2, rstd2);
-                    ov[0] = gf_from_float<T>(gf_to_float(xv[0]) + y.x);
-                    ov[1] = gf_from_float<T>(gf_to_float(xv[1]) + y.y);
-                    ov[2] = gf_from_float<T>(gf_to_float(xv[2]) + y.z);
-                    ov[3] = gf_from_float<T>(gf_to_float(xv[3]) + y.w);
+                for (int g = 0; g < 4; ++g) {
+                    const int nb = hb * 4 + q4, c = nb * 32 + 8 * g + 4 * eh2, ch = c >> 3;
+                    typedef T v4t __attribute__((ext_vector_type(4)));
+                    const v4t xv = *reinterpret_cast<const v4t*>(xrow + (ch >> 3) * 16384 + gf_lds_off(erow, ch & 7) + (c & 7) * 2);
+                    v4t ov = xv;
+                    if constexpr (KEEP) {
+                        const int cc = nb * 32 + 8 * g + 4 * eh2;
+                        const v4f ga = *reinterpret_cast<const v4f*>(vec + 2 * C + cc), be = *reinterpret_cast<const v4f*>(vec + 3 * C + cc);
+                        const v16f& t = o[nb];
+                        ov[0] = gf_from_float<T>(gf_to_float(xv[0]) + ((t[4 * g] - mean2) * rstd2 * ga.x + be.x));
+                        ov[1] = gf_from_float<T>(gf_to_float(xv[1]) + ((t[4 * g + 1] - mean2) * rstd2 * ga.y + be.y));
+                        ov[2] = gf_from_float<T>(gf_to_float(xv[2]) + ((t[4 * g + 2] - mean2) * rstd2 * ga.z + be.z));
+                        ov[3] = gf_from_float<T>(gf_to_float(xv[3]) + ((t[4 * g + 3] - mean2) * rstd2 * ga.w + be.w));
+                    }
+                    *reinterpret_cast<v4t*>(ot + (el & 31) * SLAB_RS + (q4 * 32 + 8 * g + 4 * eh2) * 2) = ov;
                 }
-                *reinterpret_cast<v4t*>(ot + lr * SLAB_RS + (q4 * 32 + 8 * g + 4 * h2) * 2) = ov;
-            }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = it * 4 + prow, tg = t0 + wave * 32 + row;
-            if (tg < a.L)
-                *reinterpret_cast<v4u*>(og + (size_t)tg * a.ldo + hb * 128 + pch * 8) = *reinterpret_cast<const v4u*>(ot + row * SLAB_RS + pch * 16);
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 4 + prow, tg = t0 + wave * 32 + row;
+                if (FULL || tg < a.L)
+                    *reinterpret_cast<v4u*>(og + (size_t)tg * a.ldo + hb * 128 + pch * 8) = *reinterpret_cast<const v4u*>(ot + row * SLAB_RS + pch * 16);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+    };
+    using std::integral_constant;
+    const bool full = t0 + TM <= a.L;
+    if (keep) {
+        if (full) finish(integral_constant<bool, true>{}, integral_constant<bool, true>{});
+        else finish(integral_constant<bool, true>{}, integral_constant<bool, false>{});
+    } else {
+        if (full) finish(integral_constant<bool, false>{}, integral_constant<bool, true>{});
+        else finish(integral_constant<bool, false>{}, integral_constant<bool, false>{});
     }
     K9_T(9);
 }
@@ -494,7 +512,7 @@ __global__ __launch_bounds__(256, 1) void enc_kv_state(EncArgs a) {
     using Mm = Mma32<T>;
     using Frag = typename Mm::Frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5, lr = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h2 = lane >> 5, lr = lane & 31;
     const int n = blockIdx.x / a.tiles, tile = blockIdx.x - n * a.tiles;
     const int t0 = tile * TM;
     const T* xg = (const T*)a.x + (size_t)n * a.S * a.ldx;
