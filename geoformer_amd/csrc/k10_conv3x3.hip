@@ -58,14 +58,20 @@ struct ConvGeo {
     static constexpr int PIECES = (PH * PW + 15) / 16;            // DMA pieces of 16 pixels x 64 B
     static constexpr int PATCH_BYTES = PIECES * 1024;
     static constexpr int W10_OFF = 2 * PATCH_BYTES;                // two weight blocks behind the two patches
-    static constexpr int BLOCK_STEPS = NW == 8 ? 3 : 6;          // a sixth / a third of a chunk's 18 steps
+    // two rows per wave (Cout <= 128): the epilogue slab aliases the patch buffer of the tile's last chunk (dead once every wave
+    // is past the last ring turn: the last step's pixel fragments are in registers by then; the next request into that buffer
+    // comes after the next tile's first turn, i.e. after every wave has left its epilogue) - that leaves room for 6-step blocks
+    static constexpr bool SLAB_ALIAS = NW == 8 && PB == 2;
+    static constexpr int BLOCK_STEPS = (NW == 8 && !SLAB_ALIAS) ? 3 : 6;   // a sixth / a third of a chunk's 18 steps
     static constexpr int FR = BLOCK_STEPS * NT;                   // fragments per block
     static constexpr int WBLK = FR * C10_FRAG;
     static constexpr int SLAB_OFF = W10_OFF + 2 * WBLK;
     static constexpr int SP = NW == 4 ? 4 : 2;                    // accumulator tiles per epilogue pass
     static constexpr int RS = SP * 64 + 16;                       // slab row: SP x 32 channels of a pixel + 16 B
-    static constexpr int SHIFT_OFF = SLAB_OFF + NW * 32 * RS;     // one 32-pixel slab per wave
+    static constexpr int SLAB_BYTES = NW * 32 * RS;               // one 32-pixel slab per wave
+    static constexpr int SHIFT_OFF = SLAB_OFF + (SLAB_ALIAS ? 0 : SLAB_BYTES);
     static constexpr int LDS = SHIFT_OFF + NT * 32 * 4;
+    static_assert(!SLAB_ALIAS || SLAB_BYTES <= PATCH_BYTES, "slab must fit the patch buffer it aliases");
     static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
@@ -283,7 +289,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
         auto epilogue = [&](auto has_res_c, auto mode_c, auto full_c) {
             constexpr bool HAS_RES = decltype(has_res_c)::value, FULL = decltype(full_c)::value;
             constexpr int MODE = decltype(mode_c)::value;       // 0 packed-half ReLU, 1 packed-half none, 2 fp32 ReLU, 3 fp32 max(f, k f)
-            char* slab = smem + G::SLAB_OFF + wave * 32 * RS;
+            // (pbuf already names the NEXT tile's first patch: the other buffer is the dead one)
+            char* slab = smem + (G::SLAB_ALIAS ? P_OFF + (pbuf ^ 1) * G::PATCH_BYTES : G::SLAB_OFF) + wave * 32 * RS;
             const float neg_k = a.act == C10_LEAKY ? a.slope : 1.f;
             constexpr int PPB = (NT + SP - 1) / SP, NPASS = PB * PPB;     // passes p = (pixel block b, tile group t0)
             int el = lane;                  // (recompute the lane's slab / pixel offsets per tile: kept across the K loop they spill)
