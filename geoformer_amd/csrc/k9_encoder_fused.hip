@@ -404,6 +404,7 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
             t0f = n0;
             t1f = n1;
         }
+        if (sl == 0) K9_T(10);
 #pragma unroll
         for (int st = 0; st < 8; ++st) {
             Frag (&cur)[8] = (st & 1) ? fb : fa;
@@ -415,6 +416,7 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
             for (int hb = 0; hb < 4; ++hb) Mm::mma(cur[4 + hb], mfrag[st][1], hd[hb]);
             step_schedule<0>();
         }
+        if (sl == 0) K9_T(11);
         Frag hfrag[4][2];
 #pragma unroll
         for (int hb = 0; hb < 4; ++hb) {
@@ -426,6 +428,7 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
             hfrag[hb][0] = pack_step<T>(hd[hb], 0);
             hfrag[hb][1] = pack_step<T>(hd[hb], 1);
         }
+        if (sl == 0) K9_T(12);
 #pragma unroll
         for (int st = 0; st < 8; ++st) {                                // out += W_2[:, 128 sl + 16 st .. + 15] hid
             Frag (&cur)[8] = (st & 1) ? fb : fa;

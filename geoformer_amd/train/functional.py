@@ -154,10 +154,13 @@ def _make_windows(kps, img_hw, window_size, scale):
     return p.masked_fill(oob[..., None], 0).long(), ~oob
 
 
-def _sample_windows(kps, fmap, s):
-    """utils/common_utils.py:166-181: kps [L,ww,2] pixel coords, fmap [C,H,W] -> [L,ww,C]."""
+def _sample_windows(kps, tokens, w, s):
+    """utils/common_utils.py:166-181: kps [L,ww,2] pixel coords, tokens [H*W, C] (the map, token-major) -> [L,ww,C].
+    index_select instead of fmap[:, y, x]: same values, but its backward is an atomic index_add instead of the sort-based
+    index_put (1.9 ms per call at 80x80x25 windows: 10 % of the training step)."""
     cell = (kps.float() // s).long()
-    return fmap[:, cell[..., 1], cell[..., 0]].permute(1, 2, 0)
+    lin = cell[..., 1] * w + cell[..., 0]
+    return tokens.index_select(0, lin.reshape(-1)).view(lin.shape[0], lin.shape[1], tokens.shape[1])
 
 
 def geo_module(P, cnn0, cnn1, data, geo_cfg, homography_fn: Callable):
@@ -204,19 +207,21 @@ def geo_module(P, cnn0, cnn1, data, geo_cfg, homography_fn: Callable):
             map0.append(m0); map1.append(m1)
 
     nhead = geo_cfg['nhead']
+    idx0 = [m.nonzero().flatten() for m in map0]          # feat[mask] (transformer.py:118,121) as index_select: ascending order
+    idx1 = [m.nonzero().flatten() for m in map1]
     f0 = [f0[b] for b in range(n)]          # per-sample lists: no in-place writes into autograd inputs
     f1 = [f1[b] for b in range(n)]
     for idx, name in enumerate(geo_cfg['layer_names']):
         lp = f'geo_module.des_transformer.layers.{idx}.'
         if name == 'self':
             for b in range(n):
-                if map0[b].any():
-                    f0[b] = encoder_layer(P, lp, f0[b][None], f0[b][map0[b]][None], nhead, 'geo')[0]
-                if map1[b].any():
-                    f1[b] = encoder_layer(P, lp, f1[b][None], f1[b][map1[b]][None], nhead, 'geo')[0]
+                if idx0[b].numel():
+                    f0[b] = encoder_layer(P, lp, f0[b][None], f0[b].index_select(0, idx0[b])[None], nhead, 'geo')[0]
+                if idx1[b].numel():
+                    f1[b] = encoder_layer(P, lp, f1[b][None], f1[b].index_select(0, idx1[b])[None], nhead, 'geo')[0]
         elif name == 'cross':
-            g0 = [None if win0[b] is None else _sample_windows(win0[b], f0[b].T.reshape(c, hh0, ww0), scale) for b in range(n)]
-            g1 = [None if win1[b] is None else _sample_windows(win1[b], f1[b].T.reshape(c, hh1, ww1), scale) for b in range(n)]
+            g0 = [None if win0[b] is None else _sample_windows(win0[b], f0[b], ww0, scale) for b in range(n)]
+            g1 = [None if win1[b] is None else _sample_windows(win1[b], f1[b], ww1, scale) for b in range(n)]
             for b in range(n):
                 if g1[b] is None:
                     continue
@@ -231,12 +236,14 @@ def geo_module(P, cnn0, cnn1, data, geo_cfg, homography_fn: Callable):
 def _fine_windows(feat_f, b_ids, cell_ids, w_c, stride, W):
     """fine_preprocess.py:41-56 (unfold + gather) without materialising the unfold."""
     pad = W // 2
-    fp = F.pad(feat_f, (pad, pad, pad, pad))
+    fp = F.pad(feat_f, (pad, pad, pad, pad)).permute(0, 2, 3, 1)           # [N, Hp, Wp, C]
+    n, hp, wp, c = fp.shape
     cy, cx = (cell_ids // w_c) * stride, (cell_ids % w_c) * stride
     r = torch.arange(W, device=feat_f.device)
     yy = (cy[:, None, None] + r[None, :, None]).expand(-1, W, W)
     xx = (cx[:, None, None] + r[None, None, :]).expand(-1, W, W)
-    return fp[b_ids[:, None, None], :, yy, xx].reshape(-1, W * W, feat_f.shape[1])
+    lin = (b_ids[:, None, None] * hp + yy) * wp + xx
+    return fp.reshape(n * hp * wp, c).index_select(0, lin.reshape(-1)).view(-1, W * W, c)      # (index_add backward)
 
 
 def fine_preprocess(P, feat_f0, feat_f1, feat_c0, feat_c1, data, W):
