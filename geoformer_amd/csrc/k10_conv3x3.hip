@@ -3,8 +3,8 @@
 // model/loftr_src/loftr/backbone/resnet_fpn.py:9-40 BasicBlock, :60-83 the FPN heads), as an implicit GEMM on the
 // matrix cores:   out[n,y,x,:] = act( sum_{ky,kx} W[:, :, ky, kx] . x[n, y+ky-1, x+kx-1, :] + shift + shortcut[n,y,x,:] )
 //
-// Same machinery as K9 (k9_encoder_fused.hip): one wave per SIMD, products transposed (MFMA A = 32 output channels,
-// B = 32 pixels, so a pixel's channels sit in one lane's registers), weights pre-packed on the host into the exact
+// Same machinery as K9 (k9_encoder_fused.hip): products transposed (MFMA A = output channels, B = pixels, so a pixel's
+// channels sit in one lane's registers; v_mfma_f32_16x16x32: 16 channels x 16 pixels x the 32 input channels of a chunk), weights pre-packed on the host into the exact
 // sequence of 1-KiB MFMA A fragments the kernel consumes and streamed from L2 through a two-block LDS ring by LDS-DMA;
 // the fragments of step i+1 (weights AND pixels) are requested before the MFMAs of step i.
 //   workgroup = 4 waves = an 8-row x 32-column pixel tile of one image; a wave owns two rows (two 32-pixel blocks):
@@ -106,7 +106,7 @@ __device__ __forceinline__ void conv_dma_patch(const ConvArgs& a, char* smem, in
     for (int i = 0; i < (G::PIECES + NW - 1) / NW; ++i) {
         const int piece = wave + NW * i;
         if (piece < G::PIECES) {
-            const int q = piece * 16 + (lane >> 2), slot = (lane & 3) ^ ((q >> 2) & 3);
+            const int q = piece * 16 + (lane >> 2), slot = (lane & 3) ^ ((q >> 1) & 3);
             const int pr = q / PW, pc = q - pr * PW;
             const bool in = (unsigned)(y0 - 1 + pr) < (unsigned)a.H && (unsigned)(x0 - 1 + pc) < (unsigned)a.W && q < G::PH * PW;
             const int off = sbase + (pr * a.W + pc) * CIN + 8 * slot;
@@ -135,7 +135,7 @@ __device__ long long k10_trace[256 * 8 * 8 * 16];
 
 template <typename T, int CIN, int COUT, int NW>
 __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
-    using Mm = Mma32<T>;
+    using Mm = Mma16<T>;
     using Frag = typename Mm::Frag;
     using G = ConvGeo<COUT / 32, NW>;
     using V4 = gf_vec<T, 4>;
@@ -144,7 +144,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
     constexpr int PB = G::PB, TH = G::TH, RS = G::RS, SP = G::SP;
     constexpr int NSTORE = PB * 2 * NT;                             // 16-byte output stores per lane and tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h2 = lane >> 5, lr = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lp = lane & 15, g4 = lane >> 4;                       // MFMA 16x16x32: row / column of the lane, its k group
     const char* ws = (const char*)a.wstream;
     float* shiftv = reinterpret_cast<float*>(smem + G::SHIFT_OFF);
     for (int i = tid; i < COUT; i += NW * 64) shiftv[i] = a.shift ? a.shift[i] : 0.f;
@@ -156,26 +157,26 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
         y0 = ty * TH;
         x0 = (r - ty * a.tiles_x) * TW;
     };
-    // byte offset (k-step 0) of this lane's pixel fragment in patch row PB wave + r, column shift kx; k-step 1 = ^ 32
-    int xaddr[PB + 2][3];
-#pragma unroll
-    for (int r = 0; r < PB + 2; ++r)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int q = (PB * wave + r) * PW + lr + kx;
-            xaddr[r][kx] = q * 64 + ((h2 ^ ((q >> 2) & 3)) << 4);
-        }
-    Frag wa[NT], wb[NT], xa[PB], xb[PB];
-    auto load_w = [&](Frag (&f)[NT], int slot, int s) {            // weight fragments of step s of the block in `slot`
+    // A sub-step = (tap, half of the output channels): NT weight fragments (16 channels x the chunk's 32 input channels each)
+    // times the 2 PB pixel fragments of the tap (16 pixels x 32 channels = the 64 bytes of a patch pixel: lane (pixel, k
+    // group) reads the 16-byte slot k group ^ ((q >> 1) & 3) - conflict-free for every patch offset).
+    const int xq0 = PB * wave * PW + lp;
+    Frag wa[NT], wb[NT], xa[2 * PB], xb[2 * PB];
+    auto load_w = [&](Frag (&f)[NT], int slot, int s) {            // weight fragments of sub-step s of the block in `slot`
         const char* p = smem + G::W10_OFF + slot * G::WBLK + s * NT * C10_FRAG + lane * 16;
 #pragma unroll
         for (int t = 0; t < NT; ++t) f[t] = *reinterpret_cast<const Frag*>(p + t * C10_FRAG);
     };
-    auto load_x = [&](Frag (&f)[PB], int buf, int ts) {            // pixel fragments of (tap, k-step) = ts of the chunk in `buf`
-        const int tap = ts >> 1, ky = tap / 3, kx = tap - 3 * ky;
+    auto load_x = [&](Frag (&f)[2 * PB], int buf, int tap) {       // pixel fragments of `tap` of the chunk in `buf`
+        const int ky = tap / 3, kx = tap - 3 * ky;
         const char* p = smem + P_OFF + buf * G::PATCH_BYTES;
+        int xq = xq0;
+        asm volatile("" : "+v"(xq));        // the 36 fragment offsets of a chunk are recomputed (4 VALU each), not kept in registers
 #pragma unroll
-        for (int b = 0; b < PB; ++b) f[b] = *reinterpret_cast<const Frag*>(p + (xaddr[b + ky][kx] ^ ((ts & 1) << 5)));
+        for (int bb = 0; bb < 2 * PB; ++bb) {
+            const int q = xq + ((bb >> 1) + ky) * PW + 16 * (bb & 1) + kx;
+            f[bb] = *reinterpret_cast<const Frag*>(p + q * 64 + ((g4 ^ ((q >> 1) & 3)) << 4));
+        }
     };
 
     int pbuf = 0, wslot = 0;                                        // patch buffer / ring slot being multiplied
@@ -199,23 +200,17 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
         K10_T(0);
         load_w(wa, wslot, 0);               // block 0 and the patch of chunk 0 landed before the previous tile's last turn
         load_x(xa, pbuf, 0);
-        v16f acc[PB][NT];
-        // accumulators start at the shift of their channel: 32 t + 8 (r / 4) + 4 h2 + (r % 4)
+        // acc[bb][ct]: pixel block bb (row bb / 2 of the wave, pixels 16 (bb % 2) .. + 15), channels 16 ct + 4 g4 + {0..3};
+        // accumulators start at the shift of their channel
+        v4f acc[2 * PB][2 * NT];
         int il = lane;
         asm volatile("" : "+v"(il));
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int ct = 0; ct < 2 * NT; ++ct) {
+            const float4 sh = *reinterpret_cast<const float4*>(shiftv + 16 * ct + 4 * (il >> 4));
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 sh = *reinterpret_cast<const float4*>(shiftv + 32 * t + 8 * g + 4 * (il >> 5));
-#pragma unroll
-                for (int b = 0; b < PB; ++b) {
-                    acc[b][t][4 * g] = sh.x;
-                    acc[b][t][4 * g + 1] = sh.y;
-                    acc[b][t][4 * g + 2] = sh.z;
-                    acc[b][t][4 * g + 3] = sh.w;
-                }
-            }
+            for (int bb = 0; bb < 2 * PB; ++bb) acc[bb][ct] = v4f{sh.x, sh.y, sh.z, sh.w};
+        }
         const T* rg = (const T*)a.res;
         T* og = (T*)a.out;
         // the epilogue runs in passes of SP accumulator tiles (the last pass of 224 channels: one fewer); in pass t0,
@@ -225,14 +220,15 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll 1
         for (int c = 0; c < NCH; ++c) {
 #pragma unroll
-            for (int ts = 0; ts < 18; ++ts) {                       // (tap, k-step) of this chunk
+            for (int ts = 0; ts < 18; ++ts) {                       // sub-step (tap ts / 2, channel half ts % 2) of this chunk
+                const int tap = ts >> 1, hf = ts & 1;
                 Frag (&cw)[NT] = (ts & 1) ? wb : wa;
                 Frag (&nw)[NT] = (ts & 1) ? wa : wb;
-                Frag (&cx)[PB] = (ts & 1) ? xb : xa;
-                Frag (&nx)[PB] = (ts & 1) ? xa : xb;
-                __builtin_amdgcn_s_waitcnt(0xC07F);                 // this step's fragments (requested a step ago) are in registers
+                Frag (&cx)[2 * PB] = (tap & 1) ? xb : xa;
+                Frag (&nx)[2 * PB] = (tap & 1) ? xa : xb;
+                __builtin_amdgcn_s_waitcnt(0xC07F);                 // this sub-step's fragments (requested a sub-step ago) are in registers
                 if (ts % BS == BS - 1) {
-                    // ring turn before the last step of a block: the next block (and a patch requested a turn ago) has
+                    // ring turn before the last sub-step of a block: the next block (and a patch requested a turn ago) has
                     // landed, every wave holds this block's last fragments in registers: its slot takes the block after next
                     // (the first turn of a tile only needs the block requested before the previous tile's epilogue: its
                     // NSTORE output stores - all issued when that tile lay inside the image - may stay in flight)
@@ -258,25 +254,27 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
                     if (ts == BS - 1 && c == 0) K10_T(15);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                // next step's fragments (a tile's first ones are read at its start: held across the epilogue they spill)
+                // next sub-step's weight fragments, and behind a tap's second half the next tap's pixel fragments (a tile's
+                // first ones are read at its start: held across the epilogue they spill)
                 if (ts < 17 || c + 1 < NCH) {
                     load_w(nw, wslot, (ts + 1) % BS);
-                    load_x(nx, ts == 17 ? pbuf ^ 1 : pbuf, (ts + 1) % 18);
+                    if (hf) load_x(nx, ts == 17 ? pbuf ^ 1 : pbuf, (tap + 1) % 9);
                 }
+                // (no issue-order hints: with 128 accumulators in four-register tuples the allocator gives an MFMA's result
+                // other registers than its addend, and every constraint on the order - sched_group_barrier pipelines, a
+                // barrier between requests and MFMAs, opaque in-order instructions - measured slower or spilled)
 #pragma unroll
-                for (int b = 0; b < PB; ++b)
+                for (int bb = 0; bb < 2 * PB; ++bb)
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) Mm::mma(cw[t], cx[b], acc[b][t]);
+                    for (int t = 0; t < NT; ++t) Mm::mma(cw[t], cx[bb], acc[bb][hf * NT + t]);
                 // issue order: two reads, then one read behind each of the first MFMAs (left alone the compiler sinks the
-                // reads behind the step's last MFMA and the next step waits out the whole LDS latency)
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-                for (int i = 0; i < NT + PB - 2; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, NT * PB - (NT + PB - 2), 0);
+                // reads behind the sub-step's last MFMA and the next one waits out the whole LDS latency)
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            // a chunk has 9 taps: the fragments of the next chunk's tap 0 were prefetched into xb, and tap 0 reads xa
+            if (c + 1 < NCH) {
+#pragma unroll
+                for (int bb = 0; bb < 2 * PB; ++bb) xa[bb] = xb[bb];
             }
             pbuf ^= 1;
             K10_T(2 + c);
@@ -298,15 +296,13 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
             // two rows per wave: the accumulators are packed to the storage type first (half the registers: room for the
             // shortcut rows); one row per wave: converted as they are written (there the packed copy is what spills)
             constexpr bool PACK_FIRST = PB == 2;
-            V4 pk[PACK_FIRST ? PB : 1][PACK_FIRST ? NT : 1][4];
+            V4 pk[PACK_FIRST ? 2 * PB : 1][PACK_FIRST ? 2 * NT : 1];
             if constexpr (PACK_FIRST) {
 #pragma unroll
-                for (int b = 0; b < PB; ++b)
+                for (int bb = 0; bb < 2 * PB; ++bb)
 #pragma unroll
-                    for (int t = 0; t < NT; ++t)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            pk[b][t][g] = V4{(T)acc[b][t][4 * g], (T)acc[b][t][4 * g + 1], (T)acc[b][t][4 * g + 2], (T)acc[b][t][4 * g + 3]};
+                    for (int ct = 0; ct < 2 * NT; ++ct)
+                        pk[bb][ct] = V4{(T)acc[bb][ct][0], (T)acc[bb][ct][1], (T)acc[bb][ct][2], (T)acc[bb][ct][3]};
                 __builtin_amdgcn_sched_barrier(0);
             }
             // every shortcut row is requested before the first output store: a load waited for behind a store (the memory
@@ -330,14 +326,17 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
             for (int p = 0; p < NPASS; ++p) {
                 const int b = p / PPB, t0 = (p % PPB) * SP, nt = pass_tiles(t0), cpr = 4 * nt, y = y0 + PB * wave + b;
+                // slab [pixel of the row][channel of the pass]: the lane's four channels 16 ct + 4 g4 + {0..3} of its pixel
 #pragma unroll
-                for (int t = 0; t < SP; ++t)
-                    if (t < nt)
+                for (int hx = 0; hx < 2; ++hx)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            *reinterpret_cast<V4*>(slab + (el & 31) * RS + (t * 32 + 8 * g + 4 * (el >> 5)) * 2) =
-                                PACK_FIRST ? pk[PACK_FIRST ? b : 0][PACK_FIRST ? t0 + t : 0][g]
-                                           : V4{(T)acc[b][t0 + t][4 * g], (T)acc[b][t0 + t][4 * g + 1], (T)acc[b][t0 + t][4 * g + 2], (T)acc[b][t0 + t][4 * g + 3]};
+                    for (int t = 0; t < 2 * SP; ++t)
+                        if (t < 2 * nt) {
+                            const int bb = 2 * b + hx, ct = 2 * t0 + t;
+                            *reinterpret_cast<V4*>(slab + (16 * hx + (el & 15)) * RS + (t * 16 + 4 * (el >> 4)) * 2) =
+                                PACK_FIRST ? pk[PACK_FIRST ? bb : 0][PACK_FIRST ? ct : 0]
+                                           : V4{(T)acc[bb][ct][0], (T)acc[bb][ct][1], (T)acc[bb][ct][2], (T)acc[bb][ct][3]};
+                        }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

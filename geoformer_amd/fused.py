@@ -122,18 +122,20 @@ _ZEROS = {}
 
 def pack_conv3x3_stream(w):
     """w [Cout, Cin, 3, 3] (BatchNorm already folded, 16-bit) -> the fragment stream of gf_conv3x3_nhwc: for each 32-channel
-    input chunk c, tap t = 3 ky + kx and 16-deep k-step s the Cout/32 standard-order fragments of W[:, 32c + 16s ..., ky, kx]
-    (18 steps per chunk; the kernel's weight blocks are 3 or 6 consecutive steps)."""
+    input chunk c, tap t = 3 ky + kx and half hf of the output channels, Cout/32 fragments of the 16x16x32 MFMA's A operand:
+    fragment tt = channels 16 (hf Cout/32 + tt) .. + 15, lane l -> row l % 16, input channels 32 c + 8 (l / 16) .. + 7
+    (18 sub-steps per chunk; the kernel's weight blocks are 3 or 6 consecutive sub-steps)."""
     cout, cin = w.shape[:2]
     nt = cout // 32
-    wt = w.reshape(cout, cin, 9)
-    parts = []
-    for c in range(cin // 32):
-        for t in range(9):
-            f = fragments(wt[:, 32 * c:32 * c + 32, t].contiguous(), 'std')            # [nt, 2, 64, 8]
-            for s in range(2):
-                parts.append(f[:, s].reshape(-1))
-    return torch.cat(parts).contiguous()
+    dev = w.device
+    lane = torch.arange(64, device=dev)
+    row, kg = lane % 16, lane // 16
+    wt = w.reshape(cout, cin // 32, 32, 9)                                           # [cout, chunk, k, tap]
+    # out[c, t, hf, tt, lane, j] = wt[16 (hf nt + tt) + row, c, 8 kg + j, t]
+    co = (16 * (torch.arange(2, device=dev)[:, None, None] * nt + torch.arange(nt, device=dev)[None, :, None]) + row[None, None, :])   # [2, nt, 64]
+    kk = 8 * kg[:, None] + torch.arange(8, device=dev)[None, :]                      # [64, 8]
+    g = wt[co[:, :, :, None], :, kk[None, None, :, :], :]                            # [2, nt, 64, 8, chunk, tap]
+    return g.permute(4, 5, 0, 1, 2, 3).contiguous().reshape(-1)
 
 
 def conv3x3_supported(cin, cout):
