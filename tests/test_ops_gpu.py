@@ -84,6 +84,28 @@ def test_linear_attention_coarse_shape(dtype):
     close(out, ref, *tol)
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('N,L,S,masks', [(7, 25, 25, False), (1, 25, 25, True), (6, 32, 17, True), (3, 9, 32, False)])
+def test_linear_attention_fine_shape(dtype, N, L, S, masks):
+    """Fine-level shape (windows of <= 32 tokens, 8 heads of 16): the one-wave-per-window kernel la_window16, incl. an odd
+    number of windows (two per workgroup), masks and strided k / v views of a fused k|v projection."""
+    from geoformer_amd import ops
+    g = torch.Generator().manual_seed(11 + N + L)
+    H, D = 8, 16
+    q = torch.randn(N, L, H * D, generator=g).to(dtype)
+    kv = torch.randn(N, S, 2 * H * D, generator=g).to(dtype)
+    qm = km = None
+    if masks:
+        qm, km = torch.rand(N, L, generator=g) > 0.3, torch.rand(N, S, generator=g) > 0.3
+        km[:, 0] = True
+    kvd = kv.to(DEV)
+    out = ops.linear_attention(q.to(DEV), kvd[..., :128], kvd[..., 128:], H, None if qm is None else qm.to(DEV),
+                               None if km is None else km.to(DEV))
+    ref = O.linear_attention(q.float().view(N, L, H, D), kv.float()[..., :128].reshape(N, S, H, D),
+                             kv.float()[..., 128:].reshape(N, S, H, D), qm, km).reshape(N, L, -1)
+    close(out, ref, *_tol(dtype, (1e-4, 1e-5), (2e-3, 2e-3)))
+
+
 # ------------------------------------------------------------------ RANSAC
 def _planted(n, n_out, H, seed):
     rng = np.random.default_rng(seed)
