@@ -480,6 +480,27 @@ def test_conv3x3_vs_torch(dtype, cin, cout, hw, act, use_res, use_shift):
     assert torch.equal(out, fused.conv3x3(x, ws, cout, shift, res, code, 0.1))
 
 
+@pytest.mark.parametrize('cin,cout,hw', [(128, 128, 320), (224, 128, 320), (256, 256, 80)])
+def test_conv3x3_full_size_vs_library(cin, cout, hw):
+    """K10 at the backbone's full sizes (16 images: 3200 / 3200 / 480 tiles walked by 256 persistent workgroups) against the
+    library convolution (MIOpen, fp16, fp32 accumulation) + shift + shortcut + ReLU on the same operands: every output element
+    is compared, so a tile skipped or written twice by the persistent walk shows up."""
+    from geoformer_amd import fused, ops
+    torch.manual_seed(hw + cin)
+    N = 16
+    x = torch.randn(N, cin, hw, hw, device='cuda', dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, 3, 3, device='cuda') * (1.5 / (3 * cin ** 0.5))).half()
+    shift = torch.randn(cout, device='cuda')
+    res = torch.randn(N, cout, hw, hw, device='cuda', dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+    out = fused.conv3x3(x, fused.pack_conv3x3_stream(w), cout, shift, res, ops.ACT_RELU)
+    conv = torch.nn.functional.conv2d(x, w.contiguous(memory_format=torch.channels_last), None, 1, 1).float()
+    ref = torch.relu(conv + shift[None, :, None, None] + res.float())
+    err = (out.float() - ref).abs()
+    # two roundings to fp16 on each side (library: convolution result; K10: accumulator + shift), values of magnitude <= ~8
+    assert float(err.max()) < 2.5e-2 and float(err.mean()) < 6e-4, (float(err.max()), float(err.mean()))
+    assert bool(torch.isfinite(out).all())
+
+
 def test_conv3x3_rejects_unsupported():
     from geoformer_amd import fused, _lib
     assert not fused.conv3x3_supported(64, 64)
