@@ -446,9 +446,145 @@ __global__ __launch_bounds__(256) void la_small(LaArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 16-bit fine level (8 heads of 16, windows of <= 32 tokens, ~2M of them) on the matrix cores: ONE WAVE per window.
+// la_small is VALU-bound there (0.48 ms per 37 k windows = 2 TB/s; a one-wave-per-window VALU form measured the same);
+// here the window's q / k / v move 16 bytes per lane, phi(K), V and phi(Q) sit row-major in wave-private LDS images, and
+//   state   KV_h[d][v] = sum_tok phi(K)[tok][h,d] V[tok][h,v] : one v_mfma_f32_16x16x32 per head, its token-major operands
+//           fetched with the transpose read ds_read_b64_tr_b16; Ksum_h = the same A operand against a ones B operand;
+//   apply   out^T[v][tok] = (KV_h / S)^T phi(Q)^T and the normaliser (Ksum_h / S replicated over the rows) : v_mfma_f32_16x16x16,
+//           whose A operand is exactly the register layout the state's accumulator has (column v on the lane, rows 4 g + i);
+//           the token is on the lane, so num / (den + eps / S) is lane-local; the result overwrites the 8 bytes of phi(Q)
+//           the lane just consumed and leaves in 16-byte row segments.
+// Rounding points (oracle: linear_attention_window): phi(q), phi(k) -> storage type; KV / S, Ksum / S -> storage type;
+// accumulation and the division in fp32; the message is rounded once.
+// ---------------------------------------------------------------------------------------------
+constexpr int LW_RS = 272, LW_IMG = 32 * LW_RS, LW_WAVE = 3 * LW_IMG;      // K | V | Q images of one wave: 26,112 B
+
+template <typename T>
+struct LwMma;
+template <>
+struct LwMma<_Float16> {
+    static __device__ __forceinline__ v4f k32(const v8h& a, const v8h& b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ v4f k16(const v4h& a, const v4h& b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
+};
+template <>
+struct LwMma<gf_bf16> {
+    static __device__ __forceinline__ v4f k32(const v8b& a, const v8b& b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ v4f k16(const v4b& a, const v4b& b, v4f c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(gf_v4s, a), __builtin_bit_cast(gf_v4s, b), c, 0, 0, 0);
+    }
+};
+
+// 16x16x32 operand of one head from a [32 tok][LW_RS] image: lane (i = channel, G) gets tokens 8 G .. 8 G + 7
+template <typename T>
+__device__ __forceinline__ gf_vec<T, 8> lw_tr_frag(const char* img, int ch0, int lane) {
+    const int G = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const char* base = img + (8 * G + q) * LW_RS + (ch0 + 4 * p) * 2;
+    typedef __attribute__((address_space(3))) gf_v4s* LP;
+    const gf_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LP)(base));
+    const gf_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LP)(base + 4 * LW_RS));
+    typedef short v8s __attribute__((__vector_size__(8 * sizeof(short))));
+    return __builtin_bit_cast(gf_vec<T, 8>, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <typename T>
+__global__ __launch_bounds__(128) void la_window_mfma(LaArgs a) {
+    using V8 = gf_vec<T, 8>;
+    using V4 = gf_vec<T, 4>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = blockIdx.x * 2 + wave;
+    if (n >= a.N) return;                                               // wave-uniform; no workgroup barrier below
+    char* kimg = smem + wave * LW_WAVE;
+    char* vimg = kimg + LW_IMG;
+    char* qimg = vimg + LW_IMG;
+    const T* kp = (const T*)a.k + (size_t)n * a.S * a.ldk;
+    const T* vp = (const T*)a.v + (size_t)n * a.S * a.ldv;
+    const T* qp = (const T*)a.q + (size_t)n * a.L * a.ldq;
+    V8 kr[8], vr[8], qr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = lane + 64 * i, row = e >> 4, ch = e & 15;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { kr[i][j] = (T)0.f; vr[i][j] = (T)0.f; qr[i][j] = (T)0.f; }
+        if (row < a.S) {
+            kr[i] = *reinterpret_cast<const V8*>(kp + (size_t)row * a.ldk + ch * 8);
+            vr[i] = *reinterpret_cast<const V8*>(vp + (size_t)row * a.ldv + ch * 8);
+        }
+        if (row < a.L) qr[i] = *reinterpret_cast<const V8*>(qp + (size_t)row * a.ldq + ch * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = lane + 64 * i, row = e >> 4, ch = e & 15;
+        const bool kk = row < a.S && (a.kv_mask == nullptr || a.kv_mask[(size_t)n * a.S + row] != 0);
+        const bool qk = row < a.L && (a.q_mask == nullptr || a.q_mask[(size_t)n * a.L + row] != 0);
+        V8 pk, pq, pv = vr[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            pk[j] = kk ? gf_from_float<T>(elu1_fast(gf_to_float(kr[i][j]))) : (T)0.f;
+            pq[j] = qk ? gf_from_float<T>(elu1_fast(gf_to_float(qr[i][j]))) : (T)0.f;
+            if (!kk) pv[j] = (T)0.f;
+        }
+        *reinterpret_cast<V8*>(kimg + row * LW_RS + ch * 16) = pk;
+        *reinterpret_cast<V8*>(vimg + row * LW_RS + ch * 16) = pv;
+        *reinterpret_cast<V8*>(qimg + row * LW_RS + ch * 16) = pq;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float inv_s = 1.0f / (float)a.S, eps_s = a.eps * inv_s;
+    const int G = lane >> 4, i16 = lane & 15;
+    V8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (T)1.0f;
+    const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+        const V8 af = lw_tr_frag<T>(kimg, h * 16, lane), bf = lw_tr_frag<T>(vimg, h * 16, lane);
+        const v4f kv = LwMma<T>::k32(af, bf, zero4);                   // KV_h[d = 4 G + i][v = i16]
+        const v4f ks = LwMma<T>::k32(af, ones, zero4);                 // Ksum_h[d = 4 G + i] in every column
+        const V4 kvp = {gf_from_float<T>(kv[0] * inv_s), gf_from_float<T>(kv[1] * inv_s), gf_from_float<T>(kv[2] * inv_s), gf_from_float<T>(kv[3] * inv_s)};
+        const V4 ksp = {gf_from_float<T>(ks[0] * inv_s), gf_from_float<T>(ks[1] * inv_s), gf_from_float<T>(ks[2] * inv_s), gf_from_float<T>(ks[3] * inv_s)};
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            if (tb * 16 < a.L) {
+                char* qa = qimg + (tb * 16 + i16) * LW_RS + (h * 16 + 4 * G) * 2;   // phi(Q)[tok = 16 tb + i16][h, 4 G .. + 3]
+                const V4 bq = *reinterpret_cast<const V4*>(qa);
+                const v4f num = LwMma<T>::k16(kvp, bq, zero4), den = LwMma<T>::k16(ksp, bq, zero4);
+                const float z = __builtin_amdgcn_rcpf(den[0] + eps_s);  // (every row of den holds the token's normaliser)
+                *reinterpret_cast<V4*>(qa) = V4{gf_from_float<T>(num[0] * z), gf_from_float<T>(num[1] * z), gf_from_float<T>(num[2] * z),
+                                                gf_from_float<T>(num[3] * z)};
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    T* op = (T*)a.out + (size_t)n * a.L * 128;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = lane + 64 * i, row = e >> 4, ch = e & 15;
+        if (row < a.L) *reinterpret_cast<V8*>(op + (size_t)row * 128 + ch * 8) = *reinterpret_cast<const V8*>(qimg + row * LW_RS + ch * 16);
+    }
+}
+
 template <typename T, int D>
 int la_launch(const LaArgs& a, hipStream_t st) {
     const size_t lds = (size_t)TOK * a.C * sizeof(float);
+    if constexpr (!std::is_same<T, float>::value && D == 16) {
+        if (a.C == 128 && a.S <= 32 && a.L <= 32 && a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 &&
+            (uintptr_t)a.q % 16 == 0 && (uintptr_t)a.k % 16 == 0 && (uintptr_t)a.v % 16 == 0 && (uintptr_t)a.out % 16 == 0) {
+            static bool attr = false;
+            if (!attr) {
+                (void)hipFuncSetAttribute((const void*)la_window_mfma<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LW_WAVE);
+                attr = true;
+            }
+            la_window_mfma<T><<<(a.N + 1) / 2, 128, 2 * LW_WAVE, st>>>(a);
+            GF_CHECK_LAUNCH();
+            return GF_OK;
+        }
+    }
     if (a.S <= CHUNK && a.L <= CHUNK) {
         la_small<T, D><<<a.N, a.C, lds + (size_t)a.C * (D + 1) * sizeof(float), st>>>(a);
         GF_CHECK_LAUNCH();

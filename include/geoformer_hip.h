@@ -107,6 +107,10 @@ int gf_pos_encode(const void* x, int x_dtype, long sn, long sc, long sh, long sw
  * replaces LinearAttention.forward (model/loftr_src/loftr/loftr_module/linear_attention.py:21-51)
  *   q [N,L,H,D], k,v [N,S,H,D] with row strides ldq/ldk/ldv (elements), masks uint8 or NULL,
  *   out [N,L,H*D] contiguous.  D in {16,32,64}, H*D in {64,128,192,256}.
+ *   Rounding points in the 16-bit modes: the coarse shape (8 heads of 32) and the fine level's windows (8 heads of 16,
+ *   L, S <= 32, 16-byte aligned rows) run on the matrix cores: phi(q), phi(k), KV / S and Ksum / S are rounded to the
+ *   storage type, sums and the division are fp32 (oracle: linear_attention_fused / linear_attention_window); every other
+ *   shape evaluates phi, the state and the normaliser in fp32 from the stored q, k, v.
  * ------------------------------------------------------------------------------------------ */
 size_t gf_linear_attention_workspace_bytes(int N, int S, int H, int D);
 int gf_linear_attention(const void* q, const void* k, const void* v, int dtype, int N, int L, int S, int H,

@@ -223,25 +223,49 @@ def encoder_layer_fused(P, prefix, x, source, nhead, st, x_mask=None, source_mas
     return _finish_fused(P, prefix, x, msg, 'loftr', st)
 
 
+def linear_attention_window(q, k, v, st, q_mask=None, kv_mask=None, eps: float = 1e-6):
+    """q [N,L,H,D], k, v [N,S,H,D] as STORED (already rounded) -> message [N,L,H,D] (rounded): the rounding points of
+    la_window_mfma (csrc/k2_linear_attention.hip, the fine level's windows in the 16-bit modes): phi(q), phi(k) are MFMA
+    operands (rounded), KV / S and Ksum / S are rounded (Ksum adds the ROUNDED phi(k)), accumulation and the division
+    are fp32."""
+    s_len = v.size(1)
+    inv_s = torch.tensor(1.0, dtype=torch.float32) / float(s_len)
+    Q, K = rt(_phi(q), st), rt(_phi(k), st)
+    if q_mask is not None:
+        Q = Q * q_mask[:, :, None, None]
+    if kv_mask is not None:
+        K = K * kv_mask[:, :, None, None]
+        v = v * kv_mask[:, :, None, None]
+    KV = rt(torch.einsum('nshd,nshv->nhdv', K, v) * inv_s, st)
+    Ks = rt(K.sum(dim=1) * inv_s, st)
+    num = torch.einsum('nlhd,nhdv->nlhv', Q, KV)
+    den = torch.einsum('nlhd,nhd->nlh', Q, Ks) + torch.tensor(eps, dtype=torch.float32) * inv_s
+    return rt(num / den[..., None], st)
+
+
 def encoder_layer_chain(P, prefix, x, source, nhead, st, x_mask=None, source_mask=None):
-    """LoFTR layer in the 'chain' storage mode (K3 linears + K2 attention of short sequences, the fine level):
-    la_small evaluates phi, the state and the normaliser in fp32 from the stored q, k, v."""
+    """LoFTR layer in the 'chain' storage mode (K3 linears + K2 attention of short sequences, the fine level).  The
+    attention: 8 heads of 16 over <= 32 tokens in a 16-bit mode runs la_window_mfma (linear_attention_window above); any
+    other shape runs la_small, which evaluates phi, the state and the normaliser in fp32 from the stored q, k, v."""
     n, _, c = x.shape
     d = c // nhead
     W = lambda name: rt(P[prefix + name], st)                                    # noqa: E731
     q = rt(F.linear(x, W('q_proj.weight')), st).view(n, -1, nhead, d)
     k = rt(F.linear(source, W('k_proj.weight')), st).view(n, -1, nhead, d)
     v = rt(F.linear(source, W('v_proj.weight')), st).view(n, -1, nhead, d)
-    Q, K = _phi(q), _phi(k)
-    if x_mask is not None:
-        Q = Q * x_mask[:, :, None, None]
-    if source_mask is not None:
-        K = K * source_mask[:, :, None, None]
-        v = v * source_mask[:, :, None, None]
-    s_len = v.size(1)
-    KV = torch.einsum('nshd,nshv->nhdv', K, v / s_len)
-    Z = 1 / (torch.einsum('nlhd,nhd->nlh', Q, K.sum(dim=1)) + 1e-6)
-    msg = rt(torch.einsum('nlhd,nhdv,nlh->nlhv', Q, KV, Z) * s_len, st).reshape(n, -1, c)
+    if st is not None and st != torch.float32 and c == 128 and d == 16 and q.shape[1] <= 32 and k.shape[1] <= 32:
+        msg = linear_attention_window(q, k, v, st, x_mask, source_mask).reshape(n, -1, c)
+    else:
+        Q, K = _phi(q), _phi(k)
+        if x_mask is not None:
+            Q = Q * x_mask[:, :, None, None]
+        if source_mask is not None:
+            K = K * source_mask[:, :, None, None]
+            v = v * source_mask[:, :, None, None]
+        s_len = v.size(1)
+        KV = torch.einsum('nshd,nshv->nhdv', K, v / s_len)
+        Z = 1 / (torch.einsum('nlhd,nhd->nlh', Q, K.sum(dim=1)) + 1e-6)
+        msg = rt(torch.einsum('nlhd,nhdv,nlh->nlhv', Q, KV, Z) * s_len, st).reshape(n, -1, c)
     m = rt(F.layer_norm(F.linear(msg, W('merge.weight')), (c,), P[prefix + 'norm1.weight'], P[prefix + 'norm1.bias']), st)
     hid = rt(torch.relu(F.linear(torch.cat([x, m], dim=2), W('mlp.0.weight'))), st)
     o = rt(F.layer_norm(F.linear(hid, W('mlp.2.weight')), (c,), P[prefix + 'norm2.weight'], P[prefix + 'norm2.bias']), st)
