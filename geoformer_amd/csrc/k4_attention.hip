@@ -7,7 +7,7 @@
 //                    [L, C] maps into compact, 32-key padded buffers (K row-major; V row-major for
 //                    fp32, [channel][key] with the MFMA k-order baked in for fp16).  K is read from
 //                    device memory, so no host sync is needed to size anything.
-//   attn_self      : flash-style forward.  One workgroup = 32 queries x 4 heads (wave = head).
+//   attn_self      : flash-style forward.  One workgroup = 32 QB queries x 4 heads (wave = head, QB = 1 or 4 query blocks).
 //                    S^T = K.Q^T is computed "swapped" so that the softmax axis (keys) lies in the
 //                    accumulator registers of the lane that owns the query: running max / sum /
 //                    rescale are lane-local, P^T feeds the P.V MFMA straight from registers
@@ -15,6 +15,8 @@
 #include <math.h>
 
 #include <type_traits>
+
+#include <cstdlib>
 
 #include "gf_common.h"
 
@@ -86,7 +88,7 @@ __device__ __forceinline__ int k_off(int row, int chunk) { return row * (CC * (i
 // fp16 V^T: [CC channels][32 keys] rows of 64 B, chunk c (0..3) stored at c ^ ((row >> 2) & 3)
 __device__ __forceinline__ int vt_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
-template <typename T>
+template <typename T, int QB>
 __global__ __launch_bounds__(256) void attn_self(AtArgs a) {
     using M = Mma32<T>;
     using Frag = typename M::Frag;
@@ -98,20 +100,30 @@ __global__ __launch_bounds__(256) void attn_self(AtArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ks = smem;
     char* vs = smem + KBYTES;
-    const int n = blockIdx.y, q0 = blockIdx.x * 32, tid = threadIdx.x;
+    const int n = blockIdx.y, q0 = blockIdx.x * (32 * QB), tid = threadIdx.x;
     const int head = tid >> 6, lane = tid & 63, h = lane >> 5, lr = lane & 31;
     const int K = a.nkeys[(size_t)n * a.nkeys_stride];
-    const int qrow = min(q0 + lr, a.L - 1);
-    const T* qp = (const T*)a.q + ((size_t)n * a.L + qrow) * a.ldq + head * HD;
-    Frag qf[NG];
+    // QB blocks of 32 queries per wave: a staged K / V tile (32 keys x 256 channels, 32 KiB) serves 32 QB queries of every head
+    // (with one block a workgroup streams the image's whole K and V for 32 queries: L2-bound at ~1200 keys)
+    Frag qf[QB][NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) qf[g] = *reinterpret_cast<const Frag*>(qp + g * KG + h * (KG / 2));
-    v16f o[2];
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qrow = min(q0 + 32 * qb + lr, a.L - 1);
+        const T* qp = (const T*)a.q + ((size_t)n * a.L + qrow) * a.ldq + head * HD;
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+        for (int g = 0; g < NG; ++g) qf[qb][g] = *reinterpret_cast<const Frag*>(qp + g * KG + h * (KG / 2));
+    }
+    v16f o[QB][2];
+    float m[QB], l[QB];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
-    float m = -INFINITY, l = 0.f;
+    for (int qb = 0; qb < QB; ++qb) {
+        m[qb] = -INFINITY;
+        l[qb] = 0.f;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qb][b][r] = 0.f;
+    }
     const T* kc = (const T*)a.kc + (size_t)n * a.Kpad * CC;
     const int ntiles = (K + KT - 1) / KT;
     for (int tile = 0; tile < ntiles; ++tile) {
@@ -141,74 +153,81 @@ __global__ __launch_bounds__(256) void attn_self(AtArgs a) {
             }
         }
         __syncthreads();
-        // ---- S^T tile: rows = keys (registers), column = query (lane)
-        v16f s;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int chunk = (head * HD + g * KG + h * (KG / 2)) / EPC;
-            const Frag kf = *reinterpret_cast<const Frag*>(ks + k_off<T>(lr, chunk));
-            M::mma(kf, qf[g], s);
-        }
-        float x[16];
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = tile * KT + gf_acc_row(r, h);
-            x[r] = key < K ? s[r] * a.softmax_temp : -INFINITY;
-            tmax = fmaxf(tmax, x[r]);
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float mnew = fmaxf(m, tmax);          // finite: every tile holds at least one real key
-        constexpr bool FAST = !std::is_same<T, float>::value;          // fp16 mode: hardware exponential
-        const float alpha = FAST ? __expf(m - mnew) : expf(m - mnew);
-        float psum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            x[r] = FAST ? __expf(x[r] - mnew) : expf(x[r] - mnew);
-            psum += x[r];
-        }
-        l = l * alpha + psum;
-        m = mnew;
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
-        // ---- O^T += V^T . P^T with P^T taken from the registers as the B operand
-        if constexpr (F32) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float* vrow = reinterpret_cast<const float*>(vs) + gf_acc_row(r, h) * CC + head * HD + lr;
-                o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[0], x[r], o[0], 0, 0, 0);
-                o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32], x[r], o[1], 0, 0, 0);
+        for (int qb = 0; qb < QB; ++qb) {
+            // ---- S^T tile: rows = keys (registers), column = query (lane)
+            v16f s;
+    #pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    #pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int chunk = (head * HD + g * KG + h * (KG / 2)) / EPC;
+                const Frag kf = *reinterpret_cast<const Frag*>(ks + k_off<T>(lr, chunk));
+                M::mma(kf, qf[qb][g], s);
             }
-        } else {
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const Frag pf{(T)x[8 * s2], (T)x[8 * s2 + 1], (T)x[8 * s2 + 2], (T)x[8 * s2 + 3],
-                              (T)x[8 * s2 + 4], (T)x[8 * s2 + 5], (T)x[8 * s2 + 6], (T)x[8 * s2 + 7]};
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const Frag vf = *reinterpret_cast<const Frag*>(vs + vt_off(head * HD + b * 32 + lr, 2 * s2 + h));
-                    M::mma(vf, pf, o[b]);
+            float x[16];
+            float tmax = -INFINITY;
+    #pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = tile * KT + gf_acc_row(r, h);
+                x[r] = key < K ? s[r] * a.softmax_temp : -INFINITY;
+                tmax = fmaxf(tmax, x[r]);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float mnew = fmaxf(m[qb], tmax);          // finite: every tile holds at least one real key
+            constexpr bool FAST = !std::is_same<T, float>::value;          // fp16 mode: hardware exponential
+            const float alpha = FAST ? __expf(m[qb] - mnew) : expf(m[qb] - mnew);
+            float psum = 0.f;
+    #pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                x[r] = FAST ? __expf(x[r] - mnew) : expf(x[r] - mnew);
+                psum += x[r];
+            }
+            l[qb] = l[qb] * alpha + psum;
+            m[qb] = mnew;
+    #pragma unroll
+            for (int b = 0; b < 2; ++b)
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) o[qb][b][r] *= alpha;
+            // ---- O^T += V^T . P^T with P^T taken from the registers as the B operand
+            if constexpr (F32) {
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float* vrow = reinterpret_cast<const float*>(vs) + gf_acc_row(r, h) * CC + head * HD + lr;
+                    o[qb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[0], x[r], o[qb][0], 0, 0, 0);
+                    o[qb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32], x[r], o[qb][1], 0, 0, 0);
+                }
+            } else {
+    #pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const Frag pf{(T)x[8 * s2], (T)x[8 * s2 + 1], (T)x[8 * s2 + 2], (T)x[8 * s2 + 3],
+                                  (T)x[8 * s2 + 4], (T)x[8 * s2 + 5], (T)x[8 * s2 + 6], (T)x[8 * s2 + 7]};
+    #pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const Frag vf = *reinterpret_cast<const Frag*>(vs + vt_off(head * HD + b * 32 + lr, 2 * s2 + h));
+                        M::mma(vf, pf, o[qb][b]);
+                    }
                 }
             }
-        }
-    }
-    l += __shfl_xor(l, 32, 64);
-    if (q0 + lr < a.L) {
-        T* op = (T*)a.out + ((size_t)n * a.L + q0 + lr) * CC + head * HD;
-        const float inv = K > 0 ? 1.0f / l : 0.f;       // K == 0: zeros (the caller skips the layer)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {             // registers 4*r4..4*r4+3 = 4 consecutive channels
-                const int d = b * 32 + 8 * r4 + 4 * h;
-                const v4f v{o[b][4 * r4] * inv, o[b][4 * r4 + 1] * inv, o[b][4 * r4 + 2] * inv, o[b][4 * r4 + 3] * inv};
-                if constexpr (F32) *reinterpret_cast<v4f*>(op + d) = v;
-                else *reinterpret_cast<gf_vec<T, 4>*>(op + d) = gf_vec<T, 4>{(T)v.x, (T)v.y, (T)v.z, (T)v.w};
             }
+    }
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const float lsum = l[qb] + __shfl_xor(l[qb], 32, 64);
+        const int qi = q0 + 32 * qb + lr;
+        if (qi < a.L) {
+            T* op = (T*)a.out + ((size_t)n * a.L + qi) * CC + head * HD;
+            const float inv = K > 0 ? 1.0f / lsum : 0.f;       // K == 0: zeros (the caller skips the layer)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {             // registers 4*r4..4*r4+3 = 4 consecutive channels
+                    const int d = b * 32 + 8 * r4 + 4 * h;
+                    const v4f v{o[qb][b][4 * r4] * inv, o[qb][b][4 * r4 + 1] * inv, o[qb][b][4 * r4 + 2] * inv, o[qb][b][4 * r4 + 3] * inv};
+                    if constexpr (F32) *reinterpret_cast<v4f*>(op + d) = v;
+                    else *reinterpret_cast<gf_vec<T, 4>*>(op + d) = gf_vec<T, 4>{(T)v.x, (T)v.y, (T)v.z, (T)v.w};
+                }
+        }
     }
 }
 
@@ -242,17 +261,23 @@ extern "C" int gf_self_attention_gathered(const void* q, const void* kmap, const
     a.vc = (char*)workspace + gf_align_up((size_t)N * a.Kpad * CC * es, 256);
     a.softmax_temp = 1.0f / sqrtf((float)D);
     hipStream_t st = (hipStream_t)stream;
-    const dim3 ggrid(a.Kpad / KT, N), agrid((L + 31) / 32, N);
-    if (dtype == GF_F32) {
-        attn_gather_kv<float><<<ggrid, 256, 0, st>>>(a);
-        attn_self<float><<<agrid, 256, 2 * KT * CC * 4, st>>>(a);
-    } else if (dtype == GF_F16) {
-        attn_gather_kv<_Float16><<<ggrid, 256, 0, st>>>(a);
-        attn_self<_Float16><<<agrid, 256, 2 * KT * CC * 2, st>>>(a);
-    } else {
-        attn_gather_kv<gf_bf16><<<ggrid, 256, 0, st>>>(a);
-        attn_self<gf_bf16><<<agrid, 256, 2 * KT * CC * 2, st>>>(a);
-    }
+    // query blocks per wave (32 QB queries share a staged K / V tile) once there are enough workgroups to fill the chip;
+    // GF_K4_QB=1|2|4 overrides (measurements)
+    static const int forced = [] { const char* e = getenv("GF_K4_QB"); return e ? atoi(e) : 0; }();
+    int qb = forced ? forced : ((long)N * ((L + 63) / 64) >= 512 ? 2 : 1);
+    if (qb != 1 && qb != 2 && qb != 4) qb = 1;
+    const dim3 ggrid(a.Kpad / KT, N), agrid((L + 32 * qb - 1) / (32 * qb), N);
+#define GF_K4_LAUNCH(T, ES)                                                                        \
+    do {                                                                                           \
+        attn_gather_kv<T><<<ggrid, 256, 0, st>>>(a);                                               \
+        if (qb == 4) attn_self<T, 4><<<agrid, 256, 2 * KT * CC * ES, st>>>(a);                     \
+        else if (qb == 2) attn_self<T, 2><<<agrid, 256, 2 * KT * CC * ES, st>>>(a);                \
+        else attn_self<T, 1><<<agrid, 256, 2 * KT * CC * ES, st>>>(a);                             \
+    } while (0)
+    if (dtype == GF_F32) GF_K4_LAUNCH(float, 4);
+    else if (dtype == GF_F16) GF_K4_LAUNCH(_Float16, 2);
+    else GF_K4_LAUNCH(gf_bf16, 2);
+#undef GF_K4_LAUNCH
     GF_CHECK_LAUNCH();
     return GF_OK;
 }
