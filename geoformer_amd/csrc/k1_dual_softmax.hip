@@ -738,9 +738,10 @@ __global__ __launch_bounds__(NT, 2) void k1_conf_pipe(K1Args a) {
         for (int bn = t0; bn <= t1; ++bn) {
             const bool mma = bn < t1, epi = bn > t0;
             if (mma) {
-                // tile bn has landed: everything issued behind its DMA (the previous iteration's 32 row stores, and
-                // possibly candidate atomics) may stay in flight; the very first tile of a unit has nothing behind it
-                if (bn == t0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // tile bn has landed: what was issued behind its DMA - the previous iteration's 32 row stores (and possibly
+                // candidate atomics) - may stay in flight.  The unit's first two tiles have no stores behind their DMA (tile
+                // t0 + 1 is requested in the iteration that only multiplies tile t0): they wait for everything.
+                if (bn <= t0 + 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
             }
             __syncthreads();                                  // ... for every wave; and every wave is done with tile bn-1's buffer
