@@ -127,3 +127,29 @@ def test_full_size_properties(thr):
     # conf <= 1 and each row / column of conf sums to <= 1 (product of two probabilities)
     assert float(conf.max()) <= 1.0 + 1e-5
     assert float(conf.sum(-1).max()) <= 1.0 + 1e-4 and float(conf.sum(-2).max()) <= 1.0 + 1e-4
+
+
+@pytest.mark.parametrize('thr', [0.2, 0.0])
+def test_full_size_repeatable(thr):
+    """The same 8-pair call 25 times (the shape of a bench step: 640 column runs per row panel, 512 persistent workgroups):
+    the confidence matrix and the matches must come out bit-identical every time (a guard against ordering bugs in the
+    pipelined pass B - tiles read while their LDS-DMA is in flight, buffers reused too early; it does NOT prove their
+    absence: a counted wait that was one tile too loose passed it, the fix came from reading the code)."""
+    from geoformer_amd import ops
+    N, L, S, C = 8, 6400, 6400, 256
+    g = torch.Generator().manual_seed(17)
+    f0 = (torch.randn(N, L, C, generator=g) * 1.3).cuda().half()
+    f1 = (f0[:, torch.randperm(S, generator=g).cuda()].float() + 0.4 * torch.randn(N, S, C, generator=g).cuda()).half()
+    first = None
+    for _ in range(25):
+        out = ops.dual_softmax_match(f0, f1, 0.1, thr, (80, 80), (80, 80), 8.0)
+        M = int(out['counts'][0])
+        digest = (M, out['conf_matrix'].view(torch.int32).sum(dtype=torch.int64).item(),
+                  out['conf_matrix'][:, ::97, ::89].clone(), out['i_ids'][:M].clone(), out['j_ids'][:M].clone(),
+                  out['mconf'][:M].clone())
+        if first is None:
+            first = digest
+            continue
+        assert digest[0] == first[0] and digest[1] == first[1]
+        for a, b in zip(digest[2:], first[2:]):
+            assert torch.equal(a, b)
