@@ -596,40 +596,32 @@ __global__ __launch_bounds__(256, 1) void enc_kv_state(EncArgs a) {
         }
     }
     K9_T(5);
-    // sum of the four waves (tree through LDS: 3 -> 1 and 2 -> 0, then 1 -> 0), then one partial per tile
-    float* red = reinterpret_cast<float*>(smem);                       // [2][8][16][64] + [2][8][64] floats = 68 KiB
-    auto put = [&](int slot) {
-#pragma unroll
-        for (int hh = 0; hh < 8; ++hh) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) red[((slot * 8 + hh) * 16 + r) * 64 + lane] = kv[hh][r];
-            red[2 * 8 * 16 * 64 + (slot * 8 + hh) * 64 + lane] = ksum[hh];
-        }
-    };
-    auto get = [&](int slot) {
-#pragma unroll
-        for (int hh = 0; hh < 8; ++hh) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) kv[hh][r] += red[((slot * 8 + hh) * 16 + r) * 64 + lane];
-            ksum[hh] += red[2 * 8 * 16 * 64 + (slot * 8 + hh) * 64 + lane];
-        }
-    };
+    // sum of the four waves, then one partial per tile: every wave parks its partial in LDS (4 x 34 KiB: the tile and the ring
+    // are dead by now), and all 256 threads add the four copies - in the order (w0 + w2) + (w1 + w3) - and store the partial
+    // (a tree that ended with ONE wave adding and storing 33 KB took 9 of the kernel's 35 thousand cycles)
+    constexpr int KVN = 8 * 16 * 64, SLOT = KVN + 8 * 64;              // floats per wave: kv[hh][r][lane] | ksum[hh][lane]
+    float* red = reinterpret_cast<float*>(smem);
     __syncthreads();
-    if (wave >= 2) put(wave - 2);
-    __syncthreads();
-    if (wave < 2) get(wave);
-    __syncthreads();
-    if (wave == 1) put(0);
+#pragma unroll
+    for (int hh = 0; hh < 8; ++hh) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave * SLOT + (hh * 16 + r) * 64 + lane] = kv[hh][r];
+        red[wave * SLOT + KVN + hh * 64 + lane] = ksum[hh];
+    }
     __syncthreads();
     K9_T(6);
-    if (wave == 0) {
-        get(0);
-        float* dst = a.part + ((size_t)n * a.tiles + tile) * (C * D + C);
-#pragma unroll
-        for (int hh = 0; hh < 8; ++hh) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dst[(size_t)(hh * D + gf_acc_row(r, h2)) * D + lr] = kv[hh][r];      // [c][v]: 128-B runs
-            if (h2 == 0) dst[C * D + hh * D + lr] = ksum[hh];
+    float* dst = a.part + ((size_t)n * a.tiles + tile) * (C * D + C);
+#pragma unroll 4
+    for (int e = tid; e < KVN; e += 256) {
+        const float sum = (red[e] + red[2 * SLOT + e]) + (red[SLOT + e] + red[3 * SLOT + e]);
+        const int hh = e >> 10, r = (e >> 6) & 15, ln = e & 63;
+        dst[(size_t)(hh * D + gf_acc_row(r, ln >> 5)) * D + (ln & 31)] = sum;                               // [c][v]: 128-B runs
+    }
+    for (int e = tid; e < 8 * 64; e += 256) {
+        const int ln = e & 63;
+        if (ln < 32) {
+            const int o = KVN + e;
+            dst[C * D + (e >> 6) * D + ln] = (red[o] + red[2 * SLOT + o]) + (red[SLOT + o] + red[3 * SLOT + o]);
         }
     }
     K9_T(7);
