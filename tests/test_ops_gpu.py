@@ -225,6 +225,31 @@ def test_self_attention_gathered(dtype):
         close(out[b], ref, *tol)
 
 
+def test_self_attention_gathered_two_blocks_per_wave():
+    """Batch large enough (N L / 64 >= 512) for the form with two 32-query blocks per wave sharing a staged K / V tile (what
+    an 8-pair bench step runs), ragged L (the last workgroup covers 40 queries), unequal key counts."""
+    from geoformer_amd import ops
+    g = torch.Generator().manual_seed(14)
+    N, L, C, H = 9, 3688, 256, 4
+    q = torch.randn(N, L, C, generator=g).half()
+    kv = torch.randn(N, L, 2 * C, generator=g).half()
+    nk = [333, 0, 70, 1, 32, 33, 500, 64, 97]
+    idx = torch.zeros(N, L, dtype=torch.int32)
+    for b in range(N):
+        idx[b, :nk[b]] = torch.sort(torch.randperm(L, generator=g)[:nk[b]])[0].int()
+    nkeys = torch.tensor(nk, dtype=torch.int32)
+    assert N * ((L + 63) // 64) >= 512
+    out = ops.self_attention_gathered(q.to(DEV), kv.to(DEV)[..., :C], kv.to(DEV)[..., C:], idx.to(DEV), nkeys.to(DEV), H)
+    for b in range(N):
+        if nk[b] == 0:
+            assert float(out[b].abs().max()) == 0.0
+            continue
+        sel = idx[b, :nk[b]].long()
+        ref = O.full_attention(q[b].float().view(1, L, H, -1), kv[b, sel, :C].float().view(1, nk[b], H, -1),
+                               kv[b, sel, C:].float().view(1, nk[b], H, -1)).reshape(L, C)
+        close(out[b], ref, 4e-3, 4e-3)
+
+
 # ------------------------------------------------------------------ K5
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
 def test_window_cross_attention(dtype):
