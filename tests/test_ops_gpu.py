@@ -85,7 +85,7 @@ def test_linear_attention_coarse_shape(dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize('N,L,S,masks', [(7, 25, 25, False), (1, 25, 25, True), (6, 32, 17, True), (3, 9, 32, False)])
+@pytest.mark.parametrize('N,L,S,masks', [(7, 25, 25, False), (1, 25, 25, True), (6, 32, 17, True), (3, 9, 32, False), (5001, 25, 25, False)])
 def test_linear_attention_fine_shape(dtype, N, L, S, masks):
     """Fine-level shape (windows of <= 32 tokens, 8 heads of 16): the one-wave-per-window kernel la_window16, incl. an odd
     number of windows (two per workgroup), masks and strided k / v views of a fused k|v projection."""
