@@ -4,26 +4,29 @@
 // matrix cores:   out[n,y,x,:] = act( sum_{ky,kx} W[:, :, ky, kx] . x[n, y+ky-1, x+kx-1, :] + shift + shortcut[n,y,x,:] )
 //
 // Same machinery as K9 (k9_encoder_fused.hip): products transposed (MFMA A = output channels, B = pixels, so a pixel's
-// channels sit in one lane's registers; v_mfma_f32_16x16x32: 16 channels x 16 pixels x the 32 input channels of a chunk), weights pre-packed on the host into the exact
-// sequence of 1-KiB MFMA A fragments the kernel consumes and streamed from L2 through a two-block LDS ring by LDS-DMA;
-// the fragments of step i+1 (weights AND pixels) are requested before the MFMAs of step i.
-//   workgroup = 4 waves = an 8-row x 32-column pixel tile of one image; a wave owns two rows (two 32-pixel blocks):
-//               every weight fragment feeds two MFMAs, 2 x COUT/32 accumulator tiles per wave (outputs wider than 128
-//               channels: 4-row tiles, one row per wave);
-//   K loop     = input channels in chunks of 32 (two 16-deep k-steps) x 9 taps: one STEP = (chunk, tap, k-step) =
-//               COUT/32 weight fragments, PB pixel fragments, PB x COUT/32 MFMAs; a weight block = 6 steps, so the ring
-//               turns at fixed places of a chunk (steps 5, 11, 17);
+// channels sit in one lane's registers; v_mfma_f32_16x16x32: 16 channels x 16 pixels x the 32 input channels of a chunk),
+// weights pre-packed on the host into the exact sequence of 1-KiB MFMA A fragments the kernel consumes and streamed from L2
+// through a two-block LDS ring by LDS-DMA; the fragments of the next sub-step are requested in front of this one's MFMAs.
+//   workgroup = 8 waves (two per SIMD, 256 registers each: one wave's DMA requests, ring turns and epilogue fill the
+//               other's MFMA gaps) = a 16-row x 32-column pixel tile of one image, a wave owns two rows = four 16-pixel
+//               blocks, 4 x COUT/16 accumulator tiles of four registers (outputs wider than 128 channels: 8-row tiles, one
+//               row per wave);
+//   K loop     = input channels in chunks of 32 x 9 taps x 2 halves of the output channels: one SUB-STEP = COUT/32 weight
+//               fragments (16 channels x 32 input channels each) times the tap's 2 PB pixel fragments (16 pixels x 32
+//               channels = the 64 bytes of a patch pixel); a weight block = 6 sub-steps (3 for the wide outputs), so the
+//               ring turns at fixed places of a chunk;
 //   pixels     = per chunk the halo patch of the tile (64 B per pixel) sits in LDS, double-buffered: the next chunk's
 //               (or the next tile's first) patch arrives by LDS-DMA while the current one is multiplied; pixels outside
 //               the image are read from a page of zeros (per-lane DMA source address); the 16-byte slot index is XORed
-//               with (pixel >> 2) & 3 on the source side so that the fragment reads of 32 consecutive pixels spread
-//               over the LDS banks;
-//   persistent = min(tiles, 256) workgroups walk the tiles (25 rounds at 16 x 320 x 320); the ring and the patch
+//               with (pixel >> 1) & 3 on the source side: the ds_read_b128 fragment reads of 16 consecutive pixels x 4
+//               k groups are then conflict-free for every patch offset;
+//   persistent = min(tiles, 256) workgroups walk the tiles (13 rounds at 16 x 320 x 320); the ring and the patch
 //               buffers run on across tiles (the next tile's first blocks and patch are requested during the last
 //               chunk), and the epilogue is wave-private: no workgroup barrier besides the ring turns;
-//   epilogue   = the shortcut rows are fetched into registers at the start of the last chunk; accumulators -> a
-//               wave-private LDS slab (pixel-major) -> + shift + shortcut -> activation -> 16-byte NHWC stores that
-//               nobody waits for.
+//   epilogue   = accumulators (started at the BatchNorm shift) -> a wave-private LDS slab (pixel-major; for the two-row
+//               variants it aliases the patch buffer of the tile's last chunk) -> + shortcut (every row requested before the
+//               first store) -> activation -> 16-byte NHWC stores that nobody waits for; one straight-line body per
+//               (shortcut?, activation form, tile inside the image?).
 #include <type_traits>
 
 #include "gf_common.h"
