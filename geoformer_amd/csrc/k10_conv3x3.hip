@@ -152,6 +152,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
     const char* ws = (const char*)a.wstream;
     float* shiftv = reinterpret_cast<float*>(smem + G::SHIFT_OFF);
     for (int i = tid; i < COUT; i += NW * 64) shiftv[i] = a.shift ? a.shift[i] : 0.f;
+    // the second-dispatched half of an 8-wave workgroup loses every arbitration on its SIMD: one static priority step for it
+    // (no per-phase flips) takes 1-2 % off every shape
+    if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
     auto decode = [&](int t, int& n, int& y0, int& x0) {
         const int per = a.tiles_x * a.tiles_y;
