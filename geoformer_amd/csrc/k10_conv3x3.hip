@@ -185,10 +185,18 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
         }
     };
 
+    // XCD-aware walk (workgroups are dealt to the 8 XCDs round-robin): XCD x owns the contiguous tile range [xbeg, xend) and
+    // its workgroups walk it side by side, so that neighbouring tiles - which share halo rows - meet in one L2
+    const int nx8 = gridDim.x >= 8 ? 8 : 1;
+    const int xcd = nx8 == 8 ? (int)(blockIdx.x & 7) : 0, xslot = nx8 == 8 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int xper = nx8 == 8 ? (int)((gridDim.x + 7 - xcd) >> 3) : (int)gridDim.x;      // workgroups on this XCD
+    const int tq = a.ntiles / nx8, tr = a.ntiles % nx8;
+    const int xbeg = xcd * tq + (xcd < tr ? xcd : tr), xend = xbeg + tq + (xcd < tr ? 1 : 0);
+    const int tile0 = xbeg + xslot;
     int pbuf = 0, wslot = 0;                                        // patch buffer / ring slot being multiplied
-    {
+    if (tile0 < xend) {
         int n, y0, x0;
-        decode(blockIdx.x, n, y0, x0);
+        decode(tile0, n, y0, x0);
         conv_dma_patch<T, CIN, NT, NW>(a, smem, 0, n, y0, x0, 0, wave, lane);
         conv_dma_block<NT, NW>(ws, smem, 0, 0, wave, lane);
         conv_dma_block<NT, NW>(ws, smem, 1, 1, wave, lane);
@@ -197,11 +205,11 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
     }
     [[maybe_unused]] int it = -1;
     bool prev_full = false;                                         // previous tile of this workgroup: all its stores issued?
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    for (int tile = tile0; tile < xend; tile += xper) {
         int n, y0, x0;
         decode(tile, n, y0, x0);
-        const int nxt_tile = tile + gridDim.x;
-        const bool has_next = nxt_tile < a.ntiles;
+        const int nxt_tile = tile + xper;
+        const bool has_next = nxt_tile < xend;
         ++it;
         K10_T(0);
         load_w(wa, wslot, 0);               // block 0 and the patch of chunk 0 landed before the previous tile's last turn
