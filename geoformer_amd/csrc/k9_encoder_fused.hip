@@ -632,7 +632,15 @@ __global__ void enc_kv_reduce(const float* part, float* fin, int tiles, int len)
     if (i >= len) return;
     const float* p = part + (size_t)n * tiles * len + i;
     float s = 0.f;
-    for (int c = 0; c < tiles; ++c) s += p[(size_t)c * len];
+    int c = 0;
+    for (; c + 10 <= tiles; c += 10) {                                 // ten loads in flight, added in tile order
+        float v[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) v[j] = p[(size_t)(c + j) * len];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) s += v[j];
+    }
+    for (; c < tiles; ++c) s += p[(size_t)c * len];
     fin[(size_t)n * len + i] = s;
 }
 
