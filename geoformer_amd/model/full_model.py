@@ -50,10 +50,18 @@ class GeoFormer(nn.Module):
         self.backbone_dtype = backbone_dtype or self.compute_dtype
         self.backbone.to(self.backbone_dtype)
         self._fused[0] = None
+        self._drop_graphs()
         return self
+
+    def _drop_graphs(self):
+        # captured graphs read the packed weight caches (K9/K10 fragment streams, folded backbone) by address: once
+        # those are dropped a replay would read freed or re-used memory - capture again on the next forward
+        if getattr(self, '_graphs', None):
+            self._graphs = {}
 
     def _invalidate(self):
         self._fused[0] = None
+        self._drop_graphs()
         for m in self.modules():
             if hasattr(m, 'invalidate'):
                 m.invalidate()
@@ -85,7 +93,8 @@ class GeoFormer(nn.Module):
 
     def _forward_graphed(self, data):
         img0, img1 = data['image0'], data['image1']
-        key = (tuple(img0.shape), tuple(img1.shape), img0.dtype, torch.cuda.current_stream().cuda_stream)
+        key = (tuple(img0.shape), tuple(img1.shape), img0.dtype, torch.cuda.current_stream().cuda_stream,
+               float(self.coarse_matching.thr), float(self.coarse_matching.temperature), self.precision)
         entry = self._graphs.get(key)
         if entry is None:
             # warm-up ON the stream the capture will use: MIOpen keeps a handle (and its algorithm picks / workspaces) per
@@ -109,7 +118,11 @@ class GeoFormer(nn.Module):
         data.update({k: v for k, v in cap.items() if k not in ('image0', 'image1')})
         data['_static'] = dict(cap['_static'])                   # the tensors are the capture's static outputs: consumed below
         data['_backbone_feats'] = tuple(cap['_static'][k] for k in ('feat_c0', 'feat_f0', 'feat_c1', 'feat_f1'))
-        return self.forward_dynamic(data)
+        data = self.forward_dynamic(data)
+        for k in ('b_ids', 'i_ids', 'j_ids', 'm_bids', 'mkpts0_c', 'mkpts1_c', 'mkpts0_f', 'mkpts1_f', 'mconf'):
+            data[k] = data[k].clone()                    # views of the capture's capacity arrays otherwise
+        data['_aliases_static_buffers'] = ('conf_matrix', 'dect_conf_matrix', '_feat_dev', '_backbone_feats')
+        return data
 
     def forward(self, data: Dict[str, torch.Tensor]):
         img0, img1 = data['image0'], data['image1']
