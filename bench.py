@@ -9,9 +9,12 @@ embarrassingly-parallel shard"): the pair list (seeds 0 .. N*K*B-1) is cut into 
 runs `steps` batches of `batch` pairs of its block through the FULL forward (ResNet-FPN backbone on PyTorch-ROCm +
 the HIP matching path).  There is no data-path collective (pairs are independent), so scaling is weak: per-GPU
 work is fixed as N grows.  Inputs are resident in HBM before the timed region.  Weights: deterministic
-closed-form fill of the reference architecture (no checkpoint offline); thresholds 0 so that matches flow through
-every stage, as in the reference CPU measurement of BASELINE.md section 2 - M (coarse matches) and K (inlier
-cells) are reported because cost scales with them.
+closed-form fill of the reference architecture (no checkpoint offline).  Random-init weights cannot produce the load
+SURVEY section 8 sizes the path for from images (M ~ 2000 coarse matches, K ~ 1000 inlier cells per pair at the
+reference's thresholds 0.2 / 0.1), so the default workload (`--pairs planted`) runs the backbone on the images and feeds
+the matching path planted-correspondence feature maps: `value` is the throughput at that NOMINAL load (M ~ 2300,
+K ~ 1200, reported in `config` because cost scales with them).  `--pairs homography` is the light-load run of rounds 1-2
+(thresholds 0, M ~ 360, K ~ 60), kept as a side measurement.
 
 Launching: `--gpus N` (N > 1) without a launcher starts the N ranks ITSELF (fresh child processes, before anything
 in the parent touches the GPU), waits for them and relays rank 0's line; under `python -m torch.distributed.run`
@@ -40,12 +43,16 @@ ROOFLINE_TAGS = [
     # tag,                   bound,  hot path, description
     ('enc_layer',            'mfma', True,  'fused encoder layer (projections + attention apply + merge/LN + MLP/LN + residual)'),
     ('enc_kv_state',         'mfma', True,  'fused k/v projection + linear-attention state'),
-    ('k3_linear',            'mfma', True,  'K3 linear_kernel family (encoder-layer / fine-level GEMMs with fused epilogues)'),
+    ('k3_linear',            'mfma', True,  'K3 linear_kernel family (Geo-layer projections, FinePreprocess and fine-level GEMMs with fused epilogues)'),
     ('k1_stats',             'mfma', True,  'K1 pass A (similarity tile statistics)'),
     ('k1_conf',              'hbm',  True,  'K1 pass B (dual-softmax correlation sweep, conf_matrix write)'),
+    ('k1_unit',              'hbm',  True,  'K1 as a unit: one CoarseMatching call (pass A + reduction + pass B + selection + compaction) against its algorithmic bytes'),
+    ('fine_layer',           'mfma', True,  'fused fine-level encoder layer (25-token windows: projections + window attention + merge/LN + MLP/LN + residual)'),
     ('k2_linear_attention',  'hbm',  True,  'K2 linear attention (state + apply)'),
     ('k5_window_attention',  'hbm',  True,  'K5 windowed cross attention (L2 gather)'),
+    ('k4_self_attention',    'mfma', True,  'K4 inlier-key self attention (flash form)'),
     ('bias_act',             'hbm',  False, 'backbone glue: shift + shortcut + activation stream'),
+    ('k3_upadd',             'mfma', False, 'backbone: 1x1 lateral convolution with the FPN upsample + add as its epilogue (K3 tile engine)'),
     ('conv3x3',              'mfma', False, 'K10 3x3 convolution of the backbone (BN shift + shortcut + activation in the epilogue; SURVEY 8f rank 4)'),
 ]
 
@@ -58,12 +65,16 @@ def parse_args(argv=None):
     ap.add_argument('--batch', type=int, default=8, help='pairs per GPU per step')
     ap.add_argument('--size', type=int, default=640)
     ap.add_argument('--precision', default='fp16', choices=['fp16', 'bf16', 'fp32'])
-    ap.add_argument('--pairs', default='homography', choices=['homography', 'shift', 'planted'],
-                    help="image1 = image0 under a random homography (default), or shifted by one coarse cell (the pair of "
-                         "the reference's CPU measurement, BASELINE.md section 2), or 'planted': the nominal-load workload of the "
-                         "side measurement as the main one (planted-correspondence feature maps, thresholds 0.2 / 0.1)")
-    ap.add_argument('--coarse-thr', type=float, default=0.0)
-    ap.add_argument('--fine-thr', type=float, default=0.0)
+    ap.add_argument('--pairs', default='planted', choices=['planted', 'homography', 'shift'],
+                    help="'planted' (default): the nominal-load workload - backbone on the images, matching path on "
+                         "planted-correspondence feature maps, the reference's thresholds 0.2 / 0.1; 'homography': image1 = image0 "
+                         "under a random homography, thresholds 0 (light load: random-init weights give few matches); 'shift': "
+                         "shifted by one coarse cell (the pair of the reference's CPU measurement, BASELINE.md section 2)")
+    ap.add_argument('--coarse-thr', type=float, default=None, help='default: 0.2 with --pairs planted (geo_config.py:13), else 0')
+    ap.add_argument('--fine-thr', type=float, default=None, help='default: 0.1 with --pairs planted (geo_config.py:15), else 0')
+    ap.add_argument('--pmc-file', default=None,
+                    help='per-tag PMC summary (tools/pmc_roofline.py --tags) whose HBM traffic / MFMA utilisation are attached to the '
+                         'roofline entries; default: the newest profiles/r*_pmc_per_tag.json recorded for this configuration')
     ap.add_argument('--streams', type=int, default=2, help='concurrent forward pipelines (host threads, one HIP stream each)')
     ap.add_argument('--tune', action='store_true', help='let MIOpen search its convolution algorithms (minutes)')
     ap.add_argument('--save-db', action='store_true', help='with --tune: copy the searched find-db over geoformer_amd/miopen_db')
@@ -80,26 +91,59 @@ def parse_args(argv=None):
 # ---------------------------------------------------------------------------------------------------------------
 def spawn_ranks(args, argv):
     """Starts N fresh child processes of this script (one per GPU) and relays rank 0's JSON line.  Nothing in this
-    parent initialises the GPU.  Returns the exit code: 0 only if every rank exited 0 and the line says n_gpus == N."""
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port), GEOFORMER_BENCH_CHILD='1')
-        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0)
+    parent initialises the GPU.  All children are polled: the first non-zero exit terminates the others (a dead rank
+    would otherwise leave its siblings in the rendezvous or a barrier until the collective timeout).  The rendezvous
+    port is probed free right before the ranks start and the launch is retried once on another port if rank 0 reports
+    it taken.  Returns the exit code: 0 only if every rank exited 0 and the line says n_gpus == N."""
+    import tempfile
+    for attempt in range(2):
+        with socket.socket() as s:
+            s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        procs, errs = [], []
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
+                       MASTER_PORT=str(port), GEOFORMER_BENCH_CHILD='1')
+            env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+            err = tempfile.TemporaryFile() if r else None                # ranks > 0: stdout dropped, stderr kept for the report
+            errs.append(err)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=err))
+        import threading
+        out0 = []
+        reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
+        failed = None
+        while any(p.poll() is None for p in procs):
+            for r, p in enumerate(procs):
+                if p.poll() not in (None, 0) and failed is None:
+                    failed = r
+                    for q in procs:
+                        if q.poll() is None:
+                            q.terminate()
+            time.sleep(0.05)
+        reader.join(timeout=10)
+        text = (out0[0] if out0 else b'').decode()
+        codes = [p.returncode for p in procs]
+        tails = ''
+        for r, err in enumerate(errs):
+            if err is not None:
+                err.seek(0)
+                t = err.read().decode(errors='replace')
+                if codes[r]:
+                    tails += f'--- rank {r} stderr tail ---\n' + t[-1500:] + '\n'
+                err.close()
+        if failed is not None and attempt == 0 and ('EADDRINUSE' in tails or 'address already in use' in tails.lower()):
+            continue                                                      # someone took the port between probe and bind
+        break
+    sys.stdout.write(text)
     sys.stdout.flush()
     if any(codes):
-        print(f'bench.py: ranks exited with {codes}', file=sys.stderr)
+        print(f'bench.py: ranks exited with {codes} (first failure: rank {failed})\n{tails}', file=sys.stderr)
         return 1
     try:
-        line = json.loads([ln for ln in out0.splitlines() if ln.startswith('{')][-1])
+        line = json.loads([ln for ln in text.splitlines() if ln.startswith('{')][-1])
     except (IndexError, ValueError):
         print('bench.py: rank 0 printed no JSON line', file=sys.stderr)
         return 1
@@ -124,8 +168,11 @@ def dry_run(args):
     import torch.distributed as dist
     from geoformer_amd.shard import shard_bounds
     rank, _, world = dist_env(args)
+    if os.environ.get('GEOFORMER_BENCH_FAIL_RANK') == str(rank):          # launcher test: a rank that dies before the rendezvous
+        raise SystemExit(3)
     if world > 1:
-        dist.init_process_group('gloo', rank=rank, world_size=world)
+        import datetime
+        dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     total = args.steps * args.batch * world
     lo, hi = shard_bounds(total, world, rank)
     if world > 1:
@@ -365,6 +412,52 @@ def measure(model, batches, steps, warmup, nstreams, dev, dist, log, profile_tag
     return time.perf_counter() - t0, pipes, step
 
 
+def load_pmc(path, run_cfg):
+    """Per-tag PMC figures (HBM bytes per launch, MFMA utilisation) from a COMMITTED rocprofv3 --pmc run
+    (tools/gpu_profile.sh + tools/pmc_roofline.py): they are not measured by the run that prints the line, so every entry
+    that carries them names the file in `traffic_source`, and a file recorded for another configuration (precision,
+    batch, size, pairs, thresholds: its `_config` block) is not attached at all."""
+    import glob
+    import re
+    cands = [path] if path else sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_per_tag.json')),
+                                       key=lambda f: [int(t) if t.isdigit() else t for t in re.split(r'(\d+)', os.path.basename(f))],
+                                       reverse=True)
+    for f in cands:
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        cfg = d.get('_config')
+        if cfg is None or any(cfg.get(k) != v for k, v in run_cfg.items()):
+            continue
+        src = f'{os.path.relpath(f, ROOT)} (separate rocprofv3 --pmc passes of this configuration, recorded {d.get("_recorded", "?")}; not this run)'
+        return {k: v for k, v in d.items() if not k.startswith('_')}, src
+    return {}, None
+
+
+def host_launch_us(model, batches, planted):
+    """Host time to ENQUEUE the data-independent part of one step (backbone .. second coarse matching; launch-only, no
+    host synchronisation inside) on an idle stream: what one host thread spends per step before the GPU has anything to
+    wait for.  With --graphs it is the cost of one replay."""
+    import torch
+    i0, i1 = batches[0]
+    ts = []
+    with torch.no_grad():
+        for _ in range(4):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            if getattr(model, '_graphs', None) is not None and planted is None:
+                model({'image0': i0, 'image1': i1})              # replay + the dynamic tail (two host syncs)
+            elif planted is None:
+                model.forward_static({'image0': i0, 'image1': i1})
+            else:
+                model._backbone(torch.cat([i0, i1], dim=0))
+                model.forward_features({'image0': i0, 'image1': i1}, *planted[0], static_only=True)
+            ts.append(time.perf_counter() - t)
+    torch.cuda.synchronize()
+    return 1e6 * min(ts[1:])
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else list(argv)
     args = parse_args(argv)
@@ -384,7 +477,8 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        import datetime
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local), timeout=datetime.timedelta(seconds=600))
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     torch.backends.cudnn.benchmark = args.tune
@@ -396,8 +490,10 @@ def main(argv=None):
     def log(msg):
         if rank == 0:
             print(f'[bench +{time.perf_counter() - tlog:6.1f}s] {msg}', file=sys.stderr, flush=True)
-    if args.pairs == 'planted' and args.coarse_thr == 0.0 and args.fine_thr == 0.0:
-        args.coarse_thr, args.fine_thr = 0.2, 0.1          # the reference's thresholds (geo_config.py:13,15)
+    if args.coarse_thr is None:
+        args.coarse_thr = 0.2 if args.pairs == 'planted' else 0.0          # the reference's threshold (geo_config.py:13)
+    if args.fine_thr is None:
+        args.fine_thr = 0.1 if args.pairs == 'planted' else 0.0            # geo_config.py:15
     model, W = build_model(args.precision, args.coarse_thr, args.fine_thr, dev)
     if args.graphs:
         model.enable_graphs()
@@ -462,6 +558,7 @@ def main(argv=None):
     torch.cuda.synchronize()
     solo = {tag: collect(tag) for tag, _, _, _ in ROOFLINE_TAGS}
     L.gf_profile_enable(0)
+    host_us = host_launch_us(model, batches, planted)
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -482,28 +579,29 @@ def main(argv=None):
     algo_bytes = args.batch * (2 * Lc * 256 * e + Lc * Lc * 4)     # per k1_conf launch (170.4 MB/pair-call at e=2)
     if solo['k1_conf'][1]:
         assert abs(solo['k1_conf'][2] / solo['k1_conf'][1] - algo_bytes) < 1.0
-    pmc = {}
-    pmc_file = os.path.join(ROOT, 'profiles', 'r02_pmc_per_tag.json')
-    if os.path.exists(pmc_file):
-        try:
-            pmc = json.load(open(pmc_file))
-        except Exception:
-            pmc = {}
+    run_cfg = {'precision': args.precision, 'batch': args.batch, 'size': args.size, 'pairs': args.pairs,
+               'coarse_thr': args.coarse_thr, 'fine_thr': args.fine_thr}
+    pmc, pmc_src = load_pmc(args.pmc_file, run_cfg)
     entries = []
+    K = int(nidx[:, 0].float().mean()) if nidx is not None else None
     for tag, bound, hot, what in ROOFLINE_TAGS:
         tot_ms, cnt, work = solo[tag]
         if cnt == 0 or tot_ms <= 0:
             continue
+        if tag == 'k4_self_attention':            # key counts are device-side: 4 L K C flops per image, 2 images per pair
+            work = cnt * 4.0 * (2 * args.batch) * Lc * (K or 0) * 256
         peak = HBM_PEAK_GBPS if bound == 'hbm' else MFMA_PEAK_TFLOPS[args.precision]
         ach = work / (tot_ms * 1e-3) / (1e9 if bound == 'hbm' else 1e12)
         p = pmc.get(tag, {})
         entries.append({'kernel': f'{tag}: {what}', 'tag': tag, 'bound': bound, 'hot_path': hot, 'achieved': ach, 'peak': peak,
                         'unit': 'GB/s' if bound == 'hbm' else 'TFLOP/s', 'frac': ach / peak,
                         'traffic': p.get('hbm_bytes_per_launch'), 'mfma_util_pmc': p.get('mfma_util'),
+                        'traffic_source': pmc_src if p else None,
                         'launches': cnt, 'launches_per_step': cnt / replay_steps, 'avg_launch_ms': tot_ms / cnt,
                         'total_ms_per_step': tot_ms / replay_steps,
                         ('algorithmic_bytes_per_launch' if bound == 'hbm' else 'algorithmic_flops_per_launch'): work / cnt})
-    hot_entries = [x for x in entries if x['hot_path']]
+    # the dominant kernel = the hot-path tag with the largest time per step (k1_unit spans k1_stats + k1_conf: not a kernel)
+    hot_entries = [x for x in entries if x['hot_path'] and x['tag'] != 'k1_unit']
     dominant = dict(max(hot_entries, key=lambda x: x['total_ms_per_step'])) if hot_entries else {}
     dominant['measured'] = ('HIP events on the launch stream; single-stream replay of the timed steps (equals the kernel '
                             'durations of a --streams 1 rocprofv3 trace, profiles/)')
@@ -511,7 +609,6 @@ def main(argv=None):
         for x in entries:
             if x['tag'] == 'k1_conf':
                 x['avg_launch_ms_in_timed_region'] = timed_conf[0] / timed_conf[1]
-    K = int(nidx[:, 0].float().mean()) if nidx is not None else None
     tot_M, tot_Mf, tot_steps = (sum(r[k] for r in rows) for k in range(3))
     res = {
         'metric': 'image-pairs/sec (640x640)', 'value': pairs / elapsed, 'unit': 'image-pairs/s',
@@ -519,13 +616,16 @@ def main(argv=None):
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': {'fp16': 'f16', 'bf16': 'bf16', 'fp32': 'f32'}[args.precision], 'data': 'synthetic',
         'config': {'workload': f'batched inference, synthetic {args.size}x{args.size} pairs (BASELINE configs[4]: static shard of the '
-                               f'pair list, {args.steps * args.batch} pairs per GPU), image1 = {args.pairs} of image0, full forward '
-                               f'incl. ResNet-FPN backbone; closed-form random-init weights; coarse_thr={args.coarse_thr} '
-                               f'fine_thr={args.fine_thr}',
+                               f'pair list, {args.steps * args.batch} pairs per GPU), ' +
+                               ('NOMINAL LOAD: ResNet-FPN backbone on the images, matching path on planted-correspondence feature maps '
+                                '(image-1 maps = image-0 maps shifted by one coarse cell + noise)' if args.pairs == 'planted' else
+                                f'image1 = {args.pairs} of image0, full forward incl. ResNet-FPN backbone') +
+                               f'; closed-form random-init weights; coarse_thr={args.coarse_thr} fine_thr={args.fine_thr}',
                    'pairs_per_gpu_per_step': args.batch, 'global_pairs_per_step': args.batch * world,
                    'coarse_matches_per_pair': tot_M / tot_steps / args.batch, 'fine_matches_per_pair': tot_Mf / tot_steps / args.batch,
                    'inlier_cells_per_pair': K, 'parallelism': f'pair-shard x{world} (no collective)',
-                   'host_pipelines_per_gpu': nstreams},
+                   'host_pipelines_per_gpu': nstreams, 'hip_graphs': bool(args.graphs), **run_cfg},
+        'host_launch_us_per_step': host_us,
         'roofline': dominant,
         'roofline_kernels': entries,
     }
@@ -542,46 +642,98 @@ def main(argv=None):
 
 
 def side_measurements(args, model, dev, log, L):
-    """Two more throughput figures of the same job, N = 1 only (they are not `value`):
-      nominal_load   the load SURVEY section 8 sizes the path for (M ~ 2000 coarse matches, K ~ 1000+ inlier cells per pair at
-                     the reference's thresholds), where K4 / K7 / K8 / loftr_fine carry real work: random-init weights
-                     cannot produce it from images, so the matching path is fed planted-correspondence feature maps
-                     while the backbone still runs on the images;
-      parity_mode    the fp32 mode in which coarse indices are bit-exact against the reference's golden vectors."""
+    """More throughput figures of the same job, N = 1 only (they are not `value`):
+      matching_path_only  the hot path alone: `forward_features` on resident planted-correspondence feature maps (no
+                          backbone in the step) at the nominal load - what the HIP kernels of SURVEY section 8(a) take;
+      light_load          (when `value` is the nominal load) the full forward on homography image pairs with thresholds 0:
+                          random-init weights give M ~ 360 matches and K ~ 60 inlier cells per pair (rounds 1-2's headline);
+      nominal_load        (when `value` is NOT the nominal load) backbone on the images + matching path on planted maps,
+                          thresholds 0.2 / 0.1;
+      parity_mode         the fp32 mode in which coarse indices are bit-exact against the reference's golden vectors."""
     import torch
     out = {}
     steps = max(4, min(args.steps, 100))
-    mn, _ = build_model(args.precision, 0.2, 0.1, dev)                  # the reference's thresholds (geo_config.py:13,15)
-    imgs = [synth_pairs(args.batch, seed=50000 + i * args.batch, size=args.size, device=dev, kind='shift') for i in range(2)]
+    dt = {'fp16': 'f16', 'bf16': 'bf16', 'fp32': 'f32'}[args.precision]
+
+    def summary(el, p, nsteps, nwarm, what):
+        rr = [p.results[i] for i in range(nwarm, nwarm + nsteps)]
+        nidx = rr[-1][2]
+        return {'value': nsteps * args.batch / el, 'unit': 'image-pairs/s', 'steps': nsteps, 'ms_per_step': 1e3 * el / nsteps,
+                'pairs': what, 'dtype': dt, 'coarse_matches_per_pair': sum(r[0] for r in rr) / len(rr) / args.batch,
+                'fine_matches_per_pair': sum(r[1] for r in rr) / len(rr) / args.batch,
+                'inlier_cells_per_pair': int(nidx[:, 0].float().mean()) if nidx is not None else None}
+    nominal = args.pairs == 'planted'
+    mn = model if nominal else build_model(args.precision, 0.2, 0.1, dev)[0]       # the reference's thresholds (geo_config.py:13,15)
     feats = [planted_features(args.batch, 60000 + i, args.size // 8, device=dev, dtype=mn.compute_dtype) for i in range(2)]
-    el, p, _ = measure(mn, imgs, steps, 3, args.streams, dev, None, log, planted=feats)
-    rr = [p.results[i] for i in range(3, 3 + steps)]
+    zero = torch.zeros(args.batch, 1, args.size, args.size, device=dev)
+
+    def feat_step(i):
+        with torch.no_grad():
+            return mn.forward_features({'image0': zero, 'image1': zero}, *feats[i % 2])
+    el, p = measure_fn(feat_step, steps, 3, args.streams, dev)
+    out['matching_path_only'] = summary(el, p, steps, 3, 'matching path only (forward_features on resident planted-correspondence '
+                                        'feature maps: no backbone in the step), coarse_thr 0.2, fine_thr 0.1')
     p.close()
-    nidx = rr[-1][2]
-    out['nominal_load'] = {'value': steps * args.batch / el, 'unit': 'image-pairs/s', 'steps': steps, 'ms_per_step': 1e3 * el / steps,
-                           'pairs': 'backbone on the images + matching path on planted-correspondence feature maps (shift by one '
-                                    'coarse cell + noise), coarse_thr 0.2, fine_thr 0.1',
-                           'dtype': {'fp16': 'f16', 'bf16': 'bf16', 'fp32': 'f32'}[args.precision],
-                           'coarse_matches_per_pair': sum(r[0] for r in rr) / len(rr) / args.batch,
-                           'fine_matches_per_pair': sum(r[1] for r in rr) / len(rr) / args.batch,
-                           'inlier_cells_per_pair': int(nidx[:, 0].float().mean()) if nidx is not None else None}
-    del mn, feats
+    log(f"matching path only: {out['matching_path_only']['value']:.1f} pairs/s ({out['matching_path_only']['ms_per_step']:.2f} ms per "
+        f"{args.batch} pairs) at M = {out['matching_path_only']['coarse_matches_per_pair']:.0f}")
+    if nominal:
+        ml, _ = build_model(args.precision, 0.0, 0.0, dev)
+        if args.graphs:
+            ml.enable_graphs()
+        homo = [synth_pairs(args.batch, seed=i * args.batch, size=args.size, device=dev, kind='homography') for i in range(2)]
+        el, p, _ = measure(ml, homo, steps, 3, args.streams, dev, None, log)
+        out['light_load'] = summary(el, p, steps, 3, 'full forward incl. backbone on homography image pairs, thresholds 0 (random-init '
+                                    'weights: few matches; the headline workload of rounds 1-2)')
+        p.close()
+        del ml, homo
+        log(f"light load: {out['light_load']['value']:.1f} pairs/s at M = {out['light_load']['coarse_matches_per_pair']:.0f}")
+    else:
+        imgs = [synth_pairs(args.batch, seed=50000 + i * args.batch, size=args.size, device=dev, kind='shift') for i in range(2)]
+        el, p, _ = measure(mn, imgs, steps, 3, args.streams, dev, None, log, planted=feats)
+        out['nominal_load'] = summary(el, p, steps, 3, 'backbone on the images + matching path on planted-correspondence feature maps '
+                                      '(shift by one coarse cell + noise), coarse_thr 0.2, fine_thr 0.1')
+        p.close()
+        log(f"nominal load: {out['nominal_load']['value']:.1f} pairs/s at M = {out['nominal_load']['coarse_matches_per_pair']:.0f}, "
+            f"K = {out['nominal_load']['inlier_cells_per_pair']}")
+        del imgs
+    del feats
+    if not nominal:
+        del mn
     torch.cuda.empty_cache()
-    log(f"nominal load: {out['nominal_load']['value']:.1f} pairs/s at M = {out['nominal_load']['coarse_matches_per_pair']:.0f}, "
-        f"K = {out['nominal_load']['inlier_cells_per_pair']}")
     if args.precision != 'fp32':
         m32, _ = build_model('fp32', args.coarse_thr, args.fine_thr, dev)
-        homo = [synth_pairs(args.batch, seed=i * args.batch, size=args.size, device=dev, kind=args.pairs) for i in range(2)]
         s32 = max(4, min(args.steps, 10))
-        el, p, _ = measure(m32, homo, s32, 2, 1, dev, None, log)
+        if nominal:
+            imgs = [synth_pairs(args.batch, seed=i * args.batch, size=args.size, device=dev, kind='shift') for i in range(2)]
+            f32 = [planted_features(args.batch, 60000 + i, args.size // 8, device=dev, dtype=torch.float32) for i in range(2)]
+            el, p, _ = measure(m32, imgs, s32, 2, 1, dev, None, log, planted=f32)
+        else:
+            imgs = [synth_pairs(args.batch, seed=i * args.batch, size=args.size, device=dev, kind=args.pairs) for i in range(2)]
+            el, p, _ = measure(m32, imgs, s32, 2, 1, dev, None, log)
         p.close()
         out['parity_mode'] = {'value': s32 * args.batch / el, 'unit': 'image-pairs/s', 'steps': s32, 'ms_per_step': 1e3 * el / s32,
-                              'dtype': 'f32', 'note': 'fp32 storage and exact-fp32 MFMA (v_mfma_f32_32x32x2_f32); unfused fp32 backbone, '
-                                                      'MIOpen immediate mode'}
+                              'dtype': 'f32', 'note': 'the same workload in fp32 storage with exact-fp32 MFMA (v_mfma_f32_32x32x2_f32); '
+                                                      'unfused fp32 backbone, MIOpen immediate mode'}
         del m32
         torch.cuda.empty_cache()
         log(f"parity mode (fp32): {out['parity_mode']['value']:.1f} pairs/s")
     return out
+
+
+def measure_fn(step, steps, warmup, nstreams, dev):
+    """`measure` for an arbitrary step function (side measurements): warm-up, then `steps` timed steps on the pipelines."""
+    import torch
+    pipes = Pipelines(step, max(1, min(nstreams, steps)), dev)
+    step(0)
+    torch.cuda.synchronize()
+    for w in range(pipes.n):
+        pipes.run_single(w, w)
+    pipes.run(0, warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pipes.run(warmup, steps)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, pipes
 
 
 if __name__ == '__main__':

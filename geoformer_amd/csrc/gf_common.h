@@ -47,6 +47,17 @@ void gf_prof_end(const char* tag, void* token, hipStream_t st);
 
 static inline size_t gf_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device only: launch sites that opt a kernel into
+// > 64 KiB of LDS do it once per device, not once per process (a process may run the model on cuda:0 and later on cuda:1;
+// the bench's pipeline threads race here, hence the atomic).  Returns true exactly once per (flag word, device).
+#include <atomic>
+static inline bool gf_first_use_on_device(std::atomic<uint64_t>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;      // unknown device: set the attribute again
+    const uint64_t bit = 1ull << dev;
+    return (done.fetch_or(bit, std::memory_order_acq_rel) & bit) == 0;
+}
+
 // carve helper for caller-provided workspaces
 struct GfCarver {
     char* base;

@@ -419,11 +419,9 @@ namespace {
 template <typename T, int CIN, int COUT, int NW>
 int conv_launch(ConvArgs a, hipStream_t st) {
     using G = ConvGeo<COUT / 32, NW>;
-    static bool attr = false;
-    if (!attr) {
+    static std::atomic<uint64_t> attr{0};
+    if (gf_first_use_on_device(attr))
         (void)hipFuncSetAttribute((const void*)conv3x3_kernel<T, CIN, COUT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-        attr = true;
-    }
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + G::TH - 1) / G::TH;
     const long nt = (long)a.N * a.tiles_x * a.tiles_y;
@@ -473,7 +471,10 @@ extern "C" int gf_conv3x3_nhwc(const void* x, const void* wstream, const float* 
     GF_CHECK_ARG((long)N * H * W * (cin > cout ? cin : cout) < (1l << 31), "maps of 2^31 elements or more are not supported");
     ConvArgs a{x, wstream, shift, residual, out, zeros, N, H, W, act, slope, 0, 0, 0};
     hipStream_t st = (hipStream_t)stream;
-    void* pt = gf_prof_begin("conv3x3", st, 2.0 * N * (double)H * W * cin * cout * 9.0);
+    // declared work = the reference's convolution: a 224-wide operand is the zero-padded form of the backbone's 196-channel maps
+    // (resnet_fpn.py block_dims (128, 196, 256); model/backbone.py pads them for the matrix cores) and the padding is not work
+    const double cin_w = cin == 224 ? 196.0 : cin, cout_w = cout == 224 ? 196.0 : cout;
+    void* pt = gf_prof_begin("conv3x3", st, 2.0 * N * (double)H * W * cin_w * cout_w * 9.0);
     const int rc = dtype == GF_F16 ? conv_dispatch<_Float16>(a, cin, cout, st) : conv_dispatch<gf_bf16>(a, cin, cout, st);
     gf_prof_end("conv3x3", pt, st);
     GF_CHECK_ARG(rc == 0, "dispatch failed");

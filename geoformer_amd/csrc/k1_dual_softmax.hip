@@ -1073,6 +1073,8 @@ int k1_launch(K1Args a, SelArgs s, void* zero_begin, size_t zero_bytes, hipStrea
     const int runs = (a.tilesN + PANEL_TILES - 1) / PANEL_TILES;
     const int units = a.N * a.tilesM * runs, wgs = units < 512 ? units : 512;    // two resident workgroups per CU
     a.rowparts = panel ? runs : a.tilesN;
+    // the whole call (statistics, reduction, confidence sweep, selection, compaction) against its algorithmic bytes
+    void* pu = gf_prof_begin("k1_unit", st, (double)a.N * ((double)(a.L + a.S) * a.C * sizeof(T) + (double)a.L * a.S * 4.0));
     void* p0 = gf_prof_begin("k1_stats", st, 2.0 * a.N * (double)a.L * a.S * a.C);
     if constexpr (!EXACT) {
         if (panel) k1_stats_panel<T><<<wgs, NT, PANEL_LDS + 2048, st>>>(a);
@@ -1089,11 +1091,10 @@ int k1_launch(K1Args a, SelArgs s, void* zero_begin, size_t zero_bytes, hipStrea
         if (panel) {
             // GF_K1_CONF=panel selects the unpipelined panel form (A/B measurements, tools/k1_trace.py)
             static const bool old_form = [] { const char* e = getenv("GF_K1_CONF"); return e && e[0] == 'p'; }();
-            static bool attr = false;
-            if (!attr) {
+            static std::atomic<uint64_t> attr{0};
+            if (gf_first_use_on_device(attr)) {
                 (void)hipFuncSetAttribute((const void*)k1_conf_pipe<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS);
                 (void)hipFuncSetAttribute((const void*)k1_conf_pipe<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS);
-                attr = true;
             }
             if (old_form) {
                 if (a.dense) k1_conf_panel<T, true><<<wgs, NT, PANEL_LDS, st>>>(a);
@@ -1111,6 +1112,7 @@ int k1_launch(K1Args a, SelArgs s, void* zero_begin, size_t zero_bytes, hipStrea
     k1_select<<<dim3((a.L + 255) / 256, a.N), 256, 0, st>>>(s);
     k1_rescan<<<256, 256, 0, st>>>(s);
     k1_compact<<<dim3(s.chunks, a.N), 1024, 0, st>>>(s);
+    gf_prof_end("k1_unit", pu, st);
     GF_CHECK_LAUNCH();
     return GF_OK;
 }

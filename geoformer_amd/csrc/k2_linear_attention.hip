@@ -575,11 +575,9 @@ int la_launch(const LaArgs& a, hipStream_t st) {
     if constexpr (!std::is_same<T, float>::value && D == 16) {
         if (a.C == 128 && a.S <= 32 && a.L <= 32 && a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 &&
             (uintptr_t)a.q % 16 == 0 && (uintptr_t)a.k % 16 == 0 && (uintptr_t)a.v % 16 == 0 && (uintptr_t)a.out % 16 == 0) {
-            static bool attr = false;
-            if (!attr) {
+            static std::atomic<uint64_t> attr{0};
+            if (gf_first_use_on_device(attr))
                 (void)hipFuncSetAttribute((const void*)la_window_mfma<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LW_WAVE);
-                attr = true;
-            }
             la_window_mfma<T><<<(a.N + 1) / 2, 128, 2 * LW_WAVE, st>>>(a);
             GF_CHECK_LAUNCH();
             return GF_OK;

@@ -515,12 +515,12 @@ extern "C" int gf_conv1x1_upsample_add_nhwc(const void* x, const void* w, const 
     a.up_ry = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
     a.up_rx = W > 1 ? (float)(wl - 1) / (float)(W - 1) : 0.f;
     hipStream_t st = (hipStream_t)stream;
-    void* pt = gf_prof_begin("k3_linear", st, 2.0 * (double)a.M * Cout * Cin);
+    void* pt = gf_prof_begin("k3_upadd", st, 2.0 * (double)a.M * Cout * Cin);      // backbone (f4), not the matching path: own tag
     // 128-wide column tiles (152 registers, three waves per SIMD): with K = 128 the kernel is all epilogue, and
     // a single 224-wide tile (NB = 7, two waves per SIMD) measured slower (607 vs 529 us) despite reading x once
     if (dtype == GF_F16) lin_launch1<_Float16, 4, EPI_UPADD>(a, st);
     else lin_launch1<gf_bf16, 4, EPI_UPADD>(a, st);
-    gf_prof_end("k3_linear", pt, st);
+    gf_prof_end("k3_upadd", pt, st);
     GF_CHECK_LAUNCH();
     return GF_OK;
 }

@@ -274,9 +274,12 @@ extern "C" int gf_self_attention_gathered(const void* q, const void* kmap, const
         else if (qb == 2) attn_self<T, 2><<<agrid, 256, 2 * KT * CC * ES, st>>>(a);                \
         else attn_self<T, 1><<<agrid, 256, 2 * KT * CC * ES, st>>>(a);                             \
     } while (0)
+    // the key counts live on the device: the caller that knows them (bench.py reads them back) declares the work, 4 L K C flops per sample
+    void* pt = gf_prof_begin("k4_self_attention", st, 0.0);
     if (dtype == GF_F32) GF_K4_LAUNCH(float, 4);
     else if (dtype == GF_F16) GF_K4_LAUNCH(_Float16, 2);
     else GF_K4_LAUNCH(gf_bf16, 2);
+    gf_prof_end("k4_self_attention", pt, st);
 #undef GF_K4_LAUNCH
     GF_CHECK_LAUNCH();
     return GF_OK;

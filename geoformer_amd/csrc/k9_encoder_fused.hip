@@ -657,18 +657,17 @@ int enc_launch(const EncArgs& a, int act, bool attn, hipStream_t st) {
     return 0;
 }
 
-bool enc_attr_done = false;
+std::atomic<uint64_t> enc_attr_done{0};
 template <typename K>
 void enc_allow_lds(K kern) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); }
 void enc_init() {
-    if (enc_attr_done) return;
+    if (!gf_first_use_on_device(enc_attr_done)) return;
     enc_allow_lds(enc_layer<_Float16, 0, true>); enc_allow_lds(enc_layer<_Float16, 1, true>);
     enc_allow_lds(enc_layer<_Float16, 0, false>); enc_allow_lds(enc_layer<_Float16, 1, false>);
     enc_allow_lds(enc_kv_state<_Float16>);
     enc_allow_lds(enc_layer<gf_bf16, 0, true>); enc_allow_lds(enc_layer<gf_bf16, 1, true>);
     enc_allow_lds(enc_layer<gf_bf16, 0, false>); enc_allow_lds(enc_layer<gf_bf16, 1, false>);
     enc_allow_lds(enc_kv_state<gf_bf16>);
-    enc_attr_done = true;
 }
 
 }   // namespace

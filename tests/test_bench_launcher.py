@@ -36,3 +36,24 @@ def test_gpus_must_match_world_size():
     assert r.returncode != 0 and 'WORLD_SIZE=2' in (r.stderr + r.stdout)
     r = _run(['--gpus', '1', '--dry-run'], env={'RANK': '0', 'LOCAL_RANK': '0', 'WORLD_SIZE': '2'})
     assert r.returncode != 0
+
+
+def test_gpus_8_starts_eight_ranks():
+    """The 8-GPU node's launch shape (BASELINE configs[4]: 1024 pairs, 128 per GPU), without GPUs: eight ranks over gloo."""
+    r = _run(['--gpus', '8', '--dry-run', '--steps', '16', '--batch', '8'])
+    assert r.returncode == 0, r.stderr
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 8 and line['scaling'] == 'weak'
+    plan = sorted(map(tuple, line['shard_plan']))
+    assert plan == [(k, 128 * k, 128 * (k + 1)) for k in range(8)]                  # 1024 pairs, contiguous blocks of 128
+    assert line['elapsed_max_s'] >= 0.08                                             # rank 7's time won the MAX
+
+
+def test_a_dead_rank_ends_the_launch_quickly():
+    """one rank dying before the rendezvous must not leave its siblings waiting for the collective timeout -
+    the launcher polls every child, terminates the rest and reports which rank failed."""
+    import time
+    t = time.time()
+    r = _run(['--gpus', '4', '--dry-run', '--steps', '2'], env={'GEOFORMER_BENCH_FAIL_RANK': '2'})
+    assert r.returncode != 0 and 'first failure: rank 2' in r.stderr, r.stderr
+    assert time.time() - t < 60

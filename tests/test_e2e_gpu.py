@@ -116,7 +116,9 @@ def test_device_ransac_vs_oracle():
 # (oracle confidences 0.1962 .. 0.2014).
 KNIFE_EDGE = 3e-2
 # measured knife-edge counts + 3 (the counts are printed into the test log; DESIGN 4 quotes them)
-MAX_KNIFE = {'640': 10, 'hpatches': 10, 'bench8': 60, 'bench8_dense': 40}
+# measured on MI355X (round 3): 640: 7 of 1206; hpatches-shaped: 6 of 1112; bench shape, thresholds 0.2 / 0.1: 36 of 10049 over
+# the eight slots (1 .. 8 per slot); bench shape, thresholds 0 / 0: 0 of 18693 over three slots
+MAX_KNIFE = {'640': 10, 'hpatches': 9, 'bench8': 39, 'bench8_slot': 11, 'bench8_dense': 3, 'bench8_dense_slot': 3}
 FINE_EDGE = 5e-2          # the same for the fine threshold: the 25x25 matrices carry two more fp16 layers
 
 
@@ -298,6 +300,7 @@ def test_bench_shape_batch8_vs_storage_oracle(mode):
     W = O.make_weights()
     ob, fb = out['b_ids'].cpu(), out['m_bids'].cpu()
     total = knife = 0
+    key = 'bench8' if mode == 'nominal' else 'bench8_dense'
     for b in (range(8) if mode == 'nominal' else (0, 3, 7)):
         one = {'image0': data['image0'][b:b + 1], 'image1': data['image1'][b:b + 1]}
         ref = O.geoformer_forward_storage(W, one, st, None, geo_cfg, RO.make_homography_fn(),
@@ -309,8 +312,7 @@ def test_bench_shape_batch8_vs_storage_oracle(mode):
         sub['m_bids'] = out['m_bids'][fsel.to(out['m_bids'].device)] * 0
         sub['conf_matrix'] = out['conf_matrix'][b:b + 1]
         total += len(ref['b_ids'])
-        knife += compare_with_storage_oracle(sub, ref, thr, f'bench-shape {mode} slot {b}', max_knife=12, fine_thr=fthr)
-    key = 'bench8' if mode == 'nominal' else 'bench8_dense'
+        knife += compare_with_storage_oracle(sub, ref, thr, f'bench-shape {mode} slot {b}', max_knife=MAX_KNIFE[key + '_slot'], fine_thr=fthr)
     print(f'bench-shape {mode}: {total} coarse matches over the checked slots, {knife} knife-edge differences (bound {MAX_KNIFE[key]})')
     assert knife <= MAX_KNIFE[key] and total > (8 if mode == 'nominal' else 3) * 1000
 

@@ -61,16 +61,21 @@ def family(name):
 TAG_FAMILIES = {
     'enc_layer': ['enc_layer<'],
     'enc_kv_state': ['enc_kv_state<', 'enc_kv_reduce'],
-    'k3_linear': ['linear_kernel'],
+    'k3_linear': ['linear_kernel'],              # minus TAG_EXCLUDE: the EPI_UPADD instance belongs to the backbone
+    'k3_upadd': [', 4, 5>'],                      # linear_kernel<T, 4, EPI_UPADD = 5>
     'k1_stats': ['k1_stats'],
     'k1_conf': ['k1_conf'],
+    'k1_unit': ['k1_'],
+    'fine_layer': ['fine_layer<', 'fine_kv'],
+    'k4_self_attention': ['attn_self<', 'attn_gather_kv'],
     'k2_linear_attention': ['la16_', 'la_kv_', 'la_apply', 'la_small'],
     'k5_window_attention': ['window_cross_attention'],
     'bias_act': ['bias_act<'],
     'conv3x3': ['conv3x3_kernel'],
 }
+TAG_EXCLUDE = {'k3_linear': [', 4, 5>']}
 # the family whose call count equals the number of tagged calls
-TAG_PRIMARY = {'enc_layer': 'enc_layer<', 'enc_kv_state': 'enc_kv_state<', 'k3_linear': 'linear_kernel', 'k1_stats': 'k1_stats',
+TAG_PRIMARY = {'k1_unit': 'k1_compact', 'fine_layer': 'fine_layer<', 'k4_self_attention': 'attn_self<', 'enc_layer': 'enc_layer<', 'enc_kv_state': 'enc_kv_state<', 'k3_linear': 'linear_kernel', 'k3_upadd': ', 4, 5>', 'k1_stats': 'k1_stats',
                'k1_conf': 'k1_conf', 'k2_linear_attention': ('la16_apply', 'la_apply', 'la_small'), 'k5_window_attention': 'window_cross_attention',
                'bias_act': 'bias_act<', 'conv3x3': 'conv3x3_kernel'}
 
@@ -131,7 +136,7 @@ def main():
     print()
     print(f'{"tag":22s} {"calls":>6s} {"avg_us":>8s} {"HBM MB/call":>12s} {"GB/s":>7s} {"mfma_util":>9s}')
     for tag, pats in TAG_FAMILIES.items():
-        fam = [r for r in rows if any(p in r['kernel'] for p in pats)]
+        fam = [r for r in rows if any(p in r['kernel'] for p in pats) and not any(x in r['kernel'] for x in TAG_EXCLUDE.get(tag, []))]
         if not fam:
             continue
         prim = TAG_PRIMARY[tag]
@@ -149,6 +154,17 @@ def main():
     if '--json' in sys.argv:
         json.dump(rows, open(sys.argv[sys.argv.index('--json') + 1], 'w'), indent=1)
     if '--tags' in sys.argv:
+        # the configuration these counters were recorded for = the bench line the traced run printed (bench.py attaches
+        # the figures only to runs of the same configuration and names this file as their source)
+        try:
+            import datetime
+            line = [ln for ln in open(os.path.join(root, tag + '_trace.json')).read().splitlines() if ln.startswith('{')][-1]
+            cfg = json.loads(line)['config']
+            per_tag['_config'] = {k: cfg.get(k) for k in ('precision', 'batch', 'size', 'pairs', 'coarse_thr', 'fine_thr')}
+            per_tag['_recorded'] = datetime.date.today().isoformat()
+        except Exception as e:                      # noqa: BLE001
+            per_tag['_config'] = None
+            print('no bench line for the _config block:', e)
         json.dump(per_tag, open(sys.argv[sys.argv.index('--tags') + 1], 'w'), indent=1)
 
 
