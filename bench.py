@@ -259,10 +259,17 @@ def cpu_baseline(W, coarse_thr, fine_thr, size, kind, seconds_budget=25.0):
     cfg.update(coarse_thr=coarse_thr, fine_thr=fine_thr)
 
     def one(seed, sz):
-        i0, i1 = synth_pairs(1, seed, sz, kind=kind)
+        planted = kind == 'planted'
+        i0, i1 = synth_pairs(1, seed, sz, kind='shift' if planted else kind)
+        feats = None
+        if planted:          # the same workload as the GPU step: backbone on the images, matching path on planted maps
+            c0, f0, c1, f1 = (t.float().contiguous() for t in planted_features(1, 60000 + seed, sz // 8))
+            feats = ((c0, f0), (c1, f1))
         t = time.perf_counter()
         with torch.no_grad():
-            out = O.geoformer_forward(W, {'image0': i0, 'image1': i1}, None, cfg, RO.make_homography_fn())
+            if planted:
+                O.backbone(W, torch.cat([i0, i1], 0))
+            out = O.geoformer_forward(W, {'image0': i0, 'image1': i1}, None, cfg, RO.make_homography_fn(), None, feats)
         return time.perf_counter() - t, len(out['b_ids'])
     one(999, 160)                                    # warm the thread pool / allocator on a small pair
     t0, ts, M = time.perf_counter(), [], 0
@@ -271,8 +278,8 @@ def cpu_baseline(W, coarse_thr, fine_thr, size, kind, seconds_budget=25.0):
         ts.append(dt)
     per_pair = sum(ts) / len(ts)
     return {'value': 1.0 / per_pair, 'unit': 'image-pairs/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{len(ts)} synthetic {size}x{size} pairs, batch 1, fp32, oracle/geoformer_oracle.py (PyTorch-CPU port of '
-                      f'the reference forward incl. backbone and RANSAC), {per_pair:.2f} s/pair, M={M} on the last pair'}
+            'sample': f'{len(ts)} synthetic {size}x{size} pairs of the same workload ({kind}), batch 1, fp32, oracle/geoformer_oracle.py '
+                      f'(PyTorch-CPU port of the reference forward incl. backbone and RANSAC), {per_pair:.2f} s/pair, M={M} on the last pair'}
 
 
 class Pipelines:
@@ -633,7 +640,7 @@ def main(argv=None):
     if world == 1 and not args.no_extras:
         res['side_measurements'] = side_measurements(args, model, dev, log, L)
     if not args.no_cpu_baseline and world == 1:          # reported on rank 0 at N = 1 only
-        res['cpu_baseline'] = cpu_baseline(W, args.coarse_thr, args.fine_thr, args.size, 'shift' if args.pairs == 'planted' else args.pairs)
+        res['cpu_baseline'] = cpu_baseline(W, args.coarse_thr, args.fine_thr, args.size, args.pairs)
     print(json.dumps(res), flush=True)
     if args.tune and args.save_db:
         gf_miopen.save_find_db()             # an explicit search: keep its picks for the next process

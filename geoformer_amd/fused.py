@@ -115,6 +115,59 @@ def encoder_layer(x, wstream, ln_params, eps1, eps2, activation, msg=None, kv_st
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# K11: fused fine-level encoder layer (csrc/k11_fine_layer.hip)
+# ---------------------------------------------------------------------------------------------------------------
+def pack_fine_layer_stream(wq, wk, wv, wm, w1, w2):
+    """Stream of gf_fine_layer (d_model 128): 80 STEPS of 4 fragments (10 blocks of 32), tile-major:
+       per channel tile nb { W_k[nb]: k-steps 0-3, 4-7 ; W_v[nb]: 0-3, 4-7 }  (standard order: the other operand is the window),
+       per nb { W_q[nb]: 0-3, 4-7 } (standard), per nb { W_m[nb]: 0-3, 4-7 } (permuted: the other operand is a packed accumulator),
+       per 32-wide hidden tile hb { W_1[hb, :128]: 0-3, 4-7 (standard) ; W_1[hb, 128:]: 0-3, 4-7 (permuted) ;
+                                    W_2[tiles 0-3, k-step 2 hb] ; W_2[tiles 0-3, k-step 2 hb + 1] (permuted) }."""
+    c = wm.shape[0]
+    if c != 128 or w1.shape != (256, 256) or w2.shape != (128, 256):
+        raise ValueError('the fused fine-level layer is built for d_model = 128')
+    dev = wm.device
+    halves = [[0, 1, 2, 3], [4, 5, 6, 7]]
+    one = lambda nb: torch.tensor([nb], device=dev)                                   # noqa: E731
+    all4 = torch.arange(4, device=dev)
+    fk, fv, fq, fm = fragments(wk, 'std'), fragments(wv, 'std'), fragments(wq, 'std'), fragments(wm, 'perm')
+    parts = []
+    for nb in range(4):
+        for f in (fk, fv):
+            parts += [_steps(f, one(nb), [h]) for h in halves]
+    for f in (fq, fm):
+        for nb in range(4):
+            parts += [_steps(f, one(nb), [h]) for h in halves]
+    f1x, f1m, f2 = fragments(w1[:, :c], 'std'), fragments(w1[:, c:], 'perm'), fragments(w2, 'perm')   # [8,8] [8,8] [4,16]
+    for hb in range(8):
+        parts += [_steps(f1x, one(hb), [h]) for h in halves]
+        parts += [_steps(f1m, one(hb), [h]) for h in halves]
+        parts += [_steps(f2, all4, [[2 * hb + s]]) for s in range(2)]
+    out = torch.cat(parts).contiguous()
+    assert out.numel() == 10 * 32 * 64 * 8                      # 10 blocks of 32 fragments of 64 lanes x 8 elements
+    return out
+
+
+def fine_layer(x, src, wstream, ln_params, eps1, eps2, attn_eps=1e-6, out=None):
+    """x, src [Nw, Lw <= 32, 128] (16-bit, contiguous; src may be x) -> out [Nw, Lw, 128]: one fine-level encoder layer."""
+    _need_cuda(x, src, wstream, ln_params)
+    Nw, Lw, C = x.shape
+    if C != 128 or src.shape != x.shape or x.dtype != src.dtype:
+        raise ValueError('gf_fine_layer: x and src must be [Nw, Lw, 128] tensors of one 16-bit dtype')
+    x = _contig(x)
+    src = x if src is x else _contig(src)
+    if out is None:
+        out = torch.empty_like(x)
+    elif out.shape != x.shape or out.dtype != x.dtype or not out.is_contiguous():
+        raise ValueError('out must be a contiguous tensor of the result shape and dtype')
+    if Nw == 0:
+        return out
+    check(_lib.lib().gf_fine_layer(_p(x), _p(src), _p(out), _dt(x), Nw, Lw, _p(wstream), _p(ln_params), float(eps1), float(eps2),
+                                   float(attn_eps), _stream()), 'gf_fine_layer')
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # K10: 3x3 convolution with fused epilogue (csrc/k10_conv3x3.hip)
 # ---------------------------------------------------------------------------------------------------------------
 _ZEROS = {}

@@ -86,6 +86,11 @@ class LoFTREncoderLayer(nn.Module):
                  'w2': self.mlp[2].weight.detach().to(dtype).contiguous(),
                  'n1': (self.norm1.weight.detach().to(f32).contiguous(), self.norm1.bias.detach().to(f32).contiguous()),
                  'n2': (self.norm2.weight.detach().to(f32).contiguous(), self.norm2.bias.detach().to(f32).contiguous())}
+            if self.fusable_window(dtype, 1):
+                # K11: the fine level's layer in one launch (csrc/k11_fine_layer.hip)
+                w['ln'] = torch.cat([w['n1'][0], w['n1'][1], w['n2'][0], w['n2'][1]]).contiguous()
+                c = self.d_model
+                w['stream_fine'] = fused.pack_fine_layer_stream(w['q'], w['kv'][:c], w['kv'][c:], w['merge'], w['w1'], w['w2'])
             if self.fusable(dtype):
                 # K9: the weights as the fragment streams the fused kernels consume (fused.py), packed once
                 c = self.d_model
@@ -101,6 +106,12 @@ class LoFTREncoderLayer(nn.Module):
         """The fused two-launch form (csrc/k9_encoder_fused.hip) exists for 16-bit storage at d_model 256, with
         8 heads of 32 when the layer's own (linear) attention is part of it."""
         return dtype != torch.float32 and self.d_model == 256 and (self.attention_kind != 'linear' or self.nhead == 8)
+
+    def fusable_window(self, dtype, seq_len):
+        """The one-launch fine-level form (csrc/k11_fine_layer.hip): 16-bit storage, d_model 128, 8 heads of 16, linear
+        attention, ReLU, sequences (windows) of at most 32 tokens."""
+        return (dtype != torch.float32 and self.d_model == 128 and self.nhead == 8 and self.attention_kind == 'linear'
+                and self.activation == 'relu' and seq_len <= 32)
 
     def invalidate(self):
         self._cache = {}
@@ -134,6 +145,11 @@ class LoFTREncoderLayer(nn.Module):
         are driven by GeoTransformer, which owns the token lists / windows)."""
         if self.attention_kind != 'linear':
             raise NotImplementedError('full attention layers are driven by GeoTransformer')
+        if (x_mask is None and source_mask is None and x.shape == source.shape and self.fusable_window(x.dtype, x.shape[1])
+                and x.is_contiguous() and source.is_contiguous()):
+            # one launch: the window's tokens stay on the CU through all six GEMMs (the fine level: [M, 25, 128] windows)
+            w = self.weights(x.dtype)
+            return fused.fine_layer(x, source, w['stream_fine'], w['ln'], self.norm1.eps, self.norm2.eps, out=out)
         if self.fusable(x.dtype):
             # two launches, three token-row transfers: source -> state (k, v never reach HBM), x -> out
             w = self.weights(x.dtype)

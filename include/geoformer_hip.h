@@ -145,6 +145,21 @@ int gf_encoder_layer(const void* x, long ldx, const void* msg, long ldm, const f
                      int N, int L, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K11 one encoder layer of the fine-level transformer in ONE launch (16-bit storage modes)
+ * replaces LoFTREncoderLayer.forward (model/loftr_src/loftr/loftr_module/transformer.py:37-60) with LinearAttention.forward
+ *          (linear_attention.py:21-51) as LocalFeatureTransformer.forward (:82-104) runs it on the fine windows
+ *          (model/full_model.py:97-98: [M, W*W = 25, 128] tensors, 8 heads of 16, no masks).
+ *   out[w] = x[w] + LN2(W_2 relu(W_1 [x[w] | LN1(W_m msg[w])])),
+ *   msg[w] = phi(W_q x[w]) KV[w] / (phi(W_q x[w]) . Ksum[w] + attn_eps),  KV[w], Ksum[w] from phi(W_k src[w]), W_v src[w]
+ *   x, src, out: [Nw][Lw][128] contiguous windows of `dtype` (src may be x: the 'self' layers), Lw <= 32;
+ *   wstream = geoformer_amd/fused.py:pack_fine_layer_stream (320 KiB); ln_params = gamma1|beta1|gamma2|beta2 fp32 [4][128].
+ *   Rounding points = those of the gf_linear / gf_linear_attention chain it replaces (q, k, v, phi(q), phi(k), KV/S, Ksum/S,
+ *   the message, LN1 output, hidden activations and LN2 output rounded to the storage type; fp32 accumulation).
+ * ------------------------------------------------------------------------------------------ */
+int gf_fine_layer(const void* x, const void* src, void* out, int dtype, int Nw, int Lw, const void* wstream,
+                  const float* ln_params, float eps1, float eps2, float attn_eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * K10 3x3 / stride 1 / pad 1 convolution of channels-last 16-bit maps with a fused epilogue (backbone)
  * replaces conv3x3 + BatchNorm(eval) [+ shortcut] + ReLU / LeakyReLU of BasicBlock.forward and of the FPN heads
  *          (model/loftr_src/loftr/backbone/resnet_fpn.py:9-40, :60-83, :100-116), BatchNorm folded into the weights

@@ -135,11 +135,11 @@ def main():
     per_tag = {}
     print()
     print(f'{"tag":22s} {"calls":>6s} {"avg_us":>8s} {"HBM MB/call":>12s} {"GB/s":>7s} {"mfma_util":>9s}')
-    for tag, pats in TAG_FAMILIES.items():
-        fam = [r for r in rows if any(p in r['kernel'] for p in pats) and not any(x in r['kernel'] for x in TAG_EXCLUDE.get(tag, []))]
+    for btag, pats in TAG_FAMILIES.items():
+        fam = [r for r in rows if any(p in r['kernel'] for p in pats) and not any(x in r['kernel'] for x in TAG_EXCLUDE.get(btag, []))]
         if not fam:
             continue
-        prim = TAG_PRIMARY[tag]
+        prim = TAG_PRIMARY[btag]
         prim = prim if isinstance(prim, tuple) else (prim,)
         calls = sum(r['calls'] for r in fam if any(p in r['kernel'] for p in prim)) or 1
         t_us = sum(r['calls'] * r['avg_us'] for r in fam)
@@ -147,9 +147,9 @@ def main():
         mb = sum(r['calls'] * r.get('mfma_busy_cycles', 0.0) for r in fam)
         ga = sum(r['calls'] * r.get('gui_active', 0.0) for r in fam)
         util = mb / (ga / 8.0 * 1024.0) if ga else None
-        per_tag[tag] = {'calls': calls, 'avg_us_per_call': t_us / calls, 'hbm_bytes_per_launch': hbm / calls if hbm else None,
+        per_tag[btag] = {'calls': calls, 'avg_us_per_call': t_us / calls, 'hbm_bytes_per_launch': hbm / calls if hbm else None,
                         'mfma_util': util, 'families': sorted({r['kernel'] for r in fam})}
-        print(f'{tag:22s} {calls:6d} {t_us / calls:8.1f} {hbm / calls / 1e6:12.1f} {hbm / max(t_us, 1e-9) * 1e-3:7.0f} '
+        print(f'{btag:22s} {calls:6d} {t_us / calls:8.1f} {hbm / calls / 1e6:12.1f} {hbm / max(t_us, 1e-9) * 1e-3:7.0f} '
               f'{(util if util is not None else float("nan")):9.3f}')
     if '--json' in sys.argv:
         json.dump(rows, open(sys.argv[sys.argv.index('--json') + 1], 'w'), indent=1)
