@@ -35,6 +35,21 @@
 
 #include "gf_common.h"
 
+// -DK11_TRACE=1 records s_memtime at the phase boundaries of the first groups of every workgroup (tools/k11_trace.py); a
+// diagnostic build only.
+#ifndef K11_TRACE
+#define K11_TRACE 0
+#endif
+#if K11_TRACE
+__device__ long long k11_trace[256 * 8 * 4 * 8];                        // [workgroup][wave][group iteration < 4][slot]
+#define K11_T(slot) do { if ((ln & 63) == 0 && blockIdx.x < 256 && git < 4) k11_trace[((blockIdx.x * 8 + wave) * 4 + git) * 8 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int gf_debug_k11_trace(long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(k11_trace), sizeof(long long) * 256 * 8 * 4 * 8);
+}
+#else
+#define K11_T(slot)
+#endif
+
 namespace {
 
 constexpr int FC = 128;                           // d_model of the fine level
@@ -74,6 +89,10 @@ __device__ __forceinline__ typename Mma32<T>::Frag fl_pack_step(const v16f& a, i
 __device__ __forceinline__ float fl_phi(float x) { return fmaxf(x, 0.f) + __builtin_amdgcn_exp2f(fminf(x, 0.f) * 1.44269504088896341f); }
 template <typename T>
 __device__ __forceinline__ float fl_rnd(float x) { return gf_to_float(gf_from_float<T>(x)); }
+
+// a zero accumulator as a CONSTANT operand: the first MFMA of a chain takes C = 0 inline instead of 16 v_mov per tile
+// (44 tiles per window: 2.8 k issue cycles)
+__device__ __forceinline__ v16f fl_zero() { return v16f{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; }
 
 // the weight ring: block g (counted over the whole kernel) sits in slot g & 1 and holds stream block g % NBLK
 struct FlRing {
@@ -167,16 +186,28 @@ __global__ __launch_bounds__(512, 2) void fine_layer(FlArgs a) {
     Frag (&nxt)[4] = ((gs) & 1) ? fa : fb;                               \
     fl_fetch_next(ring, nxt, (gs) & 7)
 
+    int git = -1;
+    (void)git;
     for (int g = blockIdx.x; g < a.groups; g += gridDim.x) {
+        ++git;
         // per-lane offsets are RECOMPUTED every group from an opaque copy of the lane id: hoisted out of the loop they stay live
         // through the whole layer and spill (77 registers in the first build)
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const int h2 = ln >> 5, lr = ln & 31;
-        const int lim = a.Lw - 4 * h2;
-        // block-diagonal (two heads of 16 per 32-channel tile) selector of a [d rows][v lanes] state tile: rows < 16 are registers 0..7
-        const bool head_lo = lr < 16;
+        // token slots >= Lw of the non-transposed products (row = token) are zeroed on the PACKED operands: element pair p of k-step s
+        // holds rows 16 s + 8 (p >> 1) + 4 h2 + 2 (p & 1) and the next one.  (A select per element in front of phi compiles into a
+        // divergent branch per element.)
+        v4u pm0, pm1;
+#pragma unroll
+        for (int p4 = 0; p4 < 4; ++p4) {
+            const int ra = 8 * (p4 >> 1) + 4 * h2 + 2 * (p4 & 1);
+            pm0[p4] = (ra < a.Lw ? 0xFFFFu : 0u) | (ra + 1 < a.Lw ? 0xFFFF0000u : 0u);
+            pm1[p4] = (ra + 16 < a.Lw ? 0xFFFFu : 0u) | (ra + 17 < a.Lw ? 0xFFFF0000u : 0u);
+        }
+        auto tok_mask = [](const Frag& f, const v4u& m) { return __builtin_bit_cast(Frag, __builtin_bit_cast(v4u, f) & m); };
         const int win = g * FW + wave;
+        K11_T(0);
         const int wclamp = win < a.Nw ? win : a.Nw - 1;                 // a tail group's spare waves recompute the last window (never stored)
         const char* xwin = (const char*)a.x + (size_t)wclamp * a.Lw * (FC * 2);
         const char* swin = (const char*)a.src + (size_t)wclamp * a.Lw * (FC * 2);
@@ -194,6 +225,7 @@ __global__ __launch_bounds__(512, 2) void fine_layer(FlArgs a) {
         }
         // the staged window as MFMA operand fragments (A of the k / v products, B of the q and mlp.0 products): k-step ks =
         // channels 16 ks + 8 h2 .. + 7 of token row lr
+        K11_T(1);
         Frag xf[8];
         auto load_xf = [&]() {
 #pragma unroll
@@ -213,9 +245,7 @@ __global__ __launch_bounds__(512, 2) void fine_layer(FlArgs a) {
         Frag kvA[4][2], ksA[4][2];
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
-            v16f k, v;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { k[r] = 0.f; v[r] = 0.f; }
+            v16f k = fl_zero(), v = fl_zero();
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
                 {
@@ -224,8 +254,8 @@ __global__ __launch_bounds__(512, 2) void fine_layer(FlArgs a) {
                     for (int i = 0; i < 4; ++i) Mm::mma(xf[4 * hf + i], cur[i], k);
                 }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) k[r] = ((r & 3) + 8 * (r >> 2)) < lim ? fl_phi(fl_rnd<T>(k[r])) : 0.f;
-            const Frag k0 = fl_pack_step<T>(k, 0), k1 = fl_pack_step<T>(k, 1);
+            for (int r = 0; r < 16; ++r) k[r] = fl_phi(fl_rnd<T>(k[r]));
+            const Frag k0 = tok_mask(fl_pack_step<T>(k, 0), pm0), k1 = tok_mask(fl_pack_step<T>(k, 1), pm1);
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
                 {
@@ -233,22 +263,19 @@ __global__ __launch_bounds__(512, 2) void fine_layer(FlArgs a) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) Mm::mma(xf[4 * hf + i], cur[i], v);
                 }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = ((r & 3) + 8 * (r >> 2)) < lim ? v[r] : 0.f;
-            const Frag v0 = fl_pack_step<T>(v, 0), v1 = fl_pack_step<T>(v, 1);
-            // KV tile = phi(k)^T v, Ksum tile = phi(k)^T 1 (every column holds Ksum[d]); off-head blocks zeroed
-            v16f kv, ks;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { kv[r] = 0.f; ks[r] = 0.f; }
+            const Frag v0 = tok_mask(fl_pack_step<T>(v, 0), pm0), v1 = tok_mask(fl_pack_step<T>(v, 1), pm1);
+            // KV tile = phi(k)^T v, Ksum tile = phi(k)^T 1 (every column holds Ksum[d]).  The tile's off-head blocks (row d and
+            // column v in different heads) are NOT zeroed: the apply below contracts head by head (one 16-deep k-step = the
+            // 16 d of one head) and reads only the result rows of that head.
+            v16f kv = fl_zero(), ks = fl_zero();
             Mm::mma(k0, v0, kv);
             Mm::mma(k1, v1, kv);
             Mm::mma(k0, ones, ks);
             Mm::mma(k1, ones, ks);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const bool keep = (r < 8) == head_lo;                   // row d and column v in the same head
-                kv[r] = keep ? kv[r] * inv_s : 0.f;
-                ks[r] = keep ? ks[r] * inv_s : 0.f;
+                kv[r] *= inv_s;
+                ks[r] *= inv_s;
             }
             kvA[nb][0] = fl_pack_step<T>(kv, 0); kvA[nb][1] = fl_pack_step<T>(kv, 1);
             ksA[nb][0] = fl_pack_step<T>(ks, 0); ksA[nb][1] = fl_pack_step<T>(ks, 1);
@@ -258,13 +285,12 @@ __global__ __launch_bounds__(512, 2) void fine_layer(FlArgs a) {
             load_xf();
         }
 
+        K11_T(2);
         // ---------------- per channel tile: q = W_q x (channel in registers, token on the lane), attention of its two heads
         Frag mB[4][2];                                                  // message, then LN1 output: B operand of the next product
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
-            v16f q;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) q[r] = 0.f;
+            v16f q = fl_zero();
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
                 {
@@ -275,19 +301,25 @@ __global__ __launch_bounds__(512, 2) void fine_layer(FlArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) q[r] = fl_phi(fl_rnd<T>(q[r]));
             const Frag q0 = fl_pack_step<T>(q, 0), q1 = fl_pack_step<T>(q, 1);
-            v16f num, den;
+            // head by head: k-step s holds the 16 d of head s of this tile, and only result rows v of the same head (registers
+            // 8 s .. 8 s + 7) are meaningful; every row of a den tile holds the token's normaliser of that head
+            v16f num0 = fl_zero(), num1 = fl_zero(), den0 = fl_zero(), den1 = fl_zero();
+            Mm::mma(kvA[nb][0], q0, num0);
+            Mm::mma(kvA[nb][1], q1, num1);
+            Mm::mma(ksA[nb][0], q0, den0);
+            Mm::mma(ksA[nb][1], q1, den1);
+            const float z0 = __builtin_amdgcn_rcpf(den0[0] + eps_s), z1 = __builtin_amdgcn_rcpf(den1[8] + eps_s);
+            v16f num;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { num[r] = 0.f; den[r] = 0.f; }
-            Mm::mma(kvA[nb][0], q0, num);
-            Mm::mma(kvA[nb][1], q1, num);
-            Mm::mma(ksA[nb][0], q0, den);
-            Mm::mma(ksA[nb][1], q1, den);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) num[r] *= __builtin_amdgcn_rcpf(den[r] + eps_s);
+            for (int r = 0; r < 8; ++r) {
+                num[r] = num0[r] * z0;
+                num[8 + r] = num1[8 + r] * z1;
+            }
             mB[nb][0] = fl_pack_step<T>(num, 0);
             mB[nb][1] = fl_pack_step<T>(num, 1);
         }
 
+        K11_T(3);
         // LayerNorm over the 128 channels of the lane's token: this lane half holds 64 of them (4 tiles x 16 registers)
         auto ln_stats = [&](const v16f (&t)[4], float eps, float& mean, float& rstd) {
             float s = 0.f, qd = 0.f;
@@ -316,8 +348,7 @@ __global__ __launch_bounds__(512, 2) void fine_layer(FlArgs a) {
             v16f m[4];
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) m[nb][r] = 0.f;
+                m[nb] = fl_zero();
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf)
                     {
@@ -337,20 +368,17 @@ __global__ __launch_bounds__(512, 2) void fine_layer(FlArgs a) {
                 }
         }
 
+        K11_T(4);
         // ---------------- per 32-wide hidden tile hb: hid = relu(W_1[hb] [x | m]) (4 steps), consumed at once by out += W_2[:, hb] hid
         // (2 steps); 6 steps per tile, so 4 tiles = 24 steps = 3 whole blocks per iteration of the outer loop
         v16f o[4];
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[nb][r] = 0.f;
+        for (int nb = 0; nb < 4; ++nb) o[nb] = fl_zero();
 #pragma unroll 1
         for (int hq = 0; hq < 2; ++hq) {
 #pragma unroll
             for (int hb = 0; hb < 4; ++hb) {
-                v16f hd;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) hd[r] = 0.f;
+                v16f hd = fl_zero();
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf)
                     {
@@ -381,6 +409,7 @@ __global__ __launch_bounds__(512, 2) void fine_layer(FlArgs a) {
             }
         }
 
+        K11_T(5);
         // ---------------- out = x + LN2(.), written into the wave's own tile (token rows), then stored in 16-byte row segments
         {
             float mean2, rstd2;
@@ -415,6 +444,7 @@ __global__ __launch_bounds__(512, 2) void fine_layer(FlArgs a) {
                 }
             }
         }
+        K11_T(6);
     }
 #undef FL_STEP_BEGIN
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

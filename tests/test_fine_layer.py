@@ -51,9 +51,11 @@ def _layer(prefix=PFX):
     return m.to(DEV), W
 
 
-def _ulp_close(got, want, what, st):
+def _ulp_close(got, want, what, st, layers=1):
+    """Two ulp of the storage type per element, mean difference far below one ulp (per layer: a value that lands on the
+    other side of a rounding boundary perturbs the whole next layer by a fraction of an ulp)."""
     got, want = got.float().cpu(), want.float()
-    k = 1 if st == torch.float16 else 8
+    k = (1 if st == torch.float16 else 8) * layers
     torch.testing.assert_close(got, want, rtol=4e-3 * k, atol=4e-3 * k, msg=lambda m: f'{what}: {m}')
     assert float((got - want).abs().mean()) < 3e-4 * k, (what, float((got - want).abs().mean()))
 
@@ -113,5 +115,5 @@ def test_fine_layer_repeatable_and_in_transformer():
     r1 = O.encoder_layer_chain(W, 'loftr_fine.layers.0.', f1, f1, 8, st)
     r0 = O.encoder_layer_chain(W, 'loftr_fine.layers.1.', r0, r1, 8, st)
     r1 = O.encoder_layer_chain(W, 'loftr_fine.layers.1.', r1, r0, 8, st)
-    _ulp_close(o0, r0, 'loftr_fine f0', st)
-    _ulp_close(o1, r1, 'loftr_fine f1', st)
+    _ulp_close(o0, r0, 'loftr_fine f0', st, layers=2)
+    _ulp_close(o1, r1, 'loftr_fine f1', st, layers=2)
