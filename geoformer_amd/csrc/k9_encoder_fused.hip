@@ -143,7 +143,9 @@ __device__ __forceinline__ void fetch_next(Ring& g, Frag (&nx)[8], int st) {
     __builtin_amdgcn_s_waitcnt(0xC07F);                               // lgkmcnt(0) only
     if (st == 3) {
         ring_turn();
+#if !defined(K9_ABLATE) || K9_ABLATE != 1
         if (g.blk + 2 < g.nblk) dma_block(g.ws, g.smem, g.blk + 2, g.wave, g.lane);
+#endif
         if (g.blk + 1 < g.nblk) load_step(g, nx, g.blk + 1, 0);
         ++g.blk;
     } else {

@@ -6,10 +6,13 @@
   * `cal_error_auc`, `cal_reproj_dists`, `eval_hpatches`
                                             eval_tool/immatch/utils/hpatches_helper.py:13-34, :94-317
 
-OpenCV and torchvision are not available offline: images are read with PIL and resized on the device
-with bilinear interpolation (half-pixel centres, no antialiasing - the convention of cv2.resize's default
-INTER_LINEAR); the homography of the HPatches metric is estimated from the fine matches by the device
-RANSAC (`ops.ransac_homography(..., thr=ransac_thres, integer_keypoints=False, min_points=4)`).
+OpenCV and torchvision are not available offline: images are read with PIL, converted to gray and resized as UINT8
+images by a restatement of OpenCV's published 8-bit paths (`cv2_gray_u8`: the 14-bit fixed-point BGR->gray of
+cv2.imread(..., IMREAD_GRAYSCALE); `cv2_resize_linear_u8`: cv2.resize's default INTER_LINEAR for 8-bit images, 11-bit
+fixed-point coefficients, half-pixel centres, round-half-up) - byte work, bit for bit; OpenCV itself is absent from the
+build container, so the restatement is pinned by hand-derived vectors (tests/test_matcher_cpu.py), not by OpenCV's own
+output.  The homography of the HPatches metric is estimated from the fine matches by the device RANSAC
+(`ops.ransac_homography(..., thr=ransac_thres, integer_keypoints=False, min_points=4)`).
 """
 import glob
 import os
@@ -18,7 +21,6 @@ from typing import Optional
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from . import ops
 from .model.cvpr_ds_config import get_default_cfg
@@ -37,16 +39,75 @@ def resize_im(wo, ho, imsize=None, dfactor=1, value_to_scale=max, aspan=False):
     return wt, ht, (wo / wt, ho / ht)
 
 
-def load_gray_scale_tensor(im_path, device, imsize=None, dfactor=8, value_to_scale=min, aspan=False):
-    """[1,1,H,W] float in [0,1] + (wo/wt, ho/ht); H, W multiples of dfactor."""
+def cv2_gray_u8(rgb):
+    """[H,W,3] uint8 RGB -> [H,W] uint8 as cv2.imread(path, cv2.IMREAD_GRAYSCALE) converts a colour file (data_io.py:50):
+    (R*4899 + G*9617 + B*1868 + 2^13) >> 14 (OpenCV imgcodecs' icvCvt_BGR2Gray_8u_C3C1R, 14-bit coefficients)."""
+    r, g, b = (rgb[..., k].astype(np.int64) for k in range(3))
+    return ((r * 4899 + g * 9617 + b * 1868 + (1 << 13)) >> 14).astype(np.uint8)
+
+
+def _cv_round(x):
+    """cvRound: round half to even (lrint) - what saturate_cast<short>(float) does."""
+    return np.rint(x)
+
+
+def _linear_coeffs(ssize, dsize, clamp_index):
+    """Source index and the two 11-bit weights of every destination position (imgproc/resize.cpp, resize generic path:
+    fx = (float)((dx + 0.5) * scale - 0.5); sx = floor(fx); fx -= sx; weights saturate_cast<short>({1 - fx, fx} * 2048)).
+    Horizontally an out-of-range sx is clamped together with fx = 0; vertically the ROW indices are clamped instead."""
+    scale = float(ssize) / float(dsize)
+    d = np.arange(dsize, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    if clamp_index:
+        lo, hi = s < 0, s >= ssize - 1
+        f = np.where(lo | hi, np.float32(0), f)
+        s = np.where(lo, 0, np.where(hi, ssize - 1, s))
+    w1 = np.clip(_cv_round(f * np.float32(2048)), -32768, 32767).astype(np.int64)
+    w0 = np.clip(_cv_round((np.float32(1) - f) * np.float32(2048)), -32768, 32767).astype(np.int64)
+    return s, w0, w1
+
+
+def cv2_resize_linear_u8(src, wt, ht):
+    """cv2.resize(src, (wt, ht)) for a single-channel uint8 image with the default INTER_LINEAR (data_io.py:53), OpenCV's
+    fixed-point path: horizontal pass into 19-bit integers (pixel x 11-bit weight), vertical pass
+    dst = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2  (VResizeLinear<uchar, int, short>).  An exact 2x
+    decimation in both directions is INTER_AREA instead (resize.cpp: 'INTER_LINEAR && is_area_fast && iscale == 2'):
+    (a + b + c + d + 2) >> 2."""
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    hs, ws = src.shape
+    if (ws, hs) == (wt, ht):
+        return src.copy()
+    if ws == 2 * wt and hs == 2 * ht:
+        t = src.astype(np.int64)
+        return ((t[0::2, 0::2] + t[0::2, 1::2] + t[1::2, 0::2] + t[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    sx, a0, a1 = _linear_coeffs(ws, wt, clamp_index=True)
+    sy, b0, b1 = _linear_coeffs(hs, ht, clamp_index=False)
+    t = src.astype(np.int64)
+    rows = t[:, sx] * a0[None, :] + t[:, np.minimum(sx + 1, ws - 1)] * a1[None, :]            # [hs, wt]
+    r0, r1 = rows[np.clip(sy, 0, hs - 1)], rows[np.clip(sy + 1, 0, hs - 1)]                  # [ht, wt]
+    out = (((b0[:, None] * (r0 >> 4)) >> 16) + ((b1[:, None] * (r1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def load_gray_image(im_path):
+    """[H,W] uint8 like cv2.imread(im_path, cv2.IMREAD_GRAYSCALE)."""
     from PIL import Image
-    im = np.array(Image.open(im_path).convert('L'), dtype=np.uint8)        # a writable copy (torch.from_numpy)
+    im = Image.open(im_path)
+    if im.mode in ('RGB', 'RGBA', 'P', 'CMYK', 'YCbCr'):
+        return cv2_gray_u8(np.array(im.convert('RGB'), dtype=np.uint8))
+    return np.array(im.convert('L'), dtype=np.uint8)
+
+
+def load_gray_scale_tensor(im_path, device, imsize=None, dfactor=8, value_to_scale=min, aspan=False):
+    """[1,1,H,W] float in [0,1] + (wo/wt, ho/ht); H, W multiples of dfactor (load_gray_scale_tensor_cv, data_io.py:48-62:
+    gray uint8 image -> cv2.resize on the uint8 image -> to_tensor)."""
+    im = load_gray_image(im_path)
     ho, wo = im.shape
     wt, ht, scale = resize_im(wo, ho, imsize=imsize, dfactor=dfactor, value_to_scale=value_to_scale, aspan=aspan)
+    im = cv2_resize_linear_u8(im, wt, ht)
     t = torch.from_numpy(im).to(device=device, dtype=torch.float32)[None, None]
-    if (ht, wt) != (ho, wo):
-        t = F.interpolate(t, size=(ht, wt), mode='bilinear', align_corners=False)
-        t = t.round().clamp_(0, 255)          # cv2.resize returns uint8
     return t / 255.0, scale
 
 

@@ -2,9 +2,9 @@
 conventions, device RANSAC on sub-pixel matches, HPatches-protocol evaluation loop on a synthetic
 two-sequence dataset.
 
-The resize itself (PIL read + bilinear, half-pixel centres) is NOT pinned against cv2.resize: OpenCV is absent from the
-build container, so no table of its outputs can be produced here; what is pinned is everything downstream of the
-resized tensors."""
+The uint8 gray conversion and resize (restatements of OpenCV's published fixed-point paths) are pinned by hand-derived
+vectors in tests/test_matcher_cpu.py; here: everything downstream of the resized tensors, and the evaluation loop's
+arithmetic on a sequence with planted homographies whose corner errors and AUC are computed by hand."""
 import os
 
 import numpy as np
@@ -119,3 +119,48 @@ def test_match_pairs_against_oracle_on_the_same_resized_tensors(tmp_path):
     np.testing.assert_allclose(up, matches * np.array(s0 + s1)[None], rtol=1e-6)
     np.testing.assert_allclose(u0, k0 * np.array(s0)[None], rtol=1e-6); np.testing.assert_allclose(u1, k1 * np.array(s1)[None], rtol=1e-6)
     assert float(u0[:, 0].max()) <= 200 and float(u1[:, 0].max()) <= 280 and float(u1[:, 0].max()) > 208 * 0.9
+
+
+def test_eval_hpatches_known_answer(tmp_path):
+    """The loop's arithmetic (hpatches_helper.py:185-239) on a planted sequence: a stub matcher returns noise-free matches in
+    RESIZED coordinates that follow the ground-truth homography moved into those coordinates, shifted by a known offset e_k
+    per pair.  Then H_pred = T(e_k) H_gt' and, H_gt being affine, every warped corner is off by exactly |e_k|: corner errors
+    (0, 0.5, 2, 4, 20) px.  By hand (errors sorted, recall 0.2 per pair, trapezoids up to the threshold, divided by it):
+        AUC@1  = (0.15 + 0.4 * 0.5) / 1                                  = 0.35
+        AUC@3  = (0.15 + 0.5 * 1.5 + 0.6 * 1) / 3                        = 0.5
+        AUC@5  = (0.15 + 0.75 + 0.7 * 2 + 0.8 * 1) / 5                   = 0.62
+        AUC@10 = (0.15 + 0.75 + 1.4 + 0.8 * 6) / 10                      = 0.71
+    and 'correct' = the fractions <= 1, 3, 5, 10 px = 0.4, 0.6, 0.8, 0.8.  A GT homography moved with the scale entries swapped,
+    or corners taken at the original instead of the resized size, moves these numbers."""
+    from PIL import Image
+    from geoformer_amd import matcher as MT
+    root = str(tmp_path)
+    d = os.path.join(root, 'v_planted')
+    os.makedirs(d)
+    w, h = 200, 160
+    H_gt = {k: np.array([[1.0 + 0.02 * k, 0.03, 5.0 * k], [-0.02, 0.97, -3.0 * k], [0, 0, 1.0]]) for k in range(2, 7)}
+    for k in range(1, 7):
+        Image.fromarray(np.zeros((h, w, 3), np.uint8)).save(os.path.join(d, f'{k}.ppm'))
+        if k > 1:
+            np.savetxt(os.path.join(d, f'H_1_{k}'), H_gt[k])
+    scale = np.array([1.25, 0.8, 2.0, 1.6])                       # (w1, h1, w2, h2) original / resized
+    offs = {2: (0.0, 0.0), 3: (0.3, -0.4), 4: (-1.2, 1.6), 5: (2.4, 3.2), 6: (12.0, -16.0)}     # |e| = 0, 0.5, 2, 4, 20
+
+    class Stub:
+        device = 'cuda:0'
+
+        def __call__(self, im1, im2):
+            k = int(os.path.basename(im2).split('.')[0])
+            Hr = np.linalg.inv(MT.scale_homography(scale[2], scale[3])) @ H_gt[k] @ MT.scale_homography(scale[0], scale[1])
+            gx, gy = np.meshgrid(np.linspace(4, w / scale[0] - 4, 12), np.linspace(4, h / scale[1] - 4, 10))
+            p = np.stack([gx.ravel(), gy.ravel()], 1)
+            q = np.c_[p, np.ones(len(p))] @ Hr.T
+            q = q[:, :2] / q[:, 2:] + np.array(offs[k])[None]
+            m = np.c_[p, q]
+            return m, p, q, np.ones(len(p)), scale
+    out = MT.eval_hpatches(Stub(), root, ransac_thres=3, log=lambda s: None)
+    assert out['pairs'] == 5 and out['failed'] == 0
+    np.testing.assert_allclose(out['auc_a'], [0.35, 0.5, 0.62, 0.71], atol=2e-3)
+    np.testing.assert_allclose(out['auc_v'], out['auc_a'])
+    np.testing.assert_allclose(out['correct_a'], [0.4, 0.6, 0.8, 0.8])
+    np.testing.assert_array_equal(out['auc_i'], np.zeros(4))
