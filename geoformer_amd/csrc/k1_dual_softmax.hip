@@ -829,9 +829,23 @@ __global__ __launch_bounds__(NT, 2) void k1_stats_panel(K1Args a) {
             for (int p = 0; p < 8; ++p) rb[p] = *reinterpret_cast<const v4u*>(g + (size_t)p * 8 * a.C);
         };
         prefetch(t0);
-        float rm[16], rs[16];
+        // Per-element work of this pass = 1 exponential, not 2.5: everything is referred to ONE lazily updated reference per
+        // row slot (a register) of this lane,
+        //     e = exp2(s2 - ref[r]),  s2 = acc * mult * log2(e),
+        // which feeds the row sum directly (rs[r] += e) and the column sum through a cached per-slot factor
+        //     csum += e * f[r],  f[r] = exp2(ref[r] - kappa)   (kappa = the lane's largest ref: csum = sum exp2(s2 - kappa)).
+        // ref[r] is a former running maximum of the slot, so the element that set it contributes 1 and whatever flushes to zero is
+        // below 2^-126 of the sum; it is moved up (rs rescaled, f recomputed: 'rescale') whenever a tile's maximum exceeds the
+        // smallest reference of the lane by more than 2^LAZY, which also bounds e by 2^LAZY.  The column partial is reported
+        // against the column's TRUE maximum (one exponential per column and tile); a tile in which some column lies more than
+        // 2^LAZY below kappa takes the two-exponential path for its column sums instead ('deep' tiles).  Maxima are taken on the
+        // raw accumulators and scaled once: bit-identical to the form this replaces; the sums are exact up to fp32 rounding.
+        constexpr float LAZY = 64.f;
+        const float mult2 = a.mult * LOG2E;
+        float rmx[16], rs[16], ref[16], fcol[16];                         // raw running maximum | sum | reference (log2) | exp2(ref - kappa)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { rm[r] = NEG_INF; rs[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { rmx[r] = NEG_INF; rs[r] = 0.f; ref[r] = NEG_INF; fcol[r] = 0.f; }
+        float minref = NEG_INF, kappa = NEG_INF;
         for (int bn = t0; bn < t1; ++bn) {
             __syncthreads();                                  // previous tile: fragments consumed, colx combined
 #pragma unroll
@@ -850,26 +864,58 @@ __global__ __launch_bounds__(NT, 2) void k1_stats_panel(K1Args a) {
                 Mma32<H>::mma(af[kg], b0, acc[0]);
                 Mma32<H>::mma(af[kg], b1, acc[1]);
             }
-            // ---- columns (lane = column): max and sum over this wave's 32 rows
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                float m = NEG_INF;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[ni][r]);
-                m = fmaxf(m, __shfl_xor(m, 32, 64)) * a.mult;
-                float l = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) l += __expf(fmaf(acc[ni][r], a.mult, -m));
-                l += __shfl_xor(l, 32, 64);
-                if (h == 0) colx[wave * 64 + ni * 32 + lr] = make_float2(m, l);
-            }
-            // ---- rows (register slot = row): online (max, sum) over the run's columns held by this lane
+            // ---- maxima on the raw accumulators: columns over the registers, row slots over the two column halves and the tiles
+            float cmr0 = NEG_INF, cmr1 = NEG_INF;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float s0 = acc[0][r] * a.mult, s1 = acc[1][r] * a.mult;
-                const float mn = fmaxf(rm[r], fmaxf(s0, s1));
-                rs[r] = rs[r] * __expf(rm[r] - mn) + __expf(s0 - mn) + __expf(s1 - mn);
-                rm[r] = mn;
+                cmr0 = fmaxf(cmr0, acc[0][r]);
+                cmr1 = fmaxf(cmr1, acc[1][r]);
+                rmx[r] = fmaxf(rmx[r], fmaxf(acc[0][r], acc[1][r]));
+            }
+            const float lanemax2 = fmaxf(cmr0, cmr1) * mult2;
+            if (__any(lanemax2 - minref > LAZY)) {                       // rescale (always taken by the run's first tile)
+                float mn = INFINITY, mxr = NEG_INF;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float nr = rmx[r] * mult2;
+                    rs[r] *= __builtin_amdgcn_exp2f(ref[r] - nr);        // 0 * exp2(-inf) = 0 on the first tile
+                    ref[r] = nr;
+                    mn = fminf(mn, nr);
+                    mxr = fmaxf(mxr, nr);
+                }
+                minref = mn;
+                kappa = mxr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) fcol[r] = __builtin_amdgcn_exp2f(ref[r] - kappa);
+            }
+            // column maxima over the wave's 32 rows (both lane halves), in log2 units
+            const float cm0 = fmaxf(cmr0, __shfl_xor(cmr0, 32, 64)), cm1 = fmaxf(cmr1, __shfl_xor(cmr1, 32, 64));
+            const float c20 = cm0 * mult2, c21 = cm1 * mult2;
+            float cs0 = 0.f, cs1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e0 = __builtin_amdgcn_exp2f(fmaf(acc[0][r], mult2, -ref[r]));
+                const float e1 = __builtin_amdgcn_exp2f(fmaf(acc[1][r], mult2, -ref[r]));
+                rs[r] += e0 + e1;
+                cs0 = fmaf(e0, fcol[r], cs0);
+                cs1 = fmaf(e1, fcol[r], cs1);
+            }
+            if (__any(kappa - fminf(c20, c21) > LAZY)) {                 // a 'deep' tile: column sums against their own maxima
+                cs0 = 0.f; cs1 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    cs0 += __builtin_amdgcn_exp2f(fmaf(acc[0][r], mult2, -c20));
+                    cs1 += __builtin_amdgcn_exp2f(fmaf(acc[1][r], mult2, -c21));
+                }
+            } else {
+                cs0 *= __builtin_amdgcn_exp2f(kappa - c20);              // from reference kappa to the column's own maximum
+                cs1 *= __builtin_amdgcn_exp2f(kappa - c21);
+            }
+            cs0 += __shfl_xor(cs0, 32, 64);
+            cs1 += __shfl_xor(cs1, 32, 64);
+            if (h == 0) {
+                colx[wave * 64 + lr] = make_float2(cm0 * a.mult, cs0);
+                colx[wave * 64 + 32 + lr] = make_float2(cm1 * a.mult, cs1);
             }
             __syncthreads();
             if (tid < 64) {                                   // combine the four waves' column partials
@@ -882,22 +928,22 @@ __global__ __launch_bounds__(NT, 2) void k1_stats_panel(K1Args a) {
                 a.colpart[((size_t)n * a.tilesM + bm) * a.S + bn * BN + tid] = make_float2(m, l);
             }
         }
-        // ---- end of the run: row maxima across the lanes, sums rescaled to them, sums across the lanes
+        // ---- end of the run: row maxima across the lanes, sums moved from the lane's reference to them, sums across the lanes
         float v[32];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) { v[q] = rm[q]; v[16 + q] = NEG_INF; }
-        const float rmax = k1_row_reduce(v, GfMaxF());
-        if (lr < 16) rowbc[wave * 32 + h * 16 + lr] = rmax;
+        for (int q = 0; q < 16; ++q) { v[q] = rmx[q]; v[16 + q] = NEG_INF; }
+        const float rmax_raw = k1_row_reduce(v, GfMaxF());
+        if (lr < 16) rowbc[wave * 32 + h * 16 + lr] = rmax_raw;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            v[q] = rs[q] * __expf(rm[q] - rowbc[wave * 32 + h * 16 + q]);
+            v[q] = rs[q] * __builtin_amdgcn_exp2f(ref[q] - rowbc[wave * 32 + h * 16 + q] * mult2);
             v[16 + q] = 0.f;
         }
         const float rsum = k1_row_reduce(v, GfAddF());
-        if (lr < 16) a.rowpart[((size_t)n * runs + run) * a.L + m0 + wave * 32 + gf_acc_row(lr, h)] = make_float2(rmax, rsum);
+        if (lr < 16) a.rowpart[((size_t)n * runs + run) * a.L + m0 + wave * 32 + gf_acc_row(lr, h)] = make_float2(rmax_raw * a.mult, rsum);
     }
 }
 

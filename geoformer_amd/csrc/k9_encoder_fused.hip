@@ -95,9 +95,17 @@ __device__ __forceinline__ typename Mma32<T>::Frag pack_step(const v16f& a, int 
     return s == 0 ? pack8<T>(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7])
                   : pack8<T>(a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15]);
 }
+// ReLU of 8 packed 16-bit floats: a set sign bit clears the element (-0 -> +0; fp16 and bf16 alike)
+template <typename F>
+__device__ __forceinline__ F relu_packed(const F& f) {
+    typedef short v8s __attribute__((ext_vector_type(8)));
+    const v8s x = __builtin_bit_cast(v8s, f);
+    return __builtin_bit_cast(F, x & ~(x >> 15));
+}
 // elu(x) + 1 (linear_attention.py:33-34) = max(x, 0) + exp(min(x, 0)): x + 1 for x > 0 (exp(0) = 1 exactly), exp(x)
 // otherwise - branch-free (a conditional exponential compiles to a divergent branch per element), hardware exponential
 __device__ __forceinline__ float phi(float x) { return fmaxf(x, 0.f) + __builtin_amdgcn_exp2f(fminf(x, 0.f) * 1.44269504088896341f); }
+__device__ __forceinline__ v16f zero16() { return v16f{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; }
 template <typename T>
 __device__ __forceinline__ float rnd(float x) { return gf_to_float(gf_from_float<T>(x)); }   // round to the storage type
 
@@ -271,17 +279,16 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
         // ---------------- q = W_q x : 16 steps (k-step ks = step, tiles nb = 0..7)
         v16f q[8];
 #pragma unroll
-        for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) q[nb][r] = 0.f;
+        for (int nb = 0; nb < 8; ++nb) q[nb] = zero16();
         Frag tf = xfrag(0);
 #pragma unroll
         for (int st = 0; st < 16; ++st) {
             Frag (&cur)[8] = (st & 1) ? fb : fa;
             Frag (&nxt)[8] = (st & 1) ? fa : fb;
-            __builtin_amdgcn_s_waitcnt(0xC07F);                        // see fetch_next: retire the current step's reads first
-            const Frag tn = xfrag(st < 15 ? st + 1 : 15);
+            // fetch_next first: its wait retires this step's fragments (requested a step ago); the token fragment of the NEXT
+            // step is requested behind it, so that no full lgkmcnt drain follows a read that was just issued
             fetch_next(ring, nxt, st & 3);
+            const Frag tn = xfrag(st < 15 ? st + 1 : 15);
 #pragma unroll
             for (int nb = 0; nb < 8; ++nb) Mm::mma(cur[nb], tf, q[nb]);
             step_schedule<1>();
@@ -304,9 +311,7 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
                 den += pq[4 * g] * k4.x + pq[4 * g + 1] * k4.y + pq[4 * g + 2] * k4.z + pq[4 * g + 3] * k4.w;
             }
             den += __shfl_xor(den, 32, 64);
-            v16f num;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) num[r] = 0.f;
+            v16f num = zero16();
             const Frag p0 = pack8<T>(pq[0], pq[1], pq[2], pq[3], pq[4], pq[5], pq[6], pq[7]);
             const Frag p1 = pack8<T>(pq[8], pq[9], pq[10], pq[11], pq[12], pq[13], pq[14], pq[15]);
             Mm::mma(*reinterpret_cast<const Frag*>(smem + KV_OFF + (hh * 2) * FRAG + lane * 16), p0, num);
@@ -323,9 +328,7 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
     // ---------------- m = LN1(W_m msg) : 16 steps, operand (tile t = step / 2, k-step s = step % 2) from registers
     v16f m[8];
 #pragma unroll
-    for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m[nb][r] = 0.f;
+    for (int nb = 0; nb < 8; ++nb) m[nb] = zero16();
 #pragma unroll
     for (int st = 0; st < 16; ++st) {
         Frag (&cur)[8] = (st & 1) ? fb : fa;
@@ -386,18 +389,15 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
     for (int sl = 0; sl < 4; ++sl) {
         v16f hd[4];
 #pragma unroll
-        for (int hb = 0; hb < 4; ++hb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) hd[hb][r] = 0.f;
+        for (int hb = 0; hb < 4; ++hb) hd[hb] = zero16();            // constant: the first MFMA of each chain takes C = 0 inline
         if (sl == 1) K9_T(6);
         Frag t0f = xfrag(0), t1f = xfrag(1);
 #pragma unroll
         for (int st = 0; st < 8; ++st) {
             Frag (&cur)[8] = (st & 1) ? fb : fa;
             Frag (&nxt)[8] = (st & 1) ? fa : fb;
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            const Frag n0 = xfrag(st < 7 ? 2 * st + 2 : 14), n1 = xfrag(st < 7 ? 2 * st + 3 : 15);
             fetch_next(ring, nxt, st & 3);
+            const Frag n0 = xfrag(st < 7 ? 2 * st + 2 : 14), n1 = xfrag(st < 7 ? 2 * st + 3 : 15);
 #pragma unroll
             for (int hb = 0; hb < 4; ++hb) Mm::mma(cur[hb], t0f, hd[hb]);
 #pragma unroll
@@ -422,13 +422,17 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
         Frag hfrag[4][2];
 #pragma unroll
         for (int hb = 0; hb < 4; ++hb) {
+            if constexpr (ACT == 0) {
+                // ReLU on the PACKED operand: relu(round(x)) = round(relu(x)), and on 16-bit floats it is 'sign bit set -> 0':
+                // one arithmetic shift + one and-not per pair of elements (fmaxf per fp32 element: accvgpr_read + canonicalise + max)
+                hfrag[hb][0] = relu_packed(pack_step<T>(hd[hb], 0));
+                hfrag[hb][1] = relu_packed(pack_step<T>(hd[hb], 1));
+            } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if constexpr (ACT == 0) hd[hb][r] = fmaxf(hd[hb][r], 0.f);
-                else hd[hb][r] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * hd[hb][r]) + 1.0f);     // tanh, ~1e-6 abs
+                for (int r = 0; r < 16; ++r) hd[hb][r] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * hd[hb][r]) + 1.0f);     // tanh, ~1e-6 abs
+                hfrag[hb][0] = pack_step<T>(hd[hb], 0);
+                hfrag[hb][1] = pack_step<T>(hd[hb], 1);
             }
-            hfrag[hb][0] = pack_step<T>(hd[hb], 0);
-            hfrag[hb][1] = pack_step<T>(hd[hb], 1);
         }
         if (sl == 0) K9_T(12);
 #pragma unroll
@@ -549,9 +553,8 @@ __global__ __launch_bounds__(256, 1) void enc_kv_state(EncArgs a) {
         for (int st = 0; st < 16; ++st) {
             Frag (&cur)[8] = (st & 1) ? fb : fa;
             Frag (&nxt)[8] = (st & 1) ? fa : fb;
-            __builtin_amdgcn_s_waitcnt(0xC07F);                        // see fetch_next: retire the current step's reads first
+            fetch_next(ring, nxt, st & 3);                             // (order: see enc_layer's q product)
             const Frag tn = xfrag(st < 15 ? st + 1 : 15);
-            fetch_next(ring, nxt, st & 3);
 #pragma unroll
             for (int nb = 0; nb < 8; ++nb) Mm::mma(tf, cur[nb], acc[nb]);
             step_schedule<1>();
