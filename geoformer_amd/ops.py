@@ -403,9 +403,12 @@ class CoarseFocalLoss(torch.autograd.Function):
         N, L, C = f0.shape
         S = f1.shape[1]
         P = pos_b.numel()
+        ctx_dtype = f0.dtype                       # the gradients go back in the caller's dtype
+        if f0.dtype == torch.bfloat16:           # the mixed-bf16 training step: the kernels take fp16 operands (same 16-bit
+            f0, f1 = f0.to(torch.float16), f1.to(torch.float16)       # storage, 3 more mantissa bits; features are O(1))
         f0c, f1c = _contig(f0), _contig(f1)
-        if f0c.dtype not in _DTYPES or f1c.dtype != f0c.dtype:
-            raise ValueError('f0/f1 must both be fp32 or fp16')
+        if f0c.dtype not in (torch.float32, torch.float16) or f1c.dtype != f0c.dtype:
+            raise ValueError('f0/f1 must both be fp32, fp16 or bf16')
         L_ = _lib.lib()
         ws = torch.empty(L_.gf_coarse_loss_workspace_bytes(N, L, S), dtype=torch.uint8, device=f0.device)
         conf = torch.empty(P, dtype=torch.float32, device=f0.device)
@@ -419,7 +422,7 @@ class CoarseFocalLoss(torch.autograd.Function):
                                         float(alpha), float(gamma), _p(conf), _p(loss), _p(grad), _p(ws), ws.numel(), _stream()),
               'gf_coarse_loss_forward')
         ctx.save_for_backward(pb, pi, pj, grad, ws)
-        ctx.meta = (N, L, S, C, float(temperature), f0.dtype)
+        ctx.meta = (N, L, S, C, float(temperature), ctx_dtype)
         ctx.mark_non_differentiable(conf)
         return loss.sum(), conf
 

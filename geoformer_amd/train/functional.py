@@ -40,7 +40,23 @@ def add_pe(x, temp_bug_fix=False):
 
 # ----------------------------------------------------------------------------- attention + encoder layers
 def linear_attention(q, k, v, q_mask=None, kv_mask=None, eps=1e-6):
-    """linear_attention.py:21-51."""
+    """linear_attention.py:21-51.  Under the mixed-bf16 step the feature maps phi and the normaliser are evaluated in fp32
+    (the reference's own comment: the /S ... *S scaling exists "to prevent fp16 overflow"); the two contractions take
+    whatever the autocast context gives them (bf16 operands, fp32 accumulation)."""
+    if q.dtype in (torch.float16, torch.bfloat16):
+        out_dtype = q.dtype
+        Q, K = F.elu(q.float()) + 1, F.elu(k.float()) + 1
+        if q_mask is not None:
+            Q = Q * q_mask[:, :, None, None]
+        if kv_mask is not None:
+            K = K * kv_mask[:, :, None, None]
+            v = v * kv_mask[:, :, None, None]
+        s_len = v.size(1)
+        KV = torch.einsum('nshd,nshv->nhdv', K.to(out_dtype), v / s_len).float()
+        with torch.autocast(device_type=q.device.type, enabled=False):
+            Z = 1 / (torch.einsum('nlhd,nhd->nlh', Q, K.sum(dim=1)) + eps)
+            out = torch.einsum('nlhd,nhdv->nlhv', Q, KV) * (Z * s_len)[..., None]
+        return out.to(out_dtype)
     Q, K = F.elu(q) + 1, F.elu(k) + 1
     if q_mask is not None:
         Q = Q * q_mask[:, :, None, None]
@@ -100,12 +116,16 @@ def local_feature_transformer(P, prefix, layer_names, nhead, f0, f1, m0=None, m1
 
 # ----------------------------------------------------------------------------- coarse matching
 def dual_softmax(f0, f1, temperature, m0=None, m1=None):
-    """coarse_matching.py:113-125."""
+    """coarse_matching.py:113-125.  Always in fp32, also inside the mixed-bf16 step: a bf16 similarity (8 significant bits
+    at magnitudes of 10-30, i.e. steps of 0.1-0.25 in the exponent) would move every probability by tens of per cent."""
     c = f0.shape[-1]
-    sim = torch.einsum('nlc,nsc->nls', f0 / c ** .5, f1 / c ** .5) / temperature
-    if m0 is not None:
-        sim = sim.masked_fill(~(m0[..., None] * m1[:, None]).bool(), -1e9)
-    return F.softmax(sim, 1) * F.softmax(sim, 2)
+    with torch.autocast(device_type=f0.device.type, enabled=False):
+        if f0.dtype in (torch.float16, torch.bfloat16):
+            f0, f1 = f0.float(), f1.float()
+        sim = torch.einsum('nlc,nsc->nls', f0 / c ** .5, f1 / c ** .5) / temperature
+        if m0 is not None:
+            sim = sim.masked_fill(~(m0[..., None] * m1[:, None]).bool(), -1e9)
+        return F.softmax(sim, 1) * F.softmax(sim, 2)
 
 
 @torch.no_grad()

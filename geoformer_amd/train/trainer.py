@@ -72,15 +72,19 @@ def warmup_lr(cfg, global_step) -> Optional[float]:
 class _Core(nn.Module):
     """What DDP wraps: supervision -> forward -> fine supervision -> loss, returning the scalar loss."""
 
-    def __init__(self, model, loss, homography_fn=None, fused=True):
+    def __init__(self, model, loss, homography_fn=None, fused=True, amp_dtype=None):
         super().__init__()
-        self.model, self.loss, self.homography_fn, self.fused = model, loss, homography_fn, fused
+        self.model, self.loss, self.homography_fn, self.fused, self.amp_dtype = model, loss, homography_fn, fused, amp_dtype
 
     def forward(self, batch):
         res = tuple(self.model.config['resolution'])
         spvs_coarse(batch, res)
         fused = self.loss.fused_params() if (self.fused and fused_coarse_loss_applicable(self.model, batch)) else None
-        forward_train(self.model, batch, self.homography_fn, fused_coarse_loss=fused)
+        dev = batch['image0'].device.type
+        # mixed precision = Lightning's precision='bf16' (BASELINE configs[3]): fp32 master parameters, convolutions and GEMMs in
+        # bf16 with fp32 accumulation, softmax / LayerNorm / losses in fp32 (torch.autocast's op lists)
+        with torch.autocast(device_type=dev, dtype=self.amp_dtype or torch.bfloat16, enabled=self.amp_dtype is not None):
+            forward_train(self.model, batch, self.homography_fn, fused_coarse_loss=fused)
         spvs_fine2(batch, res)
         return self.loss(batch)
 
@@ -98,18 +102,26 @@ class TrainStep:
     kernels `gf_coarse_loss_forward/backward`, which compute in fp16 operands / fp32 accumulation: loss value and `p`
     agree with fp32 autograd on the SAME (fp16-rounded) features to 2e-3, the feature gradients to 2e-2 in norm
     (tests/test_train_gpu.py); against un-rounded fp32 features the loss agrees to 2e-3 and the gradients to 1e-2 in
-    norm (measured 3e-4 / 2e-3), also for confident matches (p > 0.95), where the gradient itself is small."""
+    norm (measured 3e-4 / 2e-3), also for confident matches (p > 0.95), where the gradient itself is small.
+
+    `precision='bf16'` is the mixed-precision step of BASELINE configs[3] (`--precision bf16` of the reference's Lightning
+    trainer, lightning/train_depth_geoformer.py:117-119): fp32 master parameters and optimizer state, the forward under
+    torch.autocast(bfloat16); confidence matrices, softmax, LayerNorm and the losses stay fp32.  Use it with
+    `fused_coarse_loss=True`, which keeps the two L x S confidence matrices out of the autograd graph altogether."""
 
     def __init__(self, model, trainer_cfg=None, loss_cfg=None, batch_size=1, distributed=False, device_ids=None,
-                 homography_fn: Optional[Callable] = None, sparse_spvs=True, fused_coarse_loss=False):
+                 homography_fn: Optional[Callable] = None, sparse_spvs=True, fused_coarse_loss=False, precision='fp32'):
         world = torch.distributed.get_world_size() if distributed else 1
         self.cfg = scale_trainer_cfg(trainer_cfg, world, batch_size)
         if model.precision != 'fp32':
             raise ValueError("training runs the fp32 parameters: GeoFormer.set_precision('fp32')")
         model.train()
         self.model = model
+        if precision not in ('fp32', 'bf16'):
+            raise ValueError("TrainStep precision: 'fp32' or 'bf16' (mixed: fp32 master weights, bf16 GEMMs / convolutions)")
+        self.precision = precision
         core = _Core(model, GeoLoss(loss_cfg, model.config['match_coarse'].get('match_type', 'dual_softmax'), sparse_spvs),
-                     homography_fn, fused_coarse_loss)
+                     homography_fn, fused_coarse_loss, torch.bfloat16 if precision == 'bf16' else None)
         if distributed:
             if next(model.parameters()).is_cuda:      # torch's SyncBatchNorm is device-only; the gloo/CPU tests keep local BN
                 core = nn.SyncBatchNorm.convert_sync_batchnorm(core)

@@ -274,3 +274,52 @@ def test_megadepth_style_train_step_matches_cpu_step():
     if a == b:
         assert float(g['loss_scalars']['loss_f']) == pytest.approx(float(c['loss_scalars']['loss_f']), rel=2e-3)
         assert int(c['conf_matrix_fine_gt'].sum()) == int(g['conf_matrix_fine_gt'].sum())
+
+
+@pytest.mark.parametrize('style', ['homo', 'megadepth'])
+def test_mixed_bf16_step_against_the_fp32_step(style):
+    """BASELINE configs[3] names 'mixed bf16' (lightning/train_depth_geoformer.py:117-119 + Lightning's precision flag):
+    TrainStep(precision='bf16') - fp32 master weights, the forward under torch.autocast(bfloat16), confidence matrices /
+    softmax / LayerNorm / losses in fp32, the two coarse losses from the fused HIP kernels - against the fp32 step on the same
+    batch and weights: loss terms within 3 % (bf16 keeps 8 significant bits through 14 transformer layers), parameter gradients
+    aligned (cosine > 0.98 over all parameters), parameters stay fp32, and the steps reduce the loss.  'megadepth' = N = 2 with
+    padding masks, per-image scales and depth / pose supervision (the configs[3] data contract)."""
+    from geoformer_amd.model.cvpr_ds_config import get_default_cfg
+    from geoformer_amd.model.full_model import GeoFormer
+    from geoformer_amd.model.geo_config import get_cfg_model
+    from geoformer_amd.train import TrainStep, synthetic_homography_batch
+
+    def make_batch(seed):
+        if style == 'megadepth':
+            return _megadepth_style_batch('cuda')
+        return synthetic_homography_batch(2, (128, 256), seed=seed, device='cuda')
+
+    res = {}
+    for prec in ('fp32', 'bf16'):
+        g = get_cfg_model()
+        g.update(coarse_thr=0.0, fine_thr=0.0, precision='fp32')
+        model = GeoFormer(get_default_cfg(), g)
+        sd = model.state_dict(); O.closed_form_fill(sd); model.load_state_dict(sd)
+        model.cuda()
+        step = TrainStep(model, trainer_cfg={'warmup_step': 0, 'canonical_lr': 1e-2, 'gradient_clipping': 0.0}, batch_size=2,
+                         fused_coarse_loss=True, precision=prec)
+        batch = make_batch(31)
+        loss = step.core(batch)                                # forward + loss of the FIRST step, gradients kept for inspection
+        step.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        grads = {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
+        assert all(p.dtype == torch.float32 for p in model.parameters())
+        assert all(v.dtype == torch.float32 for v in grads.values())
+        scal = {k: float(v) for k, v in batch['loss_scalars'].items()}
+        losses = [float(step(make_batch(31))) for _ in range(3)]
+        res[prec] = (scal, grads, losses, len(batch['b_ids']))
+    (s32, g32, l32, m32), (s16, g16, l16, m16) = res['fp32'], res['bf16']
+    print(f'{style}: fp32 {s32} ({m32} matches) | bf16 {s16} ({m16} matches); losses over 3 steps fp32 {l32} bf16 {l16}')
+    for k in ('loss_c', 'loss_d', 'loss'):
+        assert s16[k] == pytest.approx(s32[k], rel=3e-2), (k, s32, s16)
+    common = [n for n in g32 if n in g16]
+    assert len(common) >= 0.95 * len(g32)
+    dot = sum(float((g32[n] * g16[n]).sum()) for n in common)
+    na, nb = (sum(float((g[n] ** 2).sum()) for n in common) ** 0.5 for g in (g32, g16))
+    assert dot / (na * nb) > 0.98, dot / (na * nb)
+    assert all(np.isfinite(l16)) and l16[-1] < l16[0], l16
