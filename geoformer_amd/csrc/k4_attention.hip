@@ -89,7 +89,7 @@ __device__ __forceinline__ int k_off(int row, int chunk) { return row * (CC * (i
 __device__ __forceinline__ int vt_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
 template <typename T, int QB>
-__global__ __launch_bounds__(256) void attn_self(AtArgs a) {
+__global__ __launch_bounds__(256, QB <= 2 ? 2 : 1) void attn_self(AtArgs a) {
     using M = Mma32<T>;
     using Frag = typename M::Frag;
     constexpr bool F32 = std::is_same<T, float>::value;
@@ -126,33 +126,49 @@ __global__ __launch_bounds__(256) void attn_self(AtArgs a) {
     }
     const T* kc = (const T*)a.kc + (size_t)n * a.Kpad * CC;
     const int ntiles = (K + KT - 1) / KT;
+    // the K / V tile of the NEXT iteration waits in registers (issued before this tile's products, written to LDS after the
+    // barrier that ends them): the synchronous load -> write -> barrier of round 2 exposed the L2 latency once per tile
+    constexpr int CPR = CC / EPC;                         // chunks per row
+    constexpr int PASSES = KT * CPR / 256;
+    v4u rk[PASSES], rv[F32 ? PASSES : 4];
+    auto fetch = [&](int tile) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int e = p * 256 + tid, row = e / CPR, c = e % CPR;
+            rk[p] = *reinterpret_cast<const v4u*>(kc + ((size_t)tile * KT + row) * CC + c * EPC);
+        }
+        if constexpr (F32) {
+            const T* vc = (const T*)a.vc + ((size_t)n * a.Kpad + (size_t)tile * KT) * CC;
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) rv[p] = *reinterpret_cast<const v4u*>(vc + (size_t)(p * 256 + tid) * EPC);
+        } else {
+            const T* vt = (const T*)a.vc + ((size_t)n * CC + tid) * a.Kpad + (size_t)tile * KT;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) rv[c] = *reinterpret_cast<const v4u*>(vt + c * 8);
+        }
+    };
+    if (ntiles > 0) fetch(0);
+    // logits in log2 units: exp(x - m) = exp2(x' - m') with x' = s * (temp * log2 e): one multiply per element instead of two
+    constexpr bool FAST = !std::is_same<T, float>::value;              // 16-bit modes: hardware exponential
+    const float scale2 = FAST ? a.softmax_temp * 1.44269504088896341f : a.softmax_temp;
     for (int tile = 0; tile < ntiles; ++tile) {
         __syncthreads();
-        // ---- stage the K tile (all heads): 32 rows x CC, 16 B per thread per pass
-        {
-            constexpr int CPR = CC / EPC;                 // chunks per row
-            constexpr int PASSES = KT * CPR / 256;
+        // ---- stage the tile (all heads) from the registers
 #pragma unroll
-            for (int p = 0; p < PASSES; ++p) {
-                const int e = p * 256 + tid, row = e / CPR, c = e % CPR;
-                *reinterpret_cast<v4u*>(ks + k_off<T>(row, c)) =
-                    *reinterpret_cast<const v4u*>(kc + ((size_t)tile * KT + row) * CC + c * EPC);
-            }
-            if constexpr (F32) {
-                const T* vc = (const T*)a.vc + ((size_t)n * a.Kpad + (size_t)tile * KT) * CC;
+        for (int p = 0; p < PASSES; ++p) {
+            const int e = p * 256 + tid, row = e / CPR, c = e % CPR;
+            *reinterpret_cast<v4u*>(ks + k_off<T>(row, c)) = rk[p];
+        }
+        if constexpr (F32) {
 #pragma unroll
-                for (int p = 0; p < PASSES; ++p) {
-                    const int e = p * 256 + tid;
-                    *reinterpret_cast<v4u*>(vs + (size_t)e * 16) = *reinterpret_cast<const v4u*>(vc + (size_t)e * EPC);
-                }
-            } else {
-                const T* vt = (const T*)a.vc + ((size_t)n * CC + tid) * a.Kpad + (size_t)tile * KT;
+            for (int p = 0; p < PASSES; ++p) *reinterpret_cast<v4u*>(vs + (size_t)(p * 256 + tid) * 16) = rv[p];
+        } else {
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    *reinterpret_cast<v4u*>(vs + vt_off(tid, c)) = *reinterpret_cast<const v4u*>(vt + c * 8);
-            }
+            for (int c = 0; c < 4; ++c) *reinterpret_cast<v4u*>(vs + vt_off(tid, c)) = rv[c];
         }
         __syncthreads();
+        if (tile + 1 < ntiles) fetch(tile + 1);
+        const bool ragged = (tile + 1) * KT > K;          // only the last tile can hold key slots beyond K
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             // ---- S^T tile: rows = keys (registers), column = query (lane)
@@ -167,28 +183,38 @@ __global__ __launch_bounds__(256) void attn_self(AtArgs a) {
             }
             float x[16];
             float tmax = -INFINITY;
+            if (ragged) {
     #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = tile * KT + gf_acc_row(r, h);
-                x[r] = key < K ? s[r] * a.softmax_temp : -INFINITY;
-                tmax = fmaxf(tmax, x[r]);
+                for (int r = 0; r < 16; ++r) {
+                    const int key = tile * KT + gf_acc_row(r, h);
+                    x[r] = key < K ? s[r] * scale2 : -INFINITY;
+                    tmax = fmaxf(tmax, x[r]);
+                }
+            } else {
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    x[r] = s[r] * scale2;
+                    tmax = fmaxf(tmax, x[r]);
+                }
             }
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             const float mnew = fmaxf(m[qb], tmax);          // finite: every tile holds at least one real key
-            constexpr bool FAST = !std::is_same<T, float>::value;          // fp16 mode: hardware exponential
-            const float alpha = FAST ? __expf(m[qb] - mnew) : expf(m[qb] - mnew);
             float psum = 0.f;
     #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                x[r] = FAST ? __expf(x[r] - mnew) : expf(x[r] - mnew);
+                x[r] = FAST ? __builtin_amdgcn_exp2f(x[r] - mnew) : expf(x[r] - mnew);
                 psum += x[r];
             }
-            l[qb] = l[qb] * alpha + psum;
+            if (__any(mnew != m[qb])) {                     // a running maximum moved somewhere in the wave: rescale (else alpha = 1)
+                const float alpha = FAST ? __builtin_amdgcn_exp2f(m[qb] - mnew) : expf(m[qb] - mnew);
+                l[qb] *= alpha;
+    #pragma unroll
+                for (int b = 0; b < 2; ++b)
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) o[qb][b][r] *= alpha;
+            }
+            l[qb] += psum;
             m[qb] = mnew;
-    #pragma unroll
-            for (int b = 0; b < 2; ++b)
-    #pragma unroll
-                for (int r = 0; r < 16; ++r) o[qb][b][r] *= alpha;
             // ---- O^T += V^T . P^T with P^T taken from the registers as the B operand
             if constexpr (F32) {
     #pragma unroll
