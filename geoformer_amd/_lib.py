@@ -53,7 +53,7 @@ SIGNATURES = {
                           c_int, c_void_p]),
     'gf_ransac_workspace_bytes': (c_size_t, [c_int, c_int]),
     'gf_ransac_homography': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_float,
-                                     c_int, c_uint32, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_int, c_uint32, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_size_t, c_void_p]),
     'gf_window_geometry': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

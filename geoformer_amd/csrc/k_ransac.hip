@@ -28,6 +28,7 @@ struct RsArgs {
     uint32_t seed;
     float* kp0;              // [cap][2] keypoints fed to RANSAC: integer-valued (geo_module.py:110-111, 38-43) or raw
     float* kp1;
+    int lm_iters;            // Levenberg-Marquardt steps behind the least-squares refit (OpenCV's findHomography: 10)
     int min_points;          // a sample with fewer matches gets no model (GeoModule: 9, i.e. len > 8, geo_module.py:46)
     int integer_kp;          // 1: the reference's .long() keypoints (GeoModule); 0: sub-pixel keypoints as given (eval)
     double* hyp;             // [N][iters][9]
@@ -201,8 +202,36 @@ __device__ void block_sum(double (&v)[NV], double* sh /*[256]*/) {
     }
 }
 
+// sum over the 256 threads with TWO barriers for all NV values: lanes by shuffles, the four waves through LDS (added in wave
+// order).  `part` = [4][NV] doubles of LDS; the result is returned in every thread.
+template <int NV>
+__device__ void block_sum_fast(double (&v)[NV], double* part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double x = v[k];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+            const unsigned lo = __shfl_xor((unsigned)b, d, 64), hi = __shfl_xor((unsigned)(b >> 32), d, 64);
+            x = x + __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        }
+        v[k] = x;
+    }
+    __syncthreads();                                 // the previous call's readers are done with `part`
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) part[wave * NV + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = ((part[k] + part[NV + k]) + part[2 * NV + k]) + part[3 * NV + k];
+}
+
 __global__ __launch_bounds__(256) void ransac_final(RsArgs a) {
     __shared__ double sh[256];
+    __shared__ double sh_lm[9];
+    __shared__ int sh_lm_ok;
     __shared__ long long sh_key[256];
     __shared__ double sh_h[9];
     __shared__ int sh_state;
@@ -285,7 +314,7 @@ __global__ __launch_bounds__(256) void ransac_final(RsArgs a) {
         }
     block_sum(ne, sh);
     if (t == 0) {
-        double ata[64], atb[8], g[9];
+        double ata[64], atb[8], g[9];                   // (this g: the refit's result, handed on through LDS)
         int q = 0;
         for (int i2 = 0; i2 < 8; ++i2)
             for (int j2 = i2; j2 < 8; ++j2) { ata[i2 * 8 + j2] = ne[q]; ata[j2 * 8 + i2] = ne[q]; ++q; }
@@ -311,6 +340,84 @@ __global__ __launch_bounds__(256) void ransac_final(RsArgs a) {
         }
         if (!refit)
             for (int k = 0; k < 9; ++k) g[k] = h[k];
+        for (int k = 0; k < 9; ++k) sh_lm[k] = g[k];
+    }
+    __syncthreads();
+    // ---- Levenberg-Marquardt on the inliers' forward transfer error, 8 free entries (h33 = 1): what OpenCV's findHomography
+    // appends to its RANSAC (oracle/ransac_oracle.c:lm_refine states the same steps); the mask is not touched
+    double g[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) g[k] = sh_lm[k];
+    if (a.lm_iters > 0) {
+        auto sq_error = [&](const double* hh) {
+            double e[1] = {0.0};
+            for (int i = t; i < cnt; i += 256)
+                if (keep[i]) {
+                    const double x = (double)k0[2 * i], y = (double)k0[2 * i + 1];
+                    const double iw = 1.0 / (hh[6] * x + hh[7] * y + 1.0);
+                    const double du = (hh[0] * x + hh[1] * y + hh[2]) * iw - (double)k1[2 * i], dv = (hh[3] * x + hh[4] * y + hh[5]) * iw - (double)k1[2 * i + 1];
+                    e[0] += du * du + dv * dv;
+                }
+            block_sum_fast(e, sh);
+            return e[0];
+        };
+        double lambda = 1e-3, err = sq_error(g);
+        for (int it = 0; it < a.lm_iters; ++it) {
+            double ne2[44];                              // upper triangle of J^T J (36) | J^T r (8)
+#pragma unroll
+            for (int k = 0; k < 44; ++k) ne2[k] = 0.0;
+            for (int i = t; i < cnt; i += 256)
+                if (keep[i]) {
+                    const double x = (double)k0[2 * i], y = (double)k0[2 * i + 1];
+                    const double iw = 1.0 / (g[6] * x + g[7] * y + 1.0);
+                    const double up = (g[0] * x + g[1] * y + g[2]) * iw, vp = (g[3] * x + g[4] * y + g[5]) * iw;
+                    const double ju[8] = {x * iw, y * iw, iw, 0, 0, 0, -(x * up) * iw, -(y * up) * iw};
+                    const double jv[8] = {0, 0, 0, x * iw, y * iw, iw, -(x * vp) * iw, -(y * vp) * iw};
+                    const double ru = up - (double)k1[2 * i], rv = vp - (double)k1[2 * i + 1];
+                    int q = 0;
+#pragma unroll
+                    for (int i2 = 0; i2 < 8; ++i2) {
+#pragma unroll
+                        for (int j2 = i2; j2 < 8; ++j2) ne2[q++] += ju[i2] * ju[j2] + jv[i2] * jv[j2];
+                    }
+#pragma unroll
+                    for (int i2 = 0; i2 < 8; ++i2) ne2[36 + i2] += ju[i2] * ru + jv[i2] * rv;
+                }
+            block_sum_fast(ne2, sh);
+            if (t == 0) {
+                double A[64], d[8];
+                int q = 0;
+                for (int i2 = 0; i2 < 8; ++i2)
+                    for (int j2 = i2; j2 < 8; ++j2) { A[i2 * 8 + j2] = ne2[q]; A[j2 * 8 + i2] = ne2[q]; ++q; }
+                for (int i2 = 0; i2 < 8; ++i2) { A[i2 * 8 + i2] = A[i2 * 8 + i2] + lambda * A[i2 * 8 + i2]; d[i2] = -ne2[36 + i2]; }
+                const int ok = rs_solve(A, d, 8);
+                sh_lm_ok = ok;
+                if (ok) {
+                    for (int k = 0; k < 8; ++k) sh_lm[k] = g[k] + d[k];
+                    sh_lm[8] = 1.0;
+                }
+            }
+            __syncthreads();
+            if (!sh_lm_ok) {
+                lambda = lambda * 10.0;
+                __syncthreads();
+                continue;
+            }
+            double hn[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) hn[k] = sh_lm[k];
+            const double en = sq_error(hn);              // (its barriers also fence sh_lm against the next iteration's writer)
+            if (en < err) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) g[k] = hn[k];
+                err = en;
+                lambda = lambda * 0.1;
+            } else {
+                lambda = lambda * 10.0;
+            }
+        }
+    }
+    if (t == 0) {
         // inverse in fp64 (adjugate), as torch.inverse is applied to the float64 matrix before the cast
         const double det = g[0] * (g[4] * g[8] - g[5] * g[7]) - g[1] * (g[3] * g[8] - g[5] * g[6]) +
                            g[2] * (g[3] * g[7] - g[4] * g[6]);
@@ -336,7 +443,7 @@ extern "C" size_t gf_ransac_workspace_bytes(int N, int iters) {
 
 extern "C" int gf_ransac_homography(const float* mkpts0_c, const float* mkpts1_c, const int32_t* counts, int N,
                                     int capacity, float scale, const float* scale0, const float* scale1,
-                                    float thr, int iters, uint32_t seed, int min_points, int integer_keypoints, float* kp0,
+                                    float thr, int iters, uint32_t seed, int lm_iters, int min_points, int integer_keypoints, float* kp0,
                                     float* kp1, double* M,
                                     float* M_f32, float* Minv_f32, int32_t* valid, uint8_t* keep, void* workspace,
                                     size_t workspace_bytes, void* stream) {
@@ -351,6 +458,7 @@ extern "C" int gf_ransac_homography(const float* mkpts0_c, const float* mkpts1_c
     a.mk0 = mkpts0_c; a.mk1 = mkpts1_c; a.counts = counts; a.N = N; a.iters = iters; a.scale = scale;
     a.scale0 = scale0; a.scale1 = scale1; a.thr2 = (double)thr * (double)thr; a.seed = seed;
     a.kp0 = kp0; a.kp1 = kp1; a.integer_kp = integer_keypoints; a.min_points = min_points < 4 ? 4 : min_points;
+    a.lm_iters = lm_iters < 0 ? 0 : lm_iters;
     a.hyp = (double*)workspace;
     a.hyp_cnt = (int32_t*)((char*)workspace + gf_align_up((size_t)N * iters * 9 * sizeof(double), 256));
     a.M = M; a.Mf = M_f32; a.Minv = Minv_f32; a.valid = valid; a.keep = keep;

@@ -318,7 +318,7 @@ class GeoModule(nn.Module):
         self.pos_encoding = PositionEncodingSine(d_model)
         self.des_transformer = GeoTransformer(config, config['layer_names'], d_model, linear=False)
         self.ransac_thr = 8.0                     # cv2.findHomography(..., cv2.RANSAC, 8.0) (geo_module.py:48)
-        self.ransac_iters, self.ransac_seed = ops.RANSAC_ITERS, ops.RANSAC_SEED
+        self.ransac_iters, self.ransac_seed, self.ransac_lm_iters = ops.RANSAC_ITERS, ops.RANSAC_SEED, ops.RANSAC_LM_ITERS
         # Optional HOST callback with cv2.findHomography's contract, `fn(kp0 [n,2] int64 ndarray, kp1) ->
         # (M float64 [3,3] | None, mask uint8 [n,1])`, called per sample with > 8 matches exactly like
         # geo_module.py:45-48 (e.g. lambda a, b: cv2.findHomography(a, b, cv2.RANSAC, 8.0), or a replay of
@@ -359,7 +359,7 @@ class GeoModule(nn.Module):
         scale = int(batch['hw0_i'][0]) // int(batch['hw0_c'][0])
         s0, s1 = batch.get('scale0'), batch.get('scale1')
         rs = ops.ransac_homography(raw['mkpts0_c'], raw['mkpts1_c'], raw['counts'], n, scale, s0, s1, self.ransac_thr,
-                                   self.ransac_iters, self.ransac_seed)
+                                   self.ransac_iters, self.ransac_seed, lm_iters=self.ransac_lm_iters)
         if self.homography_fn is not None:
             self._host_homographies(rs, raw['counts'], n, dev)
         L, S = hw0c[0] * hw0c[1], hw1c[0] * hw1c[1]

@@ -199,10 +199,11 @@ def linear_attention(q, k, v, nhead, q_mask=None, kv_mask=None, eps=1e-6):
 
 RANSAC_ITERS = 1024
 RANSAC_SEED = 0x5EED
+RANSAC_LM_ITERS = 10            # Levenberg-Marquardt steps behind the refit: what cv2.findHomography(..., cv2.RANSAC, ...) appends
 
 
 def ransac_homography(mkpts0_c, mkpts1_c, counts, N, scale, scale0=None, scale1=None, thr=8.0, iters=RANSAC_ITERS,
-                      seed=RANSAC_SEED, integer_keypoints=True, min_points=9):
+                      seed=RANSAC_SEED, integer_keypoints=True, min_points=9, lm_iters=RANSAC_LM_ITERS):
     """Device RANSAC on the first-pass coarse matches.  Returns dict(kp0, kp1 fp32 [cap,2], M fp64 [N,3,3],
     M_f32, Minv_f32 [N,3,3], valid int32 [N], keep uint8 [cap])."""
     _need_cuda(mkpts0_c, mkpts1_c, counts)
@@ -219,7 +220,7 @@ def ransac_homography(mkpts0_c, mkpts1_c, counts, N, scale, scale0=None, scale1=
     nbytes = L_.gf_ransac_workspace_bytes(N, iters)
     ws = _ws.get('ransac', nbytes, dev)
     check(L_.gf_ransac_homography(_p(mkpts0_c), _p(mkpts1_c), _p(counts), N, max(cap, 1), float(scale), _p(s0), _p(s1),
-                                  float(thr), int(iters), int(seed), int(min_points), int(bool(integer_keypoints)), _p(kp[0]), _p(kp[1]), _p(M), _p(Mf[0]), _p(Mf[1]),
+                                  float(thr), int(iters), int(seed), int(lm_iters), int(min_points), int(bool(integer_keypoints)), _p(kp[0]), _p(kp[1]), _p(M), _p(Mf[0]), _p(Mf[1]),
                                   _p(valid), _p(keep), _p(ws), ws.numel(), _stream()), 'gf_ransac_homography')
     return {'kp0': kp[0], 'kp1': kp[1], 'M': M, 'M_f32': Mf[0], 'Minv_f32': Mf[1], 'valid': valid, 'keep': keep}
 

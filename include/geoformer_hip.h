@@ -202,6 +202,8 @@ int gf_linear(const void* a1, long lda1, int k1, const void* a2, long lda2, int 
  * filtering of GeoModule.apply_RANSAC (model/geo_module.py:38-52).  OpenCV parity is unpinned;
  * the algorithm is the one stated in oracle/ransac_oracle.c (bit-exact inlier mask).
  *   mkpts0_c/mkpts1_c [cap,2] fp32 and counts int32[1+N] as written by gf_dual_softmax_match;
+ *   lm_iters: Levenberg-Marquardt steps on the inliers' forward transfer error behind the least-squares refit (OpenCV's
+ *   findHomography appends 10 to its RANSAC; 0 = none); the inlier mask is the best hypothesis' either way;
  *   min_points: samples with fewer matches get no model (GeoModule passes 9: `len(kp0) > 8`, :46);
  *   integer_keypoints = 1: keypoints are truncated like the reference's .long() (GeoModule);
  *   0: sub-pixel keypoints are used as given (homography estimation from fine matches in the
@@ -213,7 +215,7 @@ int gf_linear(const void* a1, long lda1, int k1, const void* a2, long lda2, int 
 size_t gf_ransac_workspace_bytes(int N, int iters);
 int gf_ransac_homography(const float* mkpts0_c, const float* mkpts1_c, const int32_t* counts, int N,
                          int capacity, float scale, const float* scale0, const float* scale1, float thr,
-                         int iters, uint32_t seed, int min_points, int integer_keypoints, float* kp0, float* kp1, double* M,
+                         int iters, uint32_t seed, int lm_iters, int min_points, int integer_keypoints, float* kp0, float* kp1, double* M,
                          float* M_f32, float* Minv_f32, int32_t* valid, uint8_t* keep, void* workspace,
                          size_t workspace_bytes, void* stream);
 

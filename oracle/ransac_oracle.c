@@ -16,7 +16,12 @@
  *   pivoting on the 8x8 system (h33 = 1); score = #points with squared forward transfer error
  *   <= thr^2; best = most inliers, ties -> smallest t; mask = inliers of the best hypothesis;
  *   M = least-squares (normal equations, Hartley-normalised, h33 = 1) refit on those inliers,
- *   falling back to the best hypothesis when the refit is singular.  Fewer than 4 inliers -> none.
+ *   falling back to the best hypothesis when the refit is singular; then `lm_iters` Levenberg-Marquardt
+ *   steps on the inliers' forward transfer error in the 8 free entries (h33 = 1) - the step OpenCV's
+ *   findHomography appends to its RANSAC (LMSolver, 10 iterations; its exact damping schedule is not
+ *   restated: lambda starts at 1e-3, /10 on an accepted step, x10 on a rejected one, damping on the
+ *   diagonal of J^T J).  The mask is the best hypothesis' and is not touched by either refit.
+ *   Fewer than 4 inliers -> none.
  *
  *   gcc -O2 -ffp-contract=off -shared -fPIC -o _build/libransac_oracle.so ransac_oracle.c -lm
  */
@@ -96,9 +101,57 @@ static int is_inlier(const double* h, double x, double y, double u, double v, do
     return dx * dx + dy * dy <= thr2;
 }
 
+/* sum over the inliers of the squared forward transfer error of h (h[8] = 1) */
+static double lm_error(const double* h, const double* p0, const double* p1, const uint8_t* mask, int n) {
+    double e = 0;
+    for (int i = 0; i < n; ++i) if (mask[i]) {
+        const double x = p0[2 * i], y = p0[2 * i + 1];
+        const double w = h[6] * x + h[7] * y + 1.0, iw = 1.0 / w;
+        const double du = (h[0] * x + h[1] * y + h[2]) * iw - p1[2 * i], dv = (h[3] * x + h[4] * y + h[5]) * iw - p1[2 * i + 1];
+        e += du * du + dv * dv;
+    }
+    return e;
+}
+
+/* Levenberg-Marquardt on h[0..7] (h[8] = 1): residuals (u' - u, v' - v) per inlier, u' = (h0 x + h1 y + h2) / w,
+ * v' = (h3 x + h4 y + h5) / w, w = h6 x + h7 y + 1;  d u' / d h = [x, y, 1, 0, 0, 0, -x u', -y u'] / w, likewise v'. */
+static void lm_refine(double* h, const double* p0, const double* p1, const uint8_t* mask, int n, int lm_iters) {
+    double lambda = 1e-3, err = lm_error(h, p0, p1, mask, n);
+    for (int it = 0; it < lm_iters; ++it) {
+        double jtj[64], jtr[8];
+        memset(jtj, 0, sizeof(jtj)); memset(jtr, 0, sizeof(jtr));
+        for (int i = 0; i < n; ++i) if (mask[i]) {
+            const double x = p0[2 * i], y = p0[2 * i + 1];
+            const double w = h[6] * x + h[7] * y + 1.0, iw = 1.0 / w;
+            const double up = (h[0] * x + h[1] * y + h[2]) * iw, vp = (h[3] * x + h[4] * y + h[5]) * iw;
+            const double ju[8] = {x * iw, y * iw, iw, 0, 0, 0, -(x * up) * iw, -(y * up) * iw};
+            const double jv[8] = {0, 0, 0, x * iw, y * iw, iw, -(x * vp) * iw, -(y * vp) * iw};
+            const double ru = up - p1[2 * i], rv = vp - p1[2 * i + 1];
+            for (int a = 0; a < 8; ++a) {
+                for (int b = 0; b < 8; ++b) jtj[a * 8 + b] += ju[a] * ju[b] + jv[a] * jv[b];
+                jtr[a] += ju[a] * ru + jv[a] * rv;
+            }
+        }
+        double A[64], d[8], hn[9];
+        for (int k = 0; k < 64; ++k) A[k] = jtj[k];
+        for (int k = 0; k < 8; ++k) { A[k * 8 + k] = jtj[k * 8 + k] + lambda * jtj[k * 8 + k]; d[k] = -jtr[k]; }
+        if (!solve(A, d, 8)) { lambda = lambda * 10.0; continue; }
+        for (int k = 0; k < 8; ++k) hn[k] = h[k] + d[k];
+        hn[8] = 1.0;
+        const double en = lm_error(hn, p0, p1, mask, n);
+        if (en < err) {
+            for (int k = 0; k < 8; ++k) h[k] = hn[k];
+            err = en;
+            lambda = lambda * 0.1;
+        } else {
+            lambda = lambda * 10.0;
+        }
+    }
+}
+
 /* kp0, kp1: int64 [n,2].  Returns 1 and fills M[9], mask[n] when a model is found, else 0 (mask zeroed). */
 int gf_oracle_ransac(const int64_t* kp0, const int64_t* kp1, int n, double thr, int iters, uint32_t seed,
-                     uint32_t sample, double* M, uint8_t* mask) {
+                     uint32_t sample, int lm_iters, double* M, uint8_t* mask) {
     memset(mask, 0, (size_t)n);
     if (n <= 8) return 0;                         /* geo_module.py:46 */
     double* p0 = (double*)malloc(sizeof(double) * 4 * (size_t)n);
@@ -172,11 +225,13 @@ int gf_oracle_ransac(const int64_t* kp0, const int64_t* kp1, int n, double thr, 
         }
         if (fabs(g[8]) > 1e-12) {
             for (int k = 0; k < 9; ++k) M[k] = g[k] / g[8];
+            if (lm_iters > 0) lm_refine(M, p0, p1, mask, n, lm_iters);
             free(p0);
             return 1;
         }
     }
     memcpy(M, best_h, sizeof(best_h));
+    if (lm_iters > 0) lm_refine(M, p0, p1, mask, n, lm_iters);
     free(p0);
     return 1;
 }

@@ -13,6 +13,7 @@ _lib = None
 
 DEFAULT_ITERS = 1024
 DEFAULT_SEED = 0x5EED
+DEFAULT_LM_ITERS = 10          # OpenCV's findHomography appends 10 Levenberg-Marquardt iterations to its RANSAC
 
 
 def _load():
@@ -23,11 +24,11 @@ def _load():
         _lib = ctypes.CDLL(_SO)
         _lib.gf_oracle_ransac.restype = ctypes.c_int
         _lib.gf_oracle_ransac.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_int,
-                                          ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+                                          ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     return _lib
 
 
-def find_homography(kp0, kp1, thr=8.0, iters=DEFAULT_ITERS, seed=DEFAULT_SEED, sample=0):
+def find_homography(kp0, kp1, thr=8.0, iters=DEFAULT_ITERS, seed=DEFAULT_SEED, sample=0, lm_iters=DEFAULT_LM_ITERS):
     """(kp0 [n,2] int, kp1 [n,2] int) -> (M float64[3,3] | None, mask uint8[n,1]) - the contract of
     cv2.findHomography(kp0, kp1, cv2.RANSAC, thr) as used at model/geo_module.py:47-48."""
     a = np.ascontiguousarray(kp0, dtype=np.int64)
@@ -35,12 +36,12 @@ def find_homography(kp0, kp1, thr=8.0, iters=DEFAULT_ITERS, seed=DEFAULT_SEED, s
     n = len(a)
     M = np.zeros(9, np.float64)
     mask = np.zeros(max(n, 1), np.uint8)
-    ok = _load().gf_oracle_ransac(a.ctypes.data, b.ctypes.data, n, float(thr), int(iters), int(seed), int(sample),
+    ok = _load().gf_oracle_ransac(a.ctypes.data, b.ctypes.data, n, float(thr), int(iters), int(seed), int(sample), int(lm_iters),
                                   M.ctypes.data, mask.ctypes.data)
     return (M.reshape(3, 3) if ok else None), mask[:n, None]
 
 
-def make_homography_fn(thr=8.0, iters=DEFAULT_ITERS, seed=DEFAULT_SEED):
+def make_homography_fn(thr=8.0, iters=DEFAULT_ITERS, seed=DEFAULT_SEED, lm_iters=DEFAULT_LM_ITERS):
     """homography_fn for geoformer_oracle.geoformer_forward: the sample index advances per call the
     way GeoModule.apply_RANSAC walks the batch."""
     state = {'sample': 0}
@@ -48,6 +49,6 @@ def make_homography_fn(thr=8.0, iters=DEFAULT_ITERS, seed=DEFAULT_SEED):
     def fn(kp0, kp1):
         s = state['sample']
         state['sample'] += 1
-        return find_homography(kp0, kp1, thr, iters, seed, s)
+        return find_homography(kp0, kp1, thr, iters, seed, s, lm_iters)
     fn.reset = lambda: state.update(sample=0)
     return fn
