@@ -407,13 +407,17 @@ __global__ __launch_bounds__(256) void ransac_final(RsArgs a) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) hn[k] = sh_lm[k];
             const double en = sq_error(hn);              // (its barriers also fence sh_lm against the next iteration's writer)
-            if (en < err) {
+            if (en < err) {                              // (every thread holds the same en / err: the exits are uniform)
+                const double gain = err - en;
 #pragma unroll
                 for (int k = 0; k < 9; ++k) g[k] = hn[k];
-                err = en;
                 lambda = lambda * 0.1;
+                const bool done = gain <= 1e-10 * err;   // converged: the refit's minimum is usually 2-3 steps away
+                err = en;
+                if (done) break;
             } else {
                 lambda = lambda * 10.0;
+                if (lambda > 1e6) break;
             }
         }
     }

@@ -178,17 +178,27 @@ class GeoFormer(nn.Module):
             data.update({'bs': torch.tensor(data['image0'].size(0)), 'hw0_i': torch.tensor(data['image0'].shape[2:]),
                          'hw1_i': torch.tensor(data['image1'].shape[2:])})
         # 2. position encoding + flatten, coarse LoFTR transformer
-        pe0 = self.pos_encoding(feat_c0, dt)
-        pe1 = self.pos_encoding(feat_c1, dt)
+        pe_both = None
+        if feat_c0.shape == feat_c1.shape:
+            # both position-encoded maps in ONE [2N, L, C] buffer: the two transformers batch the images of a pair and would
+            # otherwise concatenate them (52 MB per 8 pairs, twice per step); nothing writes into it afterwards
+            n, c, h, w = feat_c0.shape
+            pe_both = torch.empty(2 * n, h * w, c, dtype=dt, device=feat_c0.device)
+            pe0 = self.pos_encoding(feat_c0, dt, out=pe_both[:n])
+            pe1 = self.pos_encoding(feat_c1, dt, out=pe_both[n:])
+        else:
+            pe0 = self.pos_encoding(feat_c0, dt)
+            pe1 = self.pos_encoding(feat_c1, dt)
         mask_c0 = mask_c1 = None
         if 'mask0' in data:
             mask_c0, mask_c1 = data['mask0'].flatten(-2), data['mask1'].flatten(-2)
-        feat0, feat1 = self.loftr_coarse(pe0, pe1, mask_c0, mask_c1)
+        feat0, feat1 = self.loftr_coarse(pe0, pe1, mask_c0, mask_c1, both=pe_both)
         # 3. first coarse matching (detector) -> geometry-guided transformer -> second coarse matching
         self.coarse_matching(feat0, feat1, data, mask_c0=mask_c0, mask_c1=mask_c1, lazy=True)
         data['dect_conf_matrix'] = data['conf_matrix']
         same_pe = self.pos_encoding.temp_bug_fix == self.geo_module.pos_encoding.temp_bug_fix
-        geo0, geo1 = self.geo_module(feat_c0, feat_c1, data, pe0 if same_pe else None, pe1 if same_pe else None, dt)
+        geo0, geo1 = self.geo_module(feat_c0, feat_c1, data, pe0 if same_pe else None, pe1 if same_pe else None, dt,
+                                     desc_both=pe_both if same_pe else None)
         raw = self.coarse_matching(geo0, geo1, data, mask_c0=mask_c0, mask_c1=mask_c1, lazy=True)
         data['_static'] = {'raw': raw, 'feat_c0': feat_c0, 'feat_c1': feat_c1, 'feat_f0': feat_f0, 'feat_f1': feat_f1, 'geo0': geo0, 'geo1': geo1,
                            'feat0': feat0, 'feat1': feat1}

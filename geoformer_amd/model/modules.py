@@ -48,9 +48,9 @@ class PositionEncodingSine(nn.Module):
             self._tables[key] = pe.permute(1, 2, 0).contiguous().to(device)
         return self._tables[key]
 
-    def forward(self, x, out_dtype=None):
+    def forward(self, x, out_dtype=None, out=None):
         _, _, h, w = x.shape
-        return ops.pos_encode(x, self.table(h, w, x.device), out_dtype or x.dtype)
+        return ops.pos_encode(x, self.table(h, w, x.device), out_dtype or x.dtype, out)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -178,13 +178,18 @@ class LocalFeatureTransformer(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
-    def forward(self, feat0, feat1, mask0: Optional[torch.Tensor] = None, mask1: Optional[torch.Tensor] = None):
+    def forward(self, feat0, feat1, mask0: Optional[torch.Tensor] = None, mask1: Optional[torch.Tensor] = None,
+                both: Optional[torch.Tensor] = None):
+        """both: optional [2N, L, C] buffer whose halves ARE feat0 and feat1 (read only here): saves the concat."""
         assert self.d_model == feat0.size(2), 'the feature number of src and transformer must be equal'
         same = feat0.shape == feat1.shape
         n = feat0.shape[0]
         # same-shape pairs live in ONE [2N, L, C] buffer: self layers run both images in one batched launch set
         # (same weights, independent rows) and cross layers write their halves in place of a concat
-        both = torch.cat([feat0, feat1], 0) if same else None
+        if not same:
+            both = None
+        elif both is None:
+            both = torch.cat([feat0, feat1], 0)
         mboth = torch.cat([mask0, mask1], 0) if (same and mask0 is not None) else None
         for layer, name in zip(self.layers, self.layer_names):
             if name == 'self':
@@ -263,16 +268,18 @@ class GeoTransformer(nn.Module):
                 nn.init.xavier_uniform_(p)
         self.norm = nn.LayerNorm(d_model)         # present in the checkpoint, never applied (:144-145)
 
-    def forward(self, feat0, feat1, geo):
+    def forward(self, feat0, feat1, geo, both: Optional[torch.Tensor] = None):
         """feat0 [N,L,C], feat1 [N,S,C]; geo = dict(idx0, idx1, nidx, win0, win1, valid) on the device:
         idx*/nidx = tokens at inlier cells (self layers), win1 = cells of image1 seen from each cell of
-        image0 and win0 the converse (cross layers), valid = per-sample 'homography found'."""
+        image0 and win0 the converse (cross layers), valid = per-sample 'homography found'.
+        both: optional [2N, L, C] buffer whose halves ARE feat0 and feat1 (read only here): saves the concat."""
         assert self.d_model == feat0.size(2), 'the feature number of src and transformer must be equal'
         n, L, S = feat0.shape[0], feat0.shape[1], feat1.shape[1]
         same = feat0.shape == feat1.shape
         nk = geo['nidx']
         if same:                     # one [2N, L, C] buffer, as in LocalFeatureTransformer
-            both = torch.cat([feat0, feat1], 0)
+            if both is None:
+                both = torch.cat([feat0, feat1], 0)
             feat0, feat1 = both[:n], both[n:]
         for layer, name in zip(self.layers, self.layer_names):
             if name == 'self':       # keys/values = tokens at inlier cells; a sample without any keeps its features
@@ -375,9 +382,10 @@ class GeoModule(nn.Module):
         geo['ransac'] = rs
         return geo
 
-    def forward(self, cnn_desc0, cnn_desc1, batch, desc_map0=None, desc_map1=None, dtype=None):
+    def forward(self, cnn_desc0, cnn_desc1, batch, desc_map0=None, desc_map1=None, dtype=None, desc_both=None):
         """cnn_desc0/1: raw backbone coarse maps [N,C,h,w]; position encoding is added here
-        (geo_module.py:28-29) unless the caller passes the already encoded [N,L,C] maps."""
+        (geo_module.py:28-29) unless the caller passes the already encoded [N,L,C] maps (desc_both: the [2N,L,C] buffer
+        whose halves they are, if there is one)."""
         n = cnn_desc0.shape[0]
         hw0c, hw1c = tuple(cnn_desc0.shape[2:]), tuple(cnn_desc1.shape[2:])
         if desc_map0 is None:
@@ -385,7 +393,7 @@ class GeoModule(nn.Module):
             desc_map1 = self.pos_encoding(cnn_desc1, dtype)
         geo = self.geometry(batch, n, hw0c, hw1c, cnn_desc0.device)
         batch['_geo_dev'] = geo
-        return self.des_transformer(desc_map0, desc_map1, geo)
+        return self.des_transformer(desc_map0, desc_map1, geo, both=desc_both)
 
 
 # ---------------------------------------------------------------------------------------------

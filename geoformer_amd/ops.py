@@ -92,11 +92,14 @@ def _i32p(t):
     return _p(t)
 
 
-def pos_encode(x, pe_hwc, out_dtype):
-    """a1.  x [N,C,H,W] (any strides, fp32/fp16), pe_hwc fp32 [H,W,C] on the device -> [N, H*W, C]."""
+def pos_encode(x, pe_hwc, out_dtype, out=None):
+    """a1.  x [N,C,H,W] (any strides, fp32/fp16), pe_hwc fp32 [H,W,C] on the device -> [N, H*W, C] (into `out` if given)."""
     _need_cuda(x, pe_hwc)
     N, C, H, W = x.shape
-    out = torch.empty(N, H * W, C, dtype=out_dtype, device=x.device)
+    if out is None:
+        out = torch.empty(N, H * W, C, dtype=out_dtype, device=x.device)
+    elif out.shape != (N, H * W, C) or out.dtype != out_dtype or not out.is_contiguous():
+        raise ValueError('out must be a contiguous [N, H*W, C] tensor of out_dtype')
     sn, sc, sh, sw = x.stride()
     check(_lib.lib().gf_pos_encode(_p(x), _dt(x), sn, sc, sh, sw, _p(pe_hwc), _p(out), _DTYPES[out_dtype], N, C, H, W,
                                    _stream()), 'gf_pos_encode')

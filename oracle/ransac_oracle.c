@@ -19,8 +19,9 @@
  *   falling back to the best hypothesis when the refit is singular; then `lm_iters` Levenberg-Marquardt
  *   steps on the inliers' forward transfer error in the 8 free entries (h33 = 1) - the step OpenCV's
  *   findHomography appends to its RANSAC (LMSolver, 10 iterations; its exact damping schedule is not
- *   restated: lambda starts at 1e-3, /10 on an accepted step, x10 on a rejected one, damping on the
- *   diagonal of J^T J).  The mask is the best hypothesis' and is not touched by either refit.
+*   restated: lambda starts at 1e-3, /10 on an accepted step, x10 on a rejected one, damping on the
+ *   diagonal of J^T J; stops early once an accepted step gains less than 1e-10 of the error or lambda
+ *   passes 1e6).  The mask is the best hypothesis' and is not touched by either refit.
  *   Fewer than 4 inliers -> none.
  *
  *   gcc -O2 -ffp-contract=off -shared -fPIC -o _build/libransac_oracle.so ransac_oracle.c -lm
@@ -140,11 +141,15 @@ static void lm_refine(double* h, const double* p0, const double* p1, const uint8
         hn[8] = 1.0;
         const double en = lm_error(hn, p0, p1, mask, n);
         if (en < err) {
+            const double gain = err - en;
             for (int k = 0; k < 8; ++k) h[k] = hn[k];
-            err = en;
             lambda = lambda * 0.1;
+            const int done = gain <= 1e-10 * err;       /* converged: the refit's minimum is usually 2-3 steps away */
+            err = en;
+            if (done) break;
         } else {
             lambda = lambda * 10.0;
+            if (lambda > 1e6) break;                    /* no downhill step left at any damping worth trying */
         }
     }
 }
