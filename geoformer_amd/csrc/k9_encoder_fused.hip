@@ -109,72 +109,112 @@ __device__ __forceinline__ v16f zero16() { return v16f{0.f, 0.f, 0.f, 0.f, 0.f, 
 template <typename T>
 __device__ __forceinline__ float rnd(float x) { return gf_to_float(gf_from_float<T>(x)); }   // round to the storage type
 
-// one weight block (32 fragments) from the stream into ring slot (b & 1): wave w moves fragments 8w .. 8w+7
-__device__ __forceinline__ void dma_block(const char* wstream, char* smem, int b, int wave, int lane) {
-    char* dst = smem + W_OFF + (b & 1) * WBLK + wave * 8 * FRAG;
-    const char* src = wstream + (size_t)b * WBLK + wave * 8 * FRAG + lane * 16;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * FRAG),
-                                         (__attribute__((address_space(3))) void*)(dst + i * FRAG), 16, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);        // the requests go out before the block's MFMAs, not in between them
-}
-// the next block has landed (every wave waits for its own DMA) and every wave is done reading the current one
-__device__ __forceinline__ void ring_turn() {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-}
-
-// The weight stream is consumed in STEPS of 8 fragments (8 KiB, 8 MFMAs per wave); a block is 4 steps.  The
-// fragments of step i+1 are requested from LDS BEFORE the MFMAs of step i are issued (one wave per SIMD: nothing
-// else hides the LDS latency; left to itself the compiler reads each fragment right in front of the MFMA that needs it),
-// fenced with sched_barrier so the order survives the scheduler.  The ring turns before the LAST step of a block:
-// by then block b+1 has landed and every wave holds block b's last fragments in registers, so block b+2 can be
-// requested into b's slot while 8 MFMAs of block b are still to run.
+// The weight stream: 32-KiB blocks (32 fragments = 4 STEPS of 8 fragments = 8 MFMAs per wave) through a two-slot LDS ring.
+// Wave w moves fragments 8w .. 8w+7 of a block ("pieces" 0..7 of the wave) by LDS-DMA.  Requests behind the stream's end are
+// out of the buffer's range and move nothing (no conditional code inside the step bodies: one basic block per unrolled
+// phase, so the issue order below survives).
 struct Ring {
-    const char* ws;
+    __amdgpu_buffer_rsrc_t rs;   // the stream as a raw buffer of exactly nblk blocks: a request behind its end moves nothing
     char* smem;
     int wave, lane, blk, nblk;
 };
-template <typename Frag>
-__device__ __forceinline__ void load_step(const Ring& g, Frag (&f)[8], int b, int st) {
-    const char* p = g.smem + W_OFF + (b & 1) * WBLK + st * 8 * FRAG + g.lane * 16;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) f[i] = *reinterpret_cast<const Frag*>(p + i * FRAG);
+__device__ __forceinline__ Ring ring_make(const void* wstream, char* smem, int wave, int lane, int nblk) {
+    return Ring{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wstream), 0, nblk * WBLK, 0x00020000), smem, wave, lane, 0, nblk};
 }
-// to be called before the MFMAs of step `st` (0..3) of block g.blk: requests the fragments of the following step
-template <typename Frag>
-__device__ __forceinline__ void fetch_next(Ring& g, Frag (&nx)[8], int st) {
-    // the current step's fragments were requested a whole step (8 MFMAs) ago: retiring them here is free, and it keeps
-    // the outstanding LDS reads below the 4-bit lgkmcnt range (with 18 in flight the compiler falls back to
-    // lgkmcnt(0) AFTER the new requests, exposing their full latency on every second step)
-    __builtin_amdgcn_s_waitcnt(0xC07F);                               // lgkmcnt(0) only
-    if (st == 3) {
-        ring_turn();
+// LDS-DMA as buffer_load_dwordx4 ... lds (MUBUF), not global_load_lds: behind a FLAT-encoded LDS-DMA the compiler's wait
+// insertion treats every LDS counter wait as lgkmcnt(0) for as long as the request is pending (it may touch both address
+// spaces), i.e. for the whole kernel here; behind the MUBUF form it counts (lgkmcnt(7) in front of every MFMA below).  The
+// descriptor and the block offset are scalar: no 64-bit address arithmetic per piece.
+__device__ __forceinline__ void dma_piece(const Ring& g, int b, int i) {
 #if !defined(K9_ABLATE) || K9_ABLATE != 1
-        if (g.blk + 2 < g.nblk) dma_block(g.ws, g.smem, g.blk + 2, g.wave, g.lane);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(g.rs, (__attribute__((address_space(3))) void*)(g.smem + W_OFF + (b & 1) * WBLK + (g.wave * 8 + i) * FRAG), 16,
+                                             g.lane * 16 + g.wave * 8 * FRAG, b * WBLK + i * FRAG, 0, 0);
 #endif
-        if (g.blk + 1 < g.nblk) load_step(g, nx, g.blk + 1, 0);
-        ++g.blk;
+}
+// the next block has landed (every wave waits for its own pieces) and every wave is done reading the current one
+__device__ __forceinline__ void ring_turn() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#if !defined(K9_ABLATE) || K9_ABLATE != 2
+    __builtin_amdgcn_s_barrier();
+#endif
+}
+template <typename Frag>
+__device__ __forceinline__ Frag ring_read(const char* p) {
+#if defined(K9_ABLATE) && K9_ABLATE == 3
+    Frag f; asm volatile("" : "=v"(f)); return f;
+#else
+    return *reinterpret_cast<const Frag*>(p);
+#endif
+}
+// One STEP = the 8 MFMAs `mma(0..7)` on the fragments the previous step fetched, and the fetch of the next step's 8
+// fragments into `nxt`: ONE ds_read_b128 behind each MFMA, waited for by the counted lgkmcnt the compiler derives (a fragment
+// is used 8 reads = 8 MFMAs = 256 cycles after its request).  [Before: two reads per gap in the first half of a step and
+// lgkmcnt(0) at its top - the four waves of a workgroup run in lock-step behind the ring barrier, so their read bursts met
+// at the LDS (2 x 4 waves x 1 KiB per 32-cycle gap = its whole 256 B/clk) and the stalled read issue held back the MFMAs:
+// with the fragment reads compiled out the layer took 120 us instead of 166.]
+// Step 3 of a block turns the ring after its first two MFMAs: block b+1 has landed, every wave holds block b's last fragments
+// in registers; pieces 0..3 of block b+2 are requested behind MFMAs 2..5 of this step, pieces 4..7 behind MFMAs 0..3 of the
+// next (a burst of 8 requests held the MFMA pipe idle for ~270 cycles per block).  xread() issues the step's EXTRA operand
+// reads (token-tile fragments of the next step).
+template <int EXTRA, typename Frag, typename MF, typename XF>
+__device__ __forceinline__ void ring_step(Ring& g, Frag (&nxt)[8], int st, MF mma, XF xread) {
+    if (st != 3) {
+        const char* p = g.smem + W_OFF + (g.blk & 1) * WBLK + (st + 1) * 8 * FRAG + g.lane * 16;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            mma(j);
+            if (st == 0 && j < 4) dma_piece(g, g.blk + 1, 4 + j);
+            nxt[j] = ring_read<Frag>(p + j * FRAG);
+            if (j == 0) xread();
+        }
+        // issue order: MFMA, [DMA request,] fragment read(s) - eight times
+#define K9_GAP(DMA, READS)                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  \
+        if (DMA) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);         \
+        __builtin_amdgcn_sched_group_barrier(0x100, READS, 0);
+        K9_GAP(st == 0, 1 + EXTRA) K9_GAP(st == 0, 1) K9_GAP(st == 0, 1) K9_GAP(st == 0, 1)
+        K9_GAP(false, 1) K9_GAP(false, 1) K9_GAP(false, 1) K9_GAP(false, 1)
+        __builtin_amdgcn_sched_barrier(0);
     } else {
-        load_step(g, nx, g.blk, st + 1);
+        mma(0);
+        mma(1);
+        __builtin_amdgcn_sched_barrier(0);
+        ring_turn();
+        const char* p = g.smem + W_OFF + ((g.blk + 1) & 1) * WBLK + g.lane * 16;
+#pragma unroll
+        for (int j = 2; j < 8; ++j) {
+            mma(j);
+            if (j < 6) dma_piece(g, g.blk + 2, j - 2);
+            if (j < 4) {
+                nxt[2 * (j - 2)] = ring_read<Frag>(p + 2 * (j - 2) * FRAG);
+                nxt[2 * (j - 2) + 1] = ring_read<Frag>(p + (2 * (j - 2) + 1) * FRAG);
+            } else {
+                nxt[j] = ring_read<Frag>(p + j * FRAG);
+            }
+            if (j == 2) xread();
+        }
+        K9_GAP(true, 2 + EXTRA) K9_GAP(true, 2) K9_GAP(true, 1) K9_GAP(true, 1) K9_GAP(false, 1) K9_GAP(false, 1)
+#undef K9_GAP
+        __builtin_amdgcn_sched_barrier(0);
+        ++g.blk;
     }
 }
-// Scheduling of one step (placed after its 8 MFMAs): alternate MFMA / LDS read so that the requests of the next
-// step's fragments ride in the issue slots between this step's MFMAs (an MFMA holds the issue port for 8 of its 32
-// cycles) instead of in front of them, then close the region.  EXTRA = operand fragments read besides the 8 weights.
-template <int EXTRA>
-__device__ __forceinline__ void step_schedule() {
-    // the reads go out in the first half of the step (two per MFMA gap) so that they have at least four MFMAs
-    // (128 cycles) to land before the next step retires them
-    if constexpr (EXTRA > 0) __builtin_amdgcn_sched_group_barrier(0x100, EXTRA, 0);
+// prologue: block 0 whole and the first half of block 1 (its second half goes out in step 0, like every later block's)
+__device__ __forceinline__ void ring_start(const Ring& g) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // two DS reads
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    for (int i = 0; i < 8; ++i) dma_piece(g, 0, i);
     __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void ring_start2(const Ring& g) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_piece(g, 1, i);
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <typename Frag>
+__device__ __forceinline__ void load_step0(const Ring& g, Frag (&f)[8]) {
+    const char* p = g.smem + W_OFF + g.lane * 16;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = ring_read<Frag>(p + i * FRAG);
 }
 
 // x tile -> LDS: [kc][row][128 B] with the 16-B chunk index XORed with (row>>1)&7 (conflict-free ds_read_b128)
@@ -198,11 +238,11 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
     const int n = blockIdx.x / a.tiles, tile = blockIdx.x - n * a.tiles;
     const int t0 = tile * TM;                                         // first token of the tile inside image n
     const T* xg = (const T*)a.x + (size_t)n * a.L * a.ldx;
-    const char* ws = (const char*)a.wstream;
     constexpr int NBLK = ATTN ? 32 : 28;
     float* vec = reinterpret_cast<float*>(smem + VEC_OFF);
     K9_T(0);
-    dma_block(ws, smem, 0, wave, lane);
+    Ring ring = ring_make(a.wstream, smem, wave, lane, NBLK);
+    ring_start(ring);
     load_tile<T>(xg, a.ldx, t0, a.L, smem, X_OFF, tid);
 #pragma unroll
     for (int i = 0; i < 4; ++i) vec[i * C + tid] = a.ln[i * C + tid];
@@ -260,18 +300,17 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
             __syncthreads();
         }
     }
-    // blocks 0 and 1 are requested; the first turn waits for block 0 only (the 8 youngest requests are block 1's)
-    dma_block(ws, smem, 1, wave, lane);
-    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    // block 0 and the first half of block 1 are requested; wait for block 0 only (the 4 youngest requests are block 1's)
+    ring_start2(ring);
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     K9_T(1);
     const int tok = t0 + wave * 32 + lr;                              // this lane's token (accumulator column)
     const char* xrow = smem + X_OFF;
     const int myrow = wave * 32 + lr;
-    Ring ring{ws, smem, wave, lane, 0, NBLK};
     Frag fa[8], fb[8];                                                // fragments of the current / next step, alternating
-    load_step(ring, fa, 0, 0);
+    load_step0(ring, fa);
     // token-tile operand of 16-deep k-step ks (0..15)
     auto xfrag = [&](int ks) { return *reinterpret_cast<const Frag*>(xrow + (ks >> 2) * 16384 + gf_lds_off(myrow, 2 * (ks & 3) + h2)); };
 
@@ -285,13 +324,8 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
         for (int st = 0; st < 16; ++st) {
             Frag (&cur)[8] = (st & 1) ? fb : fa;
             Frag (&nxt)[8] = (st & 1) ? fa : fb;
-            // fetch_next first: its wait retires this step's fragments (requested a step ago); the token fragment of the NEXT
-            // step is requested behind it, so that no full lgkmcnt drain follows a read that was just issued
-            fetch_next(ring, nxt, st & 3);
-            const Frag tn = xfrag(st < 15 ? st + 1 : 15);
-#pragma unroll
-            for (int nb = 0; nb < 8; ++nb) Mm::mma(cur[nb], tf, q[nb]);
-            step_schedule<1>();
+            Frag tn;
+            ring_step<1>(ring, nxt, st & 3, [&](int nb) { Mm::mma(cur[nb], tf, q[nb]); }, [&] { tn = xfrag(st < 15 ? st + 1 : 15); });
             tf = tn;
         }
         K9_T(2);
@@ -333,11 +367,8 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
     for (int st = 0; st < 16; ++st) {
         Frag (&cur)[8] = (st & 1) ? fb : fa;
         Frag (&nxt)[8] = (st & 1) ? fa : fb;
-        fetch_next(ring, nxt, st & 3);
         const Frag bf = mfrag[st >> 1][st & 1];
-#pragma unroll
-        for (int nb = 0; nb < 8; ++nb) Mm::mma(cur[nb], bf, m[nb]);
-        step_schedule<0>();
+        ring_step<0>(ring, nxt, st & 3, [&](int nb) { Mm::mma(cur[nb], bf, m[nb]); }, [] {});
     }
     // nn.LayerNorm over the 256 channels of the lane's token, statistics in fp32; the other lane half holds the other
     // 128 channels.  One pass over the accumulators (they live in AGPRs: every use is a register move): sum and sum of
@@ -396,13 +427,9 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
         for (int st = 0; st < 8; ++st) {
             Frag (&cur)[8] = (st & 1) ? fb : fa;
             Frag (&nxt)[8] = (st & 1) ? fa : fb;
-            fetch_next(ring, nxt, st & 3);
-            const Frag n0 = xfrag(st < 7 ? 2 * st + 2 : 14), n1 = xfrag(st < 7 ? 2 * st + 3 : 15);
-#pragma unroll
-            for (int hb = 0; hb < 4; ++hb) Mm::mma(cur[hb], t0f, hd[hb]);
-#pragma unroll
-            for (int hb = 0; hb < 4; ++hb) Mm::mma(cur[4 + hb], t1f, hd[hb]);
-            step_schedule<2>();
+            Frag n0, n1;
+            ring_step<2>(ring, nxt, st & 3, [&](int j) { Mm::mma(cur[j], j < 4 ? t0f : t1f, hd[j & 3]); },
+                         [&] { n0 = xfrag(st < 7 ? 2 * st + 2 : 14); n1 = xfrag(st < 7 ? 2 * st + 3 : 15); });
             t0f = n0;
             t1f = n1;
         }
@@ -411,12 +438,7 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
         for (int st = 0; st < 8; ++st) {
             Frag (&cur)[8] = (st & 1) ? fb : fa;
             Frag (&nxt)[8] = (st & 1) ? fa : fb;
-            fetch_next(ring, nxt, st & 3);
-#pragma unroll
-            for (int hb = 0; hb < 4; ++hb) Mm::mma(cur[hb], mfrag[st][0], hd[hb]);
-#pragma unroll
-            for (int hb = 0; hb < 4; ++hb) Mm::mma(cur[4 + hb], mfrag[st][1], hd[hb]);
-            step_schedule<0>();
+            ring_step<0>(ring, nxt, st & 3, [&](int j) { Mm::mma(cur[j], mfrag[st][j >> 2], hd[j & 3]); }, [] {});
         }
         if (sl == 0) K9_T(11);
         Frag hfrag[4][2];
@@ -439,11 +461,8 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
         for (int st = 0; st < 8; ++st) {                                // out += W_2[:, 128 sl + 16 st .. + 15] hid
             Frag (&cur)[8] = (st & 1) ? fb : fa;
             Frag (&nxt)[8] = (st & 1) ? fa : fb;
-            fetch_next(ring, nxt, st & 3);
             const Frag bf = hfrag[st >> 1][st & 1];
-#pragma unroll
-            for (int nb = 0; nb < 8; ++nb) Mm::mma(cur[nb], bf, o[nb]);
-            step_schedule<0>();
+            ring_step<0>(ring, nxt, st & 3, [&](int nb) { Mm::mma(cur[nb], bf, o[nb]); }, [] {});
         }
     }
 
@@ -454,7 +473,11 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
     K9_T(8);
     // the predicate is per sample (flag_rows is a multiple of L in every caller): read it once, wave-uniformly
     const bool keep = a.flag == nullptr || __builtin_amdgcn_readfirstlane(a.flag[((size_t)n * a.L + t0) / a.flag_rows]) != 0;
-    char* ot = smem + W_OFF + wave * 32 * SLAB_RS;                      // the ring is idle now (every wave passed the last turn)
+    // the ring is idle now: every wave passed the last turn, which also waited for the (clamped, never read) requests behind the
+    // stream's end - except the four of the last block's step 0 and of its turn: drain them before the slab takes the ring's place
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    char* ot = smem + W_OFF + wave * 32 * SLAB_RS;
     T* og = (T*)a.out + (size_t)n * a.L * a.ldo;
     // one straight-line body per (layer kept?, tile inside the sequence?): as run-time branches inside the loops every join
     // costs a conservative wait on the stores of the first channel half
@@ -525,23 +548,22 @@ __global__ __launch_bounds__(256, 1) void enc_kv_state(EncArgs a) {
     const int n = blockIdx.x / a.tiles, tile = blockIdx.x - n * a.tiles;
     const int t0 = tile * TM;
     const T* xg = (const T*)a.x + (size_t)n * a.S * a.ldx;
-    const char* ws = (const char*)a.wstream;
     constexpr int NBLK = 8;
     K9_T(0);
-    dma_block(ws, smem, 0, wave, lane);
+    Ring ring = ring_make(a.wstream, smem, wave, lane, NBLK);
+    ring_start(ring);
     load_tile<T>(xg, a.ldx, t0, a.S, smem, X_OFF, tid);
     // validity of the wave's 32 tokens as a bit mask (tail of the image, padding mask of linear_attention.py:37-39)
     const int mytok = t0 + wave * 32 + lr;
     const bool ok = mytok < a.S && (a.kv_mask == nullptr || a.kv_mask[(size_t)n * a.S + min(mytok, a.S - 1)] != 0);
     const unsigned valid = (unsigned)__ballot(ok && h2 == 0);
-    dma_block(ws, smem, 1, wave, lane);
-    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");      // block 0 and the tile; block 1 stays in flight
+    ring_start2(ring);
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");      // block 0 and the tile; block 1's first half stays in flight
     __builtin_amdgcn_s_barrier();
     K9_T(1);
     const int myrow = wave * 32 + lr;
-    Ring ring{ws, smem, wave, lane, 0, NBLK};
     Frag fa[8], fb[8];
-    load_step(ring, fa, 0, 0);
+    load_step0(ring, fa);
     auto xfrag = [&](int ks) { return *reinterpret_cast<const Frag*>(smem + X_OFF + (ks >> 2) * 16384 + gf_lds_off(myrow, 2 * (ks & 3) + h2)); };
     auto project = [&](v16f (&acc)[8]) {                               // acc = src tile x W^T: 16 steps (k-step = step)
 #pragma unroll
@@ -553,11 +575,8 @@ __global__ __launch_bounds__(256, 1) void enc_kv_state(EncArgs a) {
         for (int st = 0; st < 16; ++st) {
             Frag (&cur)[8] = (st & 1) ? fb : fa;
             Frag (&nxt)[8] = (st & 1) ? fa : fb;
-            fetch_next(ring, nxt, st & 3);                             // (order: see enc_layer's q product)
-            const Frag tn = xfrag(st < 15 ? st + 1 : 15);
-#pragma unroll
-            for (int nb = 0; nb < 8; ++nb) Mm::mma(tf, cur[nb], acc[nb]);
-            step_schedule<1>();
+            Frag tn;
+            ring_step<1>(ring, nxt, st & 3, [&](int nb) { Mm::mma(tf, cur[nb], acc[nb]); }, [&] { tn = xfrag(st < 15 ? st + 1 : 15); });
             tf = tn;
         }
     };
@@ -606,6 +625,7 @@ __global__ __launch_bounds__(256, 1) void enc_kv_state(EncArgs a) {
     // (a tree that ended with ONE wave adding and storing 33 KB took 9 of the kernel's 35 thousand cycles)
     constexpr int KVN = 8 * 16 * 64, SLOT = KVN + 8 * 64;              // floats per wave: kv[hh][r][lane] | ksum[hh][lane]
     float* red = reinterpret_cast<float*>(smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the (clamped) requests behind the stream's end have landed
     __syncthreads();
 #pragma unroll
     for (int hh = 0; hh < 8; ++hh) {
