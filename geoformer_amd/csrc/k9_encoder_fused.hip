@@ -156,8 +156,15 @@ __device__ __forceinline__ Frag ring_read(const char* p) {
 // in registers; pieces 0..3 of block b+2 are requested behind MFMAs 2..5 of this step, pieces 4..7 behind MFMAs 0..3 of the
 // next (a burst of 8 requests held the MFMA pipe idle for ~270 cycles per block).  xread() issues the step's EXTRA operand
 // reads (token-tile fragments of the next step).
+// the fragment MFMA j has just consumed stays allocated until the next read is out: the read lands in the register of the
+// MFMA BEFORE it (issued a gap earlier, operands long read) instead of overwriting the operand of an MFMA still in the queue
+#if defined(K9_NOKEEP)
+#define K9_KEEP(f)
+#else
+#define K9_KEEP(f) asm volatile("" ::"v"(f))
+#endif
 template <int EXTRA, typename Frag, typename MF, typename XF>
-__device__ __forceinline__ void ring_step(Ring& g, Frag (&nxt)[8], int st, MF mma, XF xread) {
+__device__ __forceinline__ void ring_step(Ring& g, Frag (&cur)[8], Frag (&nxt)[8], int st, MF mma, XF xread) {
     if (st != 3) {
         const char* p = g.smem + W_OFF + (g.blk & 1) * WBLK + (st + 1) * 8 * FRAG + g.lane * 16;
 #pragma unroll
@@ -165,6 +172,7 @@ __device__ __forceinline__ void ring_step(Ring& g, Frag (&nxt)[8], int st, MF mm
             mma(j);
             if (st == 0 && j < 4) dma_piece(g, g.blk + 1, 4 + j);
             nxt[j] = ring_read<Frag>(p + j * FRAG);
+            K9_KEEP(cur[j]);
             if (j == 0) xread();
         }
         // issue order: MFMA, [DMA request,] fragment read(s) - eight times
@@ -191,6 +199,7 @@ __device__ __forceinline__ void ring_step(Ring& g, Frag (&nxt)[8], int st, MF mm
             } else {
                 nxt[j] = ring_read<Frag>(p + j * FRAG);
             }
+            K9_KEEP(cur[j]);
             if (j == 2) xread();
         }
         K9_GAP(true, 2 + EXTRA) K9_GAP(true, 2) K9_GAP(true, 1) K9_GAP(true, 1) K9_GAP(false, 1) K9_GAP(false, 1)
@@ -243,7 +252,9 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
     K9_T(0);
     Ring ring = ring_make(a.wstream, smem, wave, lane, NBLK);
     ring_start(ring);
+#if !defined(K9_ABLATE) || K9_ABLATE != 7
     load_tile<T>(xg, a.ldx, t0, a.L, smem, X_OFF, tid);
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) vec[i * C + tid] = a.ln[i * C + tid];
     if constexpr (ATTN) {
@@ -325,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
             Frag (&cur)[8] = (st & 1) ? fb : fa;
             Frag (&nxt)[8] = (st & 1) ? fa : fb;
             Frag tn;
-            ring_step<1>(ring, nxt, st & 3, [&](int nb) { Mm::mma(cur[nb], tf, q[nb]); }, [&] { tn = xfrag(st < 15 ? st + 1 : 15); });
+            ring_step<1>(ring, cur, nxt, st & 3, [&](int nb) { Mm::mma(cur[nb], tf, q[nb]); }, [&] { tn = xfrag(st < 15 ? st + 1 : 15); });
             tf = tn;
         }
         K9_T(2);
@@ -333,29 +344,54 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
         const float qmul = (a.q_mask == nullptr || a.q_mask[(size_t)n * a.L + min(tok, a.L - 1)] != 0) ? 1.f : 0.f;
         const float eps_s = a.attn_eps / (float)a.S;
         const float* ks = reinterpret_cast<const float*>(smem + KS_OFF);
+        // Two-stage pipeline over the heads (same arithmetic, same order per head): stage A(h) = phi, denominator and the two
+        // state MFMAs of head h, stage B(h) = normalise and pack; B(h-1) runs behind A(h), under A(h)'s MFMAs, and the LDS operands
+        // of head h+1 (Ksum rows, state fragments) are requested a head ahead - one wave per SIMD: nothing else hides their latency.
+        struct HeadOps { v4f k4[4]; Frag kv0, kv1; };
+        auto head_ops = [&](int hh) {
+            HeadOps o;
 #pragma unroll
-        for (int hh = 0; hh < 8; ++hh) {
+            for (int g = 0; g < 4; ++g) o.k4[g] = *reinterpret_cast<const v4f*>(ks + hh * D + 8 * g + 4 * h2);   // rows 8g + 4 h2 + {0..3} of the head
+            o.kv0 = *reinterpret_cast<const Frag*>(smem + KV_OFF + (hh * 2) * FRAG + lane * 16);
+            o.kv1 = *reinterpret_cast<const Frag*>(smem + KV_OFF + (hh * 2 + 1) * FRAG + lane * 16);
+            return o;
+        };
+        v16f num[2];
+        float den[2];
+        auto stage_a = [&](int hh, const HeadOps& ho) {
             float pq[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) pq[r] = rnd<T>(phi(q[hh][r]) * qmul);
-            float den = 0.f;
+            float d = 0.f;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {                               // rows 8g + 4 h2 + {0..3} of the head
-                const v4f k4 = *reinterpret_cast<const v4f*>(ks + hh * D + 8 * g + 4 * h2);
-                den += pq[4 * g] * k4.x + pq[4 * g + 1] * k4.y + pq[4 * g + 2] * k4.z + pq[4 * g + 3] * k4.w;
-            }
-            den += __shfl_xor(den, 32, 64);
-            v16f num = zero16();
+            for (int g = 0; g < 4; ++g)
+                d += pq[4 * g] * ho.k4[g].x + pq[4 * g + 1] * ho.k4[g].y + pq[4 * g + 2] * ho.k4[g].z + pq[4 * g + 3] * ho.k4[g].w;
+            den[hh & 1] = d;
+            num[hh & 1] = zero16();
             const Frag p0 = pack8<T>(pq[0], pq[1], pq[2], pq[3], pq[4], pq[5], pq[6], pq[7]);
             const Frag p1 = pack8<T>(pq[8], pq[9], pq[10], pq[11], pq[12], pq[13], pq[14], pq[15]);
-            Mm::mma(*reinterpret_cast<const Frag*>(smem + KV_OFF + (hh * 2) * FRAG + lane * 16), p0, num);
-            Mm::mma(*reinterpret_cast<const Frag*>(smem + KV_OFF + (hh * 2 + 1) * FRAG + lane * 16), p1, num);
-            const float z = __builtin_amdgcn_rcpf(den + eps_s);
+            Mm::mma(ho.kv0, p0, num[hh & 1]);
+            Mm::mma(ho.kv1, p1, num[hh & 1]);
+        };
+        auto stage_b = [&](int hh) {
+            float d = den[hh & 1];
+            d += __shfl_xor(d, 32, 64);
+            const float z = __builtin_amdgcn_rcpf(d + eps_s);
+            v16f& nm = num[hh & 1];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) num[r] *= z;
-            mfrag[hh][0] = pack_step<T>(num, 0);
-            mfrag[hh][1] = pack_step<T>(num, 1);
+            for (int r = 0; r < 16; ++r) nm[r] *= z;
+            mfrag[hh][0] = pack_step<T>(nm, 0);
+            mfrag[hh][1] = pack_step<T>(nm, 1);
+        };
+        HeadOps hops[2];
+        hops[0] = head_ops(0);
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) {
+            if (hh < 7) hops[(hh + 1) & 1] = head_ops(hh + 1);
+            stage_a(hh, hops[hh & 1]);
+            if (hh > 0) stage_b(hh - 1);
         }
+        stage_b(7);
     }
 
     K9_T(3);
@@ -368,7 +404,7 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
         Frag (&cur)[8] = (st & 1) ? fb : fa;
         Frag (&nxt)[8] = (st & 1) ? fa : fb;
         const Frag bf = mfrag[st >> 1][st & 1];
-        ring_step<0>(ring, nxt, st & 3, [&](int nb) { Mm::mma(cur[nb], bf, m[nb]); }, [] {});
+        ring_step<0>(ring, cur, nxt, st & 3, [&](int nb) { Mm::mma(cur[nb], bf, m[nb]); }, [] {});
     }
     // nn.LayerNorm over the 256 channels of the lane's token, statistics in fp32; the other lane half holds the other
     // 128 channels.  One pass over the accumulators (they live in AGPRs: every use is a register move): sum and sum of
@@ -388,24 +424,39 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
         mean = s * (1.0f / C);
         rstd = 1.0f / sqrtf(fmaxf(qd - s * mean, 0.f) * (1.0f / C) + eps);
     };
-    // the four normalised values of registers 4g .. 4g+3 of tile nb (channels nb*32 + 8g + 4 h2 + {0..3})
-    auto ln_apply = [&](const v16f& t, int nb, int g, const float* gamma, const float* beta, float mean, float rstd) {
-        const int c = nb * 32 + 8 * g + 4 * h2;
-        const v4f ga = *reinterpret_cast<const v4f*>(gamma + c), be = *reinterpret_cast<const v4f*>(beta + c);
-        return v4f{(t[4 * g] - mean) * rstd * ga.x + be.x, (t[4 * g + 1] - mean) * rstd * ga.y + be.y,
-                   (t[4 * g + 2] - mean) * rstd * ga.z + be.z, (t[4 * g + 3] - mean) * rstd * ga.w + be.w};
+    // gamma / beta of tile nb for this lane half (channels nb*32 + 8g + 4 h2 + {0..3}); requested a tile ahead of their use
+    struct LnOps { v4f ga[4], be[4]; };
+    auto ln_ops = [&](const float* gamma, const float* beta, int nb, int hl) {
+        LnOps o;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            o.ga[g] = *reinterpret_cast<const v4f*>(gamma + nb * 32 + 8 * g + 4 * hl);
+            o.be[g] = *reinterpret_cast<const v4f*>(beta + nb * 32 + 8 * g + 4 * hl);
+        }
+        return o;
+    };
+    // the four normalised values of registers 4g .. 4g+3 of a tile
+    auto ln_apply = [&](const v16f& t, int g, const LnOps& p, float mean, float rstd) {
+        return v4f{(t[4 * g] - mean) * rstd * p.ga[g].x + p.be[g].x, (t[4 * g + 1] - mean) * rstd * p.ga[g].y + p.be[g].y,
+                   (t[4 * g + 2] - mean) * rstd * p.ga[g].z + p.be[g].z, (t[4 * g + 3] - mean) * rstd * p.ga[g].w + p.be[g].w};
     };
     K9_T(4);
     {
         float mean, rstd;
         ln_stats(m, a.eps1, mean, rstd);
+        {
+            LnOps lp[2];
+            lp[0] = ln_ops(vec, vec + C, 0, h2);
 #pragma unroll
-        for (int nb = 0; nb < 8; ++nb)
+            for (int nb = 0; nb < 8; ++nb) {
+                if (nb < 7) lp[(nb + 1) & 1] = ln_ops(vec, vec + C, nb + 1, h2);
 #pragma unroll
-            for (int sx = 0; sx < 2; ++sx) {
-                const v4f lo = ln_apply(m[nb], nb, 2 * sx, vec, vec + C, mean, rstd), hi = ln_apply(m[nb], nb, 2 * sx + 1, vec, vec + C, mean, rstd);
-                mfrag[nb][sx] = pack8<T>(lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w);
+                for (int sx = 0; sx < 2; ++sx) {
+                    const v4f lo = ln_apply(m[nb], 2 * sx, lp[nb & 1], mean, rstd), hi = ln_apply(m[nb], 2 * sx + 1, lp[nb & 1], mean, rstd);
+                    mfrag[nb][sx] = pack8<T>(lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w);
+                }
             }
+        }
     }
 
     K9_T(5);
@@ -428,19 +479,21 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
             Frag (&cur)[8] = (st & 1) ? fb : fa;
             Frag (&nxt)[8] = (st & 1) ? fa : fb;
             Frag n0, n1;
-            ring_step<2>(ring, nxt, st & 3, [&](int j) { Mm::mma(cur[j], j < 4 ? t0f : t1f, hd[j & 3]); },
+            ring_step<2>(ring, cur, nxt, st & 3, [&](int j) { Mm::mma(cur[j], j < 4 ? t0f : t1f, hd[j & 3]); },
                          [&] { n0 = xfrag(st < 7 ? 2 * st + 2 : 14); n1 = xfrag(st < 7 ? 2 * st + 3 : 15); });
             t0f = n0;
             t1f = n1;
         }
         if (sl == 0) K9_T(10);
+        if (sl == 1) K9_T(13);
 #pragma unroll
         for (int st = 0; st < 8; ++st) {
             Frag (&cur)[8] = (st & 1) ? fb : fa;
             Frag (&nxt)[8] = (st & 1) ? fa : fb;
-            ring_step<0>(ring, nxt, st & 3, [&](int j) { Mm::mma(cur[j], mfrag[st][j >> 2], hd[j & 3]); }, [] {});
+            ring_step<0>(ring, cur, nxt, st & 3, [&](int j) { Mm::mma(cur[j], mfrag[st][j >> 2], hd[j & 3]); }, [] {});
         }
         if (sl == 0) K9_T(11);
+        if (sl == 1) K9_T(14);
         Frag hfrag[4][2];
 #pragma unroll
         for (int hb = 0; hb < 4; ++hb) {
@@ -457,18 +510,28 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
             }
         }
         if (sl == 0) K9_T(12);
+        if (sl == 1) K9_T(15);
 #pragma unroll
         for (int st = 0; st < 8; ++st) {                                // out += W_2[:, 128 sl + 16 st .. + 15] hid
             Frag (&cur)[8] = (st & 1) ? fb : fa;
             Frag (&nxt)[8] = (st & 1) ? fa : fb;
             const Frag bf = hfrag[st >> 1][st & 1];
-            ring_step<0>(ring, nxt, st & 3, [&](int nb) { Mm::mma(cur[nb], bf, o[nb]); }, [] {});
+            ring_step<0>(ring, cur, nxt, st & 3, [&](int nb) { Mm::mma(cur[nb], bf, o[nb]); }, [] {});
         }
     }
 
     K9_T(7);
     // ---------------- out = x + LN2(.) (one rounding), per-sample skip predicate, row-contiguous stores through a slab
     float mean2, rstd2;
+#if defined(K9_ABLATE) && K9_ABLATE == 6
+    {
+        float sacc = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) sacc += o[nb][0] + o[nb][15];
+        if (sacc == 1.2345f) ((float*)a.out)[threadIdx.x] = sacc;
+        return;
+    }
+#endif
     ln_stats(o, a.eps2, mean2, rstd2);
     K9_T(8);
     // the predicate is per sample (flag_rows is a multiple of L in every caller): read it once, wave-uniformly
@@ -483,41 +546,58 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
     // costs a conservative wait on the stores of the first channel half
     auto finish = [&](auto keep_c, auto full_c) {
         constexpr bool KEEP = decltype(keep_c)::value, FULL = decltype(full_c)::value;
+        typedef T v4t __attribute__((ext_vector_type(4)));
         int el = lane;
         asm volatile("" : "+v"(el));                                    // slab / row offsets recomputed here, not carried through the layer
-        const int erow = wave * 32 + (el & 31), eh2 = el >> 5, prow = el >> 4, pch = el & 15;
+        const int er = el & 31, eh2 = el >> 5, erow = wave * 32 + er, prow = el >> 4, pch = el & 15;
+        // residual x[row][nb*32 + 8g + 4 eh2 ..+3]: 16-B chunk 4 nb + g of the row = k-chunk nb >> 1, slot (4 (nb & 1) + g) ^ swizzle:
+        // eight lane-constant slot addresses, everything else is an immediate offset
+        int xs[8];
 #pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {
+        for (int k = 0; k < 8; ++k) xs[k] = X_OFF + gf_lds_off(erow, k) + eh2 * 8;
+        char* slw = ot + er * SLAB_RS + eh2 * 8;
+        struct FinOps { v4t x[4]; LnOps ln; };
+        auto fin_ops = [&](int nb) {
+            FinOps o;
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4)
+            for (int g = 0; g < 4; ++g) o.x[g] = *reinterpret_cast<const v4t*>(smem + xs[4 * (nb & 1) + g] + (nb >> 1) * 16384);
+            if constexpr (KEEP) o.ln = ln_ops(vec + 2 * C, vec + 3 * C, nb, eh2);
+            return o;
+        };
+        FinOps fo[2];
+        fo[0] = fin_ops(0);                                             // the operands of tile nb + 1 are requested before tile nb is computed
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int nb = hb * 4 + q4, c = nb * 32 + 8 * g + 4 * eh2, ch = c >> 3;
-                    typedef T v4t __attribute__((ext_vector_type(4)));
-                    const v4t xv = *reinterpret_cast<const v4t*>(xrow + (ch >> 3) * 16384 + gf_lds_off(erow, ch & 7) + (c & 7) * 2);
-                    v4t ov = xv;
-                    if constexpr (KEEP) {
-                        const int cc = nb * 32 + 8 * g + 4 * eh2;
-                        const v4f ga = *reinterpret_cast<const v4f*>(vec + 2 * C + cc), be = *reinterpret_cast<const v4f*>(vec + 3 * C + cc);
-                        const v16f& t = o[nb];
-                        ov[0] = gf_from_float<T>(gf_to_float(xv[0]) + ((t[4 * g] - mean2) * rstd2 * ga.x + be.x));
-                        ov[1] = gf_from_float<T>(gf_to_float(xv[1]) + ((t[4 * g + 1] - mean2) * rstd2 * ga.y + be.y));
-                        ov[2] = gf_from_float<T>(gf_to_float(xv[2]) + ((t[4 * g + 2] - mean2) * rstd2 * ga.z + be.z));
-                        ov[3] = gf_from_float<T>(gf_to_float(xv[3]) + ((t[4 * g + 3] - mean2) * rstd2 * ga.w + be.w));
-                    }
-                    *reinterpret_cast<v4t*>(ot + (el & 31) * SLAB_RS + (q4 * 32 + 8 * g + 4 * eh2) * 2) = ov;
+        for (int nb = 0; nb < 8; ++nb) {
+            if (nb < 7) fo[(nb + 1) & 1] = fin_ops(nb + 1);
+            const FinOps& p = fo[nb & 1];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                v4t ov = p.x[g];
+                if constexpr (KEEP) {
+                    const v4f y = ln_apply(o[nb], g, p.ln, mean2, rstd2);
+                    ov[0] = gf_from_float<T>(gf_to_float(p.x[g][0]) + y.x);
+                    ov[1] = gf_from_float<T>(gf_to_float(p.x[g][1]) + y.y);
+                    ov[2] = gf_from_float<T>(gf_to_float(p.x[g][2]) + y.z);
+                    ov[3] = gf_from_float<T>(gf_to_float(p.x[g][3]) + y.w);
                 }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int row = it * 4 + prow, tg = t0 + wave * 32 + row;
-                if (FULL || tg < a.L)
-                    *reinterpret_cast<v4u*>(og + (size_t)tg * a.ldo + hb * 128 + pch * 8) = *reinterpret_cast<const v4u*>(ot + row * SLAB_RS + pch * 16);
+                *reinterpret_cast<v4t*>(slw + ((nb & 3) * 32 + 8 * g) * 2) = ov;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            if ((nb & 3) == 3) {                                        // a 128-channel half is in the slab: row-contiguous 16-B stores
+                const int hb = nb >> 2;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                v4u rows[8];
+#pragma unroll
+                for (int it = 0; it < 8; ++it) rows[it] = *reinterpret_cast<const v4u*>(ot + (it * 4 + prow) * SLAB_RS + pch * 16);
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int tg = t0 + wave * 32 + it * 4 + prow;
+                    if (FULL || tg < a.L) *reinterpret_cast<v4u*>(og + (size_t)tg * a.ldo + hb * 128 + pch * 8) = rows[it];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     };
     using std::integral_constant;
@@ -576,7 +656,7 @@ __global__ __launch_bounds__(256, 1) void enc_kv_state(EncArgs a) {
             Frag (&cur)[8] = (st & 1) ? fb : fa;
             Frag (&nxt)[8] = (st & 1) ? fa : fb;
             Frag tn;
-            ring_step<1>(ring, nxt, st & 3, [&](int nb) { Mm::mma(tf, cur[nb], acc[nb]); }, [&] { tn = xfrag(st < 15 ? st + 1 : 15); });
+            ring_step<1>(ring, cur, nxt, st & 3, [&](int nb) { Mm::mma(tf, cur[nb], acc[nb]); }, [&] { tn = xfrag(st < 15 ? st + 1 : 15); });
             tf = tn;
         }
     };

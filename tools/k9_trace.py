@@ -41,6 +41,7 @@ d = t[:, 0, :10] - t[:, 0, :1]
 print('enc_layer  phases: 0 start | 1 prologue done | 2 q done | 3 attention done | 4 merge done | 5 LN1+pack | 6 slice 0 done | 7 slices done | 8 LN2 | 9 stored')
 print('  median offsets:', np.median(d, axis=0).astype(int).tolist())
 print('  slice 0 detail (x half done | m half done | activation packed), offsets from LN1+pack:', (np.median(t[:, 0, 10:13] - t[:, 0, 5:6], axis=0)).astype(int).tolist())
+print('  slice 1 detail (same three), offsets from slice 0 done:', (np.median(t[:, 0, 13:16] - t[:, 0, 6:7], axis=0)).astype(int).tolist())
 print('  wave0 total p10/p50/p90:', np.percentile(d[:, 9], [10, 50, 90]).astype(int).tolist(), ' kernel span', int(t[:, :, 9].max() - t[:, :, 0].min()))
 starts = np.sort(t[:, 0, 0] - t[:, :, 0].min())
-print('  WG start times (sorted) at 0/256/512/768/799:', [int(starts[i]) for i in (0, 256, 512, 768, 799)])
+print('  WG start times (sorted) at 0/256/512/768/799:', [int(starts[min(i, len(starts) - 1)]) for i in (0, 256, 512, 768, 799)])
