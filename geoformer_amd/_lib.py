@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgeoformer_hip.so')
+LIB_PATH = os.environ.get('GF_LIB_PATH') or os.path.join(_HERE, 'libgeoformer_hip.so')   # GF_LIB_PATH: A/B timing of two builds (tools/)
 
 GF_F32, GF_F16, GF_BF16 = 0, 1, 2
 

@@ -81,13 +81,16 @@ struct EncArgs {
     float* part;            // [N][tiles][C*D + C]
 };
 
+// eight fp32 values -> one 16-byte operand; converted in pairs (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32, round to nearest even:
+// element by element the compiler sometimes emits the single conversion + a byte permute)
 template <typename T>
 __device__ __forceinline__ typename Mma32<T>::Frag pack8(float a0, float a1, float a2, float a3, float a4, float a5, float a6,
                                                           float a7) {
-    typename Mma32<T>::Frag f;
-    f[0] = gf_from_float<T>(a0); f[1] = gf_from_float<T>(a1); f[2] = gf_from_float<T>(a2); f[3] = gf_from_float<T>(a3);
-    f[4] = gf_from_float<T>(a4); f[5] = gf_from_float<T>(a5); f[6] = gf_from_float<T>(a6); f[7] = gf_from_float<T>(a7);
-    return f;
+    typedef T t2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const t2 p0 = __builtin_convertvector(f2{a0, a1}, t2), p1 = __builtin_convertvector(f2{a2, a3}, t2);
+    const t2 p2 = __builtin_convertvector(f2{a4, a5}, t2), p3 = __builtin_convertvector(f2{a6, a7}, t2);
+    return typename Mma32<T>::Frag{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
 }
 // registers 8s .. 8s+7 of an accumulator tile as the operand of k-step s of the next product
 template <typename T>
@@ -494,21 +497,21 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
         }
         if (sl == 0) K9_T(11);
         if (sl == 1) K9_T(14);
+        // activation + packing of hidden tile hb (32 channels): for ReLU on the PACKED operand - relu(round(x)) = round(relu(x)),
+        // and on 16-bit floats it is 'sign bit set -> 0' (one v_pk_max_i16 per pair).  Tile 0 in front of the W_2 steps, tile
+        // hb + 1 inside steps 2 hb, 2 hb + 1 (a handful of VALU instructions per MFMA gap instead of ~350 in front of the loop).
         Frag hfrag[4][2];
-#pragma unroll
-        for (int hb = 0; hb < 4; ++hb) {
+        auto act_pack = [&](int hb, int sx) {
             if constexpr (ACT == 0) {
-                // ReLU on the PACKED operand: relu(round(x)) = round(relu(x)), and on 16-bit floats it is 'sign bit set -> 0':
-                // one arithmetic shift + one and-not per pair of elements (fmaxf per fp32 element: accvgpr_read + canonicalise + max)
-                hfrag[hb][0] = relu_packed(pack_step<T>(hd[hb], 0));
-                hfrag[hb][1] = relu_packed(pack_step<T>(hd[hb], 1));
+                hfrag[hb][sx] = relu_packed(pack_step<T>(hd[hb], sx));
             } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) hd[hb][r] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * hd[hb][r]) + 1.0f);     // tanh, ~1e-6 abs
-                hfrag[hb][0] = pack_step<T>(hd[hb], 0);
-                hfrag[hb][1] = pack_step<T>(hd[hb], 1);
+                for (int r = 8 * sx; r < 8 * sx + 8; ++r) hd[hb][r] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * hd[hb][r]) + 1.0f);     // tanh, ~1e-6 abs
+                hfrag[hb][sx] = pack_step<T>(hd[hb], sx);
             }
-        }
+        };
+        act_pack(0, 0);
+        act_pack(0, 1);
         if (sl == 0) K9_T(12);
         if (sl == 1) K9_T(15);
 #pragma unroll
@@ -516,7 +519,7 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
             Frag (&cur)[8] = (st & 1) ? fb : fa;
             Frag (&nxt)[8] = (st & 1) ? fa : fb;
             const Frag bf = hfrag[st >> 1][st & 1];
-            ring_step<0>(ring, cur, nxt, st & 3, [&](int nb) { Mm::mma(cur[nb], bf, o[nb]); }, [] {});
+            ring_step<0>(ring, cur, nxt, st & 3, [&](int nb) { Mm::mma(cur[nb], bf, o[nb]); }, [&] { if (st < 6) act_pack((st >> 1) + 1, st & 1); });
         }
     }
 
