@@ -78,33 +78,43 @@ struct ConvGeo {
     static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
+// LDS-DMA as buffer_load_dwordx4 ... lds (MUBUF) rather than global_load_lds: behind a FLAT-encoded LDS-DMA the compiler's wait
+// insertion turns every LDS counter wait into lgkmcnt(0) while the request is pending (it may touch both address spaces) - i.e.
+// always, here; behind the MUBUF form it counts.  Scalar descriptor + 32-bit offsets: no 64-bit address arithmetic per piece,
+// and a lane whose offset is outside the buffer's range gets ZEROS in LDS (tools/probes/lds_dma_oob.hip): out-of-image halo
+// pixels need no page of zeros and no pointer select.
+struct ConvRsrc {
+    __amdgpu_buffer_rsrc_t r;
+};
+__device__ __forceinline__ ConvRsrc conv_rsrc(const void* p, unsigned bytes) {
+    return ConvRsrc{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000)};
+}
+__device__ __forceinline__ void conv_lds_dma(const ConvRsrc& rs, char* dst, int voffset, int soffset) {      // 64 lanes x 16 B -> 1 KiB at dst
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs.r, (__attribute__((address_space(3))) void*)dst, 16, voffset, soffset, 0, 0);
+}
 // request weight block b of the stream into ring slot `slot`; the waves share its fragments round-robin
 template <int NT, int NW>
-__device__ __forceinline__ void conv_dma_block(const char* ws, char* smem, int b, int slot, int wave, int lane) {
+__device__ __forceinline__ void conv_dma_block(const ConvRsrc& ws, char* smem, int b, int slot, int wave, int lane) {
     using G = ConvGeo<NT, NW>;
     asm volatile("" : "+v"(lane));      // (as in conv_dma_patch)
     char* dst = smem + G::W10_OFF + slot * G::WBLK;
-    const char* src = ws + (size_t)b * G::WBLK + lane * 16;
 #pragma unroll
     for (int i = 0; i < (G::FR + NW - 1) / NW; ++i) {
         const int f = wave + NW * i;
-        if (f < G::FR)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * C10_FRAG),
-                                             (__attribute__((address_space(3))) void*)(dst + f * C10_FRAG), 16, 0, 0);
+        if (f < G::FR) conv_lds_dma(ws, dst + f * C10_FRAG, lane * 16, b * G::WBLK + f * C10_FRAG);
     }
 }
 
 // request the halo patch of (tile, channel chunk c) into patch buffer `buf`: pieces of 16 pixels x 64 B over the waves
 template <typename T, int CIN, int NT, int NW>
-__device__ __forceinline__ void conv_dma_patch(const ConvArgs& a, char* smem, int buf, int n, int y0, int x0, int c, int wave, int lane) {
+__device__ __forceinline__ void conv_dma_patch(const ConvArgs& a, const ConvRsrc& xs, char* smem, int buf, int n, int y0, int x0, int c, int wave,
+                                               int lane) {
     using G = ConvGeo<NT, NW>;
-    asm volatile("" : "+v"(lane));      // recompute the per-lane source addresses here: hoisted out of the K loop they cost
+    asm volatile("" : "+v"(lane));      // recompute the per-lane source offsets here: hoisted out of the K loop they cost
                                         // live registers per piece, and a spilled one a vmcnt(0) reload between requests
-    const char* xg = (const char*)a.x;
     char* dst = smem + P_OFF + buf * G::PATCH_BYTES;
     // element offset of patch pixel (0, 0), channel 32 c (may be negative; 32-bit: the entry point bounds the tensor)
     const int sbase = ((n * a.H + y0 - 1) * a.W + x0 - 1) * CIN + 32 * c;
-    const char* zsrc = (const char*)a.zeros + (lane & 3) * 16;
 #pragma unroll
     for (int i = 0; i < (G::PIECES + NW - 1) / NW; ++i) {
         const int piece = wave + NW * i;
@@ -113,9 +123,7 @@ __device__ __forceinline__ void conv_dma_patch(const ConvArgs& a, char* smem, in
             const int pr = q / PW, pc = q - pr * PW;
             const bool in = (unsigned)(y0 - 1 + pr) < (unsigned)a.H && (unsigned)(x0 - 1 + pc) < (unsigned)a.W && q < G::PH * PW;
             const int off = sbase + (pr * a.W + pc) * CIN + 8 * slot;
-            const char* src = in ? xg + (size_t)(unsigned)off * sizeof(T) : zsrc;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+            conv_lds_dma(xs, dst + piece * 1024, in ? off * (int)sizeof(T) : 0x7FFFFFF0, 0);                // outside the image: out of range -> zeros
         }
     }
 }
@@ -149,7 +157,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lp = lane & 15, g4 = lane >> 4;                       // MFMA 16x16x32: row / column of the lane, its k group
-    const char* ws = (const char*)a.wstream;
+    const ConvRsrc ws = conv_rsrc(a.wstream, (unsigned)NBLK * G::WBLK);
+    const ConvRsrc xs = conv_rsrc(a.x, (unsigned)a.N * a.H * a.W * CIN * (unsigned)sizeof(T));
     float* shiftv = reinterpret_cast<float*>(smem + G::SHIFT_OFF);
     for (int i = tid; i < COUT; i += NW * 64) shiftv[i] = a.shift ? a.shift[i] : 0.f;
     // the second-dispatched half of an 8-wave workgroup loses every arbitration on its SIMD: one static priority step for it
@@ -197,7 +206,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
     if (tile0 < xend) {
         int n, y0, x0;
         decode(tile0, n, y0, x0);
-        conv_dma_patch<T, CIN, NT, NW>(a, smem, 0, n, y0, x0, 0, wave, lane);
+        conv_dma_patch<T, CIN, NT, NW>(a, xs, smem, 0, n, y0, x0, 0, wave, lane);
         conv_dma_block<NT, NW>(ws, smem, 0, 0, wave, lane);
         conv_dma_block<NT, NW>(ws, smem, 1, 1, wave, lane);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -240,7 +249,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
                 Frag (&nw)[NT] = (ts & 1) ? wa : wb;
                 Frag (&cx)[2 * PB] = (tap & 1) ? xb : xa;
                 Frag (&nx)[2 * PB] = (tap & 1) ? xa : xb;
-                __builtin_amdgcn_s_waitcnt(0xC07F);                 // this sub-step's fragments (requested a sub-step ago) are in registers
+                // (this sub-step's fragments were requested a sub-step ago; the compiler's counted lgkmcnt waits retire them)
                 if (ts % BS == BS - 1) {
                     // ring turn before the last sub-step of a block: the next block (and a patch requested a turn ago) has
                     // landed, every wave holds this block's last fragments in registers: its slot takes the block after next
@@ -257,11 +266,11 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
                     else if (has_next) conv_dma_block<NT, NW>(ws, smem, nb - NBLK, wslot, wave, lane);
                     if (ts == BS - 1) {
                         // first turn of the chunk: every wave is past the previous chunk, its patch buffer is free
-                        if (c + 1 < NCH) conv_dma_patch<T, CIN, NT, NW>(a, smem, pbuf ^ 1, n, y0, x0, c + 1, wave, lane);
+                        if (c + 1 < NCH) conv_dma_patch<T, CIN, NT, NW>(a, xs, smem, pbuf ^ 1, n, y0, x0, c + 1, wave, lane);
                         else if (has_next) {
                             int n2, y2, x2;
                             decode(nxt_tile, n2, y2, x2);
-                            conv_dma_patch<T, CIN, NT, NW>(a, smem, pbuf ^ 1, n2, y2, x2, 0, wave, lane);
+                            conv_dma_patch<T, CIN, NT, NW>(a, xs, smem, pbuf ^ 1, n2, y2, x2, 0, wave, lane);
                         }
                     }
                     wslot ^= 1;
@@ -468,7 +477,7 @@ extern "C" int gf_conv3x3_nhwc(const void* x, const void* wstream, const float* 
     GF_CHECK_ARG(act != C10_LEAKY || (slope >= 0.f && slope <= 1.f), "LeakyReLU slope must lie in [0, 1]");
     GF_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)residual % 16 == 0 && (uintptr_t)wstream % 16 == 0 &&
                      (uintptr_t)zeros % 16 == 0, "tensors must be 16-byte aligned");
-    GF_CHECK_ARG((long)N * H * W * (cin > cout ? cin : cout) < (1l << 31), "maps of 2^31 elements or more are not supported");
+    GF_CHECK_ARG((long)N * H * W * (cin > cout ? cin : cout) * 2 < 0x7FFFFFF0l, "maps of 2 GiB or more are not supported (32-bit buffer offsets)");
     ConvArgs a{x, wstream, shift, residual, out, zeros, N, H, W, act, slope, 0, 0, 0};
     hipStream_t st = (hipStream_t)stream;
     // declared work = the reference's convolution: a 224-wide operand is the zero-padded form of the backbone's 196-channel maps

@@ -114,10 +114,11 @@ __device__ __forceinline__ float rnd(float x) { return gf_to_float(gf_from_float
 
 // The weight stream: 32-KiB blocks (32 fragments = 4 STEPS of 8 fragments = 8 MFMAs per wave) through a two-slot LDS ring.
 // Wave w moves fragments 8w .. 8w+7 of a block ("pieces" 0..7 of the wave) by LDS-DMA.  Requests behind the stream's end are
-// out of the buffer's range and move nothing (no conditional code inside the step bodies: one basic block per unrolled
-// phase, so the issue order below survives).
+// out of the buffer's range: they fetch nothing and leave zeros in the slot that has just been freed, which nobody reads
+// (tools/probes/lds_dma_oob.hip) - no conditional code inside the step bodies: one basic block per unrolled phase, so the
+// issue order below survives.
 struct Ring {
-    __amdgpu_buffer_rsrc_t rs;   // the stream as a raw buffer of exactly nblk blocks: a request behind its end moves nothing
+    __amdgpu_buffer_rsrc_t rs;   // the stream as a raw buffer of exactly nblk blocks: a request behind its end is out of range (zeros)
     char* smem;
     int wave, lane, blk, nblk;
 };
