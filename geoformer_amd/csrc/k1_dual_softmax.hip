@@ -624,6 +624,15 @@ __global__ __launch_bounds__(NT, 2) void k1_conf_panel(K1Args a) {
 // exp, lane swap, candidate bookkeeping per element) sharing the SIMDs with the 32 MFMAs per tile, at two waves per SIMD.
 // ---------------------------------------------------------------------------------------------
 constexpr int PIPE_LDS = 2 * BN * 512 + BM * 8 + PANEL_TILES * BN * 8;
+struct K1Rsrc {
+    __amdgpu_buffer_rsrc_t r;
+};
+__device__ __forceinline__ K1Rsrc k1_rsrc(const void* p, unsigned bytes) {
+    return K1Rsrc{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000)};
+}
+__device__ __forceinline__ void k1_lds_dma(const K1Rsrc& rs, char* dst, int voffset, int soffset) {        // 64 lanes x 16 B -> 1 KiB at dst
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs.r, (__attribute__((address_space(3))) void*)dst, 16, voffset, soffset, 0, 0);
+}
 
 template <typename H, bool DENSE>
 __global__ __launch_bounds__(NT, 2) void k1_conf_pipe(K1Args a) {
@@ -650,15 +659,16 @@ __global__ __launch_bounds__(NT, 2) void k1_conf_pipe(K1Args a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (also drains the previous unit's stores: the counted waits below start clean)
         __syncthreads();                                      // previous unit's readers of rst / cst / the tile buffers are done
         // tile bn -> buffer `buf`: 32 pieces of 2 rows x 512 B, 8 per wave; LDS slot j of row r holds chunk j ^ (r & 15)
+        // LDS-DMA as buffer_load_dwordx4 ... lds (MUBUF): behind the FLAT form (global_load_lds) the compiler's wait insertion turns
+        // every LDS counter wait into lgkmcnt(0) while a request is pending; scalar descriptor + 32-bit offsets besides
+        const K1Rsrc brs = k1_rsrc(B, (unsigned)a.S * a.C * (unsigned)sizeof(H));
         auto dma = [&](int bn, int buf) {
             int dl = lane;
-            asm volatile("" : "+v"(dl));                     // per-piece source addresses recomputed here, not kept across the tile loop
+            asm volatile("" : "+v"(dl));                     // per-piece source offsets recomputed here, not kept across the tile loop
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int p = wave * 8 + i, row = 2 * p + (dl >> 5), j = dl & 31;
-                const char* src = B + ((size_t)(bn * BN + row) * a.C + ((j ^ (row & 15)) << 3)) * sizeof(H);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(smem + buf * (BN * 512) + p * 1024), 16, 0, 0);
+                k1_lds_dma(brs, smem + buf * (BN * 512) + p * 1024, (row * a.C + ((j ^ (row & 15)) << 3)) * (int)sizeof(H), bn * BN * a.C * (int)sizeof(H));
             }
         };
         dma(t0, 0);
