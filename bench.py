@@ -652,6 +652,7 @@ def side_measurements(args, model, dev, log, L):
     """More throughput figures of the same job, N = 1 only (they are not `value`):
       matching_path_only  the hot path alone: `forward_features` on resident planted-correspondence feature maps (no
                           backbone in the step) at the nominal load - what the HIP kernels of SURVEY section 8(a) take;
+      matching_path_match_only  the same with the opt-in match-only K1 (conf matrices not materialised);
       light_load          (when `value` is the nominal load) the full forward on homography image pairs with thresholds 0:
                           random-init weights give M ~ 360 matches and K ~ 60 inlier cells per pair (rounds 1-2's headline);
       nominal_load        (when `value` is NOT the nominal load) backbone on the images + matching path on planted maps,
@@ -683,6 +684,16 @@ def side_measurements(args, model, dev, log, L):
     p.close()
     log(f"matching path only: {out['matching_path_only']['value']:.1f} pairs/s ({out['matching_path_only']['ms_per_step']:.2f} ms per "
         f"{args.batch} pairs) at M = {out['matching_path_only']['coarse_matches_per_pair']:.0f}")
+    if args.precision != 'fp32':
+        # match-only K1 (opt-in, geoformer_cfg['materialize_conf'] = False): conf_matrix / dect_conf_matrix are not written
+        # (2 x 164 MB per pair), matches bit-identical; a side measurement only - the contract mode is what `value` runs
+        mn.coarse_matching.materialize_conf = False
+        el, p = measure_fn(feat_step, steps, 3, args.streams, dev)
+        mn.coarse_matching.materialize_conf = True
+        out['matching_path_match_only'] = summary(el, p, steps, 3, 'matching path only, match-only K1 (conf matrices not materialised), '
+                                                  'coarse_thr 0.2, fine_thr 0.1')
+        p.close()
+        log(f"matching path, match-only K1: {out['matching_path_match_only']['value']:.1f} pairs/s")
     if nominal:
         ml, _ = build_model(args.precision, 0.0, 0.0, dev)
         if args.graphs:

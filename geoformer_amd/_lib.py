@@ -25,6 +25,9 @@ SIGNATURES = {
     'gf_profile_collect': (c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int),
                                    ctypes.POINTER(ctypes.c_double)]),
     'gf_dual_softmax_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'gf_dual_softmax_match_only_supported': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    'gf_dual_softmax_conf_at': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int,
+                                        c_void_p, c_void_p, c_size_t, c_void_p]),
     'gf_dual_softmax_match': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                       c_float, c_float, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -634,7 +634,7 @@ __device__ __forceinline__ void k1_lds_dma(const K1Rsrc& rs, char* dst, int voff
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs.r, (__attribute__((address_space(3))) void*)dst, 16, voffset, soffset, 0, 0);
 }
 
-template <typename H, bool DENSE>
+template <typename H, bool DENSE, bool STORE>
 __global__ __launch_bounds__(NT, 2) void k1_conf_pipe(K1Args a) {
     using V8 = gf_vec<H, 8>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -707,10 +707,12 @@ __global__ __launch_bounds__(NT, 2) void k1_conf_pipe(K1Args a) {
             float cf[2];
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) cf[ni] = __builtin_amdgcn_exp2f(fmaf(acc[ni][r], k2, st + ca[ni]));
-            float* rowp = a.conf + ((size_t)n * a.L + row_base + (r & 3) + 8 * (r >> 2)) * a.S + n0;
-            const gf_v2u sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(cf[0]), __float_as_uint(cf[1]), false, false);
-            __builtin_nontemporal_store(__uint_as_float(sw.x), rowp + lane);
-            __builtin_nontemporal_store(__uint_as_float(sw.y), rowp + 4 * a.S + lane);
+            if constexpr (STORE) {                            // (match-only mode, conf == NULL: the matrix is never written)
+                float* rowp = a.conf + ((size_t)n * a.L + row_base + (r & 3) + 8 * (r >> 2)) * a.S + n0;
+                const gf_v2u sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(cf[0]), __float_as_uint(cf[1]), false, false);
+                __builtin_nontemporal_store(__uint_as_float(sw.x), rowp + lane);
+                __builtin_nontemporal_store(__uint_as_float(sw.y), rowp + 4 * a.S + lane);
+            }
             if constexpr (!DENSE) {
                 if (fmaxf(cf[0], cf[1]) > a.thr) {
                     const int row = row_base + gf_acc_row(r, h);
@@ -751,7 +753,7 @@ __global__ __launch_bounds__(NT, 2) void k1_conf_pipe(K1Args a) {
                 // tile bn has landed: what was issued behind its DMA - the previous iteration's 32 row stores (and possibly
                 // candidate atomics) - may stay in flight.  The unit's first two tiles have no stores behind their DMA (tile
                 // t0 + 1 is requested in the iteration that only multiplies tile t0): they wait for everything.
-                if (bn <= t0 + 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (bn <= t0 + 1 || !STORE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
             }
             __syncthreads();                                  // ... for every wave; and every wave is done with tile bn-1's buffer
@@ -970,7 +972,13 @@ struct SelArgs {
     const unsigned long long* rowbest;   // [N][L]
     const unsigned* colmax;              // [N][S]
     unsigned* colset;                    // [N][SET_WORDS] bitset over hash(colmax value)
-    const float* conf;
+    const float* conf;     // null in match-only mode: single entries are recomputed (k1_conf_entry)
+    const void* f0;        // (match-only mode) the operands and statistics of the sweep
+    const void* f1;
+    const float2* rstat;
+    const float2* cstat;
+    int C;
+    float mult;
     int* scanlist;         // [N*L] rows whose first-True column needs the tie rescan
     int* scancnt;          // [1]
     int* selj;             // [N][L]  matched column or -1
@@ -1036,8 +1044,44 @@ __global__ void k1_select(SelArgs a) {
     if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&a.samplecnt[n * a.chunks + (i >> 10)], __popcll(bal));
 }
 
+// One entry conf[n][i][j] exactly as k1_conf_pipe produces it (16-bit storage, the panel configuration), computed by one wave:
+// the 32 x 32 similarity tile that holds (i, j) is multiplied with the same operands in the same k order - an MFMA result
+// depends on nothing else - and pushed through the same epilogue arithmetic.  Match-only mode (conf == NULL) uses it where the
+// contract mode reads the matrix: the tie rescan, the forced match, and gf_dual_softmax_conf_at.  Returned in every lane.
+template <typename H>
+__device__ __forceinline__ float k1_conf_entry(const SelArgs& a, int n, int i, int j) {
+    using V8 = gf_vec<H, 8>;
+    const int lane = threadIdx.x & 63, h = lane >> 5, lr = lane & 31;
+    const int i0 = i & ~31, j0 = j & ~31;
+    const H* A = (const H*)a.f0 + ((size_t)n * a.L + min(i0 + lr, a.L - 1)) * a.C + h * 8;
+    const H* B = (const H*)a.f1 + ((size_t)n * a.S + min(j0 + lr, a.S - 1)) * a.C + h * 8;
+    v16f acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int kg = 0; kg < a.C / 16; ++kg)
+        Mma32<H>::mma(*reinterpret_cast<const V8*>(A + kg * 16), *reinterpret_cast<const V8*>(B + kg * 16), acc);
+    // accumulator row ri = (r & 3) + 8 (r >> 2) + 4 h of column lane lr
+    const int ri = i - i0, rsel = (ri & 3) + 4 * (ri >> 3), lsel = (j - j0) + 32 * ((ri >> 2) & 1);
+    float v = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v = r == rsel ? acc[r] : v;
+    v = __shfl(v, lsel, 64);
+    const float2 rs = a.rstat[(size_t)n * a.L + i], cs = a.cstat[(size_t)n * a.S + j];
+    const float st = -rs.x * LOG2E - __builtin_amdgcn_logf(rs.y), ca = -cs.x * LOG2E - __builtin_amdgcn_logf(cs.y);
+    return __builtin_amdgcn_exp2f(fmaf(v, 2.0f * a.mult * LOG2E, st + ca));
+}
+
+template <typename H>
+__global__ __launch_bounds__(256) void k1_conf_at(SelArgs a, const int64_t* b, const int64_t* i, const int64_t* j, int P, float* out) {
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= P) return;
+    const float c = k1_conf_entry<H>(a, (int)b[e], (int)i[e], (int)j[e]);
+    if ((threadIdx.x & 63) == 0) out[e] = c;
+}
+
 // rows queued by k1_select: one wave per row walks the (L2-resident) column maxima for later columns
 // that hold the same value and confirms the tie on the confidence matrix itself
+template <typename H, bool MATCH_ONLY>
 __global__ __launch_bounds__(256) void k1_rescan(SelArgs a) {
     const int lane = threadIdx.x & 63;
     const int nwaves = gridDim.x * 4, total = *a.scancnt;
@@ -1047,13 +1091,23 @@ __global__ __launch_bounds__(256) void k1_rescan(SelArgs a) {
         const unsigned bits = (unsigned)(k >> 32);
         const int j = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
         const unsigned* cm = a.colmax + (size_t)n * a.S;
-        const float* crow = a.conf + (size_t)row * a.S;
         int sel = -1;
         for (int j0 = ((j + 1) / 64) * 64; j0 < a.S && sel < 0; j0 += 64) {
             const int j2 = j0 + lane;
-            const bool hit = j2 > j && j2 < a.S && cm[j2] == bits && __float_as_uint(crow[j2]) == bits;
-            const unsigned long long bal = __ballot(hit);
-            if (bal) sel = j0 + __ffsll((long long)bal) - 1;
+            if constexpr (!MATCH_ONLY) {
+                const float* crow = a.conf + (size_t)row * a.S;
+                const bool hit = j2 > j && j2 < a.S && cm[j2] == bits && __float_as_uint(crow[j2]) == bits;
+                const unsigned long long bal = __ballot(hit);
+                if (bal) sel = j0 + __ffsll((long long)bal) - 1;
+            } else {
+                // candidates by the column maxima alone, then (in column order) the entry itself, recomputed
+                unsigned long long bal = __ballot(j2 > j && j2 < a.S && cm[j2] == bits);
+                while (bal && sel < 0) {
+                    const int jc = j0 + __ffsll((long long)bal) - 1;
+                    bal &= bal - 1;
+                    if (__float_as_uint(k1_conf_entry<H>(a, n, i, jc)) == bits) sel = jc;
+                }
+            }
         }
         if (lane == 0 && sel >= 0) {
             a.selj[row] = sel;
@@ -1064,6 +1118,7 @@ __global__ __launch_bounds__(256) void k1_rescan(SelArgs a) {
 
 // one workgroup per (1024-row chunk, sample): ordered compaction in (n, i) order + keypoints
 // (coarse_matching.py:186-201).  Bases come from the chunk counts of everything in front.
+template <typename H, bool MATCH_ONLY>
 __global__ __launch_bounds__(1024) void k1_compact(SelArgs a) {
     __shared__ int wave_tot[16];
     __shared__ int sh_base, sh_forced;
@@ -1097,7 +1152,9 @@ __global__ __launch_bounds__(1024) void k1_compact(SelArgs a) {
         a.b_ids[pos] = n;
         a.i_ids[pos] = i;
         a.j_ids[pos] = j;
-        a.mconf[pos] = a.conf[((size_t)n * a.L + i) * a.S + j];
+        // match-only: a selected entry IS its row's best candidate value (k1_select / k1_rescan compared the bits)
+        if constexpr (MATCH_ONLY) a.mconf[pos] = __uint_as_float((unsigned)(a.rowbest[(size_t)n * a.L + i] >> 32));
+        else a.mconf[pos] = a.conf[((size_t)n * a.L + i) * a.S + j];
         a.mk0[2 * pos] = (float)(i % a.w0c) * s0x;
         a.mk0[2 * pos + 1] = (float)(i / a.w0c) * s0y;
         a.mk1[2 * pos] = (float)(j % a.w1c) * s1x;
@@ -1126,11 +1183,12 @@ int k1_launch(K1Args a, SelArgs s, void* zero_begin, size_t zero_bytes, hipStrea
     const dim3 grid(a.tilesN * a.tilesM, a.N);
     (void)hipMemsetAsync(zero_begin, 0, zero_bytes, st);   // rowbest, colmax, samplecnt (contiguous)
     const bool panel = !EXACT && a.mask0 == nullptr && a.L % BM == 0 && a.S % BN == 0 && a.C == 256;
+    const bool match_only = a.conf == nullptr;                 // (the entry point admits it in the panel configuration only)
     const int runs = (a.tilesN + PANEL_TILES - 1) / PANEL_TILES;
     const int units = a.N * a.tilesM * runs, wgs = units < 512 ? units : 512;    // two resident workgroups per CU
     a.rowparts = panel ? runs : a.tilesN;
     // the whole call (statistics, reduction, confidence sweep, selection, compaction) against its algorithmic bytes
-    void* pu = gf_prof_begin("k1_unit", st, (double)a.N * ((double)(a.L + a.S) * a.C * sizeof(T) + (double)a.L * a.S * 4.0));
+    void* pu = gf_prof_begin("k1_unit", st, (double)a.N * ((double)(a.L + a.S) * a.C * sizeof(T) + (match_only ? 0.0 : (double)a.L * a.S * 4.0)));
     void* p0 = gf_prof_begin("k1_stats", st, 2.0 * a.N * (double)a.L * a.S * a.C);
     if constexpr (!EXACT) {
         if (panel) k1_stats_panel<T><<<wgs, NT, PANEL_LDS + 2048, st>>>(a);
@@ -1141,7 +1199,8 @@ int k1_launch(K1Args a, SelArgs s, void* zero_begin, size_t zero_bytes, hipStrea
     gf_prof_end("k1_stats", p0, st);
     const int mx = a.L > a.S ? a.L : a.S;
     k1_reduce_stats<EXACT><<<dim3((mx + 31) / 32, 2, a.N), 256, 0, st>>>(a);
-    void* p1 = gf_prof_begin("k1_conf", st, (double)a.N * ((double)(a.L + a.S) * a.C * sizeof(T) + (double)a.L * a.S * 4.0));
+    void* p1 = gf_prof_begin(match_only ? "k1_conf_matchonly" : "k1_conf", st,
+                             (double)a.N * ((double)(a.L + a.S) * a.C * sizeof(T) + (match_only ? 0.0 : (double)a.L * a.S * 4.0)));
     bool done = false;
     if constexpr (!EXACT) {
         if (panel) {
@@ -1149,25 +1208,40 @@ int k1_launch(K1Args a, SelArgs s, void* zero_begin, size_t zero_bytes, hipStrea
             static const bool old_form = [] { const char* e = getenv("GF_K1_CONF"); return e && e[0] == 'p'; }();
             static std::atomic<uint64_t> attr{0};
             if (gf_first_use_on_device(attr)) {
-                (void)hipFuncSetAttribute((const void*)k1_conf_pipe<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS);
-                (void)hipFuncSetAttribute((const void*)k1_conf_pipe<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS);
+                (void)hipFuncSetAttribute((const void*)k1_conf_pipe<T, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS);
+                (void)hipFuncSetAttribute((const void*)k1_conf_pipe<T, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS);
+                (void)hipFuncSetAttribute((const void*)k1_conf_pipe<T, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS);
+                (void)hipFuncSetAttribute((const void*)k1_conf_pipe<T, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS);
             }
-            if (old_form) {
+            if (match_only) {
+                if (a.dense) k1_conf_pipe<T, true, false><<<wgs, NT, PIPE_LDS, st>>>(a);
+                else k1_conf_pipe<T, false, false><<<wgs, NT, PIPE_LDS, st>>>(a);
+            } else if (old_form) {
                 if (a.dense) k1_conf_panel<T, true><<<wgs, NT, PANEL_LDS, st>>>(a);
                 else k1_conf_panel<T, false><<<wgs, NT, PANEL_LDS, st>>>(a);
-            } else if (a.dense) k1_conf_pipe<T, true><<<wgs, NT, PIPE_LDS, st>>>(a);
-            else k1_conf_pipe<T, false><<<wgs, NT, PIPE_LDS, st>>>(a);
+            } else if (a.dense) k1_conf_pipe<T, true, true><<<wgs, NT, PIPE_LDS, st>>>(a);
+            else k1_conf_pipe<T, false, true><<<wgs, NT, PIPE_LDS, st>>>(a);
             done = true;
         }
     }
     if (done) {
     } else if (a.dense) k1_conf<T, true><<<grid, NT, STAGE_BYTES, st>>>(a);
     else k1_conf<T, false><<<grid, NT, STAGE_BYTES, st>>>(a);
-    gf_prof_end("k1_conf", p1, st);
+    gf_prof_end(match_only ? "k1_conf_matchonly" : "k1_conf", p1, st);
     k1_colset<<<dim3((a.S + 255) / 256, a.N), 256, 0, st>>>(s);
     k1_select<<<dim3((a.L + 255) / 256, a.N), 256, 0, st>>>(s);
-    k1_rescan<<<256, 256, 0, st>>>(s);
-    k1_compact<<<dim3(s.chunks, a.N), 1024, 0, st>>>(s);
+    if constexpr (!EXACT) {
+        if (match_only) {
+            k1_rescan<T, true><<<256, 256, 0, st>>>(s);
+            k1_compact<T, true><<<dim3(s.chunks, a.N), 1024, 0, st>>>(s);
+        } else {
+            k1_rescan<T, false><<<256, 256, 0, st>>>(s);
+            k1_compact<T, false><<<dim3(s.chunks, a.N), 1024, 0, st>>>(s);
+        }
+    } else {
+        k1_rescan<_Float16, false><<<256, 256, 0, st>>>(s);
+        k1_compact<_Float16, false><<<dim3(s.chunks, a.N), 1024, 0, st>>>(s);
+    }
     gf_prof_end("k1_unit", pu, st);
     GF_CHECK_LAUNCH();
     return GF_OK;
@@ -1456,13 +1530,44 @@ extern "C" size_t gf_dual_softmax_workspace_bytes(int N, int L, int S) {
     return k1_carve(nullptr, N, L, S).bytes;
 }
 
+// match-only mode is built for the configuration the inference path runs (the row-panel form of the sweep)
+extern "C" int gf_dual_softmax_match_only_supported(int dtype, int L, int S, int C, int masked, int force_one) {
+    return (dtype == GF_F16 || dtype == GF_BF16) && C == 256 && L > 0 && S > 0 && L % BM == 0 && S % BN == 0 && !masked && !force_one;
+}
+
+// conf[b[e]][i[e]][j[e]] for e < P, recomputed bit-identically to what gf_dual_softmax_match wrote (or, in match-only mode, would
+// have written) from the SAME features and the row / column statistics its last call left in `workspace`
+extern "C" int gf_dual_softmax_conf_at(const void* f0, const void* f1, int dtype, int N, int L, int S, int C, float temperature,
+                                       const int64_t* b, const int64_t* i, const int64_t* j, int P, float* out, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    GF_CHECK_ARG(f0 && f1 && b && i && j && out, "null pointer");
+    GF_CHECK_ARG(gf_dual_softmax_match_only_supported(dtype, L, S, C, 0, 0) && N > 0 && P >= 0 && temperature > 0.f,
+                 "built for 16-bit features, C = 256, L % 128 == 0, S % 64 == 0");
+    if (workspace == nullptr || workspace_bytes < gf_dual_softmax_workspace_bytes(N, L, S)) {
+        gf_set_error("gf_dual_softmax_conf_at: workspace too small");
+        return GF_ERR_WORKSPACE;
+    }
+    if (P == 0) return GF_OK;
+    const K1Workspace w = k1_carve(workspace, N, L, S);
+    SelArgs s{};
+    s.N = N; s.L = L; s.S = S; s.f0 = f0; s.f1 = f1; s.rstat = w.rstat; s.cstat = w.cstat; s.C = C; s.mult = (1.0f / (float)C) / temperature;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GF_F16) k1_conf_at<_Float16><<<(P + 3) / 4, 256, 0, st>>>(s, b, i, j, P, out);
+    else k1_conf_at<gf_bf16><<<(P + 3) / 4, 256, 0, st>>>(s, b, i, j, P, out);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}
+
 extern "C" int gf_dual_softmax_match(const void* f0, const void* f1, int dtype, int N, int L, int S, int C,
                                      const uint8_t* mask0, const uint8_t* mask1, float temperature, float thr,
                                      int force_one, int w0c, int w1c, float scale, const float* scale0,
                                      const float* scale1, float* conf, int64_t* b_ids, int64_t* i_ids,
                                      int64_t* j_ids, float* mconf, float* mkpts0_c, float* mkpts1_c,
                                      int32_t* counts, void* workspace, size_t workspace_bytes, void* stream) {
-    GF_CHECK_ARG(f0 && f1 && conf && b_ids && i_ids && j_ids && mconf && mkpts0_c && mkpts1_c && counts, "null pointer");
+    GF_CHECK_ARG(f0 && f1 && b_ids && i_ids && j_ids && mconf && mkpts0_c && mkpts1_c && counts, "null pointer");
+    // conf == NULL: match-only mode (the matrix is not materialised; matches and mconf are bit-identical to the contract mode's)
+    GF_CHECK_ARG(conf != nullptr || gf_dual_softmax_match_only_supported(dtype, L, S, C, mask0 != nullptr, force_one),
+                 "match-only mode (conf == NULL) needs 16-bit features, C = 256, L % 128 == 0, S % 64 == 0, no masks, no forced match");
     GF_CHECK_ARG(N > 0 && L > 0 && S > 0, "empty problem");
     GF_CHECK_ARG(dtype >= GF_F32 && dtype <= GF_BF16, "bad dtype");
     GF_CHECK_ARG(C > 0 && C % (dtype == GF_F32 ? 32 : 64) == 0, "C must be a multiple of 32 (f32) / 64 (f16)");
@@ -1487,6 +1592,7 @@ extern "C" int gf_dual_softmax_match(const void* f0, const void* f1, int dtype, 
     SelArgs s;
     s.N = N; s.L = L; s.S = S;
     s.rowbest = w.rowbest; s.colmax = w.colmax; s.colset = w.colset; s.conf = conf;
+    s.f0 = f0; s.f1 = f1; s.rstat = w.rstat; s.cstat = w.cstat; s.C = C; s.mult = a.mult;
     s.selj = w.selj; s.scanlist = w.scanlist; s.scancnt = w.scancnt; s.samplecnt = w.samplecnt; s.chunks = (L + 1023) / 1024; s.force_one = force_one; s.w0c = w0c; s.w1c = w1c;
     s.scale = scale; s.scale0 = scale0; s.scale1 = scale1;
     s.b_ids = b_ids; s.i_ids = i_ids; s.j_ids = j_ids; s.mconf = mconf; s.mk0 = mkpts0_c; s.mk1 = mkpts1_c;

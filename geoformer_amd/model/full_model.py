@@ -34,6 +34,7 @@ class GeoFormer(nn.Module):
                                                  temp_bug_fix=loftr_config['coarse']['temp_bug_fix'])
         loftr_config['match_coarse']['thr'] = geoformer_cfg['coarse_thr']     # same side effect as the reference (:31)
         self.coarse_matching = CoarseMatching(loftr_config['match_coarse'])
+        self.coarse_matching.materialize_conf = bool(geoformer_cfg.get('materialize_conf', True))     # False: match-only K1 (opt-in)
         self.fine_preprocess = FinePreprocess(loftr_config)
         self.loftr_fine = LocalFeatureTransformer(loftr_config['fine'])
         self.fine_matching = FineMatching2(geoformer_cfg['fine_temperature'], geoformer_cfg['fine_thr'])
@@ -94,7 +95,7 @@ class GeoFormer(nn.Module):
     def _forward_graphed(self, data):
         img0, img1 = data['image0'], data['image1']
         key = (tuple(img0.shape), tuple(img1.shape), img0.dtype, torch.cuda.current_stream().cuda_stream,
-               float(self.coarse_matching.thr), float(self.coarse_matching.temperature), self.precision)
+               float(self.coarse_matching.thr), float(self.coarse_matching.temperature), self.precision, self.coarse_matching.materialize_conf)
         entry = self._graphs.get(key)
         if entry is None:
             # warm-up ON the stream the capture will use: MIOpen keeps a handle (and its algorithm picks / workspaces) per

@@ -228,6 +228,9 @@ class CoarseMatching(nn.Module):
             raise NotImplementedError("only match_type='dual_softmax' is built (sinkhorn needs superglue.py, "
                                       'which the reference does not ship either)')
         self.temperature = config['dsmax_temperature']
+        # False: match-only mode of K1 - conf_matrix / dect_conf_matrix are None in `data` (inference.py:51-75 and the evaluation
+        # harness never read them), matches bit-identical; set from geoformer_cfg['materialize_conf'] (optional key, default True)
+        self.materialize_conf = True
 
     def forward(self, feat_c0, feat_c1, data: Dict[str, torch.Tensor], mask_c0: Optional[torch.Tensor] = None,
                 mask_c1: Optional[torch.Tensor] = None, lazy: bool = False):
@@ -237,7 +240,7 @@ class CoarseMatching(nn.Module):
         scale = float(data['hw0_i'][0]) / float(data['hw0_c'][0])
         raw = ops.dual_softmax_match(feat_c0, feat_c1, self.temperature, self.thr, data['hw0_c'], data['hw1_c'], scale,
                                      mask_c0, mask_c1, data.get('scale0'), data.get('scale1'),
-                                     force_one='dataset_name' in data)
+                                     force_one='dataset_name' in data, materialize=self.materialize_conf)
         data['conf_matrix'] = raw['conf_matrix']
         data['_coarse_dev'] = raw
         if not lazy:

@@ -56,17 +56,41 @@ def _contig(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def match_only_supported(f0, f1, masked=False, force_one=False):
+    """Is the match-only mode of K1 (conf_matrix not materialised) built for these operands?"""
+    return bool(_lib.lib().gf_dual_softmax_match_only_supported(_dt(f0), f0.shape[1], f1.shape[1], f0.shape[2], int(masked), int(bool(force_one))))
+
+
+def dual_softmax_conf_at(f0, f1, temperature, b, i, j):
+    """Single entries conf[b, i, j] (fp32 [P]) recomputed bit-identically to the matrix gf_dual_softmax_match writes, from the same
+    features and the statistics its last call on this device left in the workspace (match-only mode's way to a few values)."""
+    _need_cuda(f0, f1)
+    f0, f1 = _contig(f0), _contig(f1)
+    N, L, C = f0.shape
+    S = f1.shape[1]
+    b, i, j = (_contig(t.to(device=f0.device, dtype=torch.int64)) for t in (b, i, j))
+    out = torch.empty(b.numel(), dtype=torch.float32, device=f0.device)
+    L_ = _lib.lib()
+    ws = _ws.get('k1', L_.gf_dual_softmax_workspace_bytes(N, L, S), f0.device)
+    check(L_.gf_dual_softmax_conf_at(_p(f0), _p(f1), _dt(f0), N, L, S, C, float(temperature), _p(b), _p(i), _p(j), b.numel(), _p(out),
+                                     _p(ws), ws.numel(), _stream()), 'gf_dual_softmax_conf_at')
+    return out
+
+
 def dual_softmax_match(f0, f1, temperature, thr, hw0_c, hw1_c, scale, mask0=None, mask1=None, scale0=None,
-                       scale1=None, force_one=False):
+                       scale1=None, force_one=False, materialize=True):
     """K1.  f0 [N,L,C], f1 [N,S,C] -> dict(conf [N,L,S] fp32, b_ids/i_ids/j_ids int64 [cap], mconf [cap],
-    mkpts0_c/mkpts1_c [cap,2], counts int32 [1+N]) - all on the device, match arrays at capacity."""
+    mkpts0_c/mkpts1_c [cap,2], counts int32 [1+N]) - all on the device, match arrays at capacity.
+    materialize=False: match-only mode (conf_matrix is None; everything else bit-identical), where the library is built for it
+    (match_only_supported) - otherwise the matrix is materialised as usual."""
     _need_cuda(f0, f1)
     f0, f1 = _contig(f0), _contig(f1)
     N, L, C = f0.shape
     S = f1.shape[1]
     dev = f0.device
     cap = N * min(L, S) + (N if force_one else 0)
-    conf = torch.empty(N, L, S, dtype=torch.float32, device=dev)
+    match_only = not materialize and match_only_supported(f0, f1, mask0 is not None, force_one)
+    conf = None if match_only else torch.empty(N, L, S, dtype=torch.float32, device=dev)
     ids = torch.empty(3, cap, dtype=torch.int64, device=dev)
     mconf = torch.empty(cap, dtype=torch.float32, device=dev)
     mk = torch.empty(2, cap, 2, dtype=torch.float32, device=dev)

@@ -46,7 +46,7 @@ int gf_profile_collect(const char* tag, double* total_ms, int* count, double* wo
  *          (model/loftr_src/loftr/utils/coarse_matching.py:90-130, :132-212)
  *
  *   sim  = <f0[n,i,:], f1[n,j,:]> / C / temperature       (-1e9 where !(mask0[n,i] & mask1[n,j]))
- *   conf = softmax(sim, dim=1) * softmax(sim, dim=2)       -> conf [N,L,S] fp32 (always written)
+ *   conf = softmax(sim, dim=1) * softmax(sim, dim=2)       -> conf [N,L,S] fp32 (written unless conf == NULL, below)
  *   keep (n,i,j) iff conf > thr and conf is the maximum of its row and of its column; per row the
  *   first such column; rows emitted in (n,i) order, exactly like torch.where (:185-188).
  *   force_one != 0 reproduces the 'dataset_name' branch (:182-184): a sample without any match
@@ -57,8 +57,21 @@ int gf_profile_collect(const char* tag, double* total_ms, int* count, double* wo
  *   w0c/w1c = coarse grid widths, scale = hw0_i[0]/hw0_c[0] (:193);
  *   outputs have capacity N*min(L,S) (+N when force_one): b/i/j_ids int64, mconf fp32,
  *   mkpts0_c/mkpts1_c [cap,2] fp32 (x,y);  counts int32[1+N]: total, then per sample.
+ *
+ *   MATCH-ONLY MODE (conf == NULL): the [N,L,S] matrix is not materialised - what inference.py:51-75 and
+ *   eval_tool/immatch/modules/geoformer.py consume are the matches - and 2 x 164 MB of writes per 640x640 pair are
+ *   saved; ids, mconf and keypoints are bit-identical to the contract mode's (entries the selection needs are
+ *   recomputed with the sweep's own arithmetic).  Built for the configuration inference runs, see
+ *   gf_dual_softmax_match_only_supported: 16-bit features, C = 256, L % 128 == 0, S % 64 == 0, no masks,
+ *   force_one == 0; anything else with conf == NULL is GF_ERR_INVALID_ARGUMENT.
+ *   gf_dual_softmax_conf_at returns single entries conf[b,i,j] afterwards (same features, the workspace of the
+ *   last gf_dual_softmax_match call), bit-identical to what the contract mode writes.
  * ------------------------------------------------------------------------------------------ */
 size_t gf_dual_softmax_workspace_bytes(int N, int L, int S);
+int gf_dual_softmax_match_only_supported(int dtype, int L, int S, int C, int masked, int force_one);
+int gf_dual_softmax_conf_at(const void* f0, const void* f1, int dtype, int N, int L, int S, int C, float temperature,
+                            const int64_t* b, const int64_t* i, const int64_t* j, int P, float* out, void* workspace,
+                            size_t workspace_bytes, void* stream);
 int gf_dual_softmax_match(const void* f0, const void* f1, int dtype, int N, int L, int S, int C,
                           const uint8_t* mask0, const uint8_t* mask1, float temperature, float thr,
                           int force_one, int w0c, int w1c, float scale, const float* scale0,

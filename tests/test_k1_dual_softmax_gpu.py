@@ -153,3 +153,64 @@ def test_full_size_repeatable(thr):
         assert digest[0] == first[0] and digest[1] == first[1]
         for a, b in zip(digest[2:], first[2:]):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('thr', [0.0, 0.2])
+def test_match_only_equals_contract_mode(dtype, thr):
+    """Match-only mode (conf == NULL; inference.py:51-75 never reads the matrices): ids, mconf, keypoints and
+    counts BIT-IDENTICAL to the contract mode's on planted correspondences with duplicated rows and columns (exact ties), both
+    candidate forms (thr 0: dense, thr 0.2: sparse); gf_dual_softmax_conf_at returns the matrix entries bit for bit."""
+    from geoformer_amd import ops
+    dev = 'cuda:0'
+    g = torch.Generator().manual_seed(31)
+    N, h, w = 2, 16, 24                                   # L = S = 384: three row panels, six column tiles
+    L = h * w
+    f0 = torch.randn(N, L, 256, generator=g) * 1.2
+    f1 = torch.stack([f0[b][torch.randperm(L, generator=g)] for b in range(N)]) + 0.3 * torch.randn(N, L, 256, generator=g)
+    f1[0, 5] = f1[0, 200]; f1[1, 77] = f1[1, 300]         # duplicated columns: exact ties inside rows
+    f0[0, 40] = f0[0, 7]; f0[1, 333] = f0[1, 12]          # duplicated rows: exact ties inside columns
+    f0, f1 = f0.to(dev, dtype), f1.to(dev, dtype)
+    assert ops.match_only_supported(f0, f1)
+    a = ops.dual_softmax_match(f0, f1, 0.1, thr, (h, w), (h, w), 8.0)
+    b = ops.dual_softmax_match(f0, f1, 0.1, thr, (h, w), (h, w), 8.0, materialize=False)
+    torch.cuda.synchronize()
+    assert b['conf_matrix'] is None
+    assert torch.equal(a['counts'], b['counts'])
+    M = int(a['counts'][0])
+    assert M > 100
+    for k in ('b_ids', 'i_ids', 'j_ids', 'mconf', 'mkpts0_c', 'mkpts1_c'):
+        assert torch.equal(a[k][:M], b[k][:M]), k
+    # single entries: every match, and a random sample of the matrix
+    got = ops.dual_softmax_conf_at(f0, f1, 0.1, a['b_ids'][:M], a['i_ids'][:M], a['j_ids'][:M])
+    assert torch.equal(got, a['mconf'][:M])
+    bb = torch.randint(0, N, (4000,), generator=g); ii = torch.randint(0, L, (4000,), generator=g); jj = torch.randint(0, L, (4000,), generator=g)
+    got = ops.dual_softmax_conf_at(f0, f1, 0.1, bb, ii, jj)
+    want = a['conf_matrix'][bb.to(dev), ii.to(dev), jj.to(dev)]
+    assert torch.equal(got, want)
+    # outside the configuration the library is built for, the wrapper materialises the matrix as usual
+    c = ops.dual_softmax_match(f0[:, :100].contiguous(), f1, 0.1, thr, (10, 10), (h, w), 8.0, materialize=False)
+    assert c['conf_matrix'] is not None
+
+
+def test_model_match_only_flag():
+    """geoformer_cfg['materialize_conf'] = False: conf matrices absent (None), every match output identical."""
+    from geoformer_amd.model.full_model import GeoFormer
+    from geoformer_amd.model.cvpr_ds_config import get_default_cfg
+    from geoformer_amd.model.geo_config import get_cfg_model
+    dev = 'cuda:0'
+    W = O.make_weights()
+    outs = []
+    for mat in (True, False):
+        cfg = get_cfg_model(); cfg.update(precision='fp16', materialize_conf=mat)
+        m = GeoFormer(get_default_cfg(), cfg).eval()
+        m.load_state_dict(dict(W)); m = m.to(dev)
+        (c0, f0), (c1, f1) = GI.planted_features(2, 16, 16, 16, 16, 102)
+        data = {'image0': torch.zeros(2, 1, 128, 128, device=dev), 'image1': torch.zeros(2, 1, 128, 128, device=dev)}
+        with torch.no_grad():
+            outs.append(m.forward_features(data, c0.to(dev), f0.to(dev), c1.to(dev), f1.to(dev)))
+    a, b = outs
+    assert a['conf_matrix'] is not None and b['conf_matrix'] is None and b['dect_conf_matrix'] is None
+    assert len(a['b_ids']) > 50
+    for k in ('b_ids', 'i_ids', 'j_ids', 'm_bids', 'mkpts0_c', 'mkpts1_c', 'mkpts0_f', 'mkpts1_f', 'mconf'):
+        assert torch.equal(a[k], b[k]), k
