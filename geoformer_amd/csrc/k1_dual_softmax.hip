@@ -869,12 +869,23 @@ __global__ __launch_bounds__(NT, 2) void k1_stats_panel(K1Args a) {
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+            // the f1 fragments of k-group kg + 1 are requested in front of the MFMAs of kg (two waves per SIMD do not hide an LDS
+            // round trip in front of every MFMA pair: left alone the compiler reads each pair right where it is used)
+            V8 b0 = *reinterpret_cast<const V8*>(smem + k1p_off(lr, h)), b1 = *reinterpret_cast<const V8*>(smem + k1p_off(32 + lr, h));
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);          // issue order: reads(0) | reads(1) MFMAs(0) | reads(2) MFMAs(1) | ...
 #pragma unroll
             for (int kg = 0; kg < 16; ++kg) {
-                const V8 b0 = *reinterpret_cast<const V8*>(smem + k1p_off(lr, 2 * kg + h));
-                const V8 b1 = *reinterpret_cast<const V8*>(smem + k1p_off(32 + lr, 2 * kg + h));
+                V8 n0 = b0, n1 = b1;
+                if (kg < 15) {
+                    n0 = *reinterpret_cast<const V8*>(smem + k1p_off(lr, 2 * kg + 2 + h));
+                    n1 = *reinterpret_cast<const V8*>(smem + k1p_off(32 + lr, 2 * kg + 2 + h));
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
                 Mma32<H>::mma(af[kg], b0, acc[0]);
                 Mma32<H>::mma(af[kg], b1, acc[1]);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                b0 = n0;
+                b1 = n1;
             }
             // ---- maxima on the raw accumulators: columns over the registers, row slots over the two column halves and the tiles
             float cmr0 = NEG_INF, cmr1 = NEG_INF;
