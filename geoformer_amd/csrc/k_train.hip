@@ -1,0 +1,347 @@
+// Training: the backward of the K3 chain - linear + LayerNorm / ReLU / Tanh - in HIP, for the mixed-16-bit step
+// (lightning/train_depth_geoformer.py:117-119 runs the reference under 16-bit autocast; fp32 master weights and gradients).
+//
+//   y = x W^T            (nn.Linear without bias: every linear of LoFTREncoderLayer / the Geo layers / FinePreprocess' down_proj)
+//     dX = dY W          -> gf_linear itself (K3) with the transposed weight: no new kernel
+//     dW = dY^T X        -> gf_linear_wgrad below: the contraction runs over the TOKENS, i.e. over the row index of both
+//                           row-major operands - the same "TN" shape as the linear-attention state of K2, and the same
+//                           machinery: token sub-tiles staged row-major in LDS, MFMA operands fetched with the gfx950
+//                           transpose read ds_read_b64_tr_b16, fp32 accumulation, split over token chunks with fp32
+//                           partials that a second kernel adds in chunk order (deterministic: no atomics)
+//   out = LayerNorm(y)   -> gf_layernorm_forward keeps (mean, rstd) per row; gf_layernorm_backward:
+//                           dy = rstd (g - mean_c(g) - xhat mean_c(g xhat)),  g = dout * gamma,  xhat = (y - mean) rstd,
+//                           dgamma = sum_rows dout xhat, dbeta = sum_rows dout  (per-workgroup partials + ordered sum)
+//   h = act(z)           -> gf_activation_backward: dz = dh * (h > 0)  (ReLU)  |  dh * (1 - h^2)  (Tanh), from the OUTPUT h
+//
+// The autograd side (which tensors are saved, in which precision) lives in geoformer_amd/train/hip_autograd.py.
+#include <math.h>
+
+#include "gf_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dW[co][ci] = sum_t dY[t][co] X[t][ci]
+// Workgroup = 128 x 128 of dW for one chunk of tokens; 4 waves as 2 x 2, each 64 x 64 = four 32 x 32 accumulators.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int WG_T = 32;            // tokens per sub-tile (two 16-deep MFMA k-steps)
+constexpr int WG_RS = 320;          // LDS row stride of a [32 tok][128 ch] image: 256 B + 64 B (80 dwords: the four token rows of a
+                                    // transpose-read group land 16 banks apart, the two groups of a wave half 8 apart - conflict-free)
+
+struct WgArgs {
+    const void* dy;
+    const void* x;
+    long lddy, ldx, T;
+    int cout, cin, chunks, chunk_tokens;
+    float* part;        // [chunks][cout][cin]
+    float* dw;
+    long lddw;
+    int accumulate;
+};
+
+// MFMA operand of 32 channels x the 16 tokens of k-step s2: lane (channel = lane & 31, half h2) gets tokens 16 s2 + 8 h2 + 0..7
+template <typename H>
+__device__ __forceinline__ gf_vec<H, 8> wg_tr_frag(const char* img, int ch0, int s2, int lane) {
+    const int G = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int tok0 = 16 * s2 + 8 * (G >> 1);
+    const char* base = img + (tok0 + q) * WG_RS + (ch0 + 16 * (G & 1) + 4 * p) * 2;
+    typedef __attribute__((address_space(3))) gf_v4s* LP;
+    const gf_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LP)(base));
+    const gf_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LP)(base + 4 * WG_RS));
+    typedef short v8s __attribute__((__vector_size__(8 * sizeof(short))));
+    const v8s both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(gf_vec<H, 8>, both);
+}
+
+template <typename H>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgArgs a) {
+    __shared__ __attribute__((aligned(16))) char yt[WG_T * WG_RS];
+    __shared__ __attribute__((aligned(16))) char xt[WG_T * WG_RS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128, chunk = blockIdx.z;
+    const long t_begin = (long)chunk * a.chunk_tokens, t_end = t_begin + a.chunk_tokens < a.T ? t_begin + a.chunk_tokens : a.T;
+    const H* yp = (const H*)a.dy + m0;
+    const H* xp = (const H*)a.x + n0;
+    v16f acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // a sub-tile = 32 tokens x 128 channels = 512 pieces of 16 B per operand: two per thread; the next sub-tile is in flight
+    // in registers while this one is multiplied
+    const v4u zero{0u, 0u, 0u, 0u};
+    v4u ry[2], rx[2];
+    auto fetch = [&](long t0) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int e = p * 256 + tid, tok = e >> 4, c8 = (e & 15) * 8;
+            const long t = t0 + tok;
+            ry[p] = zero;
+            rx[p] = zero;
+            if (t < t_end) {
+                ry[p] = *reinterpret_cast<const v4u*>(yp + t * a.lddy + c8);
+                rx[p] = *reinterpret_cast<const v4u*>(xp + t * a.ldx + c8);
+            }
+        }
+    };
+    fetch(t_begin);
+    for (long t0 = t_begin; t0 < t_end; t0 += WG_T) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int e = p * 256 + tid, tok = e >> 4, c8 = (e & 15) * 8;
+            *reinterpret_cast<v4u*>(yt + tok * WG_RS + c8 * 2) = ry[p];
+            *reinterpret_cast<v4u*>(xt + tok * WG_RS + c8 * 2) = rx[p];
+        }
+        __syncthreads();
+        if (t0 + WG_T < t_end) fetch(t0 + WG_T);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const auto a0 = wg_tr_frag<H>(yt, wm * 64, s2, lane), a1 = wg_tr_frag<H>(yt, wm * 64 + 32, s2, lane);
+            const auto b0 = wg_tr_frag<H>(xt, wn * 64, s2, lane), b1 = wg_tr_frag<H>(xt, wn * 64 + 32, s2, lane);
+            Mma32<H>::mma(a0, b0, acc[0][0]);
+            Mma32<H>::mma(a0, b1, acc[0][1]);
+            Mma32<H>::mma(a1, b0, acc[1][0]);
+            Mma32<H>::mma(a1, b1, acc[1][1]);
+        }
+        __syncthreads();
+    }
+    // accumulator: row = dY channel (r, h2), lane = X channel: 128-B runs along ci
+    const int h2 = lane >> 5, lr = lane & 31;
+    float* dst = a.part + ((size_t)chunk * a.cout + m0 + wm * 64) * a.cin + n0 + wn * 64 + lr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(size_t)(i * 32 + gf_acc_row(r, h2)) * a.cin + j * 32] = acc[i][j][r];
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce(WgArgs a) {
+    const size_t n = (size_t)a.cout * a.cin, e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    float s = 0.f;
+    int c = 0;
+    for (; c + 8 <= a.chunks; c += 8) {                  // eight partials in flight, added in chunk order
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = a.part[(size_t)(c + k) * n + e];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[k];
+    }
+    for (; c < a.chunks; ++c) s += a.part[(size_t)c * n + e];
+    float* d = a.dw + (e / a.cin) * a.lddw + e % a.cin;
+    *d = a.accumulate ? *d + s : s;
+}
+
+int wgrad_chunks(long T, int cout, int cin) {
+    // about three workgroups per CU, at least 128 tokens per chunk
+    const long tiles = (long)(cout / 128) * (cin / 128), want = (768 + tiles - 1) / tiles, most = (T + 127) / 128;
+    long c = want < most ? want : most;
+    return (int)(c < 1 ? 1 : c);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LayerNorm over the last dimension, one wave per row, C / 64 channels per lane (C in {128, 256, 512}); statistics in fp32
+// ---------------------------------------------------------------------------------------------------------------------
+struct LnArgs {
+    const void* y;        // [T][C] pre-normalisation
+    const void* dout;     // [T][C]   (backward)
+    const float* gamma;
+    const float* beta;
+    float eps;
+    void* out;            // forward: [T][C];  backward: dy [T][C]
+    float* stats;         // [T][2]  (mean, rstd)
+    float* part;          // backward: [workgroups][2][C]  dgamma | dbeta partials
+    float* dgamma;
+    float* dbeta;
+    long T;
+    int C, parts, accumulate;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+template <typename H, int PER>
+__global__ __launch_bounds__(256) void ln_forward(LnArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.T) return;
+    const H* yr = (const H*)a.y + row * a.C + lane * PER;
+    float v[PER];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { v[k] = gf_to_float(yr[k]); s += v[k]; }
+    const float mean = wave_sum(s) * (1.0f / (float)a.C);
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) q += (v[k] - mean) * (v[k] - mean);
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / (float)a.C) + a.eps);      // biased variance, as nn.LayerNorm
+    H* o = (H*)a.out + row * a.C + lane * PER;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) o[k] = gf_from_float<H>((v[k] - mean) * rstd * a.gamma[lane * PER + k] + a.beta[lane * PER + k]);
+    if (lane == 0) { a.stats[2 * row] = mean; a.stats[2 * row + 1] = rstd; }
+}
+
+template <typename H, int PER>
+__global__ __launch_bounds__(256) void ln_backward(LnArgs a) {
+    __shared__ float red[4][2][512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float ga[PER], dg[PER], db[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { ga[k] = a.gamma[lane * PER + k]; dg[k] = 0.f; db[k] = 0.f; }
+    for (long row = (long)blockIdx.x * 4 + wave; row < a.T; row += (long)gridDim.x * 4) {
+        const float mean = a.stats[2 * row], rstd = a.stats[2 * row + 1];
+        const H* yr = (const H*)a.y + row * a.C + lane * PER;
+        const H* dr = (const H*)a.dout + row * a.C + lane * PER;
+        float xh[PER], g[PER];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const float d = gf_to_float(dr[k]);
+            xh[k] = (gf_to_float(yr[k]) - mean) * rstd;
+            g[k] = d * ga[k];
+            s1 += g[k];
+            s2 += g[k] * xh[k];
+            dg[k] += d * xh[k];
+            db[k] += d;
+        }
+        const float m1 = wave_sum(s1) * (1.0f / (float)a.C), m2 = wave_sum(s2) * (1.0f / (float)a.C);
+        H* o = (H*)a.out + row * a.C + lane * PER;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) o[k] = gf_from_float<H>(rstd * (g[k] - m1 - xh[k] * m2));
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { red[wave][0][lane * PER + k] = dg[k]; red[wave][1][lane * PER + k] = db[k]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * a.C; c += 256) {
+        const int which = c / a.C, ch = c - which * a.C;
+        a.part[((size_t)blockIdx.x * 2 + which) * a.C + ch] = (red[0][which][ch] + red[1][which][ch]) + (red[2][which][ch] + red[3][which][ch]);
+    }
+}
+
+__global__ void ln_param_reduce(LnArgs a) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= 2 * a.C) return;
+    const int which = c / a.C, ch = c - which * a.C;
+    float s = 0.f;
+    for (int p = 0; p < a.parts; ++p) s += a.part[((size_t)p * 2 + which) * a.C + ch];
+    float* d = (which ? a.dbeta : a.dgamma) + ch;
+    *d = a.accumulate ? *d + s : s;
+}
+
+template <typename H>
+__global__ void act_backward(const H* dh, const H* h, H* dz, size_t n, int kind) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const float hv = gf_to_float(h[e]), d = gf_to_float(dh[e]);
+        dz[e] = gf_from_float<H>(kind == 0 ? (hv > 0.f ? d : 0.f) : d * (1.0f - hv * hv));
+    }
+}
+
+constexpr int LN_BWD_WGS = 512;
+
+}   // namespace
+
+extern "C" size_t gf_linear_wgrad_workspace_bytes(long T, int cout, int cin) {
+    if (T <= 0 || cout <= 0 || cin <= 0 || cout % 128 || cin % 128) return 0;
+    return gf_align_up(sizeof(float) * (size_t)wgrad_chunks(T, cout, cin) * cout * cin, 256);
+}
+
+// dw[co * lddw + ci] (+)= sum_t dy[t * lddy + co] * x[t * ldx + ci]   (fp32), dy [T, cout], x [T, cin] of a 16-bit dtype
+extern "C" int gf_linear_wgrad(const void* dy, long lddy, const void* x, long ldx, int dtype, long T, int cout, int cin, float* dw,
+                               long lddw, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    GF_CHECK_ARG(dy && x && dw, "null pointer");
+    GF_CHECK_ARG(dtype == GF_F16 || dtype == GF_BF16, "built for 16-bit activations (GF_F16 / GF_BF16)");
+    GF_CHECK_ARG(T > 0 && cout > 0 && cin > 0 && cout % 128 == 0 && cin % 128 == 0, "cout and cin must be multiples of 128");
+    GF_CHECK_ARG((lddy * 2) % 16 == 0 && (ldx * 2) % 16 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)x % 16 == 0, "rows must be 16-byte aligned");
+    GF_CHECK_ARG(lddw >= cin, "lddw < cin");
+    if (workspace == nullptr || workspace_bytes < gf_linear_wgrad_workspace_bytes(T, cout, cin)) {
+        gf_set_error("gf_linear_wgrad: workspace too small");
+        return GF_ERR_WORKSPACE;
+    }
+    WgArgs a{};
+    a.dy = dy; a.x = x; a.lddy = lddy; a.ldx = ldx; a.T = T; a.cout = cout; a.cin = cin;
+    a.chunks = wgrad_chunks(T, cout, cin);
+    a.chunk_tokens = (int)(((T + a.chunks - 1) / a.chunks + WG_T - 1) / WG_T * WG_T);
+    a.chunks = (int)((T + a.chunk_tokens - 1) / a.chunk_tokens);
+    a.part = (float*)workspace; a.dw = dw; a.lddw = lddw; a.accumulate = accumulate;
+    hipStream_t st = (hipStream_t)stream;
+    void* pt = gf_prof_begin("wgrad", st, 2.0 * (double)T * cout * cin);
+    const dim3 grid(cin / 128, cout / 128, a.chunks);
+    if (dtype == GF_F16) wgrad_kernel<_Float16><<<grid, 256, 0, st>>>(a);
+    else wgrad_kernel<gf_bf16><<<grid, 256, 0, st>>>(a);
+    wgrad_reduce<<<(unsigned)(((size_t)cout * cin + 255) / 256), 256, 0, st>>>(a);
+    gf_prof_end("wgrad", pt, st);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}
+
+template <typename H>
+static int ln_dispatch(const LnArgs& a, bool backward, hipStream_t st) {
+    const unsigned fwd_grid = (unsigned)((a.T + 3) / 4);
+    switch (a.C) {
+    case 128: if (backward) ln_backward<H, 2><<<a.parts, 256, 0, st>>>(a); else ln_forward<H, 2><<<fwd_grid, 256, 0, st>>>(a); break;
+    case 256: if (backward) ln_backward<H, 4><<<a.parts, 256, 0, st>>>(a); else ln_forward<H, 4><<<fwd_grid, 256, 0, st>>>(a); break;
+    case 512: if (backward) ln_backward<H, 8><<<a.parts, 256, 0, st>>>(a); else ln_forward<H, 8><<<fwd_grid, 256, 0, st>>>(a); break;
+    default: return -1;
+    }
+    return 0;
+}
+
+// out = LayerNorm(y; gamma, beta, eps) over the last dimension, stats[t] = (mean, rstd)   (nn.LayerNorm: biased variance)
+extern "C" int gf_layernorm_forward(const void* y, int dtype, long T, int C, const float* gamma, const float* beta, float eps, void* out,
+                                    float* stats, void* stream) {
+    GF_CHECK_ARG(y && gamma && beta && out && stats, "null pointer");
+    GF_CHECK_ARG(dtype == GF_F16 || dtype == GF_BF16, "built for 16-bit activations");
+    GF_CHECK_ARG(T > 0 && (C == 128 || C == 256 || C == 512), "C must be 128, 256 or 512");
+    LnArgs a{};
+    a.y = y; a.gamma = gamma; a.beta = beta; a.eps = eps; a.out = out; a.stats = stats; a.T = T; a.C = C;
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = dtype == GF_F16 ? ln_dispatch<_Float16>(a, false, st) : ln_dispatch<gf_bf16>(a, false, st);
+    GF_CHECK_ARG(rc == 0, "dispatch failed");
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}
+
+extern "C" size_t gf_layernorm_backward_workspace_bytes(int C) { return C > 0 ? gf_align_up(sizeof(float) * LN_BWD_WGS * 2 * (size_t)C, 256) : 0; }
+
+// dy, dgamma (+)=, dbeta (+)= of out = LayerNorm(y) from dout, the saved y and stats
+extern "C" int gf_layernorm_backward(const void* dout, const void* y, const float* stats, int dtype, long T, int C, const float* gamma, void* dy,
+                                     float* dgamma, float* dbeta, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    GF_CHECK_ARG(dout && y && stats && gamma && dy && dgamma && dbeta, "null pointer");
+    GF_CHECK_ARG(dtype == GF_F16 || dtype == GF_BF16, "built for 16-bit activations");
+    GF_CHECK_ARG(T > 0 && (C == 128 || C == 256 || C == 512), "C must be 128, 256 or 512");
+    if (workspace == nullptr || workspace_bytes < gf_layernorm_backward_workspace_bytes(C)) {
+        gf_set_error("gf_layernorm_backward: workspace too small");
+        return GF_ERR_WORKSPACE;
+    }
+    LnArgs a{};
+    a.y = y; a.dout = dout; a.gamma = gamma; a.out = dy; a.stats = const_cast<float*>(stats); a.T = T; a.C = C;
+    a.part = (float*)workspace; a.dgamma = dgamma; a.dbeta = dbeta; a.accumulate = accumulate;
+    const long rows4 = (T + 3) / 4;
+    a.parts = (int)(rows4 < LN_BWD_WGS ? rows4 : LN_BWD_WGS);
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = dtype == GF_F16 ? ln_dispatch<_Float16>(a, true, st) : ln_dispatch<gf_bf16>(a, true, st);
+    GF_CHECK_ARG(rc == 0, "dispatch failed");
+    ln_param_reduce<<<(2 * C + 255) / 256, 256, 0, st>>>(a);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}
+
+// dz = dh * act'(z) from the activation's OUTPUT h: kind 0 ReLU (h > 0), 1 Tanh (1 - h^2); n elements of a 16-bit dtype
+extern "C" int gf_activation_backward(const void* dh, const void* h, void* dz, size_t n, int kind, int dtype, void* stream) {
+    GF_CHECK_ARG(dh && h && dz, "null pointer");
+    GF_CHECK_ARG(dtype == GF_F16 || dtype == GF_BF16, "built for 16-bit activations");
+    GF_CHECK_ARG(kind == 0 || kind == 1, "kind: 0 = ReLU, 1 = Tanh");
+    if (n == 0) return GF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    if (dtype == GF_F16) act_backward<_Float16><<<grid, 256, 0, st>>>((const _Float16*)dh, (const _Float16*)h, (_Float16*)dz, n, kind);
+    else act_backward<gf_bf16><<<grid, 256, 0, st>>>((const gf_bf16*)dh, (const gf_bf16*)h, (gf_bf16*)dz, n, kind);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}

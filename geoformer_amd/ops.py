@@ -470,3 +470,61 @@ class CoarseFocalLoss(torch.autograd.Function):
 
 def coarse_focal_loss(f0, f1, pos_b, pos_i, pos_j, temperature, alpha=0.25, gamma=2.0, weight=None, mask0=None, mask1=None):
     return CoarseFocalLoss.apply(f0, f1, pos_b, pos_i, pos_j, temperature, alpha, gamma, weight, mask0, mask1)
+
+
+# ---------------------------------------------------------------------------------------------
+# training: backward of the K3 chain (linear, LayerNorm, activation) - see csrc/k_train.hip
+# ---------------------------------------------------------------------------------------------
+def linear_wgrad(dy, x, out=None, accumulate=False):
+    """dW [cout, cin] fp32 (+)= dy^T x over all leading dimensions; dy [..., cout], x [..., cin] 16-bit (row-strided views allowed).
+    `out` may be a column block of a wider gradient (row stride > cin): the two halves of torch.cat([x, m]) write theirs."""
+    _need_cuda(dy, x)
+    dy, lddy = _rows2d(dy)
+    x, ldx = _rows2d(x)
+    cout, cin = dy.shape[-1], x.shape[-1]
+    T = dy.numel() // cout
+    if out is None:
+        out = torch.empty(cout, cin, dtype=torch.float32, device=dy.device)
+    L_ = _lib.lib()
+    ws = _ws.get('wgrad', L_.gf_linear_wgrad_workspace_bytes(T, cout, cin), dy.device)
+    check(L_.gf_linear_wgrad(_p(dy), lddy, _p(x), ldx, _dt(dy), T, cout, cin, _p(out), out.stride(0), int(bool(accumulate)), _p(ws), ws.numel(),
+                             _stream()), 'gf_linear_wgrad')
+    return out
+
+
+def layernorm_forward(y, gamma, beta, eps=1e-5):
+    """(LayerNorm(y) in y's 16-bit dtype, stats fp32 [T, 2] = (mean, rstd)); gamma, beta fp32."""
+    _need_cuda(y, gamma)
+    y = _contig(y)
+    C = y.shape[-1]
+    T = y.numel() // C
+    out = torch.empty_like(y)
+    stats = torch.empty(T, 2, dtype=torch.float32, device=y.device)
+    check(_lib.lib().gf_layernorm_forward(_p(y), _dt(y), T, C, _p(gamma), _p(beta), float(eps), _p(out), _p(stats), _stream()),
+          'gf_layernorm_forward')
+    return out, stats
+
+
+def layernorm_backward(dout, y, stats, gamma):
+    """(dy in y's dtype, dgamma fp32 [C], dbeta fp32 [C])."""
+    _need_cuda(dout, y)
+    dout, y = _contig(dout), _contig(y)
+    C = y.shape[-1]
+    T = y.numel() // C
+    dy = torch.empty_like(y)
+    dg = torch.empty(2, C, dtype=torch.float32, device=y.device)
+    L_ = _lib.lib()
+    ws = _ws.get('lnbwd', L_.gf_layernorm_backward_workspace_bytes(C), y.device)
+    check(L_.gf_layernorm_backward(_p(dout), _p(y), _p(stats), _dt(y), T, C, _p(gamma), _p(dy), _p(dg[0]), _p(dg[1]), 0, _p(ws), ws.numel(),
+                                   _stream()), 'gf_layernorm_backward')
+    return dy, dg[0], dg[1]
+
+
+def activation_backward(dh, h, kind):
+    """dz = dh * act'(z) from the activation's output h (kind 'relu' | 'tanh'); 16-bit tensors."""
+    _need_cuda(dh, h)
+    dh, h = _contig(dh), _contig(h)
+    dz = torch.empty_like(h)
+    check(_lib.lib().gf_activation_backward(_p(dh), _p(h), _p(dz), h.numel(), {'relu': 0, 'tanh': 1}[kind], _dt(h), _stream()),
+          'gf_activation_backward')
+    return dz

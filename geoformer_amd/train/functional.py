@@ -93,9 +93,42 @@ def full_attention(q, k, v, kv_mask=None):
     return out
 
 
+_HIP_BACKWARD = [False]
+
+
+def set_hip_backward(on: bool):
+    """Route the linears / LayerNorms / activations of the encoder layers through the HIP forward + backward kernels
+    (train/hip_autograd.py) inside a 16-bit autocast region; everything else (attention cores, losses) stays on autograd."""
+    _HIP_BACKWARD[0] = bool(on)
+
+
+def _encoder_layer_hip(P, prefix, x, source, nhead, kind, x_mask, source_mask):
+    """The same layer with the K3 chain in HIP, forward and backward.  Rounding points = those of the autocast path (16-bit
+    operands, fp32 accumulation and LayerNorm statistics), plus ONE more: the LayerNorm-2 output is rounded to the 16-bit type
+    before the fp32 residual add (autocast's layer_norm returns fp32)."""
+    from . import hip_autograd as HA
+    dt = torch.get_autocast_dtype('cuda')
+    n, _, c = x.shape
+    d = c // nhead
+    x16 = x.to(dt)
+    s16 = x16 if source is x else source.to(dt)
+    q = HA.linear(x16, P[prefix + 'q_proj.weight']).view(n, -1, nhead, d)
+    k = HA.linear(s16, P[prefix + 'k_proj.weight']).view(n, -1, nhead, d)
+    v = HA.linear(s16, P[prefix + 'v_proj.weight']).view(n, -1, nhead, d)
+    msg = linear_attention(q, k, v, x_mask, source_mask) if kind == 'loftr' else full_attention(q, k, v, source_mask)
+    msg = HA.linear(msg.reshape(n, -1, c).to(dt), P[prefix + 'merge.weight'])
+    msg = HA.layer_norm(msg, P[prefix + 'norm1.weight'], P[prefix + 'norm1.bias'])
+    hid = HA.linear(x16, P[prefix + 'mlp.0.weight'], msg, 'relu' if kind == 'loftr' else 'tanh')
+    msg = HA.linear(hid, P[prefix + 'mlp.2.weight'])
+    msg = HA.layer_norm(msg, P[prefix + 'norm2.weight'], P[prefix + 'norm2.bias'])
+    return x + msg
+
+
 def encoder_layer(P, prefix, x, source, nhead, kind, x_mask=None, source_mask=None):
     """loftr_module/transformer.py:37-60 (ReLU, linear attention) / geo_transformer/transformer.py:39-66 (Tanh, full)."""
     n, _, c = x.shape
+    if _HIP_BACKWARD[0] and x.is_cuda and torch.is_autocast_enabled() and c % 128 == 0 and x.shape[1] > 0 and source.shape[1] > 0:
+        return _encoder_layer_hip(P, prefix, x, source, nhead, kind, x_mask, source_mask)
     d = c // nhead
     q = F.linear(x, P[prefix + 'q_proj.weight']).view(n, -1, nhead, d)
     k = F.linear(source, P[prefix + 'k_proj.weight']).view(n, -1, nhead, d)

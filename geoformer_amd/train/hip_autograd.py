@@ -1,0 +1,79 @@
+"""torch.autograd Functions whose forward AND backward are the HIP kernels of the K3 chain.
+
+Used by the mixed-16-bit training step (`TrainStep(precision='bf16', hip_backward=True)`): the linears, LayerNorms and
+activations of the encoder layers (loftr_module/transformer.py:45-60, geo_transformer/transformer.py:49-66) and of
+FinePreprocess (fine_preprocess.py:61-72) run `gf_linear` / `gf_layernorm_forward` forward and
+`gf_linear` (dX = dY W), `gf_linear_wgrad` (dW = dY^T X), `gf_layernorm_backward`, `gf_activation_backward` backward.
+Master parameters stay fp32: a Function receives the fp32 parameter, casts it to the activations' 16-bit type for the
+kernels (what torch.autocast does for nn.Linear) and returns an fp32 gradient.
+
+What is saved for backward: the 16-bit inputs of every linear, the pre-LayerNorm rows with their (mean, rstd), the
+activation OUTPUTS (ReLU / Tanh derivatives are functions of the output) - the same tensors autograd keeps.
+"""
+import torch
+
+from .. import ops
+
+
+class HipLinear(torch.autograd.Function):
+    """y = act([x | x2] @ w.T), no bias; x [..., k1], x2 [..., k2] or None (the two halves of torch.cat([x, message], 2)),
+    w fp32 or 16-bit [n, k1 + k2]; act in (None, 'relu', 'tanh')."""
+
+    @staticmethod
+    def forward(ctx, x, w, x2=None, act=None):
+        w16 = w if w.dtype == x.dtype else w.detach().to(x.dtype)
+        epi = {None: ops.EPI_NONE, 'relu': ops.EPI_RELU, 'tanh': ops.EPI_TANH}[act]
+        y = ops.linear(x, w16, a2=x2, epilogue=epi)
+        ctx.act, ctx.k1, ctx.has2, ctx.wdtype = act, x.shape[-1], x2 is not None, w.dtype
+        ctx.save_for_backward(x, x2 if x2 is not None else x.new_empty(0), w16, y if act is not None else x.new_empty(0))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, x2, w16, y = ctx.saved_tensors
+        dz = ops.activation_backward(dy, y, ctx.act) if ctx.act is not None else dy.contiguous()
+        need_x, need_w, need_x2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has2 and ctx.needs_input_grad[2]
+        dx = dx2 = dw = None
+        if need_x or need_x2:
+            dfull = ops.linear(dz, w16.t().contiguous())               # [..., k1 + k2] = dZ W
+            dx = dfull[..., :ctx.k1] if need_x else None
+            dx2 = dfull[..., ctx.k1:] if need_x2 else None
+        if need_w:
+            dw = torch.empty(w16.shape, dtype=torch.float32, device=w16.device)
+            ops.linear_wgrad(dz, x, out=dw[:, :ctx.k1])
+            if ctx.has2:
+                ops.linear_wgrad(dz, x2, out=dw[:, ctx.k1:])
+            if ctx.wdtype != torch.float32:
+                dw = dw.to(ctx.wdtype)
+        return dx, dw, dx2, None
+
+
+class HipLayerNorm(torch.autograd.Function):
+    """nn.LayerNorm over the last dimension (128, 256 or 512 channels), 16-bit rows, fp32 gamma / beta and statistics."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, eps=1e-5):
+        g32, b32 = gamma.detach().float(), beta.detach().float()
+        out, stats = ops.layernorm_forward(y, g32, b32, eps)
+        ctx.save_for_backward(y, stats, g32)
+        ctx.pdtype = gamma.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, stats, g32 = ctx.saved_tensors
+        dy, dg, db = ops.layernorm_backward(dout, y, stats, g32)
+        return dy, dg.to(ctx.pdtype), db.to(ctx.pdtype), None
+
+
+def linear(x, w, x2=None, act=None):
+    return HipLinear.apply(x, w, x2, act)
+
+
+def layer_norm(y, gamma, beta, eps=1e-5):
+    return HipLayerNorm.apply(y, gamma, beta, eps)
+
+
+def supported(x, *widths):
+    """The HIP chain is built for 16-bit CUDA activations and channel counts that are multiples of 128."""
+    return x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and all(w % 128 == 0 for w in widths)

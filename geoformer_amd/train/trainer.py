@@ -107,10 +107,16 @@ class TrainStep:
     `precision='bf16'` is the mixed-precision step of BASELINE configs[3] (`--precision bf16` of the reference's Lightning
     trainer, lightning/train_depth_geoformer.py:117-119): fp32 master parameters and optimizer state, the forward under
     torch.autocast(bfloat16); confidence matrices, softmax, LayerNorm and the losses stay fp32.  Use it with
-    `fused_coarse_loss=True`, which keeps the two L x S confidence matrices out of the autograd graph altogether."""
+    `fused_coarse_loss=True`, which keeps the two L x S confidence matrices out of the autograd graph altogether.
+
+    `hip_backward=True` (with precision='bf16'): the linears, LayerNorms and activations of every encoder layer (LoFTR coarse and
+    fine, Geo) run the HIP kernels forward AND backward (train/hip_autograd.py: gf_linear, gf_linear_wgrad, gf_layernorm_*,
+    gf_activation_backward) instead of torch's GEMM / autograd; the attention cores, the fine matching and the losses other than
+    the fused coarse loss stay on autograd."""
 
     def __init__(self, model, trainer_cfg=None, loss_cfg=None, batch_size=1, distributed=False, device_ids=None,
-                 homography_fn: Optional[Callable] = None, sparse_spvs=True, fused_coarse_loss=False, precision='fp32'):
+                 homography_fn: Optional[Callable] = None, sparse_spvs=True, fused_coarse_loss=False, precision='fp32',
+                 hip_backward=False):
         world = torch.distributed.get_world_size() if distributed else 1
         self.cfg = scale_trainer_cfg(trainer_cfg, world, batch_size)
         if model.precision != 'fp32':
@@ -120,6 +126,9 @@ class TrainStep:
         if precision not in ('fp32', 'bf16'):
             raise ValueError("TrainStep precision: 'fp32' or 'bf16' (mixed: fp32 master weights, bf16 GEMMs / convolutions)")
         self.precision = precision
+        if hip_backward and precision != 'bf16':
+            raise ValueError("hip_backward=True (K3 chain forward + backward in HIP) is built for the mixed-16-bit step: precision='bf16'")
+        self.hip_backward = bool(hip_backward)
         core = _Core(model, GeoLoss(loss_cfg, model.config['match_coarse'].get('match_type', 'dual_softmax'), sparse_spvs),
                      homography_fn, fused_coarse_loss, torch.bfloat16 if precision == 'bf16' else None)
         if distributed:
@@ -136,7 +145,12 @@ class TrainStep:
         self.global_step = 0
 
     def __call__(self, batch):
-        loss = self.core(batch)
+        from .functional import set_hip_backward
+        set_hip_backward(self.hip_backward)
+        try:
+            loss = self.core(batch)
+        finally:
+            set_hip_backward(False)
         if 'loss_scalars' not in batch:          # the wrapper handed the forward a copy of the batch
             raise RuntimeError('the training forward did not write into the caller\'s batch')
         self.optimizer.zero_grad(set_to_none=True)

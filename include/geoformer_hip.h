@@ -80,6 +80,28 @@ int gf_dual_softmax_match(const void* f0, const void* f1, int dtype, int N, int 
                           int32_t* counts, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K3 (training)  backward of the linear + LayerNorm / activation chain, mixed-16-bit step
+ * what torch autograd derives for LoFTREncoderLayer.forward (model/loftr_src/loftr/loftr_module/transformer.py:45-60), the Geo
+ *          layers (model/geo_transformer/transformer.py:49-66) and FinePreprocess' linears (fine_preprocess.py:61-72) when
+ *          lightning/train_depth_geoformer.py:117-119 runs the step under 16-bit autocast; fp32 master weights / gradients.
+ *   y = x W^T:   dX = dY W is gf_linear with the transposed weight;  dW = dY^T X is gf_linear_wgrad (fp32 [cout, cin], row
+ *   stride lddw, optionally accumulated): the contraction runs over the T token rows of both operands (MFMA operands by
+ *   transpose reads), split over token chunks, partials added in chunk order (deterministic).  cout, cin multiples of 128.
+ *   gf_layernorm_forward keeps stats[t] = (mean, rstd); gf_layernorm_backward returns dy and dgamma / dbeta (fp32 [C],
+ *   optionally accumulated); C in {128, 256, 512}.  gf_activation_backward: dz = dh * act'(z) from the OUTPUT h of the
+ *   activation (kind 0 ReLU, 1 Tanh).  All activations GF_F16 or GF_BF16, statistics and parameter gradients fp32.
+ * ------------------------------------------------------------------------------------------ */
+size_t gf_linear_wgrad_workspace_bytes(long T, int cout, int cin);
+int gf_linear_wgrad(const void* dy, long lddy, const void* x, long ldx, int dtype, long T, int cout, int cin, float* dw,
+                    long lddw, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+int gf_layernorm_forward(const void* y, int dtype, long T, int C, const float* gamma, const float* beta, float eps, void* out,
+                         float* stats, void* stream);
+size_t gf_layernorm_backward_workspace_bytes(int C);
+int gf_layernorm_backward(const void* dout, const void* y, const float* stats, int dtype, long T, int C, const float* gamma, void* dy,
+                          float* dgamma, float* dbeta, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+int gf_activation_backward(const void* dh, const void* h, void* dz, size_t n, int kind, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * K1 (training)  sparse-supervision focal loss on the dual-softmax confidence, forward and backward
  * replaces, for the training step, CoarseMatching.forward's conf_matrix (coarse_matching.py:113-125) as consumed by
  *          GeoLoss.compute_coarse_loss, focal / sparse_spvs / dual_softmax branch (loftr_loss.py:246-270), and the

@@ -1,0 +1,139 @@
+"""the K3 chain's backward in HIP (csrc/k_train.hip, train/hip_autograd.py) against torch autograd of the
+same arithmetic on the same rounded operands, and the mixed-bf16 training step with it against the autocast step."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import geoformer_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('T,cout,cin', [(12800, 256, 256), (6400 + 37, 512, 512), (100, 128, 256), (31, 256, 128)])
+def test_linear_wgrad(dtype, T, cout, cin):
+    """dW = dY^T X with fp32 accumulation: against the fp64 product of the same 16-bit operands (ragged token counts, all the
+    layer widths); a column block of a wider gradient (the torch.cat([x, m]) halves); accumulation."""
+    from geoformer_amd import ops
+    g = torch.Generator().manual_seed(T)
+    dy = torch.randn(T, cout, generator=g).to(DEV, dtype)
+    x = torch.randn(T, cin, generator=g).to(DEV, dtype)
+    want = (dy.double().t() @ x.double())
+    got = ops.linear_wgrad(dy, x)
+    scale = float(want.abs().max())
+    assert float((got.double() - want).abs().max()) <= 2e-5 * scale + 1e-4 * np.sqrt(T) * 1e-2
+    # strided operands (views of wider buffers) into a column block, then accumulated once more
+    wide = torch.zeros(cout, cin + 128, device=DEV)
+    xw = torch.cat([x, x], 1)
+    ops.linear_wgrad(dy, xw[:, cin:], out=wide[:, 128:])
+    assert torch.equal(wide[:, 128:], got) and float(wide[:, :128].abs().max()) == 0.0
+    ops.linear_wgrad(dy, x, out=wide[:, 128:], accumulate=True)
+    torch.testing.assert_close(wide[:, 128:], 2 * got, rtol=1e-6, atol=1e-6)
+    # deterministic
+    assert torch.equal(ops.linear_wgrad(dy, x), got)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('C', [128, 256, 512])
+def test_layernorm_forward_backward(dtype, C):
+    from geoformer_amd import ops
+    g = torch.Generator().manual_seed(C)
+    T = 1000 + C // 64
+    y = (torch.randn(T, C, generator=g) * 1.7 + 0.3).to(DEV, dtype)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(C, generator=g)).to(DEV)
+    dout = torch.randn(T, C, generator=g).to(DEV, dtype)
+    out, stats = ops.layernorm_forward(y, gamma, beta, 1e-5)
+    yr = y.float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.layer_norm(yr, (C,), gr, br, 1e-5)
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    assert float((out.float() - ref.detach()).abs().max()) <= ulp * float(ref.detach().abs().max())
+    torch.testing.assert_close(stats[:, 0], y.float().mean(1), rtol=1e-5, atol=1e-5)
+    ref.backward(dout.float())
+    dy, dg, db = ops.layernorm_backward(dout, y, stats, gamma)
+    assert float((dy.float() - yr.grad).abs().max()) <= 2 * ulp * float(yr.grad.abs().max())
+    torch.testing.assert_close(dg, gr.grad, rtol=2e-4, atol=2e-3)
+    torch.testing.assert_close(db, br.grad, rtol=2e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize('kind', ['relu', 'tanh'])
+def test_hip_linear_function_against_autograd(kind):
+    """HipLinear (two-part input, fused activation) and HipLayerNorm chained as in an encoder layer: outputs and all gradients
+    against torch autograd of the same chain on the same bf16-rounded operands (fp32 master weights)."""
+    from geoformer_amd.train import hip_autograd as HA
+    g = torch.Generator().manual_seed(5)
+    T, c = 3000, 256
+    x = (torch.randn(2, T // 2, c, generator=g) * 0.8).to(DEV)
+    m = (torch.randn(2, T // 2, c, generator=g) * 0.8).to(DEV)
+    w1 = (torch.randn(2 * c, 2 * c, generator=g) / np.sqrt(2 * c)).to(DEV)
+    w2 = (torch.randn(c, 2 * c, generator=g) / np.sqrt(2 * c)).to(DEV)
+    gam = (1 + 0.1 * torch.randn(c, generator=g)).to(DEV); bet = (0.1 * torch.randn(c, generator=g)).to(DEV)
+    act = torch.relu if kind == 'relu' else torch.tanh
+    dt = torch.bfloat16
+
+    def run(hip):
+        ps = [t.clone().requires_grad_(True) for t in (x, m, w1, w2, gam, bet)]
+        xx, mm, a, b, ga, be = ps
+        if hip:
+            h = HA.linear(xx.to(dt), a, mm.to(dt), kind)
+            o = HA.layer_norm(HA.linear(h, b), ga, be)
+        else:
+            h = act(F.linear(torch.cat([xx.to(dt), mm.to(dt)], 2), a.to(dt)))
+            o = F.layer_norm(F.linear(h, b.to(dt)).float(), (c,), ga, be).to(dt)
+        loss = (o.float() * torch.linspace(-1, 1, c, device=DEV)).sum() / T
+        loss.backward()
+        return o.detach().float(), [p.grad.float() for p in ps]
+
+    o_ref, g_ref = run(False)
+    o_hip, g_hip = run(True)
+    assert float((o_hip - o_ref).abs().max()) <= 2 * 2.0 ** -7 * float(o_ref.abs().max())
+    for name, a, b in zip(('x', 'm', 'w1', 'w2', 'gamma', 'beta'), g_hip, g_ref):
+        rel = float((a - b).norm() / b.norm())
+        assert rel < 2e-2, (name, rel)                           # bf16 intermediates round at different points: 1e-2 in norm
+
+
+def test_hip_backward_train_step_matches_autocast_step():
+    """TrainStep(precision='bf16', hip_backward=True) against the autocast bf16 step on the same batch and weights: loss terms
+    within 2 %, parameter gradients of the first coarse term aligned (cosine > 0.97), fp32 parameters, loss decreasing."""
+    from geoformer_amd.model.cvpr_ds_config import get_default_cfg
+    from geoformer_amd.model.full_model import GeoFormer
+    from geoformer_amd.model.geo_config import get_cfg_model
+    from geoformer_amd.train import TrainStep, synthetic_homography_batch
+    res = {}
+    for hip in (False, True):
+        g = get_cfg_model()
+        g.update(coarse_thr=0.0, fine_thr=0.0, precision='fp32')
+        model = GeoFormer(get_default_cfg(), g)
+        sd = model.state_dict(); O.closed_form_fill(sd); model.load_state_dict(sd)
+        model.cuda()
+        step = TrainStep(model, trainer_cfg={'warmup_step': 0, 'canonical_lr': 1e-2, 'gradient_clipping': 0.0}, batch_size=2,
+                         fused_coarse_loss=True, precision='bf16', hip_backward=hip)
+        batch = synthetic_homography_batch(2, (128, 256), seed=31, device='cuda')
+        from geoformer_amd.train.functional import set_hip_backward
+        set_hip_backward(hip)
+        try:
+            step.core(batch)
+        finally:
+            set_hip_backward(False)
+        step.optimizer.zero_grad(set_to_none=True)
+        first = batch['loss_d_fused'][0] / batch['loss_d_fused'][1]
+        first.backward()
+        grads = {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
+        assert all(p.dtype == torch.float32 for p in model.parameters()) and all(v.dtype == torch.float32 for v in grads.values())
+        scal = {k: float(v) for k, v in batch['loss_scalars'].items()}
+        losses = [float(step(synthetic_homography_batch(2, (128, 256), seed=31, device='cuda'))) for _ in range(3)]
+        res[hip] = (scal, grads, losses)
+    (s0, g0, l0), (s1, g1, l1) = res[False], res[True]
+    print(f'autocast {s0} losses {l0} | hip backward {s1} losses {l1}')
+    for k in ('loss_c', 'loss_d'):
+        assert s1[k] == pytest.approx(s0[k], rel=2e-2), (k, s0, s1)
+    common = [n for n in g0 if n in g1 and n.startswith('loftr_coarse')]
+    assert len(common) >= 40
+    dot = sum(float((g0[n] * g1[n]).sum()) for n in common)
+    na, nb = (sum(float((g[n] ** 2).sum()) for n in common) ** 0.5 for g in (g0, g1))
+    print(f'cosine of the coarse-loss gradients (autocast vs HIP backward) {dot / (na * nb):.4f}')
+    assert dot / (na * nb) > 0.97
+    assert all(np.isfinite(l1)) and l1[-1] < l1[0], l1

@@ -1,5 +1,5 @@
 """Where the training step spends its time (torch profiler, top ops by device time).
-   python tools/train_profile.py [H W] [--no-fused] [--no-prof] [--bf16]"""
+   python tools/train_profile.py [H W] [--no-fused] [--no-prof] [--bf16] [--hip]"""
 import sys, time, torch
 HW = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 and sys.argv[1].isdigit() else (480, 640)
 FUSED = '--no-fused' not in sys.argv
@@ -13,7 +13,7 @@ from geoformer_amd.train import TrainStep, synthetic_homography_batch
 g = get_cfg_model(); g.update(coarse_thr=0.0, fine_thr=0.0, precision='fp32')
 model = deterministic_init_(GeoFormer(get_default_cfg(), g)).cuda()
 PREC = 'bf16' if '--bf16' in sys.argv else 'fp32'
-step = TrainStep(model, batch_size=2, fused_coarse_loss=FUSED, precision=PREC)
+step = TrainStep(model, batch_size=2, fused_coarse_loss=FUSED, precision=PREC, hip_backward='--hip' in sys.argv)
 for it in range(4):
     t = time.perf_counter(); step(synthetic_homography_batch(2, HW, seed=it, device='cuda')); torch.cuda.synchronize()
     print('step', it, '%.3f s' % (time.perf_counter() - t), 'fused' if FUSED else 'autograd', PREC, HW, flush=True)
