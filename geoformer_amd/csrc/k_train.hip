@@ -224,14 +224,18 @@ __global__ __launch_bounds__(256) void ln_backward(LnArgs a) {
     }
 }
 
-__global__ void ln_param_reduce(LnArgs a) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per (dgamma | dbeta, channel): lanes stride over the workgroup partials, then a shuffle tree (fixed order: deterministic)
+__global__ __launch_bounds__(256) void ln_param_reduce(LnArgs a) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= 2 * a.C) return;
     const int which = c / a.C, ch = c - which * a.C;
     float s = 0.f;
-    for (int p = 0; p < a.parts; ++p) s += a.part[((size_t)p * 2 + which) * a.C + ch];
-    float* d = (which ? a.dbeta : a.dgamma) + ch;
-    *d = a.accumulate ? *d + s : s;
+    for (int p = lane; p < a.parts; p += 64) s += a.part[((size_t)p * 2 + which) * a.C + ch];
+    s = wave_sum(s);
+    if (lane == 0) {
+        float* d = (which ? a.dbeta : a.dgamma) + ch;
+        *d = a.accumulate ? *d + s : s;
+    }
 }
 
 template <typename H>
@@ -327,7 +331,7 @@ extern "C" int gf_layernorm_backward(const void* dout, const void* y, const floa
     hipStream_t st = (hipStream_t)stream;
     const int rc = dtype == GF_F16 ? ln_dispatch<_Float16>(a, true, st) : ln_dispatch<gf_bf16>(a, true, st);
     GF_CHECK_ARG(rc == 0, "dispatch failed");
-    ln_param_reduce<<<(2 * C + 255) / 256, 256, 0, st>>>(a);
+    ln_param_reduce<<<(2 * C + 3) / 4, 256, 0, st>>>(a);
     GF_CHECK_LAUNCH();
     return GF_OK;
 }

@@ -15,13 +15,45 @@ import torch
 from .. import ops
 
 
+class WeightCache:
+    """16-bit copies of the fp32 master weights and their transposes, made once per step (a weight is used by several layer
+    calls - both images, forward and backward - and every cast or transpose is a launch the host pays for).  `TrainStep`
+    clears it behind the optimizer step."""
+
+    def __init__(self):
+        self._w, self._wt = {}, {}
+
+    def clear(self):
+        self._w.clear()
+        self._wt.clear()
+
+    def cast(self, w, dtype):
+        key = (id(w), dtype)
+        hit = self._w.get(key)
+        if hit is None or hit[0] is not w:
+            hit = (w, w.detach().to(dtype))
+            self._w[key] = hit
+        return hit[1]
+
+    def transposed(self, w16):
+        key = id(w16)
+        hit = self._wt.get(key)
+        if hit is None or hit[0] is not w16:
+            hit = (w16, w16.t().contiguous())
+            self._wt[key] = hit
+        return hit[1]
+
+
+WEIGHTS = WeightCache()
+
+
 class HipLinear(torch.autograd.Function):
     """y = act([x | x2] @ w.T), no bias; x [..., k1], x2 [..., k2] or None (the two halves of torch.cat([x, message], 2)),
     w fp32 or 16-bit [n, k1 + k2]; act in (None, 'relu', 'tanh')."""
 
     @staticmethod
     def forward(ctx, x, w, x2=None, act=None):
-        w16 = w if w.dtype == x.dtype else w.detach().to(x.dtype)
+        w16 = w if w.dtype == x.dtype else WEIGHTS.cast(w, x.dtype)
         epi = {None: ops.EPI_NONE, 'relu': ops.EPI_RELU, 'tanh': ops.EPI_TANH}[act]
         y = ops.linear(x, w16, a2=x2, epilogue=epi)
         ctx.act, ctx.k1, ctx.has2, ctx.wdtype = act, x.shape[-1], x2 is not None, w.dtype
@@ -35,7 +67,7 @@ class HipLinear(torch.autograd.Function):
         need_x, need_w, need_x2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has2 and ctx.needs_input_grad[2]
         dx = dx2 = dw = None
         if need_x or need_x2:
-            dfull = ops.linear(dz, w16.t().contiguous())               # [..., k1 + k2] = dZ W
+            dfull = ops.linear(dz, WEIGHTS.transposed(w16))            # [..., k1 + k2] = dZ W
             dx = dfull[..., :ctx.k1] if need_x else None
             dx2 = dfull[..., ctx.k1:] if need_x2 else None
         if need_w:

@@ -151,6 +151,9 @@ class TrainStep:
             loss = self.core(batch)
         finally:
             set_hip_backward(False)
+        hip_weights = None
+        if self.hip_backward:
+            from .hip_autograd import WEIGHTS as hip_weights
         if 'loss_scalars' not in batch:          # the wrapper handed the forward a copy of the batch
             raise RuntimeError('the training forward did not write into the caller\'s batch')
         self.optimizer.zero_grad(set_to_none=True)
@@ -162,6 +165,8 @@ class TrainStep:
             for pg in self.optimizer.param_groups:
                 pg['lr'] = lr
         self.optimizer.step()
+        if hip_weights is not None:
+            hip_weights.clear()                  # the 16-bit copies belong to the weights of the step that made them
         if self.cfg['scheduler_interval'] == 'step':
             self.scheduler.step()
         self.global_step += 1

@@ -118,9 +118,11 @@ def test_hip_backward_train_step_matches_autocast_step():
             step.core(batch)
         finally:
             set_hip_backward(False)
+        from geoformer_amd.train.hip_autograd import WEIGHTS
         step.optimizer.zero_grad(set_to_none=True)
         first = batch['loss_d_fused'][0] / batch['loss_d_fused'][1]
         first.backward()
+        WEIGHTS.clear()
         grads = {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
         assert all(p.dtype == torch.float32 for p in model.parameters()) and all(v.dtype == torch.float32 for v in grads.values())
         scal = {k: float(v) for k, v in batch['loss_scalars'].items()}
