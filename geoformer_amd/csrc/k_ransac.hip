@@ -186,22 +186,6 @@ __global__ __launch_bounds__(256) void ransac_score(RsArgs a) {
     }
 }
 
-template <int NV>
-__device__ void block_sum(double (&v)[NV], double* sh /*[256]*/) {
-    const int t = threadIdx.x;
-#pragma unroll 1
-    for (int k = 0; k < NV; ++k) {
-        sh[t] = v[k];
-        __syncthreads();
-        for (int s = 128; s >= 1; s >>= 1) {
-            if (t < s) sh[t] = sh[t] + sh[t + s];
-            __syncthreads();
-        }
-        v[k] = sh[0];
-        __syncthreads();
-    }
-}
-
 // sum over the 256 threads with TWO barriers for all NV values: lanes by shuffles, the four waves through LDS (added in wave
 // order).  `part` = [4][NV] doubles of LDS; the result is returned in every thread.
 template <int NV>
@@ -282,7 +266,7 @@ __global__ __launch_bounds__(256) void ransac_final(RsArgs a) {
         keep[i] = (uint8_t)in;
         if (in) { cen[0] += x; cen[1] += y; cen[2] += u; cen[3] += v; cen[4] += 1.0; }
     }
-    block_sum(cen, sh);
+    block_sum_fast(cen, sh);
     const double m = cen[4], c0x = cen[0] / m, c0y = cen[1] / m, c1x = cen[2] / m, c1y = cen[3] / m;
     double dd[2] = {0, 0};
     for (int i = t; i < cnt; i += 256)
@@ -291,7 +275,7 @@ __global__ __launch_bounds__(256) void ransac_final(RsArgs a) {
             dd[0] += sqrt((x - c0x) * (x - c0x) + (y - c0y) * (y - c0y));
             dd[1] += sqrt((u - c1x) * (u - c1x) + (v - c1y) * (v - c1y));
         }
-    block_sum(dd, sh);
+    block_sum_fast(dd, sh);
     const double s0 = dd[0] > 0 ? sqrt(2.0) * m / dd[0] : 1.0, s1 = dd[1] > 0 ? sqrt(2.0) * m / dd[1] : 1.0;
     // ---- normal equations (upper triangle of the symmetric 8x8 + rhs)
     double ne[44];
@@ -312,7 +296,7 @@ __global__ __launch_bounds__(256) void ransac_final(RsArgs a) {
 #pragma unroll
             for (int i2 = 0; i2 < 8; ++i2) ne[36 + i2] += r0[i2] * u + r1[i2] * v;
         }
-    block_sum(ne, sh);
+    block_sum_fast(ne, sh);
     if (t == 0) {
         double ata[64], atb[8], g[9];                   // (this g: the refit's result, handed on through LDS)
         int q = 0;
