@@ -398,6 +398,15 @@ def measure(model, batches, steps, warmup, nstreams, dev, dist, log, profile_tag
     pipes.run(0, warmup)
     torch.cuda.synchronize()
     t_threads = (time.perf_counter() - t) / max(warmup, 1)
+    # the first pipelined steps of a process are sometimes slow by themselves (the caching allocator fills the second stream's
+    # pool: seen as 84 ms against 15 ms once in ~10 fresh-box runs): give the pipelines two more (untimed) rounds before the verdict
+    for _ in range(2):
+        if not (pipes.n > 1 and warmup >= 2 and t_threads > 1.5 * t_serial):
+            break
+        t = time.perf_counter()
+        pipes.run(0, warmup)
+        torch.cuda.synchronize()
+        t_threads = (time.perf_counter() - t) / max(warmup, 1)
     if pipes.n > 1 and warmup >= 2 and t_threads > 1.5 * t_serial:
         log(f'pipelined steps run at {t_threads * 1e3:.1f} ms against {t_serial * 1e3:.1f} ms single-threaded: '
             f'falling back to one host pipeline')

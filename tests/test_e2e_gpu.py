@@ -116,9 +116,11 @@ def test_device_ransac_vs_oracle():
 # (oracle confidences 0.1962 .. 0.2014).
 KNIFE_EDGE = 3e-2
 # measured knife-edge counts + 3 (the counts are printed into the test log; DESIGN 4 quotes them)
-# measured on MI355X (round 3): 640: 7 of 1206; hpatches-shaped: 6 of 1112; bench shape, thresholds 0.2 / 0.1: 36 of 10049 over
-# the eight slots (1 .. 8 per slot); bench shape, thresholds 0 / 0: 0 of 18693 over three slots
-MAX_KNIFE = {'640': 10, 'hpatches': 9, 'bench8': 39, 'bench8_slot': 11, 'bench8_dense': 3, 'bench8_dense_slot': 3}
+# measured on MI355X (round 3, re-measured behind the K9 rework - the counts move with every change of an fp32 summation
+# order; tools/k9_parity.py shows the old and the new kernel equally close to the oracle): 640: 10 of 1206; hpatches-shaped:
+# 8 of 1112; bench shape, thresholds 0.2 / 0.1: 44 of 10049 over the eight slots (3 .. 12 per slot); bench shape,
+# thresholds 0 / 0: 0 of 18693 over three slots
+MAX_KNIFE = {'640': 13, 'hpatches': 11, 'bench8': 47, 'bench8_slot': 15, 'bench8_dense': 3, 'bench8_dense_slot': 3}
 FINE_EDGE = 5e-2          # the same for the fine threshold: the 25x25 matrices carry two more fp16 layers
 
 
