@@ -9,6 +9,8 @@
 //                   fine keypoint arithmetic.
 #include <math.h>
 
+#include <type_traits>
+
 #include "gf_common.h"
 
 namespace {
@@ -52,6 +54,36 @@ __global__ __launch_bounds__(256) void fine_gather(FgArgs a) {
     const T* cf = (const T*)(side ? a.c1 : a.c0) + ((size_t)b * (side ? a.S : a.L) + cell) * a.CC;
     T* co = (T*)a.ccat + ((size_t)side * a.M + m) * a.CC;
     for (int c = t; c < a.CC; c += blockDim.x) co[c] = cf[c];
+}
+
+// The 16-bit inference form (channels-last fine maps, window tensor in the same type): ONE WAVE per (match, side) moves the
+// 25 x C window as 16-byte pieces - C / 8 lanes per window position, 64 / (C / 8) positions per instruction - and the coarse
+// feature row behind it; out-of-image positions are zeros (F.unfold's padding).  The general kernel above moves 2 bytes per
+// lane and instruction with half its threads idle (226 us per 8-pair call at the nominal load against ~100 us of HBM time).
+template <typename T>
+__global__ __launch_bounds__(256) void fine_gather_rows(FgArgs a) {
+    const int lane = threadIdx.x & 63, u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u >= 2 * a.M) return;
+    const int side = u >= a.M, m = side ? u - a.M : u;
+    const int b = (int)a.b_ids[m];
+    const int cell = (int)(side ? a.j_ids[m] : a.i_ids[m]);
+    const int wc = side ? a.w1c : a.w0c;
+    const int Hf = side ? a.H1 : a.H0, Wf = side ? a.W1 : a.W0;
+    const T* f = (const T*)(side ? a.f1 : a.f0);
+    const long sn = side ? a.s1n : a.s0n, sh = side ? a.s1h : a.s0h, sw = side ? a.s1w : a.s0w;
+    const int cy = (cell / wc) * a.stride - a.W / 2, cx = (cell % wc) * a.stride - a.W / 2;
+    const int ppp = a.C / 8, pieces = a.W * a.W * ppp;                  // 16-byte pieces per position / per window
+    T* out = (T*)a.win + (size_t)u * a.W * a.W * a.C;
+    const v4u zero{0u, 0u, 0u, 0u};
+    for (int e = lane; e < pieces; e += 64) {
+        const int k = e / ppp, c8 = (e - k * ppp) * 8, y = cy + k / a.W, x = cx + k % a.W;
+        v4u v = zero;
+        if (y >= 0 && y < Hf && x >= 0 && x < Wf) v = *reinterpret_cast<const v4u*>(f + b * sn + y * sh + x * sw + c8);
+        *reinterpret_cast<v4u*>(out + (size_t)k * a.C + c8) = v;
+    }
+    const T* cf = (const T*)(side ? a.c1 : a.c0) + ((size_t)b * (side ? a.S : a.L) + cell) * a.CC;
+    T* co = (T*)a.ccat + (size_t)u * a.CC;
+    for (int c8 = lane * 8; c8 < a.CC; c8 += 512) *reinterpret_cast<v4u*>(co + c8) = *reinterpret_cast<const v4u*>(cf + c8);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -142,6 +174,89 @@ __global__ __launch_bounds__(256) void fine_match(FmArgs a) {
     }
 }
 
+// 16-bit storage modes: ONE WAVE per match, the 25 x 25 x C correlation on the matrix cores (32 x 32 tile, rows / columns
+// 25..31 re-read window position 24 and are masked out of the statistics), operands straight from global memory (a lane's
+// 16 bytes of its window row per k-step).  The tile is computed TWICE, as f0.f1^T and as f1.f0^T (C / 16 MFMAs each, the same
+// bits: a product's two factors commute and the k order is the same): a softmax statistic over a tile's ROW index is a
+// reduction over the registers of one lane (+ one exchange between the lane halves), so the column statistics come from the
+// first tile and the row statistics from the second - no 32-lane butterflies (those were 160 cross-lane operations per
+// match); the row statistics reach the first tile's layout by v_readlane.  Hardware exp2 (the arguments are <= 0) and
+// reciprocals of the two sums instead of libm's expf and 1250 divisions.  Same arithmetic as fine_match above up to fp32
+// rounding (the dot products sum in the matrix cores' order and are scaled once by 1 / (C * temperature) instead of dividing every
+// operand by sqrt(C)): 249 us -> HBM time per 8-pair call at the nominal load.
+template <typename T>
+__global__ __launch_bounds__(256) void fine_match_mfma(FmArgs a) {
+    using Mm = Mma32<T>;
+    using Frag = typename Mm::Frag;
+    const int lane = threadIdx.x & 63, h = lane >> 5, lr = lane & 31, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= a.M) return;
+    const int C = a.C, row = lr < WW ? lr : WW - 1;
+    const T* p0 = (const T*)a.f0 + ((size_t)m * WW + row) * C + h * 8;
+    const T* p1 = (const T*)a.f1 + ((size_t)m * WW + row) * C + h * 8;
+    v16f acc, acct;                     // acc[r]: row i = (r & 3) + 8 (r >> 2) + 4 h of column j = lr;  acct: the transpose
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acct[r] = 0.f; }
+    for (int ks = 0; ks < C / 16; ++ks) {
+        const Frag x0 = *reinterpret_cast<const Frag*>(p0 + ks * 16), x1 = *reinterpret_cast<const Frag*>(p1 + ks * 16);
+        Mm::mma(x0, x1, acc);
+        Mm::mma(x1, x0, acct);
+    }
+    const float scale2 = 1.4426950408889634f / ((float)C * a.temperature);     // logits in log2 units
+    const bool lok = lr < WW;           // this lane's column (first tile) / row (second tile) exists
+    // statistics over the register index: first tile -> column lr, second tile -> row lr
+    float cmx = -INFINITY, rmx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const bool ok = gf_acc_row(r, h) < WW;
+        acc[r] *= scale2;
+        acct[r] *= scale2;
+        cmx = fmaxf(cmx, ok ? acc[r] : -INFINITY);
+        rmx = fmaxf(rmx, ok ? acct[r] : -INFINITY);
+    }
+    cmx = fmaxf(cmx, __shfl_xor(cmx, 32, 64));
+    rmx = fmaxf(rmx, __shfl_xor(rmx, 32, 64));
+    float csm = 0.f, rsm = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const bool ok = gf_acc_row(r, h) < WW;
+        csm += ok ? __builtin_amdgcn_exp2f(acc[r] - cmx) : 0.f;
+        rsm += ok ? __builtin_amdgcn_exp2f(acct[r] - rmx) : 0.f;
+    }
+    csm += __shfl_xor(csm, 32, 64);
+    rsm += __shfl_xor(rsm, 32, 64);
+    const float icsm = 1.0f / csm, irsm = 1.0f / rsm;
+    unsigned long long key = 0ull;
+    float* fm = a.fine_matrix + (size_t)m * WW * WW;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        // row i of this register differs between the lane halves: both candidates by v_readlane (wave-uniform lane index)
+        const int i0 = gf_acc_row(r, 0), i1 = gf_acc_row(r, 1), i = h ? i1 : i0;
+        const int m0 = __builtin_amdgcn_readlane(__float_as_int(rmx), i0), m1 = __builtin_amdgcn_readlane(__float_as_int(rmx), i1);
+        const int q0 = __builtin_amdgcn_readlane(__float_as_int(irsm), i0), q1 = __builtin_amdgcn_readlane(__float_as_int(irsm), i1);
+        const float rm = __int_as_float(h ? m1 : m0), rq = __int_as_float(h ? q1 : q0);
+        if (i < WW && lok) {
+            const float cf = (__builtin_amdgcn_exp2f(acc[r] - cmx) * icsm) * (__builtin_amdgcn_exp2f(acc[r] - rm) * rq);
+            const int o = i * WW + lr;
+            fm[o] = cf;
+            const unsigned long long k = ((unsigned long long)__float_as_uint(cf) << 32) | (0xFFFFFFFFu - (unsigned)o);
+            key = k > key ? k : key;            // arg-max with first-index tie-break (fine_matching2.py:79)
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)key, d, 64), hi = __shfl_xor((unsigned)(key >> 32), d, 64);
+        const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+        key = other > key ? other : key;
+    }
+    if (lane == 0) {
+        const float v = __uint_as_float((unsigned)(key >> 32));
+        const int o = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+        const bool ok = v > a.thr;
+        a.sel[m] = ok ? o : -1;
+        if (ok) atomicAdd(&a.chunk_cnt[m >> 10], 1);
+    }
+}
+
 __global__ __launch_bounds__(1024) void fine_compact(FmArgs a) {
     __shared__ int wave_tot[16];
     const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -184,6 +299,16 @@ __global__ __launch_bounds__(1024) void fine_compact(FmArgs a) {
 
 template <typename TF, typename T>
 int fg_launch(const FgArgs& a, hipStream_t st) {
+    if constexpr (std::is_same<TF, T>::value && sizeof(T) == 2) {
+        const bool rows16 = a.s0c == 1 && a.s1c == 1 && a.C % 8 == 0 && a.CC % 8 == 0 && (uintptr_t)a.f0 % 16 == 0 && (uintptr_t)a.f1 % 16 == 0 &&
+                            (uintptr_t)a.c0 % 16 == 0 && (uintptr_t)a.c1 % 16 == 0 && (uintptr_t)a.win % 16 == 0 && (uintptr_t)a.ccat % 16 == 0 &&
+                            a.s0n % 8 == 0 && a.s0h % 8 == 0 && a.s0w % 8 == 0 && a.s1n % 8 == 0 && a.s1h % 8 == 0 && a.s1w % 8 == 0;
+        if (rows16) {
+            fine_gather_rows<T><<<(2 * a.M + 3) / 4, 256, 0, st>>>(a);
+            GF_CHECK_LAUNCH();
+            return GF_OK;
+        }
+    }
     fine_gather<TF, T><<<dim3(a.M, 2), 256, 0, st>>>(a);
     GF_CHECK_LAUNCH();
     return GF_OK;
@@ -240,9 +365,15 @@ extern "C" int gf_fine_match(const void* f0, const void* f1, int dtype, int M, i
     a.mk0f = mkpts0_f; a.mk1f = mkpts1_f; a.mconf = mconf; a.m_bids = m_bids; a.count = count;
     hipStream_t st = (hipStream_t)stream;
     (void)hipMemsetAsync(a.chunk_cnt, 0, (size_t)a.chunks * sizeof(int32_t), st);
+    const bool mfma = dtype != GF_F32 && C % 16 == 0 && (uintptr_t)f0 % 16 == 0 && (uintptr_t)f1 % 16 == 0;
     if (dtype == GF_F32) fine_match<float><<<M, 256, 0, st>>>(a);
-    else if (dtype == GF_F16) fine_match<_Float16><<<M, 256, 0, st>>>(a);
-    else fine_match<gf_bf16><<<M, 256, 0, st>>>(a);
+    else if (dtype == GF_F16) {
+        if (mfma) fine_match_mfma<_Float16><<<(M + 3) / 4, 256, 0, st>>>(a);
+        else fine_match<_Float16><<<M, 256, 0, st>>>(a);
+    } else {
+        if (mfma) fine_match_mfma<gf_bf16><<<(M + 3) / 4, 256, 0, st>>>(a);
+        else fine_match<gf_bf16><<<M, 256, 0, st>>>(a);
+    }
     fine_compact<<<a.chunks, 1024, 0, st>>>(a);
     GF_CHECK_LAUNCH();
     return GF_OK;

@@ -293,6 +293,28 @@ def test_fine_gather_vs_oracle(layout):
     exact(ccat[:M], I['feat_c0'][I['b_ids'], I['i_ids']]); exact(ccat[M:], I['feat_c1'][I['b_ids'], I['j_ids']])
 
 
+@pytest.mark.parametrize('st', [torch.float16, torch.bfloat16])
+def test_fine_gather_16bit_rows(st):
+    """The inference form (channels-last 16-bit fine maps -> 16-bit windows: one wave per window, 16-byte pieces) against the
+    oracle's windows of the same rounded maps - a copy, so exact; border cells (zero padding) and an odd number of windows."""
+    from geoformer_amd import ops
+    I = GI.g8_inputs()
+    f0 = I['feat_f0'].to(DEV, st).contiguous(memory_format=torch.channels_last)
+    f1 = I['feat_f1'].to(DEV, st).contiguous(memory_format=torch.channels_last)
+    b = torch.tensor([0, 0, 0, 1, 1, 1, 1]); i = torch.tensor([0, 9, 79, 3, 44, 70, 79]); j = torch.tensor([62, 0, 31, 8, 9, 54, 62])
+    win, ccat = ops.fine_gather(f0, f1, I['feat_c0'].to(DEV, st), I['feat_c1'].to(DEV, st), b.to(DEV), i.to(DEV), j.to(DEV),
+                                I['hw0_c'][1], I['hw1_c'][1], 4, 5, st)
+    M = len(b)
+    r0, r1 = I['feat_f0'].to(st).float(), I['feat_f1'].to(st).float()
+    exact(win[:M].float(), O.fine_windows(r0, b, i, I['hw0_c'][1], 4, 5))
+    exact(win[M:].float(), O.fine_windows(r1, b, j, I['hw1_c'][1], 4, 5))
+    exact(ccat[:M].float(), I['feat_c0'].to(st).float()[b, i]); exact(ccat[M:].float(), I['feat_c1'].to(st).float()[b, j])
+    # the strided (NCHW) form of the same maps takes the general kernel: same result
+    win2, _ = ops.fine_gather(f0.contiguous(), f1.contiguous(), I['feat_c0'].to(DEV, st), I['feat_c1'].to(DEV, st), b.to(DEV), i.to(DEV),
+                              j.to(DEV), I['hw0_c'][1], I['hw1_c'][1], 4, 5, st)
+    assert torch.equal(win, win2)
+
+
 def test_fine_preprocess_golden(golden):
     from geoformer_amd.model.modules import FinePreprocess
     from geoformer_amd.model.cvpr_ds_config import get_default_cfg
@@ -324,6 +346,39 @@ def test_fine_match_golden(golden, tag):
     exact(out['m_bids'][:mf], G[f'{tag}_m_bids'])
     close(out['mkpts0_f'][:mf], G[f'{tag}_mkpts0_f'], 1e-6, 1e-5); close(out['mkpts1_f'][:mf], G[f'{tag}_mkpts1_f'], 1e-6, 1e-5)
     close(out['mconf'][:mf], G[f'{tag}_mconf'], 2e-5, 1e-9)
+
+
+@pytest.mark.parametrize('st', [torch.float16, torch.bfloat16])
+def test_fine_match_16bit_on_the_matrix_cores(st):
+    """fine_match_mfma (16-bit storage: one wave per match, the 25 x 25 x 128 correlation as eight MFMAs) against the oracle's
+    FineMatching2 on the same rounded windows: fine_matrix to 2e-5 (the dot products sum in another order), arg-max / threshold
+    decisions and keypoints identical on g9's planted windows (no near-ties), and against the fp32 kernel on the same values;
+    1003 more matches for the grid tail (4 matches per workgroup)."""
+    from geoformer_amd import ops
+    I = GI.g9_inputs()
+    f0, f1 = I['f0'].to(st), I['f1'].to(st)
+    kw = dict(scale0=I['scale0'], scale1=I['scale1'])
+    got = ops.fine_match(f0.to(DEV), f1.to(DEV), I['temperature'], I['thr'], I['b_ids'].to(DEV), I['mkpts0_c'].to(DEV), I['mkpts1_c'].to(DEV),
+                         8.0, 4.0, 2.0, **kw)
+    ref = ops.fine_match(f0.float().to(DEV), f1.float().to(DEV), I['temperature'], I['thr'], I['b_ids'].to(DEV), I['mkpts0_c'].to(DEV),
+                         I['mkpts1_c'].to(DEV), 8.0, 4.0, 2.0, **kw)
+    mf = int(ref['count'][0])
+    assert int(got['count'][0]) == mf and 0 < mf < len(I['b_ids'])
+    close(got['fine_matrix'], ref['fine_matrix'].cpu().numpy(), 2e-5, 1e-9)
+    assert torch.equal(got['m_bids'][:mf], ref['m_bids'][:mf])
+    assert torch.equal(got['mkpts0_f'][:mf], ref['mkpts0_f'][:mf]) and torch.equal(got['mkpts1_f'][:mf], ref['mkpts1_f'][:mf])
+    close(got['mconf'][:mf], ref['mconf'][:mf].cpu().numpy(), 2e-5, 1e-9)
+    g = torch.Generator().manual_seed(4)
+    Mn = 1003
+    a = (torch.randn(Mn, 25, 128, generator=g) * 1.2).to(st)
+    b = (torch.randn(Mn, 25, 128, generator=g) * 1.2).to(st)
+    b[:, 7] = (a[:, 11].float() * 2.0).to(st)
+    bid = torch.zeros(Mn, dtype=torch.int64); mk = torch.zeros(Mn, 2)
+    got = ops.fine_match(a.to(DEV), b.to(DEV), 0.1, 0.1, bid.to(DEV), mk.to(DEV), mk.to(DEV), 8.0, 4.0, 2.0)
+    ref = ops.fine_match(a.float().to(DEV), b.float().to(DEV), 0.1, 0.1, bid.to(DEV), mk.to(DEV), mk.to(DEV), 8.0, 4.0, 2.0)
+    assert int(got['count'][0]) == int(ref['count'][0]) == Mn
+    close(got['fine_matrix'], ref['fine_matrix'].cpu().numpy(), 5e-5, 1e-9)
+    assert torch.equal(got['mkpts0_f'], ref['mkpts0_f']) and torch.equal(got['mkpts1_f'], ref['mkpts1_f'])
 
 
 # ------------------------------------------------------------------ encoder layers / schedules
