@@ -457,9 +457,17 @@ constexpr int PANEL_TILES = 10;
 #endif
 #if K1_TRACE
 __device__ long long k1_trace[512 * 4 * 32];
-#define K1_T(slot) do { if (lane == 0 && ui == slot0 + per_xcd && (slot) < 32) k1_trace[(blockIdx.x * 4 + wave) * 32 + (slot)] = clock64(); } while (0)
+#define K1_STAMP(slot) do { if (lane == 0 && ui == slot0 + per_xcd && (slot) < 32) k1_trace[(blockIdx.x * 4 + wave) * 32 + (slot)] = clock64(); } while (0)
+#endif
+#if K1_TRACE == 1                  // -DK1_TRACE=1: phases of pass B (tools/k1_trace.py);  -DK1_TRACE=2: phases of pass A (tools/k1_trace.py stats)
+#define K1_T(slot) K1_STAMP(slot)
 #else
 #define K1_T(slot)
+#endif
+#if K1_TRACE == 2
+#define K1_TS(slot) K1_STAMP(slot)
+#else
+#define K1_TS(slot)
 #endif
 constexpr int PANEL_LDS = BN * 512 + BM * 8;      // f1 tile [64][512 B] + row statistics [128] float2
 
@@ -825,7 +833,10 @@ __global__ __launch_bounds__(NT, 2) void k1_stats_panel(K1Args a) {
     const int q8 = units >> 3, rem = units & 7;
     const int ubeg = xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8, ucnt = q8 + (xcd < rem ? 1 : 0);
     const int srow = tid >> 5, schunk = tid & 31;
+    const int slot0 = slot;
+    (void)slot0;
     for (int ui = slot; ui < ucnt; ui += per_xcd) {
+        K1_TS(0);
         const int u = ubeg + ui;
         const int run = u % runs, pm = u / runs, bm = pm % a.tilesM, n = pm / a.tilesM;
         const int m0 = bm * BM, t0 = run * PANEL_TILES, t1 = min(t0 + PANEL_TILES, a.tilesN);
@@ -860,9 +871,11 @@ __global__ __launch_bounds__(NT, 2) void k1_stats_panel(K1Args a) {
         float minref = NEG_INF, kappa = NEG_INF;
         for (int bn = t0; bn < t1; ++bn) {
             __syncthreads();                                  // previous tile: fragments consumed, colx combined
+            K1_TS(1 + 6 * (bn - t0));
 #pragma unroll
             for (int p = 0; p < 8; ++p) *reinterpret_cast<v4u*>(smem + k1p_off(srow + 8 * p, schunk)) = rb[p];
             __syncthreads();
+            K1_TS(2 + 6 * (bn - t0));
             if (bn + 1 < t1) prefetch(bn + 1);
             v16f acc[2];
 #pragma unroll
@@ -887,6 +900,7 @@ __global__ __launch_bounds__(NT, 2) void k1_stats_panel(K1Args a) {
                 b0 = n0;
                 b1 = n1;
             }
+            K1_TS(3 + 6 * (bn - t0));
             // ---- maxima on the raw accumulators: columns over the registers, row slots over the two column halves and the tiles
             float cmr0 = NEG_INF, cmr1 = NEG_INF;
 #pragma unroll
@@ -911,6 +925,7 @@ __global__ __launch_bounds__(NT, 2) void k1_stats_panel(K1Args a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) fcol[r] = __builtin_amdgcn_exp2f(ref[r] - kappa);
             }
+            K1_TS(4 + 6 * (bn - t0));
             // column maxima over the wave's 32 rows (both lane halves), in log2 units
             const float cm0 = fmaxf(cmr0, __shfl_xor(cmr0, 32, 64)), cm1 = fmaxf(cmr1, __shfl_xor(cmr1, 32, 64));
             const float c20 = cm0 * mult2, c21 = cm1 * mult2;
@@ -940,7 +955,9 @@ __global__ __launch_bounds__(NT, 2) void k1_stats_panel(K1Args a) {
                 colx[wave * 64 + lr] = make_float2(cm0 * a.mult, cs0);
                 colx[wave * 64 + 32 + lr] = make_float2(cm1 * a.mult, cs1);
             }
+            K1_TS(5 + 6 * (bn - t0));
             __syncthreads();
+            K1_TS(6 + 6 * (bn - t0));
             if (tid < 64) {                                   // combine the four waves' column partials
                 float m = NEG_INF;
 #pragma unroll

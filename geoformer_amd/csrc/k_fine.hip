@@ -170,7 +170,6 @@ __global__ __launch_bounds__(256) void fine_match(FmArgs a) {
         // fine_matching2.py:73-82 reduces to the threshold test
         const bool ok = v > a.thr;
         a.sel[m] = ok ? o : -1;
-        if (ok) atomicAdd(&a.chunk_cnt[m >> 10], 1);
     }
 }
 
@@ -253,7 +252,22 @@ __global__ __launch_bounds__(256) void fine_match_mfma(FmArgs a) {
         const int o = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
         const bool ok = v > a.thr;
         a.sel[m] = ok ? o : -1;
-        if (ok) atomicAdd(&a.chunk_cnt[m >> 10], 1);
+    }
+}
+
+// matches that passed the threshold, per 1024-match chunk (one ballot per wave; the per-match atomicAdd this replaces put ~1000
+// same-address atomics on each of ~18 counters: 140 of fine_match's 214 us at the nominal load)
+__global__ __launch_bounds__(1024) void fine_count(FmArgs a) {
+    __shared__ int wave_tot[16];
+    const int c = blockIdx.x, tid = threadIdx.x, m = c * 1024 + tid;
+    const unsigned long long bal = __ballot(m < a.M && a.sel[m] >= 0);
+    if ((tid & 63) == 0) wave_tot[tid >> 6] = __popcll(bal);
+    __syncthreads();
+    if (tid == 0) {
+        int t = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += wave_tot[w];
+        a.chunk_cnt[c] = t;
     }
 }
 
@@ -364,7 +378,6 @@ extern "C" int gf_fine_match(const void* f0, const void* f1, int dtype, int M, i
     a.sel = (int32_t*)((char*)workspace + gf_align_up((size_t)a.chunks * sizeof(int32_t), 256));
     a.mk0f = mkpts0_f; a.mk1f = mkpts1_f; a.mconf = mconf; a.m_bids = m_bids; a.count = count;
     hipStream_t st = (hipStream_t)stream;
-    (void)hipMemsetAsync(a.chunk_cnt, 0, (size_t)a.chunks * sizeof(int32_t), st);
     const bool mfma = dtype != GF_F32 && C % 16 == 0 && (uintptr_t)f0 % 16 == 0 && (uintptr_t)f1 % 16 == 0;
     if (dtype == GF_F32) fine_match<float><<<M, 256, 0, st>>>(a);
     else if (dtype == GF_F16) {
@@ -374,6 +387,7 @@ extern "C" int gf_fine_match(const void* f0, const void* f1, int dtype, int M, i
         if (mfma) fine_match_mfma<gf_bf16><<<(M + 3) / 4, 256, 0, st>>>(a);
         else fine_match<gf_bf16><<<M, 256, 0, st>>>(a);
     }
+    fine_count<<<a.chunks, 1024, 0, st>>>(a);
     fine_compact<<<a.chunks, 1024, 0, st>>>(a);
     GF_CHECK_LAUNCH();
     return GF_OK;

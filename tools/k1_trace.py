@@ -5,7 +5,8 @@ import sys, ctypes
 import numpy as np, torch
 sys.path.insert(0, '.')
 from geoformer_amd import ops, _lib
-thr = float(sys.argv[1]) if len(sys.argv) > 1 else 0.0
+STATS = len(sys.argv) > 1 and sys.argv[1] == 'stats'      # python tools/k1_trace.py stats  (needs -DK1_TRACE=2): pass A
+thr = float(sys.argv[1]) if len(sys.argv) > 1 and not STATS else 0.0
 N, L, S, C = 8, 6400, 6400, 256
 f0 = (torch.randn(N, L, C, device='cuda') * 1.3).half()
 f1 = (f0[:, torch.randperm(S, device='cuda')].float() + 0.4 * torch.randn(N, S, C, device='cuda')).half()
@@ -14,6 +15,15 @@ for _ in range(3):
 torch.cuda.synchronize()
 buf = np.zeros(512 * 4 * 32, dtype=np.int64)
 ctypes.CDLL(_lib.LIB_PATH).gf_debug_k1_trace(buf.ctypes.data_as(ctypes.c_void_p))
+if STATS:
+    t = buf.reshape(512, 4, 32)[:, 0, :25]
+    d = t - t[:, :1]
+    m = np.median(d, axis=0)
+    print('pass A, second unit of every workgroup, median clocks from unit start (wave 0):')
+    for tl in range(4):
+        b = 1 + 6 * tl
+        print(f'tile {tl}: top {int(m[b])} | LDS write + barrier {int(m[b+1]-m[b])} | prefetch issue + MFMAs {int(m[b+2]-m[b+1])} | maxima / rescale {int(m[b+3]-m[b+2])} | exponentials, sums {int(m[b+4]-m[b+3])} | barrier {int(m[b+5]-m[b+4])} | to next top {int(m[b+6]-m[b+5]) if b + 6 < 25 else -1}')
+    sys.exit(0)
 t = buf.reshape(512, 4, 32)[:, 0, :22]
 d = t - t[:, :1]
 print('median stamps from unit start:', np.median(d, axis=0).astype(int).tolist())
