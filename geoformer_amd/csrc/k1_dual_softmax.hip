@@ -632,6 +632,7 @@ __global__ __launch_bounds__(NT, 2) void k1_conf_panel(K1Args a) {
 // exp, lane swap, candidate bookkeeping per element) sharing the SIMDs with the 32 MFMAs per tile, at two waves per SIMD.
 // ---------------------------------------------------------------------------------------------
 constexpr int PIPE_LDS = 2 * BN * 512 + BM * 8 + PANEL_TILES * BN * 8;
+constexpr int STATS_LDS = 2 * BN * 512 + 2 * 4 * 64 * 8 + 4 * 32 * 4;         // k1_stats_panel: two tile buffers | column partials | row maxima
 struct K1Rsrc {
     __amdgpu_buffer_rsrc_t r;
 };
@@ -824,15 +825,16 @@ template <typename H>
 __global__ __launch_bounds__(NT, 2) void k1_stats_panel(K1Args a) {
     using V8 = gf_vec<H, 8>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* colx = reinterpret_cast<float2*>(smem + BN * 512);            // [4 waves][64] column partials of the tile
-    float* rowbc = reinterpret_cast<float*>(smem + BN * 512 + 4 * 64 * 8);  // [4 waves][32] row maxima of the run
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, lr = lane & 31;
+    // LDS: two f1 tile buffers (LDS-DMA, one tile ahead) | column partials of two tiles [2][4 waves][64] | row maxima of the run
+    float2* colx = reinterpret_cast<float2*>(smem + 2 * BN * 512);
+    float* rowbc = reinterpret_cast<float*>(smem + 2 * BN * 512 + 2 * 4 * 64 * 8);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, lr = lane & 31;   // (wave as an SGPR:
+    // the DMA pieces' LDS targets go through M0 - from a VGPR they were hoisted, spilled and reloaded with a vmcnt(0) between the requests)
     const int runs = (a.tilesN + PANEL_TILES - 1) / PANEL_TILES;
     const int units = a.N * a.tilesM * runs;
     const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = (nwg + 7 - xcd) >> 3;
     const int q8 = units >> 3, rem = units & 7;
     const int ubeg = xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8, ucnt = q8 + (xcd < rem ? 1 : 0);
-    const int srow = tid >> 5, schunk = tid & 31;
     const int slot0 = slot;
     (void)slot0;
     for (int ui = slot; ui < ucnt; ui += per_xcd) {
@@ -845,13 +847,33 @@ __global__ __launch_bounds__(NT, 2) void k1_stats_panel(K1Args a) {
         V8 af[16];
 #pragma unroll
         for (int kg = 0; kg < 16; ++kg) af[kg] = *reinterpret_cast<const V8*>(A + kg * 16);
-        v4u rb[8];
-        auto prefetch = [&](int bn) {
-            const H* g = B + (size_t)(bn * BN + srow) * a.C + schunk * 8;
+        // tile bn -> buffer `buf` by LDS-DMA (as k1_conf_pipe: 32 pieces of 2 rows x 512 B, 8 per wave; LDS slot j of row r holds
+        // chunk j ^ (r & 15)): no staging registers, no ds_write pass
+        const K1Rsrc brs = k1_rsrc(B, (unsigned)a.S * a.C * (unsigned)sizeof(H));
+        auto dma = [&](int bn, int buf) {
+            int dl = lane;
+            asm volatile("" : "+v"(dl));
 #pragma unroll
-            for (int p = 0; p < 8; ++p) rb[p] = *reinterpret_cast<const v4u*>(g + (size_t)p * 8 * a.C);
+            for (int i = 0; i < 8; ++i) {
+                const int p = wave * 8 + i, row = 2 * p + (dl >> 5), j = dl & 31;
+                k1_lds_dma(brs, smem + buf * (BN * 512) + p * 1024, (row * a.C + ((j ^ (row & 15)) << 3)) * (int)sizeof(H), bn * BN * a.C * (int)sizeof(H));
+            }
         };
-        prefetch(t0);
+        // the column partials of tile bn - 1 (parked in LDS by the four waves) are combined behind tile bn's barrier, by wave bn % 4:
+        // no barrier of their own
+        auto combine = [&](int bn, int par) {
+            const float2* cx = colx + par * 256;
+            float m = NEG_INF;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) m = fmaxf(m, cx[w * 64 + lane].x);
+            float l = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) l += cx[w * 64 + lane].y * __expf(cx[w * 64 + lane].x - m);
+            a.colpart[((size_t)n * a.tilesM + bm) * a.S + bn * BN + lane] = make_float2(m, l);
+        };
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                      // the previous unit's readers of the buffers / colx / rowbc are done
+        dma(t0, 0);
         // Per-element work of this pass = 1 exponential, not 2.5: everything is referred to ONE lazily updated reference per
         // row slot (a register) of this lane,
         //     e = exp2(s2 - ref[r]),  s2 = acc * mult * log2(e),
@@ -869,14 +891,20 @@ __global__ __launch_bounds__(NT, 2) void k1_stats_panel(K1Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { rmx[r] = NEG_INF; rs[r] = 0.f; ref[r] = NEG_INF; fcol[r] = 0.f; }
         float minref = NEG_INF, kappa = NEG_INF;
-        for (int bn = t0; bn < t1; ++bn) {
-            __syncthreads();                                  // previous tile: fragments consumed, colx combined
+        // the tile body, instantiated for both buffer parities (the loop below walks the tiles in pairs): with the parity a compile-time
+        // constant the 32 fragment reads of a tile are the same 16 lane-constant addresses + an immediate offset - as a run-time
+        // term it doubled them, and the spilled ones were reloaded from scratch between the DMA requests
+        auto tile = [&](auto par_c, const int bn) {
+            constexpr int PAR = decltype(par_c)::value;
+            const char* tb = smem + PAR * (BN * 512);
             K1_TS(1 + 6 * (bn - t0));
-#pragma unroll
-            for (int p = 0; p < 8; ++p) *reinterpret_cast<v4u*>(smem + k1p_off(srow + 8 * p, schunk)) = rb[p];
+            // ONE barrier per tile: tile bn has landed (every wave waits for its own pieces; the only other vector-memory operations
+            // in flight are 64 column-partial stores of one wave), every wave is past tile bn - 1 (its buffer and colx slot are free)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             K1_TS(2 + 6 * (bn - t0));
-            if (bn + 1 < t1) prefetch(bn + 1);
+            if (bn + 1 < t1) dma(bn + 1, PAR ^ 1);
+            if (bn > t0 && wave == ((bn - t0) & 3)) combine(bn - 1, PAR ^ 1);
             v16f acc[2];
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
@@ -884,14 +912,14 @@ __global__ __launch_bounds__(NT, 2) void k1_stats_panel(K1Args a) {
                 for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
             // the f1 fragments of k-group kg + 1 are requested in front of the MFMAs of kg (two waves per SIMD do not hide an LDS
             // round trip in front of every MFMA pair: left alone the compiler reads each pair right where it is used)
-            V8 b0 = *reinterpret_cast<const V8*>(smem + k1p_off(lr, h)), b1 = *reinterpret_cast<const V8*>(smem + k1p_off(32 + lr, h));
+            V8 b0 = *reinterpret_cast<const V8*>(tb + k1p_off(lr, h)), b1 = *reinterpret_cast<const V8*>(tb + k1p_off(32 + lr, h));
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);          // issue order: reads(0) | reads(1) MFMAs(0) | reads(2) MFMAs(1) | ...
 #pragma unroll
             for (int kg = 0; kg < 16; ++kg) {
                 V8 n0 = b0, n1 = b1;
                 if (kg < 15) {
-                    n0 = *reinterpret_cast<const V8*>(smem + k1p_off(lr, 2 * kg + 2 + h));
-                    n1 = *reinterpret_cast<const V8*>(smem + k1p_off(32 + lr, 2 * kg + 2 + h));
+                    n0 = *reinterpret_cast<const V8*>(tb + k1p_off(lr, 2 * kg + 2 + h));
+                    n1 = *reinterpret_cast<const V8*>(tb + k1p_off(32 + lr, 2 * kg + 2 + h));
                     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 }
                 Mma32<H>::mma(af[kg], b0, acc[0]);
@@ -952,22 +980,18 @@ __global__ __launch_bounds__(NT, 2) void k1_stats_panel(K1Args a) {
             cs0 += __shfl_xor(cs0, 32, 64);
             cs1 += __shfl_xor(cs1, 32, 64);
             if (h == 0) {
-                colx[wave * 64 + lr] = make_float2(cm0 * a.mult, cs0);
-                colx[wave * 64 + 32 + lr] = make_float2(cm1 * a.mult, cs1);
+                float2* cx = colx + PAR * 256;
+                cx[wave * 64 + lr] = make_float2(cm0 * a.mult, cs0);
+                cx[wave * 64 + 32 + lr] = make_float2(cm1 * a.mult, cs1);
             }
             K1_TS(5 + 6 * (bn - t0));
-            __syncthreads();
-            K1_TS(6 + 6 * (bn - t0));
-            if (tid < 64) {                                   // combine the four waves' column partials
-                float m = NEG_INF;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) m = fmaxf(m, colx[w * 64 + tid].x);
-                float l = 0.f;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) l += colx[w * 64 + tid].y * __expf(colx[w * 64 + tid].x - m);
-                a.colpart[((size_t)n * a.tilesM + bm) * a.S + bn * BN + tid] = make_float2(m, l);
-            }
+        };
+        for (int bn = t0; bn < t1; bn += 2) {
+            tile(std::integral_constant<int, 0>{}, bn);
+            if (bn + 1 < t1) tile(std::integral_constant<int, 1>{}, bn + 1);
         }
+        __syncthreads();                                      // the last tile's column partials are parked
+        if (wave == ((t1 - t0) & 3)) combine(t1 - 1, (t1 - 1 - t0) & 1);
         // ---- end of the run: row maxima across the lanes, sums moved from the lane's reference to them, sums across the lanes
         float v[32];
 #pragma unroll
@@ -1206,6 +1230,15 @@ __global__ __launch_bounds__(1024) void k1_compact(SelArgs a) {
 }
 
 template <typename T>
+void k1_stats_allow_lds() {                                     // 68.5 KiB of dynamic LDS: opt in once per device
+    if constexpr (!std::is_same<T, float>::value) {
+        static std::atomic<uint64_t> attr{0};
+        if (gf_first_use_on_device(attr))
+            (void)hipFuncSetAttribute((const void*)k1_stats_panel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, STATS_LDS);
+    }
+}
+
+template <typename T>
 int k1_launch(K1Args a, SelArgs s, void* zero_begin, size_t zero_bytes, hipStream_t st) {
     constexpr bool EXACT = std::is_same<T, float>::value;
     const dim3 grid(a.tilesN * a.tilesM, a.N);
@@ -1219,7 +1252,10 @@ int k1_launch(K1Args a, SelArgs s, void* zero_begin, size_t zero_bytes, hipStrea
     void* pu = gf_prof_begin("k1_unit", st, (double)a.N * ((double)(a.L + a.S) * a.C * sizeof(T) + (match_only ? 0.0 : (double)a.L * a.S * 4.0)));
     void* p0 = gf_prof_begin("k1_stats", st, 2.0 * a.N * (double)a.L * a.S * a.C);
     if constexpr (!EXACT) {
-        if (panel) k1_stats_panel<T><<<wgs, NT, PANEL_LDS + 2048, st>>>(a);
+        if (panel) {
+            k1_stats_allow_lds<T>();
+            k1_stats_panel<T><<<wgs, NT, STATS_LDS, st>>>(a);
+        }
         else k1_stats<T><<<grid, NT, STAGE_BYTES, st>>>(a);
     } else {
         k1_stats<T><<<grid, NT, STAGE_BYTES, st>>>(a);
@@ -1678,7 +1714,8 @@ extern "C" int gf_coarse_loss_forward(const void* f0, const void* f1, int dtype,
     if (mask0 == nullptr) {                                   // panel form (needs no masks)
         const int runs = (a.tilesN + PANEL_TILES - 1) / PANEL_TILES, units = N * a.tilesM * runs;
         a.rowparts = runs;
-        k1_stats_panel<_Float16><<<units < 512 ? units : 512, NT, PANEL_LDS + 2048, st>>>(a);
+        k1_stats_allow_lds<_Float16>();
+        k1_stats_panel<_Float16><<<units < 512 ? units : 512, NT, STATS_LDS, st>>>(a);
     } else {
         a.rowparts = a.tilesN;
         k1_stats<_Float16><<<dim3(a.tilesN * a.tilesM, N), NT, STAGE_BYTES, st>>>(a);
