@@ -349,3 +349,269 @@ extern "C" int gf_activation_backward(const void* dh, const void* h, void* dz, s
     GF_CHECK_LAUNCH();
     return GF_OK;
 }
+
+// =====================================================================================================================
+// K2 (training): backward of LinearAttention.forward (model/loftr_src/loftr/loftr_module/linear_attention.py:21-51)
+//   Q = phi(q) [q_mask], K = phi(k) [kv_mask], vs = v [kv_mask] / S, phi = elu + 1
+//   KV = sum_s K_s^T vs_s, Ksum = sum_s K_s, den_l = Q_l . Ksum + eps, out_l = (Q_l KV) S / den_l
+// given dout:  num = Q KV,  dnum = dout S / den,  dden = -(dout . num) S / den^2
+//   dQ = dnum KV^T + dden Ksum,  dKV = sum_l Q_l^T dnum_l,  dKsum = sum_l dden_l Q_l
+//   dK_s = vs_s dKV^T + dKsum,   dvs_s = K_s dKV,   dq = dQ phi'(q) [q_mask], dk = dK phi'(k) [kv_mask], dv = dvs / S [kv_mask]
+// with phi'(x) = 1 (x > 0) | exp(x) = phi(x) (x <= 0).  Heads of D = 32; fp32 arithmetic on 16-bit operands (the state's two
+// operands rounded to the storage type as the forward rounds them); per-(image, head) states by chunk partials added in chunk
+// order (deterministic).  Five launches: state partials, sum, per-query pass (+ gradient-state partials), sum, per-source pass.
+// =====================================================================================================================
+namespace {
+
+constexpr int LB_D = 32, LB_TOK = 128, LB_RS = 36;        // head width, tokens per workgroup, LDS row stride (floats; 16-byte rows)
+constexpr int LB_STATE = LB_D * LB_D + LB_D;              // KV [d][v] | Ksum [d]
+
+struct LbArgs {
+    const void* q; const void* k; const void* v; const void* dout;
+    long ldq, ldk, ldv, ldo;
+    const uint8_t* q_mask; const uint8_t* kv_mask;
+    void* dq; void* dk; void* dv;                           // [N][L|S][H * 32] contiguous
+    float* part; float* state; float* gstate;               // [N * H][chunks][LB_STATE] | [N * H][LB_STATE] x 2
+    int N, L, S, H, chunksL, chunksS;
+    float eps;
+};
+
+__device__ __forceinline__ float lb_phi(float x) { return x > 0.f ? x + 1.f : __expf(x); }
+template <typename T>
+__device__ __forceinline__ void lb_load16(const T* p, float (&o)[16]) {
+    const gf_vec<T, 8> a = *reinterpret_cast<const gf_vec<T, 8>*>(p), b = *reinterpret_cast<const gf_vec<T, 8>*>(p + 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { o[i] = gf_to_float(a[i]); o[8 + i] = gf_to_float(b[i]); }
+}
+template <typename T>
+__device__ __forceinline__ void lb_store16(T* p, const float (&o)[16]) {
+    gf_vec<T, 8> a, b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = gf_from_float<T>(o[i]); b[i] = gf_from_float<T>(o[8 + i]); }
+    *reinterpret_cast<gf_vec<T, 8>*>(p) = a;
+    *reinterpret_cast<gf_vec<T, 8>*>(p + 8) = b;
+}
+
+// sum over the workgroup's tokens of a_t^T b_t (32 x 32) and of w_t a_t (32): rows staged in LDS [LB_TOK][LB_RS] by the caller;
+// thread -> output row d = tid >> 3, four columns v4 = (tid & 7) * 4; ROUND: a_t rounded to T inside the product (the forward's KV
+// operand), un-rounded in the weighted row sum.  Writes one partial of LB_STATE floats.
+template <typename T, bool ROUND>
+__device__ __forceinline__ void lb_outer(const float* sa, const float* sb, const float* sw, int tokens, float* dst) {
+    const int tid = threadIdx.x, d = tid >> 3, v4 = (tid & 7) * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < tokens; ++t) {
+        float a = sa[t * LB_RS + d];
+        if (ROUND) a = gf_to_float(gf_from_float<T>(a));
+        const v4f b = *reinterpret_cast<const v4f*>(sb + t * LB_RS + v4);
+        acc[0] += a * b.x; acc[1] += a * b.y; acc[2] += a * b.z; acc[3] += a * b.w;
+    }
+    *reinterpret_cast<v4f*>(dst + d * LB_D + v4) = v4f{acc[0], acc[1], acc[2], acc[3]};
+    if (tid < LB_D) {
+        float s = 0.f;
+        for (int t = 0; t < tokens; ++t) s += sw[t] * sa[t * LB_RS + tid];
+        dst[LB_D * LB_D + tid] = s;
+    }
+}
+
+// forward state partials: a = K = phi(k) [mask], b = vs = round(v [mask] / S), w = 1
+template <typename T>
+__global__ __launch_bounds__(256) void lb_state_partial(LbArgs a) {
+    __shared__ __attribute__((aligned(16))) float sa[LB_TOK * LB_RS], sb[LB_TOK * LB_RS];
+    __shared__ float sw[LB_TOK];
+    const int chunk = blockIdx.x, nh = blockIdx.y, n = nh / a.H, hh = nh - n * a.H, tid = threadIdx.x;
+    const int tok = tid >> 1, half = tid & 1, s = chunk * LB_TOK + tok;
+    const int tokens = min(LB_TOK, a.S - chunk * LB_TOK);
+    float kk[16], vv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { kk[i] = 0.f; vv[i] = 0.f; }
+    if (s < a.S && (a.kv_mask == nullptr || a.kv_mask[(size_t)n * a.S + s] != 0)) {
+        lb_load16<T>((const T*)a.k + ((size_t)n * a.S + s) * a.ldk + hh * LB_D + half * 16, kk);
+        lb_load16<T>((const T*)a.v + ((size_t)n * a.S + s) * a.ldv + hh * LB_D + half * 16, vv);
+        const float inv_s = 1.0f / (float)a.S;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { kk[i] = lb_phi(kk[i]); vv[i] = gf_to_float(gf_from_float<T>(vv[i] * inv_s)); }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { sa[tok * LB_RS + half * 16 + i] = kk[i]; sb[tok * LB_RS + half * 16 + i] = vv[i]; }
+    if (half == 0) sw[tok] = 1.f;
+    __syncthreads();
+    lb_outer<T, true>(sa, sb, sw, tokens, a.part + ((size_t)nh * a.chunksS + chunk) * LB_STATE);
+}
+
+__global__ __launch_bounds__(256) void lb_state_sum(const float* part, float* state, int chunks) {
+    const int nh = blockIdx.x;
+    for (int e = threadIdx.x; e < LB_STATE; e += 256) {
+        float s = 0.f;
+        for (int c = 0; c < chunks; ++c) s += part[((size_t)nh * chunks + c) * LB_STATE + e];
+        state[(size_t)nh * LB_STATE + e] = s;
+    }
+}
+
+// per-query pass: dq, and the partials of the gradient state (a = Q, b = dnum, w = dden)
+template <typename T>
+__global__ __launch_bounds__(256) void lb_query_pass(LbArgs a) {
+    __shared__ __attribute__((aligned(16))) float sa[LB_TOK * LB_RS], sb[LB_TOK * LB_RS];
+    __shared__ float sw[LB_TOK];
+    __shared__ __attribute__((aligned(16))) float kv[LB_STATE];
+    const int chunk = blockIdx.x, nh = blockIdx.y, n = nh / a.H, hh = nh - n * a.H, tid = threadIdx.x;
+    const int tok = tid >> 1, half = tid & 1, l = chunk * LB_TOK + tok;
+    const int tokens = min(LB_TOK, a.L - chunk * LB_TOK);
+    for (int e = tid; e < LB_STATE; e += 256) kv[e] = a.state[(size_t)nh * LB_STATE + e];
+    const bool live = l < a.L && (a.q_mask == nullptr || a.q_mask[(size_t)n * a.L + l] != 0);
+    float qr[16], qo[16], dr[16], dro[16];                   // this thread's half of the head (q, dout) and the other half
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { qr[i] = 0.f; qo[i] = 0.f; dr[i] = 0.f; dro[i] = 0.f; }
+    const int lc = min(l, a.L - 1);
+    const T* qp = (const T*)a.q + ((size_t)n * a.L + lc) * a.ldq + hh * LB_D;
+    const T* dp = (const T*)a.dout + ((size_t)n * a.L + lc) * a.ldo + hh * LB_D;
+    float qraw[16];
+    lb_load16<T>(qp + half * 16, qraw);
+    if (live) {
+        lb_load16<T>(qp + (half ^ 1) * 16, qo);
+        lb_load16<T>(dp + half * 16, dr);
+        lb_load16<T>(dp + (half ^ 1) * 16, dro);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { qr[i] = lb_phi(qraw[i]); qo[i] = lb_phi(qo[i]); }
+    }
+    __syncthreads();
+    // full rows in "head order": index d = half * 16 + i for the own half
+    float Q[32], G[32];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        Q[half * 16 + i] = qr[i]; Q[(half ^ 1) * 16 + i] = qo[i];
+        G[half * 16 + i] = dr[i]; G[(half ^ 1) * 16 + i] = dro[i];
+    }
+    float den = a.eps;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) den += Q[d] * kv[LB_D * LB_D + d];
+    // num[v] for all v (needed for dden), from the state in LDS (broadcast reads)
+    float num[32];
+#pragma unroll
+    for (int v = 0; v < 32; ++v) num[v] = 0.f;
+    for (int d = 0; d < 32; ++d) {
+        const float qd = Q[d];
+#pragma unroll
+        for (int v = 0; v < 32; v += 4) {
+            const v4f r = *reinterpret_cast<const v4f*>(kv + d * LB_D + v);
+            num[v] += qd * r.x; num[v + 1] += qd * r.y; num[v + 2] += qd * r.z; num[v + 3] += qd * r.w;
+        }
+    }
+    const float sl = (float)a.S, z = sl / den;
+    float dot = 0.f;
+#pragma unroll
+    for (int v = 0; v < 32; ++v) dot += G[v] * num[v];
+    const float dden = live ? -dot * z / den : 0.f;
+    float dnum[32];
+#pragma unroll
+    for (int v = 0; v < 32; ++v) dnum[v] = live ? G[v] * z : 0.f;
+    // dQ for the own half: dQ[d] = sum_v dnum[v] KV[d][v] + dden Ksum[d];  dq = dQ phi'(q)
+    float dq[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int d = half * 16 + i;
+        float s = dden * kv[LB_D * LB_D + d];
+#pragma unroll
+        for (int v = 0; v < 32; v += 4) {
+            const v4f r = *reinterpret_cast<const v4f*>(kv + d * LB_D + v);
+            s += dnum[v] * r.x + dnum[v + 1] * r.y + dnum[v + 2] * r.z + dnum[v + 3] * r.w;
+        }
+        dq[i] = live ? s * (qraw[i] > 0.f ? 1.f : qr[i]) : 0.f;
+    }
+    if (l < a.L) lb_store16<T>((T*)a.dq + ((size_t)n * a.L + l) * (a.H * LB_D) + hh * LB_D + half * 16, dq);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { sa[tok * LB_RS + half * 16 + i] = qr[i]; sb[tok * LB_RS + half * 16 + i] = dnum[half * 16 + i]; }
+    if (half == 0) sw[tok] = dden;
+    __syncthreads();
+    lb_outer<T, false>(sa, sb, sw, tokens, a.part + ((size_t)nh * a.chunksL + chunk) * LB_STATE);
+}
+
+// per-source pass: dk, dv from the gradient state
+template <typename T>
+__global__ __launch_bounds__(256) void lb_source_pass(LbArgs a) {
+    __shared__ __attribute__((aligned(16))) float g[LB_STATE];
+    const int chunk = blockIdx.x, nh = blockIdx.y, n = nh / a.H, hh = nh - n * a.H, tid = threadIdx.x;
+    const int tok = tid >> 1, half = tid & 1, s = chunk * LB_TOK + tok;
+    for (int e = tid; e < LB_STATE; e += 256) g[e] = a.gstate[(size_t)nh * LB_STATE + e];
+    __syncthreads();
+    if (s >= a.S) return;
+    const bool live = a.kv_mask == nullptr || a.kv_mask[(size_t)n * a.S + s] != 0;
+    float kraw[16], ko[16], vo[16], vr[16], out_k[16], out_v[16];
+    const T* kp = (const T*)a.k + ((size_t)n * a.S + s) * a.ldk + hh * LB_D;
+    const T* vp = (const T*)a.v + ((size_t)n * a.S + s) * a.ldv + hh * LB_D;
+    lb_load16<T>(kp + half * 16, kraw);
+    lb_load16<T>(kp + (half ^ 1) * 16, ko);
+    lb_load16<T>(vp + half * 16, vr);
+    lb_load16<T>(vp + (half ^ 1) * 16, vo);
+    const float inv_s = 1.0f / (float)a.S;
+    float K[32], V[32];                                       // K rounded as the forward's state operand; vs = round(v / S)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        K[half * 16 + i] = gf_to_float(gf_from_float<T>(lb_phi(kraw[i])));
+        K[(half ^ 1) * 16 + i] = gf_to_float(gf_from_float<T>(lb_phi(ko[i])));
+        V[half * 16 + i] = gf_to_float(gf_from_float<T>(vr[i] * inv_s));
+        V[(half ^ 1) * 16 + i] = gf_to_float(gf_from_float<T>(vo[i] * inv_s));
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int d = half * 16 + i;                          // dK[d] = sum_v vs[v] dKV[d][v] + dKsum[d]
+        float sk = g[LB_D * LB_D + d];
+#pragma unroll
+        for (int v = 0; v < 32; v += 4) {
+            const v4f r = *reinterpret_cast<const v4f*>(g + d * LB_D + v);
+            sk += V[v] * r.x + V[v + 1] * r.y + V[v + 2] * r.z + V[v + 3] * r.w;
+        }
+        out_k[i] = live ? sk * (kraw[i] > 0.f ? 1.f : lb_phi(kraw[i])) : 0.f;
+        float sv = 0.f;                                       // dvs[v = d] = sum_dd K[dd] dKV[dd][v]
+#pragma unroll
+        for (int dd = 0; dd < 32; ++dd) sv += K[dd] * g[dd * LB_D + d];
+        out_v[i] = live ? sv * inv_s : 0.f;
+    }
+    lb_store16<T>((T*)a.dk + ((size_t)n * a.S + s) * (a.H * LB_D) + hh * LB_D + half * 16, out_k);
+    lb_store16<T>((T*)a.dv + ((size_t)n * a.S + s) * (a.H * LB_D) + hh * LB_D + half * 16, out_v);
+}
+
+template <typename T>
+void lb_launch(const LbArgs& a, hipStream_t st) {
+    const int NH = a.N * a.H;
+    lb_state_partial<T><<<dim3(a.chunksS, NH), 256, 0, st>>>(a);
+    lb_state_sum<<<NH, 256, 0, st>>>(a.part, a.state, a.chunksS);
+    lb_query_pass<T><<<dim3(a.chunksL, NH), 256, 0, st>>>(a);
+    lb_state_sum<<<NH, 256, 0, st>>>(a.part, a.gstate, a.chunksL);
+    lb_source_pass<T><<<dim3(a.chunksS, NH), 256, 0, st>>>(a);
+}
+
+}   // namespace
+
+extern "C" size_t gf_linear_attention_backward_workspace_bytes(int N, int L, int S, int H) {
+    if (N <= 0 || L <= 0 || S <= 0 || H <= 0) return 0;
+    const size_t cl = (L + LB_TOK - 1) / LB_TOK, cs = (S + LB_TOK - 1) / LB_TOK, c = cl > cs ? cl : cs;
+    return gf_align_up(sizeof(float) * (size_t)N * H * (c + 2) * LB_STATE, 256);
+}
+
+// dq [N, L, H*32], dk, dv [N, S, H*32] (contiguous, `dtype`) of out = LinearAttention(q, k, v) given dout; q, k, v, dout are
+// [N, L|S, H, 32] views with row strides ldq / ldk / ldv / ldo (elements); masks uint8 [N, L] / [N, S] or NULL
+extern "C" int gf_linear_attention_backward(const void* q, const void* k, const void* v, const void* dout, int dtype, int N, int L, int S, int H,
+                                            int D, long ldq, long ldk, long ldv, long ldo, const uint8_t* q_mask, const uint8_t* kv_mask, float eps,
+                                            void* dq, void* dk, void* dv, void* workspace, size_t workspace_bytes, void* stream) {
+    GF_CHECK_ARG(q && k && v && dout && dq && dk && dv, "null pointer");
+    GF_CHECK_ARG(dtype == GF_F16 || dtype == GF_BF16, "built for 16-bit activations");
+    GF_CHECK_ARG(N > 0 && L > 0 && S > 0 && H > 0 && D == LB_D, "built for heads of 32 channels (the coarse level)");
+    GF_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0, "rows must be 16-byte aligned");
+    if (workspace == nullptr || workspace_bytes < gf_linear_attention_backward_workspace_bytes(N, L, S, H)) {
+        gf_set_error("gf_linear_attention_backward: workspace too small");
+        return GF_ERR_WORKSPACE;
+    }
+    LbArgs a{};
+    a.q = q; a.k = k; a.v = v; a.dout = dout; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.q_mask = q_mask; a.kv_mask = kv_mask;
+    a.dq = dq; a.dk = dk; a.dv = dv; a.N = N; a.L = L; a.S = S; a.H = H; a.eps = eps;
+    a.chunksL = (L + LB_TOK - 1) / LB_TOK; a.chunksS = (S + LB_TOK - 1) / LB_TOK;
+    const size_t c = a.chunksL > a.chunksS ? a.chunksL : a.chunksS;
+    a.part = (float*)workspace;
+    a.state = a.part + (size_t)N * H * c * LB_STATE;
+    a.gstate = a.state + (size_t)N * H * LB_STATE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GF_F16) lb_launch<_Float16>(a, st);
+    else lb_launch<gf_bf16>(a, st);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}

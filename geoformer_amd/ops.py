@@ -528,3 +528,28 @@ def activation_backward(dh, h, kind):
     check(_lib.lib().gf_activation_backward(_p(dh), _p(h), _p(dz), h.numel(), {'relu': 0, 'tanh': 1}[kind], _dt(h), _stream()),
           'gf_activation_backward')
     return dz
+
+
+def linear_attention_backward(q, k, v, dout, nhead, q_mask=None, kv_mask=None, eps=1e-6):
+    """(dq [N,L,C], dk, dv [N,S,C]) of K2's linear attention given dout [N,L,C]; q [N,L,C], k, v [N,S,C] (row-strided views allowed),
+    heads of 32 channels, 16-bit tensors."""
+    _need_cuda(q, k, v, dout)
+    N, L, C = q.shape
+    S = k.shape[1]
+    D = C // nhead
+    q, ldq = _rows(q)
+    k, ldk = _rows(k)
+    v, ldv = _rows(v)
+    dout, ldo = _rows(dout)
+    for t, ld, n in ((q, ldq, L), (dout, ldo, L), (k, ldk, S), (v, ldv, S)):
+        if t.stride(0) != ld * n:
+            raise ValueError('linear_attention_backward needs batch stride == rows * row stride')
+    dq = torch.empty(N, L, C, dtype=q.dtype, device=q.device)
+    dkv = torch.empty(2, N, S, C, dtype=q.dtype, device=q.device)
+    qm = None if q_mask is None else _contig(q_mask.reshape(N, L).to(torch.uint8))
+    km = None if kv_mask is None else _contig(kv_mask.reshape(N, S).to(torch.uint8))
+    L_ = _lib.lib()
+    ws = _ws.get('k2bwd', L_.gf_linear_attention_backward_workspace_bytes(N, L, S, nhead), q.device)
+    check(L_.gf_linear_attention_backward(_p(q), _p(k), _p(v), _p(dout), _dt(q), N, L, S, nhead, D, ldq, ldk, ldv, ldo, _p(qm), _p(km), float(eps),
+                                          _p(dq), _p(dkv[0]), _p(dkv[1]), _p(ws), ws.numel(), _stream()), 'gf_linear_attention_backward')
+    return dq, dkv[0], dkv[1]

@@ -112,10 +112,14 @@ def _encoder_layer_hip(P, prefix, x, source, nhead, kind, x_mask, source_mask):
     d = c // nhead
     x16 = x.to(dt)
     s16 = x16 if source is x else source.to(dt)
-    q = HA.linear(x16, P[prefix + 'q_proj.weight']).view(n, -1, nhead, d)
-    k = HA.linear(s16, P[prefix + 'k_proj.weight']).view(n, -1, nhead, d)
-    v = HA.linear(s16, P[prefix + 'v_proj.weight']).view(n, -1, nhead, d)
-    msg = linear_attention(q, k, v, x_mask, source_mask) if kind == 'loftr' else full_attention(q, k, v, source_mask)
+    q = HA.linear(x16, P[prefix + 'q_proj.weight'])
+    k = HA.linear(s16, P[prefix + 'k_proj.weight'])
+    v = HA.linear(s16, P[prefix + 'v_proj.weight'])
+    if kind == 'loftr' and d == 32:                      # the coarse level: K2 forward and backward in HIP
+        msg = HA.linear_attention(q, k, v, nhead, x_mask, source_mask)
+    else:
+        q, k, v = (t.view(n, -1, nhead, d) for t in (q, k, v))
+        msg = linear_attention(q, k, v, x_mask, source_mask) if kind == 'loftr' else full_attention(q, k, v, source_mask)
     msg = HA.linear(msg.reshape(n, -1, c).to(dt), P[prefix + 'merge.weight'])
     msg = HA.layer_norm(msg, P[prefix + 'norm1.weight'], P[prefix + 'norm1.bias'])
     hid = HA.linear(x16, P[prefix + 'mlp.0.weight'], msg, 'relu' if kind == 'loftr' else 'tanh')

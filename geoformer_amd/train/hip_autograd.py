@@ -98,6 +98,29 @@ class HipLayerNorm(torch.autograd.Function):
         return dy, dg.to(ctx.pdtype), db.to(ctx.pdtype), None
 
 
+class HipLinearAttention(torch.autograd.Function):
+    """LinearAttention.forward (linear_attention.py:21-51) on [N, L, C] / [N, S, C] 16-bit tensors with heads of 32 channels:
+    forward = K2 (gf_linear_attention), backward = gf_linear_attention_backward (csrc/k_train.hip)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, nhead, q_mask=None, kv_mask=None):
+        out = ops.linear_attention(q, k, v, nhead, q_mask, kv_mask)
+        ctx.nhead = nhead
+        ctx.masks = (q_mask, kv_mask)
+        ctx.save_for_backward(q, k, v)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v = ctx.saved_tensors
+        dq, dk, dv = ops.linear_attention_backward(q, k, v, dout.contiguous(), ctx.nhead, *ctx.masks)
+        return dq, dk, dv, None, None, None
+
+
+def linear_attention(q, k, v, nhead, q_mask=None, kv_mask=None):
+    return HipLinearAttention.apply(q, k, v, nhead, q_mask, kv_mask)
+
+
 def linear(x, w, x2=None, act=None):
     return HipLinear.apply(x, w, x2, act)
 

@@ -102,6 +102,18 @@ int gf_layernorm_backward(const void* dout, const void* y, const float* stats, i
 int gf_activation_backward(const void* dh, const void* h, void* dz, size_t n, int kind, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K2 (training)  backward of LinearAttention.forward (model/loftr_src/loftr/loftr_module/linear_attention.py:21-51), heads of 32
+ *   given dout [N, L, H, 32]: dq [N, L, H*32], dk, dv [N, S, H*32] (contiguous) of out = phi(q) KV S / (phi(q) . Ksum + eps),
+ *   KV = sum_s phi(k_s)^T (v_s / S), Ksum = sum_s phi(k_s), with the q / kv padding masks of :35-39.  q, k, v, dout: [N, L|S, H, 32]
+ *   views with row strides in elements (GF_F16 / GF_BF16); fp32 arithmetic; the (image, head) states are sums of chunk partials
+ *   in chunk order (deterministic).
+ * ------------------------------------------------------------------------------------------ */
+size_t gf_linear_attention_backward_workspace_bytes(int N, int L, int S, int H);
+int gf_linear_attention_backward(const void* q, const void* k, const void* v, const void* dout, int dtype, int N, int L, int S, int H,
+                                 int D, long ldq, long ldk, long ldv, long ldo, const uint8_t* q_mask, const uint8_t* kv_mask, float eps,
+                                 void* dq, void* dk, void* dv, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * K1 (training)  sparse-supervision focal loss on the dual-softmax confidence, forward and backward
  * replaces, for the training step, CoarseMatching.forward's conf_matrix (coarse_matching.py:113-125) as consumed by
  *          GeoLoss.compute_coarse_loss, focal / sparse_spvs / dual_softmax branch (loftr_loss.py:246-270), and the

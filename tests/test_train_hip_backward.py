@@ -95,6 +95,38 @@ def test_hip_linear_function_against_autograd(kind):
         assert rel < 2e-2, (name, rel)                           # bf16 intermediates round at different points: 1e-2 in norm
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('L,S,masked', [(640, 640, False), (300, 437, True), (130, 64, False)])
+def test_linear_attention_backward(dtype, L, S, masked):
+    """gf_linear_attention_backward against torch autograd of the training restatement of LinearAttention.forward
+    (train/functional.py:linear_attention, fp32 arithmetic) on the same 16-bit q, k, v, dout: dq, dk, dv to 2e-2 in norm and 3 ulp of
+    the storage type on the large entries (ragged chunks, padding masks on both sides, row-strided views of a fused projection)."""
+    from geoformer_amd import ops
+    from geoformer_amd.train import functional as TF
+    g = torch.Generator().manual_seed(L + S)
+    N, H, D = 2, 8, 32
+    C = H * D
+    q = (torch.randn(N, L, C, generator=g) * 0.8).to(DEV, dtype)
+    kvbuf = (torch.randn(N, S, 2 * C, generator=g) * 0.8).to(DEV, dtype)
+    k, v = kvbuf[..., :C], kvbuf[..., C:]                              # strided views (ld = 2 C)
+    dout = torch.randn(N, L, C, generator=g).to(DEV, dtype)
+    qm = km = None
+    if masked:
+        qm = torch.ones(N, L, dtype=torch.bool); qm[1, L // 2:] = False
+        km = torch.ones(N, S, dtype=torch.bool); km[0, S - 50:] = False; km[1, :17] = False
+        qm, km = qm.to(DEV), km.to(DEV)
+    qf, kf, vf = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    out = TF.linear_attention(qf.view(N, L, H, D), kf.view(N, S, H, D), vf.view(N, S, H, D), qm, km)
+    out.backward(dout.float().view(N, L, H, D))
+    dq, dk, dv = ops.linear_attention_backward(q, k, v, dout, H, qm, km)
+    for name, got, want in (('dq', dq, qf.grad), ('dk', dk, kf.grad), ('dv', dv, vf.grad)):
+        rel = float((got.float() - want).norm() / want.norm())
+        assert rel < 2e-2, (name, rel)
+        if masked:
+            dead = ~(qm if name == 'dq' else km)
+            assert float(got[dead].abs().max()) == 0.0, name
+
+
 def test_hip_backward_train_step_matches_autocast_step():
     """TrainStep(precision='bf16', hip_backward=True) against the autocast bf16 step on the same batch and weights: loss terms
     within 2 %, parameter gradients of the first coarse term aligned (cosine > 0.97), fp32 parameters, loss decreasing."""
