@@ -14,8 +14,11 @@ g = get_cfg_model(); g.update(coarse_thr=0.0, fine_thr=0.0, precision='fp32')
 model = deterministic_init_(GeoFormer(get_default_cfg(), g)).cuda()
 PREC = 'bf16' if '--bf16' in sys.argv else 'fp32'
 step = TrainStep(model, batch_size=2, fused_coarse_loss=FUSED, precision=PREC, hip_backward='--hip' in sys.argv)
-for it in range(10 if "--long" in sys.argv else 4):
-    t = time.perf_counter(); step(synthetic_homography_batch(2, HW, seed=it, device='cuda')); torch.cuda.synchronize()
+nsteps = 10 if "--long" in sys.argv else 4
+batches = [synthetic_homography_batch(2, HW, seed=it, device='cuda') for it in range(nsteps)]      # (made outside the timed steps)
+torch.cuda.synchronize()
+for it in range(nsteps):
+    t = time.perf_counter(); step(batches[it]); torch.cuda.synchronize()
     print('step', it, '%.3f s' % (time.perf_counter() - t), 'fused' if FUSED else 'autograd', PREC, HW, flush=True)
 if '--no-prof' in sys.argv:
     sys.exit(0)
