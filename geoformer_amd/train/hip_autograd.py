@@ -1,6 +1,7 @@
 """torch.autograd Functions whose forward AND backward are the HIP kernels of the K3 chain.
 
-Used by the mixed-16-bit training step (`TrainStep(precision='bf16', hip_backward=True)`): the linears, LayerNorms and
+Used by the mixed-16-bit training step (`TrainStep(precision='bf16', hip_backward=True)`): the coarse layers' linear attention
+(`HipLinearAttention`: K2 forward, `gf_linear_attention_backward`) and the linears, LayerNorms and
 activations of the encoder layers (loftr_module/transformer.py:45-60, geo_transformer/transformer.py:49-66) and of
 FinePreprocess (fine_preprocess.py:61-72) run `gf_linear` / `gf_layernorm_forward` forward and
 `gf_linear` (dX = dY W), `gf_linear_wgrad` (dW = dY^T X), `gf_layernorm_backward`, `gf_activation_backward` backward.
