@@ -40,6 +40,7 @@ SIGNATURES = {
     'gf_layernorm_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                       c_void_p, c_size_t, c_void_p]),
     'gf_activation_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    'gf_fine_match_backward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'gf_linear_attention_backward_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'gf_linear_attention_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long,
                                              c_long, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -615,3 +615,103 @@ extern "C" int gf_linear_attention_backward(const void* q, const void* k, const 
     GF_CHECK_LAUNCH();
     return GF_OK;
 }
+
+// =====================================================================================================================
+// K8 (training): backward of FineMatching2.forward's confidence (model/fine_matching2.py:52-63):
+//   sim = f0 f1^T / (C temperature), A = softmax(sim, dim 1), B = softmax(sim, dim 2), conf = A o B        (per match, 25 x 25)
+// given G = dL/dconf:  T = G o conf,  dsim = 2 T - A o (1 colsum(T)^T) - B o (rowsum(T) 1^T),
+//   df0 = dsim f1 / (C temperature),  df1 = dsim^T f0 / (C temperature).
+// One workgroup per match, everything in LDS, fp32 arithmetic (the forward keeps the confidence in fp32 in every precision mode).
+// =====================================================================================================================
+namespace {
+
+constexpr int FB_W = 25;
+
+template <typename T>
+__global__ __launch_bounds__(256) void fine_match_backward(const T* f0, const T* f1, const float* dconf, T* df0, T* df1, int C, float temperature) {
+    __shared__ float s0[FB_W][129], s1[FB_W][129];
+    __shared__ float sim[FB_W][FB_W + 1], ds[FB_W][FB_W + 1];
+    __shared__ float rmax[FB_W], rsum[FB_W], cmax[FB_W], csum[FB_W], rt[FB_W], ct[FB_W];
+    const int m = blockIdx.x, t = threadIdx.x;
+    const float rs = sqrtf((float)C);
+    const T* p0 = f0 + (size_t)m * FB_W * C;
+    const T* p1 = f1 + (size_t)m * FB_W * C;
+    for (int i = t; i < FB_W * C; i += 256) {
+        s0[i / C][i % C] = gf_to_float(p0[i]) / rs;          // the forward's arithmetic (fine_match: feat / C**.5 on both sides)
+        s1[i / C][i % C] = gf_to_float(p1[i]) / rs;
+    }
+    __syncthreads();
+    for (int o = t; o < FB_W * FB_W; o += 256) {
+        const int i = o / FB_W, j = o % FB_W;
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) acc += s0[i][c] * s1[j][c];
+        sim[i][j] = acc / temperature;
+    }
+    __syncthreads();
+    if (t < FB_W) {                                           // softmax over dim 2 (row statistics)
+        float mx = -INFINITY;
+        for (int j = 0; j < FB_W; ++j) mx = fmaxf(mx, sim[t][j]);
+        float s = 0.f;
+        for (int j = 0; j < FB_W; ++j) s += expf(sim[t][j] - mx);
+        rmax[t] = mx; rsum[t] = s;
+    } else if (t >= 64 && t < 64 + FB_W) {                    // softmax over dim 1 (column statistics)
+        const int j = t - 64;
+        float mx = -INFINITY;
+        for (int i = 0; i < FB_W; ++i) mx = fmaxf(mx, sim[i][j]);
+        float s = 0.f;
+        for (int i = 0; i < FB_W; ++i) s += expf(sim[i][j] - mx);
+        cmax[j] = mx; csum[j] = s;
+    }
+    __syncthreads();
+    // T = G o conf into ds (for now), then its row / column sums
+    for (int o = t; o < FB_W * FB_W; o += 256) {
+        const int i = o / FB_W, j = o % FB_W;
+        const float a = expf(sim[i][j] - cmax[j]) / csum[j], b = expf(sim[i][j] - rmax[i]) / rsum[i];
+        ds[i][j] = dconf[(size_t)m * FB_W * FB_W + o] * a * b;
+    }
+    __syncthreads();
+    if (t < FB_W) {
+        float s = 0.f;
+        for (int j = 0; j < FB_W; ++j) s += ds[t][j];
+        rt[t] = s;
+    } else if (t >= 64 && t < 64 + FB_W) {
+        const int j = t - 64;
+        float s = 0.f;
+        for (int i = 0; i < FB_W; ++i) s += ds[i][j];
+        ct[j] = s;
+    }
+    __syncthreads();
+    for (int o = t; o < FB_W * FB_W; o += 256) {
+        const int i = o / FB_W, j = o % FB_W;
+        const float a = expf(sim[i][j] - cmax[j]) / csum[j], b = expf(sim[i][j] - rmax[i]) / rsum[i];
+        ds[i][j] = (2.0f * ds[i][j] - a * ct[j] - b * rt[i]) / temperature;     // d / d(the pre-temperature product)
+    }
+    __syncthreads();
+    // df0[i][c] = sum_j ds[i][j] s1[j][c] / sqrt(C);  df1[j][c] = sum_i ds[i][j] s0[i][c] / sqrt(C)
+    for (int o = t; o < FB_W * C; o += 256) {
+        const int r = o / C, c = o % C;
+        float a0 = 0.f, a1 = 0.f;
+        for (int k = 0; k < FB_W; ++k) {
+            a0 += ds[r][k] * s1[k][c];
+            a1 += ds[k][r] * s0[k][c];
+        }
+        df0[(size_t)m * FB_W * C + o] = gf_from_float<T>(a0 / rs);
+        df1[(size_t)m * FB_W * C + o] = gf_from_float<T>(a1 / rs);
+    }
+}
+
+}   // namespace
+
+// df0, df1 [M, 25, C] (`dtype`) of fine_matrix = FineMatching2's 25 x 25 dual-softmax confidence given dconf fp32 [M, 25, 25]
+extern "C" int gf_fine_match_backward(const void* f0, const void* f1, int dtype, int M, int WWin, int C, float temperature, const float* dconf,
+                                      void* df0, void* df1, void* stream) {
+    GF_CHECK_ARG(f0 && f1 && dconf && df0 && df1, "null pointer");
+    GF_CHECK_ARG(M > 0 && WWin == FB_W && C > 0 && C <= 128, "built for 5x5 windows and C <= 128");
+    GF_CHECK_ARG(dtype >= GF_F32 && dtype <= GF_BF16 && temperature > 0.f, "bad dtype / temperature");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GF_F32) fine_match_backward<float><<<M, 256, 0, st>>>((const float*)f0, (const float*)f1, dconf, (float*)df0, (float*)df1, C, temperature);
+    else if (dtype == GF_F16) fine_match_backward<_Float16><<<M, 256, 0, st>>>((const _Float16*)f0, (const _Float16*)f1, dconf, (_Float16*)df0, (_Float16*)df1, C, temperature);
+    else fine_match_backward<gf_bf16><<<M, 256, 0, st>>>((const gf_bf16*)f0, (const gf_bf16*)f1, dconf, (gf_bf16*)df0, (gf_bf16*)df1, C, temperature);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}

@@ -553,3 +553,14 @@ def linear_attention_backward(q, k, v, dout, nhead, q_mask=None, kv_mask=None, e
     check(L_.gf_linear_attention_backward(_p(q), _p(k), _p(v), _p(dout), _dt(q), N, L, S, nhead, D, ldq, ldk, ldv, ldo, _p(qm), _p(km), float(eps),
                                           _p(dq), _p(dkv[0]), _p(dkv[1]), _p(ws), ws.numel(), _stream()), 'gf_linear_attention_backward')
     return dq, dkv[0], dkv[1]
+
+
+def fine_match_backward(f0, f1, temperature, dconf):
+    """(df0, df1) [M,25,C] of K8's fine_matrix given dconf fp32 [M,25,25]; f0, f1 [M,25,C] (M > 0) of one dtype."""
+    _need_cuda(f0, f1, dconf)
+    f0, f1, dconf = _contig(f0), _contig(f1), _contig(dconf.float())
+    M, WW, C = f0.shape
+    df = torch.empty(2, M, WW, C, dtype=f0.dtype, device=f0.device)
+    check(_lib.lib().gf_fine_match_backward(_p(f0), _p(f1), _dt(f0), M, WW, C, float(temperature), _p(dconf), _p(df[0]), _p(df[1]), _stream()),
+          'gf_fine_match_backward')
+    return df[0], df[1]

@@ -338,6 +338,14 @@ def fine_match(f0, f1, data, temperature, thr):
         return {'fine_matrix': torch.empty(0, WW, WW, device=f0.device), 'mkpts0_f': data['mkpts0_c'],
                 'mkpts1_f': data['mkpts1_c'], 'W': int(math.sqrt(WW))}
     W = int(math.sqrt(WW))
+    if _HIP_BACKWARD[0] and f0.is_cuda and C <= 128 and WW == 25:
+        # K8 forward (confidence, arg-max, threshold, keypoints) and its backward in HIP; the confidence stays fp32
+        from . import hip_autograd as HA
+        hi, hc, hf = float(data['hw0_i'][0]), float(data['hw0_c'][0]), float(data['hw0_f'][0])
+        conf, fine_b, mk0, mk1, mconf = HA.HipFineMatch.apply(f0.float().contiguous(), f1.float().contiguous(), temperature, thr, data['b_ids'],
+                                                               data['mkpts0_c'], data['mkpts1_c'], hi / hc, hf / hc, hi / hf,
+                                                               data.get('scale0'), data.get('scale1'))
+        return {'fine_matrix': conf, 'm_bids': fine_b, 'mkpts0_f': mk0, 'mkpts1_f': mk1, 'mconf': mconf, 'W': W}
     conf = dual_softmax(f0, f1, temperature)
     with torch.no_grad():
         mask = conf > thr

@@ -118,6 +118,27 @@ class HipLinearAttention(torch.autograd.Function):
         return dq, dk, dv, None, None, None
 
 
+class HipFineMatch(torch.autograd.Function):
+    """FineMatching2.forward + get_fine_match (model/fine_matching2.py:21-126) = K8: returns (fine_matrix [M, 25, 25] fp32, m_bids, mkpts0_f,
+    mkpts1_f, mconf); only fine_matrix carries a gradient (to the two window tensors), through gf_fine_match_backward."""
+
+    @staticmethod
+    def forward(ctx, f0, f1, temperature, thr, b_ids, mk0c, mk1c, cscale, c2f, fscale, scale0, scale1):
+        out = ops.fine_match(f0, f1, temperature, thr, b_ids, mk0c, mk1c, cscale, c2f, fscale, scale0, scale1)
+        n = int(out['count'][0])
+        ctx.temperature = temperature
+        ctx.save_for_backward(f0, f1)
+        res = (out['fine_matrix'], out['m_bids'][:n], out['mkpts0_f'][:n], out['mkpts1_f'][:n], out['mconf'][:n])
+        ctx.mark_non_differentiable(*res[1:])
+        return res
+
+    @staticmethod
+    def backward(ctx, dconf, *unused):
+        f0, f1 = ctx.saved_tensors
+        df0, df1 = ops.fine_match_backward(f0, f1, ctx.temperature, dconf)
+        return (df0, df1) + (None,) * 10
+
+
 def linear_attention(q, k, v, nhead, q_mask=None, kv_mask=None):
     return HipLinearAttention.apply(q, k, v, nhead, q_mask, kv_mask)
 

@@ -112,8 +112,8 @@ class TrainStep:
     `hip_backward=True` (with precision='bf16'): the linears, LayerNorms and activations of every encoder layer (LoFTR coarse and
     fine, Geo) run the HIP kernels forward AND backward (train/hip_autograd.py: gf_linear, gf_linear_wgrad, gf_layernorm_*,
     gf_activation_backward) instead of torch's GEMM / autograd, and the coarse layers' linear attention runs K2 forward and
-    gf_linear_attention_backward; the Geo attention cores, the fine level's attention (heads of 16), the fine matching and the
-    losses other than the fused coarse loss stay on autograd.  Step time at batch 2, 640x640: 0.128 s -> 0.100 s."""
+    gf_linear_attention_backward, FineMatching2 runs K8 forward and gf_fine_match_backward; the Geo attention cores, the fine
+    level's attention (heads of 16) and the losses other than the fused coarse loss stay on autograd.  Step time at batch 2, 640x640: 0.128 s -> 0.100 s."""
 
     def __init__(self, model, trainer_cfg=None, loss_cfg=None, batch_size=1, distributed=False, device_ids=None,
                  homography_fn: Optional[Callable] = None, sparse_spvs=True, fused_coarse_loss=False, precision='fp32',

@@ -108,6 +108,10 @@ int gf_activation_backward(const void* dh, const void* h, void* dz, size_t n, in
  *   views with row strides in elements (GF_F16 / GF_BF16); fp32 arithmetic; the (image, head) states are sums of chunk partials
  *   in chunk order (deterministic).
  * ------------------------------------------------------------------------------------------ */
+/* K8 (training): df0, df1 [M, 25, C] (`dtype`: GF_F32 / GF_F16 / GF_BF16) of FineMatching2.forward's confidence (model/fine_matching2.py:52-63:
+ * sim = f0 f1^T / (C temperature), conf = softmax(sim, 1) * softmax(sim, 2)) given dconf fp32 [M, 25, 25]; fp32 arithmetic. */
+int gf_fine_match_backward(const void* f0, const void* f1, int dtype, int M, int WW, int C, float temperature, const float* dconf,
+                           void* df0, void* df1, void* stream);
 size_t gf_linear_attention_backward_workspace_bytes(int N, int L, int S, int H);
 int gf_linear_attention_backward(const void* q, const void* k, const void* v, const void* dout, int dtype, int N, int L, int S, int H,
                                  int D, long ldq, long ldk, long ldv, long ldo, const uint8_t* q_mask, const uint8_t* kv_mask, float eps,

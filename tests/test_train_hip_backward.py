@@ -127,6 +127,40 @@ def test_linear_attention_backward(dtype, L, S, masked):
             assert float(got[dead].abs().max()) == 0.0, name
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_fine_match_backward(dtype):
+    """gf_fine_match_backward against autograd of the training restatement of FineMatching2's confidence (train/functional.py:dual_softmax)
+    for a random dconf, and the HipFineMatch Function's outputs against functional.fine_match (same matches, keypoints, matrix)."""
+    from geoformer_amd import ops
+    from geoformer_amd.train import functional as TF
+    import golden_inputs as GI
+    I = GI.g9_inputs()
+    f0, f1 = I['f0'].to(DEV, dtype), I['f1'].to(DEV, dtype)
+    g = torch.Generator().manual_seed(3)
+    dconf = torch.randn(f0.shape[0], 25, 25, generator=g).to(DEV)
+    a, b = f0.float().clone().requires_grad_(True), f1.float().clone().requires_grad_(True)
+    TF.dual_softmax(a, b, I['temperature']).backward(dconf)
+    df0, df1 = ops.fine_match_backward(f0, f1, I['temperature'], dconf)
+    tol = 1e-4 if dtype == torch.float32 else 1e-2
+    for name, got, want in (('df0', df0, a.grad), ('df1', df1, b.grad)):
+        rel = float((got.float() - want).norm() / want.norm())
+        assert rel < tol, (name, rel)
+    if dtype == torch.float32:
+        data = {'hw0_i': torch.tensor(I['hw0_i']), 'hw0_c': torch.tensor(I['hw0_c']), 'hw0_f': torch.tensor(I['hw0_f']), 'b_ids': I['b_ids'].to(DEV),
+                'mkpts0_c': I['mkpts0_c'].to(DEV), 'mkpts1_c': I['mkpts1_c'].to(DEV)}
+        ref = TF.fine_match(f0, f1, data, I['temperature'], I['thr'])
+        TF.set_hip_backward(True)
+        try:
+            got = TF.fine_match(f0.clone().requires_grad_(True), f1.clone().requires_grad_(True), data, I['temperature'], I['thr'])
+        finally:
+            TF.set_hip_backward(False)
+        torch.testing.assert_close(got['fine_matrix'], ref['fine_matrix'], rtol=2e-5, atol=1e-9)
+        assert torch.equal(got['m_bids'], ref['m_bids'])
+        torch.testing.assert_close(got['mkpts0_f'], ref['mkpts0_f'].float(), rtol=1e-6, atol=1e-5)
+        torch.testing.assert_close(got['mkpts1_f'], ref['mkpts1_f'].float(), rtol=1e-6, atol=1e-5)
+        assert got['fine_matrix'].requires_grad and not got['mkpts0_f'].requires_grad
+
+
 def test_hip_backward_train_step_matches_autocast_step():
     """TrainStep(precision='bf16', hip_backward=True) against the autocast bf16 step on the same batch and weights: loss terms
     within 2 %, parameter gradients of the first coarse term aligned (cosine > 0.97), fp32 parameters, loss decreasing."""
