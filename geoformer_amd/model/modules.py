@@ -163,6 +163,15 @@ class LoFTREncoderLayer(nn.Module):
         return self.finish(x, message, out=out)
 
 
+def _adjacent_halves(a, b):
+    """[2n, ...] view over a and b when they are the first and the second half of one contiguous buffer (e.g. out[:M], out[M:]), else None."""
+    if (a.shape != b.shape or a.dtype != b.dtype or not a.is_contiguous() or not b.is_contiguous() or a.numel() == 0
+            or a.untyped_storage().data_ptr() != b.untyped_storage().data_ptr()
+            or b.storage_offset() != a.storage_offset() + a.numel()):
+        return None
+    return a.as_strided((2 * a.shape[0],) + tuple(a.shape[1:]), a.stride(), a.storage_offset())
+
+
 class LocalFeatureTransformer(nn.Module):
     """reference: model/loftr_src/loftr/loftr_module/transformer.py:63-104"""
 
@@ -189,7 +198,9 @@ class LocalFeatureTransformer(nn.Module):
         if not same:
             both = None
         elif both is None:
-            both = torch.cat([feat0, feat1], 0)
+            both = _adjacent_halves(feat0, feat1)              # FinePreprocess hands out the two halves of ONE buffer: no concat
+            if both is None:
+                both = torch.cat([feat0, feat1], 0)
         mboth = torch.cat([mask0, mask1], 0) if (same and mask0 is not None) else None
         for layer, name in zip(self.layers, self.layer_names):
             if name == 'self':
