@@ -95,8 +95,19 @@ __device__ __forceinline__ float fl_rnd(float x) { return gf_to_float(gf_from_fl
 __device__ __forceinline__ v16f fl_zero() { return v16f{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; }
 
 // the weight ring: block g (counted over the whole kernel) sits in slot g & 1 and holds stream block g % NBLK
+struct FlRsrc {
+    __amdgpu_buffer_rsrc_t r;
+};
+__device__ __forceinline__ FlRsrc fl_rsrc(const void* p, unsigned bytes) {
+    return FlRsrc{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000)};
+}
+// LDS-DMA as buffer_load_dwordx4 ... lds (MUBUF): behind the FLAT form (global_load_lds) the compiler turns every LDS counter
+// wait into lgkmcnt(0) while a request is pending - which is always, here (see k9_encoder_fused.hip); scalar descriptor, 32-bit offsets
+__device__ __forceinline__ void fl_lds_dma(const FlRsrc& rs, char* dst, int voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs.r, (__attribute__((address_space(3))) void*)dst, 16, voffset, soffset, 0, 0);
+}
 struct FlRing {
-    const char* ws;
+    FlRsrc ws;
     char* smem;
     int wave, lane;
     int blk;        // block being consumed (global count)
@@ -106,11 +117,8 @@ struct FlRing {
 // stream block `sb` into ring slot `g & 1`: wave w moves fragments 4w .. 4w+3
 __device__ __forceinline__ void fl_dma_block(const FlRing& r, int g, int sb) {
     char* dst = r.smem + W_OFF + (g & 1) * WBLK + r.wave * 4 * FRAG;
-    const char* src = r.ws + (size_t)sb * WBLK + r.wave * 4 * FRAG + r.lane * 16;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * FRAG),
-                                         (__attribute__((address_space(3))) void*)(dst + i * FRAG), 16, 0, 0);
+    for (int i = 0; i < 4; ++i) fl_lds_dma(r.ws, dst + i * FRAG, r.lane * 16, sb * WBLK + (r.wave * 4 + i) * FRAG);
     __builtin_amdgcn_sched_barrier(0);
 }
 template <typename Frag>
@@ -145,14 +153,12 @@ __device__ __forceinline__ void fl_fetch_next(FlRing& r, Frag (&nx)[4], int st) 
 // window tile <- global rows by LDS-DMA: instruction i covers plane i >> 2, rows 8 (i & 3) .. + 7; the chunk swizzle of
 // gf_lds_off sits on the SOURCE side (the LDS image of a DMA is lane-linear).  Rows >= Lw re-read row Lw - 1 (finite values;
 // they only feed token slots that are masked or never stored).
-__device__ __forceinline__ void fl_tile_dma(const char* win, int Lw, char* tile, int lane) {
+__device__ __forceinline__ void fl_tile_dma(const FlRsrc& wins, int win_byte_offset, int Lw, char* tile, int lane) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int row = 8 * (i & 3) + (lane >> 3), slot = lane & 7, c = slot ^ ((row >> 1) & 7);
         const int r = row < Lw ? row : Lw - 1;
-        const char* src = win + r * (FC * 2) + (i >> 2) * 128 + c * 16;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(tile + i * FRAG), 16, 0, 0);
+        fl_lds_dma(wins, tile + i * FRAG, r * (FC * 2) + (i >> 2) * 128 + c * 16, win_byte_offset);
     }
 }
 
@@ -165,7 +171,8 @@ __global__ __launch_bounds__(512, 2) void fine_layer(FlArgs a) {
     float* vec = reinterpret_cast<float*>(smem + VEC_OFF);
     char* tile = smem + X_OFF + wave * TILE;
     const int my_groups = (a.groups - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    FlRing ring{(const char*)a.wstream, smem, wave, lane, 0, 0, my_groups * NBLK};
+    FlRing ring{fl_rsrc(a.wstream, (unsigned)NBLK * WBLK), smem, wave, lane, 0, 0, my_groups * NBLK};
+    const FlRsrc xrs = fl_rsrc(a.x, (unsigned)a.Nw * a.Lw * (FC * 2)), srs = fl_rsrc(a.src, (unsigned)a.Nw * a.Lw * (FC * 2));
     fl_dma_block(ring, 0, 0);
     fl_dma_block(ring, 1, 1);
     vec[tid] = a.ln[tid];                                               // 512 threads = 4 x 128 floats
@@ -209,11 +216,10 @@ __global__ __launch_bounds__(512, 2) void fine_layer(FlArgs a) {
         const int win = g * FW + wave;
         K11_T(0);
         const int wclamp = win < a.Nw ? win : a.Nw - 1;                 // a tail group's spare waves recompute the last window (never stored)
-        const char* xwin = (const char*)a.x + (size_t)wclamp * a.Lw * (FC * 2);
-        const char* swin = (const char*)a.src + (size_t)wclamp * a.Lw * (FC * 2);
+        const int win_off = wclamp * a.Lw * (FC * 2);                    // byte offset of the window in x / src (32-bit: the entry point bounds the tensors)
         // the wave's own earlier reads of its tile (the previous group's output rows) are in registers by now
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        fl_tile_dma(swin, a.Lw, tile, ln);
+        fl_tile_dma(srs, win_off, a.Lw, tile, ln);
         if (first) {
             // blocks 0 and 1 are requested; block 0 must have landed everywhere before its first fragment is read
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(512, 2) void fine_layer(FlArgs a) {
         if (!same_src) {
             // the source window sits in registers now: the query window takes its place in the tile (the whole k / v phase to land)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            fl_tile_dma(xwin, a.Lw, tile, ln);
+            fl_tile_dma(xrs, win_off, a.Lw, tile, ln);
         }
 
         // ---------------- per channel tile nb (= two heads): k, v = src W^T (tokens in registers, channel on the lane), state
