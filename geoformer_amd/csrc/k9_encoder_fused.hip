@@ -709,7 +709,7 @@ __global__ __launch_bounds__(256, 1) void enc_kv_state(EncArgs a) {
     // (a tree that ended with ONE wave adding and storing 33 KB took 9 of the kernel's 35 thousand cycles)
     constexpr int KVN = 8 * 16 * 64, SLOT = KVN + 8 * 64;              // floats per wave: kv[hh][r][lane] | ksum[hh][lane]
     float* red = reinterpret_cast<float*>(smem);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the (clamped) requests behind the stream's end have landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the requests behind the stream's end (out of range: zeros) have landed
     __syncthreads();
 #pragma unroll
     for (int hh = 0; hh < 8; ++hh) {
