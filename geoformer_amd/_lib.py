@@ -80,6 +80,9 @@ SIGNATURES = {
                                            c_size_t, c_void_p]),
     'gf_window_cross_attention': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                           c_long, c_long, c_long, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'gf_window_cross_attention_tiled': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                c_int, c_long, c_long, c_long, c_void_p, c_int, c_void_p, c_void_p,
+                                                c_void_p]),
     'gf_fine_gather': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -190,33 +190,58 @@ __device__ __forceinline__ void store4<gf_bf16>(gf_bf16* p, v4f v) {
     *reinterpret_cast<v4b*>(p) = v4b{(gf_bf16)v.x, (gf_bf16)v.y, (gf_bf16)v.z, (gf_bf16)v.w};
 }
 
+template <typename T> struct Raw4;
+template <> struct Raw4<float> { using type = v4f; };
+template <> struct Raw4<_Float16> { using type = v4h; };
+template <> struct Raw4<gf_bf16> { using type = v4b; };
+template <typename R>
+__device__ __forceinline__ v4f widen4(R r) { return v4f{(float)r.x, (float)r.y, (float)r.z, (float)r.w}; }
+
 template <typename T, int WW>
-__global__ __launch_bounds__(256) void window_cross_attention(CaArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void window_cross_attention(CaArgs a) {
+    using Raw = typename Raw4<T>::type;
+    constexpr bool FAST = !std::is_same<T, float>::value;     // 16-bit storage: hardware exp / reciprocal, value rows requested up front
     const int n = blockIdx.y, lane = threadIdx.x & 63;
-    const int l = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // the wave index as a scalar: the query cell, its window table row and the 25 row offsets are wave-uniform (scalar loads,
+    // scalar-base row requests)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // workgroup ids go round-robin over the 8 XCDs: each XCD (= each L2) gets a contiguous band of query cells, so that it
+    // fetches that band's windows of the key / value maps and not the whole maps
+    int bx = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);
+    const int l = bx * 4 + wave;
     if (l >= a.L) return;
     T* out = (T*)a.out + ((size_t)n * a.L + l) * 256 + lane * 4;
     if (a.valid && !a.valid[n]) {          // layer skipped for this sample; caller keeps x
         store4<T>(out, v4f{0.f, 0.f, 0.f, 0.f});
         return;
     }
-    const v4f q = load4<T>((const T*)a.q + ((size_t)n * a.L + l) * a.ldq + lane * 4);
     const int32_t* win = a.win + ((size_t)n * a.L + l) * WW;
-    const T* kb = (const T*)a.kmap + (size_t)n * a.S * a.ldk + lane * 4;
-    const T* vb = (const T*)a.vmap + (size_t)n * a.S * a.ldv + lane * 4;
-    float logit[WW];
     int cell[WW];
 #pragma unroll
     for (int k = 0; k < WW; ++k) cell[k] = win[k];
-    // branch-free gathers: a masked key reads row 0 and is overridden afterwards, so the 25 row loads are issued
-    // back to back and the 16-lane DPP reductions of different keys interleave (the per-key branches had serialised
-    // load -> 4 dependent DPP adds -> next key, with two wait states in front of every DPP read)
+    const v4f q = load4<T>((const T*)a.q + ((size_t)n * a.L + l) * a.ldq + lane * 4);
+    const T* kb = (const T*)a.kmap + (size_t)n * a.S * a.ldk + lane * 4;
+    const T* vb = (const T*)a.vmap + (size_t)n * a.S * a.ldv + lane * 4;
+    // branch-free gathers: a masked key reads row 0 and is overridden afterwards.  All 25 key rows (and, in the 16-bit modes,
+    // all 25 value rows: they do not depend on the softmax) are requested back to back before the first reduction waits.
+    Raw kraw[WW], vraw[FAST ? WW : 1];
+#pragma unroll
+    for (int k = 0; k < WW; ++k)
+        kraw[k] = *reinterpret_cast<const Raw*>(kb + (unsigned)max(cell[k], 0) * (unsigned)a.ldk);    // 32-bit offsets: S * ld < 2^32
+    if constexpr (FAST) {
+#pragma unroll
+        for (int k = 0; k < WW; ++k)
+            vraw[k] = *reinterpret_cast<const Raw*>(vb + (unsigned)max(cell[k], 0) * (unsigned)a.ldv);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     float dot[WW];
 #pragma unroll
     for (int k = 0; k < WW; ++k) {
-        const v4f kv = load4<T>(kb + (unsigned)max(cell[k], 0) * (unsigned)a.ldk);     // 32-bit offsets: S * ld < 2^32
+        const v4f kv = widen4(kraw[k]);
         dot[k] = q.x * kv.x + q.y * kv.y + q.z * kv.z + q.w * kv.w;
     }
+    // the 16-lane DPP reductions of the 25 keys interleave (two wait states in front of every DPP read otherwise)
 #pragma unroll
     for (int k = 0; k < WW; ++k) dot[k] = dpp_add<0xB1>(dot[k]);     // quad_perm [1,0,3,2]
 #pragma unroll
@@ -225,6 +250,7 @@ __global__ __launch_bounds__(256) void window_cross_attention(CaArgs a) {
     for (int k = 0; k < WW; ++k) dot[k] = dpp_add<0x141>(dot[k]);    // row_half_mirror
 #pragma unroll
     for (int k = 0; k < WW; ++k) dot[k] = dpp_add<0x140>(dot[k]);    // row_mirror
+    float logit[WW];
     float mx = -INFINITY;
     bool any = false;
 #pragma unroll
@@ -233,7 +259,6 @@ __global__ __launch_bounds__(256) void window_cross_attention(CaArgs a) {
         logit[k] = (cell[k] >= 0 ? dot[k] : -1e8f) * a.softmax_temp;   // masked_fill BEFORE the temperature (geo_attention.py:83,92)
         mx = fmaxf(mx, logit[k]);
     }
-    constexpr bool FAST = !std::is_same<T, float>::value;     // fp16 mode: hardware exp / reciprocal
     float den = 0.f;
 #pragma unroll
     for (int k = 0; k < WW; ++k) {
@@ -247,11 +272,259 @@ __global__ __launch_bounds__(256) void window_cross_attention(CaArgs a) {
         for (int k = 0; k < WW; ++k) {
             // masked keys have weight exp(-1.25e7 - mx) == 0 whenever any key is valid: their (row 0) values add 0
             const float p = cell[k] >= 0 ? (FAST ? logit[k] * rden : logit[k] / den) : 0.f;
-            const v4f vv = load4<T>(vb + (unsigned)max(cell[k], 0) * (unsigned)a.ldv);
+            v4f vv;
+            if constexpr (FAST) vv = widen4(vraw[k]);
+            else vv = load4<T>(vb + (unsigned)max(cell[k], 0) * (unsigned)a.ldv);
             acc.x += p * vv.x; acc.y += p * vv.y; acc.z += p * vv.z; acc.w += p * vv.w;
         }
     }                                       // no valid key: the row is zeroed (geo_attention.py:98-100)
     store4<T>(out, acc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5, tiled form (16-bit storage, map widths known).  One workgroup = a tile of 8 x 4 query cells and ONE head.  The windows
+// of neighbouring queries overlap: the union of the tile's 32 x 25 window cells is a small rectangle of the key map (12 x 8
+// cells for a translation), so the head's 128-byte slices of the key and value rows of that rectangle are brought into LDS
+// once (LDS-DMA, 16 bytes per lane, no registers) and the 800 row reads of the tile are LDS reads.  A tile whose rectangle
+// exceeds CT_CAP cells (zoom between the images) reads its rows from global memory with the same arithmetic.
+// Lane = 8 channels of the head (8 lanes per query, 8 queries per wave): v_dot2 for q.k, a 3-step DPP sum over the 8
+// lanes, exp2 softmax, mixed-precision FMAs for p.v.
+// ------------------------------------------------------------------------------------------------
+constexpr int CT_QX = 8, CT_QY = 4, CT_Q = CT_QX * CT_QY, CT_WW = 25, CT_TS = 28;   // table stride: 28 ints = 7 x 16 bytes
+// 144 cells x 128 B x 2 maps + the table = 40.5 KB of LDS and <= 128 registers: four workgroups per CU (measured: 192 cells /
+// three workgroups 60 us, 144 / four 51 us per 8-image call).  A translation needs 12 x 8 = 96 cells, a zoom of 1.35 fills 144.
+constexpr int CT_CAP = 144, CT_WAVES = 4;
+struct CtArgs {
+    const void* q;          // [N][L][ldq]
+    const void* kmap;       // [N][S][ldk] projected keys of the OTHER image
+    const void* vmap;
+    long ldq, ldk, ldv;
+    const int32_t* win;     // [N][L][25]
+    const int32_t* valid;   // [N] or null
+    void* out;              // [N][L][256]
+    int N, L, S, hq, wq, wk, tiles_x;
+    float scale2;           // log2(e) / sqrt(D)
+};
+struct CtRsrc {
+    __amdgpu_buffer_rsrc_t r;
+};
+__device__ __forceinline__ CtRsrc ct_rsrc(const void* p, unsigned bytes) {
+    return CtRsrc{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000)};
+}
+__device__ __forceinline__ void ct_lds_dma(const CtRsrc& rs, char* dst, int voffset) {        // 64 lanes x 16 B -> 1 KiB at dst
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs.r, (__attribute__((address_space(3))) void*)dst, 16, voffset, 0, 0, 0);
+}
+typedef _Float16 ct_v2h __attribute__((ext_vector_type(2)));
+typedef gf_bf16 ct_v2b __attribute__((ext_vector_type(2)));
+typedef unsigned ct_u4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+__device__ __forceinline__ float ct_dot2(unsigned a, unsigned b, float c);       // c + a.lo * b.lo + a.hi * b.hi in fp32
+template <>
+__device__ __forceinline__ float ct_dot2<_Float16>(unsigned a, unsigned b, float c) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(ct_v2h, a), __builtin_bit_cast(ct_v2h, b), c, false);
+}
+template <>
+__device__ __forceinline__ float ct_dot2<gf_bf16>(unsigned a, unsigned b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(ct_v2b, a), __builtin_bit_cast(ct_v2b, b), c, false);
+}
+template <typename T>
+__device__ __forceinline__ float ct_dot8(ct_u4 a, ct_u4 b) {
+    const unsigned a0 = a.x, a1 = a.y, a2 = a.z, a3 = a.w, b0 = b.x, b1 = b.y, b2 = b.z, b3 = b.w;   // (a bit_cast of a swizzle reads element 0)
+    return ct_dot2<T>(a3, b3, ct_dot2<T>(a2, b2, ct_dot2<T>(a1, b1, ct_dot2<T>(a0, b0, 0.f))));
+}
+template <typename T>
+__device__ __forceinline__ void ct_axpy8(float (&acc)[8], float p, ct_u4 v);
+template <>
+__device__ __forceinline__ void ct_axpy8<_Float16>(float (&acc)[8], float p, ct_u4 v) {
+    // acc += p * (float)half: one v_fma_mix_f32 per channel (the compiler's choice, two conversions + a packed FMA per pair, is 1.5)
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc[2 * j]) : "v"(w[j]), "v"(p));
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2 * j + 1]) : "v"(w[j]), "v"(p));
+    }
+}
+template <>
+__device__ __forceinline__ void ct_axpy8<gf_bf16>(float (&acc)[8], float p, ct_u4 v) {
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        acc[2 * j] += p * __uint_as_float(w[j] << 16);
+        acc[2 * j + 1] += p * __uint_as_float(w[j] & 0xffff0000u);
+    }
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_min(int x) {
+    return min(x, __builtin_amdgcn_update_dpp(x, x, CTRL, 0xF, 0xF, false));
+}
+// minimum over the 64 lanes, wave-uniform result: four DPP steps inside each row of 16 lanes, then the four rows through SGPRs
+__device__ __forceinline__ int ct_wave_min(int v) {
+    v = dpp_min<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = dpp_min<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = dpp_min<0x141>(v);   // row_half_mirror
+    v = dpp_min<0x140>(v);   // row_mirror
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+template <typename T, bool TILED>
+__device__ __forceinline__ void ct_attend(const CtArgs& a, const char* sK, const char* sV, const int* tab, ct_u4 qraw,
+                                          const char* kbase, const char* vbase, int sub, T* out, bool qok) {
+    // tab: this query's 25 entries (LDS): -1 = masked; TILED: cell index inside the staged rectangle, else the cell of the map
+    int t[CT_TS];
+#pragma unroll
+    for (int i = 0; i < CT_TS / 4; ++i) {
+        const int4 v = *reinterpret_cast<const int4*>(tab + 4 * i);
+        t[4 * i] = v.x; t[4 * i + 1] = v.y; t[4 * i + 2] = v.z; t[4 * i + 3] = v.w;
+    }
+    float dot[CT_WW];
+#pragma unroll
+    for (int k = 0; k < CT_WW; ++k) {
+        const unsigned c = (unsigned)max(t[k], 0);            // a masked key reads row 0 and is overridden afterwards
+        ct_u4 kr;
+        if (TILED) kr = *reinterpret_cast<const ct_u4*>(sK + (c * 128u + (unsigned)sub * 16u));
+        else kr = *reinterpret_cast<const ct_u4*>(kbase + (size_t)c * (size_t)(a.ldk * sizeof(T)));
+        dot[k] = ct_dot8<T>(qraw, kr);
+    }
+    // sum over the 8 lanes of the query; the reductions of the 25 keys interleave
+#pragma unroll
+    for (int k = 0; k < CT_WW; ++k) dot[k] = dpp_add<0xB1>(dot[k]);     // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int k = 0; k < CT_WW; ++k) dot[k] = dpp_add<0x4E>(dot[k]);     // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int k = 0; k < CT_WW; ++k) dot[k] = dpp_add<0x141>(dot[k]);    // row_half_mirror
+    // softmax of temperature * logit with masked_fill(-1e8) BEFORE the temperature (geo_attention.py:83,92), in the log2
+    // domain: exp2(scale2 * (x - max x)); the maximum is taken on the unscaled logits (scale2 > 0)
+    float mx = -INFINITY;
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < CT_WW; ++k) {
+        any = any || t[k] >= 0;
+        dot[k] = t[k] >= 0 ? dot[k] : -1e8f;
+        mx = fmaxf(mx, dot[k]);
+    }
+    const float nmx = -mx * a.scale2;
+    float den = 0.f;
+#pragma unroll
+    for (int k = 0; k < CT_WW; ++k) {
+        dot[k] = __builtin_amdgcn_exp2f(fmaf(dot[k], a.scale2, nmx));    // a masked key: exp2(-1.8e7 - ...) == 0 whenever any key is valid
+        den += dot[k];
+    }
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < CT_WW; ++k) {
+        const unsigned c = (unsigned)max(t[k], 0);
+        ct_u4 vr;
+        if (TILED) vr = *reinterpret_cast<const ct_u4*>(sV + (c * 128u + (unsigned)sub * 16u));
+        else vr = *reinterpret_cast<const ct_u4*>(vbase + (size_t)c * (size_t)(a.ldv * sizeof(T)));
+        ct_axpy8<T>(acc, dot[k], vr);
+    }
+    const float rden = any ? __builtin_amdgcn_rcpf(den) : 0.f;          // no valid key: the row is zeroed (geo_attention.py:98-100)
+    if (qok) {
+        typedef T V8 __attribute__((ext_vector_type(8)));
+        V8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (T)(acc[j] * rden);
+        *reinterpret_cast<V8*>(out) = o;
+    }
+    // the two forms end differently on purpose: the compiler otherwise merges them into one body with a branch around every row read
+    if (!TILED) asm volatile("; rows read from global memory" ::: "memory");
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, CT_WAVES) void window_cross_tiled(CtArgs a) {
+    __shared__ __attribute__((aligned(16))) char sK[CT_CAP * 128];
+    __shared__ __attribute__((aligned(16))) char sV[CT_CAP * 128];
+    __shared__ __attribute__((aligned(16))) int s_tab[CT_Q * CT_TS];
+    __shared__ __attribute__((aligned(16))) int s_box[16];    // per wave: ymin, xmin, -ymax, -xmax over its valid window cells
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = blockIdx.y;
+    // workgroup ids go round-robin over the 8 XCDs: each XCD (= each L2) gets a contiguous band of tiles
+    int bx = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);
+    const int head = bx & 3, tile = bx >> 2;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int qi = tid >> 3, sub = tid & 7;                   // 32 queries x 8 lanes
+    const int qx = tx * CT_QX + (qi & 7), qy = ty * CT_QY + (qi >> 3);
+    const bool qok = qx < a.wq && qy < a.hq;
+    const size_t row = (size_t)n * a.L + (size_t)(qy * a.wq + qx);
+    T* out = (T*)a.out + row * 256 + head * 64 + sub * 8;
+    if (a.valid && !a.valid[n]) {                             // layer skipped for this sample; caller keeps x
+        if (qok) *reinterpret_cast<ct_u4*>(out) = ct_u4{0u, 0u, 0u, 0u};
+        return;
+    }
+    ct_u4 qraw{0u, 0u, 0u, 0u};
+    if (qok) qraw = *reinterpret_cast<const ct_u4*>((const T*)a.q + row * a.ldq + head * 64 + sub * 8);
+    // the tile's window table: entry e = query * 25 + key, four per thread
+    int cell[4], cy[4], cx[4];
+    int ymin = 0x7fffffff, xmin = 0x7fffffff, nymax = 0x7fffffff, nxmax = 0x7fffffff;
+    const float rwk = 1.0f / (float)a.wk;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = tid + 256 * j, eq = e / CT_WW, ek = e - eq * CT_WW;
+        const int ex = tx * CT_QX + (eq & 7), ey = ty * CT_QY + (eq >> 3);
+        cell[j] = -1;
+        if (e < CT_Q * CT_WW && ex < a.wq && ey < a.hq)
+            cell[j] = a.win[((size_t)n * a.L + (size_t)(ey * a.wq + ex)) * CT_WW + ek];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        cy[j] = cx[j] = 0;
+        if (cell[j] >= 0) {
+            // cell / wk: the float estimate is within one of the quotient for every S < 2^31 / ld; one correction step
+            int y = (int)((float)cell[j] * rwk), x = cell[j] - y * a.wk;
+            if (x < 0) { --y; x += a.wk; }
+            if (x >= a.wk) { ++y; x -= a.wk; }
+            cy[j] = y; cx[j] = x;
+            ymin = min(ymin, y); nymax = min(nymax, -y);
+            xmin = min(xmin, x); nxmax = min(nxmax, -x);
+        }
+    }
+    ymin = ct_wave_min(ymin); xmin = ct_wave_min(xmin); nymax = ct_wave_min(nymax); nxmax = ct_wave_min(nxmax);
+    if (lane == 0) *reinterpret_cast<int4*>(&s_box[4 * wave]) = int4{ymin, xmin, nymax, nxmax};
+    __syncthreads();
+    int4 box = *reinterpret_cast<const int4*>(&s_box[0]);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        const int4 o = *reinterpret_cast<const int4*>(&s_box[4 * w]);
+        box.x = min(box.x, o.x); box.y = min(box.y, o.y); box.z = min(box.z, o.z); box.w = min(box.w, o.w);
+    }
+    const int y0 = box.x, x0 = box.y;
+    if (y0 == 0x7fffffff) {                                   // no valid key anywhere in the tile (geo_attention.py:98-100)
+        if (qok) *reinterpret_cast<ct_u4*>(out) = ct_u4{0u, 0u, 0u, 0u};
+        return;
+    }
+    const int bh = -box.z - y0 + 1, bw = -box.w - x0 + 1;
+    const bool tiled = bh <= CT_CAP && bw <= CT_CAP && bh * bw <= CT_CAP;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = tid + 256 * j, eq = e / CT_WW, ek = e - eq * CT_WW;
+        if (e < CT_Q * CT_WW) s_tab[eq * CT_TS + ek] = cell[j] < 0 ? -1 : (tiled ? (cy[j] - y0) * bw + (cx[j] - x0) : cell[j]);
+    }
+    const char* kimg = (const char*)a.kmap + (size_t)n * a.S * a.ldk * sizeof(T);
+    const char* vimg = (const char*)a.vmap + (size_t)n * a.S * a.ldv * sizeof(T);
+    if (tiled) {
+        // 8 cells (x 128 bytes of this head) per request: lane -> (cell = 8 g + lane / 8, 16-byte piece = lane % 8)
+        const CtRsrc rk = ct_rsrc(kimg, (unsigned)((size_t)a.S * a.ldk * sizeof(T)));
+        const CtRsrc rv = ct_rsrc(vimg, (unsigned)((size_t)a.S * a.ldv * sizeof(T)));
+        const int ncell = bh * bw, groups = (ncell + 7) >> 3;
+        const float rbw = 1.0f / (float)bw;
+        for (int g = wave; g < groups; g += 4) {
+            const int c = min(g * 8 + (lane >> 3), ncell - 1);
+            const int by = (int)(((float)c + 0.5f) * rbw);    // exact for c, bw <= CT_CAP
+            const int cellg = (y0 + by) * a.wk + x0 + (c - by * bw);
+            const unsigned piece = (unsigned)head * 128u + (unsigned)(lane & 7) * 16u;
+            ct_lds_dma(rk, sK + g * 1024, (int)((unsigned)cellg * (unsigned)(a.ldk * sizeof(T)) + piece));
+            ct_lds_dma(rv, sV + g * 1024, (int)((unsigned)cellg * (unsigned)(a.ldv * sizeof(T)) + piece));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    const char* kb = kimg + head * 128 + sub * 16;
+    const char* vb = vimg + head * 128 + sub * 16;
+    if (tiled) ct_attend<T, true>(a, sK, sV, s_tab + qi * CT_TS, qraw, kb, vb, sub, out, qok);
+    else ct_attend<T, false>(a, sK, sV, s_tab + qi * CT_TS, qraw, kb, vb, sub, out, qok);
 }
 
 }   // namespace
@@ -298,6 +571,30 @@ extern "C" int gf_window_cross_attention(const void* q, const void* kmap, const 
     if (dtype == GF_F32) window_cross_attention<float, 25><<<grid, 256, 0, st>>>(a);
     else if (dtype == GF_F16) window_cross_attention<_Float16, 25><<<grid, 256, 0, st>>>(a);
     else window_cross_attention<gf_bf16, 25><<<grid, 256, 0, st>>>(a);
+    gf_prof_end("k5_window_attention", pt, st);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}
+
+extern "C" int gf_window_cross_attention_tiled(const void* q, const void* kmap, const void* vmap, int dtype, int N, int hq,
+                                               int wq, int hk, int wk, int H, int D, long ldq, long ldk, long ldv,
+                                               const int32_t* win, int WW, const int32_t* valid, void* out, void* stream) {
+    GF_CHECK_ARG(q && kmap && vmap && win && out, "null pointer");
+    GF_CHECK_ARG(N > 0 && hq > 0 && wq > 0 && hk > 0 && wk > 0, "empty problem");
+    GF_CHECK_ARG(H == 4 && D == 64 && WW == 25, "built for nhead=4, head dim 64, 5x5 windows (geo_config.py:12,16)");
+    GF_CHECK_ARG(dtype >= GF_F32 && dtype <= GF_BF16, "bad dtype");
+    const int L = hq * wq, S = hk * wk;
+    if (dtype == GF_F32)                    // exact-fp32 mode: the one-wave-per-query form
+        return gf_window_cross_attention(q, kmap, vmap, dtype, N, L, S, H, D, ldq, ldk, ldv, win, WW, valid, out, stream);
+    GF_CHECK_ARG((double)S * (double)(ldk > ldv ? ldk : ldv) * 2.0 < 4294967296.0, "key map too large for 32-bit byte offsets");
+    GF_CHECK_ARG(hk < 32768 && wk < 32768 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0, "rows must be 16-byte aligned");
+    const int tiles_x = (wq + CT_QX - 1) / CT_QX, tiles_y = (hq + CT_QY - 1) / CT_QY;
+    CtArgs a{q, kmap, vmap, ldq, ldk, ldv, win, valid, out, N, L, S, hq, wq, wk, tiles_x, 1.4426950408889634f / sqrtf((float)D)};
+    const dim3 grid(tiles_x * tiles_y * 4, N);
+    hipStream_t st = (hipStream_t)stream;
+    void* pt = gf_prof_begin("k5_window_attention", st, (double)N * (2.0 * L + 2.0 * S) * H * D * 2);
+    if (dtype == GF_F16) window_cross_tiled<_Float16><<<grid, 256, 0, st>>>(a);
+    else window_cross_tiled<gf_bf16><<<grid, 256, 0, st>>>(a);
     gf_prof_end("k5_window_attention", pt, st);
     GF_CHECK_LAUNCH();
     return GF_OK;

@@ -315,8 +315,10 @@ class GeoTransformer(nn.Module):
                 # feat0_cross and feat1_cross before either update, :126-129); project, then gather.
                 k0, v0 = layer.project_kv(feat0)
                 k1, v1 = layer.project_kv(feat1)
-                m0 = ops.window_cross_attention(layer.project_q(feat0), k1, v1, geo['win1'], geo['valid'], self.nhead)
-                m1 = ops.window_cross_attention(layer.project_q(feat1), k0, v0, geo['win0'], geo['valid'], self.nhead)
+                m0 = ops.window_cross_attention(layer.project_q(feat0), k1, v1, geo['win1'], geo['valid'], self.nhead,
+                                                geo.get('hw0'), geo.get('hw1'))
+                m1 = ops.window_cross_attention(layer.project_q(feat1), k0, v0, geo['win0'], geo['valid'], self.nhead,
+                                                geo.get('hw1'), geo.get('hw0'))
                 if same:
                     nxt = torch.empty_like(both)
                     layer.finish(feat0, m0, geo['valid'], L, out=nxt[:n])
@@ -389,6 +391,7 @@ class GeoModule(nn.Module):
         geo['win1'] = ops.window_geometry(rs['M_f32'], rs['valid'], hw0c, (H1, W1), hw1c[1], scale, self.window_size, s1)
         geo['win0'] = ops.window_geometry(rs['Minv_f32'], rs['valid'], hw1c, (H0, W0), hw0c[1], scale, self.window_size, s0)
         geo['valid'] = rs['valid']
+        geo['hw0'], geo['hw1'] = tuple(hw0c), tuple(hw1c)
         geo['nidx_t'] = geo['nidx'].t().contiguous()          # [2, N]: per-side key counts, also the 'skip' predicates
         if L == S:
             geo['idx_both'] = torch.cat([geo['idx0'], geo['idx1']], 0)

@@ -307,8 +307,10 @@ def self_attention_gathered(q, kmap, vmap, idx, nkeys, nhead=4):
     return out
 
 
-def window_cross_attention(q, kmap, vmap, win, valid=None, nhead=4):
-    """K5.  q [N,L,256]; kmap, vmap [N,S,256]; win int32 [N,L,25] -> [N,L,256]."""
+def window_cross_attention(q, kmap, vmap, win, valid=None, nhead=4, hw_q=None, hw_k=None):
+    """K5.  q [N,L,256]; kmap, vmap [N,S,256]; win int32 [N,L,25] -> [N,L,256].  With the map shapes hw_q = (hq, wq),
+    hw_k = (hk, wk) (L = hq*wq, S = hk*wk) the 16-bit modes run the tiled form (key / value rows of a query tile's windows
+    staged in LDS once)."""
     _need_cuda(q, kmap, vmap, win)
     N, L, C = q.shape
     S = kmap.shape[1]
@@ -318,6 +320,13 @@ def window_cross_attention(q, kmap, vmap, win, valid=None, nhead=4):
     if q.stride(0) != ldq * L or kmap.stride(0) != ldk * S or vmap.stride(0) != ldv * S:
         raise ValueError('window_cross_attention needs batch stride == rows * row stride')
     out = torch.empty(N, L, C, dtype=q.dtype, device=q.device)
+    if hw_q is not None and hw_k is not None and ldq % 8 == 0 and ldk % 8 == 0 and ldv % 8 == 0:
+        if hw_q[0] * hw_q[1] != L or hw_k[0] * hw_k[1] != S:
+            raise ValueError('window_cross_attention: map shapes do not match the token counts')
+        check(_lib.lib().gf_window_cross_attention_tiled(_p(q), _p(kmap), _p(vmap), _dt(q), N, hw_q[0], hw_q[1], hw_k[0],
+                                                         hw_k[1], nhead, C // nhead, ldq, ldk, ldv, _p(win), win.shape[-1],
+                                                         _p(valid), _p(out), _stream()), 'gf_window_cross_attention_tiled')
+        return out
     check(_lib.lib().gf_window_cross_attention(_p(q), _p(kmap), _p(vmap), _dt(q), N, L, S, nhead, C // nhead, ldq, ldk,
                                                ldv, _p(win), win.shape[-1], _p(valid), _p(out), _stream()),
           'gf_window_cross_attention')

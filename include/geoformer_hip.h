@@ -320,6 +320,14 @@ int gf_self_attention_gathered(const void* q, const void* kmap, const void* vmap
 int gf_window_cross_attention(const void* q, const void* kmap, const void* vmap, int dtype, int N, int L, int S,
                               int H, int D, long ldq, long ldk, long ldv, const int32_t* win, int WW,
                               const int32_t* valid, void* out, void* stream);
+/* The same operation when the query map is hq x wq cells and the key map hk x wk cells (L = hq*wq, S = hk*wk, cells row-major as
+ * gf_window_geometry numbers them).  16-bit storage: one workgroup per tile of 8 x 4 query cells and head; the windows of a
+ * tile overlap, so the key / value rows of their bounding rectangle are staged in LDS once (a tile whose rectangle exceeds 144
+ * cells reads its rows from global memory).  fp32 storage: forwards to gf_window_cross_attention.  Rows must be 16-byte
+ * aligned (ld % 8 == 0). */
+int gf_window_cross_attention_tiled(const void* q, const void* kmap, const void* vmap, int dtype, int N, int hq, int wq,
+                                    int hk, int wk, int H, int D, long ldq, long ldk, long ldv, const int32_t* win,
+                                    int WW, const int32_t* valid, void* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K7  fine window extraction

@@ -277,6 +277,58 @@ def test_window_cross_attention(dtype):
     assert float(skipped[0].abs().max()) == 0.0 and torch.equal(skipped[1], out[1])
 
 
+def _warp_windows(N, hq, wq, hk, wk, zoom, g):
+    """Window tables as a smooth warp produces them: cell (y, x) of the query map looks at the 5x5 cells around
+    (zoom*y + ty, zoom*x + tx) of the key map; cells outside the key map are masked."""
+    ys, xs = torch.meshgrid(torch.arange(hq), torch.arange(wq), indexing='ij')
+    dy, dx = torch.meshgrid(torch.arange(-2, 3), torch.arange(-2, 3), indexing='ij')
+    win = torch.empty(N, hq * wq, 25, dtype=torch.int32)
+    for b in range(N):
+        ty, tx = [int(v) for v in torch.randint(-3, 4, (2,), generator=g)]
+        cy = (ys.reshape(-1, 1).float() * zoom[b]).round().long() + ty + dy.reshape(1, -1)
+        cx = (xs.reshape(-1, 1).float() * zoom[b]).round().long() + tx + dx.reshape(1, -1)
+        ok = (cy >= 0) & (cy < hk) & (cx >= 0) & (cx < wk)
+        win[b] = torch.where(ok, cy * wk + cx, torch.full_like(cy, -1)).int()
+    return win
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(16, 24, 16, 24), (13, 19, 17, 21), (60, 80, 60, 76)])
+def test_window_cross_attention_tiled(dtype, shape):
+    """K5 in its tiled form (rows of a query tile's windows staged in LDS) against the oracle and against the one-wave-per-query
+    form, on window tables a warp produces: translation (every tile staged), zoom 2.6 (rectangles beyond the staging
+    capacity: rows read from global memory), a mix of both within one call, partial tiles at the map border, masked
+    border cells, a sample without a homography."""
+    from geoformer_amd import ops
+    hq, wq, hk, wk = shape
+    g = torch.Generator().manual_seed(11 + hq)
+    N, C, H = 4, 256, 4
+    L, S = hq * wq, hk * wk
+    q = torch.randn(N, L, C, generator=g).to(dtype)
+    kv = torch.randn(N, S, 2 * C, generator=g).to(dtype)
+    win = _warp_windows(N, hq, wq, hk, wk, [1.0, 2.6, 0.5, 1.3], g)
+    win[0][torch.rand(L, 25, generator=g) < 0.1] = -1                      # holes
+    win[0, 5] = -1                                                          # a query whose 25 keys are all masked
+    win[2, : 3 * wq] = -1                                                   # whole tiles without a valid key
+    valid = torch.tensor([1, 1, 1, 1], dtype=torch.int32)
+    args = (q.to(DEV), kv.to(DEV)[..., :C], kv.to(DEV)[..., C:], win.to(DEV))
+    out = ops.window_cross_attention(*args, valid.to(DEV), H, (hq, wq), (hk, wk))
+    plain = ops.window_cross_attention(*args, valid.to(DEV), H)
+    for b in range(N):
+        cell = win[b].clamp(min=0).long()
+        ks, vs = kv[b, :, :C].float()[cell], kv[b, :, C:].float()[cell]          # [L, 25, C]
+        ref = O.full_attention(q[b].float().view(L, 1, H, -1), ks.view(L, 25, H, -1), vs.view(L, 25, H, -1), None,
+                               win[b] >= 0).reshape(L, C)
+        close(out[b], ref, 4e-3, 4e-3)
+        close(out[b], plain[b].float().cpu(), 4e-3, 4e-3)
+    assert float(out[0, 5].abs().max()) == 0.0 and float(out[2, : 3 * wq].abs().max()) == 0.0
+    again = ops.window_cross_attention(*args, valid.to(DEV), H, (hq, wq), (hk, wk))
+    assert torch.equal(again, out)
+    skipped = ops.window_cross_attention(*args, torch.tensor([1, 0, 1, 0], dtype=torch.int32, device=DEV), H, (hq, wq), (hk, wk))
+    assert float(skipped[1].abs().max()) == 0.0 and float(skipped[3].abs().max()) == 0.0
+    assert torch.equal(skipped[0], out[0]) and torch.equal(skipped[2], out[2])
+
+
 # ------------------------------------------------------------------ K7
 @pytest.mark.parametrize('layout', ['nchw', 'nhwc'])
 def test_fine_gather_vs_oracle(layout):

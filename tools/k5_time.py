@@ -3,7 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from geoformer_amd import ops
-N, H, W = 16, 80, 80
+N, H, W = (8 if '--n8' in sys.argv else 16), 80, 80
 L = H * W
 q = torch.randn(N, L, 256, device='cuda').half()
 kv = torch.randn(N, L, 512, device='cuda').half()
@@ -13,7 +13,8 @@ wy = (ys.reshape(-1, 1) + 1 + dy.reshape(1, -1)).clamp(0, H - 1)          # a on
 wx = (xs.reshape(-1, 1) + 1 + dx.reshape(1, -1)).clamp(0, W - 1)
 win = (wy * W + wx).int()[None].repeat(N, 1, 1).contiguous()
 valid = torch.ones(N, dtype=torch.int32, device='cuda')
-f = lambda: ops.window_cross_attention(q, kv[..., :256], kv[..., 256:], win, valid, 4)
+hw = (H, W) if '--plain' not in sys.argv else None
+f = lambda: ops.window_cross_attention(q, kv[..., :256], kv[..., 256:], win, valid, 4, hw, hw)
 for _ in range(3):
     f()
 torch.cuda.synchronize()
