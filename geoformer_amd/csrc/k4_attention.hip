@@ -88,6 +88,18 @@ __device__ __forceinline__ int k_off(int row, int chunk) { return row * (CC * (i
 // fp16 V^T: [CC channels][32 keys] rows of 64 B, chunk c (0..3) stored at c ^ ((row >> 2) & 3)
 __device__ __forceinline__ int vt_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
+// LDS-DMA (16-bit modes): 64 lanes x 16 B of a staged tile straight from the compact K / V^T buffers into LDS, no registers.
+// MUBUF form: the waits the compiler inserts stay counted (the FLAT form makes every LDS wait lgkmcnt(0)).
+struct AtRsrc {
+    __amdgpu_buffer_rsrc_t r;
+};
+__device__ __forceinline__ AtRsrc at_rsrc(const void* p, unsigned bytes) {
+    return AtRsrc{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000)};
+}
+__device__ __forceinline__ void at_lds_dma(const AtRsrc& rs, char* dst, int voffset, int soffset) {        // -> 1 KiB at dst
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs.r, (__attribute__((address_space(3))) void*)dst, 16, voffset, soffset, 0, 0);
+}
+
 template <typename T, int QB>
 __global__ __launch_bounds__(256, QB <= 2 ? 2 : 1) void attn_self(AtArgs a) {
     using M = Mma32<T>;
@@ -98,9 +110,12 @@ __global__ __launch_bounds__(256, QB <= 2 ? 2 : 1) void attn_self(AtArgs a) {
     constexpr int EPC = 16 / sizeof(T);      // elements per 16-B chunk
     constexpr int KBYTES = KT * CC * sizeof(T);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ks = smem;
-    char* vs = smem + KBYTES;
-    const int n = blockIdx.y, q0 = blockIdx.x * (32 * QB), tid = threadIdx.x;
+    // workgroup ids go round-robin over the 8 XCDs: give each XCD whole images (their compact K / V^T, 1.2 MB at 1200 keys,
+    // then stay in that XCD's L2 for all the query blocks), not a slice of every image
+    const int gx = gridDim.x, total = gx * gridDim.y;
+    int id = blockIdx.y * gx + blockIdx.x;
+    if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+    const int n = id / gx, q0 = (id - n * gx) * (32 * QB), tid = threadIdx.x;
     const int head = tid >> 6, lane = tid & 63, h = lane >> 5, lr = lane & 31;
     const int K = a.nkeys[(size_t)n * a.nkeys_stride];
     // QB blocks of 32 queries per wave: a staged K / V tile (32 keys x 256 channels, 32 KiB) serves 32 QB queries of every head
@@ -126,48 +141,10 @@ __global__ __launch_bounds__(256, QB <= 2 ? 2 : 1) void attn_self(AtArgs a) {
     }
     const T* kc = (const T*)a.kc + (size_t)n * a.Kpad * CC;
     const int ntiles = (K + KT - 1) / KT;
-    // the K / V tile of the NEXT iteration waits in registers (issued before this tile's products, written to LDS after the
-    // barrier that ends them): the synchronous load -> write -> barrier of round 2 exposed the L2 latency once per tile
-    constexpr int CPR = CC / EPC;                         // chunks per row
-    constexpr int PASSES = KT * CPR / 256;
-    v4u rk[PASSES], rv[F32 ? PASSES : 4];
-    auto fetch = [&](int tile) {
-#pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
-            const int e = p * 256 + tid, row = e / CPR, c = e % CPR;
-            rk[p] = *reinterpret_cast<const v4u*>(kc + ((size_t)tile * KT + row) * CC + c * EPC);
-        }
-        if constexpr (F32) {
-            const T* vc = (const T*)a.vc + ((size_t)n * a.Kpad + (size_t)tile * KT) * CC;
-#pragma unroll
-            for (int p = 0; p < PASSES; ++p) rv[p] = *reinterpret_cast<const v4u*>(vc + (size_t)(p * 256 + tid) * EPC);
-        } else {
-            const T* vt = (const T*)a.vc + ((size_t)n * CC + tid) * a.Kpad + (size_t)tile * KT;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) rv[c] = *reinterpret_cast<const v4u*>(vt + c * 8);
-        }
-    };
-    if (ntiles > 0) fetch(0);
     // logits in log2 units: exp(x - m) = exp2(x' - m') with x' = s * (temp * log2 e): one multiply per element instead of two
     constexpr bool FAST = !std::is_same<T, float>::value;              // 16-bit modes: hardware exponential
     const float scale2 = FAST ? a.softmax_temp * 1.44269504088896341f : a.softmax_temp;
-    for (int tile = 0; tile < ntiles; ++tile) {
-        __syncthreads();
-        // ---- stage the tile (all heads) from the registers
-#pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
-            const int e = p * 256 + tid, row = e / CPR, c = e % CPR;
-            *reinterpret_cast<v4u*>(ks + k_off<T>(row, c)) = rk[p];
-        }
-        if constexpr (F32) {
-#pragma unroll
-            for (int p = 0; p < PASSES; ++p) *reinterpret_cast<v4u*>(vs + (size_t)(p * 256 + tid) * 16) = rv[p];
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) *reinterpret_cast<v4u*>(vs + vt_off(tid, c)) = rv[c];
-        }
-        __syncthreads();
-        if (tile + 1 < ntiles) fetch(tile + 1);
+    auto compute = [&](int tile, const char* ks, const char* vs) {
         const bool ragged = (tile + 1) * KT > K;          // only the last tile can hold key slots beyond K
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
@@ -183,38 +160,75 @@ __global__ __launch_bounds__(256, QB <= 2 ? 2 : 1) void attn_self(AtArgs a) {
             }
             float x[16];
             float tmax = -INFINITY;
-            if (ragged) {
-    #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = tile * KT + gf_acc_row(r, h);
-                    x[r] = key < K ? s[r] * scale2 : -INFINITY;
-                    tmax = fmaxf(tmax, x[r]);
-                }
-            } else {
-    #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    x[r] = s[r] * scale2;
-                    tmax = fmaxf(tmax, x[r]);
-                }
-            }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float mnew = fmaxf(m[qb], tmax);          // finite: every tile holds at least one real key
             float psum = 0.f;
+            if constexpr (FAST) {
+                // 16-bit modes: the running maximum is kept on the UNSCALED logits (scale2 > 0) and the scale rides in the
+                // exponent's FMA: exp2(s * scale2 - max * scale2); one max3 per two logits, one FMA, one exp2, one add per
+                // logit, all single-issue (the separate multiply was packed into v_pk_mul_f32 pairs: dear beside MFMAs)
+                if (ragged) {
     #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                x[r] = FAST ? __builtin_amdgcn_exp2f(x[r] - mnew) : expf(x[r] - mnew);
-                psum += x[r];
-            }
-            if (__any(mnew != m[qb])) {                     // a running maximum moved somewhere in the wave: rescale (else alpha = 1)
-                const float alpha = FAST ? __builtin_amdgcn_exp2f(m[qb] - mnew) : expf(m[qb] - mnew);
-                l[qb] *= alpha;
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = tile * KT + gf_acc_row(r, h);
+                        x[r] = key < K ? s[r] : -INFINITY;
+                        tmax = fmaxf(tmax, x[r]);
+                    }
+                } else {
     #pragma unroll
-                for (int b = 0; b < 2; ++b)
+                    for (int r = 0; r < 16; ++r) {
+                        x[r] = s[r];
+                        tmax = fmaxf(tmax, x[r]);
+                    }
+                }
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float mnew = fmaxf(m[qb], tmax);          // finite: every tile holds at least one real key
+                const float nms = -mnew * scale2;
     #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[qb][b][r] *= alpha;
+                for (int r = 0; r < 16; ++r) {
+                    x[r] = __builtin_amdgcn_exp2f(fmaf(x[r], scale2, nms));
+                    psum += x[r];
+                }
+                if (__any(mnew != m[qb])) {                     // a running maximum moved somewhere in the wave: rescale (else alpha = 1)
+                    const float alpha = __builtin_amdgcn_exp2f((m[qb] - mnew) * scale2);
+                    l[qb] *= alpha;
+    #pragma unroll
+                    for (int b = 0; b < 2; ++b)
+    #pragma unroll
+                        for (int r = 0; r < 16; ++r) o[qb][b][r] *= alpha;
+                }
+                m[qb] = mnew;
+            } else {
+                if (ragged) {
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = tile * KT + gf_acc_row(r, h);
+                        x[r] = key < K ? s[r] * scale2 : -INFINITY;
+                        tmax = fmaxf(tmax, x[r]);
+                    }
+                } else {
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        x[r] = s[r] * scale2;
+                        tmax = fmaxf(tmax, x[r]);
+                    }
+                }
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float mnew = fmaxf(m[qb], tmax);          // finite: every tile holds at least one real key
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    x[r] = expf(x[r] - mnew);
+                    psum += x[r];
+                }
+                if (__any(mnew != m[qb])) {                     // a running maximum moved somewhere in the wave: rescale (else alpha = 1)
+                    const float alpha = expf(m[qb] - mnew);
+                    l[qb] *= alpha;
+    #pragma unroll
+                    for (int b = 0; b < 2; ++b)
+    #pragma unroll
+                        for (int r = 0; r < 16; ++r) o[qb][b][r] *= alpha;
+                }
+                m[qb] = mnew;
             }
             l[qb] += psum;
-            m[qb] = mnew;
             // ---- O^T += V^T . P^T with P^T taken from the registers as the B operand
             if constexpr (F32) {
     #pragma unroll
@@ -236,6 +250,72 @@ __global__ __launch_bounds__(256, QB <= 2 ? 2 : 1) void attn_self(AtArgs a) {
                 }
             }
             }
+    };
+    if constexpr (F32) {
+        // fp32 (parity mode): the K / V tile of the NEXT iteration waits in registers (issued before this tile's products,
+        // written to LDS after the barrier that ends them)
+        constexpr int CPR = CC / EPC;                         // chunks per row
+        constexpr int PASSES = KT * CPR / 256;
+        v4u rk[PASSES], rv[PASSES];
+        auto fetch = [&](int tile) {
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const int e = p * 256 + tid, row = e / CPR, c = e % CPR;
+                rk[p] = *reinterpret_cast<const v4u*>(kc + ((size_t)tile * KT + row) * CC + c * EPC);
+            }
+            const T* vc = (const T*)a.vc + ((size_t)n * a.Kpad + (size_t)tile * KT) * CC;
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) rv[p] = *reinterpret_cast<const v4u*>(vc + (size_t)(p * 256 + tid) * EPC);
+        };
+        if (ntiles > 0) fetch(0);
+        for (int tile = 0; tile < ntiles; ++tile) {
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const int e = p * 256 + tid, row = e / CPR, c = e % CPR;
+                *reinterpret_cast<v4u*>(smem + k_off<T>(row, c)) = rk[p];
+            }
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) *reinterpret_cast<v4u*>(smem + KBYTES + (size_t)(p * 256 + tid) * 16) = rv[p];
+            __syncthreads();
+            if (tile + 1 < ntiles) fetch(tile + 1);
+            compute(tile, smem, smem + KBYTES);
+        }
+    } else {
+        // 16-bit modes: two LDS images of the (K, V^T) tile, filled by LDS-DMA.  Iteration t: my requests of tile t have
+        // landed (vmcnt(0)) -> barrier (everyone's have, and everyone is done reading tile t-1) -> request tile t+1 into the
+        // image tile t-1 was read from -> products of tile t.  One barrier per tile, no staging registers, no LDS writes.
+        // (round 3, with the tile passing through registers and two barriers: 335 us per 16-image call at 1195 keys, 218 us
+        // with the staging compiled out)
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const AtRsrc rk = at_rsrc(kc, (unsigned)((size_t)a.Kpad * CC * sizeof(T)));
+        const AtRsrc rv = at_rsrc((const T*)a.vc + (size_t)n * CC * a.Kpad, (unsigned)((size_t)CC * a.Kpad * sizeof(T)));
+        // K image: 1 KiB group g = key rows 2g, 2g+1; slot s of row r holds chunk s ^ (r & 15) (k_off)
+        // V^T image: group g = channels 16g..16g+15, 4 slots of 16 B; slot s of channel c holds chunk s ^ ((c >> 2) & 3) (vt_off)
+        int kvo[4], vvo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int g = wv * 4 + i;
+            const int krow = 2 * g + (lane >> 5), kslot = lane & 31;
+            kvo[i] = krow * (CC * (int)sizeof(T)) + ((kslot ^ (krow & 15)) << 4);
+            const int vrow = 16 * g + (lane >> 2), vslot = lane & 3;
+            vvo[i] = vrow * (a.Kpad * (int)sizeof(T)) + ((vslot ^ ((vrow >> 2) & 3)) << 4);
+        }
+        auto request = [&](int tile) {
+            char* img = smem + (tile & 1) * (2 * KBYTES);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) at_lds_dma(rk, img + (wv * 4 + i) * 1024, kvo[i], tile * KBYTES);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) at_lds_dma(rv, img + KBYTES + (wv * 4 + i) * 1024, vvo[i], tile * (KT * (int)sizeof(T)));
+        };
+        if (ntiles > 0) request(0);
+        for (int tile = 0; tile < ntiles; ++tile) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tile + 1 < ntiles) request(tile + 1);
+            const char* img = smem + (tile & 1) * (2 * KBYTES);
+            compute(tile, img, img + KBYTES);
+        }
     }
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -295,10 +375,11 @@ extern "C" int gf_self_attention_gathered(const void* q, const void* kmap, const
     const dim3 ggrid(a.Kpad / KT, N), agrid((L + 32 * qb - 1) / (32 * qb), N);
 #define GF_K4_LAUNCH(T, ES)                                                                        \
     do {                                                                                           \
+        const size_t LDSB = (ES == 4 ? 2 : 4) * KT * CC * ES;      /* 16-bit: two (K, V^T) images */       \
         attn_gather_kv<T><<<ggrid, 256, 0, st>>>(a);                                               \
-        if (qb == 4) attn_self<T, 4><<<agrid, 256, 2 * KT * CC * ES, st>>>(a);                     \
-        else if (qb == 2) attn_self<T, 2><<<agrid, 256, 2 * KT * CC * ES, st>>>(a);                \
-        else attn_self<T, 1><<<agrid, 256, 2 * KT * CC * ES, st>>>(a);                             \
+        if (qb == 4) attn_self<T, 4><<<agrid, 256, LDSB, st>>>(a);                     \
+        else if (qb == 2) attn_self<T, 2><<<agrid, 256, LDSB, st>>>(a);                \
+        else attn_self<T, 1><<<agrid, 256, LDSB, st>>>(a);                             \
     } while (0)
     // the key counts live on the device: the caller that knows them (bench.py reads them back) declares the work, 4 L K C flops per sample
     void* pt = gf_prof_begin("k4_self_attention", st, 0.0);
