@@ -5,6 +5,7 @@ Objects are cached per source under csrc/_obj keyed on content hashes, so rebuil
 recompiles only what changed.
 """
 import hashlib
+import re
 import os
 import subprocess
 import sys
@@ -28,15 +29,26 @@ def _headers_digest():
     return h.hexdigest()
 
 
+def _file_flags(body):
+    """Per-file compiler flags: a `// hipcc-flags: ...` line among the first lines of the source."""
+    for line in body.split(b'\n')[:5]:
+        if line.startswith(b'// hipcc-flags:'):
+            return line[len(b'// hipcc-flags:'):].decode().split()
+    return []
+
+
 def _compile(src, hdig, verbose):
     body = open(src, 'rb').read()
+    extra = _file_flags(body)
+    for inc in re.findall(rb'#include "([\w.]+\.hip)"', body):       # a source that includes another one is rebuilt with it
+        body += open(os.path.join(CSRC, inc.decode()), 'rb').read()
     tag = hashlib.sha256(body + hdig.encode()).hexdigest()[:16]
     obj = os.path.join(OBJ, os.path.basename(src) + '.' + tag + '.o')
     if not os.path.exists(obj):
         for old in os.listdir(OBJ):
             if old.startswith(os.path.basename(src) + '.'):
                 os.remove(os.path.join(OBJ, old))
-        cmd = [HIPCC, *FLAGS, '-c', src, '-o', obj]
+        cmd = [HIPCC, *FLAGS, *extra, '-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.run(cmd, check=True)

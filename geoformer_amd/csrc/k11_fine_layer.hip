@@ -1,3 +1,4 @@
+// hipcc-flags: -fno-slp-vectorize
 // K11: one encoder layer of the FINE-level transformer (loftr_fine: d_model 128, 8 heads of 16, windows of W*W = 25 tokens,
 // 16-bit storage) as ONE launch per layer call: a window's tokens never leave the CU between the six GEMMs.
 //

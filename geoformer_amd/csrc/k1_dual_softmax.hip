@@ -29,9 +29,20 @@
 #include <math.h>
 
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "gf_common.h"
+
+// This file is compiled twice.  K1_PART 0 (this file's own object): everything except the instantiations of k1_stats_panel.
+// K1_PART 1 (k1_stats_noslp.hip, which includes this file): k1_stats_panel and its launcher alone, built with
+// -fno-slp-vectorize: packed into v_pk_*_f32 pairs its tile epilogue needs 256 registers + 76 bytes of scratch (a spill reload
+// waits for vmcnt(0), i.e. for the LDS-DMA in flight), unpacked 229 and none: 328 -> 285 us per 8-pair call on the same box.
+// k1_conf_pipe is 3 % faster WITH the packing, hence the split and not a file-wide flag.
+#ifndef K1_PART
+#define K1_PART 0
+#endif
+void gf_k1_stats_panel_launch(const void* k1args, int dtype, int wgs, void* stream);
 
 namespace {
 
@@ -1011,13 +1022,31 @@ __global__ __launch_bounds__(NT, 2) void k1_stats_panel(K1Args a) {
     }
 }
 
-#if K1_TRACE
+#if K1_TRACE == 1 + K1_PART        // the stamps of pass B live in part 0's buffer, those of pass A (K1_TRACE 2) in part 1's
 }
 extern "C" int gf_debug_k1_trace(long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(k1_trace), sizeof(long long) * 512 * 4 * 32);
 }
 namespace {
 #endif
+
+#if K1_PART == 1
+template <typename T>
+void k1_stats_panel_launch(const K1Args& a, int wgs, hipStream_t st) {
+    static std::atomic<uint64_t> attr{0};                       // 68.5 KiB of dynamic LDS: opt in once per device
+    if (gf_first_use_on_device(attr))
+        (void)hipFuncSetAttribute((const void*)k1_stats_panel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, STATS_LDS);
+    k1_stats_panel<T><<<wgs, NT, STATS_LDS, st>>>(a);
+}
+}   // namespace
+
+void gf_k1_stats_panel_launch(const void* k1args, int dtype, int wgs, void* stream) {
+    K1Args a;
+    memcpy(&a, k1args, sizeof(a));
+    if (dtype == GF_F16) k1_stats_panel_launch<_Float16>(a, wgs, (hipStream_t)stream);
+    else k1_stats_panel_launch<gf_bf16>(a, wgs, (hipStream_t)stream);
+}
+#else
 
 struct SelArgs {
     int N, L, S;
@@ -1230,15 +1259,6 @@ __global__ __launch_bounds__(1024) void k1_compact(SelArgs a) {
 }
 
 template <typename T>
-void k1_stats_allow_lds() {                                     // 68.5 KiB of dynamic LDS: opt in once per device
-    if constexpr (!std::is_same<T, float>::value) {
-        static std::atomic<uint64_t> attr{0};
-        if (gf_first_use_on_device(attr))
-            (void)hipFuncSetAttribute((const void*)k1_stats_panel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, STATS_LDS);
-    }
-}
-
-template <typename T>
 int k1_launch(K1Args a, SelArgs s, void* zero_begin, size_t zero_bytes, hipStream_t st) {
     constexpr bool EXACT = std::is_same<T, float>::value;
     const dim3 grid(a.tilesN * a.tilesM, a.N);
@@ -1253,8 +1273,7 @@ int k1_launch(K1Args a, SelArgs s, void* zero_begin, size_t zero_bytes, hipStrea
     void* p0 = gf_prof_begin("k1_stats", st, 2.0 * a.N * (double)a.L * a.S * a.C);
     if constexpr (!EXACT) {
         if (panel) {
-            k1_stats_allow_lds<T>();
-            k1_stats_panel<T><<<wgs, NT, STATS_LDS, st>>>(a);
+            gf_k1_stats_panel_launch(&a, std::is_same<T, _Float16>::value ? GF_F16 : GF_BF16, wgs, st);
         }
         else k1_stats<T><<<grid, NT, STAGE_BYTES, st>>>(a);
     } else {
@@ -1714,8 +1733,7 @@ extern "C" int gf_coarse_loss_forward(const void* f0, const void* f1, int dtype,
     if (mask0 == nullptr) {                                   // panel form (needs no masks)
         const int runs = (a.tilesN + PANEL_TILES - 1) / PANEL_TILES, units = N * a.tilesM * runs;
         a.rowparts = runs;
-        k1_stats_allow_lds<_Float16>();
-        k1_stats_panel<_Float16><<<units < 512 ? units : 512, NT, STATS_LDS, st>>>(a);
+        gf_k1_stats_panel_launch(&a, GF_F16, units < 512 ? units : 512, st);
     } else {
         a.rowparts = a.tilesN;
         k1_stats<_Float16><<<dim3(a.tilesN * a.tilesM, N), NT, STAGE_BYTES, st>>>(a);
@@ -1766,3 +1784,4 @@ extern "C" int gf_coarse_loss_backward(int N, int L, int S, int C, const uint8_t
     GF_CHECK_LAUNCH();
     return GF_OK;
 }
+#endif   // K1_PART
