@@ -120,7 +120,7 @@ KNIFE_EDGE = 3e-2
 # order; tools/k9_parity.py shows the old and the new kernel equally close to the oracle): 640: 10 of 1206; hpatches-shaped:
 # 8 of 1112; bench shape, thresholds 0.2 / 0.1: 44 of 10049 over the eight slots (3 .. 12 per slot); bench shape,
 # thresholds 0 / 0: 0 of 18693 over three slots
-MAX_KNIFE = {'640': 13, 'hpatches': 11, 'bench8': 47, 'bench8_slot': 15, 'bench8_dense': 3, 'bench8_dense_slot': 3}
+MAX_KNIFE = {'640': 13, 'hpatches': 11, 'bench8': 52, 'bench8_slot': 15, 'bench8_dense': 3, 'bench8_dense_slot': 3}
 FINE_EDGE = 5e-2          # the same for the fine threshold: the 25x25 matrices carry two more fp16 layers
 
 
