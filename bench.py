@@ -43,7 +43,7 @@ ROOFLINE_TAGS = [
     # tag,                   bound,  hot path, description
     ('enc_layer',            'mfma', True,  'fused encoder layer (projections + attention apply + merge/LN + MLP/LN + residual)'),
     ('enc_kv_state',         'mfma', True,  'fused k/v projection + linear-attention state'),
-    ('k3_linear',            'mfma', True,  'K3 linear_kernel family (Geo-layer projections, FinePreprocess and fine-level GEMMs with fused epilogues)'),
+    ('k3_linear',            'hbm',  True,  'K3 linear_kernel family (Geo-layer projections, FinePreprocess and fine-level GEMMs with fused epilogues; K <= 512: below the machine balance, HBM is the roof)'),
     ('k1_stats',             'mfma', True,  'K1 pass A (similarity tile statistics)'),
     ('k1_conf',              'hbm',  True,  'K1 pass B (dual-softmax correlation sweep, conf_matrix write)'),
     ('k1_unit',              'hbm',  True,  'K1 as a unit: one CoarseMatching call (pass A + reduction + pass B + selection + compaction) against its algorithmic bytes'),
@@ -52,7 +52,7 @@ ROOFLINE_TAGS = [
     ('k5_window_attention',  'hbm',  True,  'K5 windowed cross attention (L2 gather)'),
     ('k4_self_attention',    'mfma', True,  'K4 inlier-key self attention (flash form)'),
     ('bias_act',             'hbm',  False, 'backbone glue: shift + shortcut + activation stream'),
-    ('k3_upadd',             'mfma', False, 'backbone: 1x1 lateral convolution with the FPN upsample + add as its epilogue (K3 tile engine)'),
+    ('k3_upadd',             'hbm',  False, 'backbone: 1x1 lateral convolution with the FPN upsample + add as its epilogue (K3 tile engine; 67 flop/byte: HBM is the roof)'),
     ('conv3x3',              'mfma', False, 'K10 3x3 convolution of the backbone (BN shift + shortcut + activation in the epilogue; SURVEY 8f rank 4)'),
 ]
 

@@ -470,7 +470,10 @@ extern "C" int gf_linear(const void* a1, long lda1, int k1, const void* a2, long
     LinArgs a{a1, a2, lda1, lda2, k1, k2, w, bias, rowgroup_bias, rowgroup_rows, ln_gamma, ln_beta, ln_eps, residual,
               ldres, row_flag, flag_rows, out, ldo, M, N};
     hipStream_t st = (hipStream_t)stream;
-    void* pt = gf_prof_begin("k3_linear", st, 2.0 * (double)M * N * (k1 + k2));
+    // declared work = the algorithmic BYTES: with K = 128 ... 512 these GEMMs sit below the machine balance (N K / (N + K) = 64 ... 170
+    // flop per byte against 2.5 PFLOP/s : 8 TB/s = 312), so HBM is the roof that bounds them: operand rows + weights + output
+    // (+ residual) once
+    void* pt = gf_prof_begin("k3_linear", st, (double)es * ((double)M * (k1 + k2) + (double)N * (k1 + k2) + (double)M * N * (residual ? 2.0 : 1.0)));
     const bool wide = (epilogue >= EPI_LN) ? N == 256 : N % 256 == 0;
     if (dtype != GF_F32 && wide && epilogue <= EPI_TANH && rowgroup_bias == nullptr) {
         const size_t lds = (size_t)(128 + 256) * 128 + 256 * sizeof(float);
@@ -515,7 +518,9 @@ extern "C" int gf_conv1x1_upsample_add_nhwc(const void* x, const void* w, const 
     a.up_ry = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
     a.up_rx = W > 1 ? (float)(wl - 1) / (float)(W - 1) : 0.f;
     hipStream_t st = (hipStream_t)stream;
-    void* pt = gf_prof_begin("k3_upadd", st, 2.0 * (double)a.M * Cout * Cin);      // backbone (f4), not the matching path: own tag
+    // backbone (f4), not the matching path: own tag.  Declared work = algorithmic bytes (x + out + the coarser map + weights once):
+    // 67 flop per byte, HBM is the roof
+    void* pt = gf_prof_begin("k3_upadd", st, 2.0 * ((double)a.M * (Cin + Cout) + (double)N * h * wl * Cout + (double)Cin * Cout));
     // 128-wide column tiles (152 registers, three waves per SIMD): with K = 128 the kernel is all epilogue, and
     // a single 224-wide tile (NB = 7, two waves per SIMD) measured slower (607 vs 529 us) despite reading x once
     if (dtype == GF_F16) lin_launch1<_Float16, 4, EPI_UPADD>(a, st);
