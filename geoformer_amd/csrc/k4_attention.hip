@@ -88,6 +88,16 @@ __device__ __forceinline__ int k_off(int row, int chunk) { return row * (CC * (i
 // fp16 V^T: [CC channels][32 keys] rows of 64 B, chunk c (0..3) stored at c ^ ((row >> 2) & 3)
 __device__ __forceinline__ int vt_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
+#ifndef K4_TRACE
+#define K4_TRACE 0
+#endif
+#if K4_TRACE                           // -DK4_TRACE=1: phase stamps of tiles 4..7 of every workgroup's wave 0 (tools/k4_trace.py)
+__device__ long long k4_trace[2048 * 32];
+#define K4_T(slot) do { if (tid == 0 && tile >= 4 && tile < 8 && blockIdx.y * gridDim.x + blockIdx.x < 2048) k4_trace[(blockIdx.y * gridDim.x + blockIdx.x) * 32 + (tile - 4) * 8 + (slot)] = clock64(); } while (0)
+#else
+#define K4_T(slot)
+#endif
+
 // LDS-DMA (16-bit modes): 64 lanes x 16 B of a staged tile straight from the compact K / V^T buffers into LDS, no registers.
 // MUBUF form: the waits the compiler inserts stay counted (the FLAT form makes every LDS wait lgkmcnt(0)).
 struct AtRsrc {
@@ -98,6 +108,13 @@ __device__ __forceinline__ AtRsrc at_rsrc(const void* p, unsigned bytes) {
 }
 __device__ __forceinline__ void at_lds_dma(const AtRsrc& rs, char* dst, int voffset, int soffset) {        // -> 1 KiB at dst
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs.r, (__attribute__((address_space(3))) void*)dst, 16, voffset, soffset, 0, 0);
+}
+
+// max(x[lane], x[lane ^ 32]) in every lane: one v_permlane32_swap (VALU) instead of a ds_bpermute, whose lgkmcnt(0) wait also
+// drained the fragment reads in flight
+__device__ __forceinline__ float half_max(float x) {
+    const gf_v2u sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(sw.x), __uint_as_float(sw.y));
 }
 
 template <typename T, int QB>
@@ -158,6 +175,7 @@ __global__ __launch_bounds__(256, QB <= 2 ? 2 : 1) void attn_self(AtArgs a) {
                 const Frag kf = *reinterpret_cast<const Frag*>(ks + k_off<T>(lr, chunk));
                 M::mma(kf, qf[qb][g], s);
             }
+            if (qb == 0) K4_T(3);
             float x[16];
             float tmax = -INFINITY;
             float psum = 0.f;
@@ -179,7 +197,7 @@ __global__ __launch_bounds__(256, QB <= 2 ? 2 : 1) void attn_self(AtArgs a) {
                         tmax = fmaxf(tmax, x[r]);
                     }
                 }
-                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                tmax = half_max(tmax);
                 const float mnew = fmaxf(m[qb], tmax);          // finite: every tile holds at least one real key
                 const float nms = -mnew * scale2;
     #pragma unroll
@@ -211,7 +229,7 @@ __global__ __launch_bounds__(256, QB <= 2 ? 2 : 1) void attn_self(AtArgs a) {
                         tmax = fmaxf(tmax, x[r]);
                     }
                 }
-                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                tmax = half_max(tmax);
                 const float mnew = fmaxf(m[qb], tmax);          // finite: every tile holds at least one real key
     #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -229,6 +247,7 @@ __global__ __launch_bounds__(256, QB <= 2 ? 2 : 1) void attn_self(AtArgs a) {
                 m[qb] = mnew;
             }
             l[qb] += psum;
+            if (qb == 0) K4_T(4);
             // ---- O^T += V^T . P^T with P^T taken from the registers as the B operand
             if constexpr (F32) {
     #pragma unroll
@@ -249,6 +268,8 @@ __global__ __launch_bounds__(256, QB <= 2 ? 2 : 1) void attn_self(AtArgs a) {
                     }
                 }
             }
+            if (qb == 0) K4_T(5);
+            if (qb == QB - 1) K4_T(6);
             }
     };
     if constexpr (F32) {
@@ -310,8 +331,11 @@ __global__ __launch_bounds__(256, QB <= 2 ? 2 : 1) void attn_self(AtArgs a) {
         };
         if (ntiles > 0) request(0);
         for (int tile = 0; tile < ntiles; ++tile) {
+            K4_T(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            K4_T(1);
             __syncthreads();
+            K4_T(2);
             if (tile + 1 < ntiles) request(tile + 1);
             const char* img = smem + (tile & 1) * (2 * KBYTES);
             compute(tile, img, img + KBYTES);
@@ -338,6 +362,12 @@ __global__ __launch_bounds__(256, QB <= 2 ? 2 : 1) void attn_self(AtArgs a) {
 }
 
 }   // namespace
+
+#if K4_TRACE
+extern "C" int gf_debug_k4_trace(long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(k4_trace), sizeof(long long) * 2048 * 32);
+}
+#endif
 
 extern "C" size_t gf_self_attention_workspace_bytes(int N, int L, int dtype) {
     if (N <= 0 || L <= 0) return 0;
