@@ -1,5 +1,5 @@
 """Repeatability stress of the hand-pipelined kernels (LDS-DMA rings + counted s_waitcnt): K9 (enc_layer, enc_kv_state), K10
-(all five channel pairs) and K1 at the bench's shapes - 25 identical launches must give bit-identical outputs while a second
+(all five channel pairs), K1, K4 (two LDS images of the K / V^T tile) and K5 (tiled form) at the bench's shapes - 25 identical launches must give bit-identical outputs while a second
 stream runs the HBM-heavy k1_conf sweep beside them (the bench's two-pipeline situation).  A wait that is one request too
 loose lets an MFMA read an LDS tile still in flight: rare differing tiles that come and go with memory load (the k1_conf_pipe
 bug of round 2 was exactly that)."""
@@ -96,3 +96,43 @@ def test_k1_repeatable_beside_k9(nb):
             for a, b in zip(run(), first):
                 assert torch.equal(a, b), (thr, it)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('st', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('keys', [1195, 37, 0])
+def test_k4_repeatable_at_the_bench_shape(nb, st, keys):
+    """attn_self with its K / V^T tiles arriving by LDS-DMA into two LDS images (one barrier per tile): 16 images of 6400 queries
+    over `keys` inlier keys (ragged last tile, a single tile, no keys), per-sample key counts that differ."""
+    from geoformer_amd import ops
+    g = torch.Generator().manual_seed(7)
+    N, L = 16, 6400
+    q = (torch.randn(N, L, 256, generator=g) * 0.8).to(st).to(DEV)
+    kv = (torch.randn(N, L, 512, generator=g) * 0.8).to(st).to(DEV)
+    idx = torch.stack([torch.randperm(L, generator=g).sort()[0] for _ in range(N)]).int().to(DEV)
+    nk = torch.full((N,), keys, dtype=torch.int32)
+    if keys > 64:
+        nk[1::3] -= 17                                                  # other ragged tails
+        nk[2::5] = 64
+    nk = nk.to(DEV)
+    _repeat(lambda: (ops.self_attention_gathered(q, kv[..., :256], kv[..., 256:], idx, nk),), nb)
+
+
+def test_k5_tiled_repeatable_at_the_bench_shape(nb):
+    """window_cross_tiled at 8 images of 80 x 80 cells: translation (staged rectangles) and zoom 2 (global rows) in one call."""
+    from geoformer_amd import ops
+    g = torch.Generator().manual_seed(9)
+    N, H, W = 8, 80, 80
+    q = (torch.randn(N, H * W, 256, generator=g) * 0.8).half().to(DEV)
+    kv = (torch.randn(N, H * W, 512, generator=g) * 0.8).half().to(DEV)
+    ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing='ij')
+    dy, dx = torch.meshgrid(torch.arange(-2, 3), torch.arange(-2, 3), indexing='ij')
+    win = torch.empty(N, H * W, 25, dtype=torch.int32)
+    for b in range(N):
+        z = 2.0 if b % 4 == 3 else 1.0
+        cy = (ys.reshape(-1, 1) * z).long() + (b % 3) - 1 + dy.reshape(1, -1)
+        cx = (xs.reshape(-1, 1) * z).long() + 1 + dx.reshape(1, -1)
+        ok = (cy >= 0) & (cy < H) & (cx >= 0) & (cx < W)
+        win[b] = torch.where(ok, cy * W + cx, torch.full_like(cy, -1)).int()
+    win = win.to(DEV)
+    valid = torch.ones(N, dtype=torch.int32, device=DEV)
+    _repeat(lambda: (ops.window_cross_attention(q, kv[..., :256], kv[..., 256:], win, valid, 4, (H, W), (H, W)),), nb)

@@ -41,3 +41,20 @@ for ev in prof.events():
 for (site, name), n in rows.most_common(60):
     print(f'{n:5d}  {dur[(site, name)]:9.1f} us  {name:30s} {site}')
 print('total kernel-launching aten ops', sum(rows.values()))
+# device kernels of the profiled step by name (everything, ours included)
+kc = collections.Counter()
+kd = collections.Counter()
+for ev in prof.events():
+    if ev.device_type == torch.autograd.DeviceType.CUDA:
+        kc[ev.name[:80]] += 1
+        kd[ev.name[:80]] += ev.device_time if hasattr(ev, 'device_time') else ev.cuda_time
+print('device kernels of the step:', sum(kc.values()))
+for name, n in kc.most_common(25):
+    print(f'{n:5d}  {kd[name]:9.1f} us  {name}')
+par = collections.Counter()
+for ev in prof.events():
+    if ev.name.startswith('aten::') and any('gather' in k.name or 'index' in k.name for k in getattr(ev, 'kernels', [])):
+        site = next((f for f in ev.stack if 'geoformer_amd' in f or 'bench.py' in f), ev.stack[0] if ev.stack else '?')
+        par[(ev.name, site.split('/')[-1][:90])] += 1
+for (name, site), n in par.most_common(20):
+    print(f'{n:5d}  {name:28s} {site}')
