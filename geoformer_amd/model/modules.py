@@ -81,6 +81,7 @@ class LoFTREncoderLayer(nn.Module):
             f32 = torch.float32
             w = {'q': self.q_proj.weight.detach().to(dtype).contiguous(),
                  'kv': torch.cat([self.k_proj.weight, self.v_proj.weight], 0).detach().to(dtype).contiguous(),
+                 'qkv': torch.cat([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight], 0).detach().to(dtype).contiguous(),
                  'merge': self.merge.weight.detach().to(dtype).contiguous(),
                  'w1': self.mlp[0].weight.detach().to(dtype).contiguous(),
                  'w2': self.mlp[2].weight.detach().to(dtype).contiguous(),
@@ -123,6 +124,12 @@ class LoFTREncoderLayer(nn.Module):
         kv = ops.linear(source, self.weights(source.dtype)['kv'])
         c = self.d_model
         return kv[..., :c], kv[..., c:]
+
+    def project_qkv(self, x):
+        """q, k and v of the SAME tokens in one GEMM (x read once, one launch): row-strided views of a [..., 3C] tensor."""
+        qkv = ops.linear(x, self.weights(x.dtype)['qkv'])
+        c = self.d_model
+        return qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
 
     def finish(self, x, message, row_flag=None, flag_rows=0, out=None):
         """x + norm2(mlp([x, norm1(merge(message))])) in three K3 launches: merge+LN, mlp.0 on the
@@ -298,9 +305,8 @@ class GeoTransformer(nn.Module):
         for layer, name in zip(self.layers, self.layer_names):
             if name == 'self':       # keys/values = tokens at inlier cells; a sample without any keeps its features
                 if same:
-                    k, v = layer.project_kv(both)
-                    msg = ops.self_attention_gathered(layer.project_q(both), k, v, geo['idx_both'], geo['nidx_both'],
-                                                      self.nhead)
+                    q, k, v = layer.project_qkv(both)
+                    msg = ops.self_attention_gathered(q, k, v, geo['idx_both'], geo['nidx_both'], self.nhead)
                     both = layer.finish(both, msg, geo['nidx_both'], L)
                     feat0, feat1 = both[:n], both[n:]
                 else:
@@ -313,12 +319,15 @@ class GeoTransformer(nn.Module):
             elif name == 'cross':
                 # keys/values of BOTH images come from the pre-update features (the reference gathers
                 # feat0_cross and feat1_cross before either update, :126-129); project, then gather.
-                k0, v0 = layer.project_kv(feat0)
-                k1, v1 = layer.project_kv(feat1)
-                m0 = ops.window_cross_attention(layer.project_q(feat0), k1, v1, geo['win1'], geo['valid'], self.nhead,
-                                                geo.get('hw0'), geo.get('hw1'))
-                m1 = ops.window_cross_attention(layer.project_q(feat1), k0, v0, geo['win0'], geo['valid'], self.nhead,
-                                                geo.get('hw1'), geo.get('hw0'))
+                if same:             # q, k, v of both images in one GEMM over the [2N, L, C] buffer
+                    q, k, v = layer.project_qkv(both)
+                    q0, q1, k0, k1, v0, v1 = q[:n], q[n:], k[:n], k[n:], v[:n], v[n:]
+                else:
+                    k0, v0 = layer.project_kv(feat0)
+                    k1, v1 = layer.project_kv(feat1)
+                    q0, q1 = layer.project_q(feat0), layer.project_q(feat1)
+                m0 = ops.window_cross_attention(q0, k1, v1, geo['win1'], geo['valid'], self.nhead, geo.get('hw0'), geo.get('hw1'))
+                m1 = ops.window_cross_attention(q1, k0, v0, geo['win0'], geo['valid'], self.nhead, geo.get('hw1'), geo.get('hw0'))
                 if same:
                     nxt = torch.empty_like(both)
                     layer.finish(feat0, m0, geo['valid'], L, out=nxt[:n])
