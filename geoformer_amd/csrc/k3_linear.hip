@@ -70,6 +70,21 @@ struct LinArgs {
     float up_ry, up_rx;
 };
 
+// Tile of a workgroup.  Linear workgroup ids go round-robin over the 8 XCDs (= 8 L2s); with the grid's native order the column
+// tiles of one row tile are gridDim.x ids apart: same XCD, but its 4 MB L2 has long dropped the token rows, and every column
+// tile re-reads them from HBM.  Re-deal the ids in groups of 8 x gridDim.y: the gridDim.y column tiles of row tile 8 g + x all run
+// on XCD x, 8 ids apart - the second and third read of the rows hit that L2.
+__device__ __forceinline__ void lin_tile(int& row_tile, int& col_tile) {
+    const int gx = gridDim.x, gy = gridDim.y;
+    row_tile = blockIdx.x;
+    col_tile = blockIdx.y;
+    if (gy > 1 && (gx & 7) == 0) {
+        const int id = blockIdx.y * gx + blockIdx.x, grp = id / (8 * gy), j = id - grp * (8 * gy);
+        row_tile = grp * 8 + (j & 7);
+        col_tile = j >> 3;
+    }
+}
+
 template <typename T, int NB, int EPI>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void linear_kernel(LinArgs a) {
     using Mm = Mma32<T>;
@@ -84,7 +99,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void linear_kernel(Lin
     char* sw = smem + 128 * 128;                  // weight rows
     float* vec = reinterpret_cast<float*>(smem + ROWS * 128);   // bias | gamma | beta  [3][WROWS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, lr = lane & 31;
-    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * WROWS;
+    int row_tile, col_tile;
+    lin_tile(row_tile, col_tile);
+    const int m0 = row_tile * 128, n0 = col_tile * WROWS;
     const int K = a.k1 + a.k2;
 
     if (tid < WROWS) {
@@ -321,7 +338,9 @@ __global__ __launch_bounds__(256, 2) void linear_kernel_w2(LinArgs a) {
     float* vec = reinterpret_cast<float*>(smem + ROWS * 128);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, lr = lane & 31;
     const int tm = wave >> 1, tn = wave & 1;
-    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * WROWS;
+    int row_tile, col_tile;
+    lin_tile(row_tile, col_tile);
+    const int m0 = row_tile * 128, n0 = col_tile * WROWS;
     const int K = a.k1 + a.k2;
     if (tid < WROWS) vec[tid] = (a.bias && n0 + tid < a.N) ? a.bias[n0 + tid] : 0.f;
     const T* src[NLD];
