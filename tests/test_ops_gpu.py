@@ -329,6 +329,21 @@ def test_window_cross_attention_tiled(dtype, shape):
     assert torch.equal(skipped[0], out[0]) and torch.equal(skipped[2], out[2])
 
 
+def test_window_cross_attention_tiled_tiny_map():
+    """A 4 x 8 query map (one tile per head: 4 workgroups per image, the XCD re-deal of the ids is off) over a 5 x 9 key map."""
+    from geoformer_amd import ops
+    g = torch.Generator().manual_seed(3)
+    N, C, H = 3, 256, 4
+    hq, wq, hk, wk = 4, 8, 5, 9
+    q = torch.randn(N, hq * wq, C, generator=g).half()
+    kv = torch.randn(N, hk * wk, 2 * C, generator=g).half()
+    win = _warp_windows(N, hq, wq, hk, wk, [1.0, 1.0, 1.0], g)
+    valid = torch.ones(N, dtype=torch.int32)
+    args = (q.to(DEV), kv.to(DEV)[..., :C], kv.to(DEV)[..., C:], win.to(DEV), valid.to(DEV), H)
+    out = ops.window_cross_attention(*args, (hq, wq), (hk, wk))
+    close(out, ops.window_cross_attention(*args).float().cpu(), 4e-3, 4e-3)
+
+
 # ------------------------------------------------------------------ K7
 @pytest.mark.parametrize('layout', ['nchw', 'nhwc'])
 def test_fine_gather_vs_oracle(layout):
@@ -679,3 +694,20 @@ def test_conv1x1_upsample_add_vs_torch():
         lo.float(), size=(30, 44), mode='bilinear', align_corners=True)
     assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
     assert torch.allclose(out.float(), ref, atol=1e-2, rtol=4e-3), (out.float() - ref).abs().max().item()   # two fp16 roundings
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('N', [512, 768])
+def test_linear_column_tiles_per_xcd(dtype, N):
+    """M / 128 a multiple of 8 and two or three column tiles: the workgroup ids are re-dealt so that the column tiles of a row
+    tile share an XCD (k3_linear.hip:lin_tile); every output tile must still be written exactly once, from the right rows -
+    also through a row-strided output view and with a ReLU epilogue (the 2 x 2 wave tiling)."""
+    from geoformer_amd import ops
+    g = torch.Generator().manual_seed(N)
+    M, K = 128 * 24, 256
+    x = torch.randn(M, K, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.06).to(dtype).to(DEV)
+    ref = x.float() @ w.float().t()
+    tol = (2e-5, 2e-5) if dtype == torch.float32 else (1e-2, 1e-2)
+    close(ops.linear(x, w), ref, *tol)
+    close(ops.linear(x, w, epilogue=ops.EPI_RELU), ref.clamp(min=0), *tol)
