@@ -144,7 +144,10 @@ __device__ long long k10_trace[256 * 8 * 8 * 16];
 #define K10_T(slot)
 #endif
 
-template <typename T, int CIN, int COUT, int NW>
+// PADL: the last 16 output channels are padding (zero weights - act | GF_CONV_PAD16): their fragment (the last one of every odd
+// sub-step) is neither read from the ring nor multiplied; the accumulators keep the shift and the epilogue writes act(shift +
+// residual) as for every other channel
+template <typename T, int CIN, int COUT, int NW, bool PADL>
 __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
     using Mm = Mma16<T>;
     using Frag = typename Mm::Frag;
@@ -177,10 +180,11 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
     // group) reads the 16-byte slot k group ^ ((q >> 1) & 3) - conflict-free for every patch offset).
     const int xq0 = PB * wave * PW + lp;
     Frag wa[NT], wb[NT], xa[2 * PB], xb[2 * PB];
-    auto load_w = [&](Frag (&f)[NT], int slot, int s) {            // weight fragments of sub-step s of the block in `slot`
+    auto load_w = [&](Frag (&f)[NT], int slot, int s, bool second_half) {   // weight fragments of sub-step s of the block in `slot`
         const char* p = smem + G::W10_OFF + slot * G::WBLK + s * NT * C10_FRAG + lane * 16;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) f[t] = *reinterpret_cast<const Frag*>(p + t * C10_FRAG);
+        for (int t = 0; t < NT; ++t)
+            if (!(PADL && second_half && t == NT - 1)) f[t] = *reinterpret_cast<const Frag*>(p + t * C10_FRAG);
     };
     auto load_x = [&](Frag (&f)[2 * PB], int buf, int tap) {       // pixel fragments of `tap` of the chunk in `buf`
         const int ky = tap / 3, kx = tap - 3 * ky;
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
         const bool has_next = nxt_tile < xend;
         ++it;
         K10_T(0);
-        load_w(wa, wslot, 0);               // block 0 and the patch of chunk 0 landed before the previous tile's last turn
+        load_w(wa, wslot, 0, false);               // block 0 and the patch of chunk 0 landed before the previous tile's last turn
         load_x(xa, pbuf, 0);
         // acc[bb][ct]: pixel block bb (row bb / 2 of the wave, pixels 16 (bb % 2) .. + 15), channels 16 ct + 4 g4 + {0..3};
         // accumulators start at the shift of their channel
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
                 // next sub-step's weight fragments, and behind a tap's second half the next tap's pixel fragments (a tile's
                 // first ones are read at its start: held across the epilogue they spill)
                 if (ts < 17 || c + 1 < NCH) {
-                    load_w(nw, wslot, (ts + 1) % BS);
+                    load_w(nw, wslot, (ts + 1) % BS, ((ts + 1) & 1) != 0);
                     if (hf) load_x(nx, ts == 17 ? pbuf ^ 1 : pbuf, (tap + 1) % 9);
                 }
                 // (no issue-order hints: with 128 accumulators in four-register tuples the allocator gives an MFMA's result
@@ -289,7 +293,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
                 for (int bb = 0; bb < 2 * PB; ++bb)
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) Mm::mma(cw[t], cx[bb], acc[bb][hf * NT + t]);
+                    for (int t = 0; t < NT; ++t)
+                        if (!(PADL && hf == 1 && t == NT - 1)) Mm::mma(cw[t], cx[bb], acc[bb][hf * NT + t]);
                 // issue order: two reads, then one read behind each of the first MFMAs (left alone the compiler sinks the
                 // reads behind the sub-step's last MFMA and the next one waits out the whole LDS latency)
                 __builtin_amdgcn_sched_barrier(0);
@@ -425,31 +430,33 @@ extern "C" int gf_debug_k10_trace(long long* out) {
 namespace {
 #endif
 
-template <typename T, int CIN, int COUT, int NW>
+template <typename T, int CIN, int COUT, int NW, bool PADL>
 int conv_launch(ConvArgs a, hipStream_t st) {
     using G = ConvGeo<COUT / 32, NW>;
     static std::atomic<uint64_t> attr{0};
     if (gf_first_use_on_device(attr))
-        (void)hipFuncSetAttribute((const void*)conv3x3_kernel<T, CIN, COUT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        (void)hipFuncSetAttribute((const void*)conv3x3_kernel<T, CIN, COUT, NW, PADL>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + G::TH - 1) / G::TH;
     const long nt = (long)a.N * a.tiles_x * a.tiles_y;
     if (nt >= (1l << 31)) return -2;
     a.ntiles = (int)nt;
-    conv3x3_kernel<T, CIN, COUT, NW><<<a.ntiles < 256 ? a.ntiles : 256, NW * 64, G::LDS, st>>>(a);
+    conv3x3_kernel<T, CIN, COUT, NW, PADL><<<a.ntiles < 256 ? a.ntiles : 256, NW * 64, G::LDS, st>>>(a);
     return 0;
 }
 
 // 8 waves per workgroup: measured 1.1-1.3x faster than 4 at every shape (tools/k10_time.py); the 4-wave form stays
 // instantiable (conv_launch<..., 4>) for experiments
-template <typename T, int CIN, int COUT>
+template <typename T, int CIN, int COUT, bool PADL = false>
 int conv_launch_w(const ConvArgs& a, hipStream_t st) {
-    return conv_launch<T, CIN, COUT, 8>(a, st);
+    return conv_launch<T, CIN, COUT, 8, PADL>(a, st);
 }
 
 template <typename T>
-int conv_dispatch(const ConvArgs& a, int cin, int cout, hipStream_t st) {
+int conv_dispatch(const ConvArgs& a, int cin, int cout, bool padl, hipStream_t st) {
     if (cin == 128 && cout == 128) return conv_launch_w<T, 128, 128>(a, st);
+    if (cin == 224 && cout == 224 && padl) return conv_launch_w<T, 224, 224, true>(a, st);
+    if (cin == 256 && cout == 224 && padl) return conv_launch_w<T, 256, 224, true>(a, st);
     if (cin == 224 && cout == 224) return conv_launch_w<T, 224, 224>(a, st);
     if (cin == 224 && cout == 128) return conv_launch_w<T, 224, 128>(a, st);
     if (cin == 256 && cout == 256) return conv_launch_w<T, 256, 256>(a, st);
@@ -473,6 +480,8 @@ extern "C" int gf_conv3x3_nhwc(const void* x, const void* wstream, const float* 
     GF_CHECK_ARG(N > 0 && H > 0 && W > 0, "empty problem");
     GF_CHECK_ARG(dtype == GF_F16 || dtype == GF_BF16, "built for 16-bit maps");
     GF_CHECK_ARG(gf_conv3x3_supported(cin, cout), "no kernel for these channel counts (see gf_conv3x3_supported)");
+    const bool padl = (act & GF_CONV_PAD16) != 0;     // the last 16 output channels are padding (zero weights): not multiplied
+    act &= ~GF_CONV_PAD16;
     GF_CHECK_ARG(act >= C10_NONE && act <= C10_LEAKY, "unknown activation");
     GF_CHECK_ARG(act != C10_LEAKY || (slope >= 0.f && slope <= 1.f), "LeakyReLU slope must lie in [0, 1]");
     GF_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)residual % 16 == 0 && (uintptr_t)wstream % 16 == 0 &&
@@ -484,7 +493,7 @@ extern "C" int gf_conv3x3_nhwc(const void* x, const void* wstream, const float* 
     // (resnet_fpn.py block_dims (128, 196, 256); model/backbone.py pads them for the matrix cores) and the padding is not work
     const double cin_w = cin == 224 ? 196.0 : cin, cout_w = cout == 224 ? 196.0 : cout;
     void* pt = gf_prof_begin("conv3x3", st, 2.0 * N * (double)H * W * cin_w * cout_w * 9.0);
-    const int rc = dtype == GF_F16 ? conv_dispatch<_Float16>(a, cin, cout, st) : conv_dispatch<gf_bf16>(a, cin, cout, st);
+    const int rc = dtype == GF_F16 ? conv_dispatch<_Float16>(a, cin, cout, padl, st) : conv_dispatch<gf_bf16>(a, cin, cout, padl, st);
     gf_prof_end("conv3x3", pt, st);
     GF_CHECK_ARG(rc == 0, "dispatch failed");
     GF_CHECK_LAUNCH();

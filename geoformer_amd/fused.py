@@ -195,8 +195,12 @@ def conv3x3_supported(cin, cout):
     return bool(_lib.lib().gf_conv3x3_supported(int(cin), int(cout)))
 
 
-def conv3x3(x, wstream, cout, shift=None, residual=None, act=0, slope=0.01):
-    """x channels_last [N, Cin, H, W] (16-bit) -> channels_last [N, cout, H, W] = act(conv3x3(x) + shift + residual)."""
+CONV_PAD16 = 0x100          # GF_CONV_PAD16 (include/geoformer_hip.h)
+
+
+def conv3x3(x, wstream, cout, shift=None, residual=None, act=0, slope=0.01, pad16=False):
+    """x channels_last [N, Cin, H, W] (16-bit) -> channels_last [N, cout, H, W] = act(conv3x3(x) + shift + residual).
+    pad16: the last 16 output channels are zero padding (zero weights): their products are skipped."""
     _need_cuda(x, wstream)
     if x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last):
         raise ValueError('conv3x3 expects a channels_last [N, C, H, W] tensor')
@@ -208,6 +212,7 @@ def conv3x3(x, wstream, cout, shift=None, residual=None, act=0, slope=0.01):
     z = _ZEROS.get(x.device)
     if z is None:
         z = _ZEROS[x.device] = torch.zeros(256, dtype=torch.uint8, device=x.device)
-    check(_lib.lib().gf_conv3x3_nhwc(_p(x), _p(wstream), _p(shift), _p(residual), _p(out), _p(z), N, H, W, cin, cout, int(act),
+    check(_lib.lib().gf_conv3x3_nhwc(_p(x), _p(wstream), _p(shift), _p(residual), _p(out), _p(z), N, H, W, cin, cout,
+                                     int(act) | (CONV_PAD16 if pad16 else 0),
                                      float(slope), _dt(x), _stream()), 'gf_conv3x3_nhwc')
     return out

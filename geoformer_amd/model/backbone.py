@@ -109,6 +109,7 @@ class FusedInferenceBackbone:
         if dtype == torch.float16 and tuple(bb.conv1.weight.shape) == (128, 1, 7, 7) and bb.conv1.stride == (2, 2):
             self.stem_hip = (_fold(bb.conv1, bb.bn1, torch.float32)[0].contiguous(), self.stem[1])
         self.blocks = []
+        self._pad16 = {}
         for layer in (bb.layer1, bb.layer2, bb.layer3):
             for blk in layer:
                 w1, b1 = _fold(blk.conv1, blk.bn1, dtype, pm)
@@ -145,7 +146,10 @@ class FusedInferenceBackbone:
     def _conv3(self, x, w, ws, shift, shortcut, act, slope=0.01, stride=1):
         """act(conv(x, w) + shift + shortcut): one K10 launch when a stream exists."""
         if ws is not None:
-            return fused.conv3x3(x, ws, w.shape[0], shift, shortcut, act, slope)
+            pad16 = self._pad16.get(id(w))
+            if pad16 is None:             # 196 real channels in a 224-wide map: the last 16 output channels carry zero weights
+                pad16 = self._pad16[id(w)] = bool(w.shape[0] == 224 and not w[-16:].any())
+            return fused.conv3x3(x, ws, w.shape[0], shift, shortcut, act, slope, pad16)
         y = self._conv(x, w, stride)
         if shift is None and shortcut is None and act == ops.ACT_NONE:
             return y

@@ -217,11 +217,14 @@ int gf_fine_layer(const void* x, const void* src, void* out, int dtype, int Nw, 
  *   out[n,y,x,:] = act( sum_{ky,kx} w[:, :, ky, kx] . x[n, y+ky-1, x+kx-1, :] + shift + residual[n,y,x,:] )
  *   x [N,H,W,cin], out / residual [N,H,W,cout] (GF_F16 or GF_BF16); fp32 accumulation starting from the shift; the sum is
  *   rounded to the storage type once before the residual is added and once at the output (a separate convolution
- *   followed by gf_bias_act_nhwc rounds twice as well); act: 0 none, 1 ReLU, 2 LeakyReLU(slope in [0,1]);
+ *   followed by gf_bias_act_nhwc rounds twice as well); act: 0 none, 1 ReLU, 2 LeakyReLU(slope in [0,1]), optionally
+ *   | GF_CONV_PAD16: the caller states that the last 16 output channels are zero padding (zero weights, e.g. 196 real
+ *   channels in a 224-wide map) - their products are skipped, the outputs are act(shift + residual) as everywhere;
  *   shift fp32 [cout] or NULL; residual or NULL; maps must hold fewer than 2^31 elements;
  *   wstream = geoformer_amd/fused.py:pack_conv3x3_stream(w); zeros = >= 64 bytes of zeroed device memory.
  *   Channel counts: gf_conv3x3_supported(cin, cout).
  * ------------------------------------------------------------------------------------------ */
+#define GF_CONV_PAD16 0x100
 int gf_conv3x3_supported(int cin, int cout);
 int gf_conv3x3_nhwc(const void* x, const void* wstream, const float* shift, const void* residual, void* out,
                     const void* zeros, int N, int H, int W, int cin, int cout, int act, float slope, int dtype,

@@ -655,6 +655,26 @@ def test_conv3x3_full_size_vs_library(cin, cout, hw):
     assert bool(torch.isfinite(out).all())
 
 
+@pytest.mark.parametrize('cin,hw', [(224, (40, 70)), (256, (33, 37))])
+@pytest.mark.parametrize('use_res', [False, True])
+def test_conv3x3_padded_output_channels(cin, hw, use_res):
+    """GF_CONV_PAD16: with zero weights in the last 16 of 224 output channels (196 real channels padded for the matrix cores)
+    the call that skips their products gives the SAME bits as the one that multiplies the zeros - also where the shift and the
+    shortcut of the padded channels are not zero (the epilogue still runs for them)."""
+    from geoformer_amd import fused, ops
+    torch.manual_seed(cin)
+    N, (H, W), cout = 2, hw, 224
+    x = torch.randn(N, cin, H, W, device='cuda').half().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, 3, 3, device='cuda') * (1.5 / (3 * cin ** 0.5))).half()
+    w[196:] = 0
+    shift = torch.randn(cout, device='cuda')
+    res = torch.randn(N, cout, H, W, device='cuda').half().contiguous(memory_format=torch.channels_last) if use_res else None
+    ws = fused.pack_conv3x3_stream(w)
+    plain = fused.conv3x3(x, ws, cout, shift, res, ops.ACT_LEAKY, 0.1)
+    skipped = fused.conv3x3(x, ws, cout, shift, res, ops.ACT_LEAKY, 0.1, pad16=True)
+    assert torch.equal(plain, skipped)
+
+
 def test_conv3x3_rejects_unsupported():
     from geoformer_amd import fused, _lib
     assert not fused.conv3x3_supported(64, 64)
