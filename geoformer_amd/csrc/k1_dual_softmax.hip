@@ -713,6 +713,11 @@ __global__ __launch_bounds__(NT, 2) void k1_conf_pipe(K1Args a) {
         // one fma and one exponential per element; the two products with 1/sum are gone)
         float ca[2];
         unsigned cbest[2];
+#ifndef K1_CG
+#define K1_CG 4
+#endif
+        constexpr int CG = K1_CG;                             // rows per candidate test
+        [[maybe_unused]] float hold[CG][2], gmax = 0.f;
         const unsigned thr_bits = __float_as_uint(fmaxf(a.thr, 0.f));
         auto epi_begin = [&](int bn) {
 #pragma unroll
@@ -734,16 +739,24 @@ __global__ __launch_bounds__(NT, 2) void k1_conf_pipe(K1Args a) {
                 __builtin_nontemporal_store(__uint_as_float(sw.y), rowp + 4 * a.S + lane);
             }
             if constexpr (!DENSE) {
-                if (fmaxf(cf[0], cf[1]) > a.thr) {
-                    const int row = row_base + gf_acc_row(r, h);
+                // candidates (conf > thr) are rare: the test runs once per CG rows on their maximum (one max3 per row; a
+                // compare + branch per row cut the MFMA loop into 16 blocks), the rows are looked at one by one only on a hit
+                hold[r % CG][0] = cf[0];
+                hold[r % CG][1] = cf[1];
+                gmax = r % CG == 0 ? fmaxf(cf[0], cf[1]) : fmaxf(gmax, fmaxf(cf[0], cf[1]));
+                if (r % CG == CG - 1 && gmax > a.thr) {
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-                        if (cf[ni] > a.thr) {
-                            const int col = n0 + ni * 32 + lr;
-                            const unsigned bits = __float_as_uint(cf[ni]);
-                            atomicMax(rbest + row, ((unsigned long long)bits << 32) | (0xFFFFFFFFu - (unsigned)col));
-                            atomicMax(cmax + col, bits);
-                        }
+                    for (int q = 0; q < CG; ++q) {
+                        const int row = row_base + gf_acc_row(r - (CG - 1) + q, h);
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+                            if (hold[q][ni] > a.thr) {
+                                const int col = n0 + ni * 32 + lr;
+                                const unsigned bits = __float_as_uint(hold[q][ni]);
+                                atomicMax(rbest + row, ((unsigned long long)bits << 32) | (0xFFFFFFFFu - (unsigned)col));
+                                atomicMax(cmax + col, bits);
+                            }
+                    }
                 }
             } else {
                 // (conf >= 0: its bits order like its value; the threshold is applied once, to the maxima)
