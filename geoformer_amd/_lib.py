@@ -68,8 +68,11 @@ SIGNATURES = {
                           c_int, c_void_p]),
     'gf_ransac_workspace_bytes': (c_size_t, [c_int, c_int]),
     'gf_ransac_homography': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_float,
-                                     c_int, c_uint32, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_int, c_uint32, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_size_t, c_void_p]),
+    'gf_ransac_homography_v2': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_float,
+                                        c_int, c_uint32, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_size_t, c_void_p, c_int]),
     'gf_window_geometry': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'gf_inlier_index': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -98,6 +101,9 @@ SIGNATURES = {
 }
 
 
+ABI_VERSION = 3          # include/geoformer_hip.h GF_ABI_VERSION
+
+
 class GeoFormerHipError(RuntimeError):
     pass
 
@@ -116,6 +122,9 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)       # AttributeError if the symbol is missing: fail loudly
             fn.restype, fn.argtypes = res, args
+        if h.gf_abi_version() != ABI_VERSION:
+            raise GeoFormerHipError(f'{LIB_PATH} has ABI version {h.gf_abi_version()}, this binding was written against {ABI_VERSION} '
+                                    '(include/geoformer_hip.h GF_ABI_VERSION): rebuild the library')
         _lib = h
     return _lib
 

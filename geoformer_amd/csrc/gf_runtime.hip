@@ -12,7 +12,7 @@ void gf_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int gf_abi_version(void) { return 1; }
+extern "C" int gf_abi_version(void) { return GF_ABI_VERSION; }
 extern "C" const char* gf_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------------------------------------

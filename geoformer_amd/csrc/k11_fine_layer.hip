@@ -217,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void fine_layer(FlArgs a) {
         const int win = g * FW + wave;
         K11_T(0);
         const int wclamp = win < a.Nw ? win : a.Nw - 1;                 // a tail group's spare waves recompute the last window (never stored)
-        const int win_off = wclamp * a.Lw * (FC * 2);                    // byte offset of the window in x / src (32-bit: the entry point bounds the tensors)
+        const int win_off = (int)((unsigned)wclamp * (unsigned)(a.Lw * (FC * 2)));   // byte offset of the window in x / src: unsigned 32-bit (the entry point bounds a launch's tensors to < 2^31 BYTES)
         // the wave's own earlier reads of its tile (the previous group's output rows) are in registers by now
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         fl_tile_dma(srs, win_off, a.Lw, tile, ln);
@@ -468,20 +468,27 @@ extern "C" int gf_fine_layer(const void* x, const void* src, void* out, int dtyp
     GF_CHECK_ARG(dtype == GF_F16 || dtype == GF_BF16, "the fused fine-level layer is built for 16-bit storage (GF_F16 / GF_BF16)");
     GF_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)wstream % 16 == 0,
                  "tensors must be 16-byte aligned");
-    GF_CHECK_ARG((long)Nw * Lw * FC < (1l << 31), "too many windows");
     static std::atomic<uint64_t> attr{0};
     if (gf_first_use_on_device(attr)) {
         (void)hipFuncSetAttribute((const void*)fine_layer<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)fine_layer<gf_bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     }
-    FlArgs a{x, src, out, wstream, ln_params, eps1, eps2, attn_eps, Nw, Lw, (Nw + FW - 1) / FW};
     hipStream_t st = (hipStream_t)stream;
-    const int grid = a.groups < 256 ? a.groups : 256;
     // flops per window token: q, k, v, merge 4 x 2 C^2 + state and apply 4 x 2 C D (D = 16) + mlp 2 (2C)(2C) + 2 (2C) C
     const double per_tok = 8.0 * FC * FC + 8.0 * FC * 16 + 8.0 * FC * FC + 4.0 * FC * FC;
     void* pt = gf_prof_begin("fine_layer", st, per_tok * (double)Nw * Lw);
-    if (dtype == GF_F16) fine_layer<_Float16><<<grid, 512, LDS_BYTES, st>>>(a);
-    else fine_layer<gf_bf16><<<grid, 512, LDS_BYTES, st>>>(a);
+    // the kernel addresses a window through a 32-bit byte offset into a buffer descriptor: a launch takes at most
+    // GF_FINE_LAYER_MAX_BYTES of windows (2^31 - 64 KiB; 335 k windows of 25 tokens), more windows = more launches
+    const long win_bytes = (long)Lw * FC * 2;
+    const int per_launch = (int)(((1l << 31) - 65536) / win_bytes);
+    for (long w0 = 0; w0 < Nw; w0 += per_launch) {
+        const int nw = (int)((Nw - w0) < per_launch ? (Nw - w0) : per_launch);
+        FlArgs a{(const char*)x + w0 * win_bytes, (const char*)src + w0 * win_bytes, (char*)out + w0 * win_bytes, wstream, ln_params,
+                 eps1, eps2, attn_eps, nw, Lw, (nw + FW - 1) / FW};
+        const int grid = a.groups < 256 ? a.groups : 256;
+        if (dtype == GF_F16) fine_layer<_Float16><<<grid, 512, LDS_BYTES, st>>>(a);
+        else fine_layer<gf_bf16><<<grid, 512, LDS_BYTES, st>>>(a);
+    }
     gf_prof_end("fine_layer", pt, st);
     GF_CHECK_LAUNCH();
     return GF_OK;

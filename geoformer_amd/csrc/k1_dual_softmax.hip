@@ -70,6 +70,7 @@ struct K1Args {
     float* conf;
     float thr;
     int dense;                     // thr so low that candidates are not rare: reduce in the tile first
+    unsigned long long* stamp;     // [K1_STAMP_WORDS] or null: what the statistics in this workspace belong to (k1_stamp_words)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -302,6 +303,22 @@ __global__ __launch_bounds__(NT, 4) void k1_stats(K1Args a) {
     else k1_stats_epilogue<T, true>(a, acc, smem, n, bm, bn);
 }
 
+// The row / column statistics a gf_dual_softmax_match call leaves in its workspace are stamped with what they were computed
+// from (shape, scale, the two feature pointers); gf_dual_softmax_conf_at compares the stamp with its own arguments on the
+// device and returns NaN for every entry when they differ (nothing else ties a later conf_at call to that call).
+constexpr int K1_STAMP_WORDS = 5;
+__host__ __device__ __forceinline__ unsigned long long k1_stamp_word(int k, const void* f0, const void* f1, int N, int L, int S, int C, float mult) {
+    union { float f; unsigned u; } m;
+    m.f = mult;
+    switch (k) {
+        case 0: return 0x6b31737461747321ull;                                              // "k1stats!": a stamp has been written at all
+        case 1: return ((unsigned long long)(unsigned)N << 32) | (unsigned)L;
+        case 2: return ((unsigned long long)(unsigned)S << 32) | (unsigned)C;
+        case 3: return (unsigned long long)(uintptr_t)f0 ^ ((unsigned long long)m.u << 40);
+        default: return (unsigned long long)(uintptr_t)f1;
+    }
+}
+
 // combine per-tile (max, sumexp) partials: 32 rows (blockIdx.y==0) or columns (==1) per block,
 // 8 threads per row each striding over the partials, merged through LDS
 template <bool EXACT>
@@ -309,6 +326,8 @@ __global__ __launch_bounds__(256) void k1_reduce_stats(K1Args a) {
     __shared__ float2 sh[8][32];
     const int n = blockIdx.z;
     const bool rows = blockIdx.y == 0;
+    if (a.stamp != nullptr && threadIdx.x < K1_STAMP_WORDS && blockIdx.x == 0 && blockIdx.y == 0 && n == 0)
+        a.stamp[threadIdx.x] = k1_stamp_word(threadIdx.x, a.f0, a.f1, a.N, a.L, a.S, a.C, a.mult);
     const int len = rows ? a.L : a.S, np = rows ? a.rowparts : a.tilesM;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + tx;
@@ -1062,6 +1081,7 @@ void gf_k1_stats_panel_launch(const void* k1args, int dtype, int wgs, void* stre
 #else
 
 struct SelArgs {
+    const unsigned long long* stamp;   // the workspace stamp (k1_conf_at checks it)
     int N, L, S;
     const unsigned long long* rowbest;   // [N][L]
     const unsigned* colmax;              // [N][S]
@@ -1169,7 +1189,17 @@ template <typename H>
 __global__ __launch_bounds__(256) void k1_conf_at(SelArgs a, const int64_t* b, const int64_t* i, const int64_t* j, int P, float* out) {
     const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (e >= P) return;
-    const float c = k1_conf_entry<H>(a, (int)b[e], (int)i[e], (int)j[e]);
+    // the statistics in the workspace must be those of THESE features at THIS shape, and the entry must exist: NaN otherwise
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < K1_STAMP_WORDS; ++k) ok = ok && a.stamp[k] == k1_stamp_word(k, a.f0, a.f1, a.N, a.L, a.S, a.C, a.mult);
+    const long long bb = b[e], ii = i[e], jj = j[e];
+    ok = ok && bb >= 0 && bb < a.N && ii >= 0 && ii < a.L && jj >= 0 && jj < a.S;
+    if (!ok) {                                                              // wave-uniform: e is per wave
+        if ((threadIdx.x & 63) == 0) out[e] = __builtin_nanf("");
+        return;
+    }
+    const float c = k1_conf_entry<H>(a, (int)bb, (int)ii, (int)jj);
     if ((threadIdx.x & 63) == 0) out[e] = c;
 }
 
@@ -1348,6 +1378,7 @@ struct K1Workspace {
     unsigned long long* rowbest;
     unsigned *colmax, *colset;
     int *samplecnt, *scancnt, *selj, *scanlist;
+    unsigned long long* stamp;
     size_t zero_bytes, bytes;
 };
 
@@ -1368,6 +1399,7 @@ K1Workspace k1_carve(void* ws, int N, int L, int S) {
     w.cstat = c.take<float2>((size_t)N * S);
     w.selj = c.take<int>((size_t)N * L);
     w.scanlist = c.take<int>((size_t)N * L);
+    w.stamp = c.take<unsigned long long>(K1_STAMP_WORDS);
     w.bytes = c.used();
     return w;
 }
@@ -1647,6 +1679,7 @@ extern "C" int gf_dual_softmax_conf_at(const void* f0, const void* f1, int dtype
     const K1Workspace w = k1_carve(workspace, N, L, S);
     SelArgs s{};
     s.N = N; s.L = L; s.S = S; s.f0 = f0; s.f1 = f1; s.rstat = w.rstat; s.cstat = w.cstat; s.C = C; s.mult = (1.0f / (float)C) / temperature;
+    s.stamp = w.stamp;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == GF_F16) k1_conf_at<_Float16><<<(P + 3) / 4, 256, 0, st>>>(s, b, i, j, P, out);
     else k1_conf_at<gf_bf16><<<(P + 3) / 4, 256, 0, st>>>(s, b, i, j, P, out);
@@ -1685,9 +1718,10 @@ extern "C" int gf_dual_softmax_match(const void* f0, const void* f1, int dtype, 
     a.tilesM = (L + BM - 1) / BM; a.tilesN = (S + BN - 1) / BN;
     a.rowpart = w.rowpart; a.colpart = w.colpart; a.rstat = w.rstat; a.cstat = w.cstat;
     a.rowbest = w.rowbest; a.colmax = w.colmax; a.conf = conf; a.thr = thr; a.dense = thr < 0.05f;
+    a.stamp = w.stamp;
     SelArgs s;
     s.N = N; s.L = L; s.S = S;
-    s.rowbest = w.rowbest; s.colmax = w.colmax; s.colset = w.colset; s.conf = conf;
+    s.rowbest = w.rowbest; s.colmax = w.colmax; s.colset = w.colset; s.conf = conf; s.stamp = w.stamp;
     s.f0 = f0; s.f1 = f1; s.rstat = w.rstat; s.cstat = w.cstat; s.C = C; s.mult = a.mult;
     s.selj = w.selj; s.scanlist = w.scanlist; s.scancnt = w.scancnt; s.samplecnt = w.samplecnt; s.chunks = (L + 1023) / 1024; s.force_one = force_one; s.w0c = w0c; s.w1c = w1c;
     s.scale = scale; s.scale0 = scale0; s.scale1 = scale1;

@@ -429,17 +429,17 @@ extern "C" size_t gf_ransac_workspace_bytes(int N, int iters) {
     return gf_align_up((size_t)N * iters * 9 * sizeof(double), 256) + gf_align_up((size_t)N * iters * sizeof(int32_t), 256);
 }
 
-extern "C" int gf_ransac_homography(const float* mkpts0_c, const float* mkpts1_c, const int32_t* counts, int N,
-                                    int capacity, float scale, const float* scale0, const float* scale1,
-                                    float thr, int iters, uint32_t seed, int lm_iters, int min_points, int integer_keypoints, float* kp0,
-                                    float* kp1, double* M,
-                                    float* M_f32, float* Minv_f32, int32_t* valid, uint8_t* keep, void* workspace,
-                                    size_t workspace_bytes, void* stream) {
+extern "C" int gf_ransac_homography_v2(const float* mkpts0_c, const float* mkpts1_c, const int32_t* counts, int N,
+                                       int capacity, float scale, const float* scale0, const float* scale1,
+                                       float thr, int iters, uint32_t seed, int min_points, int integer_keypoints, float* kp0,
+                                       float* kp1, double* M,
+                                       float* M_f32, float* Minv_f32, int32_t* valid, uint8_t* keep, void* workspace,
+                                       size_t workspace_bytes, void* stream, int lm_iters) {
     GF_CHECK_ARG(mkpts0_c && mkpts1_c && counts && kp0 && kp1 && M && M_f32 && Minv_f32 && valid && keep, "null pointer");
     GF_CHECK_ARG(N > 0 && capacity > 0 && iters > 0 && iters % 4 == 0, "need N, capacity > 0 and iters a positive multiple of 4");
     GF_CHECK_ARG((scale0 == nullptr) == (scale1 == nullptr), "scale0/scale1 must both be set or both be NULL");
     if (workspace == nullptr || workspace_bytes < gf_ransac_workspace_bytes(N, iters)) {
-        gf_set_error("gf_ransac_homography: workspace too small");
+        gf_set_error("gf_ransac_homography_v2: workspace too small");
         return GF_ERR_WORKSPACE;
     }
     RsArgs a;
@@ -457,4 +457,15 @@ extern "C" int gf_ransac_homography(const float* mkpts0_c, const float* mkpts1_c
     ransac_final<<<N, 256, 0, st>>>(a);
     GF_CHECK_LAUNCH();
     return GF_OK;
+}
+
+// the version-1 entry point (rounds 1-2): no refinement behind the refit - callers built against that header keep their M
+extern "C" int gf_ransac_homography(const float* mkpts0_c, const float* mkpts1_c, const int32_t* counts, int N,
+                                    int capacity, float scale, const float* scale0, const float* scale1,
+                                    float thr, int iters, uint32_t seed, int min_points, int integer_keypoints, float* kp0,
+                                    float* kp1, double* M,
+                                    float* M_f32, float* Minv_f32, int32_t* valid, uint8_t* keep, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    return gf_ransac_homography_v2(mkpts0_c, mkpts1_c, counts, N, capacity, scale, scale0, scale1, thr, iters, seed, min_points,
+                                   integer_keypoints, kp0, kp1, M, M_f32, Minv_f32, valid, keep, workspace, workspace_bytes, stream, 0);
 }

@@ -92,9 +92,19 @@ def cv2_resize_linear_u8(src, wt, ht):
 
 
 def load_gray_image(im_path):
-    """[H,W] uint8 like cv2.imread(im_path, cv2.IMREAD_GRAYSCALE)."""
+    """[H,W] uint8 like cv2.imread(im_path, cv2.IMREAD_GRAYSCALE) (data_io.py:50).
+    PNG / PPM / BMP colour files (HPatches is PPM): OpenCV decodes BGR and applies its fixed-point BGR2GRAY - `cv2_gray_u8`,
+    byte for byte.  JPEG (the FIRE / ISC evaluation images): OpenCV hands IMREAD_GRAYSCALE to libjpeg as
+    out_color_space = JCS_GRAYSCALE, i.e. the decoder emits the Y plane of the file's YCbCr data itself and no RGB image ever
+    exists; PIL's `draft('L', ...)` configures libjpeg the same way, so that path is used for JPEG files (bit-equal to the Y
+    channel of a YCbCr decode: tests/test_matcher_cpu.py).  Limits: a CMYK / RGB-encoded (Adobe) JPEG falls back to the
+    formula on the decoded RGB, and libjpeg-turbo vs libjpeg IDCT differences between the two installations are not ours to pin."""
     from PIL import Image
     im = Image.open(im_path)
+    if im.format in ('JPEG', 'MPO') and im.mode in ('RGB', 'L'):
+        im.draft('L', im.size)                                       # libjpeg JCS_GRAYSCALE, what OpenCV asks for
+        if im.mode == 'L':
+            return np.array(im, dtype=np.uint8)
     if im.mode in ('RGB', 'RGBA', 'P', 'CMYK', 'YCbCr'):
         return cv2_gray_u8(np.array(im.convert('RGB'), dtype=np.uint8))
     return np.array(im.convert('L'), dtype=np.uint8)

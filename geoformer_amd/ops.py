@@ -63,7 +63,10 @@ def match_only_supported(f0, f1, masked=False, force_one=False):
 
 def dual_softmax_conf_at(f0, f1, temperature, b, i, j):
     """Single entries conf[b, i, j] (fp32 [P]) recomputed bit-identically to the matrix gf_dual_softmax_match writes, from the same
-    features and the statistics its last call on this device left in the workspace (match-only mode's way to a few values)."""
+    features and the statistics its last call on this device and stream left in the workspace (match-only mode's way to a few
+    values).  The workspace is stamped by that call with (N, L, S, C, temperature, the two feature pointers): when the stamp
+    does not belong to THESE arguments - another pair of feature tensors was matched since (GeoFormer.forward runs two
+    CoarseMatching passes on one workspace), the shape changed - or an index is out of range, the entry comes back NaN."""
     _need_cuda(f0, f1)
     f0, f1 = _contig(f0), _contig(f1)
     N, L, C = f0.shape
@@ -246,9 +249,10 @@ def ransac_homography(mkpts0_c, mkpts1_c, counts, N, scale, scale0=None, scale1=
     L_ = _lib.lib()
     nbytes = L_.gf_ransac_workspace_bytes(N, iters)
     ws = _ws.get('ransac', nbytes, dev)
-    check(L_.gf_ransac_homography(_p(mkpts0_c), _p(mkpts1_c), _p(counts), N, max(cap, 1), float(scale), _p(s0), _p(s1),
-                                  float(thr), int(iters), int(seed), int(lm_iters), int(min_points), int(bool(integer_keypoints)), _p(kp[0]), _p(kp[1]), _p(M), _p(Mf[0]), _p(Mf[1]),
-                                  _p(valid), _p(keep), _p(ws), ws.numel(), _stream()), 'gf_ransac_homography')
+    check(L_.gf_ransac_homography_v2(_p(mkpts0_c), _p(mkpts1_c), _p(counts), N, max(cap, 1), float(scale), _p(s0), _p(s1),
+                                     float(thr), int(iters), int(seed), int(min_points), int(bool(integer_keypoints)), _p(kp[0]), _p(kp[1]),
+                                     _p(M), _p(Mf[0]), _p(Mf[1]), _p(valid), _p(keep), _p(ws), ws.numel(), _stream(), int(lm_iters)),
+          'gf_ransac_homography_v2')
     return {'kp0': kp[0], 'kp1': kp[1], 'M': M, 'M_f32': Mf[0], 'Minv_f32': Mf[1], 'valid': valid, 'keep': keep}
 
 

@@ -18,8 +18,11 @@ from .. import ops
 
 class WeightCache:
     """16-bit copies of the fp32 master weights and their transposes, made once per step (a weight is used by several layer
-    calls - both images, forward and backward - and every cast or transpose is a launch the host pays for).  `TrainStep`
-    clears it behind the optimizer step."""
+    calls - both images, forward and backward - and every cast or transpose is a launch the host pays for).  An entry is
+    valid for one VERSION of one storage: the hit check compares the parameter's identity, its `_version` counter (every
+    in-place write - optimizer.step(), load_state_dict's copy_ - bumps it) and its data pointer (`p.data = ...`), so a
+    training loop that uses the HIP Functions without `TrainStep` (functional.set_hip_backward is public) never runs on
+    stale 16-bit weights.  `TrainStep` still clears the cache behind the optimizer step to drop the dead copies early."""
 
     def __init__(self):
         self._w, self._wt = {}, {}
@@ -30,9 +33,12 @@ class WeightCache:
 
     def cast(self, w, dtype):
         key = (id(w), dtype)
+        stamp = (w._version, w.data_ptr())
         hit = self._w.get(key)
-        if hit is None or hit[0] is not w:
-            hit = (w, w.detach().to(dtype))
+        if hit is None or hit[0] is not w or hit[2] != stamp:
+            if hit is not None:
+                self._wt.pop(id(hit[1]), None)                         # the transposed copy of the superseded cast
+            hit = (w, w.detach().to(dtype), stamp)
             self._w[key] = hit
         return hit[1]
 

@@ -30,6 +30,12 @@ extern "C" {
 typedef enum { GF_OK = 0, GF_ERR_INVALID_ARGUMENT = -1, GF_ERR_WORKSPACE = -2, GF_ERR_LAUNCH = -3 } gf_status;
 typedef enum { GF_F32 = 0, GF_F16 = 1, GF_BF16 = 2 } gf_dtype;
 
+/* Bumped whenever an existing entry point changes its signature or its defaults; a binding compares gf_abi_version() with the
+ * GF_ABI_VERSION of the header it was written against at load time (geoformer_amd/_lib.py does) instead of calling shifted
+ * arguments.  History: 1 = rounds 1-2; 2 = round 3 (gf_ransac_homography had gained `lm_iters` in the MIDDLE of its list: a
+ * caller built against version 1 would have passed min_points as lm_iters); 3 = round 4: gf_ransac_homography is back to its
+ * version-1 signature (no refinement), new arguments live in gf_ransac_homography_v2, appended at the END. */
+#define GF_ABI_VERSION 3
 int gf_abi_version(void);
 const char* gf_last_error(void);
 
@@ -65,7 +71,9 @@ int gf_profile_collect(const char* tag, double* total_ms, int* count, double* wo
  *   gf_dual_softmax_match_only_supported: 16-bit features, C = 256, L % 128 == 0, S % 64 == 0, no masks,
  *   force_one == 0; anything else with conf == NULL is GF_ERR_INVALID_ARGUMENT.
  *   gf_dual_softmax_conf_at returns single entries conf[b,i,j] afterwards (same features, the workspace of the
- *   last gf_dual_softmax_match call), bit-identical to what the contract mode writes.
+ *   last gf_dual_softmax_match call), bit-identical to what the contract mode writes.  gf_dual_softmax_match stamps
+ *   the workspace with (N, L, S, C, temperature, f0, f1); conf_at compares the stamp with its own arguments ON THE
+ *   DEVICE (no host synchronisation) and writes NaN for every entry if they differ, and for any b/i/j out of range.
  * ------------------------------------------------------------------------------------------ */
 size_t gf_dual_softmax_workspace_bytes(int N, int L, int S);
 int gf_dual_softmax_match_only_supported(int dtype, int L, int S, int C, int masked, int force_one);
@@ -256,8 +264,9 @@ int gf_linear(const void* a1, long lda1, int k1, const void* a2, long lda2, int 
  * filtering of GeoModule.apply_RANSAC (model/geo_module.py:38-52).  OpenCV parity is unpinned;
  * the algorithm is the one stated in oracle/ransac_oracle.c (bit-exact inlier mask).
  *   mkpts0_c/mkpts1_c [cap,2] fp32 and counts int32[1+N] as written by gf_dual_softmax_match;
- *   lm_iters: Levenberg-Marquardt steps on the inliers' forward transfer error behind the least-squares refit (OpenCV's
- *   findHomography appends 10 to its RANSAC; 0 = none); the inlier mask is the best hypothesis' either way;
+ *   gf_ransac_homography_v2 only - lm_iters: Levenberg-Marquardt steps on the inliers' forward transfer error behind the
+ *   least-squares refit (OpenCV's findHomography appends 10 to its RANSAC; 0 = none = gf_ransac_homography); the inlier mask
+ *   is the best hypothesis' either way;
  *   min_points: samples with fewer matches get no model (GeoModule passes 9: `len(kp0) > 8`, :46);
  *   integer_keypoints = 1: keypoints are truncated like the reference's .long() (GeoModule);
  *   0: sub-pixel keypoints are used as given (homography estimation from fine matches in the
@@ -269,9 +278,14 @@ int gf_linear(const void* a1, long lda1, int k1, const void* a2, long lda2, int 
 size_t gf_ransac_workspace_bytes(int N, int iters);
 int gf_ransac_homography(const float* mkpts0_c, const float* mkpts1_c, const int32_t* counts, int N,
                          int capacity, float scale, const float* scale0, const float* scale1, float thr,
-                         int iters, uint32_t seed, int lm_iters, int min_points, int integer_keypoints, float* kp0, float* kp1, double* M,
+                         int iters, uint32_t seed, int min_points, int integer_keypoints, float* kp0, float* kp1, double* M,
                          float* M_f32, float* Minv_f32, int32_t* valid, uint8_t* keep, void* workspace,
                          size_t workspace_bytes, void* stream);
+int gf_ransac_homography_v2(const float* mkpts0_c, const float* mkpts1_c, const int32_t* counts, int N,
+                            int capacity, float scale, const float* scale0, const float* scale1, float thr,
+                            int iters, uint32_t seed, int min_points, int integer_keypoints, float* kp0, float* kp1, double* M,
+                            float* M_f32, float* Minv_f32, int32_t* valid, uint8_t* keep, void* workspace,
+                            size_t workspace_bytes, void* stream, int lm_iters);
 
 /* ------------------------------------------------------------------------------------------
  * a8  window geometry

@@ -48,7 +48,10 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 def test_abi_version_and_workspace_queries(lib):
     h = lib.lib()
-    assert h.gf_abi_version() == 1
+    # the binding checks the version at load; the header's macro, the library and the binding agree
+    import re as _re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'geoformer_hip.h')).read()
+    assert h.gf_abi_version() == lib.ABI_VERSION == int(_re.search(r'#define GF_ABI_VERSION (\d+)', hdr).group(1))
     assert h.gf_dual_softmax_workspace_bytes(1, 6400, 6400) > 6400 * 8
     assert h.gf_dual_softmax_workspace_bytes(0, 1, 1) == 0
     assert h.gf_linear_attention_workspace_bytes(2, 6400, 8, 32) > 0

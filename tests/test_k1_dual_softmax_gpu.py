@@ -188,6 +188,16 @@ def test_match_only_equals_contract_mode(dtype, thr):
     got = ops.dual_softmax_conf_at(f0, f1, 0.1, bb, ii, jj)
     want = a['conf_matrix'][bb.to(dev), ii.to(dev), jj.to(dev)]
     assert torch.equal(got, want)
+    # the statistics in the workspace are tied to the call that left them - out-of-range indices, other feature
+    # tensors (a second CoarseMatching pass on the same workspace) or another temperature give NaN, not silent garbage
+    bad = ops.dual_softmax_conf_at(f0, f1, 0.1, torch.tensor([0, N, 0, 0]), torch.tensor([0, 0, L, -1]), torch.tensor([0, 0, 0, 0]))
+    assert not torch.isnan(bad[0]) and bool(torch.isnan(bad[1:]).all())
+    assert bool(torch.isnan(ops.dual_softmax_conf_at(f0, f1, 0.2, bb[:8], ii[:8], jj[:8])).all())
+    f1b = f1.clone()
+    assert bool(torch.isnan(ops.dual_softmax_conf_at(f0, f1b, 0.1, bb[:8], ii[:8], jj[:8])).all())
+    ops.dual_softmax_match(f0, f1b, 0.1, thr, (h, w), (h, w), 8.0, materialize=False)      # the workspace now belongs to (f0, f1b)
+    assert bool(torch.isnan(ops.dual_softmax_conf_at(f0, f1, 0.1, bb[:8], ii[:8], jj[:8])).all())
+    assert torch.equal(ops.dual_softmax_conf_at(f0, f1b, 0.1, bb, ii, jj), want)
     # outside the configuration the library is built for, the wrapper materialises the matrix as usual
     c = ops.dual_softmax_match(f0[:, :100].contiguous(), f1, 0.1, thr, (10, 10), (h, w), 8.0, materialize=False)
     assert c['conf_matrix'] is not None

@@ -73,3 +73,30 @@ def test_load_gray_scale_tensor_is_the_uint8_pipeline(tmp_path):
     want = MT.cv2_resize_linear_u8(MT.cv2_gray_u8(rgb), 184, 160)
     np.testing.assert_array_equal((t[0, 0].numpy() * 255).round().astype(np.uint8), want)          # k / 255 for integer k: to_tensor
     assert float((t * 255 - (t * 255).round()).abs().max()) < 1e-4
+
+
+def test_jpeg_grayscale_is_the_decoders_luma_plane(tmp_path):
+    """cv2.imread(path, IMREAD_GRAYSCALE) on a JPEG lets libjpeg emit the Y plane (JCS_GRAYSCALE); it is NOT the
+    BGR2GRAY formula on the decoded RGB.  load_gray_image takes the same libjpeg path: its result equals channel 0 of a
+    YCbCr decode of the file bit for bit, and differs from the fixed-point formula on the RGB decode."""
+    from PIL import Image
+    from geoformer_amd.matcher import cv2_gray_u8, load_gray_image
+    rng = np.random.default_rng(7)
+    base = rng.integers(0, 256, (12, 16, 3)).astype(np.uint8)
+    rgb = np.kron(base, np.ones((8, 8, 1), np.uint8))                       # blocky colour image, 96 x 128
+    rgb = np.clip(rgb.astype(np.int32) + rng.integers(-6, 7, rgb.shape), 0, 255).astype(np.uint8)
+    path = str(tmp_path / 'pair.jpg')
+    Image.fromarray(rgb).save(path, quality=90, subsampling=2)
+    got = load_gray_image(path)
+    ycc = Image.open(path)
+    ycc.draft('YCbCr', ycc.size)
+    luma = np.array(ycc)[..., 0]
+    assert got.shape == (96, 128) and got.dtype == np.uint8
+    np.testing.assert_array_equal(got, luma)
+    formula = cv2_gray_u8(np.array(Image.open(path).convert('RGB'), dtype=np.uint8))
+    assert int(np.abs(formula.astype(int) - got.astype(int)).max()) >= 1    # the two really are different functions
+    assert float(np.abs(formula.astype(int) - got.astype(int)).mean()) < 1.0  # ... of nearly the same thing (RGB clipping: up to ~10 at saturated pixels)
+    # a PNG of the same image still goes through the fixed-point formula
+    png = str(tmp_path / 'pair.png')
+    Image.fromarray(rgb).save(png)
+    np.testing.assert_array_equal(load_gray_image(png), cv2_gray_u8(rgb))

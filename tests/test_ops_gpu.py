@@ -1,6 +1,8 @@
 """Op-level parity of the HIP kernels (through the C ABI) against the reference's golden vectors and
 the oracle.  fp32 = parity mode (tight tolerances, exact integers); fp16 = oracle on the same
 rounded inputs."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -150,6 +152,38 @@ def test_ransac_matches_c_oracle_bit_exact_mask():
             exact(rs['keep'][off:off + n], np.ones(n))                 # no model: every match feeds the maps
         off += n
     assert [int(v) for v in rs['valid']] == [1, 0, 1, 0, 1, 1]
+    # lm_iters = 0 (what the version-1 entry point gf_ransac_homography runs) reproduces the model of rounds 1-2,
+    # pinned by a fixture the round-2 C oracle wrote (oracle/gen_ransac_golden.py): mask bit-exact, M to 1e-9
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g17_ransac_lm0.npz'))
+    r0 = ops.ransac_homography(mk0.to(DEV), mk1.to(DEV), counts.to(DEV), N, 8, lm_iters=0)
+    v1 = _ransac_v1(mk0.to(DEV), mk1.to(DEV), counts.to(DEV), N, 8)
+    off = 0
+    for b, (p0, p1) in enumerate(sets):
+        n = len(p0)
+        assert int(r0['valid'][b]) == int(G[f's{b}_valid']) == int(v1['valid'][b])
+        if int(G[f's{b}_valid']):
+            exact(r0['keep'][off:off + n], np.unpackbits(G[f's{b}_mask'])[:n])
+            close(r0['M'][b].double(), G[f's{b}_M'], 1e-9, 1e-9)
+            assert torch.equal(v1['M'][b], r0['M'][b]) and torch.equal(v1['keep'][off:off + n], r0['keep'][off:off + n])
+        off += n
+
+
+def _ransac_v1(mk0, mk1, counts, N, scale):
+    """The version-1 C entry point (no lm_iters argument) called directly."""
+    from geoformer_amd import _lib, ops
+    from geoformer_amd.ops import _p, _stream, _ws
+    cap = mk0.shape[0]
+    kp = torch.empty(2, cap, 2, dtype=torch.float32, device=DEV)
+    M = torch.empty(N, 3, 3, dtype=torch.float64, device=DEV)
+    Mf = torch.empty(2, N, 3, 3, dtype=torch.float32, device=DEV)
+    valid = torch.empty(N, dtype=torch.int32, device=DEV)
+    keep = torch.empty(cap, dtype=torch.uint8, device=DEV)
+    L_ = _lib.lib()
+    ws = _ws.get('ransac', L_.gf_ransac_workspace_bytes(N, ops.RANSAC_ITERS), mk0.device)
+    _lib.check(L_.gf_ransac_homography(_p(mk0), _p(mk1), _p(counts), N, cap, float(scale), None, None, 8.0, ops.RANSAC_ITERS,
+                                       ops.RANSAC_SEED, 9, 1, _p(kp[0]), _p(kp[1]), _p(M), _p(Mf[0]), _p(Mf[1]), _p(valid), _p(keep),
+                                       _p(ws), ws.numel(), _stream()), 'gf_ransac_homography')
+    return {'M': M, 'valid': valid, 'keep': keep}
 
 
 # ------------------------------------------------------------------ a8 / a12

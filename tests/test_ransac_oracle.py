@@ -57,3 +57,26 @@ def test_deterministic_and_sample_dependent():
     a = R.find_homography(p0, p1, sample=0)
     b = R.find_homography(p0, p1, sample=0)
     np.testing.assert_array_equal(a[0], b[0]); np.testing.assert_array_equal(a[1], b[1])
+
+
+def test_lm_iters_zero_reproduces_the_pre_refinement_model(golden):
+    """ADVICE r03: g17 was written by the C oracle of commit a02ec81 (rounds 1-2, before the Levenberg-Marquardt refinement;
+    oracle/gen_ransac_golden.py builds it from the git history).  Today's oracle with lm_iters = 0 must return the same
+    inlier mask bit for bit and the same M; with the default 10 LM steps the mask is still the best hypothesis' (unchanged)
+    and M moves by less than the cell quantisation."""
+    from gen_ransac_golden import point_sets
+    G = golden('g17_ransac_lm0')
+    for b, (p0, p1) in enumerate(point_sets()):
+        M0, mask0 = R.find_homography(p0, p1, sample=b, lm_iters=0)
+        n = int(G[f's{b}_n'])
+        want_mask = np.unpackbits(G[f's{b}_mask'])[:n]
+        assert (M0 is not None) == bool(G[f's{b}_valid']), b
+        if M0 is None:
+            continue
+        np.testing.assert_array_equal(mask0[:, 0], want_mask)
+        np.testing.assert_allclose(M0, G[f's{b}_M'], rtol=1e-12, atol=1e-12)
+        M10, mask10 = R.find_homography(p0, p1, sample=b)
+        np.testing.assert_array_equal(mask10[:, 0], want_mask)
+        corners = np.array([[0, 0, 1], [640, 0, 1], [0, 640, 1], [640, 640, 1.]])
+        a, c = corners @ M10.T, corners @ M0.T
+        assert np.linalg.norm(a[:, :2] / a[:, 2:] - c[:, :2] / c[:, 2:], axis=1).max() < 8.0

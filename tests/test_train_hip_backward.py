@@ -205,3 +205,35 @@ def test_hip_backward_train_step_matches_autocast_step():
     print(f'cosine of the coarse-loss gradients (autocast vs HIP backward) {dot / (na * nb):.4f}')
     assert dot / (na * nb) > 0.97
     assert all(np.isfinite(l1)) and l1[-1] < l1[0], l1
+
+
+def test_hip_functions_follow_a_hand_stepped_optimizer():
+    """functional.set_hip_backward(True) WITHOUT TrainStep (nobody clears the weight cache): after every
+    optimizer step the HIP linear must multiply by the UPDATED weight - its output tracks F.linear of the current bf16 cast,
+    and three SGD steps move the loss exactly as the same three steps through torch autograd do (same bf16 operands)."""
+    from geoformer_amd.train import hip_autograd as HA
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(2, 256, 256, generator=g)).to(DEV).to(torch.bfloat16)
+    tgt = torch.randn(2, 256, 128, generator=g).to(DEV)
+    w0 = (torch.randn(128, 256, generator=g) / 16).to(DEV)
+
+    def run(hip):
+        w = torch.nn.Parameter(w0.clone())
+        opt = torch.optim.SGD([w], lr=0.05)
+        losses = []
+        for _ in range(3):
+            y = HA.linear(x, w) if hip else F.linear(x, w.to(torch.bfloat16))
+            if hip:                                                        # the product uses the weight of THIS step
+                torch.testing.assert_close(y.float(), F.linear(x, w.detach().to(torch.bfloat16)).float(), rtol=2e-2, atol=2e-2)
+            loss = ((y.float() - tgt) ** 2).mean()
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        return losses, w.detach().clone()
+    HA.WEIGHTS.clear()
+    l_hip, w_hip = run(True)
+    l_ref, w_ref = run(False)
+    assert l_hip[2] < l_hip[1] < l_hip[0]
+    np.testing.assert_allclose(l_hip, l_ref, rtol=2e-3)
+    assert float((w_hip - w_ref).norm() / (w_ref - w0).norm()) < 2e-2
