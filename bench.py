@@ -79,6 +79,12 @@ def parse_args(argv=None):
     ap.add_argument('--tune', action='store_true', help='let MIOpen search its convolution algorithms (minutes)')
     ap.add_argument('--save-db', action='store_true', help='with --tune: copy the searched find-db over geoformer_amd/miopen_db')
     ap.add_argument('--graphs', action='store_true', help='replay the static part of the forward from a captured hipGraph (GeoFormer.enable_graphs)')
+    ap.add_argument('--repeats', type=int, default=3,
+                    help='timed regions of K steps each: the FIRST is `value` (W warm-up steps, then exactly K timed steps); the others '
+                         'follow it back to back and only feed the min / median / max of `repeats` in the line')
+    ap.add_argument('--independent', action='store_true',
+                    help="with --pairs planted: feed the matching path the planted maps WITHOUT the data dependency on that step's backbone "
+                         'output (rounds 3\'s headline; now the side measurement nominal_independent)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the nominal-load and fp32 parity-mode side measurements')
     ap.add_argument('--dry-run', action='store_true',
@@ -368,10 +374,38 @@ def planted_features(batch, seed, grid=80, noise=0.35, device='cpu', dtype=None)
     return tuple(t.to(device=device, dtype=dtype).contiguous(memory_format=torch.channels_last) for t in (c0, f0, c1, f1))
 
 
-def measure(model, batches, steps, warmup, nstreams, dev, dist, log, profile_tag=None, L=None, planted=None):
-    """W untimed + K timed steps of `model` over the resident `batches`; returns (elapsed_s, pipelines, step_fn).
-    planted = per-batch (c0, f0, c1, f1): the backbone still runs on the images (its cost stays in the step) but the
-    matching path is fed the planted feature maps."""
+def planted_maps(batch, seed, grid, device, dtype):
+    """planted_features as the backbone hands its output over: ONE coarse and ONE fine tensor holding the image-0 maps, then the
+    image-1 maps ([2N, 256, h, w], [2N, 128, 4h, 4w], channels_last) - what `planted_step` adds the backbone's output to."""
+    import torch
+    c0, f0, c1, f1 = planted_features(batch, seed, grid)
+    cl = torch.channels_last
+    return {'c': torch.cat([c0, c1], 0).to(device=device, dtype=dtype).contiguous(memory_format=cl),
+            'f': torch.cat([f0, f1], 0).to(device=device, dtype=dtype).contiguous(memory_format=cl)}
+
+
+def planted_step(model, i0, i1, pl, dependent):
+    """One nominal-load step.  dependent (the default workload): the matching path consumes THAT STEP's backbone output - every
+    feature map it reads is `planted + 0 * backbone_output`, one fused elementwise pass per map on the device (the values are the
+    planted ones bit for bit, so the matches are those of the planted run, but no kernel of the matching path can start before
+    the backbone's last kernel has written its maps: the reference's data dependency, full_model.py:55-61,83-101).  Not dependent:
+    the backbone output is discarded and the resident planted maps are read directly (round 3's headline)."""
+    import torch
+    n = i0.shape[0]
+    feats_c, feats_f = model._backbone(torch.cat([i0, i1], dim=0))
+    if not dependent:
+        return model.forward_features({'image0': i0, 'image1': i1}, pl['c'][:n], pl['f'][:n], pl['c'][n:], pl['f'][n:])
+    c = torch.add(pl['c'], feats_c, alpha=0.0)
+    f = torch.add(pl['f'], feats_f, alpha=0.0)
+    return model.forward_features({'image0': i0, 'image1': i1}, c[:n], f[:n], c[n:], f[n:])
+
+
+def measure(model, batches, steps, warmup, nstreams, dev, dist, log, profile_tag=None, L=None, planted=None, dependent=True,
+            repeats=1):
+    """W untimed + K timed steps of `model` over the resident `batches`; returns (elapsed_s, pipelines, step_fn, repeat_times).
+    planted = per-batch {'c': [2N,256,h,w], 'f': [2N,128,4h,4w]} (image-0 maps, then image-1 maps): the backbone runs on the
+    images and the matching path is fed the planted feature maps, through the backbone's output when `dependent`.
+    repeats > 1: further timed regions of K steps each behind the first (which alone is `elapsed_s`)."""
     import torch
     nres = len(batches)
 
@@ -380,8 +414,7 @@ def measure(model, batches, steps, warmup, nstreams, dev, dist, log, profile_tag
         with torch.no_grad():
             if planted is None:
                 return model({'image0': i0, 'image1': i1})
-            model._backbone(torch.cat([i0, i1], dim=0))
-            return model.forward_features({'image0': i0, 'image1': i1}, *planted[i % nres])
+            return planted_step(model, i0, i1, planted[i % nres], dependent)
     pipes = Pipelines(step, max(1, min(nstreams, steps)), dev)
     step(0)                          # single-threaded first pass: fills the weight / table caches
     torch.cuda.synchronize()
@@ -425,7 +458,24 @@ def measure(model, batches, steps, warmup, nstreams, dev, dist, log, profile_tag
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    return time.perf_counter() - t0, pipes, step
+    elapsed = time.perf_counter() - t0
+    if profile_tag is not None:
+        L.gf_profile_enable(0)                       # the in-region k1_conf figure belongs to the headline region only
+    times = [elapsed]
+    for r in range(1, repeats):                      # the same K steps again, bracketed the same way; not part of `value`
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        pipes.run(warmup + r * steps, steps)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t)
+    if profile_tag is not None:
+        L.gf_profile_enable(1)
+    return elapsed, pipes, step, times
 
 
 def load_pmc(path, run_cfg):
@@ -467,8 +517,10 @@ def host_launch_us(model, batches, planted):
             elif planted is None:
                 model.forward_static({'image0': i0, 'image1': i1})
             else:
-                model._backbone(torch.cat([i0, i1], dim=0))
-                model.forward_features({'image0': i0, 'image1': i1}, *planted[0], static_only=True)
+                n = i0.shape[0]
+                fc, ff = model._backbone(torch.cat([i0, i1], dim=0))
+                c, f = torch.add(planted[0]['c'], fc, alpha=0.0), torch.add(planted[0]['f'], ff, alpha=0.0)
+                model.forward_features({'image0': i0, 'image1': i1}, c[:n], f[:n], c[n:], f[n:], static_only=True)
             ts.append(time.perf_counter() - t)
     torch.cuda.synchronize()
     return 1e6 * min(ts[1:])
@@ -525,7 +577,7 @@ def main(argv=None):
     planted = None
     if args.pairs == 'planted':
         batches = resident('shift')
-        planted = [planted_features(args.batch, 60000 + lo + i, args.size // 8, device=dev, dtype=model.compute_dtype) for i in range(nres)]
+        planted = [planted_maps(args.batch, 60000 + lo + i, args.size // 8, dev, model.compute_dtype) for i in range(nres)]
     else:
         batches = resident(args.pairs)
     log('model + inputs ready')
@@ -550,7 +602,9 @@ def main(argv=None):
         bb_ms = backbone_ms_per_pair()
         log(f'backbone {bb_ms:.2f} ms/pair after the search')
 
-    elapsed, pipes, step = measure(model, batches, args.steps, args.warmup, args.streams, dev, dist, log, b'k1_conf', L, planted)
+    dependent = not args.independent
+    elapsed, pipes, step, rep_times = measure(model, batches, args.steps, args.warmup, args.streams, dev, dist, log, b'k1_conf', L, planted,
+                                              dependent, max(1, args.repeats))
     log('timed region done')
     nstreams = 1 if pipes.serial else pipes.n
     res_rows = [pipes.results[i] for i in range(args.warmup, args.warmup + args.steps)]
@@ -576,13 +630,14 @@ def main(argv=None):
     L.gf_profile_enable(0)
     host_us = host_launch_us(model, batches, planted)
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+        t = torch.tensor(rep_times, device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                # every region: the slowest rank's time
+        rep_times = [float(v) for v in t]
+        elapsed = rep_times[0]
         rows = [None] * world
-        dist.all_gather_object(rows, (sum(Ms), sum(Mfs), len(Ms)))
+        dist.all_gather_object(rows, (sum(Ms), sum(Mfs), len(Ms), rank, lo, hi))
     else:
-        rows = [(sum(Ms), sum(Mfs), len(Ms))]
+        rows = [(sum(Ms), sum(Mfs), len(Ms), rank, lo, hi)]
     if rank != 0:
         pipes.close()
         if dist is not None:
@@ -631,23 +686,35 @@ def main(argv=None):
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': {'fp16': 'f16', 'bf16': 'bf16', 'fp32': 'f32'}[args.precision], 'data': 'synthetic',
+        # the spread of the measurement: `repeats` timed regions of K steps each, back to back; [0] is `value`
+        'repeats': {'n': len(rep_times), 'pairs_per_s': [pairs / t for t in rep_times], 'min': pairs / max(rep_times),
+                    'median': pairs / sorted(rep_times)[len(rep_times) // 2], 'max': pairs / min(rep_times)},
+        'shard_plan': sorted([list(r[3:6]) for r in rows]),     # [rank, first pair, one past the last pair] of the job's pair list
         'config': {'workload': f'batched inference, synthetic {args.size}x{args.size} pairs (BASELINE configs[4]: static shard of the '
                                f'pair list, {args.steps * args.batch} pairs per GPU), ' +
                                ('NOMINAL LOAD: ResNet-FPN backbone on the images, matching path on planted-correspondence feature maps '
-                                '(image-1 maps = image-0 maps shifted by one coarse cell + noise)' if args.pairs == 'planted' else
+                                '(image-1 maps = image-0 maps shifted by one coarse cell + noise)' +
+                                (" fed THROUGH that step's backbone output (every map the matching path reads = planted + 0 x backbone output, "
+                                 'one fused pass per map: the forward\'s data dependency is kept, the values are the planted ones)'
+                                 if dependent else ', backbone output discarded (no data dependency between the two halves of the step)')
+                                if args.pairs == 'planted' else
                                 f'image1 = {args.pairs} of image0, full forward incl. ResNet-FPN backbone') +
                                f'; closed-form random-init weights; coarse_thr={args.coarse_thr} fine_thr={args.fine_thr}',
                    'pairs_per_gpu_per_step': args.batch, 'global_pairs_per_step': args.batch * world,
                    'coarse_matches_per_pair': tot_M / tot_steps / args.batch, 'fine_matches_per_pair': tot_Mf / tot_steps / args.batch,
                    'inlier_cells_per_pair': K, 'parallelism': f'pair-shard x{world} (no collective)',
-                   'host_pipelines_per_gpu': nstreams, 'hip_graphs': bool(args.graphs), **run_cfg},
+                   'host_pipelines_per_gpu': nstreams, 'hip_graphs': bool(args.graphs),
+                   'backbone_dependency': bool(dependent) if args.pairs == 'planted' else True, **run_cfg},
         'host_launch_us_per_step': host_us,
         'roofline': dominant,
         'roofline_kernels': entries,
     }
     pipes.close()
     if world == 1 and not args.no_extras:
-        res['side_measurements'] = side_measurements(args, model, dev, log, L)
+        res['side_measurements'] = side_measurements(args, model, dev, log, L, batches, planted)
+        ind = res['side_measurements'].get('nominal_independent')
+        if ind:                                   # what the two extra elementwise passes of the dependency cost the headline
+            res['side_measurements']['dependency_cost_pct'] = 100.0 * (ind['value'] - res['value']) / ind['value']
     if not args.no_cpu_baseline and world == 1:          # reported on rank 0 at N = 1 only
         res['cpu_baseline'] = cpu_baseline(W, args.coarse_thr, args.fine_thr, args.size, args.pairs)
     print(json.dumps(res), flush=True)
@@ -657,8 +724,11 @@ def main(argv=None):
         dist.destroy_process_group()
 
 
-def side_measurements(args, model, dev, log, L):
+def side_measurements(args, model, dev, log, L, batches=None, planted=None):
     """More throughput figures of the same job, N = 1 only (they are not `value`):
+      nominal_independent  (when `value` is the nominal load) the headline step WITHOUT the data dependency on the backbone
+                          output (the backbone's maps are discarded, the planted maps are read in place: round 3's headline);
+                          `value` pays two extra elementwise passes for the dependency (`dependency_cost_pct`);
       matching_path_only  the hot path alone: `forward_features` on resident planted-correspondence feature maps (no
                           backbone in the step) at the nominal load - what the HIP kernels of SURVEY section 8(a) take;
       matching_path_match_only  the same with the opt-in match-only K1 (conf matrices not materialised);
@@ -681,6 +751,13 @@ def side_measurements(args, model, dev, log, L):
                 'inlier_cells_per_pair': int(nidx[:, 0].float().mean()) if nidx is not None else None}
     nominal = args.pairs == 'planted'
     mn = model if nominal else build_model(args.precision, 0.2, 0.1, dev)[0]       # the reference's thresholds (geo_config.py:13,15)
+    if nominal and planted is not None:
+        el, p, _, _ = measure(model, batches, steps, 3, args.streams, dev, None, log, planted=planted, dependent=bool(args.independent))
+        key = 'nominal_dependent' if args.independent else 'nominal_independent'
+        out[key] = summary(el, p, steps, 3, 'the headline step ' + ('WITH' if args.independent else 'WITHOUT') + " the data dependency on that "
+                           "step's backbone output")
+        p.close()
+        log(f"{key}: {out[key]['value']:.1f} pairs/s")
     feats = [planted_features(args.batch, 60000 + i, args.size // 8, device=dev, dtype=mn.compute_dtype) for i in range(2)]
     zero = torch.zeros(args.batch, 1, args.size, args.size, device=dev)
 
@@ -708,7 +785,7 @@ def side_measurements(args, model, dev, log, L):
         if args.graphs:
             ml.enable_graphs()
         homo = [synth_pairs(args.batch, seed=i * args.batch, size=args.size, device=dev, kind='homography') for i in range(2)]
-        el, p, _ = measure(ml, homo, steps, 3, args.streams, dev, None, log)
+        el, p, _, _ = measure(ml, homo, steps, 3, args.streams, dev, None, log)
         out['light_load'] = summary(el, p, steps, 3, 'full forward incl. backbone on homography image pairs, thresholds 0 (random-init '
                                     'weights: few matches; the headline workload of rounds 1-2)')
         p.close()
@@ -716,7 +793,9 @@ def side_measurements(args, model, dev, log, L):
         log(f"light load: {out['light_load']['value']:.1f} pairs/s at M = {out['light_load']['coarse_matches_per_pair']:.0f}")
     else:
         imgs = [synth_pairs(args.batch, seed=50000 + i * args.batch, size=args.size, device=dev, kind='shift') for i in range(2)]
-        el, p, _ = measure(mn, imgs, steps, 3, args.streams, dev, None, log, planted=feats)
+        pm = [planted_maps(args.batch, 60000 + i, args.size // 8, dev, mn.compute_dtype) for i in range(2)]
+        el, p, _, _ = measure(mn, imgs, steps, 3, args.streams, dev, None, log, planted=pm)
+        del pm
         out['nominal_load'] = summary(el, p, steps, 3, 'backbone on the images + matching path on planted-correspondence feature maps '
                                       '(shift by one coarse cell + noise), coarse_thr 0.2, fine_thr 0.1')
         p.close()
@@ -732,11 +811,11 @@ def side_measurements(args, model, dev, log, L):
         s32 = max(4, min(args.steps, 10))
         if nominal:
             imgs = [synth_pairs(args.batch, seed=i * args.batch, size=args.size, device=dev, kind='shift') for i in range(2)]
-            f32 = [planted_features(args.batch, 60000 + i, args.size // 8, device=dev, dtype=torch.float32) for i in range(2)]
-            el, p, _ = measure(m32, imgs, s32, 2, 1, dev, None, log, planted=f32)
+            f32 = [planted_maps(args.batch, 60000 + i, args.size // 8, dev, torch.float32) for i in range(2)]
+            el, p, _, _ = measure(m32, imgs, s32, 2, 1, dev, None, log, planted=f32)
         else:
             imgs = [synth_pairs(args.batch, seed=i * args.batch, size=args.size, device=dev, kind=args.pairs) for i in range(2)]
-            el, p, _ = measure(m32, imgs, s32, 2, 1, dev, None, log)
+            el, p, _, _ = measure(m32, imgs, s32, 2, 1, dev, None, log)
         p.close()
         out['parity_mode'] = {'value': s32 * args.batch / el, 'unit': 'image-pairs/s', 'steps': s32, 'ms_per_step': 1e3 * el / s32,
                               'dtype': 'f32', 'note': 'the same workload in fp32 storage with exact-fp32 MFMA (v_mfma_f32_32x32x2_f32); '
