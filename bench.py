@@ -401,11 +401,13 @@ def planted_step(model, i0, i1, pl, dependent):
 
 
 def measure(model, batches, steps, warmup, nstreams, dev, dist, log, profile_tag=None, L=None, planted=None, dependent=True,
-            repeats=1):
+            repeats=1, pipes=None):
     """W untimed + K timed steps of `model` over the resident `batches`; returns (elapsed_s, pipelines, step_fn, repeat_times).
     planted = per-batch {'c': [2N,256,h,w], 'f': [2N,128,4h,4w]} (image-0 maps, then image-1 maps): the backbone runs on the
     images and the matching path is fed the planted feature maps, through the backbone's output when `dependent`.
-    repeats > 1: further timed regions of K steps each behind the first (which alone is `elapsed_s`)."""
+    repeats > 1: further timed regions of K steps each behind the first (which alone is `elapsed_s`).
+    pipes: host pipelines of an earlier measurement to reuse (same threads, streams, per-stream workspaces, MIOpen handles and
+    allocator pools: a SECOND set of pipelines measured ~10 % slower than the first in the same process, whatever it ran)."""
     import torch
     nres = len(batches)
 
@@ -415,7 +417,10 @@ def measure(model, batches, steps, warmup, nstreams, dev, dist, log, profile_tag
             if planted is None:
                 return model({'image0': i0, 'image1': i1})
             return planted_step(model, i0, i1, planted[i % nres], dependent)
-    pipes = Pipelines(step, max(1, min(nstreams, steps)), dev)
+    if pipes is None:
+        pipes = Pipelines(step, max(1, min(nstreams, steps)), dev)
+    else:
+        pipes.step_fn, pipes.results = step, {}
     step(0)                          # single-threaded first pass: fills the weight / table caches
     torch.cuda.synchronize()
     # each pipeline thread owns its MIOpen handle: let every one of them look its convolution algorithms up ALONE
@@ -709,12 +714,12 @@ def main(argv=None):
         'roofline': dominant,
         'roofline_kernels': entries,
     }
-    pipes.close()
     if world == 1 and not args.no_extras:
-        res['side_measurements'] = side_measurements(args, model, dev, log, L, batches, planted)
+        res['side_measurements'] = side_measurements(args, model, dev, log, L, batches, planted, pipes)
         ind = res['side_measurements'].get('nominal_independent')
         if ind:                                   # what the two extra elementwise passes of the dependency cost the headline
             res['side_measurements']['dependency_cost_pct'] = 100.0 * (ind['value'] - res['value']) / ind['value']
+    pipes.close()
     if not args.no_cpu_baseline and world == 1:          # reported on rank 0 at N = 1 only
         res['cpu_baseline'] = cpu_baseline(W, args.coarse_thr, args.fine_thr, args.size, args.pairs)
     print(json.dumps(res), flush=True)
@@ -724,7 +729,7 @@ def main(argv=None):
         dist.destroy_process_group()
 
 
-def side_measurements(args, model, dev, log, L, batches=None, planted=None):
+def side_measurements(args, model, dev, log, L, batches=None, planted=None, pipes=None):
     """More throughput figures of the same job, N = 1 only (they are not `value`):
       nominal_independent  (when `value` is the nominal load) the headline step WITHOUT the data dependency on the backbone
                           output (the backbone's maps are discarded, the planted maps are read in place: round 3's headline);
@@ -752,11 +757,10 @@ def side_measurements(args, model, dev, log, L, batches=None, planted=None):
     nominal = args.pairs == 'planted'
     mn = model if nominal else build_model(args.precision, 0.2, 0.1, dev)[0]       # the reference's thresholds (geo_config.py:13,15)
     if nominal and planted is not None:
-        el, p, _, _ = measure(model, batches, steps, 3, args.streams, dev, None, log, planted=planted, dependent=bool(args.independent))
+        el, p, _, _ = measure(model, batches, steps, 3, args.streams, dev, None, log, planted=planted, dependent=bool(args.independent), pipes=pipes)
         key = 'nominal_dependent' if args.independent else 'nominal_independent'
         out[key] = summary(el, p, steps, 3, 'the headline step ' + ('WITH' if args.independent else 'WITHOUT') + " the data dependency on that "
                            "step's backbone output")
-        p.close()
         log(f"{key}: {out[key]['value']:.1f} pairs/s")
     feats = [planted_features(args.batch, 60000 + i, args.size // 8, device=dev, dtype=mn.compute_dtype) for i in range(2)]
     zero = torch.zeros(args.batch, 1, args.size, args.size, device=dev)
@@ -764,41 +768,37 @@ def side_measurements(args, model, dev, log, L, batches=None, planted=None):
     def feat_step(i):
         with torch.no_grad():
             return mn.forward_features({'image0': zero, 'image1': zero}, *feats[i % 2])
-    el, p = measure_fn(feat_step, steps, 3, args.streams, dev)
+    el, p = measure_fn(feat_step, steps, 3, args.streams, dev, pipes)
     out['matching_path_only'] = summary(el, p, steps, 3, 'matching path only (forward_features on resident planted-correspondence '
                                         'feature maps: no backbone in the step), coarse_thr 0.2, fine_thr 0.1')
-    p.close()
     log(f"matching path only: {out['matching_path_only']['value']:.1f} pairs/s ({out['matching_path_only']['ms_per_step']:.2f} ms per "
         f"{args.batch} pairs) at M = {out['matching_path_only']['coarse_matches_per_pair']:.0f}")
     if args.precision != 'fp32':
         # match-only K1 (opt-in, geoformer_cfg['materialize_conf'] = False): conf_matrix / dect_conf_matrix are not written
         # (2 x 164 MB per pair), matches bit-identical; a side measurement only - the contract mode is what `value` runs
         mn.coarse_matching.materialize_conf = False
-        el, p = measure_fn(feat_step, steps, 3, args.streams, dev)
+        el, p = measure_fn(feat_step, steps, 3, args.streams, dev, pipes)
         mn.coarse_matching.materialize_conf = True
         out['matching_path_match_only'] = summary(el, p, steps, 3, 'matching path only, match-only K1 (conf matrices not materialised), '
                                                   'coarse_thr 0.2, fine_thr 0.1')
-        p.close()
         log(f"matching path, match-only K1: {out['matching_path_match_only']['value']:.1f} pairs/s")
     if nominal:
         ml, _ = build_model(args.precision, 0.0, 0.0, dev)
         if args.graphs:
             ml.enable_graphs()
         homo = [synth_pairs(args.batch, seed=i * args.batch, size=args.size, device=dev, kind='homography') for i in range(2)]
-        el, p, _, _ = measure(ml, homo, steps, 3, args.streams, dev, None, log)
+        el, p, _, _ = measure(ml, homo, steps, 3, args.streams, dev, None, log, pipes=pipes)
         out['light_load'] = summary(el, p, steps, 3, 'full forward incl. backbone on homography image pairs, thresholds 0 (random-init '
                                     'weights: few matches; the headline workload of rounds 1-2)')
-        p.close()
         del ml, homo
         log(f"light load: {out['light_load']['value']:.1f} pairs/s at M = {out['light_load']['coarse_matches_per_pair']:.0f}")
     else:
         imgs = [synth_pairs(args.batch, seed=50000 + i * args.batch, size=args.size, device=dev, kind='shift') for i in range(2)]
         pm = [planted_maps(args.batch, 60000 + i, args.size // 8, dev, mn.compute_dtype) for i in range(2)]
-        el, p, _, _ = measure(mn, imgs, steps, 3, args.streams, dev, None, log, planted=pm)
+        el, p, _, _ = measure(mn, imgs, steps, 3, args.streams, dev, None, log, planted=pm, pipes=pipes)
         del pm
         out['nominal_load'] = summary(el, p, steps, 3, 'backbone on the images + matching path on planted-correspondence feature maps '
                                       '(shift by one coarse cell + noise), coarse_thr 0.2, fine_thr 0.1')
-        p.close()
         log(f"nominal load: {out['nominal_load']['value']:.1f} pairs/s at M = {out['nominal_load']['coarse_matches_per_pair']:.0f}, "
             f"K = {out['nominal_load']['inlier_cells_per_pair']}")
         del imgs
@@ -826,10 +826,13 @@ def side_measurements(args, model, dev, log, L, batches=None, planted=None):
     return out
 
 
-def measure_fn(step, steps, warmup, nstreams, dev):
+def measure_fn(step, steps, warmup, nstreams, dev, pipes=None):
     """`measure` for an arbitrary step function (side measurements): warm-up, then `steps` timed steps on the pipelines."""
     import torch
-    pipes = Pipelines(step, max(1, min(nstreams, steps)), dev)
+    if pipes is None:
+        pipes = Pipelines(step, max(1, min(nstreams, steps)), dev)
+    else:
+        pipes.step_fn, pipes.results = step, {}
     step(0)
     torch.cuda.synchronize()
     for w in range(pipes.n):

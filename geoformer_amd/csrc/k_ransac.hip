@@ -3,10 +3,15 @@
 // fixing its output); this kernel implements, operation for operation and in fp64 with contraction
 // off, the algorithm stated in oracle/ransac_oracle.c, so the inlier mask can be checked bit-exactly.
 //
-//   ransac_score : grid (T/4, N), one wave per hypothesis: lane 0 draws 4 correspondences with the
-//                  counter-based hash and solves the 8x8 system; all lanes count inliers.
+//   ransac_score : grid (T/32, N), 8 hypotheses per wave: each group of 8 lanes draws 4 correspondences with the
+//                  counter-based hash and solves its 8x8 system with ONE ROW PER LANE (rs_solve8: the oracle's
+//                  elimination, every element operation unchanged, rows exchanged by shuffles); then all 64 lanes
+//                  count the inliers of the wave's 8 hypotheses in one pass over the matches.
+//                  [Round 3: one hypothesis per wave, lane 0 solving alone on a scratch-memory matrix - the serial
+//                  solve, not the scoring, was the kernel's 144 us.]
 //   ransac_final : grid N: best hypothesis (most inliers, then smallest t), inlier mask, Hartley-
-//                  normalised least-squares refit (block reductions), M, M^-1 (fp64 adjugate), fp32 casts.
+//                  normalised least-squares refit (block reductions; the 8x8 solves on eight lanes as above),
+//                  Levenberg-Marquardt steps, M, M^-1 (fp64 adjugate), fp32 casts.
 // No host synchronisation: match counts are read from device memory.
 #include <math.h>
 
@@ -83,6 +88,64 @@ __device__ int rs_solve(double* a, double* b, int n) {
     return 1;
 }
 
+// rs_solve with the 8 rows of the system on 8 consecutive lanes (lane r of the group holds row r: a[0..7] and b in registers):
+// the same partial-pivot elimination, element operation for element operation - a row operation a[r][k] - f a[c][k] is the same
+// IEEE operation on whichever lane it runs, the pivot is the FIRST row of maximal |a[r][c]| as in the serial loop, and the back
+// substitution subtracts a[c][k] x[k] in ascending k - so the solution has the serial code's bits (the inlier mask test against
+// oracle/ransac_oracle.c requires it).  Every lane of the group returns the solution x[0..7] and the ok flag.  The caller's
+// lanes must all be active (shuffles); groups are independent.
+__device__ __forceinline__ double rs_shfl(double v, int src) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = __shfl((unsigned)b, src, 64), hi = __shfl((unsigned)(b >> 32), src, 64);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ int rs_solve8(double (&a)[8], double& b, double (&x)[8]) {
+    const int lane = threadIdx.x & 63, g0 = lane & ~7, r = lane & 7;
+    int ok = 1;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        // pivot: first row >= c of maximal |a[r][c]|
+        double best = r >= c ? fabs(a[c]) : -1.0;
+        int p = r;
+#pragma unroll
+        for (int d = 1; d < 8; d <<= 1) {
+            const double ob = rs_shfl(best, lane ^ d);
+            const int op = __shfl(p, lane ^ d, 64);
+            const bool take = ob > best || (ob == best && op < p);
+            best = take ? ob : best;
+            p = take ? op : p;
+        }
+        if (!(best > 1e-12)) ok = 0;                       // (uniform in the group; the remaining steps run on, the result is discarded)
+        // swap rows c and p
+        const int src = g0 + (r == c ? p : (r == p ? c : r));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = rs_shfl(a[k], src);
+        b = rs_shfl(b, src);
+        // eliminate below: the pivot row to every lane
+        double pr[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pr[k] = k >= c ? rs_shfl(a[k], g0 + c) : 0.0;
+        const double pb = rs_shfl(b, g0 + c);
+        const double inv = 1.0 / pr[c];
+        const double f = a[c] * inv;
+        if (r > c && f != 0.0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k >= c) a[k] = a[k] - f * pr[k];
+            b = b - f * pb;
+        }
+    }
+#pragma unroll
+    for (int c = 7; c >= 0; --c) {
+        double s = b;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k > c) s = s - a[k] * x[k];
+        x[c] = rs_shfl(s / a[c], g0 + c);                   // lane c holds row c: its value is the one that counts
+    }
+    return ok;
+}
+
 __device__ __forceinline__ int rs_inlier(const double* h, double x, double y, double u, double v, double thr2) {
     const double w = h[6] * x + h[7] * y + h[8];
     if (w == 0.0) return 0;
@@ -124,84 +187,114 @@ __global__ void ransac_keypoints(RsArgs a) {
 }
 
 __global__ __launch_bounds__(256) void ransac_score(RsArgs a) {
-    __shared__ double sh_h[4][9];
-    __shared__ int sh_ok[4];
-    const int n = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + wave;
+    const int n = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> 3, r = lane & 7;
+    const int t = (blockIdx.x * 4 + wave) * 8 + grp;                   // this lane group's hypothesis
     int off, cnt;
     rs_range(a, n, off, cnt);
-    if (cnt < a.min_points || t >= a.iters) return;  // geo_module.py:46 (uniform per block / wave)
+    if (cnt < a.min_points) return;                                    // geo_module.py:46 (uniform per block)
     const float* k0 = a.kp0 + 2 * (size_t)off;
     const float* k1 = a.kp1 + 2 * (size_t)off;
-    if (lane == 0) {
-        int idx[4], ok = 1;
-        for (int k = 0; k < 4 && ok; ++k) {
-            int found = 0;
-            for (uint32_t attempt = 0; attempt < 16 && !found; ++attempt) {
-                const int c = (int)(draw(a.seed, (uint32_t)n, (uint32_t)t, (uint32_t)k, attempt) % (uint32_t)cnt);
-                int dup = 0;
-                for (int j = 0; j < k; ++j) dup |= (idx[j] == c);
-                if (!dup) { idx[k] = c; found = 1; }
-            }
-            ok = found;
+    // ---- the 4 correspondences of hypothesis t (every lane of the group draws the same four) and row r of its 8x8 system
+    int idx[4], ok = t < a.iters;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int found = 0;
+        for (uint32_t attempt = 0; attempt < 16 && !found && ok; ++attempt) {
+            const int c = (int)(draw(a.seed, (uint32_t)n, (uint32_t)t, (uint32_t)k, attempt) % (uint32_t)cnt);
+            int dup = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dup |= (j < k && idx[j] == c);
+            if (!dup) { idx[k] = c; found = 1; }
         }
-        double m[64], b[8];
-        if (ok) {
-            for (int k = 0; k < 4; ++k) {
-                const double x = (double)k0[2 * idx[k]], y = (double)k0[2 * idx[k] + 1];
-                const double u = (double)k1[2 * idx[k]], v = (double)k1[2 * idx[k] + 1];
-                double* r0 = m + (2 * k) * 8;
-                double* r1 = m + (2 * k + 1) * 8;
-                r0[0] = x; r0[1] = y; r0[2] = 1; r0[3] = 0; r0[4] = 0; r0[5] = 0; r0[6] = -(u * x); r0[7] = -(u * y);
-                r1[0] = 0; r1[1] = 0; r1[2] = 0; r1[3] = x; r1[4] = y; r1[5] = 1; r1[6] = -(v * x); r1[7] = -(v * y);
-                b[2 * k] = u; b[2 * k + 1] = v;
-            }
-            ok = rs_solve(m, b, 8);
-        }
-        sh_ok[wave] = ok;
-        if (ok) {
-            for (int k = 0; k < 8; ++k) sh_h[wave][k] = b[k];
-            sh_h[wave][8] = 1.0;
+        if (!found) { ok = 0; idx[k] = 0; }
+    }
+    const int pt = r >> 1;
+    const int ip = pt == 0 ? idx[0] : pt == 1 ? idx[1] : pt == 2 ? idx[2] : idx[3];
+    const double x = (double)k0[2 * ip], y = (double)k0[2 * ip + 1], u = (double)k1[2 * ip], v = (double)k1[2 * ip + 1];
+    double row[8], rhs, h8[8];
+    if ((r & 1) == 0) {
+        row[0] = x; row[1] = y; row[2] = 1; row[3] = 0; row[4] = 0; row[5] = 0; row[6] = -(u * x); row[7] = -(u * y);
+        rhs = u;
+    } else {
+        row[0] = 0; row[1] = 0; row[2] = 0; row[3] = x; row[4] = y; row[5] = 1; row[6] = -(v * x); row[7] = -(v * y);
+        rhs = v;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) h8[k] = 0.0;
+    ok = rs_solve8(row, rhs, h8) && ok;
+    // ---- the wave's 8 hypotheses to every lane, one pass over the matches
+    double H[8][8];
+    int okg[8], c[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) H[g][k] = rs_shfl(h8[k], 8 * g);
+        okg[g] = __shfl(ok, 8 * g, 64);
+        c[g] = 0;
+    }
+    for (int i = lane; i < cnt; i += 64) {
+        const double px = (double)k0[2 * i], py = (double)k0[2 * i + 1], qx = (double)k1[2 * i], qy = (double)k1[2 * i + 1];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const double hh[9] = {H[g][0], H[g][1], H[g][2], H[g][3], H[g][4], H[g][5], H[g][6], H[g][7], 1.0};
+            c[g] += rs_inlier(hh, px, py, qx, qy, a.thr2);
         }
     }
-    __syncthreads();
-    int32_t* out_cnt = a.hyp_cnt + (size_t)n * a.iters + t;
-    if (!sh_ok[wave]) {
-        if (lane == 0) *out_cnt = -1;
-        return;
-    }
-    double h[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) h[k] = sh_h[wave][k];
-    int c = 0;
-    for (int i = lane; i < cnt; i += 64)
-        c += rs_inlier(h, (double)k0[2 * i], (double)k0[2 * i + 1], (double)k1[2 * i], (double)k1[2 * i + 1], a.thr2);
+    for (int g = 0; g < 8; ++g)
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
-    if (lane == 0) {
-        *out_cnt = c;
-        double* hp = a.hyp + ((size_t)n * a.iters + t) * 9;
+        for (int d = 32; d >= 1; d >>= 1) c[g] += __shfl_xor(c[g], d, 64);
+    // lane 8g + k writes element k of hypothesis g (k = 0..7), lane 8g also the count and h33 = 1
+    const int tg = (blockIdx.x * 4 + wave) * 8 + grp;
+    if (tg < a.iters) {
+        int cg = 0, og = 0;
+        double hv = 0.0;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) hp[k] = h[k];
+        for (int g = 0; g < 8; ++g) {
+            cg = grp == g ? c[g] : cg;
+            og = grp == g ? okg[g] : og;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) hv = (grp == g && r == k) ? H[g][k] : hv;
+        }
+        double* hp = a.hyp + ((size_t)n * a.iters + tg) * 9;
+        if (og) hp[r] = hv;
+        if (r == 0) {
+            if (og) hp[8] = 1.0;
+            a.hyp_cnt[(size_t)n * a.iters + tg] = og ? cg : -1;
+        }
     }
 }
 
-// sum over the 256 threads with TWO barriers for all NV values: lanes by shuffles, the four waves through LDS (added in wave
+// one DPP exchange of a double (both halves; v_mov_b32 dpp has ALU latency - the ds_bpermute butterfly this replaces spent ~100
+// cycles per step and value: 44 values x 6 steps were most of a Levenberg-Marquardt iteration's 20 us)
+template <int CTRL>
+__device__ __forceinline__ double rs_dpp(double x) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double rs_readlane(double x, int l) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// sum over the 64 lanes, returned in every lane: quad (xor 1, xor 2), half row (mirror within 8), row (mirror within 16) by DPP -
+// a + b = b + a bit for bit, so both partners of an exchange hold the same value - then the four row sums through scalar registers
+__device__ __forceinline__ double rs_wave_sum(double x) {
+    x = x + rs_dpp<0xB1>(x);                          // quad_perm [1,0,3,2]
+    x = x + rs_dpp<0x4E>(x);                          // quad_perm [2,3,0,1]
+    x = x + rs_dpp<0x141>(x);                         // row_half_mirror
+    x = x + rs_dpp<0x140>(x);                         // row_mirror
+    return ((rs_readlane(x, 0) + rs_readlane(x, 16)) + rs_readlane(x, 32)) + rs_readlane(x, 48);
+}
+// sum over the 256 threads with TWO barriers for all NV values: lanes by DPP, the four waves through LDS (added in wave
 // order).  `part` = [4][NV] doubles of LDS; the result is returned in every thread.
 template <int NV>
 __device__ void block_sum_fast(double (&v)[NV], double* part) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        double x = v[k];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const unsigned long long b = (unsigned long long)__double_as_longlong(x);
-            const unsigned lo = __shfl_xor((unsigned)b, d, 64), hi = __shfl_xor((unsigned)(b >> 32), d, 64);
-            x = x + __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-        }
-        v[k] = x;
-    }
+    for (int k = 0; k < NV; ++k) v[k] = rs_wave_sum(v[k]);
     __syncthreads();                                 // the previous call's readers are done with `part`
     if (lane == 0) {
 #pragma unroll
@@ -297,21 +390,37 @@ __global__ __launch_bounds__(256) void ransac_final(RsArgs a) {
             for (int i2 = 0; i2 < 8; ++i2) ne[36 + i2] += r0[i2] * u + r1[i2] * v;
         }
     block_sum_fast(ne, sh);
-    if (t == 0) {
-        double ata[64], atb[8], g[9];                   // (this g: the refit's result, handed on through LDS)
-        int q = 0;
-        for (int i2 = 0; i2 < 8; ++i2)
-            for (int j2 = i2; j2 < 8; ++j2) { ata[i2 * 8 + j2] = ne[q]; ata[j2 * 8 + i2] = ne[q]; ++q; }
-        for (int i2 = 0; i2 < 8; ++i2) atb[i2] = ne[36 + i2];
-        bool refit = rs_solve(ata, atb, 8) != 0;
+    if (t < 64) {                                     // wave 0: lanes 0..7 hold the rows of the symmetric system (all 64 lanes run the shuffles)
+        const int r = t & 7;
+        double rowa[8], rb, sol[8], g[9];               // (this g: the refit's result, handed on through LDS)
+#pragma unroll
+        for (int j2 = 0; j2 < 8; ++j2) {
+            double v = 0.0;                              // ata[r][j2] = ne[tri(min, max)]
+            int q = 0;
+#pragma unroll
+            for (int i3 = 0; i3 < 8; ++i3)
+#pragma unroll
+                for (int j3 = i3; j3 < 8; ++j3) {
+                    const int lo_ = r < j2 ? r : j2, hi_ = r < j2 ? j2 : r;
+                    v = (i3 == lo_ && j3 == hi_) ? ne[q] : v;
+                    ++q;
+                }
+            rowa[j2] = v;
+        }
+        rb = 0.0;
+#pragma unroll
+        for (int i3 = 0; i3 < 8; ++i3) rb = r == i3 ? ne[36 + i3] : rb;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sol[k] = 0.0;
+        bool refit = rs_solve8(rowa, rb, sol) != 0;
         if (refit) {
             double hn[9], am[9];
-            for (int k = 0; k < 8; ++k) hn[k] = atb[k];
+            for (int k = 0; k < 8; ++k) hn[k] = sol[k];
             hn[8] = 1.0;
-            for (int r = 0; r < 3; ++r) {
-                am[3 * r + 0] = hn[3 * r + 0] * s0;
-                am[3 * r + 1] = hn[3 * r + 1] * s0;
-                am[3 * r + 2] = hn[3 * r + 2] - s0 * (hn[3 * r + 0] * c0x + hn[3 * r + 1] * c0y);
+            for (int rr = 0; rr < 3; ++rr) {
+                am[3 * rr + 0] = hn[3 * rr + 0] * s0;
+                am[3 * rr + 1] = hn[3 * rr + 1] * s0;
+                am[3 * rr + 2] = hn[3 * rr + 2] - s0 * (hn[3 * rr + 0] * c0x + hn[3 * rr + 1] * c0y);
             }
             for (int c = 0; c < 3; ++c) {
                 g[c] = am[c] / s1 + c1x * am[6 + c];
@@ -324,7 +433,8 @@ __global__ __launch_bounds__(256) void ransac_final(RsArgs a) {
         }
         if (!refit)
             for (int k = 0; k < 9; ++k) g[k] = h[k];
-        for (int k = 0; k < 9; ++k) sh_lm[k] = g[k];
+        if (t == 0)
+            for (int k = 0; k < 9; ++k) sh_lm[k] = g[k];
     }
     __syncthreads();
     // ---- Levenberg-Marquardt on the inliers' forward transfer error, 8 free entries (h33 = 1): what OpenCV's findHomography
@@ -333,28 +443,17 @@ __global__ __launch_bounds__(256) void ransac_final(RsArgs a) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) g[k] = sh_lm[k];
     if (a.lm_iters > 0) {
-        auto sq_error = [&](const double* hh) {
-            double e[1] = {0.0};
+        // error and normal equations at hh in ONE pass and ONE block reduction: v[0..35] = upper triangle of J^T J, v[36..43] = J^T r,
+        // v[44] = the squared error.  (The oracle recomputes J^T J at the top of every iteration; at an unchanged estimate that is the
+        // same matrix, so it is kept here when a step is rejected and taken from the candidate's evaluation when it is accepted.)
+        auto evaluate = [&](const double* hh, double (&v)[45]) {
+#pragma unroll
+            for (int k = 0; k < 45; ++k) v[k] = 0.0;
             for (int i = t; i < cnt; i += 256)
                 if (keep[i]) {
                     const double x = (double)k0[2 * i], y = (double)k0[2 * i + 1];
                     const double iw = 1.0 / (hh[6] * x + hh[7] * y + 1.0);
-                    const double du = (hh[0] * x + hh[1] * y + hh[2]) * iw - (double)k1[2 * i], dv = (hh[3] * x + hh[4] * y + hh[5]) * iw - (double)k1[2 * i + 1];
-                    e[0] += du * du + dv * dv;
-                }
-            block_sum_fast(e, sh);
-            return e[0];
-        };
-        double lambda = 1e-3, err = sq_error(g);
-        for (int it = 0; it < a.lm_iters; ++it) {
-            double ne2[44];                              // upper triangle of J^T J (36) | J^T r (8)
-#pragma unroll
-            for (int k = 0; k < 44; ++k) ne2[k] = 0.0;
-            for (int i = t; i < cnt; i += 256)
-                if (keep[i]) {
-                    const double x = (double)k0[2 * i], y = (double)k0[2 * i + 1];
-                    const double iw = 1.0 / (g[6] * x + g[7] * y + 1.0);
-                    const double up = (g[0] * x + g[1] * y + g[2]) * iw, vp = (g[3] * x + g[4] * y + g[5]) * iw;
+                    const double up = (hh[0] * x + hh[1] * y + hh[2]) * iw, vp = (hh[3] * x + hh[4] * y + hh[5]) * iw;
                     const double ju[8] = {x * iw, y * iw, iw, 0, 0, 0, -(x * up) * iw, -(y * up) * iw};
                     const double jv[8] = {0, 0, 0, x * iw, y * iw, iw, -(x * vp) * iw, -(y * vp) * iw};
                     const double ru = up - (double)k1[2 * i], rv = vp - (double)k1[2 * i + 1];
@@ -362,23 +461,50 @@ __global__ __launch_bounds__(256) void ransac_final(RsArgs a) {
 #pragma unroll
                     for (int i2 = 0; i2 < 8; ++i2) {
 #pragma unroll
-                        for (int j2 = i2; j2 < 8; ++j2) ne2[q++] += ju[i2] * ju[j2] + jv[i2] * jv[j2];
+                        for (int j2 = i2; j2 < 8; ++j2) v[q++] += ju[i2] * ju[j2] + jv[i2] * jv[j2];
                     }
 #pragma unroll
-                    for (int i2 = 0; i2 < 8; ++i2) ne2[36 + i2] += ju[i2] * ru + jv[i2] * rv;
+                    for (int i2 = 0; i2 < 8; ++i2) v[36 + i2] += ju[i2] * ru + jv[i2] * rv;
+                    v[44] += ru * ru + rv * rv;
                 }
-            block_sum_fast(ne2, sh);
-            if (t == 0) {
-                double A[64], d[8];
-                int q = 0;
-                for (int i2 = 0; i2 < 8; ++i2)
-                    for (int j2 = i2; j2 < 8; ++j2) { A[i2 * 8 + j2] = ne2[q]; A[j2 * 8 + i2] = ne2[q]; ++q; }
-                for (int i2 = 0; i2 < 8; ++i2) { A[i2 * 8 + i2] = A[i2 * 8 + i2] + lambda * A[i2 * 8 + i2]; d[i2] = -ne2[36 + i2]; }
-                const int ok = rs_solve(A, d, 8);
-                sh_lm_ok = ok;
-                if (ok) {
-                    for (int k = 0; k < 8; ++k) sh_lm[k] = g[k] + d[k];
-                    sh_lm[8] = 1.0;
+            block_sum_fast(v, sh);
+        };
+        double ne2[45], nen[45];
+        evaluate(g, ne2);
+        double lambda = 1e-3, err = ne2[44];
+        // residuals at rounding level already (RMS below 1e-9 px): nothing to refine (exact correspondences - the steps would
+        // only chase the last bits of the error sum); stated in oracle/ransac_oracle.c:lm_refine too
+        const int iters = err <= 1e-18 * m ? 0 : a.lm_iters;
+        for (int it = 0; it < iters; ++it) {
+            if (t < 64) {                                // wave 0, rows on lanes 0..7 (see the refit)
+                const int r = t & 7;
+                double rowa[8], rb, d[8];
+#pragma unroll
+                for (int j2 = 0; j2 < 8; ++j2) {
+                    double v = 0.0;
+                    int q = 0;
+#pragma unroll
+                    for (int i3 = 0; i3 < 8; ++i3)
+#pragma unroll
+                        for (int j3 = i3; j3 < 8; ++j3) {
+                            const int lo_ = r < j2 ? r : j2, hi_ = r < j2 ? j2 : r;
+                            v = (i3 == lo_ && j3 == hi_) ? ne2[q] : v;
+                            ++q;
+                        }
+                    rowa[j2] = r == j2 ? v + lambda * v : v;
+                }
+                rb = 0.0;
+#pragma unroll
+                for (int i3 = 0; i3 < 8; ++i3) rb = r == i3 ? -ne2[36 + i3] : rb;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) d[k] = 0.0;
+                const int ok = rs_solve8(rowa, rb, d);
+                if (t == 0) {
+                    sh_lm_ok = ok;
+                    if (ok) {
+                        for (int k = 0; k < 8; ++k) sh_lm[k] = g[k] + d[k];
+                        sh_lm[8] = 1.0;
+                    }
                 }
             }
             __syncthreads();
@@ -390,11 +516,14 @@ __global__ __launch_bounds__(256) void ransac_final(RsArgs a) {
             double hn[9];
 #pragma unroll
             for (int k = 0; k < 9; ++k) hn[k] = sh_lm[k];
-            const double en = sq_error(hn);              // (its barriers also fence sh_lm against the next iteration's writer)
+            evaluate(hn, nen);                           // (its barriers also fence sh_lm against the next iteration's writer)
+            const double en = nen[44];
             if (en < err) {                              // (every thread holds the same en / err: the exits are uniform)
                 const double gain = err - en;
 #pragma unroll
                 for (int k = 0; k < 9; ++k) g[k] = hn[k];
+#pragma unroll
+                for (int k = 0; k < 45; ++k) ne2[k] = nen[k];
                 lambda = lambda * 0.1;
                 const bool done = gain <= 1e-10 * err;   // converged: the refit's minimum is usually 2-3 steps away
                 err = en;
@@ -453,7 +582,7 @@ extern "C" int gf_ransac_homography_v2(const float* mkpts0_c, const float* mkpts
     hipStream_t st = (hipStream_t)stream;
     const int kb = (capacity / N + 255) / 256;
     ransac_keypoints<<<dim3(kb < 1 ? 1 : (kb > 64 ? 64 : kb), N), 256, 0, st>>>(a);
-    ransac_score<<<dim3(iters / 4, N), 256, 0, st>>>(a);
+    ransac_score<<<dim3((iters + 31) / 32, N), 256, 0, st>>>(a);
     ransac_final<<<N, 256, 0, st>>>(a);
     GF_CHECK_LAUNCH();
     return GF_OK;

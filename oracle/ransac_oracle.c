@@ -118,6 +118,10 @@ static double lm_error(const double* h, const double* p0, const double* p1, cons
  * v' = (h3 x + h4 y + h5) / w, w = h6 x + h7 y + 1;  d u' / d h = [x, y, 1, 0, 0, 0, -x u', -y u'] / w, likewise v'. */
 static void lm_refine(double* h, const double* p0, const double* p1, const uint8_t* mask, int n, int lm_iters) {
     double lambda = 1e-3, err = lm_error(h, p0, p1, mask, n);
+    int m = 0;
+    for (int i = 0; i < n; ++i) m += mask[i];
+    /* residuals at rounding level already (RMS below 1e-9 px: exact correspondences): nothing to refine */
+    if (err <= 1e-18 * (double)m) return;
     for (int it = 0; it < lm_iters; ++it) {
         double jtj[64], jtr[8];
         memset(jtj, 0, sizeof(jtj)); memset(jtr, 0, sizeof(jtr));
