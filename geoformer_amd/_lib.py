@@ -59,6 +59,8 @@ SIGNATURES = {
     'gf_encoder_kv_state': (c_int, [c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'gf_encoder_layer': (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_int, c_void_p, c_float, c_void_p, c_void_p, c_float,
                                  c_float, c_int, c_void_p, c_int, c_void_p, c_long, c_int, c_int, c_int, c_void_p]),
+    'gf_encoder_layer_kv': (c_int, [c_void_p, c_long, c_void_p, c_int, c_void_p, c_float, c_void_p, c_void_p, c_float, c_float, c_int,
+                                    c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'gf_fine_layer': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_float, c_float, c_void_p]),
     'gf_conv3x3_supported': (c_int, [c_int, c_int]),
     'gf_conv3x3_nhwc': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,

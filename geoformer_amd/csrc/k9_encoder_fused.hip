@@ -40,7 +40,7 @@
 #endif
 #if K9_TRACE
 __device__ long long k9_trace[4096 * 4 * 16];
-#define K9_T(slot) do { if (lane == 0 && blockIdx.x < 4096) k9_trace[(blockIdx.x * 4 + wave) * 16 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define K9_T(slot) do { if ((slot) < 16 && lane == 0 && blockIdx.x < 4096) k9_trace[(blockIdx.x * 4 + wave) * 16 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 extern "C" int gf_debug_k9_trace(long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(k9_trace), sizeof(long long) * 4096 * 4 * 16);
 }
@@ -79,6 +79,12 @@ struct EncArgs {
     // enc_kv_state
     const uint8_t* kv_mask; // [N*S] or null
     float* part;            // [N][tiles][C*D + C]
+    // enc_layer's state tail (round 4): the images n >= tail_first ALSO leave the linear-attention state of their OUTPUT rows for
+    // the layer call that reads them as its source: k / v projection with `wstream_tail` (that consumer's W_k | W_v stream)
+    // straight from the finished tile in LDS, per-tile partials in `part` ([N - tail_first][tiles][C*D + C]); q_mask doubles as
+    // the source mask (the rows are the same tokens).  null = no tail.
+    const void* wstream_tail;
+    int tail_first;
 };
 
 // eight fp32 values -> one 16-byte operand; converted in pairs (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32, round to nearest even:
@@ -109,6 +115,20 @@ __device__ __forceinline__ F relu_packed(const F& f) {
 // otherwise - branch-free (a conditional exponential compiles to a divergent branch per element), hardware exponential
 __device__ __forceinline__ float phi(float x) { return fmaxf(x, 0.f) + __builtin_amdgcn_exp2f(fminf(x, 0.f) * 1.44269504088896341f); }
 __device__ __forceinline__ v16f zero16() { return v16f{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; }
+// the lane id recomputed where a late phase needs it (two VALU instructions; volatile: neither hoisted nor merged): carried in a
+// register from the kernel's top it is the 511th live value of enc_layer and gets spilled - and a scratch reload waits for the
+// LDS-DMA in flight
+__device__ __forceinline__ int fresh_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+// x[lane] + x[lane ^ 32] in every lane: one v_permlane32_swap (VALU, no address register, no LDS counter) instead of a ds_bpermute -
+// the permute's byte-address register stayed live from the first LayerNorm to the state tail and was the value that got spilled
+__device__ __forceinline__ float half_sum(float x) {
+    const gf_v2u sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(sw.x) + __uint_as_float(sw.y);
+}
 template <typename T>
 __device__ __forceinline__ float rnd(float x) { return gf_to_float(gf_from_float<T>(x)); }   // round to the storage type
 
@@ -119,11 +139,15 @@ __device__ __forceinline__ float rnd(float x) { return gf_to_float(gf_from_float
 // issue order below survives.
 struct Ring {
     __amdgpu_buffer_rsrc_t rs;   // the stream as a raw buffer of exactly nblk blocks: a request behind its end is out of range (zeros)
+    __amdgpu_buffer_rsrc_t rs2;  // blocks nblk .. nblk + nblk2 - 1 come from a second stream (the state tail's W_k | W_v)
     char* smem;
     int wave, lane, blk, nblk;
 };
-__device__ __forceinline__ Ring ring_make(const void* wstream, char* smem, int wave, int lane, int nblk) {
-    return Ring{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wstream), 0, nblk * WBLK, 0x00020000), smem, wave, lane, 0, nblk};
+__device__ __forceinline__ Ring ring_make(const void* wstream, char* smem, int wave, int lane, int nblk, const void* wstream2 = nullptr,
+                                          int nblk2 = 0) {
+    return Ring{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wstream), 0, nblk * WBLK, 0x00020000),
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wstream2 ? wstream2 : wstream), 0, wstream2 ? nblk2 * WBLK : 0, 0x00020000),
+                smem, wave, lane, 0, nblk};
 }
 // LDS-DMA as buffer_load_dwordx4 ... lds (MUBUF), not global_load_lds: behind a FLAT-encoded LDS-DMA the compiler's wait
 // insertion treats every LDS counter wait as lgkmcnt(0) for as long as the request is pending (it may touch both address
@@ -131,8 +155,10 @@ __device__ __forceinline__ Ring ring_make(const void* wstream, char* smem, int w
 // descriptor and the block offset are scalar: no 64-bit address arithmetic per piece.
 __device__ __forceinline__ void dma_piece(const Ring& g, int b, int i) {
 #if !defined(K9_ABLATE) || K9_ABLATE != 1
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(g.rs, (__attribute__((address_space(3))) void*)(g.smem + W_OFF + (b & 1) * WBLK + (g.wave * 8 + i) * FRAG), 16,
-                                             g.lane * 16 + g.wave * 8 * FRAG, b * WBLK + i * FRAG, 0, 0);
+    // b is wave-uniform: the descriptor select is scalar
+    const bool second = b >= g.nblk;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? g.rs2 : g.rs, (__attribute__((address_space(3))) void*)(g.smem + W_OFF + (b & 1) * WBLK + (g.wave * 8 + i) * FRAG), 16,
+                                             g.lane * 16 + g.wave * 8 * FRAG, (second ? b - g.nblk : b) * WBLK + i * FRAG, 0, 0);
 #endif
 }
 // the next block has landed (every wave waits for its own pieces) and every wave is done reading the current one
@@ -242,6 +268,10 @@ __device__ __forceinline__ void load_tile(const T* base, long ld, int row0, int 
     }
 }
 
+template <typename T>
+__device__ __forceinline__ void kv_tail(Ring& ring, typename Mma32<T>::Frag (&fa)[8], typename Mma32<T>::Frag (&fb)[8], char* smem, unsigned valid,
+                                        float* dst, int wave, int lane, int tid, int trace_base);
+
 template <typename T, int ACT, bool ATTN>
 __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
     using Mm = Mma32<T>;
@@ -254,7 +284,10 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
     constexpr int NBLK = ATTN ? 32 : 28;
     float* vec = reinterpret_cast<float*>(smem + VEC_OFF);
     K9_T(0);
-    Ring ring = ring_make(a.wstream, smem, wave, lane, NBLK);
+    // state tail (see EncArgs): this image's finished rows also leave their linear-attention state; the tail's 8 weight blocks
+    // simply follow the layer's in the ring (requests behind the layer's last block are out of range without a tail: zeros)
+    const bool tail = ATTN && a.wstream_tail != nullptr && n >= a.tail_first;
+    Ring ring = ring_make(a.wstream, smem, wave, lane, NBLK, tail ? a.wstream_tail : nullptr, 8);
     ring_start(ring);
 #if !defined(K9_ABLATE) || K9_ABLATE != 7
     load_tile<T>(xg, a.ldx, t0, a.L, smem, X_OFF, tid);
@@ -345,7 +378,7 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
         }
         K9_T(2);
         // ---------------- linear attention per head: tile h of q is head h (32 channels)
-        const float qmul = (a.q_mask == nullptr || a.q_mask[(size_t)n * a.L + min(tok, a.L - 1)] != 0) ? 1.f : 0.f;
+        const float qmul = (a.q_mask == nullptr || a.q_mask[(size_t)n * a.L + min(t0 + wave * 32 + (fresh_lane() & 31), a.L - 1)] != 0) ? 1.f : 0.f;
         const float eps_s = a.attn_eps / (float)a.S;
         const float* ks = reinterpret_cast<const float*>(smem + KS_OFF);
         // Two-stage pipeline over the heads (same arithmetic, same order per head): stage A(h) = phi, denominator and the two
@@ -379,7 +412,7 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
         };
         auto stage_b = [&](int hh) {
             float d = den[hh & 1];
-            d += __shfl_xor(d, 32, 64);
+            d = half_sum(d);
             const float z = __builtin_amdgcn_rcpf(d + eps_s);
             v16f& nm = num[hh & 1];
 #pragma unroll
@@ -423,8 +456,8 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
                 s += v;
                 qd = fmaf(v, v, qd);
             }
-        s += __shfl_xor(s, 32, 64);
-        qd += __shfl_xor(qd, 32, 64);
+        s = half_sum(s);
+        qd = half_sum(qd);
         mean = s * (1.0f / C);
         rstd = 1.0f / sqrtf(fmaxf(qd - s * mean, 0.f) * (1.0f / C) + eps);
     };
@@ -540,26 +573,22 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
     K9_T(8);
     // the predicate is per sample (flag_rows is a multiple of L in every caller): read it once, wave-uniformly
     const bool keep = a.flag == nullptr || __builtin_amdgcn_readfirstlane(a.flag[((size_t)n * a.L + t0) / a.flag_rows]) != 0;
-    // the ring is idle now: every wave passed the last turn, which also waited for the (clamped, never read) requests behind the
-    // stream's end - except the four of the last block's step 0 and of its turn: drain them before the slab takes the ring's place
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    char* ot = smem + W_OFF + wave * 32 * SLAB_RS;
+    // The finished rows replace the x tile IN PLACE (a lane overwrites exactly the residual bytes it has just read) and leave for
+    // HBM from there, two whole 512-byte rows per store instruction.  [Rounds 2-3 went through a slab in the ring's LDS: the ring had
+    // to be drained first and could not run on into the state tail.]  Only the wave's own 32 rows are touched: no workgroup barrier.
     T* og = (T*)a.out + (size_t)n * a.L * a.ldo;
     // one straight-line body per (layer kept?, tile inside the sequence?): as run-time branches inside the loops every join
     // costs a conservative wait on the stores of the first channel half
     auto finish = [&](auto keep_c, auto full_c) {
         constexpr bool KEEP = decltype(keep_c)::value, FULL = decltype(full_c)::value;
         typedef T v4t __attribute__((ext_vector_type(4)));
-        int el = lane;
-        asm volatile("" : "+v"(el));                                    // slab / row offsets recomputed here, not carried through the layer
-        const int er = el & 31, eh2 = el >> 5, erow = wave * 32 + er, prow = el >> 4, pch = el & 15;
+        const int el = fresh_lane();                                    // row offsets recomputed here, not carried through the layer
+        const int er = el & 31, eh2 = el >> 5, erow = wave * 32 + er;
         // residual x[row][nb*32 + 8g + 4 eh2 ..+3]: 16-B chunk 4 nb + g of the row = k-chunk nb >> 1, slot (4 (nb & 1) + g) ^ swizzle:
         // eight lane-constant slot addresses, everything else is an immediate offset
         int xs[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) xs[k] = X_OFF + gf_lds_off(erow, k) + eh2 * 8;
-        char* slw = ot + er * SLAB_RS + eh2 * 8;
         struct FinOps { v4t x[4]; LnOps ln; };
         auto fin_ops = [&](int nb) {
             FinOps o;
@@ -568,40 +597,39 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
             if constexpr (KEEP) o.ln = ln_ops(vec + 2 * C, vec + 3 * C, nb, eh2);
             return o;
         };
-        FinOps fo[2];
-        fo[0] = fin_ops(0);                                             // the operands of tile nb + 1 are requested before tile nb is computed
+        if constexpr (KEEP) {
+            FinOps fo[2];
+            fo[0] = fin_ops(0);                                         // the operands of tile nb + 1 are requested before tile nb is computed
 #pragma unroll
-        for (int nb = 0; nb < 8; ++nb) {
-            if (nb < 7) fo[(nb + 1) & 1] = fin_ops(nb + 1);
-            const FinOps& p = fo[nb & 1];
+            for (int nb = 0; nb < 8; ++nb) {
+                if (nb < 7) fo[(nb + 1) & 1] = fin_ops(nb + 1);
+                const FinOps& p = fo[nb & 1];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                v4t ov = p.x[g];
-                if constexpr (KEEP) {
+                for (int g = 0; g < 4; ++g) {
                     const v4f y = ln_apply(o[nb], g, p.ln, mean2, rstd2);
+                    v4t ov;
                     ov[0] = gf_from_float<T>(gf_to_float(p.x[g][0]) + y.x);
                     ov[1] = gf_from_float<T>(gf_to_float(p.x[g][1]) + y.y);
                     ov[2] = gf_from_float<T>(gf_to_float(p.x[g][2]) + y.z);
                     ov[3] = gf_from_float<T>(gf_to_float(p.x[g][3]) + y.w);
+                    *reinterpret_cast<v4t*>(smem + xs[4 * (nb & 1) + g] + (nb >> 1) * 16384) = ov;
                 }
-                *reinterpret_cast<v4t*>(slw + ((nb & 3) * 32 + 8 * g) * 2) = ov;
             }
-            if ((nb & 3) == 3) {                                        // a 128-channel half is in the slab: row-contiguous 16-B stores
-                const int hb = nb >> 2;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                v4u rows[8];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        // (layer skipped: out = x, the tile is the result as it stands)
+        // 16-B piece c32 of a row = plane c32 >> 3, slot c32 & 7: lanes 0..31 one row, lanes 32..63 the next
+        const int c32 = el & 31, rsel = el >> 5;
+        v4u rows[16];
 #pragma unroll
-                for (int it = 0; it < 8; ++it) rows[it] = *reinterpret_cast<const v4u*>(ot + (it * 4 + prow) * SLAB_RS + pch * 16);
+        for (int it = 0; it < 16; ++it)
+            rows[it] = *reinterpret_cast<const v4u*>(smem + X_OFF + (c32 >> 3) * 16384 + gf_lds_off(wave * 32 + 2 * it + rsel, c32 & 7));
 #pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int tg = t0 + wave * 32 + it * 4 + prow;
-                    if (FULL || tg < a.L) *reinterpret_cast<v4u*>(og + (size_t)tg * a.ldo + hb * 128 + pch * 8) = rows[it];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
+        for (int it = 0; it < 16; ++it) {
+            const int tg = t0 + wave * 32 + 2 * it + rsel;
+            if (FULL || tg < a.L) *reinterpret_cast<v4u*>(og + (size_t)tg * a.ldo + c32 * 8) = rows[it];
         }
     };
     using std::integral_constant;
@@ -614,6 +642,116 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
         else finish(integral_constant<bool, false>{}, integral_constant<bool, false>{});
     }
     K9_T(9);
+    if constexpr (ATTN) {
+        if (tail) {
+            // the finished rows (storage type, in the x tile's place) are the source tile of the state: masked or out-of-sequence
+            // tokens do not count (linear_attention.py:37-39).  The ring runs on: its next blocks are the tail's W_k | W_v.
+            const int tl = fresh_lane();                                // the tail's lane-derived addresses are computed here, not carried through the layer
+            ring.lane = tl;
+            const int ttok = t0 + wave * 32 + (tl & 31);
+            const bool ok = ttok < a.L && (a.q_mask == nullptr || a.q_mask[(size_t)n * a.L + min(ttok, a.L - 1)] != 0);
+            const unsigned valid = (unsigned)__ballot(ok && (tl >> 5) == 0);
+            kv_tail<T>(ring, fa, fb, smem, valid, a.part + ((size_t)(n - a.tail_first) * a.tiles + tile) * (C * D + C), wave, tl, wave * 64 + tl, 16);
+        }
+    }
+}
+
+// The body both enc_kv_state and enc_layer's state tail run: the token tile is in LDS at X_OFF (x-tile layout), the ring's
+// current block is the first block of a W_k | W_v stream with its step-0 fragments in `fa`; `valid` = bit mask of the wave's 32
+// tokens that count.  Ends with the tile's partial state in `dst`; uses ALL of the workgroup's LDS at the end (the tile and the
+// ring are dead by then).
+template <typename T>
+__device__ __forceinline__ void kv_tail(Ring& ring, typename Mma32<T>::Frag (&fa)[8], typename Mma32<T>::Frag (&fb)[8], char* smem, unsigned valid,
+                                        float* dst, int wave, int lane, int tid, int trace_base) {
+    using Mm = Mma32<T>;
+    using Frag = typename Mm::Frag;
+    const int h2 = lane >> 5, lr = lane & 31;
+    const int myrow = wave * 32 + lr;
+    auto xfrag = [&](int ks) { return *reinterpret_cast<const Frag*>(smem + X_OFF + (ks >> 2) * 16384 + gf_lds_off(myrow, 2 * (ks & 3) + h2)); };
+    auto project = [&](v16f (&acc)[8], auto between) {                  // acc = src tile x W^T: 16 steps (k-step = step)
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+        Frag tf = xfrag(0);
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            Frag (&cur)[8] = (st & 1) ? fb : fa;
+            Frag (&nxt)[8] = (st & 1) ? fa : fb;
+            Frag tn;
+            ring_step<1>(ring, cur, nxt, st & 3, [&](int nb) { Mm::mma(tf, cur[nb], acc[nb]); }, [&] { tn = xfrag(st < 15 ? st + 1 : 15); between(st); });
+            tf = tn;
+        }
+    };
+    // k first; phi(k) = elu + 1, its sum and the packing of head hh as MFMA operands then ride in the gaps of the v projection's
+    // steps 2 hh, 2 hh + 1 (eight values per lane and step: ~60 VALU instructions beside 8 MFMAs) - as a phase of its own between the
+    // two projections they were ~5 of the tail's ~20 thousand cycles with the matrix pipe idle
+    Frag kf[8][2];
+    float ksum[8];
+    float vm[16];                                                       // 1 / 0 per accumulator row (token) of this lane half
+#pragma unroll
+    for (int r = 0; r < 16; ++r) vm[r] = ((valid >> gf_acc_row(r, h2)) & 1u) ? 1.f : 0.f;
+    v16f k[8];
+    project(k, [](int) {});
+    K9_T(trace_base + 0);
+    float srun = 0.f;
+    auto phi_half = [&](int st) {
+        const int hh = st >> 1, sx = st & 1;
+        float s = sx == 0 ? 0.f : srun;
+#pragma unroll
+        for (int r = 8 * sx; r < 8 * sx + 8; ++r) {
+            const float p = phi(k[hh][r]) * vm[r];
+            k[hh][r] = p;                                               // rounded when packed as the MFMA operand
+            s += p;                                                     // Ksum adds the fp32 values, rows in order
+        }
+        kf[hh][sx] = pack_step<T>(k[hh], sx);
+        if (sx == 0) srun = s;
+        else ksum[hh] = half_sum(s);                                  // lane lr = channel d
+    };
+    // state of the wave's 32 tokens: head h = channel tile h; rows = d, lane = v
+    v16f kv[8];
+    {
+        v16f v[8];
+        K9_T(trace_base + 1);
+        project(v, phi_half);
+        K9_T(trace_base + 2);
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) kv[hh][r] = 0.f;
+            Mm::mma(kf[hh][0], pack_step<T>(v[hh], 0), kv[hh]);
+            Mm::mma(kf[hh][1], pack_step<T>(v[hh], 1), kv[hh]);
+        }
+    }
+    K9_T(trace_base + 3);
+    // sum of the four waves, then one partial per tile: every wave parks its partial in LDS (4 x 34 KiB: the tile and the ring
+    // are dead by now), and all 256 threads add the four copies - in the order (w0 + w2) + (w1 + w3) - and store the partial
+    // (a tree that ended with ONE wave adding and storing 33 KB took 9 of the kernel's 35 thousand cycles)
+    constexpr int KVN = 8 * 16 * 64, SLOT = KVN + 8 * 64;              // floats per wave: kv[hh][r][lane] | ksum[hh][lane]
+    float* red = reinterpret_cast<float*>(smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the requests behind the stream's end (out of range: zeros) have landed
+    __syncthreads();
+#pragma unroll
+    for (int hh = 0; hh < 8; ++hh) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave * SLOT + (hh * 16 + r) * 64 + lane] = kv[hh][r];
+        red[wave * SLOT + KVN + hh * 64 + lane] = ksum[hh];
+    }
+    __syncthreads();
+    K9_T(trace_base + 4);
+#pragma unroll 4
+    for (int e = tid; e < KVN; e += 256) {
+        const float sum = (red[e] + red[2 * SLOT + e]) + (red[SLOT + e] + red[3 * SLOT + e]);
+        const int hh = e >> 10, r = (e >> 6) & 15, ln = e & 63;
+        dst[(size_t)(hh * D + gf_acc_row(r, ln >> 5)) * D + (ln & 31)] = sum;                               // [c][v]: 128-B runs
+    }
+    for (int e = tid; e < 8 * 64; e += 256) {
+        const int ln = e & 63;
+        if (ln < 32) {
+            const int o = KVN + e;
+            dst[C * D + (e >> 6) * D + ln] = (red[o] + red[2 * SLOT + o]) + (red[SLOT + o] + red[3 * SLOT + o]);
+        }
+    }
 }
 
 // -------------------------------------------------------------------------------------------------------------
@@ -645,94 +783,9 @@ __global__ __launch_bounds__(256, 1) void enc_kv_state(EncArgs a) {
     asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");      // block 0 and the tile; block 1's first half stays in flight
     __builtin_amdgcn_s_barrier();
     K9_T(1);
-    const int myrow = wave * 32 + lr;
     Frag fa[8], fb[8];
     load_step0(ring, fa);
-    auto xfrag = [&](int ks) { return *reinterpret_cast<const Frag*>(smem + X_OFF + (ks >> 2) * 16384 + gf_lds_off(myrow, 2 * (ks & 3) + h2)); };
-    auto project = [&](v16f (&acc)[8]) {                               // acc = src tile x W^T: 16 steps (k-step = step)
-#pragma unroll
-        for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-        Frag tf = xfrag(0);
-#pragma unroll
-        for (int st = 0; st < 16; ++st) {
-            Frag (&cur)[8] = (st & 1) ? fb : fa;
-            Frag (&nxt)[8] = (st & 1) ? fa : fb;
-            Frag tn;
-            ring_step<1>(ring, cur, nxt, st & 3, [&](int nb) { Mm::mma(tf, cur[nb], acc[nb]); }, [&] { tn = xfrag(st < 15 ? st + 1 : 15); });
-            tf = tn;
-        }
-    };
-    // phi(k) first (its accumulators are packed to 16-bit operands and released), then v: 128 accumulators at a time
-    Frag kf[8][2];
-    float ksum[8];
-    float vm[16];                                                       // 1 / 0 per accumulator row (token) of this lane half
-#pragma unroll
-    for (int r = 0; r < 16; ++r) vm[r] = ((valid >> gf_acc_row(r, h2)) & 1u) ? 1.f : 0.f;
-    {
-        v16f k[8];
-        project(k);
-        K9_T(2);
-#pragma unroll
-        for (int hh = 0; hh < 8; ++hh) {
-            float s = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = phi(k[hh][r]) * vm[r];
-                k[hh][r] = p;                                           // rounded when packed as the MFMA operand
-                s += p;                                                 // Ksum adds the fp32 values
-            }
-            ksum[hh] = s + __shfl_xor(s, 32, 64);                     // lane lr = channel d
-            kf[hh][0] = pack_step<T>(k[hh], 0);
-            kf[hh][1] = pack_step<T>(k[hh], 1);
-        }
-    }
-    // state of the wave's 32 tokens: head h = channel tile h; rows = d, lane = v
-    v16f kv[8];
-    {
-        v16f v[8];
-        K9_T(3);
-        project(v);
-        K9_T(4);
-#pragma unroll
-        for (int hh = 0; hh < 8; ++hh) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) kv[hh][r] = 0.f;
-            Mm::mma(kf[hh][0], pack_step<T>(v[hh], 0), kv[hh]);
-            Mm::mma(kf[hh][1], pack_step<T>(v[hh], 1), kv[hh]);
-        }
-    }
-    K9_T(5);
-    // sum of the four waves, then one partial per tile: every wave parks its partial in LDS (4 x 34 KiB: the tile and the ring
-    // are dead by now), and all 256 threads add the four copies - in the order (w0 + w2) + (w1 + w3) - and store the partial
-    // (a tree that ended with ONE wave adding and storing 33 KB took 9 of the kernel's 35 thousand cycles)
-    constexpr int KVN = 8 * 16 * 64, SLOT = KVN + 8 * 64;              // floats per wave: kv[hh][r][lane] | ksum[hh][lane]
-    float* red = reinterpret_cast<float*>(smem);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the requests behind the stream's end (out of range: zeros) have landed
-    __syncthreads();
-#pragma unroll
-    for (int hh = 0; hh < 8; ++hh) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[wave * SLOT + (hh * 16 + r) * 64 + lane] = kv[hh][r];
-        red[wave * SLOT + KVN + hh * 64 + lane] = ksum[hh];
-    }
-    __syncthreads();
-    K9_T(6);
-    float* dst = a.part + ((size_t)n * a.tiles + tile) * (C * D + C);
-#pragma unroll 4
-    for (int e = tid; e < KVN; e += 256) {
-        const float sum = (red[e] + red[2 * SLOT + e]) + (red[SLOT + e] + red[3 * SLOT + e]);
-        const int hh = e >> 10, r = (e >> 6) & 15, ln = e & 63;
-        dst[(size_t)(hh * D + gf_acc_row(r, ln >> 5)) * D + (ln & 31)] = sum;                               // [c][v]: 128-B runs
-    }
-    for (int e = tid; e < 8 * 64; e += 256) {
-        const int ln = e & 63;
-        if (ln < 32) {
-            const int o = KVN + e;
-            dst[C * D + (e >> 6) * D + ln] = (red[o] + red[2 * SLOT + o]) + (red[SLOT + o] + red[3 * SLOT + o]);
-        }
-    }
+    kv_tail<T>(ring, fa, fb, smem, valid, a.part + ((size_t)n * a.tiles + tile) * (C * D + C), wave, lane, tid, 2);
     K9_T(7);
 }
 
@@ -810,6 +863,45 @@ extern "C" int gf_encoder_kv_state(const void* src, long ld, int dtype, int N, i
     else enc_kv_state<gf_bf16><<<N * a.tiles, 256, W_OFF + 2 * WBLK + 8192, st>>>(a);
     enc_kv_reduce<<<dim3((len + 255) / 256, N), 256, 0, st>>>(a.part, kv_state, a.tiles, len);
     gf_prof_end("enc_kv_state", pt, st);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}
+
+// the encoder layer with its state tail: the layer of gf_encoder_layer (linear attention form) whose images tail_first .. N-1 also
+// leave kv_state_out[n - tail_first] = the linear-attention state of their OUTPUT rows under wstream_tail (the W_k | W_v stream of
+// the layer call that will read those rows as its source): no second pass over the features, no second launch
+extern "C" int gf_encoder_layer_kv(const void* x, long ldx, const float* kv_state, int S, const uint8_t* q_mask, float attn_eps,
+                                   const void* wstream, const float* ln_params, float eps1, float eps2, int activation, void* out,
+                                   long ldo, int dtype, int N, int L, const void* wstream_tail, int tail_first, float* kv_state_out,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+    GF_CHECK_ARG(x && wstream && ln_params && out && kv_state, "null pointer");
+    GF_CHECK_ARG(wstream_tail && kv_state_out && tail_first >= 0 && tail_first < N, "the state tail needs its weight stream, its output and 0 <= tail_first < N");
+    GF_CHECK_ARG(N > 0 && L > 0 && S > 0, "empty problem");
+    GF_CHECK_ARG(dtype == GF_F16 || dtype == GF_BF16, "the fused encoder kernels are built for 16-bit storage (GF_F16 / GF_BF16)");
+    GF_CHECK_ARG(activation == 0 || activation == 1, "activation: 0 = ReLU, 1 = Tanh");
+    GF_CHECK_ARG((ldx * 2) % 16 == 0 && (ldo * 2) % 16 == 0, "rows must be 16-byte aligned");
+    GF_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)wstream % 16 == 0 && (uintptr_t)wstream_tail % 16 == 0,
+                 "tensors must be 16-byte aligned");
+    const int nt = N - tail_first;
+    if (workspace == nullptr || workspace_bytes < gf_encoder_kv_workspace_bytes(nt, L)) {
+        gf_set_error("gf_encoder_layer_kv: workspace too small");
+        return GF_ERR_WORKSPACE;
+    }
+    enc_init();
+    EncArgs a{};
+    a.x = x; a.ldx = ldx; a.kvfinal = kv_state; a.q_mask = q_mask; a.wstream = wstream; a.ln = ln_params;
+    a.eps1 = eps1; a.eps2 = eps2; a.attn_eps = attn_eps; a.out = out; a.ldo = ldo; a.N = N; a.L = L; a.S = S;
+    a.tiles = (L + TM - 1) / TM;
+    a.wstream_tail = wstream_tail; a.tail_first = tail_first; a.part = (float*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    const double per_tok = 2.0 * C * C + 2.0 * C * (D + 1) + 2.0 * C * C + 8.0 * C * C + 4.0 * C * C;
+    const double tail_tok = 2.0 * C * (2.0 * C + 2.0 * D);                // the flops gf_encoder_kv_state declares per source token
+    void* pt = gf_prof_begin("enc_layer", st, per_tok * N * (double)L + tail_tok * nt * (double)L);
+    if (dtype == GF_F16) enc_launch<_Float16>(a, activation, true, st);
+    else enc_launch<gf_bf16>(a, activation, true, st);
+    const int len = C * D + C;
+    enc_kv_reduce<<<dim3((len + 255) / 256, nt), 256, 0, st>>>(a.part, kv_state_out, a.tiles, len);
+    gf_prof_end("enc_layer", pt, st);
     GF_CHECK_LAUNCH();
     return GF_OK;
 }

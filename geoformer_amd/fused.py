@@ -78,7 +78,15 @@ def pack_kv_stream(wk, wv):
     return torch.cat([_steps(fragments(w, 'std'), all8, [[ks] for ks in range(16)]) for w in (wk, wv)]).contiguous()
 
 
-def encoder_kv_state(src, wstream_kv, kv_mask=None):
+def _state_out(out, n, C, device):
+    if out is None:
+        return torch.empty(n, C * 32 + C, dtype=torch.float32, device=device)
+    if out.shape != (n, C * 32 + C) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError('the state output must be a contiguous fp32 [N, 256*32 + 256] tensor (a row range of a larger one is fine)')
+    return out
+
+
+def encoder_kv_state(src, wstream_kv, kv_mask=None, out=None):
     """src [N, S, 256] (16-bit) -> kv_state fp32 [N, 256*32 + 256]."""
     _need_cuda(src, wstream_kv)
     N, S, C = src.shape
@@ -87,7 +95,7 @@ def encoder_kv_state(src, wstream_kv, kv_mask=None):
     src, ld = _rows2d(src)
     L_ = _lib.lib()
     ws = _ws.get('k6', L_.gf_encoder_kv_workspace_bytes(N, S), src.device)
-    out = torch.empty(N, C * 32 + C, dtype=torch.float32, device=src.device)
+    out = _state_out(out, N, C, src.device)
     km = None if kv_mask is None else _contig(kv_mask.reshape(N, S).to(torch.uint8))
     check(L_.gf_encoder_kv_state(_p(src), ld, _dt(src), N, S, _p(km), _p(wstream_kv), _p(out), _p(ws), ws.numel(), _stream()),
           'gf_encoder_kv_state')
@@ -95,8 +103,10 @@ def encoder_kv_state(src, wstream_kv, kv_mask=None):
 
 
 def encoder_layer(x, wstream, ln_params, eps1, eps2, activation, msg=None, kv_state=None, source_len=0, q_mask=None,
-                  attn_eps=1e-6, row_flag=None, flag_rows=0, out=None):
-    """x [N, L, 256] -> out [N, L, 256]; give either `msg` (attention output) or `kv_state` (+ source_len)."""
+                  attn_eps=1e-6, row_flag=None, flag_rows=0, out=None, tail_stream=None, tail_first=0, tail_out=None):
+    """x [N, L, 256] -> out [N, L, 256]; give either `msg` (attention output) or `kv_state` (+ source_len).
+    tail_stream (a pack_kv_stream, linear-attention form only): returns (out, kv_state_out) with kv_state_out [N - tail_first,
+    256*32 + 256] = encoder_kv_state(out[tail_first:], tail_stream, q_mask[tail_first:]) computed inside the same launch."""
     _need_cuda(x, wstream, ln_params)
     N, L, C = x.shape
     x, ldx = _rows2d(x)
@@ -108,6 +118,17 @@ def encoder_layer(x, wstream, ln_params, eps1, eps2, activation, msg=None, kv_st
     elif out.shape != (N, L, C) or out.dtype != x.dtype or not out.is_contiguous():
         raise ValueError('out must be a contiguous tensor of the result shape and dtype')
     qm = None if q_mask is None else _contig(q_mask.reshape(N, L).to(torch.uint8))
+    if tail_stream is not None:
+        if kv_state is None or row_flag is not None:
+            raise ValueError('the state tail belongs to the linear-attention form (kv_state given, no row_flag)')
+        L_ = _lib.lib()
+        nt = N - int(tail_first)
+        ws = _ws.get('k6', L_.gf_encoder_kv_workspace_bytes(nt, L), x.device)
+        st_out = _state_out(tail_out, nt, C, x.device)
+        check(L_.gf_encoder_layer_kv(_p(x), ldx, _p(kv_state), int(source_len), _p(qm), float(attn_eps), _p(wstream), _p(ln_params),
+                                     float(eps1), float(eps2), int(activation), _p(out), C, _dt(x), N, L, _p(tail_stream), int(tail_first),
+                                     _p(st_out), _p(ws), ws.numel(), _stream()), 'gf_encoder_layer_kv')
+        return out, st_out
     check(_lib.lib().gf_encoder_layer(_p(x), ldx, _p(msg), ldm, _p(kv_state), int(source_len), _p(qm), float(attn_eps), _p(wstream),
                                       _p(ln_params), float(eps1), float(eps2), int(activation), _p(row_flag), int(flag_rows), _p(out), C,
                                       _dt(x), N, L, _stream()), 'gf_encoder_layer')

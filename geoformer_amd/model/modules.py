@@ -169,6 +169,20 @@ class LoFTREncoderLayer(nn.Module):
         message = ops.linear_attention(q, k, v, self.nhead, x_mask, source_mask)
         return self.finish(x, message, out=out)
 
+    def kv_state(self, source, source_mask=None, out=None):
+        """The linear-attention state of `source` under this layer's k / v projections (fused 16-bit form)."""
+        return fused.encoder_kv_state(source, self.weights(source.dtype)['stream_kv'], source_mask, out=out)
+
+    def forward_state(self, x, state, source_len, x_mask=None, out=None, tail_layer=None, tail_first=0, tail_out=None):
+        """The layer on x given the source's state (fused 16-bit form, one launch).  tail_layer: the layer that will read THIS
+        call's output rows as its source - the images tail_first.. also leave their state under that layer's k / v projections
+        (returned second; csrc/k9_encoder_fused.hip's state tail), so the consumer needs no pass of its own over the features."""
+        w = self.weights(x.dtype)
+        tail = None if tail_layer is None else tail_layer.weights(x.dtype)['stream_kv']
+        return fused.encoder_layer(x, w['stream'], w['ln'], self.norm1.eps, self.norm2.eps, 0 if self.activation == 'relu' else 1,
+                                   kv_state=state, source_len=source_len, q_mask=x_mask, out=out, tail_stream=tail,
+                                   tail_first=tail_first, tail_out=tail_out)
+
 
 def _adjacent_halves(a, b):
     """[2n, ...] view over a and b when they are the first and the second half of one contiguous buffer (e.g. out[:M], out[M:]), else None."""
@@ -209,6 +223,8 @@ class LocalFeatureTransformer(nn.Module):
             if both is None:
                 both = torch.cat([feat0, feat1], 0)
         mboth = torch.cat([mask0, mask1], 0) if (same and mask0 is not None) else None
+        if same and both.is_cuda and all(ly.fusable(both.dtype) for ly in self.layers):
+            return self._forward_fused(both, n, mask0, mask1, mboth)
         for layer, name in zip(self.layers, self.layer_names):
             if name == 'self':
                 if same:
@@ -228,6 +244,57 @@ class LocalFeatureTransformer(nn.Module):
             else:
                 raise KeyError
         return (both[:n], both[n:]) if same else (feat0, feat1)
+
+    def _forward_fused(self, both, n, mask0, mask1, mboth):
+        """The same schedule (transformer.py:82-104) on the fused 16-bit layer kernels, one launch per layer call: the state a
+        call needs - phi(K)^T V of its source - is left behind by the call that PRODUCED the source rows (its state tail),
+        under the consumer's k / v weights.  Only what no earlier call of this transformer produced (the first layer's
+        sources, and image 0's rows in front of a 'self' layer - its producer's tail is busy with the state the second cross
+        call needs) takes a gf_encoder_kv_state pass of its own: 40 image-states per 8-pair step instead of 128."""
+        L = both.shape[1]
+        C = self.d_model
+        layers, names = list(self.layers), list(self.layer_names)
+        have = {}                                                # half (0 / 1) -> state rows [n, 8448] under the NEXT layer's k / v
+        for idx, (layer, name) in enumerate(zip(layers, names)):
+            nxt_layer = layers[idx + 1] if idx + 1 < len(layers) else None
+            nxt_name = names[idx + 1] if nxt_layer is not None else None
+            if name == 'self':
+                st = have.get('buf')                              # a producer's tail wrote its half straight into this buffer
+                if st is None:
+                    st = torch.empty(2 * n, C * 32 + C, dtype=torch.float32, device=both.device)
+                    for half in (0, 1):
+                        if half in have:
+                            st[half * n:(half + 1) * n].copy_(have[half])
+                for half, (rows, msk) in enumerate(((both[:n], mask0), (both[n:], mask1))):
+                    if half not in have:
+                        layer.kv_state(rows, msk, out=st[half * n:(half + 1) * n])
+                have = {}
+                if nxt_layer is None:
+                    both = layer.forward_state(both, st, L, mboth)
+                elif nxt_name == 'cross':                         # its first call reads image 1's rows
+                    both, t = layer.forward_state(both, st, L, mboth, tail_layer=nxt_layer, tail_first=n)
+                    have = {1: t}
+                else:                                             # another 'self' layer reads both
+                    both, t = layer.forward_state(both, st, L, mboth, tail_layer=nxt_layer, tail_first=0)
+                    have = {0: t[:n], 1: t[n:], 'buf': t}
+            elif name == 'cross':                                 # feat1 attends to the UPDATED feat0 (transformer.py:99-100)
+                st1 = have[1] if 1 in have else layer.kv_state(both[n:], mask1)
+                new = torch.empty_like(both)
+                _, st0 = layer.forward_state(both[:n], st1, L, mask0, out=new[:n], tail_layer=layer, tail_first=0)
+                have = {}
+                if nxt_layer is None:
+                    layer.forward_state(both[n:], st0, L, mask1, out=new[n:])
+                elif nxt_name == 'self':                          # its state buffer: image 1's half from this call's tail
+                    buf = torch.empty(2 * n, C * 32 + C, dtype=torch.float32, device=both.device)
+                    layer.forward_state(both[n:], st0, L, mask1, out=new[n:], tail_layer=nxt_layer, tail_first=0, tail_out=buf[n:])
+                    have = {1: buf[n:], 'buf': buf}
+                else:                                             # another 'cross' layer: its first call reads image 1's new rows
+                    _, t = layer.forward_state(both[n:], st0, L, mask1, out=new[n:], tail_layer=nxt_layer, tail_first=0)
+                    have = {1: t}
+                both = new
+            else:
+                raise KeyError
+        return both[:n], both[n:]
 
 
 # ---------------------------------------------------------------------------------------------

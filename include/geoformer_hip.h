@@ -202,6 +202,17 @@ int gf_encoder_layer(const void* x, long ldx, const void* msg, long ldm, const f
                      const uint8_t* q_mask, float attn_eps, const void* wstream, const float* ln_params, float eps1,
                      float eps2, int activation, const int32_t* row_flag, int flag_rows, void* out, long ldo, int dtype,
                      int N, int L, void* stream);
+/*   gf_encoder_layer_kv (round 4): gf_encoder_layer in its linear-attention form (kv_state given) whose launch ALSO produces,
+ *          for the images tail_first .. N-1, kv_state_out[n - tail_first] = gf_encoder_kv_state of their OUTPUT rows under
+ *          wstream_tail - the W_k | W_v stream of the layer call that reads those rows as its source (transformer.py:95-100:
+ *          the next layer's source is this layer's output).  The finished 128-token tile is still in the CU's LDS when the
+ *          tail's weights arrive through the same ring: no second read of the features, no second launch; masked rows
+ *          (q_mask) do not count, as in gf_encoder_kv_state with kv_mask = q_mask.  workspace: gf_encoder_kv_workspace_bytes(
+ *          N - tail_first, L).  The states are bit-identical to gf_encoder_kv_state(out[tail_first:], ...)'s. */
+int gf_encoder_layer_kv(const void* x, long ldx, const float* kv_state, int S, const uint8_t* q_mask, float attn_eps,
+                        const void* wstream, const float* ln_params, float eps1, float eps2, int activation, void* out,
+                        long ldo, int dtype, int N, int L, const void* wstream_tail, int tail_first, float* kv_state_out,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K11 one encoder layer of the fine-level transformer in ONE launch (16-bit storage modes)

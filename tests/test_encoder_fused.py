@@ -143,3 +143,68 @@ def test_full_size_layer_against_unfused_chain():
         want = ops.linear(hid, w['w2'], epilogue=ops.EPI_LN_RES, ln=w['n2'], eps=layer.norm2.eps, residual=x)
     torch.testing.assert_close(got.float(), want.float(), rtol=1e-2, atol=1e-2)
     assert float((got.float() - want.float()).abs().mean()) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('st', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('L,masked,tail_first', [(256, False, 0), (300, True, 1), (6400, False, 2)])
+def test_state_tail_equals_a_separate_state_pass(L, masked, tail_first, st):
+    """gf_encoder_layer_kv (round 4): the layer's output is unchanged by the tail, and the states the launch leaves for the
+    images tail_first.. are BIT-IDENTICAL to gf_encoder_kv_state run on that output with the consumer's weights (same tile,
+    same operand order, same reduction order) - ragged last tile, query masks as the source masks, tails on a suffix of the batch."""
+    from geoformer_amd import fused
+    layer, _ = _layer(PFX, 'linear', 'relu', 8)
+    consumer, _ = _layer('loftr_coarse.layers.3.', 'linear', 'relu', 8)
+    g = torch.Generator().manual_seed(13)
+    N = 3
+    x = (torch.randn(N, L, 256, generator=g) * 0.7).to(DEV).to(st)
+    src = (torch.randn(N, L, 256, generator=g) * 0.7).to(DEV).to(st)
+    xm = None
+    if masked:
+        xm = torch.ones(N, L, dtype=torch.bool); xm[1, 150:] = False; xm[2, :33] = False
+        xm = xm.to(DEV)
+    with torch.no_grad():
+        state = layer.kv_state(src)
+        plain = layer.forward_state(x, state, L, xm)
+        out, tail = layer.forward_state(x, state, L, xm, tail_layer=consumer, tail_first=tail_first)
+        want = consumer.kv_state(plain[tail_first:], None if xm is None else xm[tail_first:])
+    assert torch.equal(out, plain)
+    assert tail.shape == (N - tail_first, 256 * 32 + 256)
+    assert torch.equal(tail, want)
+    # into a row range of a larger buffer (how LocalFeatureTransformer hands a 'self' layer its two halves)
+    buf = torch.full((N + 2, 256 * 32 + 256), -7.0, device=DEV)
+    with torch.no_grad():
+        layer.forward_state(x, state, L, xm, tail_layer=consumer, tail_first=tail_first, tail_out=buf[1:1 + N - tail_first])
+    assert torch.equal(buf[1:1 + N - tail_first], want) and float(buf[0, 0]) == -7.0 and float(buf[-1, -1]) == -7.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('masked', [False, True])
+def test_transformer_with_state_tails_equals_layer_by_layer(masked):
+    """LocalFeatureTransformer on the fused path (states handed from producer to consumer through the tails) against the same
+    eight layers run one by one, each with its own gf_encoder_kv_state pass (round 3's schedule): bit-identical features."""
+    from geoformer_amd.model.modules import LocalFeatureTransformer
+    from geoformer_amd.model.cvpr_ds_config import get_default_cfg
+    cfg = get_default_cfg()['coarse']
+    m = LocalFeatureTransformer(cfg)
+    W = O.make_weights()
+    m.load_state_dict({k[len('loftr_coarse.'):]: v for k, v in W.items() if k.startswith('loftr_coarse.')})
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(17)
+    n, L = 2, 420
+    f0 = (torch.randn(n, L, 256, generator=g) * 0.7).to(DEV).half()
+    f1 = (torch.randn(n, L, 256, generator=g) * 0.7).to(DEV).half()
+    m0 = m1 = None
+    if masked:
+        m0 = torch.ones(n, L, dtype=torch.bool, device=DEV); m0[0, 400:] = False
+        m1 = torch.ones(n, L, dtype=torch.bool, device=DEV); m1[1, :50] = False
+    with torch.no_grad():
+        a0, a1 = m(f0, f1, m0, m1)
+        b0, b1 = f0, f1
+        for layer, name in zip(m.layers, m.layer_names):
+            if name == 'self':
+                b0, b1 = layer(b0, b0, m0, m0), layer(b1, b1, m1, m1)
+            else:
+                b0 = layer(b0, b1, m0, m1)
+                b1 = layer(b1, b0, m1, m0)
+    assert torch.equal(a0, b0) and torch.equal(a1, b1)

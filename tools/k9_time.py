@@ -49,6 +49,10 @@ def old():
     return ops.linear(h, w['w2'], epilogue=ops.EPI_LN_RES, ln=w['n2'], eps=1e-5, residual=x)
 
 
+t_tail = timeit(lambda: fused.encoder_layer(x, w['stream'], w['ln'], 1e-5, 1e-5, 0, kv_state=state, source_len=L, tail_stream=w['stream_kv'], tail_first=0))
+t_tail_half = timeit(lambda: fused.encoder_layer(x, w['stream'], w['ln'], 1e-5, 1e-5, 0, kv_state=state, source_len=L, tail_stream=w['stream_kv'], tail_first=N // 2))
+print(f'{N} images: layer + state tail (all images) {t_tail:.1f} us [separate: {t_layer + t_kv:.1f}], tail on the second half {t_tail_half:.1f} us '
+      f'[separate: {t_layer:.1f} + {N // 2}-image state pass]')
 t_old = timeit(old)
 print(f'{N} images: enc_kv_state {t_kv:.1f} us ({fl_kv / t_kv * 1e-6:.0f} TFLOP/s)  enc_layer {t_layer:.1f} us ({fl_layer / t_layer * 1e-6:.0f} TFLOP/s)  '
       f'finish-only {t_fin:.1f} us  | K3+K2 chain {t_old:.1f} us')
