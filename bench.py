@@ -41,8 +41,9 @@ MFMA_PEAK_TFLOPS = {'fp16': 2500.0, 'bf16': 2500.0, 'fp32': 157.3}     # dense, 
 # is, which roofline bounds the family, and whether it belongs to the matching path (the north_star's hot path)
 ROOFLINE_TAGS = [
     # tag,                   bound,  hot path, description
-    ('enc_layer',            'mfma', True,  'fused encoder layer (projections + attention apply + merge/LN + MLP/LN + residual)'),
-    ('enc_kv_state',         'mfma', True,  'fused k/v projection + linear-attention state'),
+    ('enc_layer',            'mfma', True,  'fused encoder layer (projections + attention apply + merge/LN + MLP/LN + residual; since round 4 most launches also '
+                                            "leave the linear-attention state of their output rows for the next layer call: the state tail's flops are declared with them)"),
+    ('enc_kv_state',         'mfma', True,  'fused k/v projection + linear-attention state as a pass of its own (the sources no earlier layer call of the transformer produced)'),
     ('k3_linear',            'hbm',  True,  'K3 linear_kernel family (Geo-layer projections, FinePreprocess and fine-level GEMMs with fused epilogues; K <= 512: below the machine balance, HBM is the roof)'),
     ('k1_stats',             'mfma', True,  'K1 pass A (similarity tile statistics)'),
     ('k1_conf',              'hbm',  True,  'K1 pass B (dual-softmax correlation sweep, conf_matrix write)'),
@@ -53,6 +54,7 @@ ROOFLINE_TAGS = [
     ('k4_self_attention',    'mfma', True,  'K4 inlier-key self attention (flash form)'),
     ('bias_act',             'hbm',  False, 'backbone glue: shift + shortcut + activation stream'),
     ('k3_upadd',             'hbm',  False, 'backbone: 1x1 lateral convolution with the FPN upsample + add as its epilogue (K3 tile engine; 67 flop/byte: HBM is the roof)'),
+    ('conv1x1',              'hbm',  False, 'backbone: 1x1 convolutions on the K3 tile engine (layer3_outconv, the stride-2 downsample shortcuts)'),
     ('conv3x3',              'mfma', False, 'K10 3x3 convolution of the backbone (BN shift + shortcut + activation in the epilogue; SURVEY 8f rank 4)'),
 ]
 

@@ -68,6 +68,10 @@ struct LinArgs {
     const void* up_lo;
     int up_h, up_w, up_H, up_W;
     float up_ry, up_rx;
+    // row map of a1 (a strided 1x1 convolution's input pixels; k2 == 0): row r of the product reads a1 at element offset
+    // (r / rm_w) * rm_line + (r % rm_w) * rm_pix instead of r * lda1; rm_w == 0: off
+    int rm_w;
+    long rm_line, rm_pix;
 };
 
 // Tile of a workgroup.  Linear workgroup ids go round-robin over the 8 XCDs (= 8 L2s); with the grid's native order the column
@@ -85,7 +89,9 @@ __device__ __forceinline__ void lin_tile(int& row_tile, int& col_tile) {
     }
 }
 
-template <typename T, int NB, int EPI>
+// CONVX: the forms the backbone's 1x1 convolutions need (compiled only into their instances: the matching path's kernels keep their
+// register budget) - K not a multiple of the K step, and the strided-pixel row map of LinArgs
+template <typename T, int NB, int EPI, bool CONVX = false>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void linear_kernel(LinArgs a) {
     using Mm = Mma32<T>;
     using Frag = typename Mm::Frag;
@@ -129,6 +135,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void linear_kernel(Lin
         }
     }
     v4u regs[NLD];
+    // K need not be a multiple of the 128-byte K step (a 224-channel 1x1 convolution): chunks at or behind a row's end are staged
+    // as zeros on both sides (k2 == 0 then: the entry point checks)
+    const bool ragged = CONVX && (K % BK) != 0;
     auto gload = [&](int k0) {
         const bool first = k0 < a.k1;
         const T* ab = (const T*)(first ? a.a1 : a.a2);
@@ -137,8 +146,16 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void linear_kernel(Lin
 #pragma unroll
         for (int p = 0; p < NLD; ++p) {
             const int e = p * 256 + tid, row = e >> 3, c = e & 7;
-            const T* g = isa[p] ? ab + (size_t)min(m0 + row, a.M - 1) * ld + kk + c * EPC : src[p] + k0;
-            regs[p] = *reinterpret_cast<const v4u*>(g);
+            const T* g;
+            if (isa[p]) {
+                const int r = min(m0 + row, a.M - 1);
+                const size_t ro = (CONVX && a.rm_w > 0) ? (size_t)(r / a.rm_w) * a.rm_line + (size_t)(r % a.rm_w) * a.rm_pix : (size_t)r * ld;
+                g = ab + ro + kk + c * EPC;
+            } else {
+                g = src[p] + k0;
+            }
+            if (!ragged || k0 + c * EPC < K) regs[p] = *reinterpret_cast<const v4u*>(g);
+            else regs[p] = v4u{0u, 0u, 0u, 0u};
         }
     };
     auto lstore = [&]() {
@@ -151,7 +168,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void linear_kernel(Lin
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
 
-    const int nk = K / BK;
+    const int nk = (K + BK - 1) / BK;
     K3_T(0);
     gload(0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -440,12 +457,12 @@ __global__ __launch_bounds__(256, 2) void linear_kernel_w2(LinArgs a) {
     }
 }
 
-template <typename T, int NB, int EPI>
+template <typename T, int NB, int EPI, bool CONVX = false>
 void lin_launch1(const LinArgs& a, hipStream_t st) {
     constexpr int WROWS = 32 * NB;
     size_t lds = (size_t)(128 + WROWS) * 128 + 3 * WROWS * sizeof(float);
     if (lds < 4 * 32 * 272) lds = 4 * 32 * 272;                          // fp16 epilogue slabs
-    linear_kernel<T, NB, EPI><<<dim3((a.M + 127) / 128, (a.N + WROWS - 1) / WROWS), 256, lds, st>>>(a);
+    linear_kernel<T, NB, EPI, CONVX><<<dim3((a.M + 127) / 128, (a.N + WROWS - 1) / WROWS), 256, lds, st>>>(a);
 }
 
 template <typename T, int NB>
@@ -528,7 +545,7 @@ extern "C" int gf_conv1x1_upsample_add_nhwc(const void* x, const void* w, const 
     GF_CHECK_ARG(x && w && lo && out, "null pointer");
     GF_CHECK_ARG(N > 0 && h > 0 && wl > 0 && H > 0 && W > 0, "empty problem");
     GF_CHECK_ARG(dtype == GF_F16 || dtype == GF_BF16, "built for 16-bit maps (the inference backbone)");
-    GF_CHECK_ARG(Cin % 64 == 0 && Cout % 32 == 0, "Cin must be a multiple of 64, Cout of 32");
+    GF_CHECK_ARG(Cin % 32 == 0 && Cout % 32 == 0, "Cin and Cout must be multiples of 32");
     GF_CHECK_ARG((long)N * H * W < (1l << 31), "too many pixels");
     GF_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)lo % 16 == 0, "tensors must be 16-byte aligned");
     LinArgs a{};
@@ -542,9 +559,34 @@ extern "C" int gf_conv1x1_upsample_add_nhwc(const void* x, const void* w, const 
     void* pt = gf_prof_begin("k3_upadd", st, 2.0 * ((double)a.M * (Cin + Cout) + (double)N * h * wl * Cout + (double)Cin * Cout));
     // 128-wide column tiles (152 registers, three waves per SIMD): with K = 128 the kernel is all epilogue, and
     // a single 224-wide tile (NB = 7, two waves per SIMD) measured slower (607 vs 529 us) despite reading x once
-    if (dtype == GF_F16) lin_launch1<_Float16, 4, EPI_UPADD>(a, st);
-    else lin_launch1<gf_bf16, 4, EPI_UPADD>(a, st);
+    if (dtype == GF_F16) lin_launch1<_Float16, 4, EPI_UPADD, true>(a, st);
+    else lin_launch1<gf_bf16, 4, EPI_UPADD, true>(a, st);
     gf_prof_end("k3_upadd", pt, st);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}
+
+// 1x1 convolution of a channels-last 16-bit map, stride 1 or 2, no bias (the backbone's lateral and downsample-shortcut
+// convolutions with the BatchNorm scale folded into w; a shift is added by whoever consumes the map): out[n, y, x, :] =
+// W x[n, s y, s x, :] - the K3 tile engine on the strided pixel rows
+extern "C" int gf_conv1x1_nhwc(const void* x, const void* w, void* out, int N, int H, int W, int Cin, int Cout, int stride, int dtype,
+                               void* stream) {
+    GF_CHECK_ARG(x && w && out, "null pointer");
+    GF_CHECK_ARG(N > 0 && H > 0 && W > 0, "empty problem");
+    GF_CHECK_ARG(stride == 1 || (stride == 2 && H % 2 == 0 && W % 2 == 0), "stride 1, or 2 on even-sized maps");
+    GF_CHECK_ARG(dtype == GF_F16 || dtype == GF_BF16, "built for 16-bit maps (the inference backbone)");
+    GF_CHECK_ARG(Cin % 32 == 0 && Cout % 32 == 0, "Cin and Cout must be multiples of 32");
+    GF_CHECK_ARG((long)N * H * W < (1l << 31), "too many pixels");
+    GF_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)w % 16 == 0, "tensors must be 16-byte aligned");
+    const int oh = H / stride, ow = W / stride;
+    LinArgs a{};
+    a.a1 = x; a.lda1 = Cin; a.k1 = Cin; a.w = w; a.out = out; a.ldo = Cout; a.M = N * oh * ow; a.N = Cout;
+    if (stride == 2) { a.rm_w = ow; a.rm_line = 2l * W * Cin; a.rm_pix = 2l * Cin; }
+    hipStream_t st = (hipStream_t)stream;
+    void* pt = gf_prof_begin("conv1x1", st, 2.0 * ((double)a.M * (Cin + Cout) + (double)Cin * Cout));
+    if (dtype == GF_F16) lin_launch1<_Float16, 4, EPI_NONE, true>(a, st);
+    else lin_launch1<gf_bf16, 4, EPI_NONE, true>(a, st);
+    gf_prof_end("conv1x1", pt, st);
     GF_CHECK_LAUNCH();
     return GF_OK;
 }

@@ -117,11 +117,12 @@ class FusedInferenceBackbone:
                 wd = None
                 if blk.downsample is not None:
                     wd, bd = _fold(blk.downsample[0], blk.downsample[1], dtype, pm)
+                    wd = self._w1x1(wd)
                     b2 = (b2 + bd).contiguous()
                 self.blocks.append((w1, b1, w2, b2, wd, blk.conv1.stride, self._stream(w1, blk.conv1.stride), self._stream(w2)))
-        self.l3_out = _fold(bb.layer3_outconv, None, dtype, pm)[0]
-        self.l2_out = _fold(bb.layer2_outconv, None, dtype, pm)[0]
-        self.l1_out = _fold(bb.layer1_outconv, None, dtype, pm)[0]
+        self.l3_out = self._w1x1(_fold(bb.layer3_outconv, None, dtype, pm)[0])
+        self.l2_out = self._w1x1(_fold(bb.layer2_outconv, None, dtype, pm)[0])
+        self.l1_out = self._w1x1(_fold(bb.layer1_outconv, None, dtype, pm)[0])
         self.l2_oc2 = (_fold(bb.layer2_outconv2[0], bb.layer2_outconv2[1], dtype, pm), bb.layer2_outconv2[2].negative_slope,
                        _fold(bb.layer2_outconv2[3], None, dtype, pm)[0])
         self.l1_oc2 = (_fold(bb.layer1_outconv2[0], bb.layer1_outconv2[1], dtype, pm), bb.layer1_outconv2[2].negative_slope,
@@ -129,8 +130,14 @@ class FusedInferenceBackbone:
         self.l2_oc2 += (self._stream(self.l2_oc2[0][0]), self._stream(self.l2_oc2[2]))
         self.l1_oc2 += (self._stream(self.l1_oc2[0][0]), self._stream(self.l1_oc2[2]))
 
+    def _w1x1(self, w):
+        """1x1 kernels as contiguous [Cout, Cin] matrices for the K3 engine (16-bit modes); the fp32 mode keeps conv2d's 4-D form."""
+        return w if self.dtype == torch.float32 else w.reshape(w.shape[0], w.shape[1]).contiguous()
+
     @staticmethod
     def _conv(x, w, stride=1):
+        if w.dim() == 2:
+            w = w[:, :, None, None]
         y = F.conv2d(x, w, None, stride, w.shape[-1] // 2)
         return y if y.is_contiguous(memory_format=torch.channels_last) else y.contiguous(memory_format=torch.channels_last)
 
@@ -155,10 +162,16 @@ class FusedInferenceBackbone:
             return y
         return ops.bias_act_(y, shift, shortcut, act, slope)
 
+    def _conv1(self, x, w, stride=1):
+        """1x1 convolution without bias: the K3 tile engine on the (strided) pixel rows in the 16-bit modes, MIOpen otherwise."""
+        if self.dtype != torch.float32 and x.shape[1] % 32 == 0 and w.shape[0] % 32 == 0 and (stride == 1 or (x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)):
+            return ops.conv1x1(x, w, stride)
+        return self._conv(x, w, stride)
+
     def _block(self, x, p):
         w1, b1, w2, b2, wd, stride, s1, s2 = p
         y = self._conv3(x, w1, s1, b1, None, ops.ACT_RELU, stride=stride)
-        shortcut = x if wd is None else self._conv(x, wd, stride)
+        shortcut = x if wd is None else self._conv1(x, wd, stride[0])
         return self._conv3(y, w2, s2, b2, shortcut, ops.ACT_RELU)
 
     def _head(self, x, p):
@@ -174,9 +187,12 @@ class FusedInferenceBackbone:
         x1 = self._block(self._block(x, self.blocks[0]), self.blocks[1])
         x2 = self._block(self._block(x1, self.blocks[2]), self.blocks[3])
         x3 = self._block(self._block(x2, self.blocks[4]), self.blocks[5])
-        c3 = self._conv(x3, self.l3_out)
-        c2 = self._head(ops.upsample_add_(self._conv(x2, self.l2_out), c3), self.l2_oc2)
-        if self.l1_out.shape[1] % 64 == 0 and self.dtype != torch.float32:      # lateral 1x1 + merge in one K3 launch
+        c3 = self._conv1(x3, self.l3_out)
+        if self.l2_out.shape[1] % 32 == 0 and self.dtype != torch.float32:      # lateral 1x1 + merge in one K3 launch (K = 224: ragged K step)
+            c2 = self._head(ops.conv1x1_upsample_add(x2, self.l2_out, c3), self.l2_oc2)
+        else:
+            c2 = self._head(ops.upsample_add_(self._conv(x2, self.l2_out), c3), self.l2_oc2)
+        if self.l1_out.shape[1] % 32 == 0 and self.dtype != torch.float32:      # lateral 1x1 + merge in one K3 launch
             c1 = self._head(ops.conv1x1_upsample_add(x1, self.l1_out, c2), self.l1_oc2)
         else:
             c1 = self._head(ops.upsample_add_(self._conv(x1, self.l1_out), c2), self.l1_oc2)

@@ -182,6 +182,21 @@ def conv1x1_upsample_add(x, weight, lo):
     return out
 
 
+def conv1x1(x, weight, stride=1):
+    """Backbone glue: 1x1 convolution (no bias) of channels_last x [N,Cin,H,W] with weight [Cout,Cin(,1,1)], stride 1 or 2 ->
+    channels_last [N,Cout,H/stride,W/stride]; one K3 launch on the (strided) pixel rows (gf_conv1x1_nhwc)."""
+    _need_cuda(x, weight)
+    _nhwc(x)
+    N, Cin, H, W = x.shape
+    Cout = weight.shape[0]
+    w2 = _contig(weight.reshape(Cout, Cin))
+    if w2.dtype != x.dtype:
+        raise ValueError('weight must have the dtype of x')
+    out = torch.empty(N, Cout, H // stride, W // stride, dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    check(_lib.lib().gf_conv1x1_nhwc(_p(x), _p(w2), _p(out), N, H, W, Cin, Cout, int(stride), _dt(x), _stream()), 'gf_conv1x1_nhwc')
+    return out
+
+
 def stem_conv7x7(image, weight, shift):
     """Backbone stem: image [N,1,H,W] (fp32/fp16, contiguous), weight fp32 [128,1,7,7] (BN folded), shift fp32 [128]
     -> relu(conv 7x7 / stride 2 / pad 3 + shift), fp16 channels_last [N,128,Ho,Wo]."""

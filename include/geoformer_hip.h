@@ -388,6 +388,11 @@ int gf_upsample_add_nhwc(const void* lo, const void* hi, void* out, int N, int h
  *                         convolution with the top-down merge as its epilogue (resnet_fpn.py:109-111); fp16, Cin % 64 == 0 */
 int gf_conv1x1_upsample_add_nhwc(const void* x, const void* w, const void* lo, void* out, int N, int h, int wl, int H,
                                  int W, int Cin, int Cout, int dtype, void* stream);
+/* 1x1 convolution of a channels-last 16-bit map, stride 1 or 2 (H, W even), no bias: out [N, H/s, W/s, Cout] = W x[n, s y, s x, :]
+ * (resnet_fpn.py:23-27 the BasicBlock downsample shortcut conv1x1(stride 2), :69-71 layer3_outconv / layer2_outconv, with the
+ * BatchNorm scale folded into w [Cout, Cin]); Cin, Cout multiples of 32. */
+int gf_conv1x1_nhwc(const void* x, const void* w, void* out, int N, int H, int W, int Cin, int Cout, int stride, int dtype,
+                    void* stream);
 /*   gf_stem_conv7x7:      out[n,oy,ox,c] = relu(sum_{ky,kx} image[n, 2oy-3+ky, 2ox-3+kx] * weight[c,ky,kx] + shift[c])
  *                         = conv1 (7x7, stride 2, pad 3, 1 input channel) + bn1 (folded) + relu, resnet_fpn.py:60-62, :92;
  *                         image [N,H,W] fp32 or fp16, weight fp32 [C,7,7], shift fp32 [C], out fp16 [N,Ho,Wo,C], C = 128 */

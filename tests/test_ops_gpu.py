@@ -779,6 +779,37 @@ def test_conv1x1_upsample_add_vs_torch():
     assert torch.allclose(out.float(), ref, atol=1e-2, rtol=4e-3), (out.float() - ref).abs().max().item()   # two fp16 roundings
 
 
+def test_conv1x1_upsample_add_ragged_k():
+    """K = 224 (the 196-channel pyramid level padded to 7 x 32): not a multiple of the engine's 64-element K step - the last
+    step's missing chunks are staged as zeros (layer2_outconv + FPN merge in one launch, resnet_fpn.py:108-110)."""
+    from geoformer_amd import ops
+    torch.manual_seed(8)
+    x = torch.randn(2, 224, 26, 36, device='cuda').half().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(256, 224, device='cuda') * 0.1).half()
+    lo = torch.randn(2, 256, 13, 18, device='cuda').half().contiguous(memory_format=torch.channels_last)
+    out = ops.conv1x1_upsample_add(x, w, lo)
+    ref = torch.nn.functional.conv2d(x.float(), w.float()[:, :, None, None]) + torch.nn.functional.interpolate(
+        lo.float(), size=(26, 36), mode='bilinear', align_corners=True)
+    assert torch.allclose(out.float(), ref, atol=1.5e-2, rtol=4e-3), (out.float() - ref).abs().max().item()
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('cin,cout,stride,hw', [(256, 256, 1, (20, 28)), (128, 224, 2, (40, 56)), (224, 256, 2, (22, 30)), (224, 256, 1, (9, 13))])
+def test_conv1x1_vs_torch(dtype, cin, cout, stride, hw):
+    """gf_conv1x1_nhwc (the lateral and downsample-shortcut 1x1 convolutions on the K3 engine; stride 2 = every other pixel of every
+    other row through the row map; K = 224 ragged) against torch's fp32 convolution of the same 16-bit operands."""
+    from geoformer_amd import ops
+    torch.manual_seed(cin + cout + stride)
+    H, W = hw
+    x = torch.randn(3, cin, H, W, device='cuda').to(dtype).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, device='cuda') / cin ** 0.5).to(dtype)
+    out = ops.conv1x1(x, w, stride)
+    ref = torch.nn.functional.conv2d(x.float(), w.float()[:, :, None, None], None, stride)
+    assert out.shape == ref.shape and out.dtype == dtype and out.is_contiguous(memory_format=torch.channels_last)
+    ulp = 2.0 ** (-10 if dtype == torch.float16 else -7)
+    assert float(((out.float() - ref).abs() / ref.abs().clamp_min(1.0)).max()) < 1.1 * ulp
+
+
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16, torch.float32])
 @pytest.mark.parametrize('N', [512, 768])
 def test_linear_column_tiles_per_xcd(dtype, N):

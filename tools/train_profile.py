@@ -1,8 +1,9 @@
 """Where the training step spends its time (torch profiler, top ops by device time).
-   python tools/train_profile.py [H W] [--no-fused] [--no-prof] [--bf16] [--hip]"""
+   python tools/train_profile.py [H W] [--no-fused] [--no-prof] [--bf16] [--hip] [--batch B] [--long]"""
 import sys, time, torch
 HW = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 and sys.argv[1].isdigit() else (480, 640)
 FUSED = '--no-fused' not in sys.argv
+B = int(sys.argv[sys.argv.index('--batch') + 1]) if '--batch' in sys.argv else 2
 sys.path.insert(0, '.')
 from geoformer_amd import miopen; miopen.use_shipped_find_db()
 from geoformer_amd.model.cvpr_ds_config import get_default_cfg
@@ -13,16 +14,21 @@ from geoformer_amd.train import TrainStep, synthetic_homography_batch
 g = get_cfg_model(); g.update(coarse_thr=0.0, fine_thr=0.0, precision='fp32')
 model = deterministic_init_(GeoFormer(get_default_cfg(), g)).cuda()
 PREC = 'bf16' if '--bf16' in sys.argv else 'fp32'
-step = TrainStep(model, batch_size=2, fused_coarse_loss=FUSED, precision=PREC, hip_backward='--hip' in sys.argv)
+step = TrainStep(model, batch_size=B, fused_coarse_loss=FUSED, precision=PREC, hip_backward='--hip' in sys.argv)
 nsteps = 10 if "--long" in sys.argv else 4
-batches = [synthetic_homography_batch(2, HW, seed=it, device='cuda') for it in range(nsteps)]      # (made outside the timed steps)
+batches = [synthetic_homography_batch(B, HW, seed=it, device='cuda') for it in range(nsteps)]      # (made outside the timed steps)
 torch.cuda.synchronize()
 for it in range(nsteps):
     t = time.perf_counter(); step(batches[it]); torch.cuda.synchronize()
-    print('step', it, '%.3f s' % (time.perf_counter() - t), 'fused' if FUSED else 'autograd', PREC, HW, flush=True)
+    print('step', it, '%.3f s' % (time.perf_counter() - t), 'fused' if FUSED else 'autograd', PREC, HW, 'batch', B, flush=True)
 if '--no-prof' in sys.argv:
     sys.exit(0)
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
-    step(synthetic_homography_batch(2, HW, seed=9, device='cuda')); torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=25, max_name_column_width=50))
+    step(synthetic_homography_batch(B, HW, seed=9, device='cuda')); torch.cuda.synchronize()
+ka = prof.key_averages()
+print(ka.table(sort_by='cuda_time_total', row_limit=25, max_name_column_width=50))
+dev = sum(getattr(e, 'self_device_time_total', getattr(e, 'self_cuda_time_total', 0)) for e in ka) * 1e-3
+ncalls = sum(e.count for e in ka if getattr(e, 'self_device_time_total', getattr(e, 'self_cuda_time_total', 0)) > 0)
+print(f'device time (sum over kernels) {dev:.1f} ms in {ncalls} device-side calls; host ops recorded {sum(e.count for e in ka)}')
+print(ka.table(sort_by='self_cpu_time_total', row_limit=15, max_name_column_width=50))
