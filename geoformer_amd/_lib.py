@@ -42,6 +42,8 @@ SIGNATURES = {
     'gf_activation_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     'gf_fine_match_backward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'gf_linear_attention_backward_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
+    'gf_window_linear_attention_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
+                                                    c_void_p, c_void_p]),
     'gf_linear_attention_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long,
                                              c_long, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'gf_coarse_loss_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
@@ -85,6 +87,8 @@ SIGNATURES = {
                                            c_size_t, c_void_p]),
     'gf_window_cross_attention': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                           c_long, c_long, c_long, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'gf_window_cross_attention_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                   c_long, c_long, c_long, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'gf_window_cross_attention_tiled': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                                 c_int, c_long, c_long, c_long, c_void_p, c_int, c_void_p, c_void_p,
                                                 c_void_p]),

@@ -282,6 +282,111 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 }
 
 // ------------------------------------------------------------------------------------------------
+// K5 backward (training): gradients of window_cross_attention's output with respect to q and to the two projected
+// maps.  One wave per query, lane = 4 channels (its head = lane / 16), as the forward: the 25 logits and the 25 products
+// dP_k = dout . v_k are recomputed from the rows (no attention matrix is kept by the forward), then with p = softmax(logit):
+//     dlogit_k = p_k (dP_k - sum_j p_j dP_j) / sqrt(D),   dq = sum_k dlogit_k k_k,   dk[cell_k] += dlogit_k q,   dv[cell_k] += p_k dout.
+// The windows of neighbouring queries overlap, so dk / dv are scatter-ADDS: fp32 atomic adds (256 contiguous bytes per wave
+// instruction) into zero-initialised fp32 maps [N][S][256] - the sums of ~25 contributions per cell stay in fp32 and are rounded
+// to the storage type once by the caller.  Masked window positions (cell < 0) have p = 0: no gradient; a query without any valid
+// key has a zeroed output (geo_attention.py:98-100): no gradient at all.
+// ------------------------------------------------------------------------------------------------
+struct CbArgs {
+    const void* q;
+    const void* kmap;
+    const void* vmap;
+    const void* dout;       // [N][L][256]
+    long ldq, ldk, ldv;
+    const int32_t* win;     // [N][L][WW]
+    void* dq;               // [N][L][256] of T
+    float* dk;              // [N][S][256] fp32, zeroed by the caller
+    float* dv;
+    int N, L, S;
+    float softmax_temp;
+};
+
+template <typename T, int WW>
+__global__ __launch_bounds__(256) void window_cross_attention_backward(CbArgs a) {
+    using Raw = typename Raw4<T>::type;
+    const int n = blockIdx.y, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l = blockIdx.x * 4 + wave;
+    if (l >= a.L) return;
+    const int32_t* win = a.win + ((size_t)n * a.L + l) * WW;
+    int cell[WW];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < WW; ++k) {
+        cell[k] = win[k];
+        any = any || cell[k] >= 0;
+    }
+    T* dq = (T*)a.dq + ((size_t)n * a.L + l) * 256 + lane * 4;
+    if (!any) {
+        store4<T>(dq, v4f{0.f, 0.f, 0.f, 0.f});
+        return;
+    }
+    const v4f q = load4<T>((const T*)a.q + ((size_t)n * a.L + l) * a.ldq + lane * 4);
+    const v4f go = load4<T>((const T*)a.dout + ((size_t)n * a.L + l) * 256 + lane * 4);
+    const T* kb = (const T*)a.kmap + (size_t)n * a.S * a.ldk + lane * 4;
+    const T* vb = (const T*)a.vmap + (size_t)n * a.S * a.ldv + lane * 4;
+    Raw kraw[WW];
+    float dot[WW], dp[WW];
+#pragma unroll
+    for (int k = 0; k < WW; ++k) kraw[k] = *reinterpret_cast<const Raw*>(kb + (unsigned)max(cell[k], 0) * (unsigned)a.ldk);
+#pragma unroll
+    for (int k = 0; k < WW; ++k) {
+        const v4f vv = widen4(*reinterpret_cast<const Raw*>(vb + (unsigned)max(cell[k], 0) * (unsigned)a.ldv));
+        dp[k] = go.x * vv.x + go.y * vv.y + go.z * vv.z + go.w * vv.w;
+    }
+#pragma unroll
+    for (int k = 0; k < WW; ++k) {
+        const v4f kv = widen4(kraw[k]);
+        dot[k] = q.x * kv.x + q.y * kv.y + q.z * kv.z + q.w * kv.w;
+    }
+#pragma unroll
+    for (int k = 0; k < WW; ++k) { dot[k] = dpp_add<0xB1>(dot[k]); dp[k] = dpp_add<0xB1>(dp[k]); }
+#pragma unroll
+    for (int k = 0; k < WW; ++k) { dot[k] = dpp_add<0x4E>(dot[k]); dp[k] = dpp_add<0x4E>(dp[k]); }
+#pragma unroll
+    for (int k = 0; k < WW; ++k) { dot[k] = dpp_add<0x141>(dot[k]); dp[k] = dpp_add<0x141>(dp[k]); }
+#pragma unroll
+    for (int k = 0; k < WW; ++k) { dot[k] = dpp_add<0x140>(dot[k]); dp[k] = dpp_add<0x140>(dp[k]); }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < WW; ++k) {
+        dot[k] = (cell[k] >= 0 ? dot[k] : -1e8f) * a.softmax_temp;
+        mx = fmaxf(mx, dot[k]);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int k = 0; k < WW; ++k) {
+        dot[k] = cell[k] >= 0 ? expf(dot[k] - mx) : 0.f;
+        den += dot[k];
+    }
+    float pd = 0.f;
+#pragma unroll
+    for (int k = 0; k < WW; ++k) {
+        dot[k] = dot[k] / den;                                   // p_k (this head's)
+        pd += dot[k] * dp[k];
+    }
+    v4f acc{0.f, 0.f, 0.f, 0.f};
+    float* dkb = a.dk + (size_t)n * a.S * 256 + lane * 4;
+    float* dvb = a.dv + (size_t)n * a.S * 256 + lane * 4;
+#pragma unroll
+    for (int k = 0; k < WW; ++k) {
+        if (cell[k] < 0) continue;                               // (wave-uniform)
+        const float p = dot[k], dl = p * (dp[k] - pd) * a.softmax_temp;
+        const v4f kv = widen4(kraw[k]);
+        acc.x += dl * kv.x; acc.y += dl * kv.y; acc.z += dl * kv.z; acc.w += dl * kv.w;
+        float* dkp = dkb + (size_t)cell[k] * 256;
+        float* dvp = dvb + (size_t)cell[k] * 256;
+        atomicAdd(dkp + 0, dl * q.x); atomicAdd(dkp + 1, dl * q.y); atomicAdd(dkp + 2, dl * q.z); atomicAdd(dkp + 3, dl * q.w);
+        atomicAdd(dvp + 0, p * go.x); atomicAdd(dvp + 1, p * go.y); atomicAdd(dvp + 2, p * go.z); atomicAdd(dvp + 3, p * go.w);
+    }
+    store4<T>(dq, acc);
+}
+
+// ------------------------------------------------------------------------------------------------
 // K5, tiled form (16-bit storage, map widths known).  One workgroup = a tile of 8 x 4 query cells and ONE head.  The windows
 // of neighbouring queries overlap: the union of the tile's 32 x 25 window cells is a small rectangle of the key map (12 x 8
 // cells for a translation), so the head's 128-byte slices of the key and value rows of that rectangle are brought into LDS
@@ -572,6 +677,25 @@ extern "C" int gf_window_cross_attention(const void* q, const void* kmap, const 
     else if (dtype == GF_F16) window_cross_attention<_Float16, 25><<<grid, 256, 0, st>>>(a);
     else window_cross_attention<gf_bf16, 25><<<grid, 256, 0, st>>>(a);
     gf_prof_end("k5_window_attention", pt, st);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}
+
+// dq [N, L, 256] of `dtype`, dk / dv fp32 [N, S, 256] (ZEROED by the caller: the kernel adds into them) of gf_window_cross_attention
+extern "C" int gf_window_cross_attention_backward(const void* q, const void* kmap, const void* vmap, const void* dout, int dtype, int N, int L,
+                                                  int S, int H, int D, long ldq, long ldk, long ldv, const int32_t* win, int WW, void* dq,
+                                                  float* dk, float* dv, void* stream) {
+    GF_CHECK_ARG(q && kmap && vmap && dout && win && dq && dk && dv, "null pointer");
+    GF_CHECK_ARG(N > 0 && L > 0 && S > 0, "empty problem");
+    GF_CHECK_ARG(H == 4 && D == 64 && WW == 25, "built for nhead=4, head dim 64, 5x5 windows (geo_config.py:12,16)");
+    GF_CHECK_ARG((double)S * (double)(ldk > ldv ? ldk : ldv) < 4294967296.0, "key map too large for 32-bit row offsets");
+    GF_CHECK_ARG(dtype >= GF_F32 && dtype <= GF_BF16, "bad dtype");
+    CbArgs a{q, kmap, vmap, dout, ldq, ldk, ldv, win, dq, dk, dv, N, L, S, 1.0f / sqrtf((float)D)};
+    const dim3 grid((L + 3) / 4, N);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GF_F32) window_cross_attention_backward<float, 25><<<grid, 256, 0, st>>>(a);
+    else if (dtype == GF_F16) window_cross_attention_backward<_Float16, 25><<<grid, 256, 0, st>>>(a);
+    else window_cross_attention_backward<gf_bf16, 25><<<grid, 256, 0, st>>>(a);
     GF_CHECK_LAUNCH();
     return GF_OK;
 }

@@ -617,6 +617,142 @@ extern "C" int gf_linear_attention_backward(const void* q, const void* k, const 
 }
 
 // =====================================================================================================================
+// K2 (training, fine level): backward of LinearAttention.forward (linear_attention.py:21-51) on the fine-level windows -
+// [Nw, Lw <= 32, 8 heads x 16 channels] tensors, no masks (full_model.py:97-98) - whose forward is la_window_mfma
+// (k2_linear_attention.hip).  With A = phi(q), B = phi(k), vs = v / Lw, KV = B^T vs, ks = sum_s B_s, den = A ks + eps,
+// num = A KV, out = Lw num / den:
+//   dnum = dout Lw / den,  dden = -(dout . num) Lw / den^2,  dA = dnum KV^T + dden ks,  dKV = A^T dnum,  dks = sum_l dden_l A_l,
+//   dB = vs dKV^T + dks,  dvs = B dKV,  dq = dA phi'(q),  dk = dB phi'(k),  dv = dvs / Lw,   phi'(x) = x > 0 ? 1 : exp(x).
+// One workgroup of 128 threads per window (thread = channel (head, d)), everything in LDS, fp32 arithmetic on the 16-bit
+// operands; the state's MFMA operands are rounded to the storage type where the forward rounds them (phi(q), phi(k), vs).
+// =====================================================================================================================
+namespace {
+
+constexpr int WB_C = 128, WB_D = 16, WB_H = 8, WB_L = 32;
+
+template <typename T>
+__global__ __launch_bounds__(128) void window_la_backward(const T* q, const T* k, const T* v, const T* dout, T* dq, T* dk, T* dv, int Lw, float eps) {
+    extern __shared__ __attribute__((aligned(16))) char wb_smem[];                     // 4 x [Lw][129] floats: phi(q) | phi(k) | v / Lw | dout -> dnum
+    typedef float Row[WB_C + 1];
+    Row* sA = reinterpret_cast<Row*>(wb_smem);
+    Row* sB = sA + Lw;
+    Row* sV = sB + Lw;
+    Row* sG = sV + Lw;
+    __shared__ float sKV[WB_H][WB_D][WB_D + 1], sdKV[WB_H][WB_D][WB_D + 1];
+    __shared__ float sks[WB_C], sdks[WB_C], sden[WB_L][WB_H], sdd[WB_L][WB_H];
+    const int w = blockIdx.x, c = threadIdx.x, h = c >> 4, d = c & 15;
+    const size_t base = (size_t)w * Lw * WB_C;
+    const float inv_l = 1.0f / (float)Lw, fl = (float)Lw;
+    auto rt = [](float x) { return gf_to_float(gf_from_float<T>(x)); };
+    auto phi = [](float x) { return x > 0.f ? x + 1.f : __expf(x); };
+    for (int l = 0; l < Lw; ++l) {
+        sA[l][c] = rt(phi(gf_to_float(q[base + (size_t)l * WB_C + c])));
+        sB[l][c] = rt(phi(gf_to_float(k[base + (size_t)l * WB_C + c])));
+        sV[l][c] = rt(gf_to_float(v[base + (size_t)l * WB_C + c]) * inv_l);
+        sG[l][c] = gf_to_float(dout[base + (size_t)l * WB_C + c]);
+    }
+    __syncthreads();
+    // ---- forward state: ks, KV[h][d][:] (thread (h, d))
+    {
+        float s = 0.f, kv[WB_D];
+#pragma unroll
+        for (int u = 0; u < WB_D; ++u) kv[u] = 0.f;
+        for (int l = 0; l < Lw; ++l) {
+            const float b = sB[l][c];
+            s += b;
+#pragma unroll
+            for (int u = 0; u < WB_D; ++u) kv[u] += b * sV[l][h * WB_D + u];
+        }
+        sks[c] = s;
+#pragma unroll
+        for (int u = 0; u < WB_D; ++u) sKV[h][d][u] = kv[u];
+    }
+    __syncthreads();
+    // ---- den[l][h] (threads < Lw * 8), then num[l][(h, v)] on thread (h, v): dnum, and dden through sdd
+    for (int e = c; e < Lw * WB_H; e += 128) {
+        const int l = e >> 3, hh = e & 7;
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < WB_D; ++u) s += sA[l][hh * WB_D + u] * sks[hh * WB_D + u];
+        sden[l][hh] = s + eps;
+        sdd[l][hh] = 0.f;
+    }
+    __syncthreads();
+    for (int l = 0; l < Lw; ++l) {
+        float num = 0.f;
+#pragma unroll
+        for (int u = 0; u < WB_D; ++u) num += sA[l][h * WB_D + u] * sKV[h][u][d];          // (thread's d plays v here)
+        const float g = sG[l][c], den = sden[l][h];
+        sG[l][c] = g * fl / den;                                                            // dnum
+        // dden[l][h] = -(sum_v dout num) Lw / den^2: sum over the head's 16 lanes
+        float t = g * num;
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) t += __shfl_xor(t, o, 64);
+        if (d == 0) sdd[l][h] = -t * fl / (den * den);
+    }
+    __syncthreads();
+    // ---- dA -> dq; dKV, dks (thread (h, d))
+    {
+        float dkv[WB_D], dks = 0.f;
+#pragma unroll
+        for (int u = 0; u < WB_D; ++u) dkv[u] = 0.f;
+        const float ksd = sks[c];
+        for (int l = 0; l < Lw; ++l) {
+            float da = sdd[l][h] * ksd;
+#pragma unroll
+            for (int u = 0; u < WB_D; ++u) da += sG[l][h * WB_D + u] * sKV[h][d][u];
+            const float a = sA[l][c];
+#pragma unroll
+            for (int u = 0; u < WB_D; ++u) dkv[u] += a * sG[l][h * WB_D + u];
+            dks += sdd[l][h] * a;
+            const float x = gf_to_float(q[base + (size_t)l * WB_C + c]);
+            dq[base + (size_t)l * WB_C + c] = gf_from_float<T>(da * (x > 0.f ? 1.f : __expf(x)));
+        }
+#pragma unroll
+        for (int u = 0; u < WB_D; ++u) sdKV[h][d][u] = dkv[u];
+        sdks[c] = dks;
+    }
+    __syncthreads();
+    // ---- dB -> dk (thread (h, d)); dvs -> dv (thread (h, v))
+    for (int l = 0; l < Lw; ++l) {
+        float db = sdks[c], dvs = 0.f;
+#pragma unroll
+        for (int u = 0; u < WB_D; ++u) {
+            db += sV[l][h * WB_D + u] * sdKV[h][d][u];
+            dvs += sB[l][h * WB_D + u] * sdKV[h][u][d];
+        }
+        const float x = gf_to_float(k[base + (size_t)l * WB_C + c]);
+        dk[base + (size_t)l * WB_C + c] = gf_from_float<T>(db * (x > 0.f ? 1.f : __expf(x)));
+        dv[base + (size_t)l * WB_C + c] = gf_from_float<T>(dvs * inv_l);
+    }
+}
+
+}   // namespace
+
+// dq, dk, dv [Nw, Lw, 128] (contiguous, `dtype`) of the fine-level window linear attention (8 heads of 16, no masks) given dout
+extern "C" int gf_window_linear_attention_backward(const void* q, const void* k, const void* v, const void* dout, int dtype, int Nw, int Lw,
+                                                   float eps, void* dq, void* dk, void* dv, void* stream) {
+    GF_CHECK_ARG(q && k && v && dout && dq && dk && dv, "null pointer");
+    GF_CHECK_ARG(dtype == GF_F16 || dtype == GF_BF16, "built for 16-bit activations");
+    GF_CHECK_ARG(Nw > 0 && Lw > 0 && Lw <= WB_L, "windows of 1 .. 32 tokens");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)4 * Lw * (WB_C + 1) * sizeof(float);                  // 66 KB at Lw = 32
+    static std::atomic<uint64_t> attr{0};
+    if (gf_first_use_on_device(attr)) {
+        (void)hipFuncSetAttribute((const void*)window_la_backward<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WB_L * (WB_C + 1) * 4);
+        (void)hipFuncSetAttribute((const void*)window_la_backward<gf_bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WB_L * (WB_C + 1) * 4);
+    }
+    if (dtype == GF_F16)
+        window_la_backward<_Float16><<<Nw, 128, lds, st>>>((const _Float16*)q, (const _Float16*)k, (const _Float16*)v, (const _Float16*)dout,
+                                                        (_Float16*)dq, (_Float16*)dk, (_Float16*)dv, Lw, eps);
+    else
+        window_la_backward<gf_bf16><<<Nw, 128, lds, st>>>((const gf_bf16*)q, (const gf_bf16*)k, (const gf_bf16*)v, (const gf_bf16*)dout, (gf_bf16*)dq,
+                                                       (gf_bf16*)dk, (gf_bf16*)dv, Lw, eps);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}
+
+// =====================================================================================================================
 // K8 (training): backward of FineMatching2.forward's confidence (model/fine_matching2.py:52-63):
 //   sim = f0 f1^T / (C temperature), A = softmax(sim, dim 1), B = softmax(sim, dim 2), conf = A o B        (per match, 25 x 25)
 // given G = dL/dconf:  T = G o conf,  dsim = 2 T - A o (1 colsum(T)^T) - B o (rowsum(T) 1^T),

@@ -352,6 +352,25 @@ def window_cross_attention(q, kmap, vmap, win, valid=None, nhead=4, hw_q=None, h
     return out
 
 
+def window_cross_attention_backward(q, kmap, vmap, dout, win, nhead=4):
+    """(dq [N,L,256] of q's dtype, dk, dv fp32 [N,S,256]) of window_cross_attention given dout [N,L,256]."""
+    _need_cuda(q, kmap, vmap, dout, win)
+    N, L, C = q.shape
+    S = kmap.shape[1]
+    q, ldq = _rows(q)
+    kmap, ldk = _rows(kmap)
+    vmap, ldv = _rows(vmap)
+    if q.stride(0) != ldq * L or kmap.stride(0) != ldk * S or vmap.stride(0) != ldv * S:
+        raise ValueError('window_cross_attention_backward needs batch stride == rows * row stride')
+    dout = _contig(dout)
+    dq = torch.empty(N, L, C, dtype=q.dtype, device=q.device)
+    dkv = torch.zeros(2, N, S, C, dtype=torch.float32, device=q.device)
+    check(_lib.lib().gf_window_cross_attention_backward(_p(q), _p(kmap), _p(vmap), _p(dout), _dt(q), N, L, S, nhead, C // nhead, ldq, ldk, ldv,
+                                                        _p(win), win.shape[-1], _p(dq), _p(dkv[0]), _p(dkv[1]), _stream()),
+          'gf_window_cross_attention_backward')
+    return dq, dkv[0], dkv[1]
+
+
 def fine_gather(feat_f0, feat_f1, feat_c0, feat_c1, b_ids, i_ids, j_ids, w0c, w1c, stride, window, out_dtype):
     """K7.  feat_f* [N,Cf,H,W] any strides; feat_c* [N,L,CC] contiguous of out_dtype; ids int64 [M] (M > 0)
     -> (win [2M, W*W, Cf], ccat [2M, CC])."""
@@ -581,6 +600,20 @@ def linear_attention_backward(q, k, v, dout, nhead, q_mask=None, kv_mask=None, e
     check(L_.gf_linear_attention_backward(_p(q), _p(k), _p(v), _p(dout), _dt(q), N, L, S, nhead, D, ldq, ldk, ldv, ldo, _p(qm), _p(km), float(eps),
                                           _p(dq), _p(dkv[0]), _p(dkv[1]), _p(ws), ws.numel(), _stream()), 'gf_linear_attention_backward')
     return dq, dkv[0], dkv[1]
+
+
+def window_linear_attention_backward(q, k, v, dout, eps=1e-6):
+    """(dq, dk, dv) [Nw, Lw, 128] of the fine level's window linear attention (8 heads of 16, Lw <= 32, no masks) given dout."""
+    _need_cuda(q, k, v, dout)
+    q, k, v, dout = _contig(q), _contig(k), _contig(v), _contig(dout)
+    Nw, Lw, C = q.shape
+    if C != 128 or Lw > 32 or k.shape != q.shape or v.shape != q.shape or dout.shape != q.shape:
+        raise ValueError('window_linear_attention_backward: [Nw, Lw <= 32, 128] tensors of one shape')
+    d = torch.empty(3, Nw, Lw, C, dtype=q.dtype, device=q.device)
+    if Nw:
+        check(_lib.lib().gf_window_linear_attention_backward(_p(q), _p(k), _p(v), _p(dout), _dt(q), Nw, Lw, float(eps), _p(d[0]), _p(d[1]),
+                                                             _p(d[2]), _stream()), 'gf_window_linear_attention_backward')
+    return d[0], d[1], d[2]
 
 
 def fine_match_backward(f0, f1, temperature, dconf):

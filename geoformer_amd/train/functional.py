@@ -117,15 +117,37 @@ def _encoder_layer_hip(P, prefix, x, source, nhead, kind, x_mask, source_mask):
     v = HA.linear(s16, P[prefix + 'v_proj.weight'])
     if kind == 'loftr' and d == 32:                      # the coarse level: K2 forward and backward in HIP
         msg = HA.linear_attention(q, k, v, nhead, x_mask, source_mask)
+    elif (kind == 'loftr' and d == 16 and c == 128 and x.shape[1] <= 32 and source.shape[1] == x.shape[1] and x_mask is None
+          and source_mask is None):                      # the fine level's 25-token windows: K2's window form and its backward
+        msg = HA.window_linear_attention(q, k, v, nhead)
     else:
         q, k, v = (t.view(n, -1, nhead, d) for t in (q, k, v))
         msg = linear_attention(q, k, v, x_mask, source_mask) if kind == 'loftr' else full_attention(q, k, v, source_mask)
-    msg = HA.linear(msg.reshape(n, -1, c).to(dt), P[prefix + 'merge.weight'])
+    return _finish_layer_hip(P, prefix, x, x16, msg.reshape(n, -1, c).to(dt), kind)
+
+
+def _finish_layer_hip(P, prefix, x, x16, msg, kind):
+    """merge -> LayerNorm -> MLP on [x | message] -> LayerNorm -> + x on the HIP Functions (the part of an encoder layer behind its
+    attention; transformer.py:53-60 / geo_transformer/transformer.py:59-66)."""
+    from . import hip_autograd as HA
+    msg = HA.linear(msg, P[prefix + 'merge.weight'])
     msg = HA.layer_norm(msg, P[prefix + 'norm1.weight'], P[prefix + 'norm1.bias'])
     hid = HA.linear(x16, P[prefix + 'mlp.0.weight'], msg, 'relu' if kind == 'loftr' else 'tanh')
     msg = HA.linear(hid, P[prefix + 'mlp.2.weight'])
     msg = HA.layer_norm(msg, P[prefix + 'norm2.weight'], P[prefix + 'norm2.bias'])
     return x + msg
+
+
+def _geo_cross_layer_hip(P, prefix, x, kmap, vmap, win, nhead):
+    """One side of GeoTransformer's 'cross' layer (geo_transformer/transformer.py:125-139) on the HIP Functions: x [L, C] attends to
+    the 25 window positions `win` [L, 25] (cells of the other image, -1 = masked) of the other image's PROJECTED maps kmap / vmap
+    [S, C] (project-then-gather: k_proj / v_proj have no bias, so gathering their outputs equals projecting the gathered rows)."""
+    from . import hip_autograd as HA
+    dt = torch.get_autocast_dtype('cuda')
+    x16 = x.to(dt)[None]
+    q = HA.linear(x16, P[prefix + 'q_proj.weight'])
+    msg = HA.window_cross_attention(q, kmap, vmap, win, nhead)
+    return _finish_layer_hip(P, prefix, x[None], x16, msg, 'geo')[0]
 
 
 def encoder_layer(P, prefix, x, source, nhead, kind, x_mask=None, source_mask=None):
@@ -279,6 +301,7 @@ def geo_module(P, cnn0, cnn1, data, geo_cfg, homography_fn: Callable):
     idx1 = [m.nonzero().flatten() for m in map1]
     f0 = [f0[b] for b in range(n)]          # per-sample lists: no in-place writes into autograd inputs
     f1 = [f1[b] for b in range(n)]
+    cells = [None] * n                      # HIP path: (win1 cells, win0 cells) int32 [1, L, 25] per sample, -1 = masked
     for idx, name in enumerate(geo_cfg['layer_names']):
         lp = f'geo_module.des_transformer.layers.{idx}.'
         if name == 'self':
@@ -287,6 +310,22 @@ def geo_module(P, cnn0, cnn1, data, geo_cfg, homography_fn: Callable):
                     f0[b] = encoder_layer(P, lp, f0[b][None], f0[b].index_select(0, idx0[b])[None], nhead, 'geo')[0]
                 if idx1[b].numel():
                     f1[b] = encoder_layer(P, lp, f1[b][None], f1[b].index_select(0, idx1[b])[None], nhead, 'geo')[0]
+        elif name == 'cross' and _HIP_BACKWARD[0] and cnn0.is_cuda and torch.is_autocast_enabled() and c == 256 and nhead == 4 and wsz == 5:
+            # K5 forward and backward in HIP on the projected maps (both images' keys / values from the PRE-update features, :126-129)
+            from . import hip_autograd as HA
+            dt = torch.get_autocast_dtype('cuda')
+            for b in range(n):
+                if win1[b] is None:
+                    continue
+                if cells[b] is None:
+                    with torch.no_grad():
+                        cells[b] = tuple(torch.where(m, (k[..., 1] // scale) * wk_ + k[..., 0] // scale, -1).to(torch.int32)[None].contiguous()
+                                         for k, m, wk_ in ((win1[b], msk1[b], ww1), (win0[b], msk0[b], ww0)))
+                s0, s1 = f0[b].to(dt)[None], f1[b].to(dt)[None]
+                k0, v0 = HA.linear(s0, P[lp + 'k_proj.weight']), HA.linear(s0, P[lp + 'v_proj.weight'])
+                k1, v1 = HA.linear(s1, P[lp + 'k_proj.weight']), HA.linear(s1, P[lp + 'v_proj.weight'])
+                f0[b] = _geo_cross_layer_hip(P, lp, f0[b], k1, v1, cells[b][0], nhead)
+                f1[b] = _geo_cross_layer_hip(P, lp, f1[b], k0, v0, cells[b][1], nhead)
         elif name == 'cross':
             g0 = [None if win0[b] is None else _sample_windows(win0[b], f0[b], ww0, scale) for b in range(n)]
             g1 = [None if win1[b] is None else _sample_windows(win1[b], f1[b], ww1, scale) for b in range(n)]

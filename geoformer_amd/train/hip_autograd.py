@@ -124,6 +124,44 @@ class HipLinearAttention(torch.autograd.Function):
         return dq, dk, dv, None, None, None
 
 
+class HipWindowLinearAttention(torch.autograd.Function):
+    """LinearAttention.forward on the fine level's windows ([Nw, Lw <= 32, 128], 8 heads of 16, no masks; full_model.py:97-98):
+    forward = K2's window form (la_window_mfma), backward = gf_window_linear_attention_backward (csrc/k_train.hip)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, nhead):
+        out = ops.linear_attention(q, k, v, nhead)
+        ctx.save_for_backward(q, k, v)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v = ctx.saved_tensors
+        dq, dk, dv = ops.window_linear_attention_backward(q, k, v, dout)
+        return dq, dk, dv, None
+
+
+class HipWindowCrossAttention(torch.autograd.Function):
+    """FullAttention.forward over the 25 keys of each query's window (geo_attention.py:72-101 as GeoTransformer's 'cross' branch
+    calls it, transformer.py:125-139) on the PROJECTED maps: q [N,L,256], kmap / vmap [N,S,256] = k_proj / v_proj of every token of
+    the other image, win int32 [N,L,25] (cell of the other image per window position, -1 = masked).  Project-then-gather is the same
+    arithmetic as the reference's gather-then-project (the projections have no bias) at 1/25 of its k / v projection flops and without
+    the [L, 25, C] gathered tensors; forward = K5, backward = gf_window_cross_attention_backward."""
+
+    @staticmethod
+    def forward(ctx, q, kmap, vmap, win, nhead):
+        out = ops.window_cross_attention(q, kmap, vmap, win, None, nhead)
+        ctx.save_for_backward(q, kmap, vmap, win)
+        ctx.nhead = nhead
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kmap, vmap, win = ctx.saved_tensors
+        dq, dk, dv = ops.window_cross_attention_backward(q, kmap, vmap, dout, win, ctx.nhead)
+        return dq, dk.to(kmap.dtype), dv.to(vmap.dtype), None, None
+
+
 class HipFineMatch(torch.autograd.Function):
     """FineMatching2.forward + get_fine_match (model/fine_matching2.py:21-126) = K8: returns (fine_matrix [M, 25, 25] fp32, m_bids, mkpts0_f,
     mkpts1_f, mconf); only fine_matrix carries a gradient (to the two window tensors), through gf_fine_match_backward."""
@@ -147,6 +185,14 @@ class HipFineMatch(torch.autograd.Function):
 
 def linear_attention(q, k, v, nhead, q_mask=None, kv_mask=None):
     return HipLinearAttention.apply(q, k, v, nhead, q_mask, kv_mask)
+
+
+def window_linear_attention(q, k, v, nhead):
+    return HipWindowLinearAttention.apply(q, k, v, nhead)
+
+
+def window_cross_attention(q, kmap, vmap, win, nhead=4):
+    return HipWindowCrossAttention.apply(q, kmap, vmap, win, nhead)
 
 
 def linear(x, w, x2=None, act=None):

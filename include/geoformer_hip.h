@@ -124,6 +124,10 @@ size_t gf_linear_attention_backward_workspace_bytes(int N, int L, int S, int H);
 int gf_linear_attention_backward(const void* q, const void* k, const void* v, const void* dout, int dtype, int N, int L, int S, int H,
                                  int D, long ldq, long ldk, long ldv, long ldo, const uint8_t* q_mask, const uint8_t* kv_mask, float eps,
                                  void* dq, void* dk, void* dv, void* workspace, size_t workspace_bytes, void* stream);
+/* the same backward for the fine level's windows: q, k, v, dout, dq, dk, dv contiguous [Nw, Lw <= 32, 8 heads x 16] tensors, no masks
+ * (the forward is gf_linear_attention's window form); one workgroup per window, fp32 arithmetic on the 16-bit operands. */
+int gf_window_linear_attention_backward(const void* q, const void* k, const void* v, const void* dout, int dtype, int Nw, int Lw,
+                                        float eps, void* dq, void* dk, void* dv, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K1 (training)  sparse-supervision focal loss on the dual-softmax confidence, forward and backward
@@ -348,6 +352,12 @@ int gf_self_attention_gathered(const void* q, const void* kmap, const void* vmap
 int gf_window_cross_attention(const void* q, const void* kmap, const void* vmap, int dtype, int N, int L, int S,
                               int H, int D, long ldq, long ldk, long ldv, const int32_t* win, int WW,
                               const int32_t* valid, void* out, void* stream);
+/* Backward of gf_window_cross_attention for the training step: dq [N,L,256] of `dtype`; dk, dv fp32 [N,S,256],
+ * ZEROED by the caller - overlapping windows make them scatter-adds (fp32 atomics; the sums are rounded to the storage type once,
+ * by the caller).  dout [N,L,256] contiguous.  Masked window positions and queries without a valid key get no gradient. */
+int gf_window_cross_attention_backward(const void* q, const void* kmap, const void* vmap, const void* dout, int dtype, int N, int L,
+                                       int S, int H, int D, long ldq, long ldk, long ldv, const int32_t* win, int WW, void* dq,
+                                       float* dk, float* dv, void* stream);
 /* The same operation when the query map is hq x wq cells and the key map hk x wk cells (L = hq*wq, S = hk*wk, cells row-major as
  * gf_window_geometry numbers them).  16-bit storage: one workgroup per tile of 8 x 4 query cells and head; the windows of a
  * tile overlap, so the key / value rows of their bounding rectangle are staged in LDS once (a tile whose rectangle exceeds 144

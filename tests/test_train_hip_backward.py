@@ -237,3 +237,71 @@ def test_hip_functions_follow_a_hand_stepped_optimizer():
     assert l_hip[2] < l_hip[1] < l_hip[0]
     np.testing.assert_allclose(l_hip, l_ref, rtol=2e-3)
     assert float((w_hip - w_ref).norm() / (w_ref - w0).norm()) < 2e-2
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('Lw', [25, 32, 7])
+def test_window_linear_attention_backward(dtype, Lw):
+    """The fine level's window linear attention (8 heads of 16, <= 32 tokens, no masks): HipWindowLinearAttention - forward K2's
+    window form, backward gf_window_linear_attention_backward - against autograd of the functional restatement
+    (linear_attention.py:21-51) on the same 16-bit tensors: output to the storage type's resolution, dq / dk / dv to 2e-2 in norm."""
+    from geoformer_amd.train import functional as TF
+    from geoformer_amd.train import hip_autograd as HA
+    g = torch.Generator().manual_seed(Lw)
+    Nw = 300
+    q, k, v = ((torch.randn(Nw, Lw, 128, generator=g) * 0.8).to(DEV).to(dtype) for _ in range(3))
+    dout = (torch.randn(Nw, Lw, 128, generator=g) * 0.5).to(DEV).to(dtype)
+    a = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    ref = TF.linear_attention(*(t.view(Nw, Lw, 8, 16) for t in a)).reshape(Nw, Lw, 128)
+    ref.backward(dout)
+    b = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    out = HA.window_linear_attention(*b, 8)
+    out.backward(dout)
+    ulp = 2.0 ** (-10 if dtype == torch.float16 else -7)
+    assert float((out.float() - ref.float()).abs().max()) < 4 * ulp * float(ref.float().abs().max())
+    for name, x, y in zip('qkv', b, a):
+        rel = float((x.grad.float() - y.grad.float()).norm() / y.grad.float().norm())
+        assert rel < 2e-2, (name, rel)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32])
+def test_window_cross_attention_backward(dtype):
+    """GeoTransformer's 'cross' attention (25 window keys per query, 4 heads of 64; geo_attention.py:72-101) on the projected maps:
+    HipWindowCrossAttention - forward K5, backward gf_window_cross_attention_backward (fp32 scatter-adds for the overlapping
+    windows) - against autograd of the functional restatement (gather the window rows, full_attention with the window mask) on the
+    same tensors; masked window positions, a query without any valid key, repeated cells."""
+    from geoformer_amd.train import functional as TF
+    from geoformer_amd.train import hip_autograd as HA
+    g = torch.Generator().manual_seed(23)
+    hq, wq, hk, wk = 20, 24, 18, 26
+    L, S, C = hq * wq, hk * wk, 256
+    q = (torch.randn(1, L, C, generator=g) * 0.8).to(DEV).to(dtype)
+    km = (torch.randn(1, S, C, generator=g) * 0.8).to(DEV).to(dtype)
+    vm = (torch.randn(1, S, C, generator=g) * 0.8).to(DEV).to(dtype)
+    dout = (torch.randn(1, L, C, generator=g) * 0.5).to(DEV).to(dtype)
+    # windows: 5 x 5 neighbourhoods around a shifted position (overlapping between neighbouring queries), some positions outside
+    ys, xs = torch.meshgrid(torch.arange(hq), torch.arange(wq), indexing='ij')
+    cy, cx = (ys.flatten() * hk) // hq + 1, (xs.flatten() * wk) // wq - 1
+    dy, dx = torch.meshgrid(torch.arange(-2, 3), torch.arange(-2, 3), indexing='ij')
+    yy, xx = cy[:, None] + dy.flatten()[None], cx[:, None] + dx.flatten()[None]
+    ok = (yy >= 0) & (yy < hk) & (xx >= 0) & (xx < wk)
+    win = torch.where(ok, yy * wk + xx, -1)
+    win[7] = -1                                           # a query without any valid key
+    win[11, :5] = win[11, 5]                              # repeated cells inside one window
+    win = win.to(torch.int32).to(DEV)[None].contiguous()
+    a = [t.clone().requires_grad_(True) for t in (q, km, vm)]
+    mask = (win[0] >= 0)
+    idx = win[0].clamp_min(0).long()
+    kg = a[1][0].index_select(0, idx.reshape(-1)).view(L, 25, 4, 64)
+    vg = a[2][0].index_select(0, idx.reshape(-1)).view(L, 25, 4, 64)
+    ref = TF.full_attention(a[0][0].view(L, 1, 4, 64), kg, vg, mask).reshape(1, L, C)
+    ref.backward(dout)
+    b = [t.clone().requires_grad_(True) for t in (q, km, vm)]
+    out = HA.window_cross_attention(*b, win, 4)
+    out.backward(dout)
+    tol = {torch.float32: 2e-5, torch.float16: 4e-3, torch.bfloat16: 3e-2}[dtype]
+    assert float((out.float() - ref.float()).abs().max()) < tol * max(1.0, float(ref.float().abs().max()))
+    assert float(out[0, 7].abs().max()) == 0.0 and float(b[0].grad[0, 7].abs().max()) == 0.0
+    for name, x, y in zip(('dq', 'dk', 'dv'), b, a):
+        rel = float((x.grad.float() - y.grad.float()).norm() / y.grad.float().norm())
+        assert rel < (1e-4 if dtype == torch.float32 else 2e-2), (name, rel)
