@@ -480,7 +480,10 @@ def forward_train(model, data: Dict[str, torch.Tensor], homography_fn: Optional[
     n = img0.size(0)
     data.update({'bs': torch.tensor(n), 'hw0_i': torch.tensor(img0.shape[2:]), 'hw1_i': torch.tensor(img1.shape[2:])})
     if img0.shape[2:] == img1.shape[2:]:
-        feats_c, feats_f = model.backbone(torch.cat([img0, img1], dim=0))
+        both = torch.cat([img0, img1], dim=0)
+        if getattr(model, '_train_channels_last', False):          # TrainStep(channels_last=True): NHWC convolutions (MIOpen / CK)
+            both = both.contiguous(memory_format=torch.channels_last)
+        feats_c, feats_f = model.backbone(both)
         (cnn0, cnn1), (ff0, ff1) = feats_c.split(n), feats_f.split(n)
     else:
         (cnn0, ff0), (cnn1, ff1) = model.backbone(img0), model.backbone(img1)

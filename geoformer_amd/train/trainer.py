@@ -117,12 +117,17 @@ class TrainStep:
 
     def __init__(self, model, trainer_cfg=None, loss_cfg=None, batch_size=1, distributed=False, device_ids=None,
                  homography_fn: Optional[Callable] = None, sparse_spvs=True, fused_coarse_loss=False, precision='fp32',
-                 hip_backward=False):
+                 hip_backward=False, channels_last=False):
         world = torch.distributed.get_world_size() if distributed else 1
         self.cfg = scale_trainer_cfg(trainer_cfg, world, batch_size)
         if model.precision != 'fp32':
             raise ValueError("training runs the fp32 parameters: GeoFormer.set_precision('fp32')")
         model.train()
+        # channels_last: the backbone's weights and its input in NHWC memory format (the arithmetic is the same; MIOpen then runs
+        # its NHWC convolution kernels forward and backward); an option, off by default - measured per shape, tools/train_profile.py --cl
+        model._train_channels_last = bool(channels_last)
+        if channels_last:
+            model.backbone.to(memory_format=torch.channels_last)
         self.model = model
         if precision not in ('fp32', 'bf16'):
             raise ValueError("TrainStep precision: 'fp32' or 'bf16' (mixed: fp32 master weights, bf16 GEMMs / convolutions)")

@@ -6,6 +6,8 @@ FUSED = '--no-fused' not in sys.argv
 B = int(sys.argv[sys.argv.index('--batch') + 1]) if '--batch' in sys.argv else 2
 sys.path.insert(0, '.')
 from geoformer_amd import miopen; miopen.use_shipped_find_db()
+if '--search' in sys.argv:
+    torch.backends.cudnn.benchmark = True          # MIOpen find mode: searches the convolution algorithms of the training shapes once
 from geoformer_amd.model.cvpr_ds_config import get_default_cfg
 from geoformer_amd.model.full_model import GeoFormer
 from geoformer_amd.model.geo_config import get_cfg_model
@@ -14,7 +16,7 @@ from geoformer_amd.train import TrainStep, synthetic_homography_batch
 g = get_cfg_model(); g.update(coarse_thr=0.0, fine_thr=0.0, precision='fp32')
 model = deterministic_init_(GeoFormer(get_default_cfg(), g)).cuda()
 PREC = 'bf16' if '--bf16' in sys.argv else 'fp32'
-step = TrainStep(model, batch_size=B, fused_coarse_loss=FUSED, precision=PREC, hip_backward='--hip' in sys.argv)
+step = TrainStep(model, batch_size=B, fused_coarse_loss=FUSED, precision=PREC, hip_backward='--hip' in sys.argv, channels_last='--cl' in sys.argv)
 nsteps = 10 if "--long" in sys.argv else 4
 batches = [synthetic_homography_batch(B, HW, seed=it, device='cuda') for it in range(nsteps)]      # (made outside the timed steps)
 torch.cuda.synchronize()
