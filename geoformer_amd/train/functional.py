@@ -479,7 +479,11 @@ def forward_train(model, data: Dict[str, torch.Tensor], homography_fn: Optional[
     img0, img1 = data['image0'], data['image1']
     n = img0.size(0)
     data.update({'bs': torch.tensor(n), 'hw0_i': torch.tensor(img0.shape[2:]), 'hw1_i': torch.tensor(img1.shape[2:])})
-    if img0.shape[2:] == img1.shape[2:]:
+    if data.get('_backbone_features') is not None:
+        # gradient checks of the matching path alone (tests/test_train_gpu.py): ((cnn0, ff0), (cnn1, ff1)) given as leaf tensors,
+        # e.g. planted-correspondence maps - a regime with decisive confidences that random-init weights on images never reach
+        (cnn0, ff0), (cnn1, ff1) = data['_backbone_features']
+    elif img0.shape[2:] == img1.shape[2:]:
         both = torch.cat([img0, img1], dim=0)
         if getattr(model, '_train_channels_last', False):          # TrainStep(channels_last=True): NHWC convolutions (MIOpen / CK)
             both = both.contiguous(memory_format=torch.channels_last)
