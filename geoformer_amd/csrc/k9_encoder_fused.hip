@@ -129,6 +129,20 @@ __device__ __forceinline__ float half_sum(float x) {
     const gf_v2u sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     return __uint_as_float(sw.x) + __uint_as_float(sw.y);
 }
+// sum_j a_j b_j over the 8 sixteen-bit elements of two packed operands, fp32 accumulation (v_dot2c_f32_f16 / _bf16: the products of
+// two 16-bit values are exact in fp32)
+__device__ __forceinline__ float dot8(const v8h& a, const v8h& b, float c) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_fdot2(h2{a[2 * i], a[2 * i + 1]}, h2{b[2 * i], b[2 * i + 1]}, c, false);
+    return c;
+}
+__device__ __forceinline__ float dot8(const v8b& a, const v8b& b, float c) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_fdot2_f32_bf16(b2{a[2 * i], a[2 * i + 1]}, b2{b[2 * i], b[2 * i + 1]}, c, false);
+    return c;
+}
 template <typename T>
 __device__ __forceinline__ float rnd(float x) { return gf_to_float(gf_from_float<T>(x)); }   // round to the storage type
 
@@ -308,7 +322,12 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
                 pack8<T>(src[0] * inv_s, src[D] * inv_s, src[2 * D] * inv_s, src[3 * D] * inv_s, src[8 * D] * inv_s, src[9 * D] * inv_s,
                          src[10 * D] * inv_s, src[11 * D] * inv_s);
         }
-        reinterpret_cast<float*>(smem + KS_OFF)[tid] = rnd<T>(kvf[C * D + tid] * inv_s);
+        {
+            // Ksum / S rounded to the storage type, as 16-byte operands in the k order of the packed phi(q): entry (hh, s, h2),
+            // element j = channel 32 hh + 16 s + 8 (j >> 2) + 4 h2 + (j & 3) - the denominator is then 4 dot-pair instructions per k-step
+            const int j = tid & 7, hx = (tid >> 3) & 1, sx = (tid >> 4) & 1, hh = tid >> 5;
+            reinterpret_cast<T*>(smem + KS_OFF)[tid] = gf_from_float<T>(kvf[C * D + hh * D + 16 * sx + 8 * (j >> 2) + 4 * hx + (j & 3)] * inv_s);
+        }
     }
     Frag mfrag[8][2];                      // the B operand of the merge product, then of the second half of mlp.0
     if constexpr (!ATTN) {
@@ -380,40 +399,39 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
         // ---------------- linear attention per head: tile h of q is head h (32 channels)
         const float qmul = (a.q_mask == nullptr || a.q_mask[(size_t)n * a.L + min(t0 + wave * 32 + (fresh_lane() & 31), a.L - 1)] != 0) ? 1.f : 0.f;
         const float eps_s = a.attn_eps / (float)a.S;
-        const float* ks = reinterpret_cast<const float*>(smem + KS_OFF);
         // Two-stage pipeline over the heads (same arithmetic, same order per head): stage A(h) = phi, denominator and the two
         // state MFMAs of head h, stage B(h) = normalise and pack; B(h-1) runs behind A(h), under A(h)'s MFMAs, and the LDS operands
         // of head h+1 (Ksum rows, state fragments) are requested a head ahead - one wave per SIMD: nothing else hides their latency.
-        struct HeadOps { v4f k4[4]; Frag kv0, kv1; };
+        struct HeadOps { Frag ks0, ks1; Frag kv0, kv1; };
         auto head_ops = [&](int hh) {
             HeadOps o;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) o.k4[g] = *reinterpret_cast<const v4f*>(ks + hh * D + 8 * g + 4 * h2);   // rows 8g + 4 h2 + {0..3} of the head
+            o.ks0 = *reinterpret_cast<const Frag*>(smem + KS_OFF + ((hh * 2 + 0) * 2 + h2) * 16);
+            o.ks1 = *reinterpret_cast<const Frag*>(smem + KS_OFF + ((hh * 2 + 1) * 2 + h2) * 16);
             o.kv0 = *reinterpret_cast<const Frag*>(smem + KV_OFF + (hh * 2) * FRAG + lane * 16);
             o.kv1 = *reinterpret_cast<const Frag*>(smem + KV_OFF + (hh * 2 + 1) * FRAG + lane * 16);
             return o;
         };
         v16f num[2];
         float den[2];
+        // phi(q) is rounded by its packing (one conversion per pair) and the denominator phi(q) . Ksum / S is summed from the PACKED
+        // operands (the 16-bit products are exact in fp32) - rounds 2-3 rounded every value by a conversion there and back, multiplied
+        // in fp32 and converted again for the packing; a masked query (phi(q) = 0 in linear_attention.py:35-36, message 0 / eps = 0)
+        // is zeroed through its normaliser instead of a multiply per value
         auto stage_a = [&](int hh, const HeadOps& ho) {
             float pq[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) pq[r] = rnd<T>(phi(q[hh][r]) * qmul);
-            float d = 0.f;
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                d += pq[4 * g] * ho.k4[g].x + pq[4 * g + 1] * ho.k4[g].y + pq[4 * g + 2] * ho.k4[g].z + pq[4 * g + 3] * ho.k4[g].w;
-            den[hh & 1] = d;
-            num[hh & 1] = zero16();
+            for (int r = 0; r < 16; ++r) pq[r] = phi(q[hh][r]);
             const Frag p0 = pack8<T>(pq[0], pq[1], pq[2], pq[3], pq[4], pq[5], pq[6], pq[7]);
             const Frag p1 = pack8<T>(pq[8], pq[9], pq[10], pq[11], pq[12], pq[13], pq[14], pq[15]);
+            den[hh & 1] = dot8(p1, ho.ks1, dot8(p0, ho.ks0, 0.f));
+            num[hh & 1] = zero16();
             Mm::mma(ho.kv0, p0, num[hh & 1]);
             Mm::mma(ho.kv1, p1, num[hh & 1]);
         };
         auto stage_b = [&](int hh) {
             float d = den[hh & 1];
             d = half_sum(d);
-            const float z = __builtin_amdgcn_rcpf(d + eps_s);
+            const float z = __builtin_amdgcn_rcpf(d + eps_s) * qmul;
             v16f& nm = num[hh & 1];
 #pragma unroll
             for (int r = 0; r < 16; ++r) nm[r] *= z;
@@ -473,14 +491,16 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
         return o;
     };
     // the four normalised values of registers 4g .. 4g+3 of a tile
-    auto ln_apply = [&](const v16f& t, int g, const LnOps& p, float mean, float rstd) {
-        return v4f{(t[4 * g] - mean) * rstd * p.ga[g].x + p.be[g].x, (t[4 * g + 1] - mean) * rstd * p.ga[g].y + p.be[g].y,
-                   (t[4 * g + 2] - mean) * rstd * p.ga[g].z + p.be[g].z, (t[4 * g + 3] - mean) * rstd * p.ga[g].w + p.be[g].w};
+    // (t - mean) rstd gamma + beta as two FMAs per value: t rstd - mean rstd, then times gamma plus beta (`nmr` = -mean rstd)
+    auto ln_apply = [&](const v16f& t, int g, const LnOps& p, float nmr, float rstd) {
+        return v4f{fmaf(fmaf(t[4 * g], rstd, nmr), p.ga[g].x, p.be[g].x), fmaf(fmaf(t[4 * g + 1], rstd, nmr), p.ga[g].y, p.be[g].y),
+                   fmaf(fmaf(t[4 * g + 2], rstd, nmr), p.ga[g].z, p.be[g].z), fmaf(fmaf(t[4 * g + 3], rstd, nmr), p.ga[g].w, p.be[g].w)};
     };
     K9_T(4);
     {
         float mean, rstd;
         ln_stats(m, a.eps1, mean, rstd);
+        const float nmr = -mean * rstd;
         {
             LnOps lp[2];
             lp[0] = ln_ops(vec, vec + C, 0, h2);
@@ -489,7 +509,7 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
                 if (nb < 7) lp[(nb + 1) & 1] = ln_ops(vec, vec + C, nb + 1, h2);
 #pragma unroll
                 for (int sx = 0; sx < 2; ++sx) {
-                    const v4f lo = ln_apply(m[nb], 2 * sx, lp[nb & 1], mean, rstd), hi = ln_apply(m[nb], 2 * sx + 1, lp[nb & 1], mean, rstd);
+                    const v4f lo = ln_apply(m[nb], 2 * sx, lp[nb & 1], nmr, rstd), hi = ln_apply(m[nb], 2 * sx + 1, lp[nb & 1], nmr, rstd);
                     mfrag[nb][sx] = pack8<T>(lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w);
                 }
             }
@@ -570,6 +590,7 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
     }
 #endif
     ln_stats(o, a.eps2, mean2, rstd2);
+    const float nmr2 = -mean2 * rstd2;
     K9_T(8);
     // the predicate is per sample (flag_rows is a multiple of L in every caller): read it once, wave-uniformly
     const bool keep = a.flag == nullptr || __builtin_amdgcn_readfirstlane(a.flag[((size_t)n * a.L + t0) / a.flag_rows]) != 0;
@@ -606,7 +627,7 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
                 const FinOps& p = fo[nb & 1];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const v4f y = ln_apply(o[nb], g, p.ln, mean2, rstd2);
+                    const v4f y = ln_apply(o[nb], g, p.ln, nmr2, rstd2);
                     v4t ov;
                     ov[0] = gf_from_float<T>(gf_to_float(p.x[g][0]) + y.x);
                     ov[1] = gf_from_float<T>(gf_to_float(p.x[g][1]) + y.y);
