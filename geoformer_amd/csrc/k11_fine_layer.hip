@@ -338,16 +338,20 @@ __global__ __launch_bounds__(512, 2) void fine_layer(FlArgs a) {
                     s += v;
                     qd = fmaf(v, v, qd);
                 }
-            s += __shfl_xor(s, 32, 64);
-            qd += __shfl_xor(qd, 32, 64);
+            // x[lane] + x[lane ^ 32] by one v_permlane32_swap each (VALU; the ds_bpermute form waits on the LDS counter)
+            const gf_v2u ss = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+            const gf_v2u sq = __builtin_amdgcn_permlane32_swap(__float_as_uint(qd), __float_as_uint(qd), false, false);
+            s = __uint_as_float(ss.x) + __uint_as_float(ss.y);
+            qd = __uint_as_float(sq.x) + __uint_as_float(sq.y);
             mean = s * (1.0f / FC);
             rstd = 1.0f / sqrtf(fmaxf(qd - s * mean, 0.f) * (1.0f / FC) + eps);
         };
         auto ln_apply = [&](const v16f& t, int nb, int g4, const float* gamma, const float* beta, float mean, float rstd) {
             const int c = nb * 32 + 8 * g4 + 4 * h2;
             const v4f ga = *reinterpret_cast<const v4f*>(gamma + c), be = *reinterpret_cast<const v4f*>(beta + c);
-            return v4f{(t[4 * g4] - mean) * rstd * ga.x + be.x, (t[4 * g4 + 1] - mean) * rstd * ga.y + be.y,
-                       (t[4 * g4 + 2] - mean) * rstd * ga.z + be.z, (t[4 * g4 + 3] - mean) * rstd * ga.w + be.w};
+            const float nmr = -mean * rstd;                  // (t - mean) rstd gamma + beta as two FMAs per value
+            return v4f{fmaf(fmaf(t[4 * g4], rstd, nmr), ga.x, be.x), fmaf(fmaf(t[4 * g4 + 1], rstd, nmr), ga.y, be.y),
+                       fmaf(fmaf(t[4 * g4 + 2], rstd, nmr), ga.z, be.z), fmaf(fmaf(t[4 * g4 + 3], rstd, nmr), ga.w, be.w)};
         };
 
         // ---------------- m = LN1(W_m msg)

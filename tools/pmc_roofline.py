@@ -62,7 +62,8 @@ TAG_FAMILIES = {
     'enc_layer': ['enc_layer<'],
     'enc_kv_state': ['enc_kv_state<', 'enc_kv_reduce'],
     'k3_linear': ['linear_kernel'],              # minus TAG_EXCLUDE: the EPI_UPADD instance belongs to the backbone
-    'k3_upadd': [', 4, 5>'],                      # linear_kernel<T, 4, EPI_UPADD = 5>
+    'k3_upadd': [', 4, 5, true>'],                # linear_kernel<T, 4, EPI_UPADD = 5, CONVX>
+    'conv1x1': [', 4, 0, true>'],                 # linear_kernel<T, 4, EPI_NONE, CONVX>: gf_conv1x1_nhwc
     'k1_stats': ['k1_stats'],
     'k1_conf': ['k1_conf'],
     'k1_unit': ['k1_'],
@@ -73,9 +74,9 @@ TAG_FAMILIES = {
     'bias_act': ['bias_act<'],
     'conv3x3': ['conv3x3_kernel'],
 }
-TAG_EXCLUDE = {'k3_linear': [', 4, 5>']}
+TAG_EXCLUDE = {'k3_linear': [', 4, 5, true>', ', 4, 0, true>']}
 # the family whose call count equals the number of tagged calls
-TAG_PRIMARY = {'k1_unit': 'k1_compact', 'fine_layer': 'fine_layer<', 'k4_self_attention': 'attn_self<', 'enc_layer': 'enc_layer<', 'enc_kv_state': 'enc_kv_state<', 'k3_linear': 'linear_kernel', 'k3_upadd': ', 4, 5>', 'k1_stats': 'k1_stats',
+TAG_PRIMARY = {'k1_unit': 'k1_compact', 'fine_layer': 'fine_layer<', 'k4_self_attention': 'attn_self<', 'enc_layer': 'enc_layer<', 'enc_kv_state': 'enc_kv_state<', 'k3_linear': 'linear_kernel', 'k3_upadd': ', 4, 5, true>', 'conv1x1': ', 4, 0, true>', 'k1_stats': 'k1_stats',
                'k1_conf': 'k1_conf', 'k2_linear_attention': ('la16_apply', 'la_apply', 'la_small'), 'k5_window_attention': ('window_cross_tiled', 'window_cross_attention'),
                'bias_act': 'bias_act<', 'conv3x3': 'conv3x3_kernel'}
 
