@@ -125,6 +125,11 @@ def lib():
             raise GeoFormerHipError(
                 f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                 '(hipcc --offload-arch=gfx950).  geoformer_amd has no CPU / PyTorch fallback.')
+        # torch first: its wheel ships its own HIP runtime (libamdhip64), and whichever copy is loaded FIRST is the one this library's
+        # launches go through - loaded before torch, the library binds /opt/rocm's runtime and its first launch fails with "no
+        # ROCm-capable device is detected" once torch has initialised the device through the other copy (seen with
+        # `python __graft_entry__.py smoke`, where build() loads the library before anything imports torch)
+        import torch  # noqa: F401
         h = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)       # AttributeError if the symbol is missing: fail loudly
