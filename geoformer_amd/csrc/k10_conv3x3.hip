@@ -50,7 +50,7 @@ struct ConvArgs {
     int tiles_x, tiles_y, ntiles;
 };
 
-template <int NT, int NW>
+template <int NT, int NW, bool REM = false>
 struct ConvGeo {
     // output widths up to 128 channels: a wave owns two 32-pixel rows (every weight fragment feeds two MFMAs, 2 x NT
     // accumulator tiles); wider outputs: one row per wave (the accumulators of two would not fit the register file).
@@ -73,7 +73,10 @@ struct ConvGeo {
     static constexpr int RS = SP * 64 + 16;                       // slab row: SP x 32 channels of a pixel + 16 B
     static constexpr int SLAB_BYTES = NW * 32 * RS;               // one 32-pixel slab per wave
     static constexpr int SHIFT_OFF = SLAB_OFF + (SLAB_ALIAS ? 0 : SLAB_BYTES);
-    static constexpr int LDS = SHIFT_OFF + NT * 32 * 4;
+    // REM (GF_CONV_REM8): the patch of the 8-channel remainder chunk (16 B per pixel) has a buffer of its own, in pieces of 64 pixels
+    static constexpr int RPIECES = (PH * PW + 63) / 64;
+    static constexpr int R_OFF = SHIFT_OFF + NT * 32 * 4;
+    static constexpr int LDS = R_OFF + (REM ? RPIECES * 1024 : 0);
     static_assert(!SLAB_ALIAS || SLAB_BYTES <= PATCH_BYTES, "slab must fit the patch buffer it aliases");
     static_assert(LDS <= 160 * 1024, "LDS budget");
 };
@@ -128,6 +131,26 @@ __device__ __forceinline__ void conv_dma_patch(const ConvArgs& a, const ConvRsrc
     }
 }
 
+// request the REMAINDER patch of a tile (channels 192 .. 199 of every halo pixel: 16 B per pixel, pixel q at q * 16): pieces of 64 pixels
+template <typename T, int CIN, int NT, int NW>
+__device__ __forceinline__ void conv_dma_patch_rem(const ConvArgs& a, const ConvRsrc& xs, char* smem, int n, int y0, int x0, int wave, int lane) {
+    using G = ConvGeo<NT, NW, true>;
+    asm volatile("" : "+v"(lane));
+    char* dst = smem + G::R_OFF;
+    const int sbase = ((n * a.H + y0 - 1) * a.W + x0 - 1) * CIN + 192;
+#pragma unroll
+    for (int i = 0; i < (G::RPIECES + NW - 1) / NW; ++i) {
+        const int piece = wave + NW * i;
+        if (piece < G::RPIECES) {
+            const int q = piece * 64 + lane;
+            const int pr = q / PW, pc = q - pr * PW;
+            const bool in = (unsigned)(y0 - 1 + pr) < (unsigned)a.H && (unsigned)(x0 - 1 + pc) < (unsigned)a.W && q < G::PH * PW;
+            const int off = sbase + (pr * a.W + pc) * CIN;
+            conv_lds_dma(xs, dst + piece * 1024, in ? off * (int)sizeof(T) : 0x7FFFFFF0, 0);
+        }
+    }
+}
+
 // -DK10_TRACE=1 records s_memtime at the phase boundaries of the first 8 tiles of every wave (tools/k10_trace.py)
 #ifndef K10_TRACE
 #define K10_TRACE 0
@@ -147,14 +170,20 @@ __device__ long long k10_trace[256 * 8 * 8 * 16];
 // PADL: the last 16 output channels are padding (zero weights - act | GF_CONV_PAD16): their fragment (the last one of every odd
 // sub-step) is neither read from the ring nor multiplied; the accumulators keep the shift and the epilogue writes act(shift +
 // residual) as for every other channel
-template <typename T, int CIN, int COUT, int NW, bool PADL>
+// REM (act | GF_CONV_REM8, CIN = 224): the input channels 200 .. 223 carry zero weights (the 196-channel pyramid level padded for the
+// matrix cores): six full chunks, then channels 192 .. 199 as a REMAINDER chunk whose 9 taps x 8 channels fill three 32-deep k-steps
+// (lane k group g4 of k-step s reads tap 4 s + g4 of its pixel: 16 bytes) - 6 sub-steps instead of the 18 of a seventh chunk, i.e. 114
+// instead of 126 sub-steps per tile
+template <typename T, int CIN, int COUT, int NW, bool PADL, bool REM = false>
 __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
     using Mm = Mma16<T>;
     using Frag = typename Mm::Frag;
-    using G = ConvGeo<COUT / 32, NW>;
+    using G = ConvGeo<COUT / 32, NW, REM>;
     using V4 = gf_vec<T, 4>;
     using V8 = gf_vec<T, 8>;
-    constexpr int NT = COUT / 32, NCH = CIN / 32, BS = G::BLOCK_STEPS, BPC = 18 / BS, NBLK = NCH * BPC;
+    static_assert(!REM || CIN == 224, "the remainder form is built for 224-channel inputs");
+    constexpr int NT = COUT / 32, NCH = REM ? 6 : CIN / 32, BS = G::BLOCK_STEPS, BPC = 18 / BS, RBPC = 6 / BS;
+    constexpr int NBLK = NCH * BPC + (REM ? RBPC : 0);
     constexpr int PB = G::PB, TH = G::TH, RS = G::RS, SP = G::SP;
     constexpr int NSTORE = PB * 2 * NT;                             // 16-byte output stores per lane and tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -195,6 +224,20 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
         for (int bb = 0; bb < 2 * PB; ++bb) {
             const int q = xq + ((bb >> 1) + ky) * PW + 16 * (bb & 1) + kx;
             f[bb] = *reinterpret_cast<const Frag*>(p + q * 64 + ((g4 ^ ((q >> 1) & 3)) << 4));
+        }
+    };
+
+    auto load_xr = [&](Frag (&f)[2 * PB], int ks) {               // remainder: k group g4 of k-step ks = tap 4 ks + g4 (9 .. 11: zero weights)
+        const char* p = smem + G::R_OFF;
+        int xq = xq0;
+        asm volatile("" : "+v"(xq));
+        int tap = 4 * ks + g4;
+        tap = tap > 8 ? 8 : tap;                                    // (a pixel that exists: finite values against zero weights)
+        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;         // tap / 3 for 0 .. 8
+#pragma unroll
+        for (int bb = 0; bb < 2 * PB; ++bb) {
+            const int q = xq + ((bb >> 1) + ky) * PW + 16 * (bb & 1) + kx;
+            f[bb] = *reinterpret_cast<const Frag*>(p + q * 16);
         }
     };
 
@@ -244,10 +287,17 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
         // a lane's chunk jj is slab chunk e = lane + 64 jj -> pixel e / cpr, 16-byte channel chunk e % cpr (cpr = 4 nt)
         auto pass_tiles = [](int t0) { return NT - t0 < SP ? NT - t0 : SP; };
 
-#pragma unroll 1
-        for (int c = 0; c < NCH; ++c) {
+        // one chunk of the K loop: a FULL chunk c (32 input channels: 9 taps x 2 halves of the output channels = 18 sub-steps) or the
+        // REMAINDER chunk (REM: 8 channels: 3 k-steps x 2 halves = 6 sub-steps; its patch has its own buffer, so the two patch buffers keep
+        // alternating over the full chunks and the next tile's first patch is requested during the last FULL chunk, as without it)
+        auto chunk = [&](auto rem_c, int c) {
+            constexpr bool R = decltype(rem_c)::value;
+            constexpr int NTS = R ? 6 : 18;
+            const int blk0 = R ? NCH * BPC : c * BPC;                       // this chunk's first weight block
+            const bool tile_ends = R || (!REM && c + 1 == NCH);              // no chunk of this tile behind this one
+            const bool rem_next = !R && REM && c + 1 == NCH;                 // the remainder follows
 #pragma unroll
-            for (int ts = 0; ts < 18; ++ts) {                       // sub-step (tap ts / 2, channel half ts % 2) of this chunk
+            for (int ts = 0; ts < NTS; ++ts) {                               // sub-step (tap or k-step ts / 2, channel half ts % 2)
                 const int tap = ts >> 1, hf = ts & 1;
                 Frag (&cw)[NT] = (ts & 1) ? wb : wa;
                 Frag (&nw)[NT] = (ts & 1) ? wa : wb;
@@ -259,33 +309,46 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
                     // landed, every wave holds this block's last fragments in registers: its slot takes the block after next
                     // (the first turn of a tile only needs the block requested before the previous tile's epilogue: its
                     // NSTORE output stores - all issued when that tile lay inside the image - may stay in flight)
-                    if (ts == BS - 1 && c == 0) K10_T(12);
-                    if (ts == BS - 1 && c == 0 && prev_full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
+                    const bool first_turn = !R && ts == BS - 1 && c == 0;
+                    if (first_turn) K10_T(12);
+                    if (first_turn && prev_full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (ts == BS - 1 && c == 0) K10_T(13);
+                    if (first_turn) K10_T(13);
                     __builtin_amdgcn_s_barrier();
-                    if (ts == BS - 1 && c == 0) K10_T(14);
-                    const int nb = c * BPC + ts / BS + 2;
+                    if (first_turn) K10_T(14);
+                    const int nb = blk0 + ts / BS + 2;
                     if (nb < NBLK) conv_dma_block<NT, NW>(ws, smem, nb, wslot, wave, lane);
                     else if (has_next) conv_dma_block<NT, NW>(ws, smem, nb - NBLK, wslot, wave, lane);
-                    if (ts == BS - 1) {
-                        // first turn of the chunk: every wave is past the previous chunk, its patch buffer is free
+                    if (!R && ts == BS - 1) {
+                        // first turn of a full chunk: every wave is past the previous chunk, its patch buffer is free
                         if (c + 1 < NCH) conv_dma_patch<T, CIN, NT, NW>(a, xs, smem, pbuf ^ 1, n, y0, x0, c + 1, wave, lane);
                         else if (has_next) {
                             int n2, y2, x2;
                             decode(nxt_tile, n2, y2, x2);
                             conv_dma_patch<T, CIN, NT, NW>(a, xs, smem, pbuf ^ 1, n2, y2, x2, 0, wave, lane);
                         }
+                        // the tile's remainder patch: its buffer is free since every wave left the previous tile's remainder chunk
+                        if constexpr (REM) {
+                            if (c == 0) conv_dma_patch_rem<T, CIN, NT, NW>(a, xs, smem, n, y0, x0, wave, lane);
+                        }
                     }
                     wslot ^= 1;
-                    if (ts == BS - 1 && c == 0) K10_T(15);
+                    if (first_turn) K10_T(15);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // next sub-step's weight fragments, and behind a tap's second half the next tap's pixel fragments (a tile's
                 // first ones are read at its start: held across the epilogue they spill)
-                if (ts < 17 || c + 1 < NCH) {
+                if (ts < NTS - 1 || !tile_ends) {
                     load_w(nw, wslot, (ts + 1) % BS, ((ts + 1) & 1) != 0);
-                    if (hf) load_x(nx, ts == 17 ? pbuf ^ 1 : pbuf, (tap + 1) % 9);
+                    if (hf) {
+                        if constexpr (R) {
+                            if (ts < NTS - 1) load_xr(nx, tap + 1);
+                        } else {
+                            if (ts < NTS - 1) load_x(nx, pbuf, tap + 1);
+                            else if (rem_next) load_xr(nx, 0);
+                            else load_x(nx, pbuf ^ 1, 0);
+                        }
+                    }
                 }
                 // (no issue-order hints: with 128 accumulators in four-register tuples the allocator gives an MFMA's result
                 // other registers than its addend, and every constraint on the order - sched_group_barrier pipelines, a
@@ -299,14 +362,20 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
                 // reads behind the sub-step's last MFMA and the next one waits out the whole LDS latency)
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // a chunk has 9 taps: the fragments of the next chunk's tap 0 were prefetched into xb, and tap 0 reads xa
-            if (c + 1 < NCH) {
+            // a chunk has an odd number of taps / k-steps (9, 3): the next chunk's first fragments were prefetched into xb, and its
+            // first tap reads xa
+            if (!tile_ends) {
 #pragma unroll
                 for (int bb = 0; bb < 2 * PB; ++bb) xa[bb] = xb[bb];
             }
-            pbuf ^= 1;
+            if constexpr (!R) pbuf ^= 1;
+        };
+#pragma unroll 1
+        for (int c = 0; c < NCH; ++c) {
+            chunk(std::integral_constant<bool, false>{}, c);
             K10_T(2 + c);
         }
+        if constexpr (REM) chunk(std::integral_constant<bool, true>{}, NCH);
         // ---------------- epilogue (wave-private): T(acc) -> slab [pixel][SP x 32 channels] -> + shortcut -> act -> NHWC
         K10_T(10);
         const bool full = y0 + TH <= a.H && x0 + TW <= a.W;
@@ -430,30 +499,35 @@ extern "C" int gf_debug_k10_trace(long long* out) {
 namespace {
 #endif
 
-template <typename T, int CIN, int COUT, int NW, bool PADL>
+template <typename T, int CIN, int COUT, int NW, bool PADL, bool REM = false>
 int conv_launch(ConvArgs a, hipStream_t st) {
-    using G = ConvGeo<COUT / 32, NW>;
+    using G = ConvGeo<COUT / 32, NW, REM>;
     static std::atomic<uint64_t> attr{0};
     if (gf_first_use_on_device(attr))
-        (void)hipFuncSetAttribute((const void*)conv3x3_kernel<T, CIN, COUT, NW, PADL>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        (void)hipFuncSetAttribute((const void*)conv3x3_kernel<T, CIN, COUT, NW, PADL, REM>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + G::TH - 1) / G::TH;
     const long nt = (long)a.N * a.tiles_x * a.tiles_y;
     if (nt >= (1l << 31)) return -2;
     a.ntiles = (int)nt;
-    conv3x3_kernel<T, CIN, COUT, NW, PADL><<<a.ntiles < 256 ? a.ntiles : 256, NW * 64, G::LDS, st>>>(a);
+    conv3x3_kernel<T, CIN, COUT, NW, PADL, REM><<<a.ntiles < 256 ? a.ntiles : 256, NW * 64, G::LDS, st>>>(a);
     return 0;
 }
 
 // 8 waves per workgroup: measured 1.1-1.3x faster than 4 at every shape (tools/k10_time.py); the 4-wave form stays
 // instantiable (conv_launch<..., 4>) for experiments
-template <typename T, int CIN, int COUT, bool PADL = false>
+template <typename T, int CIN, int COUT, bool PADL = false, bool REM = false>
 int conv_launch_w(const ConvArgs& a, hipStream_t st) {
-    return conv_launch<T, CIN, COUT, 8, PADL>(a, st);
+    return conv_launch<T, CIN, COUT, 8, PADL, REM>(a, st);
 }
 
 template <typename T>
-int conv_dispatch(const ConvArgs& a, int cin, int cout, bool padl, hipStream_t st) {
+int conv_dispatch(const ConvArgs& a, int cin, int cout, bool padl, bool rem, hipStream_t st) {
+    if (rem) {                                           // the 196-channel level as input: 6 chunks + the 8-channel remainder
+        if (cin == 224 && cout == 224 && padl) return conv_launch_w<T, 224, 224, true, true>(a, st);
+        if (cin == 224 && cout == 128 && !padl) return conv_launch_w<T, 224, 128, false, true>(a, st);
+        return -1;
+    }
     if (cin == 128 && cout == 128) return conv_launch_w<T, 128, 128>(a, st);
     if (cin == 224 && cout == 224 && padl) return conv_launch_w<T, 224, 224, true>(a, st);
     if (cin == 256 && cout == 224 && padl) return conv_launch_w<T, 256, 224, true>(a, st);
@@ -481,7 +555,10 @@ extern "C" int gf_conv3x3_nhwc(const void* x, const void* wstream, const float* 
     GF_CHECK_ARG(dtype == GF_F16 || dtype == GF_BF16, "built for 16-bit maps");
     GF_CHECK_ARG(gf_conv3x3_supported(cin, cout), "no kernel for these channel counts (see gf_conv3x3_supported)");
     const bool padl = (act & GF_CONV_PAD16) != 0;     // the last 16 output channels are padding (zero weights): not multiplied
-    act &= ~GF_CONV_PAD16;
+    const bool rem = (act & GF_CONV_REM8) != 0;        // the input channels 200.. carry zero weights; wstream is the rem8 packing
+    act &= ~(GF_CONV_PAD16 | GF_CONV_REM8);
+    GF_CHECK_ARG(!rem || (cin == 224 && ((cout == 224 && padl) || (cout == 128 && !padl))),
+                 "GF_CONV_REM8 is built for Cin = 224 with Cout = 224 | GF_CONV_PAD16 or Cout = 128");
     GF_CHECK_ARG(act >= C10_NONE && act <= C10_LEAKY, "unknown activation");
     GF_CHECK_ARG(act != C10_LEAKY || (slope >= 0.f && slope <= 1.f), "LeakyReLU slope must lie in [0, 1]");
     GF_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)residual % 16 == 0 && (uintptr_t)wstream % 16 == 0 &&
@@ -493,7 +570,7 @@ extern "C" int gf_conv3x3_nhwc(const void* x, const void* wstream, const float* 
     // (resnet_fpn.py block_dims (128, 196, 256); model/backbone.py pads them for the matrix cores) and the padding is not work
     const double cin_w = cin == 224 ? 196.0 : cin, cout_w = cout == 224 ? 196.0 : cout;
     void* pt = gf_prof_begin("conv3x3", st, 2.0 * N * (double)H * W * cin_w * cout_w * 9.0);
-    const int rc = dtype == GF_F16 ? conv_dispatch<_Float16>(a, cin, cout, padl, st) : conv_dispatch<gf_bf16>(a, cin, cout, padl, st);
+    const int rc = dtype == GF_F16 ? conv_dispatch<_Float16>(a, cin, cout, padl, rem, st) : conv_dispatch<gf_bf16>(a, cin, cout, padl, rem, st);
     gf_prof_end("conv3x3", pt, st);
     GF_CHECK_ARG(rc == 0, "dispatch failed");
     GF_CHECK_LAUNCH();

@@ -194,22 +194,38 @@ def fine_layer(x, src, wstream, ln_params, eps1, eps2, attn_eps=1e-6, out=None):
 _ZEROS = {}
 
 
-def pack_conv3x3_stream(w):
+def pack_conv3x3_stream(w, rem8=False):
     """w [Cout, Cin, 3, 3] (BatchNorm already folded, 16-bit) -> the fragment stream of gf_conv3x3_nhwc: for each 32-channel
     input chunk c, tap t = 3 ky + kx and half hf of the output channels, Cout/32 fragments of the 16x16x32 MFMA's A operand:
     fragment tt = channels 16 (hf Cout/32 + tt) .. + 15, lane l -> row l % 16, input channels 32 c + 8 (l / 16) .. + 7
-    (18 sub-steps per chunk; the kernel's weight blocks are 3 or 6 consecutive sub-steps)."""
+    (18 sub-steps per chunk; the kernel's weight blocks are 3 or 6 consecutive sub-steps).
+    rem8 (Cin = 224 whose channels 200.. carry zero weights - the 196-channel pyramid level): six full chunks (channels 0 .. 191)
+    and a REMAINDER of channels 192 .. 199 whose 9 taps x 8 channels = 72 contraction elements fill three 32-deep MFMA k-steps
+    (lane k group kg of k-step s = tap 4 s + kg, taps 9 .. 11 zero) instead of the nine k-steps of a seventh chunk: 6 sub-steps
+    (k-step s, half hf) of Cout/32 fragments behind the full chunks' (GF_CONV_REM8)."""
     cout, cin = w.shape[:2]
     nt = cout // 32
     dev = w.device
     lane = torch.arange(64, device=dev)
     row, kg = lane % 16, lane // 16
-    wt = w.reshape(cout, cin // 32, 32, 9)                                           # [cout, chunk, k, tap]
     # out[c, t, hf, tt, lane, j] = wt[16 (hf nt + tt) + row, c, 8 kg + j, t]
     co = (16 * (torch.arange(2, device=dev)[:, None, None] * nt + torch.arange(nt, device=dev)[None, :, None]) + row[None, None, :])   # [2, nt, 64]
     kk = 8 * kg[:, None] + torch.arange(8, device=dev)[None, :]                      # [64, 8]
+    full = 192 if rem8 else cin
+    if rem8 and (cin != 224 or bool(w[:, 200:].any())):
+        raise ValueError('rem8 packs a 224-channel convolution whose input channels 200.. have zero weights')
+    wt = w[:, :full].reshape(cout, full // 32, 32, 9)                                # [cout, chunk, k, tap]
     g = wt[co[:, :, :, None], :, kk[None, None, :, :], :]                            # [2, nt, 64, 8, chunk, tap]
-    return g.permute(4, 5, 0, 1, 2, 3).contiguous().reshape(-1)
+    out = g.permute(4, 5, 0, 1, 2, 3).contiguous().reshape(-1)
+    if not rem8:
+        return out
+    wr = torch.zeros(cout, 8, 12, dtype=w.dtype, device=dev)                         # [cout, channel 192 + j, tap (9 real + 3 zero)]
+    wr[:, :, :9] = w[:, 192:200].reshape(cout, 8, 9)
+    j = torch.arange(8, device=dev)
+    tap = 4 * torch.arange(3, device=dev)[:, None] + kg[None, :]                      # [3 k-steps, 64 lanes]
+    # rem[s, hf, tt, lane, j] = wr[16 (hf nt + tt) + row, j, 4 s + kg]
+    r = wr[co[None, :, :, :, None], j[None, None, None, None, :], tap[:, None, None, :, None]]        # [3, 2, nt, 64, 8]
+    return torch.cat([out, r.contiguous().reshape(-1)])
 
 
 def conv3x3_supported(cin, cout):
@@ -217,11 +233,13 @@ def conv3x3_supported(cin, cout):
 
 
 CONV_PAD16 = 0x100          # GF_CONV_PAD16 (include/geoformer_hip.h)
+CONV_REM8 = 0x200           # GF_CONV_REM8
 
 
-def conv3x3(x, wstream, cout, shift=None, residual=None, act=0, slope=0.01, pad16=False):
+def conv3x3(x, wstream, cout, shift=None, residual=None, act=0, slope=0.01, pad16=False, rem8=False):
     """x channels_last [N, Cin, H, W] (16-bit) -> channels_last [N, cout, H, W] = act(conv3x3(x) + shift + residual).
-    pad16: the last 16 output channels are zero padding (zero weights): their products are skipped."""
+    pad16: the last 16 output channels are zero padding (zero weights): their products are skipped.
+    rem8: wstream = pack_conv3x3_stream(w, rem8=True) (Cin = 224, input channels 200.. have zero weights: not multiplied)."""
     _need_cuda(x, wstream)
     if x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last):
         raise ValueError('conv3x3 expects a channels_last [N, C, H, W] tensor')
@@ -234,6 +252,6 @@ def conv3x3(x, wstream, cout, shift=None, residual=None, act=0, slope=0.01, pad1
     if z is None:
         z = _ZEROS[x.device] = torch.zeros(256, dtype=torch.uint8, device=x.device)
     check(_lib.lib().gf_conv3x3_nhwc(_p(x), _p(wstream), _p(shift), _p(residual), _p(out), _p(z), N, H, W, cin, cout,
-                                     int(act) | (CONV_PAD16 if pad16 else 0),
+                                     int(act) | (CONV_PAD16 if pad16 else 0) | (CONV_REM8 if rem8 else 0),
                                      float(slope), _dt(x), _stream()), 'gf_conv3x3_nhwc')
     return out

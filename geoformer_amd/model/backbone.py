@@ -110,6 +110,7 @@ class FusedInferenceBackbone:
             self.stem_hip = (_fold(bb.conv1, bb.bn1, torch.float32)[0].contiguous(), self.stem[1])
         self.blocks = []
         self._pad16 = {}
+        self._rem8 = {}
         for layer in (bb.layer1, bb.layer2, bb.layer3):
             for blk in layer:
                 w1, b1 = _fold(blk.conv1, blk.bn1, dtype, pm)
@@ -148,7 +149,12 @@ class FusedInferenceBackbone:
             return None
         if not fused.conv3x3_supported(w.shape[1], w.shape[0]):
             return None
-        return fused.pack_conv3x3_stream(w)
+        # 196 real input channels in a 224-wide map (zero weights from channel 196 on): channels 192 .. 199 as the 8-channel remainder
+        # chunk (GF_CONV_REM8: 114 instead of 126 sub-steps per tile); built for Cout = 224 with padded outputs and for Cout = 128
+        cout, cin = w.shape[:2]
+        rem8 = bool(cin == 224 and not w[:, 200:].any() and ((cout == 224 and not w[-16:].any()) or cout == 128))
+        self._rem8[id(w)] = rem8
+        return fused.pack_conv3x3_stream(w, rem8=rem8)
 
     def _conv3(self, x, w, ws, shift, shortcut, act, slope=0.01, stride=1):
         """act(conv(x, w) + shift + shortcut): one K10 launch when a stream exists."""
@@ -156,7 +162,7 @@ class FusedInferenceBackbone:
             pad16 = self._pad16.get(id(w))
             if pad16 is None:             # 196 real channels in a 224-wide map: the last 16 output channels carry zero weights
                 pad16 = self._pad16[id(w)] = bool(w.shape[0] == 224 and not w[-16:].any())
-            return fused.conv3x3(x, ws, w.shape[0], shift, shortcut, act, slope, pad16)
+            return fused.conv3x3(x, ws, w.shape[0], shift, shortcut, act, slope, pad16, self._rem8.get(id(w), False))
         y = self._conv(x, w, stride)
         if shift is None and shortcut is None and act == ops.ACT_NONE:
             return y

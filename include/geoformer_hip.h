@@ -248,6 +248,12 @@ int gf_fine_layer(const void* x, const void* src, void* out, int dtype, int Nw, 
  *   Channel counts: gf_conv3x3_supported(cin, cout).
  * ------------------------------------------------------------------------------------------ */
 #define GF_CONV_PAD16 0x100
+/*   | GF_CONV_REM8 (round 4; Cin = 224 with Cout = 224 | GF_CONV_PAD16, or Cout = 128): the caller states that the INPUT channels
+ *     200 .. 223 carry zero weights (196 real channels: the other side of the same padding) and passes the rem8 packing of the
+ *     weights (fused.py:pack_conv3x3_stream(w, rem8=True)): channels 0 .. 191 run as six 32-channel chunks, channels 192 .. 199 as a
+ *     remainder whose 9 taps x 8 channels fill three MFMA k-steps instead of a seventh chunk's nine - 114 instead of 126 sub-steps per
+ *     tile, the result differs from the plain call only by the order of the fp32 sums. */
+#define GF_CONV_REM8 0x200
 int gf_conv3x3_supported(int cin, int cout);
 int gf_conv3x3_nhwc(const void* x, const void* wstream, const float* shift, const void* residual, void* out,
                     const void* zeros, int N, int H, int W, int cin, int cout, int act, float slope, int dtype,

@@ -738,6 +738,37 @@ def test_conv3x3_captured_equals_eager_bit_for_bit(cin, cout, hw):
         assert torch.equal(out, fused.conv3x3(x, ws, cout, shift, res, ops.ACT_RELU))
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('cout,hw,use_res', [(224, (40, 70), True), (224, (160, 160), False), (128, (33, 37), True), (128, (64, 96), False)])
+def test_conv3x3_remainder_chunk(dtype, cout, hw, use_res):
+    """GF_CONV_REM8: a 224-channel input whose channels 196.. carry zero weights (the 196-channel pyramid level) - six 32-channel
+    chunks + channels 192 .. 199 as a remainder of three k-steps - against torch's fp32 convolution of the same operands (the
+    tolerance of test_conv3x3_vs_torch) and against the plain seven-chunk call (same products, another summation order: equal to
+    one rounding of the storage type); the input's padding channels hold NON-zero values here: they must not be read into the sum."""
+    from geoformer_amd import fused, ops
+    torch.manual_seed(cout + hw[0])
+    N, (H, W), cin = 2, hw, 224
+    x = torch.randn(N, cin, H, W, device='cuda').to(dtype).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, 3, 3, device='cuda') * (1.5 / (3 * 196 ** 0.5))).to(dtype)
+    w[:, 196:] = 0
+    pad16 = cout == 224
+    if pad16:
+        w[196:] = 0
+    shift = torch.randn(cout, device='cuda')
+    res = torch.randn(N, cout, H, W, device='cuda').to(dtype).contiguous(memory_format=torch.channels_last) if use_res else None
+    plain = fused.conv3x3(x, fused.pack_conv3x3_stream(w), cout, shift, res, ops.ACT_RELU, pad16=pad16)
+    rem = fused.conv3x3(x, fused.pack_conv3x3_stream(w, rem8=True), cout, shift, res, ops.ACT_RELU, pad16=pad16, rem8=True)
+    pre = torch.nn.functional.conv2d(x.float(), w.float(), None, 1, 1) + shift[None, :, None, None]
+    ref = torch.relu(pre + (res.float() if use_res else 0))
+    ulp = 2.0 ** (-10 if dtype == torch.float16 else -7)
+    scale = torch.maximum(pre.abs(), ref.abs()).clamp_min(1.0)
+    assert float(((rem.float() - ref).abs() / scale).max()) < 1.1 * ulp
+    assert float(((rem.float() - plain.float()).abs() / scale).max()) <= 1.01 * ulp
+    assert torch.equal(rem, fused.conv3x3(x, fused.pack_conv3x3_stream(w, rem8=True), cout, shift, res, ops.ACT_RELU, pad16=pad16, rem8=True))
+    with pytest.raises(ValueError):                              # weights in the channels the remainder form skips
+        fused.pack_conv3x3_stream(torch.ones(cout, 224, 3, 3, device='cuda', dtype=dtype), rem8=True)
+
+
 def test_conv3x3_rejects_unsupported():
     from geoformer_amd import fused, _lib
     assert not fused.conv3x3_supported(64, 64)

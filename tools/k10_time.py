@@ -44,3 +44,18 @@ for (N, CI, CO, H, W) in ((2, 128, 128, 37, 70), (16, 128, 128, 320, 320), (16, 
     fl = 2.0 * N * H * W * CI * CO * 9
     print(f'{N}x{CI}->{CO}x{H}x{W}: err {err:.3g} / plain {err0:.3g} | K10 {t_k7:.3f} ms ({fl / t_k7 / 1e9:.0f} TFLOP/s) | '
           f'MIOpen conv {t_conv:.3f} + bias_act = {t_sep:.3f} ms', flush=True)
+
+# the 196-channel level: plain seven-chunk call (PAD16 where the output is padded too) against the remainder form (GF_CONV_REM8)
+for (N, CI, CO, H, W) in ((16, 224, 224, 160, 160), (16, 224, 128, 320, 320)):
+    x = torch.randn(N, CI, H, W, device='cuda', dtype=dt).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(CO, CI, 3, 3, device='cuda', dtype=dt) * 0.03)
+    w[:, 196:] = 0
+    pad16 = CO == 224
+    if pad16:
+        w[196:] = 0
+    b = torch.randn(CO, device='cuda')
+    z = torch.randn(N, CO, H, W, device='cuda', dtype=dt).contiguous(memory_format=torch.channels_last)
+    ws, wr = fused.pack_conv3x3_stream(w), fused.pack_conv3x3_stream(w, rem8=True)
+    t_plain = timeit(lambda: fused.conv3x3(x, ws, CO, b, z, ops.ACT_RELU, pad16=pad16))
+    t_rem = timeit(lambda: fused.conv3x3(x, wr, CO, b, z, ops.ACT_RELU, pad16=pad16, rem8=True))
+    print(f'{N}x196(224)->{CO}x{H}x{W}: seven chunks {t_plain:.3f} ms | six chunks + remainder {t_rem:.3f} ms ({100 * (1 - t_rem / t_plain):.1f} % less)', flush=True)
