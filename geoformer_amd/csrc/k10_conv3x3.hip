@@ -61,23 +61,18 @@ struct ConvGeo {
     static constexpr int PIECES = (PH * PW + 15) / 16;            // DMA pieces of 16 pixels x 64 B
     static constexpr int PATCH_BYTES = PIECES * 1024;
     static constexpr int W10_OFF = 2 * PATCH_BYTES;                // two weight blocks behind the two patches
-    // two rows per wave (Cout <= 128): the epilogue slab aliases the patch buffer of the tile's last chunk (dead once every wave
-    // is past the last ring turn: the last step's pixel fragments are in registers by then; the next request into that buffer
-    // comes after the next tile's first turn, i.e. after every wave has left its epilogue) - that leaves room for 6-step blocks
-    static constexpr bool SLAB_ALIAS = NW == 8 && PB == 2;
-    static constexpr int BLOCK_STEPS = (NW == 8 && !SLAB_ALIAS) ? 3 : 6;   // a sixth / a third of a chunk's 18 steps
+    // a weight block = 6 sub-steps (a third of a chunk's 18); K10_BS=3 builds the short blocks of rounds 2-3 for the wide outputs
+#ifndef K10_BS
+#define K10_BS 6
+#endif
+    static constexpr int BLOCK_STEPS = (NW == 8 && PB == 1) ? K10_BS : 6;
     static constexpr int FR = BLOCK_STEPS * NT;                   // fragments per block
     static constexpr int WBLK = FR * C10_FRAG;
-    static constexpr int SLAB_OFF = W10_OFF + 2 * WBLK;
-    static constexpr int SP = NW == 4 ? 4 : 2;                    // accumulator tiles per epilogue pass
-    static constexpr int RS = SP * 64 + 16;                       // slab row: SP x 32 channels of a pixel + 16 B
-    static constexpr int SLAB_BYTES = NW * 32 * RS;               // one 32-pixel slab per wave
-    static constexpr int SHIFT_OFF = SLAB_OFF + (SLAB_ALIAS ? 0 : SLAB_BYTES);
+    static constexpr int SHIFT_OFF = W10_OFF + 2 * WBLK;
     // REM (GF_CONV_REM8): the patch of the 8-channel remainder chunk (16 B per pixel) has a buffer of its own, in pieces of 64 pixels
     static constexpr int RPIECES = (PH * PW + 63) / 64;
-    static constexpr int R_OFF = SHIFT_OFF + NT * 32 * 4;
+    static constexpr int R_OFF = SHIFT_OFF + NT * 32 * 4 + 16;   // (behind the shifts: the LeakyReLU slope)
     static constexpr int LDS = R_OFF + (REM ? RPIECES * 1024 : 0);
-    static_assert(!SLAB_ALIAS || SLAB_BYTES <= PATCH_BYTES, "slab must fit the patch buffer it aliases");
     static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
@@ -97,21 +92,23 @@ __device__ __forceinline__ void conv_lds_dma(const ConvRsrc& rs, char* dst, int 
 }
 // request weight block b of the stream into ring slot `slot`; the waves share its fragments round-robin
 template <int NT, int NW>
-__device__ __forceinline__ void conv_dma_block(const ConvRsrc& ws, char* smem, int b, int slot, int wave, int lane) {
+__device__ __forceinline__ void conv_dma_block(const ConvRsrc& ws, char* smem, int b, int slot, int wave, int lane, int i0 = 0, int i1 = 1 << 20) {
     using G = ConvGeo<NT, NW>;
     asm volatile("" : "+v"(lane));      // (as in conv_dma_patch)
     char* dst = smem + G::W10_OFF + slot * G::WBLK;
+    // the wave's pieces i0 .. i1 - 1 (the requests of a block are dealt to sub-steps; constant loop bounds: the range folds once the
+    // sub-step loop is unrolled)
 #pragma unroll
     for (int i = 0; i < (G::FR + NW - 1) / NW; ++i) {
         const int f = wave + NW * i;
-        if (f < G::FR) conv_lds_dma(ws, dst + f * C10_FRAG, lane * 16, b * G::WBLK + f * C10_FRAG);
+        if (i >= i0 && i < i1 && f < G::FR) conv_lds_dma(ws, dst + f * C10_FRAG, lane * 16, b * G::WBLK + f * C10_FRAG);
     }
 }
 
 // request the halo patch of (tile, channel chunk c) into patch buffer `buf`: pieces of 16 pixels x 64 B over the waves
 template <typename T, int CIN, int NT, int NW>
 __device__ __forceinline__ void conv_dma_patch(const ConvArgs& a, const ConvRsrc& xs, char* smem, int buf, int n, int y0, int x0, int c, int wave,
-                                               int lane) {
+                                               int lane, int i0 = 0, int i1 = 1 << 20) {
     using G = ConvGeo<NT, NW>;
     asm volatile("" : "+v"(lane));      // recompute the per-lane source offsets here: hoisted out of the K loop they cost
                                         // live registers per piece, and a spilled one a vmcnt(0) reload between requests
@@ -121,7 +118,7 @@ __device__ __forceinline__ void conv_dma_patch(const ConvArgs& a, const ConvRsrc
 #pragma unroll
     for (int i = 0; i < (G::PIECES + NW - 1) / NW; ++i) {
         const int piece = wave + NW * i;
-        if (piece < G::PIECES) {
+        if (i >= i0 && i < i1 && piece < G::PIECES) {
             const int q = piece * 16 + (lane >> 2), slot = (lane & 3) ^ ((q >> 1) & 3);
             const int pr = q / PW, pc = q - pr * PW;
             const bool in = (unsigned)(y0 - 1 + pr) < (unsigned)a.H && (unsigned)(x0 - 1 + pc) < (unsigned)a.W && q < G::PH * PW;
@@ -163,8 +160,12 @@ __device__ __forceinline__ void conv_dma_patch_rem(const ConvArgs& a, const Conv
 #if K10_TRACE
 __device__ long long k10_trace[256 * 8 * 8 * 16];
 #define K10_T(slot) do { if (lane == 0 && it < 8) k10_trace[((blockIdx.x * 8 + it) * 8 + wave) * 16 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+// sub-step stamps of chunk 1 of the workgroup's fifth tile: 0..17 sub-step starts, 18 chunk end, 20+b vmcnt wait done at turn b, 24+b barrier passed
+__device__ long long k10_trace2[256 * 8 * 32];
+#define K10_T2(slot) do { if (lane == 0 && it == 4 && c == 1) k10_trace2[(blockIdx.x * 8 + wave) * 32 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define K10_T(slot)
+#define K10_T2(slot)
 #endif
 
 // PADL: the last 16 output channels are padding (zero weights - act | GF_CONV_PAD16): their fragment (the last one of every odd
@@ -184,15 +185,32 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
     static_assert(!REM || CIN == 224, "the remainder form is built for 224-channel inputs");
     constexpr int NT = COUT / 32, NCH = REM ? 6 : CIN / 32, BS = G::BLOCK_STEPS, BPC = 18 / BS, RBPC = 6 / BS;
     constexpr int NBLK = NCH * BPC + (REM ? RBPC : 0);
-    constexpr int PB = G::PB, TH = G::TH, RS = G::RS, SP = G::SP;
+    constexpr int PB = G::PB, TH = G::TH;
     constexpr int NSTORE = PB * 2 * NT;                             // 16-byte output stores per lane and tile
+    // DMA pieces per wave: WP of a weight block, PP of a patch (every wave at least PPMIN).  They are requested in the turn's own
+    // sub-step (K10_DEAL=1 builds the round-4 experiment that deals them to the sub-steps behind the turn - weight pieces to the
+    // first WS, patch pieces to the other BS - WS, waves 0-3 in front of a sub-step's MFMAs, waves 4-7 behind them: a piece costs its
+    // wave 180-300 cycles of issue wherever it stands, and requested later it lands later - an L2 hit takes 2 thousand cycles, a
+    // patch piece from HBM 3.2 thousand, against the 4.2 thousand of a block: the turns waited 400-600 cycles on vmcnt, +4 % per tile)
+    constexpr int WP = (G::FR + NW - 1) / NW, PP = (G::PIECES + NW - 1) / NW, PPMIN = G::PIECES / NW;
+#ifndef K10_DEAL
+#define K10_DEAL 0
+#endif
+    constexpr bool DEAL = K10_DEAL != 0;
+    constexpr int WS = !DEAL ? 1 : WP <= 3 ? WP : 4, PS0 = DEAL ? WS : 0, PS = DEAL ? BS - WS : 1;
+    auto wbeg = [](int k) { return k >= WS ? WP : k * (WP / WS) + (k < WP % WS ? k : WP % WS); };
+    auto pbeg = [](int k) { return k >= PS ? PP : k * (PP / PS) + (k < PP % PS ? k : PP % PS); };
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lp = lane & 15, g4 = lane >> 4;                       // MFMA 16x16x32: row / column of the lane, its k group
     const ConvRsrc ws = conv_rsrc(a.wstream, (unsigned)NBLK * G::WBLK);
     const ConvRsrc xs = conv_rsrc(a.x, (unsigned)a.N * a.H * a.W * CIN * (unsigned)sizeof(T));
+    const ConvRsrc rres = conv_rsrc(a.res, (unsigned)a.N * a.H * a.W * COUT * (unsigned)sizeof(T));
+    const ConvRsrc rout = conv_rsrc(a.out, (unsigned)a.N * a.H * a.W * COUT * (unsigned)sizeof(T));
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
     float* shiftv = reinterpret_cast<float*>(smem + G::SHIFT_OFF);
     for (int i = tid; i < COUT; i += NW * 64) shiftv[i] = a.shift ? a.shift[i] : 0.f;
+    if (tid == 0) shiftv[COUT] = a.act == C10_LEAKY ? a.slope : 1.f;     // (read per tile: as a kernel-long live value it is one register too many)
     // the second-dispatched half of an 8-wave workgroup loses every arbitration on its SIMD: one static priority step for it
     // (no per-phase flips) takes 1-2 % off every shape
     if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
@@ -259,34 +277,30 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    [[maybe_unused]] int it = -1;
-    bool prev_full = false;                                         // previous tile of this workgroup: all its stores issued?
+    int it = -1;
     for (int tile = tile0; tile < xend; tile += xper) {
         int n, y0, x0;
         decode(tile, n, y0, x0);
         const int nxt_tile = tile + xper;
         const bool has_next = nxt_tile < xend;
+        int n2 = 0, y2 = 0, x2 = 0;
+        if (has_next) decode(nxt_tile, n2, y2, x2);
         ++it;
         K10_T(0);
         load_w(wa, wslot, 0, false);               // block 0 and the patch of chunk 0 landed before the previous tile's last turn
         load_x(xa, pbuf, 0);
-        // acc[bb][ct]: pixel block bb (row bb / 2 of the wave, pixels 16 (bb % 2) .. + 15), channels 16 ct + 4 g4 + {0..3};
-        // accumulators start at the shift of their channel
+        // acc[bb][ct]: pixel block bb (row bb / 2 of the wave, pixels 16 (bb % 2) .. + 15), channels 32 (ct / 2) + 8 g4 + 4 (ct % 2) + {0..3}
+        // (the packing deals the output channels to the fragment rows so that the tiles 2 j and 2 j + 1 of a lane are EIGHT CONSECUTIVE
+        // channels of its pixel: 16 bytes of the NHWC output - the epilogue stores from registers); accumulators start at the shift
         v4f acc[2 * PB][2 * NT];
         int il = lane;
         asm volatile("" : "+v"(il));
 #pragma unroll
         for (int ct = 0; ct < 2 * NT; ++ct) {
-            const float4 sh = *reinterpret_cast<const float4*>(shiftv + 16 * ct + 4 * (il >> 4));
+            const float4 sh = *reinterpret_cast<const float4*>(shiftv + 32 * (ct >> 1) + 4 * (ct & 1) + 8 * (il >> 4));
 #pragma unroll
             for (int bb = 0; bb < 2 * PB; ++bb) acc[bb][ct] = v4f{sh.x, sh.y, sh.z, sh.w};
         }
-        const T* rg = (const T*)a.res;
-        T* og = (T*)a.out;
-        // the epilogue runs in passes of SP accumulator tiles (the last pass of 224 channels: one fewer); in pass t0,
-        // a lane's chunk jj is slab chunk e = lane + 64 jj -> pixel e / cpr, 16-byte channel chunk e % cpr (cpr = 4 nt)
-        auto pass_tiles = [](int t0) { return NT - t0 < SP ? NT - t0 : SP; };
-
         // one chunk of the K loop: a FULL chunk c (32 input channels: 9 taps x 2 halves of the output channels = 18 sub-steps) or the
         // REMAINDER chunk (REM: 8 channels: 3 k-steps x 2 halves = 6 sub-steps; its patch has its own buffer, so the two patch buffers keep
         // alternating over the full chunks and the next tile's first patch is requested during the last FULL chunk, as without it)
@@ -296,6 +310,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
             const int blk0 = R ? NCH * BPC : c * BPC;                       // this chunk's first weight block
             const bool tile_ends = R || (!REM && c + 1 == NCH);              // no chunk of this tile behind this one
             const bool rem_next = !R && REM && c + 1 == NCH;                 // the remainder follows
+            const bool patch_req = c + 1 < NCH || has_next;                  // a full chunk requests a patch behind its first turn
 #pragma unroll
             for (int ts = 0; ts < NTS; ++ts) {                               // sub-step (tap or k-step ts / 2, channel half ts % 2)
                 const int tap = ts >> 1, hf = ts & 1;
@@ -304,36 +319,63 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
                 Frag (&cx)[2 * PB] = (tap & 1) ? xb : xa;
                 Frag (&nx)[2 * PB] = (tap & 1) ? xa : xb;
                 // (this sub-step's fragments were requested a sub-step ago; the compiler's counted lgkmcnt waits retire them)
-                if (ts % BS == BS - 1) {
-                    // ring turn before the last sub-step of a block: the next block (and a patch requested a turn ago) has
-                    // landed, every wave holds this block's last fragments in registers: its slot takes the block after next
-                    // (the first turn of a tile only needs the block requested before the previous tile's epilogue: its
-                    // NSTORE output stores - all issued when that tile lay inside the image - may stay in flight)
-                    const bool first_turn = !R && ts == BS - 1 && c == 0;
-                    if (first_turn) K10_T(12);
-                    if (first_turn && prev_full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (first_turn) K10_T(13);
-                    __builtin_amdgcn_s_barrier();
-                    if (first_turn) K10_T(14);
-                    const int nb = blk0 + ts / BS + 2;
-                    if (nb < NBLK) conv_dma_block<NT, NW>(ws, smem, nb, wslot, wave, lane);
-                    else if (has_next) conv_dma_block<NT, NW>(ws, smem, nb - NBLK, wslot, wave, lane);
-                    if (!R && ts == BS - 1) {
-                        // first turn of a full chunk: every wave is past the previous chunk, its patch buffer is free
-                        if (c + 1 < NCH) conv_dma_patch<T, CIN, NT, NW>(a, xs, smem, pbuf ^ 1, n, y0, x0, c + 1, wave, lane);
-                        else if (has_next) {
-                            int n2, y2, x2;
-                            decode(nxt_tile, n2, y2, x2);
-                            conv_dma_patch<T, CIN, NT, NW>(a, xs, smem, pbuf ^ 1, n2, y2, x2, 0, wave, lane);
-                        }
-                        // the tile's remainder patch: its buffer is free since every wave left the previous tile's remainder chunk
-                        if constexpr (REM) {
-                            if (c == 0) conv_dma_patch_rem<T, CIN, NT, NW>(a, xs, smem, n, y0, x0, wave, lane);
+                const int kslot = (ts + 1) % BS;                               // sub-steps since the last ring turn (0: the turn is in this one)
+                if constexpr (!R) K10_T2(ts);
+                // the DMA requests behind a turn: the weight pieces of the block after the landed one, then (a full chunk's first turn)
+                // the pieces of the next patch - in this order: the chunk's second turn waits for the weights only
+                auto dma_slot = [&]() {
+                    if (ts == NTS - 1 && tile_ends) return;                     // (issued whole at the turn)
+                    if (kslot < WS) {
+                        if (ts >= BS - 1 || R || c > 0) {                        // (a tile's first sub-steps: nothing is pending)
+                            const int nb = blk0 + (ts + 1) / BS + 1;             // = block being finished + 2 at the turn, current block + 1 behind it
+                            if (nb < NBLK) conv_dma_block<NT, NW>(ws, smem, nb, wslot ^ 1, wave, lane, wbeg(kslot), wbeg(kslot + 1));
+                            else if (has_next) conv_dma_block<NT, NW>(ws, smem, nb - NBLK, wslot ^ 1, wave, lane, wbeg(kslot), wbeg(kslot + 1));
                         }
                     }
-                    wslot ^= 1;
-                    if (first_turn) K10_T(15);
+                    if (!R && ts >= BS - 1 + PS0 && ts < BS - 1 + PS0 + PS) {
+                        // behind the first turn of a full chunk every wave is past the previous chunk: its patch buffer is free
+                        const int kp = ts - (BS - 1 + PS0);
+                        if (c + 1 < NCH) conv_dma_patch<T, CIN, NT, NW>(a, xs, smem, pbuf ^ 1, n, y0, x0, c + 1, wave, lane, pbeg(kp), pbeg(kp + 1));
+                        else if (has_next) conv_dma_patch<T, CIN, NT, NW>(a, xs, smem, pbuf ^ 1, n2, y2, x2, 0, wave, lane, pbeg(kp), pbeg(kp + 1));
+                        // the tile's remainder patch: its buffer is free since every wave left the previous tile's remainder chunk
+                        if constexpr (REM) {
+                            if (c == 0 && kp == PS - 1) conv_dma_patch_rem<T, CIN, NT, NW>(a, xs, smem, n, y0, x0, wave, lane);
+                        }
+                    }
+                };
+                if (kslot == 0) {
+                    // ring turn before the last sub-step of a block: the next block (and a patch requested a turn ago) has
+                    // landed, every wave holds this block's last fragments in registers: its slot takes the block after next.
+                    // What must have landed: the weight pieces, requested in the sub-steps behind the previous turn; a chunk's SECOND
+                    // turn leaves the patch pieces requested behind them in flight (every wave has issued at least PPMIN of them);
+                    // the first turn of a tile only needs the block requested before the previous tile's epilogue: its NSTORE output
+                    // stores - a store outside the image is issued too, and dropped - may stay in flight
+                    const bool first_turn = !R && ts == BS - 1 && c == 0;
+                    if (first_turn) K10_T(12);
+                    if (first_turn && it > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
+                    else if (!R && ts == 2 * BS - 1 && patch_req) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPMIN) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (first_turn) K10_T(13);
+                    if constexpr (!R) K10_T2(20 + ts / BS);
+                    __builtin_amdgcn_s_barrier();
+                    if constexpr (!R) K10_T2(24 + ts / BS);
+                    if (first_turn) K10_T(14);
+                    wslot ^= 1;                                                 // the landed block; the other slot is the one to fill
+                    if (ts == NTS - 1 && tile_ends) {
+                        // last turn of a tile: the whole request at once (dealt to the next tile's first sub-steps its pieces would
+                        // queue behind the epilogue's stores, and the next first turn would have to wait for those)
+                        const int nb = blk0 + ts / BS + 2;
+                        if (has_next) conv_dma_block<NT, NW>(ws, smem, nb - NBLK, wslot ^ 1, wave, lane);
+                    }
+                    if (!DEAL) {
+                        dma_slot();
+                        if (first_turn) K10_T(15);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // (in front of the fragment reads, behind the MFMAs: where the sub-step's 32-64 fragment registers of one buffer are dead)
+                if (DEAL && wave < 4) {
+                    dma_slot();
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // next sub-step's weight fragments, and behind a tap's second half the next tap's pixel fragments (a tile's
@@ -358,6 +400,10 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
                         if (!(PADL && hf == 1 && t == NT - 1)) Mm::mma(cw[t], cx[bb], acc[bb][hf * NT + t]);
+                if (DEAL && wave >= 4) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    dma_slot();
+                }
                 // issue order: two reads, then one read behind each of the first MFMAs (left alone the compiler sinks the
                 // reads behind the sub-step's last MFMA and the next one waits out the whole LDS latency)
                 __builtin_amdgcn_sched_barrier(0);
@@ -369,6 +415,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
                 for (int bb = 0; bb < 2 * PB; ++bb) xa[bb] = xb[bb];
             }
             if constexpr (!R) pbuf ^= 1;
+            if constexpr (!R) K10_T2(18);
         };
 #pragma unroll 1
         for (int c = 0; c < NCH; ++c) {
@@ -376,106 +423,129 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
             K10_T(2 + c);
         }
         if constexpr (REM) chunk(std::integral_constant<bool, true>{}, NCH);
-        // ---------------- epilogue (wave-private): T(acc) -> slab [pixel][SP x 32 channels] -> + shortcut -> act -> NHWC
+        // ---------------- epilogue (wave-private, registers only): T(acc) + shortcut -> act -> 16-byte NHWC stores
         K10_T(10);
-        const bool full = y0 + TH <= a.H && x0 + TW <= a.W;
-        // one straight-line body per (shortcut?, activation form, tile inside the image?): with these as run-time branches
-        // inside the passes every join waits for vmcnt(0), i.e. for the previous pass's stores to come back
-        auto epilogue = [&](auto has_res_c, auto mode_c, auto full_c) {
-            constexpr bool HAS_RES = decltype(has_res_c)::value, FULL = decltype(full_c)::value;
+        // one straight-line body per (shortcut?, activation form): with these as run-time branches inside the body every join
+        // waits for vmcnt(0), i.e. for the stores in flight
+        auto epilogue = [&](auto has_res_c, auto mode_c) {
+            constexpr bool HAS_RES = decltype(has_res_c)::value;
             constexpr int MODE = decltype(mode_c)::value;       // 0 packed-half ReLU, 1 packed-half none, 2 fp32 ReLU, 3 fp32 max(f, k f)
-            // (pbuf already names the NEXT tile's first patch: the other buffer is the dead one)
-            char* slab = smem + (G::SLAB_ALIAS ? P_OFF + (pbuf ^ 1) * G::PATCH_BYTES : G::SLAB_OFF) + wave * 32 * RS;
-            const float neg_k = a.act == C10_LEAKY ? a.slope : 1.f;
-            constexpr int PPB = (NT + SP - 1) / SP, NPASS = PB * PPB;     // passes p = (pixel block b, tile group t0)
-            int el = lane;                  // (recompute the lane's slab / pixel offsets per tile: kept across the K loop they spill)
+            int el = lane;                  // (recompute the lane's pixel offsets per tile: kept across the K loop they spill)
             asm volatile("" : "+v"(el));
-            // two rows per wave: the accumulators are packed to the storage type first (half the registers: room for the
-            // shortcut rows); one row per wave: converted as they are written (there the packed copy is what spills)
-            constexpr bool PACK_FIRST = PB == 2;
-            V4 pk[PACK_FIRST ? 2 * PB : 1][PACK_FIRST ? 2 * NT : 1];
-            if constexpr (PACK_FIRST) {
+            const float neg_k = MODE == 3 ? shiftv[COUT + (el >> 6)] : 1.f;
+            // Accumulator layout: lane (pixel lp = el % 16 of block bb, k group g4 = el / 16) holds the 16-byte pieces j = 0 .. NT - 1 of its
+            // pixel: channels 32 j + 8 g4 .. + 7 - stored as they are, an instruction would write 16 pixels x 64 bytes, and half-line
+            // writes run at 0.4 of the rate of whole 128-byte lines (tools/probes/epi_store.hip: 6900 against 2600 cycles per tile).
+            // So neighbouring pixels exchange pieces first (one DPP move per register): instruction A of (bb, m) writes the block's EVEN
+            // pixels, instruction B the odd ones, 128 bytes each - the even lane of a pair brings piece 2 m, the odd lane piece 2 m + 1.
+            // Buffer addressing: a 32-bit byte offset per (block, instruction) - out of range for a pixel outside the image (its load
+            // returns zeros, its store is dropped) - and 128 m in the instruction's immediate.
+            const int odd = el & 1, ey = y0 + PB * wave;
+            const int exa = x0 + (el & 14), exo = x0 + (el & 15);
+            const int ebase = ((n * a.H + ey) * a.W + x0) * COUT * (int)sizeof(T) + 16 * (el >> 4);        // (32-bit: the entry point bounds the maps)
+#ifndef K10_XCHG_WIDE
+#define K10_XCHG_WIDE 1
+#endif
+            constexpr int NB = 2 * PB, NM = (PB == 2 || K10_XCHG_WIDE) ? NT / 2 : 0, NL = NT - 2 * NM;
+            constexpr bool LONE = NL != 0;                    // pieces 2 NM .. NT - 1 are stored in the accumulator layout (224 channels: piece 6 has no partner)
+            int voa[NB], vob[NB], vol[LONE ? NB : 1];
 #pragma unroll
-                for (int bb = 0; bb < 2 * PB; ++bb)
-#pragma unroll
-                    for (int ct = 0; ct < 2 * NT; ++ct)
-                        pk[bb][ct] = V4{(T)acc[bb][ct][0], (T)acc[bb][ct][1], (T)acc[bb][ct][2], (T)acc[bb][ct][3]};
-                __builtin_amdgcn_sched_barrier(0);
+            for (int bb = 0; bb < NB; ++bb) {
+                const int rowoff = ((bb >> 1) * a.W + 16 * (bb & 1)) * COUT * (int)sizeof(T);
+                const bool iny = ey + (bb >> 1) < a.H;
+                voa[bb] = iny && exa + 16 * (bb & 1) < a.W ? ebase + rowoff + (el & 14) * COUT * (int)sizeof(T) + 64 * odd : 0x7FFFFFF0;
+                vob[bb] = iny && exa + 1 + 16 * (bb & 1) < a.W ? ebase + rowoff + ((el & 14) + 1) * COUT * (int)sizeof(T) + 64 * odd : 0x7FFFFFF0;
+                if constexpr (LONE) vol[bb] = iny && exo + 16 * (bb & 1) < a.W ? ebase + rowoff + (el & 15) * COUT * (int)sizeof(T) + 64 * (2 * NM) : 0x7FFFFFF0;
             }
-            // every shortcut row is requested before the first output store: a load waited for behind a store (the memory
-            // counter is in issue order) would expose the store's round trip once per pass
-            V8 rl[HAS_RES ? NPASS : 1][2 * SP];
-            if constexpr (HAS_RES) {
+            auto pack8 = [](const v4f& lo, const v4f& hi) {
+                return V8{(T)lo[0], (T)lo[1], (T)lo[2], (T)lo[3], (T)hi[0], (T)hi[1], (T)hi[2], (T)hi[3]};
+            };
+            // pieces p0 (2 m) and p1 (2 m + 1) of the lane's pixel -> what the lane stores in instruction A / B
+            auto exchange = [&](const V8& p0, const V8& p1, V8& da, V8& db) {
+                const v4u u0 = __builtin_bit_cast(v4u, p0), u1 = __builtin_bit_cast(v4u, p1);
+                v4u ua, ub;
 #pragma unroll
-                for (int p = 0; p < NPASS; ++p) {
-                    const int b = p / PPB, t0 = (p % PPB) * SP, nt = pass_tiles(t0), cpr = 4 * nt, y = y0 + PB * wave + b;
-#pragma unroll
-                    for (int jj = 0; jj < 2 * SP; ++jj)
-                        if (jj < 2 * nt) {
-                            const int e = el + 64 * jj, px = e / cpr, cc = e - px * cpr, x = x0 + px;
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) rl[p][jj][i] = (T)0.f;
-                            if (FULL || (y < a.H && x < a.W))
-                                rl[p][jj] = *reinterpret_cast<const V8*>(rg + (((size_t)n * a.H + y) * a.W + x) * COUT + (t0 * 4 + cc) * 8);
-                        }
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned send = odd ? u0[i] : u1[i];                                               // the piece the neighbour stores
+                    const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+                    ua[i] = odd ? recv : u0[i];
+                    ub[i] = odd ? u1[i] : recv;
                 }
-            }
+                da = __builtin_bit_cast(V8, ua);
+                db = __builtin_bit_cast(V8, ub);
+            };
+            auto finish = [&](const V8& v, const V8& r) {                  // + shortcut, activation (v: the sum rounded to the storage type)
+                V8 o;
+                if constexpr (MODE <= 1) {
+                    // packed half arithmetic: the sum of two halves rounded to half is what the fp32 route gives
+                    // (up to a double rounding when the exponents are > 13 apart), max is exact
+                    o = v;
+                    if constexpr (HAS_RES) o = o + r;
+                    if constexpr (MODE == 0) o = __builtin_elementwise_max(o, V8{0, 0, 0, 0, 0, 0, 0, 0});
+                } else {
+                    float f[8];
 #pragma unroll
-            for (int p = 0; p < NPASS; ++p) {
-                const int b = p / PPB, t0 = (p % PPB) * SP, nt = pass_tiles(t0), cpr = 4 * nt, y = y0 + PB * wave + b;
-                // slab [pixel of the row][channel of the pass]: the lane's four channels 16 ct + 4 g4 + {0..3} of its pixel
+                    for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+                    if constexpr (HAS_RES) {
 #pragma unroll
-                for (int hx = 0; hx < 2; ++hx)
+                        for (int i = 0; i < 8; ++i) f[i] += (float)r[i];
+                    }
 #pragma unroll
-                    for (int t = 0; t < 2 * SP; ++t)
-                        if (t < 2 * nt) {
-                            const int bb = 2 * b + hx, ct = 2 * t0 + t;
-                            *reinterpret_cast<V4*>(slab + (16 * hx + (el & 15)) * RS + (t * 16 + 4 * (el >> 4)) * 2) =
-                                PACK_FIRST ? pk[PACK_FIRST ? bb : 0][PACK_FIRST ? ct : 0]
-                                           : V4{(T)acc[bb][ct][0], (T)acc[bb][ct][1], (T)acc[bb][ct][2], (T)acc[bb][ct][3]};
+                    for (int i = 0; i < 8; ++i) o[i] = (T)(MODE == 2 ? fmaxf(f[i], 0.f) : fmaxf(f[i], f[i] * neg_k));
+                }
+                return o;
+            };
+            auto load8 = [&](int vo, int imm) { return __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(rres.r, vo + imm, 0, 0)); };
+            auto store8 = [&](const V8& o, int vo, int imm) {
+                if (K10_STORE_OK) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), rout.r, vo + imm, 0, 0);
+            };
+            // every shortcut piece is requested before the first output store: a load waited for behind a store (the memory
+            // counter is in issue order) would expose the store's round trip (the LeakyReLU-with-shortcut body, which no layer of the
+            // backbone uses, goes pixel block by pixel block instead: its fp32 route would spill beside all the shortcut rows)
+            constexpr int BATCH = (HAS_RES && MODE == 3) ? 1 : NB;
+#pragma unroll
+            for (int b0 = 0; b0 < NB; b0 += BATCH) {
+                V8 ra[HAS_RES ? BATCH : 1][HAS_RES ? NM : 1], rb[HAS_RES ? BATCH : 1][HAS_RES ? NM : 1], rlone[HAS_RES && LONE ? BATCH : 1][LONE ? NL : 1];
+                if constexpr (HAS_RES) {
+#pragma unroll
+                    for (int bq = 0; bq < BATCH; ++bq) {
+#pragma unroll
+                        for (int m = 0; m < NM; ++m) {
+                            ra[bq][m] = load8(voa[b0 + bq], 128 * m);
+                            rb[bq][m] = load8(vob[b0 + bq], 128 * m);
                         }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        if constexpr (LONE) {
 #pragma unroll
-                for (int jj = 0; jj < 2 * SP; ++jj) {
-                    if (jj < 2 * nt) {
-                        const int e = el + 64 * jj, px = e / cpr, cc = e - px * cpr, x = x0 + px, ch8 = t0 * 4 + cc;
-                        const V8 v = *reinterpret_cast<const V8*>(slab + px * RS + cc * 16);
-                        V8 o;
-                        if constexpr (MODE <= 1) {
-                            // packed half arithmetic: the sum of two halves rounded to half is what the fp32 route gives
-                            // (up to a double rounding when the exponents are > 13 apart), max is exact
-                            o = v;
-                            if constexpr (HAS_RES) o = o + rl[p][jj];
-                            if constexpr (MODE == 0) o = __builtin_elementwise_max(o, V8{0, 0, 0, 0, 0, 0, 0, 0});
-                        } else {
-                            float f[8];
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
-                            if constexpr (HAS_RES) {
-#pragma unroll
-                                for (int i = 0; i < 8; ++i) f[i] += (float)rl[p][jj][i];
-                            }
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) o[i] = (T)(MODE == 2 ? fmaxf(f[i], 0.f) : fmaxf(f[i], f[i] * neg_k));
+                            for (int q = 0; q < NL; ++q) rlone[bq][q] = load8(vol[b0 + bq], 64 * q);
                         }
-                        if ((FULL || (y < a.H && x < a.W)) && K10_STORE_OK)
-                            *reinterpret_cast<V8*>(og + (((size_t)n * a.H + y) * a.W + x) * COUT + ch8 * 8) = o;
                     }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int bq = 0; bq < BATCH; ++bq) {
+                    const int bb = b0 + bq;
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) {
+                        V8 da, db;
+                        exchange(pack8(acc[bb][4 * m], acc[bb][4 * m + 1]), pack8(acc[bb][4 * m + 2], acc[bb][4 * m + 3]), da, db);
+                        store8(finish(da, ra[HAS_RES ? bq : 0][HAS_RES ? m : 0]), voa[bb], 128 * m);
+                        store8(finish(db, rb[HAS_RES ? bq : 0][HAS_RES ? m : 0]), vob[bb], 128 * m);
+                        // (left alone the scheduler runs the arithmetic of every piece before the first store: 100+ more live registers)
+                        if constexpr (MODE >= 2) __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if constexpr (LONE) {
+#pragma unroll
+                        for (int q = 0; q < NL; ++q) {
+                            store8(finish(pack8(acc[bb][4 * NM + 2 * q], acc[bb][4 * NM + 2 * q + 1]), rlone[HAS_RES ? bq : 0][q]), vol[bb], 64 * q);
+                            if constexpr (MODE >= 2) __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
             }
         };
         using std::integral_constant;
-        auto by_tile = [&](auto has_res_c, auto mode_c) {
-            if (full) epilogue(has_res_c, mode_c, integral_constant<bool, true>{});
-            else epilogue(has_res_c, mode_c, integral_constant<bool, false>{});
-        };
         auto by_res = [&](auto mode_c) {
-            if (rg) by_tile(integral_constant<bool, true>{}, mode_c);
-            else by_tile(integral_constant<bool, false>{}, mode_c);
+            if (a.res) epilogue(integral_constant<bool, true>{}, mode_c);
+            else epilogue(integral_constant<bool, false>{}, mode_c);
         };
         if constexpr (std::is_same<T, _Float16>::value) {
             if (a.act == C10_RELU) by_res(integral_constant<int, 0>{});
@@ -485,7 +555,6 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
             if (a.act == C10_RELU) by_res(integral_constant<int, 2>{});
             else by_res(integral_constant<int, 3>{});
         }
-        prev_full = full;
         K10_T(11);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -495,6 +564,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
 }
 extern "C" int gf_debug_k10_trace(long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(k10_trace), sizeof(k10_trace)) == hipSuccess ? 0 : -1;
+}
+extern "C" int gf_debug_k10_trace2(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(k10_trace2), sizeof(k10_trace2)) == hipSuccess ? 0 : -1;
 }
 namespace {
 #endif

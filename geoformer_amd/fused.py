@@ -197,8 +197,10 @@ _ZEROS = {}
 def pack_conv3x3_stream(w, rem8=False):
     """w [Cout, Cin, 3, 3] (BatchNorm already folded, 16-bit) -> the fragment stream of gf_conv3x3_nhwc: for each 32-channel
     input chunk c, tap t = 3 ky + kx and half hf of the output channels, Cout/32 fragments of the 16x16x32 MFMA's A operand:
-    fragment tt = channels 16 (hf Cout/32 + tt) .. + 15, lane l -> row l % 16, input channels 32 c + 8 (l / 16) .. + 7
-    (18 sub-steps per chunk; the kernel's weight blocks are 3 or 6 consecutive sub-steps).
+    fragment tt = accumulator tile ct = hf Cout/32 + tt, lane l -> row l % 16, input channels 32 c + 8 (l / 16) .. + 7; row r of
+    tile ct is output channel 32 (ct / 2) + 8 (r / 4) + 4 (ct % 2) + r % 4 - the four accumulator rows a lane owns in the tiles
+    2 j and 2 j + 1 are eight consecutive channels, i.e. 16 bytes of the NHWC output, stored from registers
+    (18 sub-steps per chunk; the kernel's weight blocks are 6 consecutive sub-steps).
     rem8 (Cin = 224 whose channels 200.. carry zero weights - the 196-channel pyramid level): six full chunks (channels 0 .. 191)
     and a REMAINDER of channels 192 .. 199 whose 9 taps x 8 channels = 72 contraction elements fill three 32-deep MFMA k-steps
     (lane k group kg of k-step s = tap 4 s + kg, taps 9 .. 11 zero) instead of the nine k-steps of a seventh chunk: 6 sub-steps
@@ -208,8 +210,9 @@ def pack_conv3x3_stream(w, rem8=False):
     dev = w.device
     lane = torch.arange(64, device=dev)
     row, kg = lane % 16, lane // 16
-    # out[c, t, hf, tt, lane, j] = wt[16 (hf nt + tt) + row, c, 8 kg + j, t]
-    co = (16 * (torch.arange(2, device=dev)[:, None, None] * nt + torch.arange(nt, device=dev)[None, :, None]) + row[None, None, :])   # [2, nt, 64]
+    # out[c, t, hf, tt, lane, j] = wt[channel(hf nt + tt, row), c, 8 kg + j, t]
+    ct = torch.arange(2, device=dev)[:, None, None] * nt + torch.arange(nt, device=dev)[None, :, None]                              # [2, nt, 1]
+    co = 32 * (ct // 2) + 4 * (ct % 2) + (8 * (row // 4) + row % 4)[None, None, :]                                                 # [2, nt, 64]
     kk = 8 * kg[:, None] + torch.arange(8, device=dev)[None, :]                      # [64, 8]
     full = 192 if rem8 else cin
     if rem8 and (cin != 224 or bool(w[:, 200:].any())):
@@ -223,7 +226,7 @@ def pack_conv3x3_stream(w, rem8=False):
     wr[:, :, :9] = w[:, 192:200].reshape(cout, 8, 9)
     j = torch.arange(8, device=dev)
     tap = 4 * torch.arange(3, device=dev)[:, None] + kg[None, :]                      # [3 k-steps, 64 lanes]
-    # rem[s, hf, tt, lane, j] = wr[16 (hf nt + tt) + row, j, 4 s + kg]
+    # rem[s, hf, tt, lane, j] = wr[channel(hf nt + tt, row), j, 4 s + kg]
     r = wr[co[None, :, :, :, None], j[None, None, None, None, :], tap[:, None, None, :, None]]        # [3, 2, nt, 64, 8]
     return torch.cat([out, r.contiguous().reshape(-1)])
 
@@ -238,7 +241,7 @@ CONV_REM8 = 0x200           # GF_CONV_REM8
 
 def conv3x3(x, wstream, cout, shift=None, residual=None, act=0, slope=0.01, pad16=False, rem8=False):
     """x channels_last [N, Cin, H, W] (16-bit) -> channels_last [N, cout, H, W] = act(conv3x3(x) + shift + residual).
-    pad16: the last 16 output channels are zero padding (zero weights): their products are skipped.
+    pad16 (cout = 224): the output channels 196 .. 223 are zero padding (zero weights): the all-padding accumulator tile is skipped.
     rem8: wstream = pack_conv3x3_stream(w, rem8=True) (Cin = 224, input channels 200.. have zero weights: not multiplied)."""
     _need_cuda(x, wstream)
     if x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last):

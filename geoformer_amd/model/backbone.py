@@ -152,7 +152,7 @@ class FusedInferenceBackbone:
         # 196 real input channels in a 224-wide map (zero weights from channel 196 on): channels 192 .. 199 as the 8-channel remainder
         # chunk (GF_CONV_REM8: 114 instead of 126 sub-steps per tile); built for Cout = 224 with padded outputs and for Cout = 128
         cout, cin = w.shape[:2]
-        rem8 = bool(cin == 224 and not w[:, 200:].any() and ((cout == 224 and not w[-16:].any()) or cout == 128))
+        rem8 = bool(cin == 224 and not w[:, 200:].any() and ((cout == 224 and not w[196:].any()) or cout == 128))
         self._rem8[id(w)] = rem8
         return fused.pack_conv3x3_stream(w, rem8=rem8)
 
@@ -160,8 +160,8 @@ class FusedInferenceBackbone:
         """act(conv(x, w) + shift + shortcut): one K10 launch when a stream exists."""
         if ws is not None:
             pad16 = self._pad16.get(id(w))
-            if pad16 is None:             # 196 real channels in a 224-wide map: the last 16 output channels carry zero weights
-                pad16 = self._pad16[id(w)] = bool(w.shape[0] == 224 and not w[-16:].any())
+            if pad16 is None:             # 196 real channels in a 224-wide map: the output channels 196.. carry zero weights
+                pad16 = self._pad16[id(w)] = bool(w.shape[0] == 224 and not w[196:].any())
             return fused.conv3x3(x, ws, w.shape[0], shift, shortcut, act, slope, pad16, self._rem8.get(id(w), False))
         y = self._conv(x, w, stride)
         if shift is None and shortcut is None and act == ops.ACT_NONE:

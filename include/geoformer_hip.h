@@ -238,11 +238,13 @@ int gf_fine_layer(const void* x, const void* src, void* out, int dtype, int Nw, 
  * replaces conv3x3 + BatchNorm(eval) [+ shortcut] + ReLU / LeakyReLU of BasicBlock.forward and of the FPN heads
  *          (model/loftr_src/loftr/backbone/resnet_fpn.py:9-40, :60-83, :100-116), BatchNorm folded into the weights
  *   out[n,y,x,:] = act( sum_{ky,kx} w[:, :, ky, kx] . x[n, y+ky-1, x+kx-1, :] + shift + residual[n,y,x,:] )
- *   x [N,H,W,cin], out / residual [N,H,W,cout] (GF_F16 or GF_BF16); fp32 accumulation starting from the shift; the sum is
- *   rounded to the storage type once before the residual is added and once at the output (a separate convolution
- *   followed by gf_bias_act_nhwc rounds twice as well); act: 0 none, 1 ReLU, 2 LeakyReLU(slope in [0,1]), optionally
- *   | GF_CONV_PAD16: the caller states that the last 16 output channels are zero padding (zero weights, e.g. 196 real
- *   channels in a 224-wide map) - their products are skipped, the outputs are act(shift + residual) as everywhere;
+ *   x [N,H,W,cin], out / residual [N,H,W,cout] (GF_F16 or GF_BF16); fp32 accumulation starting from the shift; GF_F16 with
+ *   act 0 / 1: the sum is rounded to half before the residual is added in packed half arithmetic and once more at the output (a
+ *   separate convolution followed by gf_bias_act_nhwc rounds twice as well); GF_BF16 and LeakyReLU: residual and activation on
+ *   the fp32 accumulators, ONE rounding at the output; act: 0 none, 1 ReLU, 2 LeakyReLU(slope in [0,1]), optionally
+ *   | GF_CONV_PAD16 (cout = 224): the caller states that the output channels 196 .. 223 are zero padding (zero weights: the 196
+ *   real channels of the reference's middle pyramid level in a 224-wide map) - 16 of them are not multiplied (the accumulator tile
+ *   that holds only padding), their outputs are act(shift + residual) as everywhere;
  *   shift fp32 [cout] or NULL; residual or NULL; maps must hold fewer than 2^31 elements;
  *   wstream = geoformer_amd/fused.py:pack_conv3x3_stream(w); zeros = >= 64 bytes of zeroed device memory.
  *   Channel counts: gf_conv3x3_supported(cin, cout).

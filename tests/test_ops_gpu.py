@@ -692,8 +692,8 @@ def test_conv3x3_full_size_vs_library(cin, cout, hw):
 @pytest.mark.parametrize('cin,hw', [(224, (40, 70)), (256, (33, 37))])
 @pytest.mark.parametrize('use_res', [False, True])
 def test_conv3x3_padded_output_channels(cin, hw, use_res):
-    """GF_CONV_PAD16: with zero weights in the last 16 of 224 output channels (196 real channels padded for the matrix cores)
-    the call that skips their products gives the SAME bits as the one that multiplies the zeros - also where the shift and the
+    """GF_CONV_PAD16: with zero weights in the output channels 196 .. 223 (196 real channels padded for the matrix cores)
+    the call that skips the all-padding accumulator tile gives the SAME bits as the one that multiplies the zeros - also where the shift and the
     shortcut of the padded channels are not zero (the epilogue still runs for them)."""
     from geoformer_amd import fused, ops
     torch.manual_seed(cin)

@@ -14,6 +14,7 @@ z = torch.randn(N, CO, H, H, device='cuda', dtype=torch.float16).contiguous(memo
 b = torch.randn(CO, device='cuda')
 ws = fused.pack_conv3x3_stream(w)
 fn = ctypes.CDLL(_lib.LIB_PATH).gf_debug_k10_trace
+fn2 = ctypes.CDLL(_lib.LIB_PATH).gf_debug_k10_trace2
 for res in (z, None):
     for _ in range(3):
         fused.conv3x3(x, ws, CO, b, res, ops.ACT_RELU)
@@ -31,3 +32,11 @@ for res in (z, None):
     for it in (0, 1, 4, 7):
         d = t[:, it, cols] - t[:, it, :1]
         print(f'  tile {it}: median offsets', np.median(d, axis=0).astype(int).tolist(), ' start-after-kernel-begin', int(np.median(t[:, it, 0]) - t[:, 0, 0].min()))
+    b2 = np.zeros(256 * 8 * 32, dtype=np.int64)
+    fn2(b2.ctypes.data_as(ctypes.c_void_p))
+    S = b2.reshape(256, 8, 32)
+    for w in (0, 4):
+        d = S[:, w, :] - S[:, 0, :1]
+        m = np.median(d, axis=0).astype(int)
+        print(f'  tile 4 chunk 1 wave {w}: sub-step starts', m[:19].tolist())
+        print(f'      sub-step lengths', np.diff(m[:19]).tolist(), '| turns: wait done', m[20:23].tolist(), 'barrier passed', m[24:27].tolist())
