@@ -13,8 +13,8 @@
 //               row per wave);
 //   K loop     = input channels in chunks of 32 x 9 taps x 2 halves of the output channels: one SUB-STEP = COUT/32 weight
 //               fragments (16 channels x 32 input channels each) times the tap's 2 PB pixel fragments (16 pixels x 32
-//               channels = the 64 bytes of a patch pixel); a weight block = 6 sub-steps (3 for the wide outputs), so the
-//               ring turns at fixed places of a chunk;
+//               channels = the 64 bytes of a patch pixel); a weight block = 6 sub-steps, so the ring turns at fixed
+//               places of a chunk;
 //   pixels     = per chunk the halo patch of the tile (64 B per pixel) sits in LDS, double-buffered: the next chunk's
 //               (or the next tile's first) patch arrives by LDS-DMA while the current one is multiplied; pixels outside
 //               the image are read from a page of zeros (per-lane DMA source address); the 16-byte slot index is XORed
@@ -23,10 +23,11 @@
 //   persistent = min(tiles, 256) workgroups walk the tiles (13 rounds at 16 x 320 x 320); the ring and the patch
 //               buffers run on across tiles (the next tile's first blocks and patch are requested during the last
 //               chunk), and the epilogue is wave-private: no workgroup barrier besides the ring turns;
-//   epilogue   = accumulators (started at the BatchNorm shift) -> a wave-private LDS slab (pixel-major; for the two-row
-//               variants it aliases the patch buffer of the tile's last chunk) -> + shortcut (every row requested before the
-//               first store) -> activation -> 16-byte NHWC stores that nobody waits for; one straight-line body per
-//               (shortcut?, activation form, tile inside the image?).
+//   epilogue   = from registers (wave-private): the packing deals the output channels to the fragment rows so that two accumulator
+//               tiles of a lane are 8 consecutive channels; accumulators (started at the BatchNorm shift) -> storage type -> neighbouring
+//               pixels exchange pieces by DPP so that an instruction writes 8 pixels x 128 B -> + shortcut (every piece requested
+//               before the first store) -> activation -> 16-byte buffer stores that nobody waits for (pixels outside the image: an
+//               out-of-range offset); one straight-line body per (shortcut?, activation form).
 #include <type_traits>
 
 #include "gf_common.h"
