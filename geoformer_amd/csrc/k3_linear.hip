@@ -66,7 +66,7 @@ struct LinArgs {
     // EPI_UPADD (the FPN merge fused into the 1x1 lateral convolution): rows are the pixels of [n][H][W] maps and
     // out += bilinear(lo -> H x W, align_corners=True), lo = [n][h][w][N] of T
     const void* up_lo;
-    int up_h, up_w, up_H, up_W;
+    int up_h, up_w, up_H, up_W, up_n;
     float up_ry, up_rx;
     // row map of a1 (a strided 1x1 convolution's input pixels; k2 == 0): row r of the product reads a1 at element offset
     // (r / rm_w) * rm_line + (r % rm_w) * rm_pix instead of r * lda1; rm_w == 0: off
@@ -278,32 +278,71 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void linear_kernel(Lin
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if constexpr (EPI == EPI_UPADD) {
+                // Two phases, no branch between them: ALL 32 tap rows of the slab are requested, then consumed.  (Round 3's form - taps
+                // loaded and used row group by row group, with `continue` / the wrap loop between the groups - exposed one L2 round trip
+                // per group: 16 thousand cycles per slab, 30 of a tile's 40 thousand; tools/k3_upadd_trace.py.)
+                const int cg = n0 + hb * 128 + pch * 8;
+                const bool cok = cg < a.N;
+                const T* lo = (const T*)a.up_lo + (cok ? cg : 0);
+#ifndef K3_UPADD_BATCH
+#define K3_UPADD_BATCH 4
+#endif
+                constexpr int UB = K3_UPADD_BATCH;                       // row groups per batch (8: 194 registers = two waves per SIMD instead of three)
+#pragma unroll
+                for (int b0 = 0; b0 < 8; b0 += UB) {
+                V8 tap[UB][4];
+                float wgt[UB][2];
+#pragma unroll
+                for (int ib = 0; ib < UB; ++ib) {
+                    const int it = b0 + ib;
+                    // pixel of this row: the wave's first row is decoded once (uniform), rows step along x and wrap (rows of 32+ pixels:
+                    // at most once; narrower maps take the division)
+                    const int row = it * 4 + prow;
+                    int px = upx + row, py = upy, pn = upn;
+                    if (a.up_W >= 32) {
+                        const bool wr = px >= a.up_W;
+                        px -= wr ? a.up_W : 0;
+                        py += wr ? 1 : 0;
+                        const bool wy = py >= a.up_H;
+                        py = wy ? 0 : py;
+                        pn += wy ? 1 : 0;
+                    } else {
+                        const unsigned t = (unsigned)(m0 + wave * 32 + row), q = t / (unsigned)a.up_W;
+                        px = (int)(t - q * (unsigned)a.up_W);
+                        py = (int)(q % (unsigned)a.up_H);
+                        pn = (int)(q / (unsigned)a.up_H);
+                    }
+                    pn = pn < a.up_n ? pn : a.up_n - 1;                  // (rows behind the last pixel: any valid address; not stored)
+                    const float fy = a.up_ry * py, fx = a.up_rx * px;
+                    const int y0 = (int)fy, x0 = (int)fx;
+                    const int y1 = y0 + (y0 < a.up_h - 1), x1 = x0 + (x0 < a.up_w - 1);
+                    wgt[ib][0] = fy - y0;
+                    wgt[ib][1] = fx - x0;
+                    const T* lp = lo + (size_t)pn * a.up_h * a.up_w * a.N;
+                    tap[ib][0] = *reinterpret_cast<const V8*>(lp + ((size_t)y0 * a.up_w + x0) * a.N);
+                    tap[ib][1] = *reinterpret_cast<const V8*>(lp + ((size_t)y0 * a.up_w + x1) * a.N);
+                    tap[ib][2] = *reinterpret_cast<const V8*>(lp + ((size_t)y1 * a.up_w + x0) * a.N);
+                    tap[ib][3] = *reinterpret_cast<const V8*>(lp + ((size_t)y1 * a.up_w + x1) * a.N);
+                }
+#pragma unroll
+                for (int ib = 0; ib < UB; ++ib) {
+                    const int row = (b0 + ib) * 4 + prow, tg = m0 + wave * 32 + row;
+                    V8 v = *reinterpret_cast<const V8*>(ot + row * RS + pch * 16);
+                    const float wy1 = wgt[ib][0], wx1 = wgt[ib][1], wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        v[i] = (T)((float)v[i] + wy0 * (wx0 * (float)tap[ib][0][i] + wx1 * (float)tap[ib][1][i]) +
+                                          wy1 * (wx0 * (float)tap[ib][2][i] + wx1 * (float)tap[ib][3][i]));
+                    if (tg < a.M && cok) *reinterpret_cast<V8*>((T*)a.out + (size_t)tg * a.ldo + cg) = v;
+                }
+                }
+            } else {
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int row = it * 4 + prow, tg = m0 + wave * 32 + row, cg = n0 + hb * 128 + pch * 8;
                 if (tg >= a.M || cg >= a.N) continue;
                 V8 v = *reinterpret_cast<const V8*>(ot + row * RS + pch * 16);
-                if constexpr (EPI == EPI_UPADD) {
-                    // pixel of this row: the wave's first row is decoded once (uniform), rows step along x with wrap
-                    int px = upx + row, py = upy, pn = upn;
-                    while (px >= a.up_W) {
-                        px -= a.up_W;
-                        if (++py >= a.up_H) { py = 0; ++pn; }
-                    }
-                    const float fy = a.up_ry * py, fx = a.up_rx * px;
-                    const int y0 = (int)fy, x0 = (int)fx;
-                    const int y1 = y0 + (y0 < a.up_h - 1), x1 = x0 + (x0 < a.up_w - 1);
-                    const float wy1 = fy - y0, wx1 = fx - x0, wy0 = 1.f - wy1, wx0 = 1.f - wx1;
-                    const T* lo = (const T*)a.up_lo + (size_t)pn * a.up_h * a.up_w * a.N + cg;
-                    const V8 v00 = *reinterpret_cast<const V8*>(lo + ((size_t)y0 * a.up_w + x0) * a.N);
-                    const V8 v01 = *reinterpret_cast<const V8*>(lo + ((size_t)y0 * a.up_w + x1) * a.N);
-                    const V8 v10 = *reinterpret_cast<const V8*>(lo + ((size_t)y1 * a.up_w + x0) * a.N);
-                    const V8 v11 = *reinterpret_cast<const V8*>(lo + ((size_t)y1 * a.up_w + x1) * a.N);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        v[i] = (T)((float)v[i] + wy0 * (wx0 * (float)v00[i] + wx1 * (float)v01[i]) +
-                                          wy1 * (wx0 * (float)v10[i] + wx1 * (float)v11[i]));
-                }
                 if constexpr (EPI == EPI_LN_RES) {
                     const V8 x = *reinterpret_cast<const V8*>((const T*)a.res + (size_t)tg * a.ldres + cg);
                     const bool keep = a.flag == nullptr || a.flag[tg / a.flag_rows] != 0;
@@ -311,6 +350,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void linear_kernel(Lin
                     for (int i = 0; i < 8; ++i) v[i] = keep ? (T)((float)x[i] + (float)v[i]) : x[i];
                 }
                 *reinterpret_cast<V8*>((T*)a.out + (size_t)tg * a.ldo + cg) = v;
+            }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -550,7 +590,7 @@ extern "C" int gf_conv1x1_upsample_add_nhwc(const void* x, const void* w, const 
     GF_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)lo % 16 == 0, "tensors must be 16-byte aligned");
     LinArgs a{};
     a.a1 = x; a.lda1 = Cin; a.k1 = Cin; a.w = w; a.out = out; a.ldo = Cout; a.M = N * H * W; a.N = Cout;
-    a.up_lo = lo; a.up_h = h; a.up_w = wl; a.up_H = H; a.up_W = W;
+    a.up_lo = lo; a.up_h = h; a.up_w = wl; a.up_H = H; a.up_W = W; a.up_n = N;
     a.up_ry = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
     a.up_rx = W > 1 ? (float)(wl - 1) / (float)(W - 1) : 0.f;
     hipStream_t st = (hipStream_t)stream;
