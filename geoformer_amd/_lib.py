@@ -65,6 +65,7 @@ SIGNATURES = {
                                     c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'gf_fine_layer': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_float, c_float, c_void_p]),
     'gf_conv3x3_supported': (c_int, [c_int, c_int]),
+    'gf_conv3x3s2_supported': (c_int, [c_int, c_int]),
     'gf_conv3x3_nhwc': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                 c_float, c_int, c_void_p]),
     'gf_linear': (c_int, [c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
@@ -108,7 +109,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 3          # include/geoformer_hip.h GF_ABI_VERSION
+ABI_VERSION = 4          # include/geoformer_hip.h GF_ABI_VERSION (4: the conv3x3 stream deals the output channels for the register epilogue)
 
 
 class GeoFormerHipError(RuntimeError):

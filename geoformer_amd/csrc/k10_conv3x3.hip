@@ -46,27 +46,33 @@ struct ConvArgs {
     const void* res;        // [N][H][W][COUT] or null
     void* out;              // [N][H][W][COUT]
     const void* zeros;      // >= 64 bytes of zeros (source of out-of-image pixels)
-    int N, H, W, act;
+    int N, H, W, act;       // H x W: the OUTPUT map (= the input map at stride 1)
     float slope;
     int tiles_x, tiles_y, ntiles;
+    int Hi, Wi;             // the input map (stride 2: H = (Hi - 1) / 2 + 1)
 };
 
-template <int NT, int NW, bool REM = false>
+template <int NT, int NW, bool REM = false, bool S2 = false>
 struct ConvGeo {
     // output widths up to 128 channels: a wave owns two 32-pixel rows (every weight fragment feeds two MFMAs, 2 x NT
     // accumulator tiles); wider outputs: one row per wave (the accumulators of two would not fit the register file).
     // NW = 4 waves (one per SIMD, 512 registers each) or 8 (two per SIMD, 256 each: one wave's issue gaps - DMA requests,
     // ring turns, the epilogue - are filled by the other's MFMAs).
     static constexpr int PB = NT <= 4 ? 2 : 1;
-    static constexpr int TH = NW * PB, PH = TH + 2;               // tile / halo-patch height
-    static constexpr int PIECES = (PH * PW + 15) / 16;            // DMA pieces of 16 pixels x 64 B
-    static constexpr int PATCH_BYTES = PIECES * 1024;
-    static constexpr int W10_OFF = 2 * PATCH_BYTES;                // two weight blocks behind the two patches
+    // S2 (stride 2, wide outputs only): the halo patch of a chunk is held as its four PARITY PLANES (rows / columns of equal parity
+    // relative to the patch origin: a tap reads ONE plane, at stride 1 - plane pixel (yl + ky / 2, xl + kx / 2) of plane (ky & 1, kx & 1));
+    // a plane = (TH + 1) x PW pixels; ONE set of planes (80 KB: no room for two), refilled plane by plane as the taps leave them
+    static constexpr int TH = NW * PB, PH = S2 ? TH + 1 : TH + 2;  // tile / halo-patch (plane) height
+    static constexpr int PIECES = (PH * PW + 15) / 16;            // DMA pieces of 16 pixels x 64 B (per patch; S2: per plane)
+    static constexpr int PLANE_BYTES = PIECES * 1024;
+    static constexpr int PATCH_BYTES = S2 ? 4 * PLANE_BYTES : PIECES * 1024;
+    static constexpr int W10_OFF = S2 ? PATCH_BYTES : 2 * PATCH_BYTES;   // two weight blocks behind the two patches (S2: the one set of planes)
+    static_assert(!S2 || PB == 1, "the stride-2 form is built for the wide outputs (one row per wave)");
     // a weight block = 6 sub-steps (a third of a chunk's 18); K10_BS=3 builds the short blocks of rounds 2-3 for the wide outputs
 #ifndef K10_BS
 #define K10_BS 6
 #endif
-    static constexpr int BLOCK_STEPS = (NW == 8 && PB == 1) ? K10_BS : 6;
+    static constexpr int BLOCK_STEPS = S2 ? 3 : (NW == 8 && PB == 1) ? K10_BS : 6;   // (S2: 80 KB of planes leave room for short blocks only)
     static constexpr int FR = BLOCK_STEPS * NT;                   // fragments per block
     static constexpr int WBLK = FR * C10_FRAG;
     static constexpr int SHIFT_OFF = W10_OFF + 2 * WBLK;
@@ -92,9 +98,9 @@ __device__ __forceinline__ void conv_lds_dma(const ConvRsrc& rs, char* dst, int 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs.r, (__attribute__((address_space(3))) void*)dst, 16, voffset, soffset, 0, 0);
 }
 // request weight block b of the stream into ring slot `slot`; the waves share its fragments round-robin
-template <int NT, int NW>
+template <int NT, int NW, bool S2 = false>
 __device__ __forceinline__ void conv_dma_block(const ConvRsrc& ws, char* smem, int b, int slot, int wave, int lane, int i0 = 0, int i1 = 1 << 20) {
-    using G = ConvGeo<NT, NW>;
+    using G = ConvGeo<NT, NW, false, S2>;
     asm volatile("" : "+v"(lane));      // (as in conv_dma_patch)
     char* dst = smem + G::W10_OFF + slot * G::WBLK;
     // the wave's pieces i0 .. i1 - 1 (the requests of a block are dealt to sub-steps; constant loop bounds: the range folds once the
@@ -115,16 +121,40 @@ __device__ __forceinline__ void conv_dma_patch(const ConvArgs& a, const ConvRsrc
                                         // live registers per piece, and a spilled one a vmcnt(0) reload between requests
     char* dst = smem + P_OFF + buf * G::PATCH_BYTES;
     // element offset of patch pixel (0, 0), channel 32 c (may be negative; 32-bit: the entry point bounds the tensor)
-    const int sbase = ((n * a.H + y0 - 1) * a.W + x0 - 1) * CIN + 32 * c;
+    const int sbase = ((n * a.Hi + y0 - 1) * a.Wi + x0 - 1) * CIN + 32 * c;
 #pragma unroll
     for (int i = 0; i < (G::PIECES + NW - 1) / NW; ++i) {
         const int piece = wave + NW * i;
         if (i >= i0 && i < i1 && piece < G::PIECES) {
             const int q = piece * 16 + (lane >> 2), slot = (lane & 3) ^ ((q >> 1) & 3);
             const int pr = q / PW, pc = q - pr * PW;
-            const bool in = (unsigned)(y0 - 1 + pr) < (unsigned)a.H && (unsigned)(x0 - 1 + pc) < (unsigned)a.W && q < G::PH * PW;
-            const int off = sbase + (pr * a.W + pc) * CIN + 8 * slot;
+            const bool in = (unsigned)(y0 - 1 + pr) < (unsigned)a.Hi && (unsigned)(x0 - 1 + pc) < (unsigned)a.Wi && q < G::PH * PW;
+            const int off = sbase + (pr * a.Wi + pc) * CIN + 8 * slot;
             conv_lds_dma(xs, dst + piece * 1024, in ? off * (int)sizeof(T) : 0x7FFFFFF0, 0);                // outside the image: out of range -> zeros
+        }
+    }
+}
+
+// stride 2: request parity plane `plane` = (row parity, column parity) of the halo patch of (tile at OUTPUT pixel (y0, x0), channel chunk c):
+// plane pixel (pr, pc) = input pixel (2 (y0 + pr) - 1 + plane / 2, 2 (x0 + pc) - 1 + plane % 2); pieces of 16 plane pixels x 64 B
+template <typename T, int CIN, int NT, int NW>
+__device__ __forceinline__ void conv_dma_plane(const ConvArgs& a, const ConvRsrc& xs, char* smem, int plane, int n, int y0, int x0, int c, int wave,
+                                               int lane) {
+    using G = ConvGeo<NT, NW, false, true>;
+    asm volatile("" : "+v"(lane));
+    char* dst = smem + P_OFF + plane * G::PLANE_BYTES;
+    const int py = plane >> 1, px = plane & 1;
+    const int iy0 = 2 * y0 - 1 + py, ix0 = 2 * x0 - 1 + px;
+    const int sbase = ((n * a.Hi + iy0) * a.Wi + ix0) * CIN + 32 * c;
+#pragma unroll
+    for (int i = 0; i < (G::PIECES + NW - 1) / NW; ++i) {
+        const int piece = wave + NW * i;
+        if (piece < G::PIECES) {
+            const int q = piece * 16 + (lane >> 2), slot = (lane & 3) ^ ((q >> 1) & 3);
+            const int pr = q / PW, pc = q - pr * PW;
+            const bool in = (unsigned)(iy0 + 2 * pr) < (unsigned)a.Hi && (unsigned)(ix0 + 2 * pc) < (unsigned)a.Wi && q < G::PH * PW;
+            const int off = sbase + 2 * (pr * a.Wi + pc) * CIN + 8 * slot;
+            conv_lds_dma(xs, dst + piece * 1024, in ? off * (int)sizeof(T) : 0x7FFFFFF0, 0);
         }
     }
 }
@@ -135,15 +165,15 @@ __device__ __forceinline__ void conv_dma_patch_rem(const ConvArgs& a, const Conv
     using G = ConvGeo<NT, NW, true>;
     asm volatile("" : "+v"(lane));
     char* dst = smem + G::R_OFF;
-    const int sbase = ((n * a.H + y0 - 1) * a.W + x0 - 1) * CIN + 192;
+    const int sbase = ((n * a.Hi + y0 - 1) * a.Wi + x0 - 1) * CIN + 192;
 #pragma unroll
     for (int i = 0; i < (G::RPIECES + NW - 1) / NW; ++i) {
         const int piece = wave + NW * i;
         if (piece < G::RPIECES) {
             const int q = piece * 64 + lane;
             const int pr = q / PW, pc = q - pr * PW;
-            const bool in = (unsigned)(y0 - 1 + pr) < (unsigned)a.H && (unsigned)(x0 - 1 + pc) < (unsigned)a.W && q < G::PH * PW;
-            const int off = sbase + (pr * a.W + pc) * CIN;
+            const bool in = (unsigned)(y0 - 1 + pr) < (unsigned)a.Hi && (unsigned)(x0 - 1 + pc) < (unsigned)a.Wi && q < G::PH * PW;
+            const int off = sbase + (pr * a.Wi + pc) * CIN;
             conv_lds_dma(xs, dst + piece * 1024, in ? off * (int)sizeof(T) : 0x7FFFFFF0, 0);
         }
     }
@@ -176,11 +206,16 @@ __device__ long long k10_trace2[256 * 8 * 32];
 // matrix cores): six full chunks, then channels 192 .. 199 as a REMAINDER chunk whose 9 taps x 8 channels fill three 32-deep k-steps
 // (lane k group g4 of k-step s reads tap 4 s + g4 of its pixel: 16 bytes) - 6 sub-steps instead of the 18 of a seventh chunk, i.e. 114
 // instead of 126 sub-steps per tile
-template <typename T, int CIN, int COUT, int NW, bool PADL, bool REM = false>
+// S2 (act | GF_CONV_S2): stride 2 (the first convolution of layer2 / layer3: resnet_fpn.py:14-17 with stride 2).  Same sub-steps, ring and
+// epilogue; the weight stream lists the taps plane by plane ((0,0) (0,2) (2,0) (2,2) | (0,1) (2,1) | (1,0) (1,2) | (1,1)), a chunk's patch is
+// its four parity planes (ConvGeo), and plane p of the NEXT chunk is requested at the turn that follows the last tap of plane p
+// (turns 8, 11, 14, 17 of a chunk's 18 sub-steps): one set of planes does what two patch buffers do at stride 1
+template <typename T, int CIN, int COUT, int NW, bool PADL, bool REM = false, bool S2 = false>
 __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
     using Mm = Mma16<T>;
     using Frag = typename Mm::Frag;
-    using G = ConvGeo<COUT / 32, NW, REM>;
+    using G = ConvGeo<COUT / 32, NW, REM, S2>;
+    static_assert(!(S2 && REM), "no remainder form at stride 2");
     using V4 = gf_vec<T, 4>;
     using V8 = gf_vec<T, 8>;
     static_assert(!REM || CIN == 224, "the remainder form is built for 224-channel inputs");
@@ -193,7 +228,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
     // first WS, patch pieces to the other BS - WS, waves 0-3 in front of a sub-step's MFMAs, waves 4-7 behind them: a piece costs its
     // wave 180-300 cycles of issue wherever it stands, and requested later it lands later - an L2 hit takes 2 thousand cycles, a
     // patch piece from HBM 3.2 thousand, against the 4.2 thousand of a block: the turns waited 400-600 cycles on vmcnt, +4 % per tile)
-    constexpr int WP = (G::FR + NW - 1) / NW, PP = (G::PIECES + NW - 1) / NW, PPMIN = G::PIECES / NW;
+    constexpr int WP = (G::FR + NW - 1) / NW, PP = (G::PIECES + NW - 1) / NW, PPMIN = G::PIECES / NW;    // (S2: PIECES = a plane's)
 #ifndef K10_DEAL
 #define K10_DEAL 0
 #endif
@@ -205,7 +240,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lp = lane & 15, g4 = lane >> 4;                       // MFMA 16x16x32: row / column of the lane, its k group
     const ConvRsrc ws = conv_rsrc(a.wstream, (unsigned)NBLK * G::WBLK);
-    const ConvRsrc xs = conv_rsrc(a.x, (unsigned)a.N * a.H * a.W * CIN * (unsigned)sizeof(T));
+    const ConvRsrc xs = conv_rsrc(a.x, (unsigned)a.N * a.Hi * a.Wi * CIN * (unsigned)sizeof(T));
     const ConvRsrc rres = conv_rsrc(a.res, (unsigned)a.N * a.H * a.W * COUT * (unsigned)sizeof(T));
     const ConvRsrc rout = conv_rsrc(a.out, (unsigned)a.N * a.H * a.W * COUT * (unsigned)sizeof(T));
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -235,8 +270,10 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
             if (!(PADL && second_half && t == NT - 1)) f[t] = *reinterpret_cast<const Frag*>(p + t * C10_FRAG);
     };
     auto load_x = [&](Frag (&f)[2 * PB], int buf, int tap) {       // pixel fragments of `tap` of the chunk in `buf`
-        const int ky = tap / 3, kx = tap - 3 * ky;
-        const char* p = smem + P_OFF + buf * G::PATCH_BYTES;
+        // stride 2: tap index -> (plane, row / column offset inside the plane) in the stream's plane-by-plane order
+        constexpr int s2_plane[9] = {0, 0, 0, 0, 1, 1, 2, 2, 3}, s2_dy[9] = {0, 0, 1, 1, 0, 1, 0, 0, 0}, s2_dx[9] = {0, 1, 0, 1, 0, 0, 0, 1, 0};
+        const int ky = S2 ? s2_dy[tap] : tap / 3, kx = S2 ? s2_dx[tap] : tap - 3 * (tap / 3);
+        const char* p = smem + P_OFF + (S2 ? s2_plane[tap] * G::PLANE_BYTES : buf * G::PATCH_BYTES);
         int xq = xq0;
         asm volatile("" : "+v"(xq));        // the 36 fragment offsets of a chunk are recomputed (4 VALU each), not kept in registers
 #pragma unroll
@@ -272,9 +309,14 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
     if (tile0 < xend) {
         int n, y0, x0;
         decode(tile0, n, y0, x0);
-        conv_dma_patch<T, CIN, NT, NW>(a, xs, smem, 0, n, y0, x0, 0, wave, lane);
-        conv_dma_block<NT, NW>(ws, smem, 0, 0, wave, lane);
-        conv_dma_block<NT, NW>(ws, smem, 1, 1, wave, lane);
+        if constexpr (S2) {
+#pragma unroll
+            for (int pl = 0; pl < 4; ++pl) conv_dma_plane<T, CIN, NT, NW>(a, xs, smem, pl, n, y0, x0, 0, wave, lane);
+        } else {
+            conv_dma_patch<T, CIN, NT, NW>(a, xs, smem, 0, n, y0, x0, 0, wave, lane);
+        }
+        conv_dma_block<NT, NW, S2>(ws, smem, 0, 0, wave, lane);
+        conv_dma_block<NT, NW, S2>(ws, smem, 1, 1, wave, lane);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -325,15 +367,20 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
                 // the DMA requests behind a turn: the weight pieces of the block after the landed one, then (a full chunk's first turn)
                 // the pieces of the next patch - in this order: the chunk's second turn waits for the weights only
                 auto dma_slot = [&]() {
-                    if (ts == NTS - 1 && tile_ends) return;                     // (issued whole at the turn)
-                    if (kslot < WS) {
+                    if (kslot < WS && !(ts == NTS - 1 && tile_ends)) {            // (a tile's last turn: issued whole at the turn)
                         if (ts >= BS - 1 || R || c > 0) {                        // (a tile's first sub-steps: nothing is pending)
                             const int nb = blk0 + (ts + 1) / BS + 1;             // = block being finished + 2 at the turn, current block + 1 behind it
-                            if (nb < NBLK) conv_dma_block<NT, NW>(ws, smem, nb, wslot ^ 1, wave, lane, wbeg(kslot), wbeg(kslot + 1));
-                            else if (has_next) conv_dma_block<NT, NW>(ws, smem, nb - NBLK, wslot ^ 1, wave, lane, wbeg(kslot), wbeg(kslot + 1));
+                            if (nb < NBLK) conv_dma_block<NT, NW, S2>(ws, smem, nb, wslot ^ 1, wave, lane, wbeg(kslot), wbeg(kslot + 1));
+                            else if (has_next) conv_dma_block<NT, NW, S2>(ws, smem, nb - NBLK, wslot ^ 1, wave, lane, wbeg(kslot), wbeg(kslot + 1));
                         }
                     }
-                    if (!R && ts >= BS - 1 + PS0 && ts < BS - 1 + PS0 + PS) {
+                    if constexpr (S2) {
+                        // plane (ts - 8) / 3 of the next chunk: its last tap's fragments are in registers, every wave is past the barrier
+                        if (kslot == 0 && ts >= 8) {
+                            if (c + 1 < NCH) conv_dma_plane<T, CIN, NT, NW>(a, xs, smem, (ts - 8) / 3, n, y0, x0, c + 1, wave, lane);
+                            else if (has_next) conv_dma_plane<T, CIN, NT, NW>(a, xs, smem, (ts - 8) / 3, n2, y2, x2, 0, wave, lane);
+                        }
+                    } else if (!R && ts >= BS - 1 + PS0 && ts < BS - 1 + PS0 + PS) {
                         // behind the first turn of a full chunk every wave is past the previous chunk: its patch buffer is free
                         const int kp = ts - (BS - 1 + PS0);
                         if (c + 1 < NCH) conv_dma_patch<T, CIN, NT, NW>(a, xs, smem, pbuf ^ 1, n, y0, x0, c + 1, wave, lane, pbeg(kp), pbeg(kp + 1));
@@ -354,7 +401,10 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
                     const bool first_turn = !R && ts == BS - 1 && c == 0;
                     if (first_turn) K10_T(12);
                     if (first_turn && it > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
-                    else if (!R && ts == 2 * BS - 1 && patch_req) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPMIN) : "memory");
+                    else if (!S2 && !R && ts == 2 * BS - 1 && patch_req) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPMIN) : "memory");
+                    // (S2: behind a turn that requested a plane - weights first, then the plane - the plane's pieces stay in flight; it is
+                    // needed nine sub-steps after its request at the earliest, and two turns later all of it has landed)
+                    else if (S2 && ((ts >= 11 && patch_req) || (ts == BS - 1 && c > 0))) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPMIN) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (first_turn) K10_T(13);
                     if constexpr (!R) K10_T2(20 + ts / BS);
@@ -366,7 +416,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
                         // last turn of a tile: the whole request at once (dealt to the next tile's first sub-steps its pieces would
                         // queue behind the epilogue's stores, and the next first turn would have to wait for those)
                         const int nb = blk0 + ts / BS + 2;
-                        if (has_next) conv_dma_block<NT, NW>(ws, smem, nb - NBLK, wslot ^ 1, wave, lane);
+                        if (has_next) conv_dma_block<NT, NW, S2>(ws, smem, nb - NBLK, wslot ^ 1, wave, lane);
                     }
                     if (!DEAL) {
                         dma_slot();
@@ -572,30 +622,36 @@ extern "C" int gf_debug_k10_trace2(long long* out) {
 namespace {
 #endif
 
-template <typename T, int CIN, int COUT, int NW, bool PADL, bool REM = false>
+template <typename T, int CIN, int COUT, int NW, bool PADL, bool REM = false, bool S2 = false>
 int conv_launch(ConvArgs a, hipStream_t st) {
-    using G = ConvGeo<COUT / 32, NW, REM>;
+    using G = ConvGeo<COUT / 32, NW, REM, S2>;
     static std::atomic<uint64_t> attr{0};
     if (gf_first_use_on_device(attr))
-        (void)hipFuncSetAttribute((const void*)conv3x3_kernel<T, CIN, COUT, NW, PADL, REM>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        (void)hipFuncSetAttribute((const void*)conv3x3_kernel<T, CIN, COUT, NW, PADL, REM, S2>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + G::TH - 1) / G::TH;
     const long nt = (long)a.N * a.tiles_x * a.tiles_y;
     if (nt >= (1l << 31)) return -2;
     a.ntiles = (int)nt;
-    conv3x3_kernel<T, CIN, COUT, NW, PADL, REM><<<a.ntiles < 256 ? a.ntiles : 256, NW * 64, G::LDS, st>>>(a);
+    conv3x3_kernel<T, CIN, COUT, NW, PADL, REM, S2><<<a.ntiles < 256 ? a.ntiles : 256, NW * 64, G::LDS, st>>>(a);
     return 0;
 }
 
 // 8 waves per workgroup: measured 1.1-1.3x faster than 4 at every shape (tools/k10_time.py); the 4-wave form stays
 // instantiable (conv_launch<..., 4>) for experiments
-template <typename T, int CIN, int COUT, bool PADL = false, bool REM = false>
+template <typename T, int CIN, int COUT, bool PADL = false, bool REM = false, bool S2 = false>
 int conv_launch_w(const ConvArgs& a, hipStream_t st) {
-    return conv_launch<T, CIN, COUT, 8, PADL, REM>(a, st);
+    return conv_launch<T, CIN, COUT, 8, PADL, REM, S2>(a, st);
 }
 
 template <typename T>
-int conv_dispatch(const ConvArgs& a, int cin, int cout, bool padl, bool rem, hipStream_t st) {
+int conv_dispatch(const ConvArgs& a, int cin, int cout, bool padl, bool rem, bool s2, hipStream_t st) {
+    if (s2) {                                            // the stride-2 convolutions of the (128, 196 -> 224, 256) pyramid
+        if (cin == 128 && cout == 224 && padl) return conv_launch_w<T, 128, 224, true, false, true>(a, st);
+        if (cin == 128 && cout == 224) return conv_launch_w<T, 128, 224, false, false, true>(a, st);
+        if (cin == 224 && cout == 256) return conv_launch_w<T, 224, 256, false, false, true>(a, st);
+        return -1;
+    }
     if (rem) {                                           // the 196-channel level as input: 6 chunks + the 8-channel remainder
         if (cin == 224 && cout == 224 && padl) return conv_launch_w<T, 224, 224, true, true>(a, st);
         if (cin == 224 && cout == 128 && !padl) return conv_launch_w<T, 224, 128, false, true>(a, st);
@@ -613,6 +669,9 @@ int conv_dispatch(const ConvArgs& a, int cin, int cout, bool padl, bool rem, hip
 
 }   // namespace
 
+// 1 if gf_conv3x3_nhwc has a stride-2 kernel (act | GF_CONV_S2) for these channel counts
+extern "C" int gf_conv3x3s2_supported(int cin, int cout) { return (cin == 128 && cout == 224) || (cin == 224 && cout == 256); }
+
 // 1 if gf_conv3x3_nhwc has a kernel for these channel counts
 extern "C" int gf_conv3x3_supported(int cin, int cout) {
     return (cin == 128 && cout == 128) || (cin == 224 && (cout == 224 || cout == 128)) || (cin == 256 && (cout == 256 || cout == 224));
@@ -626,24 +685,28 @@ extern "C" int gf_conv3x3_nhwc(const void* x, const void* wstream, const float* 
     GF_CHECK_ARG(x && wstream && out && zeros, "null pointer");
     GF_CHECK_ARG(N > 0 && H > 0 && W > 0, "empty problem");
     GF_CHECK_ARG(dtype == GF_F16 || dtype == GF_BF16, "built for 16-bit maps");
-    GF_CHECK_ARG(gf_conv3x3_supported(cin, cout), "no kernel for these channel counts (see gf_conv3x3_supported)");
-    const bool padl = (act & GF_CONV_PAD16) != 0;     // the last 16 output channels are padding (zero weights): not multiplied
+    const bool padl = (act & GF_CONV_PAD16) != 0;     // the output channels 196.. are padding (zero weights): their own tile is not multiplied
     const bool rem = (act & GF_CONV_REM8) != 0;        // the input channels 200.. carry zero weights; wstream is the rem8 packing
-    act &= ~(GF_CONV_PAD16 | GF_CONV_REM8);
-    GF_CHECK_ARG(!rem || (cin == 224 && ((cout == 224 && padl) || (cout == 128 && !padl))),
-                 "GF_CONV_REM8 is built for Cin = 224 with Cout = 224 | GF_CONV_PAD16 or Cout = 128");
+    const bool s2 = (act & GF_CONV_S2) != 0;           // stride 2: H x W is the INPUT map, out / residual are [N][(H-1)/2+1][(W-1)/2+1][cout]
+    act &= ~(GF_CONV_PAD16 | GF_CONV_REM8 | GF_CONV_S2);
+    GF_CHECK_ARG(s2 ? gf_conv3x3s2_supported(cin, cout) : gf_conv3x3_supported(cin, cout),
+                 "no kernel for these channel counts (see gf_conv3x3_supported / gf_conv3x3s2_supported)");
+    GF_CHECK_ARG(!rem || (!s2 && cin == 224 && ((cout == 224 && padl) || (cout == 128 && !padl))),
+                 "GF_CONV_REM8 is built for stride 1, Cin = 224 with Cout = 224 | GF_CONV_PAD16 or Cout = 128");
+    GF_CHECK_ARG(!padl || cout == 224, "GF_CONV_PAD16 belongs to 224-wide outputs");
     GF_CHECK_ARG(act >= C10_NONE && act <= C10_LEAKY, "unknown activation");
     GF_CHECK_ARG(act != C10_LEAKY || (slope >= 0.f && slope <= 1.f), "LeakyReLU slope must lie in [0, 1]");
     GF_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)residual % 16 == 0 && (uintptr_t)wstream % 16 == 0 &&
                      (uintptr_t)zeros % 16 == 0, "tensors must be 16-byte aligned");
     GF_CHECK_ARG((long)N * H * W * (cin > cout ? cin : cout) * 2 < 0x7FFFFFF0l, "maps of 2 GiB or more are not supported (32-bit buffer offsets)");
-    ConvArgs a{x, wstream, shift, residual, out, zeros, N, H, W, act, slope, 0, 0, 0};
+    const int Ho = s2 ? (H - 1) / 2 + 1 : H, Wo = s2 ? (W - 1) / 2 + 1 : W;
+    ConvArgs a{x, wstream, shift, residual, out, zeros, N, Ho, Wo, act, slope, 0, 0, 0, H, W};
     hipStream_t st = (hipStream_t)stream;
     // declared work = the reference's convolution: a 224-wide operand is the zero-padded form of the backbone's 196-channel maps
     // (resnet_fpn.py block_dims (128, 196, 256); model/backbone.py pads them for the matrix cores) and the padding is not work
     const double cin_w = cin == 224 ? 196.0 : cin, cout_w = cout == 224 ? 196.0 : cout;
-    void* pt = gf_prof_begin("conv3x3", st, 2.0 * N * (double)H * W * cin_w * cout_w * 9.0);
-    const int rc = dtype == GF_F16 ? conv_dispatch<_Float16>(a, cin, cout, padl, rem, st) : conv_dispatch<gf_bf16>(a, cin, cout, padl, rem, st);
+    void* pt = gf_prof_begin("conv3x3", st, 2.0 * N * (double)Ho * Wo * cin_w * cout_w * 9.0);
+    const int rc = dtype == GF_F16 ? conv_dispatch<_Float16>(a, cin, cout, padl, rem, s2, st) : conv_dispatch<gf_bf16>(a, cin, cout, padl, rem, s2, st);
     gf_prof_end("conv3x3", pt, st);
     GF_CHECK_ARG(rc == 0, "dispatch failed");
     GF_CHECK_LAUNCH();

@@ -285,6 +285,11 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void linear_kernel(Lin
                 const int cg = n0 + hb * 128 + pch * 8;
                 const bool cok = cg < a.N;
                 const T* lo = (const T*)a.up_lo + (cok ? cg : 0);
+#ifdef K3_EXP_NOGATHER     // ablation: the four tap rows are one row (L1 hits)
+#define K3_TAP(p) (*reinterpret_cast<const V8*>(lp))
+#else
+#define K3_TAP(p) (*reinterpret_cast<const V8*>(p))
+#endif
 #ifndef K3_UPADD_BATCH
 #define K3_UPADD_BATCH 4
 #endif
@@ -320,10 +325,10 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void linear_kernel(Lin
                     wgt[ib][0] = fy - y0;
                     wgt[ib][1] = fx - x0;
                     const T* lp = lo + (size_t)pn * a.up_h * a.up_w * a.N;
-                    tap[ib][0] = *reinterpret_cast<const V8*>(lp + ((size_t)y0 * a.up_w + x0) * a.N);
-                    tap[ib][1] = *reinterpret_cast<const V8*>(lp + ((size_t)y0 * a.up_w + x1) * a.N);
-                    tap[ib][2] = *reinterpret_cast<const V8*>(lp + ((size_t)y1 * a.up_w + x0) * a.N);
-                    tap[ib][3] = *reinterpret_cast<const V8*>(lp + ((size_t)y1 * a.up_w + x1) * a.N);
+                    tap[ib][0] = K3_TAP(lp + ((size_t)y0 * a.up_w + x0) * a.N);
+                    tap[ib][1] = K3_TAP(lp + ((size_t)y0 * a.up_w + x1) * a.N);
+                    tap[ib][2] = K3_TAP(lp + ((size_t)y1 * a.up_w + x0) * a.N);
+                    tap[ib][3] = K3_TAP(lp + ((size_t)y1 * a.up_w + x1) * a.N);
                 }
 #pragma unroll
                 for (int ib = 0; ib < UB; ++ib) {

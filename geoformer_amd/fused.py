@@ -194,7 +194,7 @@ def fine_layer(x, src, wstream, ln_params, eps1, eps2, attn_eps=1e-6, out=None):
 _ZEROS = {}
 
 
-def pack_conv3x3_stream(w, rem8=False):
+def pack_conv3x3_stream(w, rem8=False, s2=False):
     """w [Cout, Cin, 3, 3] (BatchNorm already folded, 16-bit) -> the fragment stream of gf_conv3x3_nhwc: for each 32-channel
     input chunk c, tap t = 3 ky + kx and half hf of the output channels, Cout/32 fragments of the 16x16x32 MFMA's A operand:
     fragment tt = accumulator tile ct = hf Cout/32 + tt, lane l -> row l % 16, input channels 32 c + 8 (l / 16) .. + 7; row r of
@@ -204,7 +204,9 @@ def pack_conv3x3_stream(w, rem8=False):
     rem8 (Cin = 224 whose channels 200.. carry zero weights - the 196-channel pyramid level): six full chunks (channels 0 .. 191)
     and a REMAINDER of channels 192 .. 199 whose 9 taps x 8 channels = 72 contraction elements fill three 32-deep MFMA k-steps
     (lane k group kg of k-step s = tap 4 s + kg, taps 9 .. 11 zero) instead of the nine k-steps of a seventh chunk: 6 sub-steps
-    (k-step s, half hf) of Cout/32 fragments behind the full chunks' (GF_CONV_REM8)."""
+    (k-step s, half hf) of Cout/32 fragments behind the full chunks' (GF_CONV_REM8).
+    s2 (GF_CONV_S2, stride 2): the taps of a chunk are listed parity plane by parity plane - (ky, kx) = (0,0) (0,2) (2,0) (2,2) |
+    (0,1) (2,1) | (1,0) (1,2) | (1,1) - the order in which the kernel walks (and refills) the four planes of its halo patch."""
     cout, cin = w.shape[:2]
     nt = cout // 32
     dev = w.device
@@ -218,6 +220,10 @@ def pack_conv3x3_stream(w, rem8=False):
     if rem8 and (cin != 224 or bool(w[:, 200:].any())):
         raise ValueError('rem8 packs a 224-channel convolution whose input channels 200.. have zero weights')
     wt = w[:, :full].reshape(cout, full // 32, 32, 9)                                # [cout, chunk, k, tap]
+    if s2:
+        if rem8:
+            raise ValueError('no remainder form at stride 2')
+        wt = wt[..., torch.tensor([0, 2, 6, 8, 1, 7, 3, 5, 4], device=dev)]
     g = wt[co[:, :, :, None], :, kk[None, None, :, :], :]                            # [2, nt, 64, 8, chunk, tap]
     out = g.permute(4, 5, 0, 1, 2, 3).contiguous().reshape(-1)
     if not rem8:
@@ -237,17 +243,26 @@ def conv3x3_supported(cin, cout):
 
 CONV_PAD16 = 0x100          # GF_CONV_PAD16 (include/geoformer_hip.h)
 CONV_REM8 = 0x200           # GF_CONV_REM8
+CONV_S2 = 0x400             # GF_CONV_S2
 
 
-def conv3x3(x, wstream, cout, shift=None, residual=None, act=0, slope=0.01, pad16=False, rem8=False):
+def conv3x3s2_supported(cin, cout):
+    return bool(_lib.lib().gf_conv3x3s2_supported(int(cin), int(cout)))
+
+
+def conv3x3(x, wstream, cout, shift=None, residual=None, act=0, slope=0.01, pad16=False, rem8=False, stride=1):
     """x channels_last [N, Cin, H, W] (16-bit) -> channels_last [N, cout, H, W] = act(conv3x3(x) + shift + residual).
     pad16 (cout = 224): the output channels 196 .. 223 are zero padding (zero weights): the all-padding accumulator tile is skipped.
-    rem8: wstream = pack_conv3x3_stream(w, rem8=True) (Cin = 224, input channels 200.. have zero weights: not multiplied)."""
+    rem8: wstream = pack_conv3x3_stream(w, rem8=True) (Cin = 224, input channels 200.. have zero weights: not multiplied).
+    stride 2: wstream = pack_conv3x3_stream(w, s2=True); the result is [N, cout, (H-1)//2+1, (W-1)//2+1]."""
     _need_cuda(x, wstream)
     if x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last):
         raise ValueError('conv3x3 expects a channels_last [N, C, H, W] tensor')
     N, cin, H, W = x.shape
-    out = torch.empty(N, cout, H, W, dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    if stride not in (1, 2):
+        raise ValueError('stride 1 or 2')
+    Ho, Wo = ((H - 1) // 2 + 1, (W - 1) // 2 + 1) if stride == 2 else (H, W)
+    out = torch.empty(N, cout, Ho, Wo, dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     if residual is not None and (residual.shape != out.shape or residual.dtype != x.dtype or
                                  not residual.is_contiguous(memory_format=torch.channels_last)):
         raise ValueError('residual must be a channels_last tensor of the output shape and dtype')
@@ -255,6 +270,6 @@ def conv3x3(x, wstream, cout, shift=None, residual=None, act=0, slope=0.01, pad1
     if z is None:
         z = _ZEROS[x.device] = torch.zeros(256, dtype=torch.uint8, device=x.device)
     check(_lib.lib().gf_conv3x3_nhwc(_p(x), _p(wstream), _p(shift), _p(residual), _p(out), _p(z), N, H, W, cin, cout,
-                                     int(act) | (CONV_PAD16 if pad16 else 0) | (CONV_REM8 if rem8 else 0),
+                                     int(act) | (CONV_PAD16 if pad16 else 0) | (CONV_REM8 if rem8 else 0) | (CONV_S2 if stride == 2 else 0),
                                      float(slope), _dt(x), _stream()), 'gf_conv3x3_nhwc')
     return out

@@ -93,11 +93,10 @@ def _fold(conv, bn, dtype, pad_multiple=1, pad_out=True):
 class FusedInferenceBackbone:
     """Inference form of ResNetFPN_8_2 for the 16-bit modes: BatchNorm folded into the
     preceding convolution, channels_last throughout.  The 3x3 / stride-1 convolutions (13 of the 17, >90 % of
-    the backbone's FLOPs) run on K10 (csrc/k10_conv3x3.hip) with the BN shift, the BasicBlock shortcut add and
-    ReLU / LeakyReLU in the kernel's epilogue; the three stride-2 convolutions, the 1x1 laterals and the
-    downsample shortcuts go through MIOpen (NHWC, called WITHOUT bias) with the glue kernels of
-    csrc/k_backbone_glue.hip in between (one read and one write per activation map); the stem is its own
-    kernel.  Same arithmetic as resnet_fpn.py:85-118 in eval mode up to fp16 rounding points."""
+    the backbone's FLOPs) and, since round 4, the two 3x3 / stride-2 ones (GF_CONV_S2) run on K10 (csrc/k10_conv3x3.hip) with the BN
+    shift, the BasicBlock shortcut add and ReLU / LeakyReLU in the kernel's epilogue; the 1x1 laterals and downsample shortcuts run on the
+    K3 tile engine, the stem is its own kernel: in the 16-bit modes no convolution of the (128, 196, 256) pyramid goes to MIOpen any more
+    (other widths, and the fp32 mode, still do: F.conv2d NHWC WITHOUT bias + the glue kernels of csrc/k_backbone_glue.hip).  Same arithmetic as resnet_fpn.py:85-118 in eval mode up to fp16 rounding points."""
 
     def __init__(self, bb: 'ResNetFPN_8_2', dtype, pad_multiple=32):
         self.dtype = dtype
@@ -111,6 +110,7 @@ class FusedInferenceBackbone:
         self.blocks = []
         self._pad16 = {}
         self._rem8 = {}
+        self._s2 = set()
         for layer in (bb.layer1, bb.layer2, bb.layer3):
             for blk in layer:
                 w1, b1 = _fold(blk.conv1, blk.bn1, dtype, pm)
@@ -143,10 +143,15 @@ class FusedInferenceBackbone:
         return y if y.is_contiguous(memory_format=torch.channels_last) else y.contiguous(memory_format=torch.channels_last)
 
     def _stream(self, w, stride=(1, 1)):
-        """K10 fragment stream of a 3x3 / stride-1 convolution whose widths gf_conv3x3_nhwc is built for (16-bit modes), else None
-        (the convolution then goes through MIOpen + the glue kernel)."""
-        if self.dtype == torch.float32 or tuple(w.shape[2:]) != (3, 3) or tuple(stride) != (1, 1):
+        """K10 fragment stream of a 3x3 convolution whose widths gf_conv3x3_nhwc is built for (16-bit modes; stride 1, or stride 2 =
+        GF_CONV_S2: the first convolution of layer2 / layer3), else None (the convolution then goes through MIOpen + the glue kernel)."""
+        if self.dtype == torch.float32 or tuple(w.shape[2:]) != (3, 3) or tuple(stride) not in ((1, 1), (2, 2)):
             return None
+        if tuple(stride) == (2, 2):
+            if not fused.conv3x3s2_supported(w.shape[1], w.shape[0]):
+                return None
+            self._s2.add(id(w))
+            return fused.pack_conv3x3_stream(w, s2=True)
         if not fused.conv3x3_supported(w.shape[1], w.shape[0]):
             return None
         # 196 real input channels in a 224-wide map (zero weights from channel 196 on): channels 192 .. 199 as the 8-channel remainder
@@ -162,7 +167,8 @@ class FusedInferenceBackbone:
             pad16 = self._pad16.get(id(w))
             if pad16 is None:             # 196 real channels in a 224-wide map: the output channels 196.. carry zero weights
                 pad16 = self._pad16[id(w)] = bool(w.shape[0] == 224 and not w[196:].any())
-            return fused.conv3x3(x, ws, w.shape[0], shift, shortcut, act, slope, pad16, self._rem8.get(id(w), False))
+            return fused.conv3x3(x, ws, w.shape[0], shift, shortcut, act, slope, pad16, self._rem8.get(id(w), False),
+                                 2 if id(w) in self._s2 else 1)
         y = self._conv(x, w, stride)
         if shift is None and shortcut is None and act == ops.ACT_NONE:
             return y

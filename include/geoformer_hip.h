@@ -35,7 +35,7 @@ typedef enum { GF_F32 = 0, GF_F16 = 1, GF_BF16 = 2 } gf_dtype;
  * arguments.  History: 1 = rounds 1-2; 2 = round 3 (gf_ransac_homography had gained `lm_iters` in the MIDDLE of its list: a
  * caller built against version 1 would have passed min_points as lm_iters); 3 = round 4: gf_ransac_homography is back to its
  * version-1 signature (no refinement), new arguments live in gf_ransac_homography_v2, appended at the END. */
-#define GF_ABI_VERSION 3
+#define GF_ABI_VERSION 4
 int gf_abi_version(void);
 const char* gf_last_error(void);
 
@@ -256,7 +256,13 @@ int gf_fine_layer(const void* x, const void* src, void* out, int dtype, int Nw, 
  *     remainder whose 9 taps x 8 channels fill three MFMA k-steps instead of a seventh chunk's nine - 114 instead of 126 sub-steps per
  *     tile, the result differs from the plain call only by the order of the fp32 sums. */
 #define GF_CONV_REM8 0x200
+/*   | GF_CONV_S2 (round 4; cin -> cout in gf_conv3x3s2_supported: 128 -> 224, 224 -> 256): STRIDE 2 - the first convolution of layer2 /
+ *     layer3 (resnet_fpn.py:14-17 with stride = 2).  H x W is then the INPUT map; out (and residual) are [N][(H-1)/2+1][(W-1)/2+1][cout];
+ *     wstream = fused.py:pack_conv3x3_stream(w, s2=True) (the taps listed parity plane by parity plane).  Replaces the last two
+ *     F.conv2d / MIOpen calls + gf_bias_act_nhwc of the 16-bit backbone. */
+#define GF_CONV_S2 0x400
 int gf_conv3x3_supported(int cin, int cout);
+int gf_conv3x3s2_supported(int cin, int cout);
 int gf_conv3x3_nhwc(const void* x, const void* wstream, const float* shift, const void* residual, void* out,
                     const void* zeros, int N, int H, int W, int cin, int cout, int act, float slope, int dtype,
                     void* stream);

@@ -769,6 +769,56 @@ def test_conv3x3_remainder_chunk(dtype, cout, hw, use_res):
         fused.pack_conv3x3_stream(torch.ones(cout, 224, 3, 3, device='cuda', dtype=dtype), rem8=True)
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('cin,cout,pad16', [(128, 224, True), (128, 224, False), (224, 256, False)])
+@pytest.mark.parametrize('hw', [(64, 128), (37, 70), (16, 33), (2, 3)])
+def test_conv3x3_stride2_vs_torch(dtype, cin, cout, pad16, hw):
+    """GF_CONV_S2 (the first convolution of layer2 / layer3, resnet_fpn.py:14-17 with stride 2) against torch's fp32 convolution of
+    the same 16-bit operands + shift + ReLU: even and odd input sizes (the last input row / column is then read by the last output
+    pixel's centre taps only), tiles that hang over the image on every side, several tiles per image (the parity planes of chunk c + 1
+    are requested while chunk c is multiplied: a stale plane would show as an error of the size of a term)."""
+    from geoformer_amd import fused, ops
+    torch.manual_seed(cin + hw[0])
+    N, (H, W) = 3, hw
+    x = torch.randn(N, cin, H, W, device='cuda').to(dtype).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, 3, 3, device='cuda') * (1.5 / (3 * cin ** 0.5))).to(dtype)
+    if pad16:
+        w[196:] = 0
+    shift = torch.randn(cout, device='cuda')
+    assert fused.conv3x3s2_supported(cin, cout)
+    ws = fused.pack_conv3x3_stream(w, s2=True)
+    out = fused.conv3x3(x, ws, cout, shift, None, ops.ACT_RELU, pad16=pad16, stride=2)
+    pre = torch.nn.functional.conv2d(x.float(), w.float(), None, 2, 1) + shift[None, :, None, None]
+    ref = torch.relu(pre)
+    assert out.shape == ref.shape and out.dtype == dtype and out.is_contiguous(memory_format=torch.channels_last)
+    ulp = 2.0 ** (-10 if dtype == torch.float16 else -7)
+    err = (out.float() - ref).abs()
+    assert float((err / torch.maximum(pre.abs(), ref.abs()).clamp_min(1.0)).max()) < 1.1 * ulp, float(err.max())
+    assert torch.equal(out, fused.conv3x3(x, ws, cout, shift, None, ops.ACT_RELU, pad16=pad16, stride=2))
+    if pad16:       # the skipped tile: same bits as the call that multiplies the zeros
+        assert torch.equal(out, fused.conv3x3(x, ws, cout, shift, None, ops.ACT_RELU, stride=2))
+
+
+@pytest.mark.parametrize('cin,cout,hw', [(128, 224, 320), (224, 256, 160)])
+def test_conv3x3_stride2_full_size_vs_library(cin, cout, hw):
+    """GF_CONV_S2 at the backbone's full sizes (16 images: 1600 / 480 tiles walked by 256 persistent workgroups - the planes of the NEXT
+    tile's first chunk are requested during the last chunk of this one) against the library convolution + shift + ReLU."""
+    from geoformer_amd import fused, ops
+    torch.manual_seed(hw + cin)
+    N = 16
+    x = torch.randn(N, cin, hw, hw, device='cuda', dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, 3, 3, device='cuda') * (1.5 / (3 * cin ** 0.5))).half()
+    shift = torch.randn(cout, device='cuda')
+    out = fused.conv3x3(x, fused.pack_conv3x3_stream(w, s2=True), cout, shift, None, ops.ACT_RELU, stride=2)
+    conv = torch.nn.functional.conv2d(x, w.contiguous(memory_format=torch.channels_last), None, 2, 1).float()
+    ref = torch.relu(conv + shift[None, :, None, None])
+    err = (out.float() - ref).abs()
+    assert out.shape == ref.shape
+    assert float(err.max()) < 2.5e-2 and float(err.mean()) < 6e-4, (float(err.max()), float(err.mean()))
+    assert bool(torch.isfinite(out).all())
+    assert torch.equal(out, fused.conv3x3(x, fused.pack_conv3x3_stream(w, s2=True), cout, shift, None, ops.ACT_RELU, stride=2))
+
+
 def test_conv3x3_rejects_unsupported():
     from geoformer_amd import fused, _lib
     assert not fused.conv3x3_supported(64, 64)

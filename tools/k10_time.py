@@ -59,3 +59,18 @@ for (N, CI, CO, H, W) in ((16, 224, 224, 160, 160), (16, 224, 128, 320, 320)):
     t_plain = timeit(lambda: fused.conv3x3(x, ws, CO, b, z, ops.ACT_RELU, pad16=pad16))
     t_rem = timeit(lambda: fused.conv3x3(x, wr, CO, b, z, ops.ACT_RELU, pad16=pad16, rem8=True))
     print(f'{N}x196(224)->{CO}x{H}x{W}: seven chunks {t_plain:.3f} ms | six chunks + remainder {t_rem:.3f} ms ({100 * (1 - t_rem / t_plain):.1f} % less)', flush=True)
+
+# stride 2 (GF_CONV_S2) against the library convolution + gf_bias_act
+for (N, CI, CO, H) in ((16, 128, 224, 320), (16, 224, 256, 160)):
+    x = torch.randn(N, CI, H, H, device='cuda', dtype=dt).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(CO, CI, 3, 3, device='cuda', dtype=dt) * 0.03)
+    pad16 = CO == 224
+    if pad16:
+        w[196:] = 0
+    wcl = w.contiguous(memory_format=torch.channels_last)
+    b = torch.randn(CO, device='cuda')
+    ws = fused.pack_conv3x3_stream(w, s2=True)
+    t_k = timeit(lambda: fused.conv3x3(x, ws, CO, b, None, ops.ACT_RELU, pad16=pad16, stride=2))
+    t_sep = timeit(lambda: ops.bias_act_(F.conv2d(x, wcl, None, 2, 1), b, None, ops.ACT_RELU))
+    fl = 2.0 * N * (H // 2) ** 2 * CI * CO * 9
+    print(f'stride 2 {N}x{CI}->{CO}x{H}x{H}: K10 {t_k:.3f} ms ({fl / t_k / 1e9:.0f} TFLOP/s) | MIOpen conv + bias_act {t_sep:.3f} ms', flush=True)
