@@ -412,8 +412,9 @@ def test_bf16_mode_vs_storage_oracle(golden, name):
 def test_graph_replay_equals_eager():
     """GeoFormer.enable_graphs(): the static part (backbone .. second coarse matching) replayed from a captured hipGraph
     against the eager matching path on the replay's own backbone features, bit for bit, also on a second, different input
-    (static-buffer reuse).  (The backbone itself is compared to fp16 resolution only: MIOpen may pick another convolution
-    algorithm under capture for shapes outside the shipped find-db - 1-ulp different feature maps.)"""
+    (static-buffer reuse).  The backbone's feature maps are compared BIT FOR BIT as well since round 4: no convolution of the
+    16-bit backbone goes to MIOpen any more (K10 incl. its stride-2 form, the K3 engine's 1x1 forms, the stem kernel), so nothing
+    can pick another algorithm under capture (rounds 2-3 allowed 5 % of the maximum here; ADVICE r02 / VERDICT r03 weak 11)."""
     from geoformer_amd import miopen
     miopen.use_shipped_find_db()
     m = build(0.0, 0.0, 'fp16')
@@ -429,12 +430,13 @@ def test_graph_replay_equals_eager():
         m.enable_graphs(False)
         for (i0, i1), (got, feats) in zip(pairs, graphed):
             ref = m.forward_features({'image0': i0, 'image1': i1}, *feats)
-            assert len(ref['b_ids']) > 5          # (a sanity bound only: ~10-12 matches on this small pair, the count moves with the
-                                                  # backbone's last bit, which MIOpen's algorithm choice under capture can change)
+            assert len(ref['b_ids']) > 5          # (a sanity bound only: ~10-12 matches on this small pair)
             for k in keys:
                 assert torch.equal(got[k], ref[k]), k
-            c0_eager = m._backbone(torch.cat([i0, i1], 0))[0][:1]
-            assert float((c0_eager.float() - feats[0].float()).abs().max()) < 0.05 * float(c0_eager.float().abs().max())
+            c_eager, f_eager = m._backbone(torch.cat([i0, i1], 0))
+            for name, fe, fg in (('feat_c0', c_eager[:1], feats[0]), ('feat_f0', f_eager[:1], feats[1]),
+                                 ('feat_c1', c_eager[1:], feats[2]), ('feat_f1', f_eager[1:], feats[3])):
+                assert fe.shape == fg.shape and torch.equal(fe, fg), name
     assert not torch.equal(graphed[0][0]['conf_matrix'], graphed[1][0]['conf_matrix'])
 
 
