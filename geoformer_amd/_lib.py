@@ -66,6 +66,8 @@ SIGNATURES = {
     'gf_fine_layer': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_float, c_float, c_void_p]),
     'gf_conv3x3_supported': (c_int, [c_int, c_int]),
     'gf_conv3x3s2_supported': (c_int, [c_int, c_int]),
+    'gf_lateral_supported': (c_int, [c_int, c_int]),
+    'gf_lateral_upsample_add_nhwc': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'gf_conv3x3_nhwc': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                 c_float, c_int, c_void_p]),
     'gf_linear': (c_int, [c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,

@@ -237,6 +237,41 @@ def pack_conv3x3_stream(w, rem8=False, s2=False):
     return torch.cat([out, r.contiguous().reshape(-1)])
 
 
+def pack_lateral_frags(w):
+    """w [Cout, Cin(,1,1)] (16-bit) -> the A fragments of gf_lateral_upsample_add_nhwc (K12): [Cin/32][Cout/16][64 lanes][8]: fragment
+    (kc, ct), lane l = row l % 16 of accumulator tile ct - output channel 32 (ct / 2) + 8 (row / 4) + 4 (ct % 2) + row % 4, the deal of
+    pack_conv3x3_stream - and input channels 32 kc + 8 (l / 16) .. + 7."""
+    w = w.reshape(w.shape[0], w.shape[1])
+    cout, cin = w.shape
+    dev = w.device
+    lane = torch.arange(64, device=dev)
+    row, kg = lane % 16, lane // 16
+    ct = torch.arange(cout // 16, device=dev)[:, None]
+    co = 32 * (ct // 2) + 4 * (ct % 2) + (8 * (row // 4) + row % 4)[None, :]                       # [nct, 64]
+    kk = 8 * kg[:, None] + torch.arange(8, device=dev)[None, :]                                      # [64, 8]
+    kc = torch.arange(cin // 32, device=dev)
+    return w[co[None, :, :, None], (32 * kc[:, None, None, None] + kk[None, None, :, :])].contiguous().reshape(-1)
+
+
+def lateral_supported(cin, cout):
+    return bool(_lib.lib().gf_lateral_supported(int(cin), int(cout)))
+
+
+def lateral_upsample_add(x, wfrag, cout, lo):
+    """K12: 1x1 convolution of channels_last x [N, Cin, H, W] (weights as pack_lateral_frags) + bilinear (align_corners=True) upsampling of
+    channels_last lo [N, cout, h, w] -> channels_last [N, cout, H, W]; W even."""
+    _need_cuda(x, wfrag, lo)
+    if x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last) or not lo.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError('lateral_upsample_add expects channels_last [N, C, H, W] tensors')
+    N, cin, H, W = x.shape
+    if lo.shape[:2] != (N, cout) or lo.dtype != x.dtype or wfrag.dtype != x.dtype:
+        raise ValueError('lo must be [N, cout, h, w] of the dtype of x and of the fragments')
+    out = torch.empty(N, cout, H, W, dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    check(_lib.lib().gf_lateral_upsample_add_nhwc(_p(x), _p(wfrag), _p(lo), _p(out), N, lo.shape[2], lo.shape[3], H, W, cin, cout,
+                                                  _dt(x), _stream()), 'gf_lateral_upsample_add_nhwc')
+    return out
+
+
 def conv3x3_supported(cin, cout):
     return bool(_lib.lib().gf_conv3x3_supported(int(cin), int(cout)))
 

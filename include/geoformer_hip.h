@@ -412,6 +412,14 @@ int gf_upsample_add_nhwc(const void* lo, const void* hi, void* out, int N, int h
  *                         convolution with the top-down merge as its epilogue (resnet_fpn.py:109-111); fp16, Cin % 64 == 0 */
 int gf_conv1x1_upsample_add_nhwc(const void* x, const void* w, const void* lo, void* out, int N, int h, int wl, int H,
                                  int W, int Cin, int Cout, int dtype, void* stream);
+
+/* K12 (round 4): the same operation as gf_conv1x1_upsample_add_nhwc for the 1/2-scale lateral (cin 128 -> cout 224: layer1_outconv +
+ * the merge with the upsampled 1/4-scale map, resnet_fpn.py:109-111) as a streaming kernel of its own - weights resident in LDS as MFMA
+ * fragments (wfrag = geoformer_amd/fused.py:pack_lateral_frags(w)), pixel rows by LDS-DMA, the merge's taps requested in front of the
+ * tile's MFMAs, 128-byte stores; W must be even.  gf_lateral_supported(cin, cout) names the built widths. */
+int gf_lateral_supported(int cin, int cout);
+int gf_lateral_upsample_add_nhwc(const void* x, const void* wfrag, const void* lo, void* out, int N, int h, int w, int H, int W,
+                                 int cin, int cout, int dtype, void* stream);
 /* 1x1 convolution of a channels-last 16-bit map, stride 1 or 2 (H, W even), no bias: out [N, H/s, W/s, Cout] = W x[n, s y, s x, :]
  * (resnet_fpn.py:23-27 the BasicBlock downsample shortcut conv1x1(stride 2), :69-71 layer3_outconv / layer2_outconv, with the
  * BatchNorm scale folded into w [Cout, Cin]); Cin, Cout multiples of 32. */

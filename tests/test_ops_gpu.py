@@ -860,6 +860,31 @@ def test_conv1x1_upsample_add_vs_torch():
     assert torch.allclose(out.float(), ref, atol=1e-2, rtol=4e-3), (out.float() - ref).abs().max().item()   # two fp16 roundings
 
 
+@pytest.mark.parametrize('dtype', [torch.float16])
+@pytest.mark.parametrize('N,hw', [(2, (30, 44)), (3, (7, 6)), (16, (320, 320)), (1, (1, 2))])
+def test_lateral_upsample_add_vs_torch(dtype, N, hw):
+    """K12 (gf_lateral_upsample_add_nhwc: layer1_outconv + the FPN merge, resnet_fpn.py:109-111) against torch fp32 on the same 16-bit
+    operands and against the K3 form it replaces: ragged last tile, single-row / two-pixel maps, the full 16 x 320 x 320 launch
+    (12800 tiles on 256 persistent workgroups whose waves run unsynchronised behind the prologue)."""
+    from geoformer_amd import fused, ops
+    torch.manual_seed(N + hw[0])
+    H, W = hw
+    h, w_ = max(1, H // 2), max(1, W // 2)
+    x = torch.randn(N, 128, H, W, device='cuda').to(dtype).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(224, 128, device='cuda') * 0.1).to(dtype)
+    lo = torch.randn(N, 224, h, w_, device='cuda').to(dtype).contiguous(memory_format=torch.channels_last)
+    assert fused.lateral_supported(128, 224)
+    out = fused.lateral_upsample_add(x, fused.pack_lateral_frags(w), 224, lo)
+    ref = torch.nn.functional.conv2d(x.float(), w.float()[:, :, None, None]) + torch.nn.functional.interpolate(
+        lo.float(), size=(H, W), mode='bilinear', align_corners=True)
+    assert out.shape == ref.shape and out.dtype == dtype and out.is_contiguous(memory_format=torch.channels_last)
+    tol = (1e-2, 4e-3) if dtype == torch.float16 else (8e-2, 3e-2)          # two roundings to the storage type
+    assert torch.allclose(out.float(), ref, atol=tol[0], rtol=tol[1]), (out.float() - ref).abs().max().item()
+    k3 = ops.conv1x1_upsample_add(x, w, lo)
+    assert float((out.float() - k3.float()).abs().max()) <= (2e-2 if dtype == torch.float16 else 0.13)      # other summation order: last bit
+    assert torch.equal(out, fused.lateral_upsample_add(x, fused.pack_lateral_frags(w), 224, lo))
+
+
 def test_conv1x1_upsample_add_ragged_k():
     """K = 224 (the 196-channel pyramid level padded to 7 x 32): not a multiple of the engine's 64-element K step - the last
     step's missing chunks are staged as zeros (layer2_outconv + FPN merge in one launch, resnet_fpn.py:108-110)."""

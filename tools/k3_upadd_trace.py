@@ -20,6 +20,24 @@ for (cin, cout, H, h) in ((128, 224, 320, 160), (224, 256, 160, 80)):
     ms = (time.perf_counter() - t0) / 20 * 1e3
     by = 16 * H * H * (cin + cout) * 2 + 16 * h * h * cout * 2
     print(f'{cin}->{cout} at {H}x{H}: {ms * 1e3:.0f} us, {by / ms / 1e6:.0f} GB/s algorithmic')
+    from geoformer_amd import fused
+    if hasattr(fused, 'lateral_supported') and fused.lateral_supported(cin, cout):
+        wf = fused.pack_lateral_frags(w)
+        for _ in range(3):
+            fused.lateral_upsample_add(x, wf, cout, lo)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            fused.lateral_upsample_add(x, wf, cout, lo)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 20 * 1e3
+        print(f'   K12 streaming form: {ms * 1e3:.0f} us, {by / ms / 1e6:.0f} GB/s algorithmic')
+        f12 = getattr(ctypes.CDLL(_lib.LIB_PATH), 'gf_debug_k12_trace', None)
+        if f12 is not None:
+            b12 = np.zeros(256 * 8 * 8, dtype=np.int64)
+            f12(b12.ctypes.data_as(ctypes.c_void_p))
+            t12 = b12.reshape(256, 8, 8)[:, :, :5]
+            print('   K12 cycles per wave over its 50 tiles: product / merge (waits for the taps) / requests / stores / drain, median', np.median(t12.reshape(-1, 5), axis=0).astype(int).tolist())
     if fn is not None:
         buf = np.zeros(1024 * 4 * 16, dtype=np.int64)
         fn(buf.ctypes.data_as(ctypes.c_void_p))
