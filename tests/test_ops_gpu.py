@@ -819,6 +819,38 @@ def test_conv3x3_stride2_full_size_vs_library(cin, cout, hw):
     assert torch.equal(out, fused.conv3x3(x, fused.pack_conv3x3_stream(w, s2=True), cout, shift, None, ops.ACT_RELU, stride=2))
 
 
+def test_conv3x3_stride2_and_lateral_random_shapes():
+    """Seeded random map sizes for the two kernels round 4 added to the backbone (K10's stride-2 form, K12): every size class of the
+    tile walk - maps smaller than a tile, tiles hanging over two sides, odd and even sizes, several tiles per workgroup - against torch
+    fp32 on the same fp16 operands."""
+    from geoformer_amd import fused, ops
+    rng = np.random.default_rng(2024)
+    F = torch.nn.functional
+    for case in range(14):
+        N, H, W = int(rng.integers(1, 5)), int(rng.integers(2, 90)), int(rng.integers(2, 90))
+        cin, cout = ((128, 224), (224, 256))[case % 2]
+        torch.manual_seed(case)
+        x = torch.randn(N, cin, H, W, device='cuda').half().contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(cout, cin, 3, 3, device='cuda') * (1.5 / (3 * cin ** 0.5))).half()
+        shift = torch.randn(cout, device='cuda')
+        out = fused.conv3x3(x, fused.pack_conv3x3_stream(w, s2=True), cout, shift, None, ops.ACT_RELU, stride=2)
+        pre = F.conv2d(x.float(), w.float(), None, 2, 1) + shift[None, :, None, None]
+        ref = torch.relu(pre)
+        assert out.shape == ref.shape, (case, N, H, W)
+        err = ((out.float() - ref).abs() / torch.maximum(pre.abs(), ref.abs()).clamp_min(1.0)).max()
+        assert float(err) < 1.1 * 2.0 ** -10, (case, N, H, W, float(err))
+    for case in range(10):
+        N, H, W = int(rng.integers(1, 4)), int(rng.integers(1, 70)), 2 * int(rng.integers(1, 40))
+        h, w_ = max(1, (H + 1) // 2), max(1, W // 2)
+        torch.manual_seed(100 + case)
+        x = torch.randn(N, 128, H, W, device='cuda').half().contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(224, 128, device='cuda') * 0.1).half()
+        lo = torch.randn(N, 224, h, w_, device='cuda').half().contiguous(memory_format=torch.channels_last)
+        out = fused.lateral_upsample_add(x, fused.pack_lateral_frags(w), 224, lo)
+        ref = F.conv2d(x.float(), w.float()[:, :, None, None]) + F.interpolate(lo.float(), size=(H, W), mode='bilinear', align_corners=True)
+        assert torch.allclose(out.float(), ref, atol=1e-2, rtol=4e-3), (case, N, H, W, (out.float() - ref).abs().max().item())
+
+
 def test_conv3x3_rejects_unsupported():
     from geoformer_amd import fused, _lib
     assert not fused.conv3x3_supported(64, 64)
