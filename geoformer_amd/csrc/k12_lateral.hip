@@ -18,8 +18,7 @@
 // issue path: per tile a wave issues 28 tap loads + 4 LDS-DMA pieces + 7 stores of 1 KB and spends 45 % of its cycles doing so (-DK12_TRACE=1:
 // product 32 %, merge 10 %, requests 45 %, stores 14 %) - 313 KB per tile pass the CU's texture path, 224 KB of them taps (with every tap
 // piece read from one address: 253 us; with the stores compiled out: 68 us; 734 MB of pure stores: 135 us, tools/probes/row448.hip).
-// Next: the two rows of the coarser map a tile needs staged in LDS once (59 KB instead of 224 KB of gathers) - it needs the weights out
-// of LDS or a smaller tile.
+// The STAGED form below (widths that are multiples of 16, scale factor 2: the FPN case) cuts the taps' share of that path: 326 us.
 #include <type_traits>
 
 #include "gf_common.h"
@@ -265,6 +264,198 @@ __global__ __launch_bounds__(L12_NW * 64) void lateral_kernel(LatArgs a) {
 #endif
 }
 
+// The STAGED form (W a multiple of 16 and exactly twice the coarser map's width: the FPN case): a wave's 16 pixels lie in one row, and
+// the taps of all of them come from TWO rows x TEN pixels of the coarser map - 8960 bytes, brought into a wave-private LDS area by ten
+// LDS-DMA pieces per tile instead of the 28 gathers of 1 KB the form above issues (the vector-memory issue path is what bounds it:
+// 39 -> 21 instructions per tile and wave); the merge reads its tap pieces from there (ds_read_b128).  LDS: weights 56 KB + 8 x (4 KB of
+// rows + 8960 B of the coarser map) = 158 KB - ONE buffer each: the rows of tile t + 1 are requested behind the product of tile t, its
+// piece of the coarser map behind the merge of tile t, both in front of tile t's stores (the memory counter retires in issue order).
+template <typename T, int CIN, int COUT>
+__global__ __launch_bounds__(L12_NW * 64) void lateral_staged_kernel(LatArgs a) {
+    using Mm = Mma16<T>;
+    using Frag = typename Mm::Frag;
+    using V8 = gf_vec<T, 8>;
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    constexpr int KC = CIN / 32, NCT = COUT / 16, NP = COUT / 32, NM = NP / 2;
+    constexpr bool LONE = (NP & 1) != 0;
+    constexpr int ROWB = COUT * (int)sizeof(T);                              // bytes of a pixel of the coarser map / of the output
+    constexpr int LOC = 10, LOROW = LOC * ROWB, LOP = (LOROW + 1023) / 1024;  // staged pixels per row, their bytes, DMA pieces per row
+    constexpr int W_BYTES = KC * NCT * 1024, XW = KC * 1024, WV = XW + 2 * LOROW;   // a wave's area: its rows, then two rows of the coarser map
+    constexpr int NST = 2 * NM + (LONE ? 1 : 0);                              // stores per tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lp = lane & 15, g4 = lane >> 4, odd = lane & 1;
+    const LatRsrc xs = lat_rsrc(a.x, (unsigned)a.P * CIN * (unsigned)sizeof(T));
+    const LatRsrc wsr = lat_rsrc(a.wfrag, (unsigned)W_BYTES);
+    const LatRsrc los = lat_rsrc(a.lo, (unsigned)a.N * a.h * a.w * COUT * (unsigned)sizeof(T));
+    const LatRsrc outs = lat_rsrc(a.out, (unsigned)a.P * COUT * (unsigned)sizeof(T));
+    const int nx8 = gridDim.x >= 8 ? 8 : 1;
+    const int xcd = nx8 == 8 ? (int)(blockIdx.x & 7) : 0, xslot = nx8 == 8 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int xper = nx8 == 8 ? (int)((gridDim.x + 7 - xcd) >> 3) : (int)gridDim.x;
+    const int tq = a.ntiles / nx8, tr = a.ntiles % nx8;
+    const int xbeg = xcd * tq + (xcd < tr ? xcd : tr), xend = xbeg + tq + (xcd < tr ? 1 : 0);
+    const int tile0 = xbeg + xslot;
+    if (tile0 >= xend) return;
+    char* const wv = smem + W_BYTES + wave * WV;                               // the wave's area
+
+    auto dma_x = [&](int t) {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        const int q = l >> 2, slot = (l & 3) ^ ((q >> 1) & 3);
+        const int off = ((t * L12_TP + wave * 16 + q) * CIN + 8 * slot) * (int)sizeof(T);
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) lat_lds_dma(xs, wv + kc * 1024, off, kc * 64);
+    };
+    // ---- per-tile state.  Wave-uniform: the row of the wave's 16 pixels (image n, row y), its two rows y0 / y1 of the coarser map and
+    // xl0, the first staged column.  Per lane: LDS offsets of the four taps of its A / B / lone pieces, their weights, the store offsets.
+    int toA[4], toB[4], toL[4];
+    float wA[4], wB[4], wL[4];
+    int sA = 0, sB = 0, sL = 0;
+    auto stage = [&](int tile) {
+        const int p0 = tile * L12_TP + wave * 16;                              // (uniform)
+        const unsigned qy = (unsigned)p0 / (unsigned)a.W;
+        const int xw = p0 - (int)qy * a.W, n = (int)(qy / (unsigned)a.H), y = (int)qy - n * a.H;
+        const float fy = a.ry * y;
+        const int y0 = (int)fy, y1 = y0 + (y0 < a.h - 1);
+        const float wy1 = fy - y0, wy0 = 1.f - wy1;
+        const int xl0 = (int)(a.rx * xw);
+        // the two rows, LOC pixels from column xl0: contiguous bytes of the map (columns behind the row's end belong to the next row or
+        // are out of range: no tap reads them); tiles behind the last pixel: image n is out of range, zeros
+        int l = lane;
+        asm volatile("" : "+v"(l));
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int rbase = ((n * a.h + (r ? y1 : y0)) * a.w + xl0) * ROWB;
+#pragma unroll
+            for (int i = 0; i < LOP; ++i) {
+                // (the last piece of a row is partial: its lanes behind the row's end are masked off - an out-of-range lane would write
+                // zeros over the start of the next row's area)
+                const int b = i * 1024 + l * 16;
+                if (b < LOROW) lat_lds_dma(los, wv + XW + r * LOROW + i * 1024, p0 < a.P ? rbase + b : 0x7FFFFFF0, 0);
+            }
+        }
+        int el = lane;
+        asm volatile("" : "+v"(el));
+        const int xa = xw + (el & 14), pa = p0 + (el & 14);
+        const int cb = 64 * (el & 1) + 16 * (el >> 4);
+        auto taps = [&](int x, int colbyte, int (&to)[4], float (&wt)[4]) {
+            const float fx = a.rx * x;
+            const int x0 = (int)fx, x1 = x0 + (x0 < a.w - 1);
+            const float wx1 = fx - x0, wx0 = 1.f - wx1;
+            to[0] = XW + (x0 - xl0) * ROWB + colbyte;
+            to[1] = XW + (x1 - xl0) * ROWB + colbyte;
+            to[2] = to[0] + LOROW;
+            to[3] = to[1] + LOROW;
+            wt[0] = wy0 * wx0; wt[1] = wy0 * wx1; wt[2] = wy1 * wx0; wt[3] = wy1 * wx1;
+        };
+        taps(xa, cb, toA, wA);
+        taps(xa + 1, cb, toB, wB);
+        if constexpr (LONE) taps(xa + (el & 1), 128 * NM + 16 * (el >> 4), toL, wL);
+        sA = pa < a.P ? pa * ROWB + cb : 0x7FFFFFF0;
+        sB = pa + 1 < a.P ? (pa + 1) * ROWB + cb : 0x7FFFFFF0;
+        const int pl = pa + (el & 1);
+        sL = pl < a.P ? pl * ROWB + 128 * NM + 16 * (el >> 4) : 0x7FFFFFF0;
+    };
+    auto pack8 = [](const v4f& lo_, const v4f& hi_) {
+        return V8{(T)lo_[0], (T)lo_[1], (T)lo_[2], (T)lo_[3], (T)hi_[0], (T)hi_[1], (T)hi_[2], (T)hi_[3]};
+    };
+    auto exchange = [&](const V8& p0, const V8& p1, V8& da, V8& db) {
+        const v4u u0 = __builtin_bit_cast(v4u, p0), u1 = __builtin_bit_cast(v4u, p1);
+        v4u ua, ub;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned send = odd ? u0[i] : u1[i];
+            const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+            ua[i] = odd ? recv : u0[i];
+            ub[i] = odd ? u1[i] : recv;
+        }
+        da = __builtin_bit_cast(V8, ua);
+        db = __builtin_bit_cast(V8, ub);
+    };
+    // v + sum_k wt[k] * tap k, the taps read from the wave's staged rows at to[k] + imm
+    auto merge = [&](const V8& v, const int (&to)[4], int imm, const float (&wt)[4]) {
+        v4u u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) u[k] = *reinterpret_cast<const v4u*>(wv + to[k] + imm);
+        const v4u uv = __builtin_bit_cast(v4u, v);
+        V8 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float lo_, hi_;
+            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(lo_) : "v"(u[0][i]), "v"(wt[0]), "v"(uv[i]));
+            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(hi_) : "v"(u[0][i]), "v"(wt[0]), "v"(uv[i]));
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(lo_) : "v"(u[k][i]), "v"(wt[k]));
+                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(hi_) : "v"(u[k][i]), "v"(wt[k]));
+            }
+            o[2 * i] = (T)lo_;
+            o[2 * i + 1] = (T)hi_;
+        }
+        return o;
+    };
+    auto store8 = [&](const V8& o, int vo, int imm) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), outs.r, vo + imm, 0, 0); };
+
+    // prologue: the weights (once per workgroup), the first tile's rows and its piece of the coarser map
+#pragma unroll
+    for (int i = 0; i < (KC * NCT + L12_NW - 1) / L12_NW; ++i) {
+        const int f = wave + L12_NW * i;
+        if (f < KC * NCT) lat_lds_dma(wsr, smem + f * 1024, lane * 16, f * 1024);
+    }
+    dma_x(tile0);
+    stage(tile0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    bool first = true;
+    for (int tile = tile0; tile < xend; tile += xper) {
+        const bool has_next = tile + xper < xend;
+        // ---- the product.  In flight, oldest first: rows(t) | map(t) | stores(t - 1)
+        if (!first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOP + NST) : "memory");
+        v4f acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = v4f{0.f, 0.f, 0.f, 0.f};
+        const char* xb = wv + lp * 64 + ((g4 ^ ((lp >> 1) & 3)) << 4);
+        const char* wb = smem + lane * 16;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const Frag xf = *reinterpret_cast<const Frag*>(xb + kc * 1024);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) Mm::mma(*reinterpret_cast<const Frag*>(wb + (kc * NCT + ct) * 1024), xf, acc[ct]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // the rows of the next tile take the place of this one's (every fragment read above has returned: the MFMAs consumed them)
+        if (has_next) dma_x(tile + xper);
+        // ---- the merge.  In flight: map(t) | stores(t - 1) | rows(t + 1)
+        if (!first) {
+            if (has_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST + KC) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+        }
+        V8 oA[NM], oB[NM], oL;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            V8 da, db;
+            exchange(pack8(acc[4 * m], acc[4 * m + 1]), pack8(acc[4 * m + 2], acc[4 * m + 3]), da, db);
+            oA[m] = merge(da, toA, 128 * m, wA);
+            oB[m] = merge(db, toB, 128 * m, wB);
+        }
+        if constexpr (LONE) oL = merge(pack8(acc[4 * NM], acc[4 * NM + 1]), toL, 0, wL);
+        const int stA = sA, stB = sB, stL = sL;
+        __builtin_amdgcn_sched_barrier(0);
+        // the next tile's piece of the coarser map takes the place of this one's (its tap reads have returned), then this tile's stores
+        if (has_next) stage(tile + xper);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            store8(oA[m], stA, 128 * m);
+            store8(oB[m], stB, 128 * m);
+        }
+        if constexpr (LONE) store8(oL, stL, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        first = false;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 template <typename T, int CIN, int COUT>
 int lat_launch(LatArgs a, hipStream_t st) {
     constexpr int LDS = (CIN / 32) * (COUT / 16) * 1024 + 2 * L12_NW * (CIN / 32) * 1024;
@@ -273,6 +464,17 @@ int lat_launch(LatArgs a, hipStream_t st) {
     if (gf_first_use_on_device(attr))
         (void)hipFuncSetAttribute((const void*)lateral_kernel<T, CIN, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     lateral_kernel<T, CIN, COUT><<<a.ntiles < 256 ? a.ntiles : 256, L12_NW * 64, LDS, st>>>(a);
+    return 0;
+}
+
+template <typename T, int CIN, int COUT>
+int lat_launch_staged(LatArgs a, hipStream_t st) {
+    constexpr int LDS = (CIN / 32) * (COUT / 16) * 1024 + L12_NW * ((CIN / 32) * 1024 + 2 * 10 * COUT * (int)sizeof(T));
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    static std::atomic<uint64_t> attr{0};
+    if (gf_first_use_on_device(attr))
+        (void)hipFuncSetAttribute((const void*)lateral_staged_kernel<T, CIN, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    lateral_staged_kernel<T, CIN, COUT><<<a.ntiles < 256 ? a.ntiles : 256, L12_NW * 64, LDS, st>>>(a);
     return 0;
 }
 
@@ -307,6 +509,11 @@ extern "C" int gf_lateral_upsample_add_nhwc(const void* x, const void* wfrag, co
     hipStream_t st = (hipStream_t)stream;
     // same tag and declared work as the K3 form it replaces: algorithmic bytes (x + out + the coarser map + weights once)
     void* pt = gf_prof_begin("k3_upadd", st, 2.0 * ((double)a.P * (cin + cout) + (double)N * h * wl * cout + (double)cin * cout));
+    // the staged form where a wave's 16 pixels share a row and 10 columns of the coarser map cover their taps (scale factor 2)
+#ifndef K12_NO_STAGED
+    if (W % 16 == 0 && W == 2 * wl) lat_launch_staged<_Float16, 128, 224>(a, st);
+    else
+#endif
     lat_launch<_Float16, 128, 224>(a, st);
     gf_prof_end("k3_upadd", pt, st);
     GF_CHECK_LAUNCH();

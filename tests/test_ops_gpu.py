@@ -893,11 +893,12 @@ def test_conv1x1_upsample_add_vs_torch():
 
 
 @pytest.mark.parametrize('dtype', [torch.float16])
-@pytest.mark.parametrize('N,hw', [(2, (30, 44)), (3, (7, 6)), (16, (320, 320)), (1, (1, 2))])
+@pytest.mark.parametrize('N,hw', [(2, (30, 44)), (3, (7, 6)), (16, (320, 320)), (1, (1, 2)), (2, (9, 32)), (3, (20, 48)), (1, (2, 16))])
 def test_lateral_upsample_add_vs_torch(dtype, N, hw):
     """K12 (gf_lateral_upsample_add_nhwc: layer1_outconv + the FPN merge, resnet_fpn.py:109-111) against torch fp32 on the same 16-bit
     operands and against the K3 form it replaces: ragged last tile, single-row / two-pixel maps, the full 16 x 320 x 320 launch
-    (12800 tiles on 256 persistent workgroups whose waves run unsynchronised behind the prologue)."""
+    (12800 tiles on 256 persistent workgroups whose waves run unsynchronised behind the prologue).  Widths that are multiples of 16
+    (32, 48, 16, 320) take the STAGED form - two rows x ten pixels of the coarser map per wave and tile in LDS - the others the gather form."""
     from geoformer_amd import fused, ops
     torch.manual_seed(N + hw[0])
     H, W = hw
