@@ -379,18 +379,33 @@ __global__ __launch_bounds__(L12_NW * 64) void lateral_staged_kernel(LatArgs a) 
         for (int k = 0; k < 4; ++k) u[k] = *reinterpret_cast<const v4u*>(wv + to[k] + imm);
         const v4u uv = __builtin_bit_cast(v4u, v);
         V8 o;
+        if constexpr (std::is_same<T, _Float16>::value) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float lo_, hi_;
-            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(lo_) : "v"(u[0][i]), "v"(wt[0]), "v"(uv[i]));
-            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(hi_) : "v"(u[0][i]), "v"(wt[0]), "v"(uv[i]));
+            for (int i = 0; i < 4; ++i) {
+                float lo_, hi_;
+                asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(lo_) : "v"(u[0][i]), "v"(wt[0]), "v"(uv[i]));
+                asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(hi_) : "v"(u[0][i]), "v"(wt[0]), "v"(uv[i]));
 #pragma unroll
-            for (int k = 1; k < 4; ++k) {
-                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(lo_) : "v"(u[k][i]), "v"(wt[k]));
-                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(hi_) : "v"(u[k][i]), "v"(wt[k]));
+                for (int k = 1; k < 4; ++k) {
+                    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(lo_) : "v"(u[k][i]), "v"(wt[k]));
+                    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(hi_) : "v"(u[k][i]), "v"(wt[k]));
+                }
+                o[2 * i] = (T)lo_;
+                o[2 * i + 1] = (T)hi_;
             }
-            o[2 * i] = (T)lo_;
-            o[2 * i + 1] = (T)hi_;
+        } else {
+            // bf16: a value is the high half of its fp32 form (a shift / a mask), same sums in the same order
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float lo_ = __uint_as_float(uv[i] << 16), hi_ = __uint_as_float(uv[i] & 0xFFFF0000u);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    lo_ = fmaf(__uint_as_float(u[k][i] << 16), wt[k], lo_);
+                    hi_ = fmaf(__uint_as_float(u[k][i] & 0xFFFF0000u), wt[k], hi_);
+                }
+                o[2 * i] = (T)lo_;
+                o[2 * i + 1] = (T)hi_;
+            }
         }
         return o;
     };
@@ -490,12 +505,15 @@ extern "C" int gf_debug_k12_trace(long long* out) {
 extern "C" int gf_lateral_supported(int cin, int cout) { return cin == 128 && cout == 224; }
 
 // out[n,y,x,:] = W . x[n,y,x,:] + bilinear(lo -> H x W, align_corners=True)[n,y,x,:]; x [N,H,W,cin], lo [N,h,w,cout], out [N,H,W,cout]
-// (GF_F16, channels-last); wfrag = fused.py:pack_lateral_frags(w [cout, cin]); W must be even
+// (GF_F16; GF_BF16 where the staged form applies: W % 16 == 0 and W == 2 w; channels-last); wfrag = fused.py:pack_lateral_frags(w [cout, cin]); W must be even
 extern "C" int gf_lateral_upsample_add_nhwc(const void* x, const void* wfrag, const void* lo, void* out, int N, int h, int wl, int H, int W,
                                             int cin, int cout, int dtype, void* stream) {
     GF_CHECK_ARG(x && wfrag && lo && out, "null pointer");
     GF_CHECK_ARG(N > 0 && h > 0 && wl > 0 && H > 0 && W > 0, "empty problem");
-    GF_CHECK_ARG(dtype == GF_F16, "built for fp16 maps (bf16 has no v_fma_mix: its merge needs more registers than two waves per SIMD leave; use gf_conv1x1_upsample_add_nhwc)");
+    GF_CHECK_ARG(dtype == GF_F16 || dtype == GF_BF16, "built for 16-bit maps (the inference backbone)");
+    const bool staged = W % 16 == 0 && W == 2 * wl;
+    GF_CHECK_ARG(dtype == GF_F16 || staged, "bf16 runs the staged form only (W a multiple of 16 and twice the coarser map's width): without v_fma_mix the "
+                                            "gather form's merge needs more registers than two waves per SIMD leave; use gf_conv1x1_upsample_add_nhwc");
     GF_CHECK_ARG(gf_lateral_supported(cin, cout), "no kernel for these channel counts (see gf_lateral_supported)");
     GF_CHECK_ARG(W % 2 == 0, "W must be even (a pixel pair shares its row)");
     GF_CHECK_ARG((long)N * H * W * 224 * 2 < 0x7FFFFFF0l, "maps of 2 GiB or more are not supported (32-bit buffer offsets)");
@@ -510,11 +528,12 @@ extern "C" int gf_lateral_upsample_add_nhwc(const void* x, const void* wfrag, co
     // same tag and declared work as the K3 form it replaces: algorithmic bytes (x + out + the coarser map + weights once)
     void* pt = gf_prof_begin("k3_upadd", st, 2.0 * ((double)a.P * (cin + cout) + (double)N * h * wl * cout + (double)cin * cout));
     // the staged form where a wave's 16 pixels share a row and 10 columns of the coarser map cover their taps (scale factor 2)
-#ifndef K12_NO_STAGED
-    if (W % 16 == 0 && W == 2 * wl) lat_launch_staged<_Float16, 128, 224>(a, st);
-    else
-#endif
-    lat_launch<_Float16, 128, 224>(a, st);
+    if (staged) {
+        if (dtype == GF_F16) lat_launch_staged<_Float16, 128, 224>(a, st);
+        else lat_launch_staged<gf_bf16, 128, 224>(a, st);
+    } else {
+        lat_launch<_Float16, 128, 224>(a, st);
+    }
     gf_prof_end("k3_upadd", pt, st);
     GF_CHECK_LAUNCH();
     return GF_OK;

@@ -125,7 +125,7 @@ class FusedInferenceBackbone:
         self.l2_out = self._w1x1(_fold(bb.layer2_outconv, None, dtype, pm)[0])
         self.l1_out = self._w1x1(_fold(bb.layer1_outconv, None, dtype, pm)[0])
         self.l1_frags = None
-        if dtype == torch.float16 and fused.lateral_supported(self.l1_out.shape[1], self.l1_out.shape[0]):
+        if dtype in (torch.float16, torch.bfloat16) and fused.lateral_supported(self.l1_out.shape[1], self.l1_out.shape[0]):
             self.l1_frags = fused.pack_lateral_frags(self.l1_out)
         self.l2_oc2 = (_fold(bb.layer2_outconv2[0], bb.layer2_outconv2[1], dtype, pm), bb.layer2_outconv2[2].negative_slope,
                        _fold(bb.layer2_outconv2[3], None, dtype, pm)[0])
@@ -207,7 +207,9 @@ class FusedInferenceBackbone:
             c2 = self._head(ops.conv1x1_upsample_add(x2, self.l2_out, c3), self.l2_oc2)
         else:
             c2 = self._head(ops.upsample_add_(self._conv(x2, self.l2_out), c3), self.l2_oc2)
-        if self.l1_frags is not None and x1.shape[3] % 2 == 0:                  # lateral 1x1 + merge: the streaming kernel K12 (fp16, 128 -> 224)
+        w1 = x1.shape[3]
+        if self.l1_frags is not None and ((w1 % 16 == 0 and w1 == 2 * c2.shape[3]) or (self.dtype == torch.float16 and w1 % 2 == 0)):
+            # lateral 1x1 + merge: the streaming kernel K12 (128 -> 224; bf16: its staged form only)
             c1 = self._head(fused.lateral_upsample_add(x1, self.l1_frags, self.l1_out.shape[0], c2), self.l1_oc2)
         elif self.l1_out.shape[1] % 32 == 0 and self.dtype != torch.float32:    # lateral 1x1 + merge in one K3 launch
             c1 = self._head(ops.conv1x1_upsample_add(x1, self.l1_out, c2), self.l1_oc2)

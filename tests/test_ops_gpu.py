@@ -892,7 +892,7 @@ def test_conv1x1_upsample_add_vs_torch():
     assert torch.allclose(out.float(), ref, atol=1e-2, rtol=4e-3), (out.float() - ref).abs().max().item()   # two fp16 roundings
 
 
-@pytest.mark.parametrize('dtype', [torch.float16])
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('N,hw', [(2, (30, 44)), (3, (7, 6)), (16, (320, 320)), (1, (1, 2)), (2, (9, 32)), (3, (20, 48)), (1, (2, 16))])
 def test_lateral_upsample_add_vs_torch(dtype, N, hw):
     """K12 (gf_lateral_upsample_add_nhwc: layer1_outconv + the FPN merge, resnet_fpn.py:109-111) against torch fp32 on the same 16-bit
@@ -903,6 +903,8 @@ def test_lateral_upsample_add_vs_torch(dtype, N, hw):
     torch.manual_seed(N + hw[0])
     H, W = hw
     h, w_ = max(1, H // 2), max(1, W // 2)
+    if dtype == torch.bfloat16 and not (W % 16 == 0 and W == 2 * w_):
+        pytest.skip('bf16 runs the staged form only')
     x = torch.randn(N, 128, H, W, device='cuda').to(dtype).contiguous(memory_format=torch.channels_last)
     w = (torch.randn(224, 128, device='cuda') * 0.1).to(dtype)
     lo = torch.randn(N, 224, h, w_, device='cuda').to(dtype).contiguous(memory_format=torch.channels_last)
