@@ -148,19 +148,34 @@ __global__ __launch_bounds__(256, 2) void stem_conv(StArgs a) {
         for (int r = 0; r < 16; ++r) sh[nb][r] = a.shift[nb * 32 + gf_acc_row(r, h)];
 
     const long ntiles = (long)a.N * a.tiles_y * a.tiles_x;
+    // the image pixels of a tile: requested into registers one tile AHEAD, in front of the previous tile's output stores (the memory
+    // counter retires in issue order: requested behind them, every tile waited for its predecessor's stores to come back)
+    constexpr int NPRE = (TH * TW + 255) / 256;
+    _Float16 pre[NPRE];
+    auto request = [&](long t) {
+        const int tx = (int)(t % a.tiles_x);
+        const long q = t / a.tiles_x;
+        const int ty = (int)(q % a.tiles_y), n = (int)(q / a.tiles_y);
+        const TI* img = (const TI*)a.img + (long)n * a.H * a.W;
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            const int e = tid + 256 * i, r = e / TW, c = e % TW;
+            const int y = 8 * ty - 3 + r, x = 64 * tx - 3 + c;
+            pre[i] = (e < TH * TW && y >= 0 && y < a.H && x >= 0 && x < a.W) ? (_Float16)gf_to_float(img[(long)y * a.W + x]) : (_Float16)0.f;
+        }
+    };
+    if ((long)blockIdx.x < ntiles) request(blockIdx.x);
     for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int tx = (int)(t % a.tiles_x);
         const long q = t / a.tiles_x;
         const int ty = (int)(q % a.tiles_y), n = (int)(q / a.tiles_y);
         const int ox0 = tx * 32, oy0 = ty * 4;
-        const TI* img = (const TI*)a.img + (long)n * a.H * a.W;
         __syncthreads();                                   // previous tile's fragments are consumed
-        for (int e = tid; e < TH * TW; e += 256) {
-            const int r = e / TW, c = e % TW;
-            const int y = 2 * oy0 - 3 + r, x = 2 * ox0 - 3 + c;
-            tile[e] = (y >= 0 && y < a.H && x >= 0 && x < a.W) ? (_Float16)gf_to_float(img[(long)y * a.W + x]) : (_Float16)0.f;
-        }
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i)
+            if (tid + 256 * i < TH * TW) tile[tid + 256 * i] = pre[i];
         __syncthreads();
+        if (t + gridDim.x < ntiles) request(t + gridDim.x);
         v16f acc[4];
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
