@@ -262,6 +262,11 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
     // times the 2 PB pixel fragments of the tap (16 pixels x 32 channels = the 64 bytes of a patch pixel: lane (pixel, k
     // group) reads the 16-byte slot k group ^ ((q >> 1) & 3) - conflict-free for every patch offset).
     const int xq0 = PB * wave * PW + lp;
+    // (see load_x) the slot table of the lane: entry d = g4 ^ (((xq0 + d) >> 1) & 3), and the byte offset of its pixel xq0
+    int swz = 0;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) swz |= (g4 ^ (((xq0 + d) >> 1) & 3)) << (2 * d);
+    const int xbase = xq0 * 64;
     Frag wa[NT], wb[NT], xa[2 * PB], xb[2 * PB];
     auto load_w = [&](Frag (&f)[NT], int slot, int s, bool second_half) {   // weight fragments of sub-step s of the block in `slot`
         const char* p = smem + G::W10_OFF + slot * G::WBLK + s * NT * C10_FRAG + lane * 16;
@@ -274,12 +279,29 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
         constexpr int s2_plane[9] = {0, 0, 0, 0, 1, 1, 2, 2, 3}, s2_dy[9] = {0, 0, 1, 1, 0, 1, 0, 0, 0}, s2_dx[9] = {0, 1, 0, 1, 0, 0, 0, 1, 0};
         const int ky = S2 ? s2_dy[tap] : tap / 3, kx = S2 ? s2_dx[tap] : tap - 3 * (tap / 3);
         const char* p = smem + P_OFF + (S2 ? s2_plane[tap] * G::PLANE_BYTES : buf * G::PATCH_BYTES);
+#ifndef K10_SWZ_TABLE
+#define K10_SWZ_TABLE 1
+#endif
+        if constexpr (K10_SWZ_TABLE != 0) {
+            // pixel q = xq0 + c, c a compile-time constant of (fragment, tap): its byte offset c * 64 goes into the read's immediate, and the
+            // 16-byte slot g4 ^ ((q >> 1) & 3) depends on (xq0 + c) % 8 only - eight 2-bit entries in ONE register per lane (swz):
+            // a bit-field extract and a shift-add per fragment instead of six instructions
+            int tb = swz, xb = xbase;
+            asm volatile("" : "+v"(tb), "+v"(xb));
+#pragma unroll
+            for (int bb = 0; bb < 2 * PB; ++bb) {
+                const int c = ((bb >> 1) + ky) * PW + 16 * (bb & 1) + kx;
+                const int slot = __builtin_amdgcn_ubfe(tb, 2 * (c & 7), 2);
+                f[bb] = *reinterpret_cast<const Frag*>(p + (xb + (slot << 4)) + c * 64);
+            }
+        } else {
         int xq = xq0;
         asm volatile("" : "+v"(xq));        // the 36 fragment offsets of a chunk are recomputed (4 VALU each), not kept in registers
 #pragma unroll
         for (int bb = 0; bb < 2 * PB; ++bb) {
             const int q = xq + ((bb >> 1) + ky) * PW + 16 * (bb & 1) + kx;
             f[bb] = *reinterpret_cast<const Frag*>(p + q * 64 + ((g4 ^ ((q >> 1) & 3)) << 4));
+        }
         }
     };
 
