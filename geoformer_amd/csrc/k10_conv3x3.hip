@@ -108,7 +108,8 @@ __device__ __forceinline__ void conv_dma_block(const ConvRsrc& ws, char* smem, i
 #pragma unroll
     for (int i = 0; i < (G::FR + NW - 1) / NW; ++i) {
         const int f = wave + NW * i;
-        if (i >= i0 && i < i1 && f < G::FR) conv_lds_dma(ws, dst + f * C10_FRAG, lane * 16, b * G::WBLK + f * C10_FRAG);
+        // (f < FR holds for every wave where NW (i + 1) <= FR: no scalar branch for those pieces)
+        if (i >= i0 && i < i1 && (NW * (i + 1) <= G::FR || f < G::FR)) conv_lds_dma(ws, dst + f * C10_FRAG, lane * 16, b * G::WBLK + f * C10_FRAG);
     }
 }
 
@@ -125,12 +126,13 @@ __device__ __forceinline__ void conv_dma_patch(const ConvArgs& a, const ConvRsrc
 #pragma unroll
     for (int i = 0; i < (G::PIECES + NW - 1) / NW; ++i) {
         const int piece = wave + NW * i;
-        if (i >= i0 && i < i1 && piece < G::PIECES) {
+        if (i >= i0 && i < i1 && (NW * (i + 1) <= G::PIECES || piece < G::PIECES)) {
             const int q = piece * 16 + (lane >> 2), slot = (lane & 3) ^ ((q >> 1) & 3);
             const int pr = q / PW, pc = q - pr * PW;
             const bool in = (unsigned)(y0 - 1 + pr) < (unsigned)a.Hi && (unsigned)(x0 - 1 + pc) < (unsigned)a.Wi && q < G::PH * PW;
-            const int off = sbase + (pr * a.Wi + pc) * CIN + 8 * slot;
-            conv_lds_dma(xs, dst + piece * 1024, in ? off * (int)sizeof(T) : 0x7FFFFFF0, 0);                // outside the image: out of range -> zeros
+            int off = (sbase + (pr * a.Wi + pc) * CIN + 8 * slot) * (int)sizeof(T);
+            asm volatile("" : "+v"(off));       // (computed for every lane: left to the compiler the select becomes an exec-masked branch per piece)
+            conv_lds_dma(xs, dst + piece * 1024, in ? off : 0x7FFFFFF0, 0);                // outside the image: out of range -> zeros
         }
     }
 }
@@ -153,8 +155,9 @@ __device__ __forceinline__ void conv_dma_plane(const ConvArgs& a, const ConvRsrc
             const int q = piece * 16 + (lane >> 2), slot = (lane & 3) ^ ((q >> 1) & 3);
             const int pr = q / PW, pc = q - pr * PW;
             const bool in = (unsigned)(iy0 + 2 * pr) < (unsigned)a.Hi && (unsigned)(ix0 + 2 * pc) < (unsigned)a.Wi && q < G::PH * PW;
-            const int off = sbase + 2 * (pr * a.Wi + pc) * CIN + 8 * slot;
-            conv_lds_dma(xs, dst + piece * 1024, in ? off * (int)sizeof(T) : 0x7FFFFFF0, 0);
+            int off = (sbase + 2 * (pr * a.Wi + pc) * CIN + 8 * slot) * (int)sizeof(T);
+            asm volatile("" : "+v"(off));
+            conv_lds_dma(xs, dst + piece * 1024, in ? off : 0x7FFFFFF0, 0);
         }
     }
 }
@@ -261,6 +264,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
     // A sub-step = (tap, half of the output channels): NT weight fragments (16 channels x the chunk's 32 input channels each)
     // times the 2 PB pixel fragments of the tap (16 pixels x 32 channels = the 64 bytes of a patch pixel: lane (pixel, k
     // group) reads the 16-byte slot k group ^ ((q >> 1) & 3) - conflict-free for every patch offset).
+    const int n_none = a.N;                                            // (an image index that is out of range: a request nobody reads)
     const int xq0 = PB * wave * PW + lp;
     // (see load_x) the slot table of the lane: entry d = g4 ^ (((xq0 + d) >> 1) & 3), and the byte offset of its pixel xq0
     int swz = 0;
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
         decode(tile, n, y0, x0);
         const int nxt_tile = tile + xper;
         const bool has_next = nxt_tile < xend;
-        int n2 = 0, y2 = 0, x2 = 0;
+        int n2 = n_none, y2 = 0, x2 = 0;                              // (no next tile: its patch requests name an image that is out of range)
         if (has_next) decode(nxt_tile, n2, y2, x2);
         ++it;
         K10_T(0);
@@ -375,7 +379,6 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
             const int blk0 = R ? NCH * BPC : c * BPC;                       // this chunk's first weight block
             const bool tile_ends = R || (!REM && c + 1 == NCH);              // no chunk of this tile behind this one
             const bool rem_next = !R && REM && c + 1 == NCH;                 // the remainder follows
-            const bool patch_req = c + 1 < NCH || has_next;                  // a full chunk requests a patch behind its first turn
 #pragma unroll
             for (int ts = 0; ts < NTS; ++ts) {                               // sub-step (tap or k-step ts / 2, channel half ts % 2)
                 const int tap = ts >> 1, hf = ts & 1;
@@ -392,21 +395,24 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
                     if (kslot < WS && !(ts == NTS - 1 && tile_ends)) {            // (a tile's last turn: issued whole at the turn)
                         if (ts >= BS - 1 || R || c > 0) {                        // (a tile's first sub-steps: nothing is pending)
                             const int nb = blk0 + (ts + 1) / BS + 1;             // = block being finished + 2 at the turn, current block + 1 behind it
-                            if (nb < NBLK) conv_dma_block<NT, NW, S2>(ws, smem, nb, wslot ^ 1, wave, lane, wbeg(kslot), wbeg(kslot + 1));
-                            else if (has_next) conv_dma_block<NT, NW, S2>(ws, smem, nb - NBLK, wslot ^ 1, wave, lane, wbeg(kslot), wbeg(kslot + 1));
+                            // (one call, no branch: behind the last tile's last blocks the request names a block outside the stream - out of
+                            // range: zeros into a slot nobody reads)
+                            conv_dma_block<NT, NW, S2>(ws, smem, nb < NBLK ? nb : has_next ? nb - NBLK : NBLK, wslot ^ 1, wave, lane, wbeg(kslot), wbeg(kslot + 1));
                         }
                     }
                     if constexpr (S2) {
                         // plane (ts - 8) / 3 of the next chunk: its last tap's fragments are in registers, every wave is past the barrier
                         if (kslot == 0 && ts >= 8) {
-                            if (c + 1 < NCH) conv_dma_plane<T, CIN, NT, NW>(a, xs, smem, (ts - 8) / 3, n, y0, x0, c + 1, wave, lane);
-                            else if (has_next) conv_dma_plane<T, CIN, NT, NW>(a, xs, smem, (ts - 8) / 3, n2, y2, x2, 0, wave, lane);
+                            const bool same = c + 1 < NCH;
+                            conv_dma_plane<T, CIN, NT, NW>(a, xs, smem, (ts - 8) / 3, same ? n : n2, same ? y0 : y2, same ? x0 : x2, same ? c + 1 : 0, wave, lane);
                         }
                     } else if (!R && ts >= BS - 1 + PS0 && ts < BS - 1 + PS0 + PS) {
                         // behind the first turn of a full chunk every wave is past the previous chunk: its patch buffer is free
                         const int kp = ts - (BS - 1 + PS0);
-                        if (c + 1 < NCH) conv_dma_patch<T, CIN, NT, NW>(a, xs, smem, pbuf ^ 1, n, y0, x0, c + 1, wave, lane, pbeg(kp), pbeg(kp + 1));
-                        else if (has_next) conv_dma_patch<T, CIN, NT, NW>(a, xs, smem, pbuf ^ 1, n2, y2, x2, 0, wave, lane, pbeg(kp), pbeg(kp + 1));
+                        // (one call: the next chunk of this tile, or the first of the next tile; behind the last tile's last chunk: image N, out of range)
+                        const bool same = c + 1 < NCH;
+                        conv_dma_patch<T, CIN, NT, NW>(a, xs, smem, pbuf ^ 1, same ? n : n2, same ? y0 : y2, same ? x0 : x2, same ? c + 1 : 0,
+                                                       wave, lane, pbeg(kp), pbeg(kp + 1));
                         // the tile's remainder patch: its buffer is free since every wave left the previous tile's remainder chunk
                         if constexpr (REM) {
                             if (c == 0 && kp == PS - 1) conv_dma_patch_rem<T, CIN, NT, NW>(a, xs, smem, n, y0, x0, wave, lane);
@@ -423,10 +429,10 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
                     const bool first_turn = !R && ts == BS - 1 && c == 0;
                     if (first_turn) K10_T(12);
                     if (first_turn && it > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
-                    else if (!S2 && !R && ts == 2 * BS - 1 && patch_req) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPMIN) : "memory");
+                    else if (!S2 && !R && ts == 2 * BS - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPMIN) : "memory");
                     // (S2: behind a turn that requested a plane - weights first, then the plane - the plane's pieces stay in flight; it is
                     // needed nine sub-steps after its request at the earliest, and two turns later all of it has landed)
-                    else if (S2 && ((ts >= 11 && patch_req) || (ts == BS - 1 && c > 0))) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPMIN) : "memory");
+                    else if (S2 && (ts >= 11 || (ts == BS - 1 && c > 0))) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPMIN) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (first_turn) K10_T(13);
                     if constexpr (!R) K10_T2(20 + ts / BS);
