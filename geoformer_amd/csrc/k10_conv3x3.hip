@@ -444,7 +444,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
                         // last turn of a tile: the whole request at once (dealt to the next tile's first sub-steps its pieces would
                         // queue behind the epilogue's stores, and the next first turn would have to wait for those)
                         const int nb = blk0 + ts / BS + 2;
-                        if (has_next) conv_dma_block<NT, NW, S2>(ws, smem, nb - NBLK, wslot ^ 1, wave, lane);
+                        conv_dma_block<NT, NW, S2>(ws, smem, has_next ? nb - NBLK : NBLK, wslot ^ 1, wave, lane);      // (no next tile: out of range)
                     }
                     if (!DEAL) {
                         dma_slot();
