@@ -819,6 +819,24 @@ def test_conv3x3_stride2_full_size_vs_library(cin, cout, hw):
     assert torch.equal(out, fused.conv3x3(x, fused.pack_conv3x3_stream(w, s2=True), cout, shift, None, ops.ACT_RELU, stride=2))
 
 
+def test_conv3x3_stride2_with_shortcut_and_leaky():
+    """GF_CONV_S2 with the epilogue forms the backbone does not use at stride 2 (a shortcut of the OUTPUT shape, LeakyReLU, no shift):
+    the header allows them."""
+    from geoformer_amd import fused, ops
+    torch.manual_seed(5)
+    F = torch.nn.functional
+    x = torch.randn(2, 128, 45, 70, device='cuda').half().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(224, 128, 3, 3, device='cuda') * (1.5 / (3 * 128 ** 0.5))).half()
+    res = torch.randn(2, 224, 23, 35, device='cuda').half().contiguous(memory_format=torch.channels_last)
+    ws = fused.pack_conv3x3_stream(w, s2=True)
+    for act, fn in ((ops.ACT_LEAKY, lambda t: F.leaky_relu(t, 0.1)), (ops.ACT_RELU, torch.relu), (ops.ACT_NONE, lambda t: t)):
+        out = fused.conv3x3(x, ws, 224, None, res, act, 0.1, stride=2)
+        pre = F.conv2d(x.float(), w.float(), None, 2, 1)
+        ref = fn(pre + res.float())
+        err = ((out.float() - ref).abs() / torch.maximum(pre.abs(), ref.abs()).clamp_min(1.0)).max()
+        assert out.shape == ref.shape and float(err) < 1.1 * 2.0 ** -10, (act, float(err))
+
+
 def test_conv3x3_stride2_and_lateral_random_shapes():
     """Seeded random map sizes for the two kernels round 4 added to the backbone (K10's stride-2 form, K12): every size class of the
     tile walk - maps smaller than a tile, tiles hanging over two sides, odd and even sizes, several tiles per workgroup - against torch
