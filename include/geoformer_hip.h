@@ -35,6 +35,8 @@ typedef enum { GF_F32 = 0, GF_F16 = 1, GF_BF16 = 2 } gf_dtype;
  * arguments.  History: 1 = rounds 1-2; 2 = round 3 (gf_ransac_homography had gained `lm_iters` in the MIDDLE of its list: a
  * caller built against version 1 would have passed min_points as lm_iters); 3 = round 4: gf_ransac_homography is back to its
  * version-1 signature (no refinement), new arguments live in gf_ransac_homography_v2, appended at the END. */
+/* 4 (round 4): the fragment stream of gf_conv3x3_nhwc deals the output channels differently (fused.py:pack_conv3x3_stream: a stream packed for
+ * version 3 gives wrong channels) and GF_CONV_PAD16 now states that channels 196 .. 223 are padding; new: GF_CONV_S2, gf_lateral_upsample_add_nhwc. */
 #define GF_ABI_VERSION 4
 int gf_abi_version(void);
 const char* gf_last_error(void);
