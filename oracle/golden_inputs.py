@@ -282,3 +282,58 @@ def g16_inputs():
             'b_ids': torch.zeros(M, dtype=torch.long), 'W': torch.tensor(5), 'hw0_i': torch.tensor([H, W]),
             'hw0_c': torch.tensor([H // 8, W // 8]), 'hw0_f': torch.tensor([H // 2, W // 2]), 'dataset_name': ['megadepth']}
     return {'kpts': kpts, 'coarse': coarse, 'fine': fine}
+
+
+# ------------------------------------------------------------------------------------------ outcome-level parity
+def hpatches_like_homography(seed, k, w, h):
+    """Ground-truth homography of pair `k` (1..5, as HPatches' H_1_2 .. H_1_6) of synthetic sequence `seed`: the four image corners move
+    by up to a * k pixels (the four-point parametrisation, solved exactly), a = 2 for even seeds (near-planar, small-baseline
+    sequences) and 8 for odd ones (viewpoint sequences) - the strength grows along the sequence as HPatches' does."""
+    import numpy as np
+    rng = np.random.default_rng(1000 * seed + k)
+    amp = (2.0 if seed % 2 == 0 else 8.0) * k
+    src = np.array([[0, 0], [w - 1, 0], [w - 1, h - 1], [0, h - 1]], dtype=np.float64)
+    dst = src + rng.uniform(-amp, amp, (4, 2))
+    A, b = [], []
+    for (x, y), (u, v) in zip(src, dst):
+        A += [[x, y, 1, 0, 0, 0, -u * x, -u * y], [0, 0, 0, x, y, 1, -v * x, -v * y]]
+        b += [u, v]
+    hvec = np.linalg.solve(np.array(A), np.array(b))
+    return np.append(hvec, 1.0).reshape(3, 3)
+
+
+def _field_sample(lat, xy, spacing, margin):
+    """Bilinear sample of the lattice field lat [C, Hl, Wl] (node (r, c) sits at pixel (c * spacing - margin, r * spacing - margin)) at
+    pixel positions xy [h, w, 2] -> [C, h, w]."""
+    C, Hl, Wl = lat.shape
+    gx = (xy[..., 0] + margin) / spacing / (Wl - 1) * 2 - 1
+    gy = (xy[..., 1] + margin) / spacing / (Hl - 1) * 2 - 1
+    grid = torch.stack([gx, gy], -1)[None].float()
+    return torch.nn.functional.grid_sample(lat[None], grid, mode='bilinear', padding_mode='border', align_corners=True)[0]
+
+
+def hpatches_like_features(seed, k, h0=60, w0=80, h1=60, w1=76, noise=0.25, margin=128, sc=8, sf=2):
+    """Planted feature maps of a synthetic HPatches-protocol pair (480x640 against 480x608 by default, data_io.py:16-26's shape
+    class): ONE continuous random field per level, defined over image-0 pixel coordinates (a lattice of white noise every 8 px for
+    the coarse level / every 2 px for the fine level, bilinearly interpolated); image 0's maps sample it at their own cell
+    positions, image 1's maps at H^-1 of theirs, plus noise - the maps a perfect backbone would hand over for a planar scene.
+    Returns ((c0, f0), (c1, f1)) [1, 256, h, w] / [1, 128, 4h, 4w] fp32 and H (3x3, image 0 -> image 1 pixels)."""
+    import numpy as np
+    g = gen(7000 + 10 * seed + k)
+    H = hpatches_like_homography(seed, k, 8 * w0, 8 * h0)
+    Hinv = torch.from_numpy(np.linalg.inv(H)).double()
+
+    def positions(h, w, step, warp):
+        ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float64) * step, torch.arange(w, dtype=torch.float64) * step, indexing='ij')
+        p = torch.stack([xs, ys, torch.ones_like(xs)], -1)
+        if warp:
+            p = p @ Hinv.T
+        return (p[..., :2] / p[..., 2:]).float()
+    Wl, Hl = 8 * max(w0, w1) + 2 * margin, 8 * max(h0, h1) + 2 * margin
+    latc = torch.randn(256, Hl // sc + 1, Wl // sc + 1, generator=g) * 0.5
+    latf = torch.randn(128, Hl // sf + 1, Wl // sf + 1, generator=g)
+    c0 = _field_sample(latc, positions(h0, w0, 8, False), sc, margin)
+    c1 = _field_sample(latc, positions(h1, w1, 8, True), sc, margin) + noise * torch.randn(256, h1, w1, generator=g)
+    f0 = _field_sample(latf, positions(4 * h0, 4 * w0, 2, False), sf, margin)
+    f1 = _field_sample(latf, positions(4 * h1, 4 * w1, 2, True), sf, margin) + noise * torch.randn(128, 4 * h1, 4 * w1, generator=g)
+    return (c0[None].contiguous(), f0[None].contiguous()), (c1[None].contiguous(), f1[None].contiguous()), H

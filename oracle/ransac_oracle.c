@@ -158,14 +158,11 @@ static void lm_refine(double* h, const double* p0, const double* p1, const uint8
     }
 }
 
-/* kp0, kp1: int64 [n,2].  Returns 1 and fills M[9], mask[n] when a model is found, else 0 (mask zeroed). */
-int gf_oracle_ransac(const int64_t* kp0, const int64_t* kp1, int n, double thr, int iters, uint32_t seed,
-                     uint32_t sample, int lm_iters, double* M, uint8_t* mask) {
-    memset(mask, 0, (size_t)n);
-    if (n <= 8) return 0;                         /* geo_module.py:46 */
-    double* p0 = (double*)malloc(sizeof(double) * 4 * (size_t)n);
+/* The algorithm on fp64 points p0 = [n,2 | n,2] (p1 = p0 + 2n; freed here).  min_points: the caller's gate (geo_module.py:46 demands
+ * MORE than 8 matches = 9; the evaluation harness' findHomography needs 4). */
+static int ransac_core(double* p0, int n, double thr, int iters, uint32_t seed, uint32_t sample, int lm_iters, double* M,
+                       uint8_t* mask) {
     double* p1 = p0 + 2 * (size_t)n;
-    for (int i = 0; i < 2 * n; ++i) { p0[i] = (double)kp0[i]; p1[i] = (double)kp1[i]; }
     const double thr2 = thr * thr;
     int best_cnt = -1, best_t = -1;
     double best_h[9];
@@ -243,4 +240,28 @@ int gf_oracle_ransac(const int64_t* kp0, const int64_t* kp1, int n, double thr, 
     if (lm_iters > 0) lm_refine(M, p0, p1, mask, n, lm_iters);
     free(p0);
     return 1;
+}
+
+/* kp0, kp1: int64 [n,2].  Returns 1 and fills M[9], mask[n] when a model is found, else 0 (mask zeroed). */
+int gf_oracle_ransac(const int64_t* kp0, const int64_t* kp1, int n, double thr, int iters, uint32_t seed,
+                     uint32_t sample, int lm_iters, double* M, uint8_t* mask) {
+    memset(mask, 0, (size_t)n);
+    if (n <= 8) return 0;                         /* geo_module.py:46 */
+    double* p0 = (double*)malloc(sizeof(double) * 4 * (size_t)n);
+    double* p1 = p0 + 2 * (size_t)n;
+    for (int i = 0; i < 2 * n; ++i) { p0[i] = (double)kp0[i]; p1[i] = (double)kp1[i]; }
+    return ransac_core(p0, n, thr, iters, seed, sample, lm_iters, M, mask);
+}
+
+/* The same on sub-pixel keypoints (float32 [n,2], widened to fp64 as k_ransac.hip does with integer_keypoints = 0) and a caller-chosen
+ * gate: the evaluation harness' homography from the final matches (hpatches_helper.py:185-239 calls cv2.findHomography(..., RANSAC, 3)),
+ * geoformer_amd/matcher.py:estimate_homography on the device. */
+int gf_oracle_ransac_f32(const float* kp0, const float* kp1, int n, double thr, int iters, uint32_t seed, uint32_t sample,
+                         int lm_iters, int min_points, double* M, uint8_t* mask) {
+    memset(mask, 0, (size_t)(n > 0 ? n : 0));
+    if (n < min_points || n < 4) return 0;
+    double* p0 = (double*)malloc(sizeof(double) * 4 * (size_t)n);
+    double* p1 = p0 + 2 * (size_t)n;
+    for (int i = 0; i < 2 * n; ++i) { p0[i] = (double)kp0[i]; p1[i] = (double)kp1[i]; }
+    return ransac_core(p0, n, thr, iters, seed, sample, lm_iters, M, mask);
 }

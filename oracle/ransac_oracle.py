@@ -25,6 +25,10 @@ def _load():
         _lib.gf_oracle_ransac.restype = ctypes.c_int
         _lib.gf_oracle_ransac.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_int,
                                           ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        _lib.gf_oracle_ransac_f32.restype = ctypes.c_int
+        _lib.gf_oracle_ransac_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_int,
+                                              ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                              ctypes.c_void_p]
     return _lib
 
 
@@ -38,6 +42,21 @@ def find_homography(kp0, kp1, thr=8.0, iters=DEFAULT_ITERS, seed=DEFAULT_SEED, s
     mask = np.zeros(max(n, 1), np.uint8)
     ok = _load().gf_oracle_ransac(a.ctypes.data, b.ctypes.data, n, float(thr), int(iters), int(seed), int(sample), int(lm_iters),
                                   M.ctypes.data, mask.ctypes.data)
+    return (M.reshape(3, 3) if ok else None), mask[:n, None]
+
+
+def find_homography_subpixel(kp0, kp1, thr=3.0, iters=DEFAULT_ITERS, seed=DEFAULT_SEED, sample=0, lm_iters=DEFAULT_LM_ITERS,
+                             min_points=4):
+    """Sub-pixel keypoints (float32 [n,2]) and a caller-chosen gate: the evaluation harness' homography from the final
+    matches (hpatches_helper.py:185-239: cv2.findHomography(p1, p2, cv2.RANSAC, 3)), the CPU statement of
+    geoformer_amd.matcher.estimate_homography (device RANSAC with integer_keypoints=False, min_points=4)."""
+    a = np.ascontiguousarray(kp0, dtype=np.float32)
+    b = np.ascontiguousarray(kp1, dtype=np.float32)
+    n = len(a)
+    M = np.zeros(9, np.float64)
+    mask = np.zeros(max(n, 1), np.uint8)
+    ok = _load().gf_oracle_ransac_f32(a.ctypes.data, b.ctypes.data, n, float(thr), int(iters), int(seed), int(sample),
+                                      int(lm_iters), int(min_points), M.ctypes.data, mask.ctypes.data)
     return (M.reshape(3, 3) if ok else None), mask[:n, None]
 
 

@@ -42,6 +42,20 @@ def close(a, b, rtol, atol):
     np.testing.assert_allclose(a.detach().float().cpu().numpy(), np.asarray(b), rtol=rtol, atol=atol)
 
 
+# BASELINE.md section 3's gate for the fp32 parity mode: mconf within 1e-4 (ABSOLUTE: confidences live in [0, 1]) of the reference's
+# own run, after 14 exact-fp32 transformer layers and two dual-softmax stages whose summation orders differ from torch's
+MCONF_ATOL_FP32 = 1e-4
+
+
+def mconf_close_fp32(got, want, what):
+    g, w = got.detach().float().cpu().numpy(), np.asarray(want, dtype=np.float32)
+    d = np.abs(g - w)
+    rel = d / np.maximum(np.abs(w), 1e-12)
+    print(f'{what}: fp32 mconf on {len(w)} matches: max |d| {d.max() if len(d) else 0.0:.2e} (gate {MCONF_ATOL_FP32:g} absolute), '
+          f'max relative {rel.max() if len(d) else 0.0:.2e}')
+    assert len(g) == len(w) and (len(d) == 0 or float(d.max()) <= MCONF_ATOL_FP32), (what, float(d.max()))
+
+
 @pytest.mark.parametrize('name', list(GI.g10_cases().keys()))
 def test_golden_fp32(golden, name):
     """Reference outputs, injected reference homographies: coarse and fine indices bit-exact."""
@@ -59,6 +73,7 @@ def test_golden_fp32(golden, name):
         np.testing.assert_array_equal(out[k].cpu().numpy(), G['out_' + k])
     for k in ('mkpts0_c', 'mkpts1_c', 'mkpts0_f', 'mkpts1_f'):
         close(out[k], G['out_' + k], 1e-6, 1e-5)
+    mconf_close_fp32(out['mconf'], G['out_mconf'], name)
     close(out['mconf'], G['out_mconf'], 1e-3, 1e-6)
     close(out['conf_matrix'], G['out_conf_matrix'], 5e-3, 1e-7)
     close(out['dect_conf_matrix'], G['out_dect_conf_matrix'], 5e-3, 1e-7)
@@ -83,6 +98,7 @@ def test_640_digest_fp32(golden):
     np.testing.assert_array_equal(out['j_ids'].cpu().numpy(), G['j_ids'].astype(np.int64))
     np.testing.assert_array_equal(GI.digest(out['b_ids'].cpu(), out['i_ids'].cpu(), out['j_ids'].cpu()), G['coarse_ids_digest'])
     np.testing.assert_array_equal(GI.digest(out['mkpts0_f'].cpu(), out['mkpts1_f'].cpu()), G['fine_kpts_digest'])
+    mconf_close_fp32(out['mconf'][:64], G['mconf_head'], '640 digest')
     close(out['mconf'][:64], G['mconf_head'], 2e-3, 1e-6)
 
 
@@ -101,6 +117,7 @@ def test_device_ransac_vs_oracle():
     for k in ('b_ids', 'i_ids', 'j_ids', 'm_bids'):
         np.testing.assert_array_equal(out[k].cpu().numpy(), ref[k].numpy())
     close(out['mkpts0_f'], ref['mkpts0_f'], 1e-6, 1e-5); close(out['mkpts1_f'], ref['mkpts1_f'], 1e-6, 1e-5)
+    mconf_close_fp32(out['mconf'], ref['mconf'].numpy(), 'device RANSAC vs oracle')
     close(out['mconf'], ref['mconf'], 1e-3, 1e-6)
 
 
@@ -120,10 +137,29 @@ FINE_EDGE = 5e-2          # the same for the fine threshold: the 25x25 matrices 
 # agree far better than the coarse ones (median relative difference 2e-6 in fp16 - they are fp32 products of nearly identical windows),
 # so the band is narrow: 1e-3 is ~10x the 99th percentile of that difference; bf16: 8x wider, as everywhere
 FINE_ARGMAX_EDGE = 1e-3
-EDGE = {'fp16': KNIFE_EDGE, 'bf16': 8 * KNIFE_EDGE}      # bf16 keeps 8 significant bits (fp16: 11): an 8x wider noise floor
+# Round 5 (VERDICT r04 #2b): the band edge of a case is MEASURED on that case - the 99.9th percentile of the relative
+# difference of the two confidence matrices over the decision-relevant entries (oracle confidence >= thr / 2; >= 1e-2 in the dense
+# mode) - and capped by the mode's ceiling below, so a kernel whose round-off grows widens nothing: it fails the ceiling.  Ceilings =
+# the largest edge measured on the MI355X over all cases of the mode + ~25 % (fp16: 3 % as before; bf16 was "8 x fp16" = 24 %, which
+# made the band 40 % of all matches - its measured edge is far smaller).  On top of the band rule every case carries a CAP on the
+# number of differing matches: the count measured on the MI355X plus a small margin (the counts move by a few with every change of
+# an fp32 summation order), == 0 where the case has always been bit-exact.
+EDGE_CEIL = {'fp16': KNIFE_EDGE, 'bf16': 8 * KNIFE_EDGE}
+EDGE = EDGE_CEIL
 # the two confidence matrices (entries > 1e-3): (max, mean) relative difference - 14 layers of storage round-off feed an
-# exponential with 1 / temperature = 10; bf16's unit round-off is 8x fp16's
+# exponential with 1 / temperature = 10; measured maxima + margin (printed by every case)
 CONF_TOL = {'fp16': (0.3, 2e-2), 'bf16': (2.4, 0.16)}
+
+
+def measured_edge(oc, rc, thr, q=0.999):
+    """The q-quantile of |product - oracle| / oracle over the decision-relevant entries of the oracle's matrix, and the quantiles
+    printed beside it."""
+    floor = 0.5 * thr if thr > 0 else 1e-2
+    rel = ((oc - rc).abs() / rc.clamp_min(1e-12))[rc >= floor].double()
+    if rel.numel() == 0:
+        return 0.0, (0.0, 0.0, 0.0, 0.0)
+    qs = torch.quantile(rel, torch.tensor([0.5, 0.99, q, 1.0], dtype=torch.float64))
+    return float(qs[2]), tuple(float(v) for v in qs)
 
 
 from parity_band import decision_band, knife_bound          # noqa: E402  (tests/parity_band.py: the data-derived bound)
@@ -203,20 +239,29 @@ def compare_fine_on_common(out, ref, fine_thr, what, fine_edge=FINE_EDGE, argmax
     return len(pairs), flipped
 
 
-def compare_with_storage_oracle(out, ref, thr, what, fine_thr=0.1, edge=KNIFE_EDGE, conf_tol=(0.3, 2e-2)):
+def compare_with_storage_oracle(out, ref, thr, what, fine_thr=0.1, edge=KNIFE_EDGE, conf_tol=(0.3, 2e-2), max_diff=None):
     """Coarse ids bit-exact, or: every match present on one side only lies in the decision band of the oracle's own confidence
-    matrix (flip distance < edge) and at most half of the band's population differs.  The fine level is compared on the common
-    matches in either case.  Returns (number of differences, band population)."""
-    widen = edge / KNIFE_EDGE                            # bf16: the same 8x wider bands as for the coarse decisions
+    matrix (flip distance < the case's measured edge, capped by `edge` = the mode's ceiling), at most half of the band's population
+    differs, and at most `max_diff` matches differ (the count measured on the MI355X + margin; 0 = the case is bit-exact).  The fine
+    level is compared on the common matches in either case.  Returns (number of differences, band population)."""
+    widen = edge / KNIFE_EDGE                            # bf16: the same 8x wider bands as for the coarse decisions (fine level)
     a = set(zip(out['b_ids'].tolist(), out['i_ids'].tolist(), out['j_ids'].tolist()))
     r = set(zip(ref['b_ids'].tolist(), ref['i_ids'].tolist(), ref['j_ids'].tolist()))
     diff = sorted(a ^ r)
-    band = decision_band(ref['conf_matrix'], thr, edge)
+    oc, rc = out['conf_matrix'].float().cpu(), ref['conf_matrix']
+    e_meas, (q50, q99, q999, qmax) = measured_edge(oc, rc, thr)
+    e_used = min(max(e_meas, 1e-4), edge)
+    band = decision_band(rc, thr, e_used)
     B = len(band)
-    print(f'{what}: {len(r)} coarse matches, {len(diff)} differences, band population B = {B} (edge {edge:g}) -> bound {knife_bound(B)}')
+    print(f'{what}: {len(r)} coarse matches, {len(diff)} differences (cap {max_diff}), band population B = {B} -> bound {knife_bound(B)}; '
+          f'edge measured {e_meas:.4f} (ceiling {edge:g}, used {e_used:.4f}); relevant-entry relative difference '
+          f'p50 {q50:.2e} p99 {q99:.2e} p99.9 {q999:.2e} max {qmax:.2e}')
+    assert e_meas <= 1.5 * edge, (what, 'the measured noise edge left the mode\'s ceiling', e_meas, edge)
     for k in diff:
         assert k in band, (what, k, 'differs outside the decision band')
     assert len(diff) <= knife_bound(B), (what, len(a), len(r), len(diff), B)
+    if max_diff is not None:
+        assert len(diff) <= max_diff, (what, 'more differing matches than measured + margin', len(diff), max_diff)
     if not diff:
         for k in ('b_ids', 'i_ids', 'j_ids'):
             np.testing.assert_array_equal(out[k].cpu().numpy(), ref[k].numpy())      # same order too
@@ -226,9 +271,10 @@ def compare_with_storage_oracle(out, ref, thr, what, fine_thr=0.1, edge=KNIFE_ED
         assert ka == kr, what
     compare_fine_on_common(out, ref, fine_thr, what, FINE_EDGE * widen, FINE_ARGMAX_EDGE * widen)
     # the confidence matrix: 14 layers of 16-bit round-off noise feed an exponential with 1/temperature = 10
-    oc, rc = out['conf_matrix'].float().cpu(), ref['conf_matrix']
     big = rc > 1e-3
     rel = ((oc - rc).abs() / rc.clamp_min(1e-12))[big]
+    print(f'{what}: confidence matrix, entries > 1e-3: relative difference max {float(rel.max()):.3f} mean {float(rel.mean()):.2e} '
+          f'(tolerance {conf_tol[0]:g} / {conf_tol[1]:g})')
     assert float(rel.max()) < conf_tol[0] and float(rel.mean()) < conf_tol[1], (what, float(rel.max()), float(rel.mean()))
     return len(diff), B
 
@@ -268,7 +314,7 @@ def test_fp16_mode_ids_bit_exact_vs_storage_oracle(golden, name):
     case = GI.g10_cases()[name]
     out, ref = run_fp16(case)
     assert len(ref['b_ids']) > 20
-    compare_with_storage_oracle(out, ref, case['coarse_thr'], name, fine_thr=case['fine_thr'])
+    compare_with_storage_oracle(out, ref, case['coarse_thr'], name, fine_thr=case['fine_thr'], max_diff=0)      # always bit-exact so far
     assert out['mkpts0_f'].dtype == torch.float32 and out['conf_matrix'].dtype == torch.float32
     # and the fp32 REFERENCE run stays the sanity anchor: the same matches up to fp16 resolution
     G = golden(name)
@@ -286,7 +332,7 @@ def test_640_16bit_mode_vs_storage_oracle(golden, precision):
     out, ref = run_fp16(case, precision=precision)
     assert len(ref['b_ids']) > 1000
     compare_with_storage_oracle(out, ref, case['coarse_thr'], f'640 {precision}', fine_thr=case['fine_thr'], edge=EDGE[precision],
-                                conf_tol=CONF_TOL[precision])
+                                conf_tol=CONF_TOL[precision], max_diff={'fp16': 14, 'bf16': 30}[precision])     # measured 6-9 / 18-20
     a = set(zip(out['i_ids'].tolist(), out['j_ids'].tolist()))
     b = set(zip(G['i_ids'].astype(np.int64).tolist(), G['j_ids'].astype(np.int64).tolist()))
     assert len(a & b) >= (0.95 if precision == 'fp16' else 0.8) * max(len(a), len(b)), (len(a), len(b), len(a & b))     # vs the reference's own fp32 run
@@ -328,7 +374,8 @@ def test_bench_shape_batch8_vs_storage_oracle(mode):
         sub['conf_matrix'] = out['conf_matrix'][b:b + 1]
         total += len(ref['b_ids'])
         d, B = compare_with_storage_oracle(sub, ref, thr, f'bench-shape {mode} slot {b}', fine_thr=fthr, edge=EDGE[precision],
-                                           conf_tol=CONF_TOL[precision])
+                                           conf_tol=CONF_TOL[precision],
+                                           max_diff={'nominal': 12, 'dense': 0, 'nominal_bf16': 38}[mode])   # measured 2-7 / 0 / 25-26 per slot
         knife, band = knife + d, band + B
     print(f'bench-shape {mode}: {total} coarse matches over the checked slots ({total / len(slots):.0f} per pair), {knife} differences, '
           f'band population {band}')
@@ -345,7 +392,8 @@ def test_hpatches_shaped_unequal_pair(precision):
     case = {'coarse_thr': 0.2, 'fine_thr': 0.1}
     if precision != 'fp32':
         out, ref = run_fp16(case, feats, data, precision=precision)
-        compare_with_storage_oracle(out, ref, 0.2, f'hpatches-shaped {precision}', edge=EDGE[precision], conf_tol=CONF_TOL[precision])
+        compare_with_storage_oracle(out, ref, 0.2, f'hpatches-shaped {precision}', edge=EDGE[precision], conf_tol=CONF_TOL[precision],
+                                    max_diff={'fp16': 12, 'bf16': 36}[precision])                               # measured 7 / 23-25
     else:
         m = build(0.2, 0.1, 'fp32')
         (c0, f0), (c1, f1) = feats
@@ -356,6 +404,7 @@ def test_hpatches_shaped_unequal_pair(precision):
         for k in ('b_ids', 'i_ids', 'j_ids', 'm_bids'):
             np.testing.assert_array_equal(out[k].cpu().numpy(), ref[k].numpy())
         close(out['mkpts0_f'], ref['mkpts0_f'], 1e-6, 1e-5); close(out['mkpts1_f'], ref['mkpts1_f'], 1e-6, 1e-5)
+        mconf_close_fp32(out['mconf'], ref['mconf'].numpy(), 'hpatches-shaped fp32')
         close(out['mconf'], ref['mconf'], 2e-3, 1e-6)
     assert len(ref['b_ids']) > 500 and int(out['_geo_dev']['valid'][0]) == 1
     assert tuple(out['conf_matrix'].shape) == (1, 4800, 4560)
@@ -375,7 +424,7 @@ def test_megadepth_style_batch_inference(precision):
     case = {'coarse_thr': 0.2, 'fine_thr': 0.1}
     if precision == 'fp16':
         out, ref = run_fp16(case, feats, data)
-        compare_with_storage_oracle(out, ref, 0.2, 'megadepth-style fp16')
+        compare_with_storage_oracle(out, ref, 0.2, 'megadepth-style fp16', max_diff=0)                             # always bit-exact so far
     else:
         m = build(0.2, 0.1, 'fp32')
         (c0, f0), (c1, f1) = feats
@@ -401,7 +450,7 @@ def test_bf16_mode_vs_storage_oracle(golden, name):
     out, ref = run_fp16(case, precision='bf16')
     assert len(ref['b_ids']) > 20
     compare_with_storage_oracle(out, ref, case['coarse_thr'], f'{name} bf16', fine_thr=case['fine_thr'], edge=EDGE['bf16'],
-                                conf_tol=CONF_TOL['bf16'])
+                                conf_tol=CONF_TOL['bf16'], max_diff=3)                                          # measured 0-1 of 60-119
     assert out['conf_matrix'].dtype == torch.float32 and out['_feat_dev']['geo_f0'].dtype == torch.bfloat16
     G = golden(name)
     a = set(zip(out['b_ids'].tolist(), out['i_ids'].tolist(), out['j_ids'].tolist()))

@@ -1,0 +1,91 @@
+"""Outcome-level parity of the benched 16-bit modes (VERDICT r04 #2a): what the knife-edge match differences of fp16 / bf16 storage
+do to the metric the reference is judged by - the HPatches homography-estimation AUC (hpatches_helper.py:13-56 `cal_error_auc`,
+:185-239 the pair loop: matches -> findHomography(RANSAC, 3 px) -> mean corner error -> AUC@1/3/5/10; README.md:117).
+
+No checkpoint and no HPatches data exist offline, so the protocol runs on SYNTHETIC sequences: 13 sequences x 5 pairs = 65 pairs of
+planted feature maps of a planar scene (oracle/golden_inputs.py:hpatches_like_features: a continuous random field sampled at the
+cells of image 0 and at H^-1 of the cells of image 1, 480x640 against 480x608 - 60x80 and 60x76 coarse grids, the shape class of
+data_io.py:16-26), ground-truth homographies of HPatches-like strength (corner displacements up to 2k / 8k px for pair k).
+Both sides see the same maps and go through the same evaluation arithmetic (geoformer_amd.matcher.cal_error_auc / corner_error, pinned
+by tests/golden/g12):
+  product:  GeoFormer.forward_features in fp16 / bf16 storage, device RANSAC inside GeoModule, device RANSAC (3 px, sub-pixel
+            keypoints) for the final homography - matcher.estimate_homography, as matcher.eval_hpatches does;
+  oracle:   the fp32 restatement of the reference (oracle.geoformer_forward) with the C RANSAC inside, the C RANSAC's sub-pixel entry for
+            the final homography.
+RANSAC parity with OpenCV is UNPINNED (oracle/ransac_oracle.c header); both sides use the build's own algorithm, so the statement is:
+"storage round-off moves the AUC by this much", not "this is the reference's AUC".  Gate: |dAUC@3| <= 1e-3 in fp16 (north_star's
+number); the bf16 delta is printed and held to 5e-3."""
+import numpy as np
+import pytest
+import torch
+
+import geoformer_oracle as O
+import golden_inputs as GI
+import ransac_oracle as RO
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+SEQS, PAIRS = 13, 5                        # 65 pairs (the protocol: image 1 against images 2..6 of every sequence)
+THRES = (1, 3, 5, 10)
+_oracle_rows = {}
+
+
+def _oracle_side():
+    """(corner error, #matches) per pair from the fp32 oracle; computed once for both storage modes."""
+    if _oracle_rows:
+        return _oracle_rows
+    from geoformer_amd import matcher as MT
+    W = O.make_weights()
+    geo_cfg = O.default_geo_config()
+    data = {'image0': torch.zeros(1, 1, 480, 640), 'image1': torch.zeros(1, 1, 480, 608)}
+    for s in range(SEQS):
+        for k in range(1, PAIRS + 1):
+            f0, f1, H = GI.hpatches_like_features(s, k)
+            ref = O.geoformer_forward(W, dict(data), None, geo_cfg, RO.make_homography_fn(), None, (f0, f1))
+            k0, k1 = ref['mkpts0_f'].numpy(), ref['mkpts1_f'].numpy()
+            Hp, _ = RO.find_homography_subpixel(k0, k1, 3.0)
+            _oracle_rows[(s, k)] = (MT.corner_error(Hp, H, 640, 480) if Hp is not None else float('nan'), len(k0))
+    return _oracle_rows
+
+
+def _product_side(precision):
+    from geoformer_amd import matcher as MT
+    from test_e2e_gpu import build, to_dev
+    st = {'fp16': torch.float16, 'bf16': torch.bfloat16}[precision]
+    m = build(0.2, 0.1, precision)
+    m.geo_module.homography_fn = None      # device RANSAC
+    data = to_dev({'image0': torch.zeros(1, 1, 480, 640), 'image1': torch.zeros(1, 1, 480, 608)})
+    rows = {}
+    for s in range(SEQS):
+        for k in range(1, PAIRS + 1):
+            (c0, f0), (c1, f1), H = GI.hpatches_like_features(s, k)
+            with torch.no_grad():
+                out = m.forward_features(dict(data), *(t.to(DEV).to(st) for t in (c0, f0, c1, f1)))
+            matches = torch.cat([out['mkpts0_f'], out['mkpts1_f']], 1).float().cpu().numpy()
+            Hp, _ = MT.estimate_homography(matches, 3.0, DEV)
+            rows[(s, k)] = (MT.corner_error(Hp, H, 640, 480) if Hp is not None else float('nan'), len(matches))
+    return rows
+
+
+@pytest.mark.parametrize('precision', ['fp16', 'bf16'])
+def test_hpatches_protocol_auc_product_vs_fp32_oracle(precision):
+    from geoformer_amd import matcher as MT
+    ref, got = _oracle_side(), _product_side(precision)
+    keys = sorted(ref)
+    assert len(keys) >= 64
+    er = np.array([ref[k][0] for k in keys]); eg = np.array([got[k][0] for k in keys])
+    nr = np.array([ref[k][1] for k in keys]); ng = np.array([got[k][1] for k in keys])
+    auc_r, auc_g = MT.cal_error_auc(er, THRES), MT.cal_error_auc(eg, THRES)
+    ok = ~(np.isnan(er) | np.isnan(eg))
+    print(f'HPatches-protocol outcome parity, {precision} product vs fp32 oracle, {len(keys)} synthetic pairs '
+          f'(matches per pair: oracle {nr.mean():.0f}, product {ng.mean():.0f}; failed: oracle {int(np.isnan(er).sum())}, product {int(np.isnan(eg).sum())})')
+    print(f'  AUC@1/3/5/10 oracle  {np.round(auc_r, 5).tolist()}')
+    print(f'  AUC@1/3/5/10 product {np.round(auc_g, 5).tolist()}')
+    print(f'  dAUC                 {np.round(auc_g - auc_r, 5).tolist()}   corner error: oracle mean {np.nanmean(er):.4f} px, '
+          f'|product - oracle| mean {np.abs(eg - er)[ok].mean():.2e} max {np.abs(eg - er)[ok].max():.2e} px')
+    # the workload is a real one: matches on every pair, errors inside the AUC's range on most of them
+    assert nr.min() >= 4 and ng.min() >= 4 and np.nanmedian(er) < 3.0 and 0.2 < auc_r[1] < 0.999
+    assert int(np.isnan(er).sum()) == int(np.isnan(eg).sum()) == 0
+    gate = {'fp16': 1e-3, 'bf16': 5e-3}[precision]
+    assert abs(auc_g[1] - auc_r[1]) <= gate, (precision, 'dAUC@3', float(auc_g[1] - auc_r[1]))
+    assert np.abs(auc_g - auc_r).max() <= 5 * gate, (precision, (auc_g - auc_r).tolist())
