@@ -25,6 +25,7 @@ One JSON line on rank 0 (see README / DESIGN.md for the fields).
 import argparse
 import ctypes
 import json
+import math
 import os
 import socket
 import subprocess
@@ -89,6 +90,7 @@ def parse_args(argv=None):
                          'output (rounds 3\'s headline; now the side measurement nominal_independent)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the nominal-load and fp32 parity-mode side measurements')
+    ap.add_argument('--no-train', action='store_true', help='skip the training-step side measurement (BASELINE configs[2] / [3])')
     ap.add_argument('--dry-run', action='store_true',
                     help='launcher / rendezvous / shard plan only, on CPU over gloo (what tests/test_bench_launcher.py runs)')
     return ap.parse_args(argv)
@@ -161,6 +163,55 @@ def spawn_ranks(args, argv):
     return 0
 
 
+def _cpulist(text):
+    out = []
+    for part in text.strip().split(','):
+        if part:
+            a, _, b = part.partition('-')
+            out += list(range(int(a), int(b or a) + 1))
+    return out
+
+
+def rank_cpu_set(local, nlocal, allowed=None, sysfs='/sys'):
+    """The host cores rank `local` of `nlocal` on this node should run on: the cores of its GPU's NUMA node (amdgpu PCI functions in
+    bus order = HIP device order; ranks that share a node split its cores), else an even contiguous split of the allowed cores.  Reads
+    sysfs only - nothing here touches the GPU, so it can run before the first HIP call of the process."""
+    allowed = sorted(os.sched_getaffinity(0)) if allowed is None else sorted(allowed)
+    nodes = []
+    try:
+        drv = os.path.join(sysfs, 'bus/pci/drivers/amdgpu')
+        for d in sorted(x for x in os.listdir(drv) if ':' in x):
+            nodes.append(int(open(os.path.join(drv, d, 'numa_node')).read()))
+    except (OSError, ValueError):
+        nodes = []
+    if len(nodes) >= nlocal and all(n >= 0 for n in nodes[:nlocal]):
+        node = nodes[local]
+        try:
+            cores = [c for c in _cpulist(open(os.path.join(sysfs, f'devices/system/node/node{node}/cpulist')).read()) if c in set(allowed)]
+        except OSError:
+            cores = []
+        sharers = [r for r in range(nlocal) if nodes[r] == node]
+        if len(cores) >= len(sharers):
+            k, per = sharers.index(local), len(cores) // len(sharers)
+            return cores[k * per:(k + 1) * per]
+    per = max(1, len(allowed) // max(nlocal, 1))
+    return allowed[local * per:(local + 1) * per] or allowed
+
+
+def pin_rank(local, nlocal):
+    """Per-rank CPU affinity: set inside the rank's own process BEFORE anything initialises the GPU (never through
+    taskset / numactl in front of a profiled program: that is an exec after the profiler's preload has touched the GPU).  The two
+    host pipelines, the caching allocator's and RCCL's helper threads inherit it."""
+    if nlocal <= 1 or os.environ.get('GEOFORMER_BENCH_NO_PIN') == '1':
+        return None
+    cores = rank_cpu_set(local, nlocal)
+    try:
+        os.sched_setaffinity(0, cores)
+    except OSError:
+        return None
+    return cores
+
+
 def dist_env(args):
     rank, local, world = (int(os.environ.get(k, d)) for k, d in (('RANK', 0), ('LOCAL_RANK', 0), ('WORLD_SIZE', 1)))
     if world != args.gpus:
@@ -175,7 +226,8 @@ def dry_run(args):
     import torch
     import torch.distributed as dist
     from geoformer_amd.shard import shard_bounds
-    rank, _, world = dist_env(args)
+    rank, local, world = dist_env(args)
+    pinned = pin_rank(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
     if os.environ.get('GEOFORMER_BENCH_FAIL_RANK') == str(rank):          # launcher test: a rank that dies before the rendezvous
         raise SystemExit(3)
     if world > 1:
@@ -194,12 +246,15 @@ def dry_run(args):
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_gather_object(plan, (rank, lo, hi))
+        pins = [None] * world
+        dist.all_gather_object(pins, sorted(pinned) if pinned else None)
     else:
         plan = [(rank, lo, hi)]
+        pins = [None]
     if rank == 0:
         print(json.dumps({'metric': 'image-pairs/sec (640x640)', 'value': 0.0, 'unit': 'image-pairs/s', 'n_gpus': world,
                           'steps': args.steps, 'warmup': args.warmup, 'dry_run': True, 'elapsed_max_s': float(t[0]),
-                          'shard_plan': plan, 'scaling': 'weak'}), flush=True)
+                          'shard_plan': plan, 'scaling': 'weak', 'rank_cpu_sets': pins}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -541,6 +596,7 @@ def main(argv=None):
     if args.dry_run:
         return dry_run(args)
     rank, local, world = dist_env(args)
+    pinned = pin_rank(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)))          # before the first GPU call of this process
 
     # MIOpen's convolution search results for the bench shapes are shipped with the repo (plain-text user find-db
     # for gfx950), so warm-up looks the algorithms up instead of re-running a multi-minute search; every process
@@ -636,15 +692,16 @@ def main(argv=None):
     solo = {tag: collect(tag) for tag, _, _, _ in ROOFLINE_TAGS}
     L.gf_profile_enable(0)
     host_us = host_launch_us(model, batches, planted)
+    own_times = [float(v) for v in rep_times]                   # this rank's own regions (before the MAX over ranks)
     if dist is not None:
         t = torch.tensor(rep_times, device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)                # every region: the slowest rank's time
         rep_times = [float(v) for v in t]
         elapsed = rep_times[0]
         rows = [None] * world
-        dist.all_gather_object(rows, (sum(Ms), sum(Mfs), len(Ms), rank, lo, hi))
+        dist.all_gather_object(rows, (sum(Ms), sum(Mfs), len(Ms), rank, lo, hi, own_times, host_us, len(pinned) if pinned else 0))
     else:
-        rows = [(sum(Ms), sum(Mfs), len(Ms), rank, lo, hi)]
+        rows = [(sum(Ms), sum(Mfs), len(Ms), rank, lo, hi, own_times, host_us, 0)]
     if rank != 0:
         pipes.close()
         if dist is not None:
@@ -696,7 +753,15 @@ def main(argv=None):
         # the spread of the measurement: `repeats` timed regions of K steps each, back to back; [0] is `value`
         'repeats': {'n': len(rep_times), 'pairs_per_s': [pairs / t for t in rep_times], 'min': pairs / max(rep_times),
                     'median': pairs / sorted(rep_times)[len(rep_times) // 2], 'max': pairs / min(rep_times)},
-        'shard_plan': sorted([list(r[3:6]) for r in rows]),     # [rank, first pair, one past the last pair] of the job's pair list
+        'repeats_min': pairs / max(rep_times), 'repeats_median': pairs / sorted(rep_times)[len(rep_times) // 2],
+        'repeats_max': pairs / min(rep_times),     # top-level scalars (a parser that keeps only scalar keys sees the spread too)
+        'shard_plan': sorted([list(r[3:6]) for r in rows]),
+        # rank skew: every rank's OWN time for the region `value` is quoted on (the line's ms_per_step is their MAX),
+        # its host launch time per step and the number of host cores it is pinned to (0 = not pinned: a single rank)
+        'per_rank': [{'rank': r[3], 'ms_per_step': 1e3 * r[6][0] / args.steps, 'host_launch_us_per_step': r[7], 'pinned_cores': r[8]}
+                     for r in sorted(rows, key=lambda r: r[3])],
+        'rank_ms_per_step_min': 1e3 * min(r[6][0] for r in rows) / args.steps,
+        'rank_ms_per_step_max': 1e3 * max(r[6][0] for r in rows) / args.steps,     # [rank, first pair, one past the last pair] of the job's pair list
         'config': {'workload': f'batched inference, synthetic {args.size}x{args.size} pairs (BASELINE configs[4]: static shard of the '
                                f'pair list, {args.steps * args.batch} pairs per GPU), ' +
                                ('NOMINAL LOAD: ResNet-FPN backbone on the images, matching path on planted-correspondence feature maps '
@@ -722,6 +787,12 @@ def main(argv=None):
         if ind:                                   # what the two extra elementwise passes of the dependency cost the headline
             res['side_measurements']['dependency_cost_pct'] = 100.0 * (ind['value'] - res['value']) / ind['value']
     pipes.close()
+    if world == 1 and not args.no_extras and not args.no_train:
+        del model, batches, planted
+        torch.cuda.empty_cache()
+        res['side_measurements']['train_step'] = train_measurements(dev, log)
+        for k, v in res['side_measurements']['train_step'].items():      # top-level scalars as well
+            res[f'train_{k}_pairs_per_s'], res[f'train_{k}_ms_per_step'] = v['value'], v['ms_per_step']
     if not args.no_cpu_baseline and world == 1:          # reported on rank 0 at N = 1 only
         res['cpu_baseline'] = cpu_baseline(W, args.coarse_thr, args.fine_thr, args.size, args.pairs)
     print(json.dumps(res), flush=True)
@@ -825,6 +896,47 @@ def side_measurements(args, model, dev, log, L, batches=None, planted=None, pipe
         del m32
         torch.cuda.empty_cache()
         log(f"parity mode (fp32): {out['parity_mode']['value']:.1f} pairs/s")
+    return out
+
+
+def train_measurements(dev, log, steps=5, warmup=2):
+    """The training step of BASELINE configs[2] / [3] at their per-GPU sizes (VERDICT r04 #6a), N = 1: mixed bf16 (fp32 master weights,
+    `train_depth_geoformer.py:117-119`) with the fused HIP coarse loss and the HIP forward + backward Functions
+    (`TrainStep(precision='bf16', fused_coarse_loss=True, hip_backward=True)`): supervision -> forward -> loss -> backward -> clipped
+    AdamW step (`lightning_homo_geoformer.py:69-107`), batches made outside the timed steps.
+      configs2_homo:      640 x 480 synthetic homography pairs, batch 4 per GPU (batch 32 over 8 GPUs; `homo_trainval_640.py:5`)
+      configs3_megadepth: 640 x 640 MegaDepth-style pairs (depth + pose supervision, padding masks, per-image scales), batch 8 per GPU
+    Closed-form random-init weights, thresholds 0 / 0 (untrained weights give no match above 0.2); a side measurement, never `value`."""
+    import torch
+    from geoformer_amd.model.cvpr_ds_config import get_default_cfg
+    from geoformer_amd.model.full_model import GeoFormer
+    from geoformer_amd.model.geo_config import get_cfg_model
+    from geoformer_amd.weights import deterministic_init_
+    from geoformer_amd.train import TrainStep, synthetic_homography_batch, synthetic_megadepth_batch
+    out = {}
+    for key, make, hw, batch in (('configs2_homo', synthetic_homography_batch, (480, 640), 4),
+                                 ('configs3_megadepth', synthetic_megadepth_batch, (640, 640), 8)):
+        g = get_cfg_model()
+        g.update(coarse_thr=0.0, fine_thr=0.0, precision='fp32')
+        model = deterministic_init_(GeoFormer(get_default_cfg(), g)).to(dev)
+        step = TrainStep(model, batch_size=batch, fused_coarse_loss=True, precision='bf16', hip_backward=True)
+        data = [make(batch, hw, seed=900 + i, device=dev) for i in range(warmup + steps)]
+        losses = []
+        for i in range(warmup):
+            losses.append(float(step(data[i])))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(warmup, warmup + steps):
+            losses.append(step(data[i]))
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        losses = [float(v) for v in losses]
+        out[key] = {'value': steps * batch / el, 'unit': 'image-pairs/s', 'ms_per_step': 1e3 * el / steps, 'steps': steps, 'warmup': warmup,
+                    'batch_per_gpu': batch, 'image_hw': list(hw), 'precision': 'mixed bf16 (fp32 master weights)', 'hip_backward': True,
+                    'fused_coarse_loss': True, 'losses': losses, 'finite': all(math.isfinite(v) for v in losses)}
+        log(f"train step {key}: {out[key]['ms_per_step']:.1f} ms at batch {batch} = {out[key]['value']:.1f} pairs/s, losses {losses[0]:.3f} -> {losses[-1]:.3f}")
+        del step, model, data
+        torch.cuda.empty_cache()
     return out
 
 

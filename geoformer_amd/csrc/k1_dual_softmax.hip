@@ -71,6 +71,7 @@ struct K1Args {
     float thr;
     int dense;                     // thr so low that candidates are not rare: reduce in the tile first
     unsigned long long* stamp;     // [K1_STAMP_WORDS] or null: what the statistics in this workspace belong to (k1_stamp_words)
+    int esize;                     // bytes per feature element (the stamp's content fingerprint samples whole 8-byte words)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -306,7 +307,26 @@ __global__ __launch_bounds__(NT, 4) void k1_stats(K1Args a) {
 // The row / column statistics a gf_dual_softmax_match call leaves in its workspace are stamped with what they were computed
 // from (shape, scale, the two feature pointers); gf_dual_softmax_conf_at compares the stamp with its own arguments on the
 // device and returns NaN for every entry when they differ (nothing else ties a later conf_at call to that call).
-constexpr int K1_STAMP_WORDS = 5;
+// Round 5: the caching allocator hands the address of a freed feature tensor to the next one of the same shape (the
+// second CoarseMatching pass, the next batch), so pointers alone do not tell whose statistics the workspace holds: the LAST word is a
+// fingerprint of the CONTENT - 32 eight-byte samples of each tensor, evenly spaced, one per lane of a wave, mixed and XOR-reduced.
+constexpr int K1_STAMP_WORDS = 5;          // the words k1_stamp_word() makes; word K1_STAMP_WORDS is the fingerprint
+__device__ __forceinline__ unsigned long long k1_fingerprint(const void* f0, const void* f1, size_t bytes0, size_t bytes1, int lane) {
+    const bool second = lane >= 32;
+    const unsigned long long* p = (const unsigned long long*)(second ? f1 : f0);
+    const size_t words = (second ? bytes1 : bytes0) / 8;
+    const int k = lane & 31;
+    unsigned long long w = words ? p[(words - 1) * (size_t)k / 31] : 0ull;
+    w = (w + 0x9e3779b97f4a7c15ull * (unsigned long long)(lane + 1)) * 0xff51afd7ed558ccdull;
+    w ^= w >> 33;
+    unsigned lo = (unsigned)w, hi = (unsigned)(w >> 32);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        lo ^= (unsigned)__shfl_xor((int)lo, d, 64);
+        hi ^= (unsigned)__shfl_xor((int)hi, d, 64);
+    }
+    return ((unsigned long long)hi << 32) | lo;
+}
 __host__ __device__ __forceinline__ unsigned long long k1_stamp_word(int k, const void* f0, const void* f1, int N, int L, int S, int C, float mult) {
     union { float f; unsigned u; } m;
     m.f = mult;
@@ -326,8 +346,11 @@ __global__ __launch_bounds__(256) void k1_reduce_stats(K1Args a) {
     __shared__ float2 sh[8][32];
     const int n = blockIdx.z;
     const bool rows = blockIdx.y == 0;
-    if (a.stamp != nullptr && threadIdx.x < K1_STAMP_WORDS && blockIdx.x == 0 && blockIdx.y == 0 && n == 0)
-        a.stamp[threadIdx.x] = k1_stamp_word(threadIdx.x, a.f0, a.f1, a.N, a.L, a.S, a.C, a.mult);
+    if (a.stamp != nullptr && threadIdx.x < 64 && blockIdx.x == 0 && blockIdx.y == 0 && n == 0) {          // wave 0 of one block
+        const unsigned long long fp = k1_fingerprint(a.f0, a.f1, (size_t)a.N * a.L * a.C * a.esize, (size_t)a.N * a.S * a.C * a.esize, threadIdx.x);
+        if (threadIdx.x < K1_STAMP_WORDS) a.stamp[threadIdx.x] = k1_stamp_word(threadIdx.x, a.f0, a.f1, a.N, a.L, a.S, a.C, a.mult);
+        if (threadIdx.x == K1_STAMP_WORDS) a.stamp[K1_STAMP_WORDS] = fp;
+    }
     const int len = rows ? a.L : a.S, np = rows ? a.rowparts : a.tilesM;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + tx;
@@ -1193,6 +1216,8 @@ __global__ __launch_bounds__(256) void k1_conf_at(SelArgs a, const int64_t* b, c
     bool ok = true;
 #pragma unroll
     for (int k = 0; k < K1_STAMP_WORDS; ++k) ok = ok && a.stamp[k] == k1_stamp_word(k, a.f0, a.f1, a.N, a.L, a.S, a.C, a.mult);
+    ok = ok && a.stamp[K1_STAMP_WORDS] == k1_fingerprint(a.f0, a.f1, (size_t)a.N * a.L * a.C * sizeof(H), (size_t)a.N * a.S * a.C * sizeof(H),
+                                                         threadIdx.x & 63);
     const long long bb = b[e], ii = i[e], jj = j[e];
     ok = ok && bb >= 0 && bb < a.N && ii >= 0 && ii < a.L && jj >= 0 && jj < a.S;
     if (!ok) {                                                              // wave-uniform: e is per wave
@@ -1399,7 +1424,7 @@ K1Workspace k1_carve(void* ws, int N, int L, int S) {
     w.cstat = c.take<float2>((size_t)N * S);
     w.selj = c.take<int>((size_t)N * L);
     w.scanlist = c.take<int>((size_t)N * L);
-    w.stamp = c.take<unsigned long long>(K1_STAMP_WORDS);
+    w.stamp = c.take<unsigned long long>(K1_STAMP_WORDS + 1);
     w.bytes = c.used();
     return w;
 }
@@ -1719,6 +1744,7 @@ extern "C" int gf_dual_softmax_match(const void* f0, const void* f1, int dtype, 
     a.rowpart = w.rowpart; a.colpart = w.colpart; a.rstat = w.rstat; a.cstat = w.cstat;
     a.rowbest = w.rowbest; a.colmax = w.colmax; a.conf = conf; a.thr = thr; a.dense = thr < 0.05f;
     a.stamp = w.stamp;
+    a.esize = dtype == GF_F32 ? 4 : 2;
     SelArgs s;
     s.N = N; s.L = L; s.S = S;
     s.rowbest = w.rowbest; s.colmax = w.colmax; s.colset = w.colset; s.conf = conf; s.stamp = w.stamp;

@@ -26,6 +26,7 @@ constexpr int HD = 64;      // head dim
 constexpr int NH = 4;       // heads  (geo_config.py:12)
 constexpr int CC = 256;     // channels
 constexpr int KT = 32;      // keys per tile
+constexpr float K4_DEFER = 8.0f;   // 16-bit modes: a query's softmax reference moves only when a tile's maximum exceeds it by this much (log2 units)
 
 struct AtArgs {
     const void* q;          // [N][L][ldq]
@@ -49,14 +50,15 @@ __device__ __forceinline__ int vt_pos(int p) { return (p & 19) | ((p & 4) << 1) 
 
 template <typename T>
 __global__ __launch_bounds__(256) void attn_gather_kv(AtArgs a) {
-    const int n = blockIdx.y, p0 = blockIdx.x * KT, t = threadIdx.x;
+    const int n = blockIdx.y, t = threadIdx.x;
     const int K = a.nkeys[(size_t)n * a.nkeys_stride];
-    if (p0 >= ((K + KT - 1) / KT) * KT) return;
     const int32_t* idx = a.idx + (size_t)n * a.idx_stride;
     const T* km = (const T*)a.kmap + (size_t)n * a.L * a.ldk;
     const T* vm = (const T*)a.vmap + (size_t)n * a.L * a.ldv;
-    T* kc = (T*)a.kc + ((size_t)n * a.Kpad + p0) * CC;
     if constexpr (std::is_same<T, float>::value) {
+        const int p0 = blockIdx.x * KT;
+        if (p0 >= ((K + KT - 1) / KT) * KT) return;
+        T* kc = (T*)a.kc + ((size_t)n * a.Kpad + p0) * CC;
         T* vc = (T*)a.vc + ((size_t)n * a.Kpad + p0) * CC;
         for (int p = 0; p < KT; ++p) {
             const bool ok = p0 + p < K;
@@ -65,19 +67,38 @@ __global__ __launch_bounds__(256) void attn_gather_kv(AtArgs a) {
             vc[(size_t)p * CC + t] = ok ? vm[(size_t)tok * a.ldv + t] : 0.f;
         }
     } else {
-        T vt[KT];
-#pragma unroll
-        for (int p = 0; p < KT; ++p) {
-            const bool ok = p0 + p < K;
-            const int tok = ok ? idx[p0 + p] : 0;
-            kc[(size_t)p * CC + t] = ok ? km[(size_t)tok * a.ldk + t] : (T)0;
-            vt[vt_pos(p)] = ok ? vm[(size_t)tok * a.ldv + t] : (T)0;
-        }
+        // 16-bit modes (round 5): EIGHT keys per workgroup instead of 32 - four times the workgroups (the 32-key form ran 608 of
+        // them at 1195 keys x 16 images: 2.4 per CU, each a chain of 64 two-byte loads per thread; 22 us for 39 MB) - and the K rows
+        // move as 16-byte pieces (thread = row t >> 5, piece t & 31: one load + one store per thread); V^T: thread = channel, its 8
+        // keys land as two 8-byte pieces of the channel's 64-byte row of the 32-key block (vt_pos swaps key bits 2 and 3).
+        constexpr int KS = 8;
         using V8 = gf_vec<T, 8>;
-        V8* dst = reinterpret_cast<V8*>((T*)a.vc + ((size_t)n * CC + t) * a.Kpad + p0);
+        using V4 = gf_vec<T, 4>;
+        const int kround = ((K + KT - 1) / KT) * KT;                     // the ragged tile's spare key slots are written as zeros
+        // (the key count lives on the device: a fixed grid of 64 workgroups per image walks the sub-blocks instead of one workgroup
+        // per possible sub-block, of which 4 in 5 would find nothing to do)
+        for (int p0 = blockIdx.x * KS; p0 < kround; p0 += gridDim.x * KS) {
+            {
+                const int row = t >> 5, piece = t & 31;
+                const bool ok = p0 + row < K;
+                const int tok = ok ? idx[p0 + row] : 0;
+                V8 v = *reinterpret_cast<const V8*>(km + (size_t)tok * a.ldk + piece * 8);
+                if (!ok) v = V8{(T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0};
+                *reinterpret_cast<V8*>((T*)a.kc + ((size_t)n * a.Kpad + p0 + row) * CC + piece * 8) = v;
+            }
+            T vt[KS];
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            dst[c] = V8{vt[8 * c], vt[8 * c + 1], vt[8 * c + 2], vt[8 * c + 3], vt[8 * c + 4], vt[8 * c + 5], vt[8 * c + 6], vt[8 * c + 7]};
+            for (int j = 0; j < KS; ++j) {
+                const bool ok = p0 + j < K;
+                const int tok = ok ? idx[p0 + j] : 0;
+                vt[j] = ok ? vm[(size_t)tok * a.ldv + t] : (T)0;
+            }
+            // key p = 8 c + j of its 32-key block (c = sub-block): position (j & 3) | (c & 1) << 2 | (j >> 2) << 3 | (c >> 1) << 4
+            const int blk = p0 / KT, c = (p0 % KT) / KS;
+            T* dst = (T*)a.vc + ((size_t)n * CC + t) * a.Kpad + blk * KT + ((c & 1) << 2) + ((c >> 1) << 4);
+            *reinterpret_cast<V4*>(dst) = V4{vt[0], vt[1], vt[2], vt[3]};
+            *reinterpret_cast<V4*>(dst + 8) = V4{vt[4], vt[5], vt[6], vt[7]};
+        }
     }
 }
 
@@ -117,8 +138,15 @@ __device__ __forceinline__ float half_max(float x) {
     return fmaxf(__uint_as_float(sw.x), __uint_as_float(sw.y));
 }
 
-template <typename T, int QB>
-__global__ __launch_bounds__(256, QB <= 2 ? 2 : 1) void attn_self(AtArgs a) {
+// WV = 4: one wave per head, QB query blocks per wave.  WV = 8 (16-bit modes): two waves per head (query groups of 32 QB queries
+// each) share every staged tile - half the L2 -> LDS bytes per query, and with QB = 1 the wave fits 128 registers: four waves per
+// SIMD (two workgroups of eight) cover each other's LDS / MFMA latencies where two waves per SIMD ran nearly serially.
+// WV = 16 (round 5): FOUR waves per head, one 32-query block each - a staged tile serves 128 queries of every head (the L2 -> LDS
+// stream, not the matrix pipe, is what paces the two-wave forms: 1.95 GB per 16-image call at 1195 keys = 37 GB/s per CU, half of what
+// the LDS-DMA path reaches), 16 waves = four per SIMD, and a THREE-image ring: the tile after next is already requested when a tile is
+// computed (counted vmcnt: the wait at a tile's top leaves the next tile's pieces in flight).
+template <typename T, int QB, int WV>
+__global__ __launch_bounds__(64 * WV, WV == 16 ? 4 : WV == 8 ? (QB == 1 ? 4 : 2) : (QB <= 2 ? 2 : 1)) void attn_self(AtArgs a) {
     using M = Mma32<T>;
     using Frag = typename M::Frag;
     constexpr bool F32 = std::is_same<T, float>::value;
@@ -132,8 +160,9 @@ __global__ __launch_bounds__(256, QB <= 2 ? 2 : 1) void attn_self(AtArgs a) {
     const int gx = gridDim.x, total = gx * gridDim.y;
     int id = blockIdx.y * gx + blockIdx.x;
     if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
-    const int n = id / gx, q0 = (id - n * gx) * (32 * QB), tid = threadIdx.x;
-    const int head = tid >> 6, lane = tid & 63, h = lane >> 5, lr = lane & 31;
+    const int tid = threadIdx.x;
+    const int n = id / gx, q0 = (id - n * gx) * (32 * QB * (WV / 4)) + (tid >> 8) * (32 * QB);
+    const int head = (tid >> 6) & 3, lane = tid & 63, h = lane >> 5, lr = lane & 31;
     const int K = a.nkeys[(size_t)n * a.nkeys_stride];
     // QB blocks of 32 queries per wave: a staged K / V tile (32 keys x 256 channels, 32 KiB) serves 32 QB queries of every head
     // (with one block a workgroup streams the image's whole K and V for 32 queries: L2-bound at ~1200 keys)
@@ -161,6 +190,8 @@ __global__ __launch_bounds__(256, QB <= 2 ? 2 : 1) void attn_self(AtArgs a) {
     // logits in log2 units: exp(x - m) = exp2(x' - m') with x' = s * (temp * log2 e): one multiply per element instead of two
     constexpr bool FAST = !std::is_same<T, float>::value;              // 16-bit modes: hardware exponential
     const float scale2 = FAST ? a.softmax_temp * 1.44269504088896341f : a.softmax_temp;
+    const float defer = K4_DEFER / scale2;                                // the threshold on the unscaled logits (16-bit modes)
+    (void)defer;
     auto compute = [&](int tile, const char* ks, const char* vs) {
         const bool ragged = (tile + 1) * KT > K;          // only the last tile can hold key slots beyond K
 #pragma unroll
@@ -198,22 +229,28 @@ __global__ __launch_bounds__(256, QB <= 2 ? 2 : 1) void attn_self(AtArgs a) {
                     }
                 }
                 tmax = half_max(tmax);
-                const float mnew = fmaxf(m[qb], tmax);          // finite: every tile holds at least one real key
-                const float nms = -mnew * scale2;
-    #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    x[r] = __builtin_amdgcn_exp2f(fmaf(x[r], scale2, nms));
-                    psum += x[r];
-                }
-                if (__any(mnew != m[qb])) {                     // a running maximum moved somewhere in the wave: rescale (else alpha = 1)
-                    const float alpha = __builtin_amdgcn_exp2f((m[qb] - mnew) * scale2);
+                // Deferred reference (round 5; guide T13): a query's m moves only when its tile maximum exceeds it by more than
+                // K4_DEFER = 8 in the exponent's log2 units (always in the first tile: m = -inf), so P <= 2^8 - exact in fp16 / bf16 up
+                // to their rounding, the row sum is fp32 - and the rescale of O, which the wave-wide test `some running maximum moved`
+                // ran in nearly every one of 38 tiles (a third of the kernel's vector instructions), becomes a rare side path.  Only
+                // the queries that need it change m (alpha = 1 for the others): a per-query rule, restated in the oracle.
+                const bool need = tmax - m[qb] > defer;         // tmax finite: every tile holds at least one real key
+                if (__any(need)) {
+                    const float mnew = need ? tmax : m[qb];
+                    const float alpha = __builtin_amdgcn_exp2f((m[qb] - mnew) * scale2);      // 0 in the first tile (O = l = 0)
                     l[qb] *= alpha;
     #pragma unroll
                     for (int b = 0; b < 2; ++b)
     #pragma unroll
                         for (int r = 0; r < 16; ++r) o[qb][b][r] *= alpha;
+                    m[qb] = mnew;
                 }
-                m[qb] = mnew;
+                const float nms = -m[qb] * scale2;
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    x[r] = __builtin_amdgcn_exp2f(fmaf(x[r], scale2, nms));
+                    psum += x[r];
+                }
             } else {
                 if (ragged) {
     #pragma unroll
@@ -313,32 +350,60 @@ __global__ __launch_bounds__(256, QB <= 2 ? 2 : 1) void attn_self(AtArgs a) {
         const AtRsrc rv = at_rsrc((const T*)a.vc + (size_t)n * CC * a.Kpad, (unsigned)((size_t)CC * a.Kpad * sizeof(T)));
         // K image: 1 KiB group g = key rows 2g, 2g+1; slot s of row r holds chunk s ^ (r & 15) (k_off)
         // V^T image: group g = channels 16g..16g+15, 4 slots of 16 B; slot s of channel c holds chunk s ^ ((c >> 2) & 3) (vt_off)
-        int kvo[4], vvo[4];
+        constexpr int PW = 16 / WV;                            // 1-KiB pieces per wave, tile and operand
+        int kvo[PW], vvo[PW];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int g = wv * 4 + i;
+        for (int i = 0; i < PW; ++i) {
+            const int g = wv * PW + i;
             const int krow = 2 * g + (lane >> 5), kslot = lane & 31;
             kvo[i] = krow * (CC * (int)sizeof(T)) + ((kslot ^ (krow & 15)) << 4);
             const int vrow = 16 * g + (lane >> 2), vslot = lane & 3;
             vvo[i] = vrow * (a.Kpad * (int)sizeof(T)) + ((vslot ^ ((vrow >> 2) & 3)) << 4);
         }
-        auto request = [&](int tile) {
-            char* img = smem + (tile & 1) * (2 * KBYTES);
+        constexpr int NB = WV == 16 ? 3 : 2;                   // LDS images of the (K, V^T) tile
+        auto request = [&](int tile, int slot) {
+            char* img = smem + slot * (2 * KBYTES);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) at_lds_dma(rk, img + (wv * 4 + i) * 1024, kvo[i], tile * KBYTES);
+            for (int i = 0; i < PW; ++i) at_lds_dma(rk, img + (wv * PW + i) * 1024, kvo[i], tile * KBYTES);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) at_lds_dma(rv, img + KBYTES + (wv * 4 + i) * 1024, vvo[i], tile * (KT * (int)sizeof(T)));
+            for (int i = 0; i < PW; ++i) at_lds_dma(rv, img + KBYTES + (wv * PW + i) * 1024, vvo[i], tile * (KT * (int)sizeof(T)));
         };
-        if (ntiles > 0) request(0);
-        for (int tile = 0; tile < ntiles; ++tile) {
-            K4_T(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            K4_T(1);
-            __syncthreads();
-            K4_T(2);
-            if (tile + 1 < ntiles) request(tile + 1);
-            const char* img = smem + (tile & 1) * (2 * KBYTES);
-            compute(tile, img, img + KBYTES);
+        if constexpr (NB == 2) {
+            if (ntiles > 0) request(0, 0);
+            for (int tile = 0; tile < ntiles; ++tile) {
+                K4_T(0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                K4_T(1);
+                __syncthreads();
+                K4_T(2);
+                if (tile + 1 < ntiles) request(tile + 1, (tile + 1) & 1);
+                const char* img = smem + (tile & 1) * (2 * KBYTES);
+                compute(tile, img, img + KBYTES);
+            }
+        } else {
+            // three images: iteration t waits for ITS tile only (the 2 PW youngest requests are tile t + 1's), the barrier says that
+            // everyone's pieces of tile t have landed and that everyone is done with tile t - 1, whose image then takes tile t + 2.
+            // Requests behind the last tile are made all the same (the counted wait needs a fixed number in flight): out of the
+            // descriptor's range they fetch nothing, in range (V^T rows) they fetch bytes nobody reads.
+            int slot = 0;
+            if (ntiles > 0) {
+                request(0, 0);
+                request(1, 1);
+            }
+            for (int tile = 0; tile < ntiles; ++tile) {
+                K4_T(0);
+                if constexpr (PW == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                K4_T(1);
+                __syncthreads();
+                K4_T(2);
+                const int nslot = slot == 0 ? 2 : slot - 1;             // (slot + 2) % 3
+                request(tile + 2, nslot);
+                const char* img = smem + slot * (2 * KBYTES);
+                compute(tile, img, img + KBYTES);
+                slot = slot == 2 ? 0 : slot + 1;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // nothing of the ring in flight behind the kernel's LDS
         }
     }
 #pragma unroll
@@ -356,6 +421,246 @@ __global__ __launch_bounds__(256, QB <= 2 ? 2 : 1) void attn_self(AtArgs a) {
                     const v4f v{o[qb][b][4 * r4] * inv, o[qb][b][4 * r4 + 1] * inv, o[qb][b][4 * r4 + 2] * inv, o[qb][b][4 * r4 + 3] * inv};
                     if constexpr (F32) *reinterpret_cast<v4f*>(op + d) = v;
                     else *reinterpret_cast<gf_vec<T, 4>*>(op + d) = gf_vec<T, 4>{(T)v.x, (T)v.y, (T)v.z, (T)v.w};
+                }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 5: the 16-bit forward as a software pipeline.  What the counters said about attn_self (tools/kernel_pmc.sh,
+// 16 images x 1195 keys): SQ_ACTIVE_INST_VALU = 53 % of all SIMD cycles, the matrix pipe busy for 26 %, and the kernel's time = their
+// SUM plus waits - a wave alternates an MFMA-only phase (S, P.V) with a VALU-only phase (softmax) and with two (or four) waves per SIMD
+// the phases of different waves almost never fall beside each other; 113 vector instructions per 1024 logits, a third of them the
+// rescale of O, which ran in nearly every tile (the wave-wide `any running maximum moved` is true for most tiles of 38).  Hence:
+//   * deferred maximum (guide T13): a query's reference m moves only when its tile maximum exceeds it by more than THR = 8 in the
+//     exponent's log2 units (P <= 256: exact in fp16 / bf16 up to their rounding, the row sum stays fp32); the rescale becomes a rare
+//     side path of the loop and only the lanes that need it change m (alpha = 1 for the others: a per-QUERY rule the oracle restates);
+//   * S of tile t + 1 is computed WHILE tile t's softmax runs: one basic block per tile in which the 16 MFMAs of a wave (S_next of both
+//     query blocks, P.V of both) sit between the exponentials of the two blocks, so the matrix pipe works under the vector phases of the
+//     SAME wave instead of waiting for another wave's; tile t + 1 must have landed a tile early: three LDS images;
+//   * eight waves = two per head share a staged tile (half the L2 -> LDS bytes per query), one workgroup of 128 KiB per CU.
+// Arithmetic per query = attn_self's except for the deferred reference (same tile order, same operand order inside the MFMAs).
+// ABL != 0: diagnostic instances (GF_K4_ABL=n, fp16 only; results are wrong by construction): 1 no exponential, 2 no softmax
+// arithmetic at all, 3 no MFMA, 4 no fragment reads from LDS, 5 no LDS-DMA and no barrier, 6 no barrier only
+template <typename T, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void attn_self_pipe(AtArgs a) {
+    using M = Mma32<T>;
+    using Frag = typename M::Frag;
+    constexpr int KG = M::kGroup, NG = HD / KG, EPC = 16 / sizeof(T), QB = 2, PW = 2;
+    constexpr int KBYTES = KT * CC * sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int gx = gridDim.x, total = gx * gridDim.y, tid = threadIdx.x;
+    int id = blockIdx.y * gx + blockIdx.x;
+    if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);           // whole images per XCD (see attn_self)
+    const int n = id / gx, q0 = (id - n * gx) * (64 * QB) + (tid >> 8) * (32 * QB);
+    const int head = (tid >> 6) & 3, lane = tid & 63, h = lane >> 5, lr = lane & 31;
+    const int K = a.nkeys[(size_t)n * a.nkeys_stride];
+    Frag qf[QB][NG];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qrow = min(q0 + 32 * qb + lr, a.L - 1);
+        const T* qp = (const T*)a.q + ((size_t)n * a.L + qrow) * a.ldq + head * HD;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) qf[qb][g] = *reinterpret_cast<const Frag*>(qp + g * KG + h * (KG / 2));
+    }
+    v16f o[QB][2];
+    float m[QB], l[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        m[qb] = -INFINITY;
+        l[qb] = 0.f;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qb][b][r] = 0.f;
+    }
+    const T* kc = (const T*)a.kc + (size_t)n * a.Kpad * CC;
+    const int ntiles = (K + KT - 1) / KT;
+    const float scale2 = a.softmax_temp * 1.44269504088896341f;
+    const float defer = K4_DEFER / scale2;                               // the threshold on the unscaled logits
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const AtRsrc rk = at_rsrc(kc, (unsigned)((size_t)a.Kpad * CC * sizeof(T)));
+    const AtRsrc rv = at_rsrc((const T*)a.vc + (size_t)n * CC * a.Kpad, (unsigned)((size_t)CC * a.Kpad * sizeof(T)));
+    int kvo[PW], vvo[PW];
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        const int g = wv * PW + i;
+        const int krow = 2 * g + (lane >> 5), kslot = lane & 31;
+        kvo[i] = krow * (CC * (int)sizeof(T)) + ((kslot ^ (krow & 15)) << 4);
+        const int vrow = 16 * g + (lane >> 2), vslot = lane & 3;
+        vvo[i] = vrow * (a.Kpad * (int)sizeof(T)) + ((vslot ^ ((vrow >> 2) & 3)) << 4);
+    }
+    auto request = [&](int tile, int slot) {
+        if constexpr (ABL == 5) return;
+        char* img = smem + slot * (2 * KBYTES);
+#pragma unroll
+        for (int i = 0; i < PW; ++i) at_lds_dma(rk, img + (wv * PW + i) * 1024, kvo[i], tile * KBYTES);
+#pragma unroll
+        for (int i = 0; i < PW; ++i) at_lds_dma(rv, img + KBYTES + (wv * PW + i) * 1024, vvo[i], tile * (KT * (int)sizeof(T)));
+    };
+    // lane-constant LDS offsets of the fragments: K row lr, chunks of head-dim group g; V^T channel rows b * 32 + lr, key chunks 2 s2 + h
+    int koff[NG], voff[2][2];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) koff[g] = k_off<T>(lr, (head * HD + g * KG + h * (KG / 2)) / EPC);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) voff[s2][b] = KBYTES + vt_off(head * HD + b * 32 + lr, 2 * s2 + h);
+    // FOUR LDS images (128 KiB): iteration t reads V of tile t and K of tile t + 1, tile t + 2 is in flight and tile t + 3 is requested
+    // into tile t - 1's image - two whole iterations for a request to land.  The tile loop is unrolled by the ring's length so that
+    // an image's base is a compile-time constant (fragment addresses = lane constant + immediate).
+    constexpr int NS = 4, IMG = 2 * KBYTES;
+    v16f sc[QB];
+    if (ntiles > 0) {
+        request(0, 0);
+        request(1, 1);
+        request(2, 2);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                   // tiles 0 and 1 (the 4 youngest requests are tile 2's)
+        __syncthreads();
+        Frag kf[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) kf[g] = *reinterpret_cast<const Frag*>(smem + koff[g]);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[qb][r] = 0.f;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) M::mma(kf[g], qf[qb][g], sc[qb]);
+        }
+    }
+    auto body = [&](auto slot_c, int tile) {
+        constexpr int SLOT = decltype(slot_c)::value, NSLOT = (SLOT + 1) % NS, FSLOT = (SLOT + 3) % NS;
+        if (tile > 0) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");               // my pieces of tile + 1 (tile + 2's stay in flight)
+            if constexpr (ABL != 5 && ABL != 6) __syncthreads();           // everyone's; and everyone is done with tile - 1
+        }
+        request(tile + 3, FSLOT);                                          // into tile - 1's image (behind the last tile: bytes nobody reads)
+        // ---- the reference of each query: moves only when the tile's maximum is more than THR above it (and in the first tile)
+        if ((tile + 1) * KT > K) {                                         // the ragged last tile: key slots >= K do not count
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[qb][r] = tile * KT + gf_acc_row(r, h) < K ? sc[qb][r] : -INFINITY;
+        }
+        float tmax[QB];
+        bool need = false;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            float t = sc[qb][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) t = fmaxf(t, sc[qb][r]);
+            tmax[qb] = half_max(t);
+            need = need || (tmax[qb] - m[qb] > defer);                     // m = -inf: +inf > defer
+        }
+        if (__any(need)) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const float mnew = (tmax[qb] - m[qb] > defer) ? tmax[qb] : m[qb];     // only the queries that need it
+                const float alpha = __builtin_amdgcn_exp2f((m[qb] - mnew) * scale2);  // 1 for the others, 0 in the first tile (O = l = 0)
+                l[qb] *= alpha;
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[qb][b][r] *= alpha;
+                m[qb] = mnew;
+            }
+        }
+        // ---- one basic block: S of tile + 1 and P.V of this tile between the exponentials of the two query blocks
+        const char* cur = smem + SLOT * IMG;
+        const char* nxt = smem + NSLOT * IMG;
+        Frag kf[NG], vf[2][2];
+        if constexpr (ABL == 4) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) kf[g] = qf[0][g];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) vf[s2][b] = qf[1][2 * s2 + b];
+        } else {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) kf[g] = *reinterpret_cast<const Frag*>(nxt + koff[g]);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) vf[s2][b] = *reinterpret_cast<const Frag*>(cur + voff[s2][b]);
+        }
+        v16f sn[QB];
+        Frag pf[QB][2];
+        float psum[QB];
+        auto s_next = [&](int qb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sn[qb][r] = 0.f;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if constexpr (ABL == 3) sn[qb][g] += (float)kf[g][0] * (float)qf[qb][g][1];
+                else M::mma(kf[g], qf[qb][g], sn[qb]);
+            }
+        };
+        auto softmax = [&](int qb) {
+            const float nms = -m[qb] * scale2;
+            float x[16];
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if constexpr (ABL == 2) x[r] = sc[qb][r];
+                else if constexpr (ABL == 1) x[r] = fmaf(sc[qb][r], scale2, nms);
+                else x[r] = __builtin_amdgcn_exp2f(fmaf(sc[qb][r], scale2, nms));
+                if constexpr (ABL != 2) ps += x[r];
+            }
+            psum[qb] = ps;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+                pf[qb][s2] = Frag{(T)x[8 * s2], (T)x[8 * s2 + 1], (T)x[8 * s2 + 2], (T)x[8 * s2 + 3],
+                                  (T)x[8 * s2 + 4], (T)x[8 * s2 + 5], (T)x[8 * s2 + 6], (T)x[8 * s2 + 7]};
+        };
+        auto pv = [&](int qb) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    if constexpr (ABL == 3) o[qb][b][s2] += (float)vf[s2][b][0] * (float)pf[qb][s2][1];
+                    else M::mma(vf[s2][b], pf[qb][s2], o[qb][b]);
+                }
+        };
+        s_next(0);
+        softmax(0);
+        pv(0);
+        s_next(1);
+        softmax(1);
+        pv(1);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            l[qb] += psum[qb];
+            sc[qb] = sn[qb];
+        }
+    };
+    using std::integral_constant;
+    int tile = 0;
+    for (; tile + NS <= ntiles; tile += NS) {
+        body(integral_constant<int, 0>{}, tile);
+        body(integral_constant<int, 1>{}, tile + 1);
+        body(integral_constant<int, 2>{}, tile + 2);
+        body(integral_constant<int, 3>{}, tile + 3);
+    }
+    if (tile < ntiles) body(integral_constant<int, 0>{}, tile);
+    if (tile + 1 < ntiles) body(integral_constant<int, 1>{}, tile + 1);
+    if (tile + 2 < ntiles) body(integral_constant<int, 2>{}, tile + 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // nothing of the ring in flight behind the kernel's LDS
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const float lsum = l[qb] + __shfl_xor(l[qb], 32, 64);
+        const int qi = q0 + 32 * qb + lr;
+        if (qi < a.L) {
+            T* op = (T*)a.out + ((size_t)n * a.L + qi) * CC + head * HD;
+            const float inv = K > 0 ? 1.0f / lsum : 0.f;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int d = b * 32 + 8 * r4 + 4 * h;
+                    *reinterpret_cast<gf_vec<T, 4>*>(op + d) = gf_vec<T, 4>{(T)(o[qb][b][4 * r4] * inv), (T)(o[qb][b][4 * r4 + 1] * inv),
+                                                                            (T)(o[qb][b][4 * r4 + 2] * inv), (T)(o[qb][b][4 * r4 + 3] * inv)};
                 }
         }
     }
@@ -384,9 +689,26 @@ extern "C" int gf_self_attention_gathered(const void* q, const void* kmap, const
     GF_CHECK_ARG(N > 0 && L > 0, "empty problem");
     GF_CHECK_ARG(H == NH && D == HD, "built for nhead=4, head dim 64 (geo_config.py:12, d_model 256)");
     GF_CHECK_ARG(dtype >= GF_F32 && dtype <= GF_BF16, "bad dtype");
+    GF_CHECK_ARG(dtype == GF_F32 || ((uintptr_t)kmap % 16 == 0 && ldk % 8 == 0 && (uintptr_t)q % 16 == 0 && ldq % 8 == 0),
+                 "16-bit modes move key / query rows as 16-byte pieces: 16-byte aligned maps, row strides that are multiples of 8 elements");
     if (workspace == nullptr || workspace_bytes < gf_self_attention_workspace_bytes(N, L, dtype)) {
         gf_set_error("gf_self_attention_gathered: workspace too small");
         return GF_ERR_WORKSPACE;
+    }
+    static std::atomic<uint64_t> attr{0};
+    if (gf_first_use_on_device(attr)) {                           // the three-image ring of the 16-wave form: 96 KiB
+        (void)hipFuncSetAttribute((const void*)attn_self<_Float16, 1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * KT * CC * 2);
+        (void)hipFuncSetAttribute((const void*)attn_self<gf_bf16, 1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * KT * CC * 2);
+        (void)hipFuncSetAttribute((const void*)attn_self_pipe<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * KT * CC * 2);
+#ifdef K4_ABLATE
+        (void)hipFuncSetAttribute((const void*)attn_self_pipe<_Float16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * KT * CC * 2);
+        (void)hipFuncSetAttribute((const void*)attn_self_pipe<_Float16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * KT * CC * 2);
+        (void)hipFuncSetAttribute((const void*)attn_self_pipe<_Float16, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * KT * CC * 2);
+        (void)hipFuncSetAttribute((const void*)attn_self_pipe<_Float16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * KT * CC * 2);
+        (void)hipFuncSetAttribute((const void*)attn_self_pipe<_Float16, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * KT * CC * 2);
+        (void)hipFuncSetAttribute((const void*)attn_self_pipe<_Float16, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * KT * CC * 2);
+#endif
+        (void)hipFuncSetAttribute((const void*)attn_self_pipe<gf_bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * KT * CC * 2);
     }
     AtArgs a;
     a.q = q; a.kmap = kmap; a.vmap = vmap; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
@@ -400,22 +722,66 @@ extern "C" int gf_self_attention_gathered(const void* q, const void* kmap, const
     // query blocks per wave (32 QB queries share a staged K / V tile) once there are enough workgroups to fill the chip;
     // GF_K4_QB=1|2|4 overrides (measurements)
     static const int forced = [] { const char* e = getenv("GF_K4_QB"); return e ? atoi(e) : 0; }();
+    static const int forced_wv = [] { const char* e = getenv("GF_K4_WV"); return e ? atoi(e) : 0; }();
     int qb = forced ? forced : ((long)N * ((L + 63) / 64) >= 512 ? 2 : 1);
     if (qb != 1 && qb != 2 && qb != 4) qb = 1;
-    const dim3 ggrid(a.Kpad / KT, N), agrid((L + 32 * qb - 1) / (32 * qb), N);
-#define GF_K4_LAUNCH(T, ES)                                                                        \
+    int wv = (forced_wv == 8 || forced_wv == 16) && dtype != GF_F32 && qb <= 2 ? forced_wv : 4;
+    // round 5, 16-bit modes: once the chip is full, eight waves = two per head share each staged tile and a wave owns ONE query
+    // block (95 registers: two such workgroups per CU, four waves per SIMD) - 16 images x 1195 keys, same box: 224 us against 237
+    // for two blocks per wave of a four-wave workgroup (288 for one block per wave, 237 for sixteen waves, 257 for eight waves x
+    // two blocks; all with the deferred maximum; tools/k4_ab.py)
+    if (!forced && !forced_wv && dtype != GF_F32 && qb == 2) { wv = 8; qb = 1; }
+    if (wv == 16) qb = 1;
+    // GF_K4_FORM=pipe: the pipelined form (deferred maximum, S of the next tile under this tile's softmax; 128 queries per workgroup)
+    static const bool pipe = [] { const char* e = getenv("GF_K4_FORM"); return e && e[0] == 'p'; }();
+    if (pipe && dtype != GF_F32) { wv = 32; qb = 2; }
+    static const int abl = [] { const char* e = getenv("GF_K4_ABL"); return e ? atoi(e) : 0; }();
+    (void)abl;
+    const dim3 ggrid(dtype == GF_F32 ? a.Kpad / KT : (a.Kpad / 8 < 64 ? a.Kpad / 8 : 64), N), agrid((L + 8 * qb * wv - 1) / (8 * qb * wv), N);
+#define GF_K4_WIDE_16(T)                                                                           \
+    do {                                                                                           \
+        if (wv == 32) { GF_K4_PIPE(T); }                                                          \
+        else if (wv == 16) attn_self<T, 1, 16><<<agrid, 1024, 6 * KT * CC * 2, st>>>(a);           \
+        else if (qb == 2) attn_self<T, 2, 8><<<agrid, 512, 4 * KT * CC * 2, st>>>(a);              \
+        else attn_self<T, 1, 8><<<agrid, 512, 4 * KT * CC * 2, st>>>(a);                           \
+    } while (0)
+#ifdef K4_ABLATE                    /* -DK4_ABLATE: the diagnostic instances of attn_self_pipe, picked by GF_K4_ABL=1..6 (fp16) */
+#define GF_K4_PIPE(T)                                                                              \
+    do {                                                                                           \
+        const dim3 pg((L + 127) / 128, N);                                                         \
+        if constexpr (std::is_same<T, _Float16>::value) {                                          \
+            switch (abl) {                                                                         \
+                case 1: attn_self_pipe<_Float16, 1><<<pg, 512, 8 * KT * CC * 2, st>>>(a); break;   \
+                case 2: attn_self_pipe<_Float16, 2><<<pg, 512, 8 * KT * CC * 2, st>>>(a); break;   \
+                case 3: attn_self_pipe<_Float16, 3><<<pg, 512, 8 * KT * CC * 2, st>>>(a); break;   \
+                case 4: attn_self_pipe<_Float16, 4><<<pg, 512, 8 * KT * CC * 2, st>>>(a); break;   \
+                case 5: attn_self_pipe<_Float16, 5><<<pg, 512, 8 * KT * CC * 2, st>>>(a); break;   \
+                case 6: attn_self_pipe<_Float16, 6><<<pg, 512, 8 * KT * CC * 2, st>>>(a); break;   \
+                default: attn_self_pipe<_Float16><<<pg, 512, 8 * KT * CC * 2, st>>>(a);            \
+            }                                                                                      \
+        } else {                                                                                   \
+            attn_self_pipe<T><<<pg, 512, 8 * KT * CC * 2, st>>>(a);                                \
+        }                                                                                          \
+    } while (0)
+#else
+#define GF_K4_PIPE(T) attn_self_pipe<T><<<dim3((L + 127) / 128, N), 512, 8 * KT * CC * 2, st>>>(a)
+#endif
+#define GF_K4_LAUNCH(T, ES, GF_K4_WIDE)                                                                        \
     do {                                                                                           \
         const size_t LDSB = (ES == 4 ? 2 : 4) * KT * CC * ES;      /* 16-bit: two (K, V^T) images */       \
         attn_gather_kv<T><<<ggrid, 256, 0, st>>>(a);                                               \
-        if (qb == 4) attn_self<T, 4><<<agrid, 256, LDSB, st>>>(a);                     \
-        else if (qb == 2) attn_self<T, 2><<<agrid, 256, LDSB, st>>>(a);                \
-        else attn_self<T, 1><<<agrid, 256, LDSB, st>>>(a);                             \
+        if (wv >= 8) { GF_K4_WIDE(T); break; }                                                     \
+        if (qb == 4) attn_self<T, 4, 4><<<agrid, 256, LDSB, st>>>(a);                     \
+        else if (qb == 2) attn_self<T, 2, 4><<<agrid, 256, LDSB, st>>>(a);                \
+        else attn_self<T, 1, 4><<<agrid, 256, LDSB, st>>>(a);                             \
     } while (0)
     // the key counts live on the device: the caller that knows them (bench.py reads them back) declares the work, 4 L K C flops per sample
     void* pt = gf_prof_begin("k4_self_attention", st, 0.0);
-    if (dtype == GF_F32) GF_K4_LAUNCH(float, 4);
-    else if (dtype == GF_F16) GF_K4_LAUNCH(_Float16, 2);
-    else GF_K4_LAUNCH(gf_bf16, 2);
+#define GF_K4_NOWIDE(T) do { } while (0)
+    if (dtype == GF_F32) GF_K4_LAUNCH(float, 4, GF_K4_NOWIDE);
+    else if (dtype == GF_F16) GF_K4_LAUNCH(_Float16, 2, GF_K4_WIDE_16);
+    else GF_K4_LAUNCH(gf_bf16, 2, GF_K4_WIDE_16);
+#undef GF_K4_NOWIDE
     gf_prof_end("k4_self_attention", pt, st);
 #undef GF_K4_LAUNCH
     GF_CHECK_LAUNCH();

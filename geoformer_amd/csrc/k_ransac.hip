@@ -62,11 +62,13 @@ __device__ int rs_solve(double* a, double* b, int n) {
     for (int c = 0; c < n; ++c) {
         int p = c;
         double best = fabs(a[c * n + c]);
+        if (!(best == best)) best = INFINITY;              /* a non-finite entry in the column fails the solve (round 5: NaN keypoints) */
         for (int r = c + 1; r < n; ++r) {
-            const double v = fabs(a[r * n + c]);
+            double v = fabs(a[r * n + c]);
+            if (!(v == v)) v = INFINITY;
             if (v > best) { best = v; p = r; }
         }
-        if (!(best > 1e-12)) return 0;
+        if (!(best > 1e-12) || best == INFINITY) return 0;
         if (p != c) {
             for (int k = 0; k < n; ++k) { const double tmp = a[c * n + k]; a[c * n + k] = a[p * n + k]; a[p * n + k] = tmp; }
             const double tb = b[c]; b[c] = b[p]; b[p] = tb;
@@ -105,7 +107,11 @@ __device__ __forceinline__ int rs_solve8(double (&a)[8], double& b, double (&x)[
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         // pivot: first row >= c of maximal |a[r][c]|
-        double best = r >= c ? fabs(a[c]) : -1.0;
+        // (a NaN compares false both ways: the lanes of a group would disagree on (best, p), shuffle different rows and end with
+        // different ok flags - ADVICE r04.  A non-finite entry counts as +inf: it wins the maximum on every lane alike and fails the
+        // solve below, as the serial code's NaN solution fails every inlier test.)
+        const double av = fabs(a[c]);
+        double best = r >= c ? (av == av ? av : INFINITY) : -1.0;
         int p = r;
 #pragma unroll
         for (int d = 1; d < 8; d <<= 1) {
@@ -115,7 +121,7 @@ __device__ __forceinline__ int rs_solve8(double (&a)[8], double& b, double (&x)[
             best = take ? ob : best;
             p = take ? op : p;
         }
-        if (!(best > 1e-12)) ok = 0;                       // (uniform in the group; the remaining steps run on, the result is discarded)
+        if (!(best > 1e-12) || best == INFINITY) ok = 0;   // (uniform in the group; the remaining steps run on, the result is discarded)
         // swap rows c and p
         const int src = g0 + (r == c ? p : (r == p ? c : r));
 #pragma unroll
@@ -143,6 +149,8 @@ __device__ __forceinline__ int rs_solve8(double (&a)[8], double& b, double (&x)[
             if (k > c) s = s - a[k] * x[k];
         x[c] = rs_shfl(s / a[c], g0 + c);                   // lane c holds row c: its value is the one that counts
     }
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) ok &= __shfl(ok, lane ^ d, 64);                  // one flag per group, whatever the values were
     return ok;
 }
 

@@ -66,9 +66,13 @@ def dual_softmax_conf_at(f0, f1, temperature, b, i, j):
     features and the statistics its last call on this device and stream left in the workspace (match-only mode's way to a few
     values).  The workspace is stamped by that call with (N, L, S, C, temperature, the two feature pointers): when the stamp
     does not belong to THESE arguments - another pair of feature tensors was matched since (GeoFormer.forward runs two
-    CoarseMatching passes on one workspace), the shape changed - or an index is out of range, the entry comes back NaN."""
+    CoarseMatching passes on one workspace), the shape changed - or an index is out of range, the entry comes back NaN.  The stamp also
+    carries a fingerprint of the features' CONTENT (64 sampled 8-byte words): a new tensor that the caching allocator placed at a freed
+    tensor's address does not pass for it.  The features must be contiguous (the very tensors the match call got): a copy made here
+    would never carry the stamped pointers."""
     _need_cuda(f0, f1)
-    f0, f1 = _contig(f0), _contig(f1)
+    if not (f0.is_contiguous() and f1.is_contiguous()):
+        raise ValueError('dual_softmax_conf_at: pass the contiguous feature tensors gf_dual_softmax_match was called with')
     N, L, C = f0.shape
     S = f1.shape[1]
     b, i, j = (_contig(t.to(device=f0.device, dtype=torch.int64)) for t in (b, i, j))

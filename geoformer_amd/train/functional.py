@@ -468,24 +468,27 @@ def fused_coarse_loss_applicable(model, data):
 
 
 def forward_train(model, data: Dict[str, torch.Tensor], homography_fn: Optional[Callable] = None,
-                  fused_coarse_loss=None):
+                  fused_coarse_loss=None, backbone_features=None, channels_last=False):
     """`GeoFormer.forward` (model/full_model.py:39-123) under autograd.  `model` is `geoformer_amd.GeoFormer` in fp32
     precision; its backbone runs as the nn.Module (train-mode BatchNorm / SyncBatchNorm).
     fused_coarse_loss = (alpha, gamma): both coarse stages take matches from K1 and their focal term from the fused
     HIP loss (writes data['loss_d_fused'], data['loss_c_fused'] = (sum over positives, count)); None = autograd on
-    the materialised confidence matrices."""
+    the materialised confidence matrices.
+    backbone_features = ((cnn0, ff0), (cnn1, ff1)): skip the backbone and run the matching path on these maps (gradient checks of the
+    matching path alone, tests/test_train_gpu.py - an explicit argument: nothing in a batch dict can switch the backbone off).
+    channels_last: the backbone's input in NHWC memory format (TrainStep(channels_last=True))."""
     cfg, gcfg = model.config, model.geo_cfg
     P = dict(model.named_parameters())
     img0, img1 = data['image0'], data['image1']
     n = img0.size(0)
     data.update({'bs': torch.tensor(n), 'hw0_i': torch.tensor(img0.shape[2:]), 'hw1_i': torch.tensor(img1.shape[2:])})
-    if data.get('_backbone_features') is not None:
-        # gradient checks of the matching path alone (tests/test_train_gpu.py): ((cnn0, ff0), (cnn1, ff1)) given as leaf tensors,
-        # e.g. planted-correspondence maps - a regime with decisive confidences that random-init weights on images never reach
-        (cnn0, ff0), (cnn1, ff1) = data['_backbone_features']
+    if backbone_features is not None:
+        # ((cnn0, ff0), (cnn1, ff1)) given as leaf tensors, e.g. planted-correspondence maps - a regime with decisive confidences that
+        # random-init weights on images never reach
+        (cnn0, ff0), (cnn1, ff1) = backbone_features
     elif img0.shape[2:] == img1.shape[2:]:
         both = torch.cat([img0, img1], dim=0)
-        if getattr(model, '_train_channels_last', False):          # TrainStep(channels_last=True): NHWC convolutions (MIOpen / CK)
+        if channels_last:                                          # TrainStep(channels_last=True): NHWC convolutions (MIOpen / CK)
             both = both.contiguous(memory_format=torch.channels_last)
         feats_c, feats_f = model.backbone(both)
         (cnn0, cnn1), (ff0, ff1) = feats_c.split(n), feats_f.split(n)

@@ -72,11 +72,12 @@ def warmup_lr(cfg, global_step) -> Optional[float]:
 class _Core(nn.Module):
     """What DDP wraps: supervision -> forward -> fine supervision -> loss, returning the scalar loss."""
 
-    def __init__(self, model, loss, homography_fn=None, fused=True, amp_dtype=None):
+    def __init__(self, model, loss, homography_fn=None, fused=True, amp_dtype=None, channels_last=False):
         super().__init__()
         self.model, self.loss, self.homography_fn, self.fused, self.amp_dtype = model, loss, homography_fn, fused, amp_dtype
+        self.channels_last = bool(channels_last)
 
-    def forward(self, batch):
+    def forward(self, batch, backbone_features=None):
         res = tuple(self.model.config['resolution'])
         spvs_coarse(batch, res)
         fused = self.loss.fused_params() if (self.fused and fused_coarse_loss_applicable(self.model, batch)) else None
@@ -84,7 +85,8 @@ class _Core(nn.Module):
         # mixed precision = Lightning's precision='bf16' (BASELINE configs[3]): fp32 master parameters, convolutions and GEMMs in
         # bf16 with fp32 accumulation, softmax / LayerNorm / losses in fp32 (torch.autocast's op lists)
         with torch.autocast(device_type=dev, dtype=self.amp_dtype or torch.bfloat16, enabled=self.amp_dtype is not None):
-            forward_train(self.model, batch, self.homography_fn, fused_coarse_loss=fused)
+            forward_train(self.model, batch, self.homography_fn, fused_coarse_loss=fused, backbone_features=backbone_features,
+                          channels_last=self.channels_last)
         spvs_fine2(batch, res)
         return self.loss(batch)
 
@@ -111,9 +113,14 @@ class TrainStep:
 
     `hip_backward=True` (with precision='bf16'): the linears, LayerNorms and activations of every encoder layer (LoFTR coarse and
     fine, Geo) run the HIP kernels forward AND backward (train/hip_autograd.py: gf_linear, gf_linear_wgrad, gf_layernorm_*,
-    gf_activation_backward) instead of torch's GEMM / autograd, and the coarse layers' linear attention runs K2 forward and
-    gf_linear_attention_backward, FineMatching2 runs K8 forward and gf_fine_match_backward; the Geo attention cores, the fine
-    level's attention (heads of 16) and the losses other than the fused coarse loss stay on autograd.  Step time at batch 2, 640x640: 0.128 s -> 0.100 s."""
+    gf_activation_backward) instead of torch's GEMM / autograd; the coarse layers' linear attention runs K2 forward and
+    gf_linear_attention_backward, the fine level's 25-token windows K2's window form and gf_window_linear_attention_backward,
+    GeoTransformer's cross attention K5 and gf_window_cross_attention_backward, FineMatching2 K8 and gf_fine_match_backward; the Geo
+    SELF-attention core (K4), the backbone and the losses other than the fused coarse loss stay on autograd.  Step time at batch 2,
+    640x640: 0.128 s -> 0.075 s.
+    NOT bit-reproducible run to run with hip_backward=True: gf_window_cross_attention_backward sums dk / dv of the overlapping 5 x 5
+    windows with fp32 atomic adds (the order of the adds varies; differences are at fp32 rounding level, ~1e-7 relative, and DDP ranks
+    still hold identical parameters after the all-reduce).  Every other HIP backward sums its partials in a fixed order."""
 
     def __init__(self, model, trainer_cfg=None, loss_cfg=None, batch_size=1, distributed=False, device_ids=None,
                  homography_fn: Optional[Callable] = None, sparse_spvs=True, fused_coarse_loss=False, precision='fp32',
@@ -125,7 +132,6 @@ class TrainStep:
         model.train()
         # channels_last: the backbone's weights and its input in NHWC memory format (the arithmetic is the same; MIOpen then runs
         # its NHWC convolution kernels forward and backward); an option, off by default - measured per shape, tools/train_profile.py --cl
-        model._train_channels_last = bool(channels_last)
         if channels_last:
             model.backbone.to(memory_format=torch.channels_last)
         self.model = model
@@ -136,7 +142,7 @@ class TrainStep:
             raise ValueError("hip_backward=True (K3 chain forward + backward in HIP) is built for the mixed-16-bit step: precision='bf16'")
         self.hip_backward = bool(hip_backward)
         core = _Core(model, GeoLoss(loss_cfg, model.config['match_coarse'].get('match_type', 'dual_softmax'), sparse_spvs),
-                     homography_fn, fused_coarse_loss, torch.bfloat16 if precision == 'bf16' else None)
+                     homography_fn, fused_coarse_loss, torch.bfloat16 if precision == 'bf16' else None, channels_last)
         if distributed:
             if next(model.parameters()).is_cuda:      # torch's SyncBatchNorm is device-only; the gloo/CPU tests keep local BN
                 core = nn.SyncBatchNorm.convert_sync_batchnorm(core)
@@ -215,3 +221,39 @@ def synthetic_homography_batch(n, hw, seed, device='cpu', max_shift=0.12):
     img1 = torch.nn.functional.grid_sample(img0, grid, mode='bilinear', padding_mode='zeros', align_corners=True)
     return {'image0': img0.to(device), 'image1': img1.to(device), 'H_0to1': H01.float().to(device),
             'H_1to0': H10.float().to(device), 'dataset_name': ['oxford'] * n, 'pair_names': [f'synthetic{seed}'] * n}
+
+
+def synthetic_megadepth_batch(n, hw, seed, device='cpu'):
+    """A MegaDepth-style batch (BASELINE configs[3]; the keys lightning_depth_geoformer.py:87-99 feeds: image*, depth*, T_*, K*, scale*,
+    mask*, dataset_name) without the dataset: a smooth random texture seen by two cameras 0.27 units apart over a slanted plane at
+    depth ~6 (focal length 180: image 1 is image 0 shifted by ~8 px = one coarse cell, the depth / pose supervision finds those
+    correspondences), zero-padded to (H, W) the way the MegaDepth loader pads to its square size - the bottom eighth of image 0 in the odd
+    samples and the right eighth of image 1 in the even ones are padding (`mask0` / `mask1` at 1/8 scale) -, per-image scales
+    (depth maps live at the original resolution, up to 1.5x the padded one)."""
+    H, W = hw
+    g = torch.Generator().manual_seed(seed)
+    base = torch.rand(n, 1, H // 8 + 3, W // 8 + 3, generator=g)
+    img = torch.nn.functional.interpolate(base, size=(H + 8, W + 8), mode='bicubic', align_corners=True)
+    img = (img + 0.15 * torch.rand(n, 1, H + 8, W + 8, generator=g)).clamp(0, 1)
+    image0, image1 = img[:, :, :H, :W].clone(), img[:, :, 8:, 8:].clone()
+    mask0 = torch.ones(n, H // 8, W // 8, dtype=torch.bool)
+    mask1 = torch.ones(n, H // 8, W // 8, dtype=torch.bool)
+    r0, c1 = (H // 8) * 7 // 8, (W // 8) * 7 // 8
+    mask0[1::2, r0:] = False
+    mask1[0::2, :, c1:] = False
+    image0[1::2, :, 8 * r0:] = 0
+    image1[0::2, :, :, 8 * c1:] = 0
+    scale0 = torch.ones(n, 2); scale1 = torch.ones(n, 2)
+    scale0[1::2] = torch.tensor([1.25, 1.5]); scale1[0::2] = torch.tensor([1.5, 1.25])
+    Hd, Wd = 2 * H, 2 * W
+    ys, xs = torch.meshgrid(torch.arange(Hd, dtype=torch.float32), torch.arange(Wd, dtype=torch.float32), indexing='ij')
+    depth0 = (6.0 + 0.004 * xs + 0.006 * ys)[None].repeat(n, 1, 1)
+    depth1 = (6.1 + 0.004 * xs + 0.006 * ys)[None].repeat(n, 1, 1)
+    K = torch.tensor([[[180., 0., W / 2.], [0., 180., H / 2.], [0., 0., 1.]]]).repeat(n, 1, 1)
+    T = torch.eye(4)[None].repeat(n, 1, 1)
+    T[:, :3, 3] = torch.tensor([-0.27, -0.27, 0.0])
+    out = {'image0': image0, 'image1': image1, 'depth0': depth0, 'depth1': depth1, 'T_0to1': T, 'T_1to0': torch.inverse(T),
+           'K0': K, 'K1': K.clone(), 'scale0': scale0, 'scale1': scale1, 'mask0': mask0, 'mask1': mask1}
+    out = {k: v.to(device) for k, v in out.items()}
+    out.update(dataset_name=['megadepth'] * n, pair_names=[f'synthetic{seed}'] * n)
+    return out

@@ -646,21 +646,29 @@ def geoformer_forward(P, data, loftr_cfg=None, geo_cfg=None, homography_fn: Call
 # --------------------------------------------------------------------------------------
 
 
+K4_DEFER_LOG2 = 8.0      # geoformer_amd/csrc/k4_attention.hip:K4_DEFER
+
+
 def _flash_self_attention(q, k, v, st, tile: int = 32):
-    """q [L,H,D], k, v [K,H,D] (rounded) -> [L,H,D]: online softmax over key tiles exactly as attn_self runs it - running
-    maximum per query, probabilities exp(s - m_running) rounded to the storage type for the P.V product while their
-    sum stays fp32, rescale by exp(m_old - m_new) per tile, one division at the end."""
+    """q [L,H,D], k, v [K,H,D] (rounded) -> [L,H,D]: online softmax over key tiles exactly as attn_self runs it in the 16-bit
+    modes - a reference m per query that moves only when a tile's maximum exceeds it by more than 8 in the exponent's log2 units
+    (always in the first tile; round 5: the kernel's deferred maximum, a per-query rule), probabilities exp(s - m) rounded to the
+    storage type for the P.V product while their sum stays fp32, rescale by exp(m_old - m_new) where m moved, one division at
+    the end.  (Mathematically the reference's softmax(QK^T / sqrt(D)) V, geo_attention.py:72-101, whatever the threshold.)"""
     L, H, D = q.shape
     K = k.shape[0]
     temp = 1.0 / D ** .5
+    defer = K4_DEFER_LOG2 * math.log(2.0)                 # on the scaled logits x = s * temp (natural-log units)
     m = torch.full((L, H), float('-inf'))
     l = torch.zeros(L, H)
     o = torch.zeros(L, H, D)
     for t0 in range(0, K, tile):
         kt, vt = k[t0:t0 + tile], v[t0:t0 + tile]
         x = torch.einsum('lhd,shd->lhs', q, kt) * temp
-        mnew = torch.maximum(m, x.max(dim=2)[0])
-        alpha = torch.exp(m - mnew)
+        tmax = x.max(dim=2)[0]
+        need = (tmax - m) > defer                          # m = -inf: True
+        mnew = torch.where(need, tmax, m)
+        alpha = torch.where(need, torch.exp(m - mnew), torch.ones_like(m))
         p = torch.exp(x - mnew[..., None])
         l = l * alpha + p.sum(dim=2)
         o = o * alpha[..., None] + torch.einsum('lhs,shd->lhd', rt(p, st), vt)

@@ -50,11 +50,13 @@ static int solve(double* a, double* b, int n) {
     for (int c = 0; c < n; ++c) {
         int p = c;
         double best = fabs(a[c * n + c]);
+        if (!(best == best)) best = INFINITY;              /* a non-finite entry in the column fails the solve (round 5: NaN keypoints) */
         for (int r = c + 1; r < n; ++r) {
-            const double v = fabs(a[r * n + c]);
+            double v = fabs(a[r * n + c]);
+            if (!(v == v)) v = INFINITY;
             if (v > best) { best = v; p = r; }
         }
-        if (!(best > 1e-12)) return 0;
+        if (!(best > 1e-12) || best == INFINITY) return 0;
         if (p != c) {
             for (int k = 0; k < n; ++k) { const double tmp = a[c * n + k]; a[c * n + k] = a[p * n + k]; a[p * n + k] = tmp; }
             const double tb = b[c]; b[c] = b[p]; b[p] = tb;

@@ -57,3 +57,41 @@ def test_a_dead_rank_ends_the_launch_quickly():
     r = _run(['--gpus', '4', '--dry-run', '--steps', '2'], env={'GEOFORMER_BENCH_FAIL_RANK': '2'})
     assert r.returncode != 0 and 'first failure: rank 2' in r.stderr, r.stderr
     assert time.time() - t < 60
+
+
+def test_ranks_are_pinned_to_disjoint_core_sets():
+    """every rank pins itself (os.sched_setaffinity inside the rank's process, before any GPU call) to its own
+    block of host cores; the dry run reports the sets."""
+    r = _run(['--gpus', '2', '--dry-run', '--steps', '2'])
+    assert r.returncode == 0, r.stderr
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    a, b = line['rank_cpu_sets']
+    ncpu = len(os.sched_getaffinity(0))
+    if ncpu >= 2:
+        assert a and b and not set(a) & set(b) and len(a) == len(b) == ncpu // 2
+    r = _run(['--gpus', '2', '--dry-run', '--steps', '2'], env={'GEOFORMER_BENCH_NO_PIN': '1'})
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['rank_cpu_sets'] == [None, None]
+
+
+def test_rank_cpu_set_follows_the_gpus_numa_nodes(tmp_path):
+    """The cores of the GPU's NUMA node (sysfs: amdgpu PCI functions in bus order), shared evenly by the ranks on that node; an even
+    split of the allowed cores where sysfs says nothing."""
+    sys.path.insert(0, ROOT)
+    import bench
+    root = tmp_path / 'sys'
+    for k, node in enumerate([0, 0, 1, 1]):
+        d = root / 'bus/pci/drivers/amdgpu' / f'0000:{10 * (k + 1):02x}:00.0'
+        d.mkdir(parents=True)
+        (d / 'numa_node').write_text(f'{node}\n')
+    for node, cl in ((0, '0-7,16-23'), (1, '8-15,24-31')):
+        d = root / f'devices/system/node/node{node}'
+        d.mkdir(parents=True)
+        (d / 'cpulist').write_text(cl + '\n')
+    allowed = range(32)
+    sets = [bench.rank_cpu_set(r, 4, allowed, str(root)) for r in range(4)]
+    assert sets[0] == [0, 1, 2, 3, 4, 5, 6, 7] and sets[1] == [16, 17, 18, 19, 20, 21, 22, 23]
+    assert sets[2] == [8, 9, 10, 11, 12, 13, 14, 15] and sets[3] == [24, 25, 26, 27, 28, 29, 30, 31]
+    # no sysfs information: contiguous even split
+    assert bench.rank_cpu_set(1, 4, allowed, str(tmp_path / 'none')) == list(range(8, 16))
+    assert bench.rank_cpu_set(0, 1, [3, 4], str(tmp_path / 'none')) == [3, 4]

@@ -139,16 +139,21 @@ FINE_EDGE = 5e-2          # the same for the fine threshold: the 25x25 matrices 
 FINE_ARGMAX_EDGE = 1e-3
 # Round 5 (VERDICT r04 #2b): the band edge of a case is MEASURED on that case - the 99.9th percentile of the relative
 # difference of the two confidence matrices over the decision-relevant entries (oracle confidence >= thr / 2; >= 1e-2 in the dense
-# mode) - and capped by the mode's ceiling below, so a kernel whose round-off grows widens nothing: it fails the ceiling.  Ceilings =
-# the largest edge measured on the MI355X over all cases of the mode + ~25 % (fp16: 3 % as before; bf16 was "8 x fp16" = 24 %, which
-# made the band 40 % of all matches - its measured edge is far smaller).  On top of the band rule every case carries a CAP on the
-# number of differing matches: the count measured on the MI355X plus a small margin (the counts move by a few with every change of
-# an fp32 summation order), == 0 where the case has always been bit-exact.
-EDGE_CEIL = {'fp16': KNIFE_EDGE, 'bf16': 8 * KNIFE_EDGE}
-EDGE = EDGE_CEIL
+# mode) - and capped by the mode's EDGE below; a kernel whose round-off grows widens nothing: the measured percentile has its own
+# ceiling NOISE_CEIL = the largest value measured on the MI355X over all cases of the mode x 1.25 (gpurun_out/r05a_pytest.log: fp16
+# 0.002 ... 0.082, bf16 0.026 ... 0.100; the large values belong to the `g11` / HPatches-shaped planted maps whose confidences sit
+# close to the threshold, the bench's own maps measure 0.006 ... 0.020 in fp16 and 0.075 in bf16).  fp16 keeps EDGE = 3 % (every
+# difference ever seen sat inside it); bf16 was "8 x fp16" = 24 %, which made the band 40 % of all matches - its measured noise is no
+# larger than fp16's p99.9 on the same maps (0.085 / 0.099 against 0.082 / 0.081), so its edge is min(measured, 12.5 %): B = 147 ...
+# 190 instead of 445 ... 760.  On top of the band rule every case carries a CAP on the number of differing matches: the count measured
+# on the MI355X plus a small margin (the counts move by a few with every change of an fp32 summation order), == 0 where the case has
+# always been bit-exact.
+EDGE = {'fp16': KNIFE_EDGE, 'bf16': 0.125}
+NOISE_CEIL = {KNIFE_EDGE: 0.10, 0.125: 0.125}        # keyed by the mode's EDGE (compare_with_storage_oracle gets the edge, not the mode)
+FINE_WIDEN = {KNIFE_EDGE: 1.0, 0.125: 8.0}           # the fine level's bands in bf16: 8 x fp16's (8 instead of 11 significant bits), as before
 # the two confidence matrices (entries > 1e-3): (max, mean) relative difference - 14 layers of storage round-off feed an
-# exponential with 1 / temperature = 10; measured maxima + margin (printed by every case)
-CONF_TOL = {'fp16': (0.3, 2e-2), 'bf16': (2.4, 0.16)}
+# exponential with 1 / temperature = 10; the maxima measured on the MI355X (fp16: 0.053 on the bench's maps; bf16: 0.246 / 0.027) + margin
+CONF_TOL = {'fp16': (0.25, 1.2e-2), 'bf16': (0.4, 4e-2)}
 
 
 def measured_edge(oc, rc, thr, q=0.999):
@@ -239,12 +244,12 @@ def compare_fine_on_common(out, ref, fine_thr, what, fine_edge=FINE_EDGE, argmax
     return len(pairs), flipped
 
 
-def compare_with_storage_oracle(out, ref, thr, what, fine_thr=0.1, edge=KNIFE_EDGE, conf_tol=(0.3, 2e-2), max_diff=None):
+def compare_with_storage_oracle(out, ref, thr, what, fine_thr=0.1, edge=KNIFE_EDGE, conf_tol=CONF_TOL['fp16'], max_diff=None):
     """Coarse ids bit-exact, or: every match present on one side only lies in the decision band of the oracle's own confidence
-    matrix (flip distance < the case's measured edge, capped by `edge` = the mode's ceiling), at most half of the band's population
+    matrix (flip distance < the case's measured edge, capped by `edge` = the mode's EDGE), at most half of the band's population
     differs, and at most `max_diff` matches differ (the count measured on the MI355X + margin; 0 = the case is bit-exact).  The fine
     level is compared on the common matches in either case.  Returns (number of differences, band population)."""
-    widen = edge / KNIFE_EDGE                            # bf16: the same 8x wider bands as for the coarse decisions (fine level)
+    widen = FINE_WIDEN.get(edge, edge / KNIFE_EDGE)      # the fine level's bands
     a = set(zip(out['b_ids'].tolist(), out['i_ids'].tolist(), out['j_ids'].tolist()))
     r = set(zip(ref['b_ids'].tolist(), ref['i_ids'].tolist(), ref['j_ids'].tolist()))
     diff = sorted(a ^ r)
@@ -254,9 +259,9 @@ def compare_with_storage_oracle(out, ref, thr, what, fine_thr=0.1, edge=KNIFE_ED
     band = decision_band(rc, thr, e_used)
     B = len(band)
     print(f'{what}: {len(r)} coarse matches, {len(diff)} differences (cap {max_diff}), band population B = {B} -> bound {knife_bound(B)}; '
-          f'edge measured {e_meas:.4f} (ceiling {edge:g}, used {e_used:.4f}); relevant-entry relative difference '
+          f'edge measured {e_meas:.4f} (cap {edge:g}, used {e_used:.4f}; noise ceiling {NOISE_CEIL.get(edge, 1.5 * edge):g}); relevant-entry relative difference '
           f'p50 {q50:.2e} p99 {q99:.2e} p99.9 {q999:.2e} max {qmax:.2e}')
-    assert e_meas <= 1.5 * edge, (what, 'the measured noise edge left the mode\'s ceiling', e_meas, edge)
+    assert e_meas <= NOISE_CEIL.get(edge, 1.5 * edge), (what, 'the measured noise left the mode\'s ceiling', e_meas, NOISE_CEIL.get(edge))
     for k in diff:
         assert k in band, (what, k, 'differs outside the decision band')
     assert len(diff) <= knife_bound(B), (what, len(a), len(r), len(diff), B)

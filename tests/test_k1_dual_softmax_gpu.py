@@ -198,6 +198,15 @@ def test_match_only_equals_contract_mode(dtype, thr):
     ops.dual_softmax_match(f0, f1b, 0.1, thr, (h, w), (h, w), 8.0, materialize=False)      # the workspace now belongs to (f0, f1b)
     assert bool(torch.isnan(ops.dual_softmax_conf_at(f0, f1, 0.1, bb[:8], ii[:8], jj[:8])).all())
     assert torch.equal(ops.dual_softmax_conf_at(f0, f1b, 0.1, bb, ii, jj), want)
+    # same ADDRESS, other CONTENT (the caching allocator hands a freed feature tensor's memory to the next one of the same
+    # shape): the stamp carries a fingerprint of the content, so the stale statistics are refused ...
+    f1b.mul_(1.25)
+    assert bool(torch.isnan(ops.dual_softmax_conf_at(f0, f1b, 0.1, bb[:8], ii[:8], jj[:8])).all())
+    f1b.copy_(f1)
+    assert torch.equal(ops.dual_softmax_conf_at(f0, f1b, 0.1, bb, ii, jj), want)          # ... and accepted again with the content back
+    # a non-contiguous view is refused (a silent copy would never match the stamped pointers: all-NaN)
+    with pytest.raises(ValueError):
+        ops.dual_softmax_conf_at(f0.transpose(1, 2).contiguous().transpose(1, 2), f1b, 0.1, bb[:8], ii[:8], jj[:8])
     # outside the configuration the library is built for, the wrapper materialises the matrix as usual
     c = ops.dual_softmax_match(f0[:, :100].contiguous(), f1, 0.1, thr, (10, 10), (h, w), 8.0, materialize=False)
     assert c['conf_matrix'] is not None

@@ -5,7 +5,7 @@ do to the metric the reference is judged by - the HPatches homography-estimation
 No checkpoint and no HPatches data exist offline, so the protocol runs on SYNTHETIC sequences: 13 sequences x 5 pairs = 65 pairs of
 planted feature maps of a planar scene (oracle/golden_inputs.py:hpatches_like_features: a continuous random field sampled at the
 cells of image 0 and at H^-1 of the cells of image 1, 480x640 against 480x608 - 60x80 and 60x76 coarse grids, the shape class of
-data_io.py:16-26), ground-truth homographies of HPatches-like strength (corner displacements up to 2k / 8k px for pair k).
+data_io.py:16-26), ground-truth homographies of HPatches-like strength (corner displacements up to 6k / 8k px for pair k = 1..5).
 Both sides see the same maps and go through the same evaluation arithmetic (geoformer_amd.matcher.cal_error_auc / corner_error, pinned
 by tests/golden/g12):
   product:  GeoFormer.forward_features in fp16 / bf16 storage, device RANSAC inside GeoModule, device RANSAC (3 px, sub-pixel
@@ -84,7 +84,7 @@ def test_hpatches_protocol_auc_product_vs_fp32_oracle(precision):
     print(f'  dAUC                 {np.round(auc_g - auc_r, 5).tolist()}   corner error: oracle mean {np.nanmean(er):.4f} px, '
           f'|product - oracle| mean {np.abs(eg - er)[ok].mean():.2e} max {np.abs(eg - er)[ok].max():.2e} px')
     # the workload is a real one: matches on every pair, errors inside the AUC's range on most of them
-    assert nr.min() >= 4 and ng.min() >= 4 and np.nanmedian(er) < 3.0 and 0.2 < auc_r[1] < 0.999
+    assert nr.min() >= 30 and ng.min() >= 30 and np.nanmedian(er) < 3.0 and 0.2 < auc_r[1] < 0.999
     assert int(np.isnan(er).sum()) == int(np.isnan(eg).sum()) == 0
     gate = {'fp16': 1e-3, 'bf16': 5e-3}[precision]
     assert abs(auc_g[1] - auc_r[1]) <= gate, (precision, 'dAUC@3', float(auc_g[1] - auc_r[1]))

@@ -338,7 +338,7 @@ def test_mixed_bf16_step_against_the_fp32_step(style):
 def test_bf16_gradients_per_module_in_a_trained_like_regime():
     """the 0.85 cosine gate above is what UNTRAINED weights on images allow (near-uniform confidences: the coarse
     loss's gradient is a small difference of large sums).  Here the matching path is driven with planted-correspondence feature maps
-    (forward_train's `_backbone_features` hook; image 1 = image 0 shifted by one coarse cell, the supervision's homography is that
+    (forward_train's `backbone_features` argument; image 1 = image 0 shifted by one coarse cell, the supervision's homography is that
     translation) - decisive confidences, hundreds of matches above the reference's threshold 0.2, the regime of a trained model -
     and the gradients of the first coarse loss term are compared module by module: every one of the eight loftr_coarse layers, and
     the gradient with respect to the two coarse feature maps, must have cosine >= 0.99 between the fp32 step and the mixed-bf16 step
@@ -363,12 +363,11 @@ def test_bf16_gradients_per_module_in_a_trained_like_regime():
                          fused_coarse_loss=True, precision=prec, hip_backward=hip)
         feats = [[t.clone().cuda().requires_grad_(i == 0) for i, t in enumerate(pair)] for pair in ((c0, f0), (c1, f1))]
         batch = {'image0': torch.zeros(2, 1, 8 * h, 8 * w, device='cuda'), 'image1': torch.zeros(2, 1, 8 * h, 8 * w, device='cuda'),
-                 'H_0to1': T.cuda(), 'H_1to0': torch.inverse(T).cuda(), 'dataset_name': ['oxford'] * 2, 'pair_names': ['p'] * 2,
-                 '_backbone_features': ((feats[0][0], feats[0][1]), (feats[1][0], feats[1][1]))}
+                 'H_0to1': T.cuda(), 'H_1to0': torch.inverse(T).cuda(), 'dataset_name': ['oxford'] * 2, 'pair_names': ['p'] * 2}
         from geoformer_amd.train.functional import set_hip_backward
         set_hip_backward(hip)
         try:
-            step.core(batch)
+            step.core(batch, backbone_features=((feats[0][0], feats[0][1]), (feats[1][0], feats[1][1])))
         finally:
             set_hip_backward(False)
         step.optimizer.zero_grad(set_to_none=True)
@@ -397,3 +396,44 @@ def test_bf16_gradients_per_module_in_a_trained_like_regime():
         print(f"trained-like regime, bf16{' + HIP backward' if hip else ''}: {m16} matches (fp32 {m32}), loss {l16:.4f} (fp32 {l32:.4f}), "
               'cosine per module ' + ' '.join(f'{k.rstrip(".").split(".")[-1]}={v:.3f}' for k, v in cos.items()))
         assert min(cos.values()) >= 0.99, cos                   # measured 0.998-0.999 for every module (MI355X, round 4)
+
+
+@pytest.mark.parametrize('style', ['configs2_homo_640x480_b4', 'configs3_megadepth_640x640_b8'])
+def test_full_size_training_step(style):
+    """VERDICT r04 #6b: the training step at the sizes BASELINE configs[2] / [3] name PER GPU - 640 x 480 homography pairs at batch 4
+    (batch 32 over 8 GPUs, homo_trainval_640.py:5) and 640 x 640 MegaDepth-style pairs at batch 8 with padding masks, per-image scales
+    and depth + pose supervision - in the mixed-bf16 configuration the bench's `train_step` side measurement runs (fused HIP coarse
+    loss, HIP forward + backward Functions): losses finite and falling below the first step's within five steps on one batch (AdamW at
+    lr 1e-3 x the batch scaling; at the lr of the small tests, 1e-2, the full-size loss oscillates in BOTH legs: 11.9, 12.4, 11.6), every loss term within the
+    existing 2 % of the autocast step (hip_backward=False) on the same batch and weights, parameters stay fp32."""
+    from geoformer_amd.model.cvpr_ds_config import get_default_cfg
+    from geoformer_amd.model.full_model import GeoFormer
+    from geoformer_amd.model.geo_config import get_cfg_model
+    from geoformer_amd.train import TrainStep, synthetic_homography_batch, synthetic_megadepth_batch
+    from geoformer_amd.weights import deterministic_init_
+    make, hw, B = ((synthetic_homography_batch, (480, 640), 4) if style.startswith('configs2') else (synthetic_megadepth_batch, (640, 640), 8))
+    res = {}
+    for hip in (False, True):
+        g = get_cfg_model()
+        g.update(coarse_thr=0.0, fine_thr=0.0, precision='fp32')
+        model = deterministic_init_(GeoFormer(get_default_cfg(), g)).cuda()
+        step = TrainStep(model, trainer_cfg={'warmup_step': 0, 'canonical_lr': 1e-3, 'gradient_clipping': 0.0}, batch_size=B,
+                         fused_coarse_loss=True, precision='bf16', hip_backward=hip)
+        losses, scal = [], None
+        for it in range(5):
+            batch = make(B, hw, seed=77, device='cuda')
+            losses.append(float(step(batch)))
+            if it == 0:
+                scal = {k: float(v) for k, v in batch['loss_scalars'].items()}
+                nm = len(batch['b_ids'])
+        assert all(p.dtype == torch.float32 for p in model.parameters())
+        res[hip] = (losses, scal, nm)
+        del step, model
+        torch.cuda.empty_cache()
+    (l0, s0, n0), (l1, s1, n1) = res[False], res[True]
+    print(f'{style}: autocast losses {l0} ({n0} matches) | HIP forward + backward losses {l1} ({n1} matches); first-step terms {s0} | {s1}')
+    assert all(np.isfinite(l1)) and min(l1[1:]) < l1[0] and l1[-1] < l1[0] + 0.05, l1
+    assert all(np.isfinite(l0)) and min(l0[1:]) < l0[0], l0
+    for k in ('loss_c', 'loss_d'):
+        assert s1[k] == pytest.approx(s0[k], rel=2e-2), (k, s0, s1)
+    assert n1 > 100 * B / 4
