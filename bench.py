@@ -920,7 +920,8 @@ def train_measurements(dev, log, steps=5, warmup=2):
         g.update(coarse_thr=0.0, fine_thr=0.0, precision='fp32')
         model = deterministic_init_(GeoFormer(get_default_cfg(), g)).to(dev)
         step = TrainStep(model, batch_size=batch, fused_coarse_loss=True, precision='bf16', hip_backward=True)
-        data = [make(batch, hw, seed=900 + i, device=dev) for i in range(warmup + steps)]
+        base = [make(batch, hw, seed=900 + i, device=dev) for i in range(2)]         # two resident batches, taken in turn (the step writes its
+        data = [dict(base[i % 2]) for i in range(warmup + steps)]                    # supervision and outputs into the dict it is given: a fresh dict per step)
         losses = []
         for i in range(warmup):
             losses.append(float(step(data[i])))

@@ -185,6 +185,20 @@ __global__ __launch_bounds__(64 * WV, WV == 16 ? 4 : WV == 8 ? (QB == 1 ? 4 : 2)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[qb][b][r] = 0.f;
     }
+    // 16-bit modes (round 5): the row sums l = sum_k P come from the matrix pipe - P^T (the packed operand of P.V) against a ones
+    // operand, two MFMAs per 32 x 32 logits instead of 16 vector adds (the kernel is paced by its instruction count, the pipe has
+    // room); every row of the result tile holds the query's sum over BOTH lane halves' keys, l = register 0.  The sum is then over
+    // the ROUNDED probabilities, the very weights P.V applies (the oracle's storage mode follows).
+    v16f lacc[QB];
+    Frag ones;
+    if constexpr (!F32) {
+#pragma unroll
+        for (int j8 = 0; j8 < (int)(sizeof(Frag) / sizeof(T)); ++j8) ones[j8] = (T)1.0f;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lacc[qb][r] = 0.f;
+    }
     const T* kc = (const T*)a.kc + (size_t)n * a.Kpad * CC;
     const int ntiles = (K + KT - 1) / KT;
     // logits in log2 units: exp(x - m) = exp2(x' - m') with x' = s * (temp * log2 e): one multiply per element instead of two
@@ -238,7 +252,7 @@ __global__ __launch_bounds__(64 * WV, WV == 16 ? 4 : WV == 8 ? (QB == 1 ? 4 : 2)
                 if (__any(need)) {
                     const float mnew = need ? tmax : m[qb];
                     const float alpha = __builtin_amdgcn_exp2f((m[qb] - mnew) * scale2);      // 0 in the first tile (O = l = 0)
-                    l[qb] *= alpha;
+                    lacc[qb][0] *= alpha;                        // (the tile's other rows are copies nobody reads)
     #pragma unroll
                     for (int b = 0; b < 2; ++b)
     #pragma unroll
@@ -247,10 +261,7 @@ __global__ __launch_bounds__(64 * WV, WV == 16 ? 4 : WV == 8 ? (QB == 1 ? 4 : 2)
                 }
                 const float nms = -m[qb] * scale2;
     #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    x[r] = __builtin_amdgcn_exp2f(fmaf(x[r], scale2, nms));
-                    psum += x[r];
-                }
+                for (int r = 0; r < 16; ++r) x[r] = __builtin_amdgcn_exp2f(fmaf(x[r], scale2, nms));
             } else {
                 if (ragged) {
     #pragma unroll
@@ -303,6 +314,7 @@ __global__ __launch_bounds__(64 * WV, WV == 16 ? 4 : WV == 8 ? (QB == 1 ? 4 : 2)
                         const Frag vf = *reinterpret_cast<const Frag*>(vs + vt_off(head * HD + b * 32 + lr, 2 * s2 + h));
                         M::mma(vf, pf, o[qb][b]);
                     }
+                    M::mma(ones, pf, lacc[qb]);
                 }
             }
             if (qb == 0) K4_T(5);
@@ -408,7 +420,9 @@ __global__ __launch_bounds__(64 * WV, WV == 16 ? 4 : WV == 8 ? (QB == 1 ? 4 : 2)
     }
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        const float lsum = l[qb] + __shfl_xor(l[qb], 32, 64);
+        float lsum;
+        if constexpr (F32) lsum = l[qb] + __shfl_xor(l[qb], 32, 64);
+        else lsum = lacc[qb][0];
         const int qi = q0 + 32 * qb + lr;
         if (qi < a.L) {
             T* op = (T*)a.out + ((size_t)n * a.L + qi) * CC + head * HD;
@@ -440,7 +454,8 @@ __global__ __launch_bounds__(64 * WV, WV == 16 ? 4 : WV == 8 ? (QB == 1 ? 4 : 2)
 //     query blocks, P.V of both) sit between the exponentials of the two blocks, so the matrix pipe works under the vector phases of the
 //     SAME wave instead of waiting for another wave's; tile t + 1 must have landed a tile early: three LDS images;
 //   * eight waves = two per head share a staged tile (half the L2 -> LDS bytes per query), one workgroup of 128 KiB per CU.
-// Arithmetic per query = attn_self's except for the deferred reference (same tile order, same operand order inside the MFMAs).
+// Arithmetic per query = attn_self's (same tile order, same operand order inside the MFMAs) except that the row sums here are vector adds
+// of the UNROUNDED probabilities (attn_self sums the rounded ones on the matrix pipe since): an experiment kept for the record, not a product path.
 // ABL != 0: diagnostic instances (GF_K4_ABL=n, fp16 only; results are wrong by construction): 1 no exponential, 2 no softmax
 // arithmetic at all, 3 no MFMA, 4 no fragment reads from LDS, 5 no LDS-DMA and no barrier, 6 no barrier only
 template <typename T, int ABL = 0>
