@@ -145,7 +145,7 @@ __device__ __forceinline__ float half_max(float x) {
 // stream, not the matrix pipe, is what paces the two-wave forms: 1.95 GB per 16-image call at 1195 keys = 37 GB/s per CU, half of what
 // the LDS-DMA path reaches), 16 waves = four per SIMD, and a THREE-image ring: the tile after next is already requested when a tile is
 // computed (counted vmcnt: the wait at a tile's top leaves the next tile's pieces in flight).
-template <typename T, int QB, int WV>
+template <typename T, int QB, int WV, bool MSUM = false>
 __global__ __launch_bounds__(64 * WV, WV == 16 ? 4 : WV == 8 ? (QB == 1 ? 4 : 2) : (QB <= 2 ? 2 : 1)) void attn_self(AtArgs a) {
     using M = Mma32<T>;
     using Frag = typename M::Frag;
@@ -185,13 +185,13 @@ __global__ __launch_bounds__(64 * WV, WV == 16 ? 4 : WV == 8 ? (QB == 1 ? 4 : 2)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[qb][b][r] = 0.f;
     }
-    // 16-bit modes (round 5): the row sums l = sum_k P come from the matrix pipe - P^T (the packed operand of P.V) against a ones
-    // operand, two MFMAs per 32 x 32 logits instead of 16 vector adds (the kernel is paced by its instruction count, the pipe has
-    // room); every row of the result tile holds the query's sum over BOTH lane halves' keys, l = register 0.  The sum is then over
-    // the ROUNDED probabilities, the very weights P.V applies (the oracle's storage mode follows).
+    // MSUM (round 5 experiment, GF_K4_MSUM=1; NOT the default): the row sums l = sum_k P from the matrix pipe - P^T (the packed operand
+    // of P.V) against a ones operand, two MFMAs per 32 x 32 logits instead of 16 vector adds; every row of the result tile holds the
+    // query's sum over BOTH lane halves' keys, l = register 0 (a sum of the ROUNDED probabilities).  Same box, 16 images x 1195 keys:
+    // 229-230 us per call against 221-223 with the vector adds - ten MFMAs per tile instead of eight cost more than sixteen adds.
     v16f lacc[QB];
     Frag ones;
-    if constexpr (!F32) {
+    if constexpr (!F32 && MSUM) {
 #pragma unroll
         for (int j8 = 0; j8 < (int)(sizeof(Frag) / sizeof(T)); ++j8) ones[j8] = (T)1.0f;
 #pragma unroll
@@ -252,7 +252,8 @@ __global__ __launch_bounds__(64 * WV, WV == 16 ? 4 : WV == 8 ? (QB == 1 ? 4 : 2)
                 if (__any(need)) {
                     const float mnew = need ? tmax : m[qb];
                     const float alpha = __builtin_amdgcn_exp2f((m[qb] - mnew) * scale2);      // 0 in the first tile (O = l = 0)
-                    lacc[qb][0] *= alpha;                        // (the tile's other rows are copies nobody reads)
+                    if constexpr (MSUM) lacc[qb][0] *= alpha;    // (the tile's other rows are copies nobody reads)
+                    l[qb] *= alpha;
     #pragma unroll
                     for (int b = 0; b < 2; ++b)
     #pragma unroll
@@ -261,7 +262,10 @@ __global__ __launch_bounds__(64 * WV, WV == 16 ? 4 : WV == 8 ? (QB == 1 ? 4 : 2)
                 }
                 const float nms = -m[qb] * scale2;
     #pragma unroll
-                for (int r = 0; r < 16; ++r) x[r] = __builtin_amdgcn_exp2f(fmaf(x[r], scale2, nms));
+                for (int r = 0; r < 16; ++r) {
+                    x[r] = __builtin_amdgcn_exp2f(fmaf(x[r], scale2, nms));
+                    if constexpr (!MSUM) psum += x[r];
+                }
             } else {
                 if (ragged) {
     #pragma unroll
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(64 * WV, WV == 16 ? 4 : WV == 8 ? (QB == 1 ? 4 : 2)
                         const Frag vf = *reinterpret_cast<const Frag*>(vs + vt_off(head * HD + b * 32 + lr, 2 * s2 + h));
                         M::mma(vf, pf, o[qb][b]);
                     }
-                    M::mma(ones, pf, lacc[qb]);
+                    if constexpr (MSUM) M::mma(ones, pf, lacc[qb]);
                 }
             }
             if (qb == 0) K4_T(5);
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(64 * WV, WV == 16 ? 4 : WV == 8 ? (QB == 1 ? 4 : 2)
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         float lsum;
-        if constexpr (F32) lsum = l[qb] + __shfl_xor(l[qb], 32, 64);
+        if constexpr (F32 || !MSUM) lsum = l[qb] + __shfl_xor(l[qb], 32, 64);
         else lsum = lacc[qb][0];
         const int qi = q0 + 32 * qb + lr;
         if (qi < a.L) {
@@ -750,6 +754,7 @@ extern "C" int gf_self_attention_gathered(const void* q, const void* kmap, const
     // GF_K4_FORM=pipe: the pipelined form (deferred maximum, S of the next tile under this tile's softmax; 128 queries per workgroup)
     static const bool pipe = [] { const char* e = getenv("GF_K4_FORM"); return e && e[0] == 'p'; }();
     if (pipe && dtype != GF_F32) { wv = 32; qb = 2; }
+    static const bool msum = [] { const char* e = getenv("GF_K4_MSUM"); return e && e[0] == '1'; }();      // A/B: row sums on the matrix pipe
     static const int abl = [] { const char* e = getenv("GF_K4_ABL"); return e ? atoi(e) : 0; }();
     (void)abl;
     const dim3 ggrid(dtype == GF_F32 ? a.Kpad / KT : (a.Kpad / 8 < 64 ? a.Kpad / 8 : 64), N), agrid((L + 8 * qb * wv - 1) / (8 * qb * wv), N);
@@ -758,6 +763,7 @@ extern "C" int gf_self_attention_gathered(const void* q, const void* kmap, const
         if (wv == 32) { GF_K4_PIPE(T); }                                                          \
         else if (wv == 16) attn_self<T, 1, 16><<<agrid, 1024, 6 * KT * CC * 2, st>>>(a);           \
         else if (qb == 2) attn_self<T, 2, 8><<<agrid, 512, 4 * KT * CC * 2, st>>>(a);              \
+        else if (msum) attn_self<T, 1, 8, true><<<agrid, 512, 4 * KT * CC * 2, st>>>(a);          \
         else attn_self<T, 1, 8><<<agrid, 512, 4 * KT * CC * 2, st>>>(a);                           \
     } while (0)
 #ifdef K4_ABLATE                    /* -DK4_ABLATE: the diagnostic instances of attn_self_pipe, picked by GF_K4_ABL=1..6 (fp16) */

@@ -113,7 +113,11 @@ __device__ __forceinline__ F relu_packed(const F& f) {
 }
 // elu(x) + 1 (linear_attention.py:33-34) = max(x, 0) + exp(min(x, 0)): x + 1 for x > 0 (exp(0) = 1 exactly), exp(x)
 // otherwise - branch-free (a conditional exponential compiles to a divergent branch per element), hardware exponential
-__device__ __forceinline__ float phi(float x) { return fmaxf(x, 0.f) + __builtin_amdgcn_exp2f(fminf(x, 0.f) * 1.44269504088896341f); }
+// (round 5: exp(min(x, 0)) = the exponential CLAMPED to [0, 1] - `v_exp_f32 ... clamp`, the output modifier is free - instead of a
+// v_min in front of it: the same bits (for x <= 0 the clamp does nothing, for x > 0 both give exactly 1), one instruction less per value)
+__device__ __forceinline__ float phi(float x) {
+    return fmaxf(x, 0.f) + __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(x * 1.44269504088896341f), 0.f, 1.f);
+}
 __device__ __forceinline__ v16f zero16() { return v16f{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; }
 // the lane id recomputed where a late phase needs it (two VALU instructions; volatile: neither hoisted nor merged): carried in a
 // register from the kernel's top it is the 511th live value of enc_layer and gets spilled - and a scratch reload waits for the

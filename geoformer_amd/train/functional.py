@@ -82,6 +82,13 @@ def full_attention(q, k, v, kv_mask=None):
             qk = qk.masked_fill(~kv_mask[:, :, None], -1e8)
         a = torch.softmax(qk * temp, dim=1)
         out = (a.unsqueeze(-1) * v).sum(1, keepdim=True).to(v.dtype)       # [n, 1, H, D]
+    elif kv_mask is None and q.is_cuda and q.dtype in (torch.float16, torch.bfloat16):
+        # GeoTransformer's 'self' layers in the mixed-16-bit step (all L queries against the gathered inlier keys, no mask): the fused
+        # attention of the library (flash form, forward AND backward) instead of materialised [L, K, H] logits + softmax under autograd -
+        # at batch 8 / 640 x 640 with thousands of inlier cells per image those tensors were 300 of the step's 440 ms of GPU time
+        # (aten::copy_ 121, bmm + its backward 165, softmax + its backward 75; tools/train_profile.py --mega).  Same arithmetic up to
+        # the 16-bit rounding of P (fp32 softmax statistics, scale 1 / sqrt(D)); the fp32 step keeps the explicit form below.
+        return F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)).transpose(1, 2)
     else:
         qk = torch.einsum('nlhd,nshd->nlsh', q, k)
         if kv_mask is not None:

@@ -352,7 +352,7 @@ int gf_inlier_index(const float* kp0, const float* kp1, const uint8_t* keep, con
  *   the token list of gf_inlier_index; out [N,L,256]; nkeys == 0 -> zeros (layer skipped by caller).
  *   16-bit modes: q and kmap 16-byte aligned with row strides that are multiples of 8 elements (rows move as 16-byte pieces).
  *   Arithmetic of the 16-bit modes (flash form): per query a softmax reference that moves only when a key tile's maximum exceeds
- *   it by more than 8 in log2 units, probabilities rounded to the storage type both for P.V and for their (fp32) sum;
+ *   it by more than 8 in log2 units, probabilities rounded to the storage type for P.V, their sum in fp32;
  *   mathematically softmax(Q K^T / sqrt(D)) V whatever the reference.  GF_F32: the exact running maximum, fp32 throughout.
  * ------------------------------------------------------------------------------------------ */
 size_t gf_self_attention_workspace_bytes(int N, int L, int dtype);

@@ -653,7 +653,7 @@ def _flash_self_attention(q, k, v, st, tile: int = 32):
     """q [L,H,D], k, v [K,H,D] (rounded) -> [L,H,D]: online softmax over key tiles exactly as attn_self runs it in the 16-bit
     modes - a reference m per query that moves only when a tile's maximum exceeds it by more than 8 in the exponent's log2 units
     (always in the first tile; round 5: the kernel's deferred maximum, a per-query rule), probabilities exp(s - m) rounded to the
-    storage type for the P.V product AND for their fp32 sum, rescale by exp(m_old - m_new) where m moved, one division at
+    storage type for the P.V product while their sum stays fp32, rescale by exp(m_old - m_new) where m moved, one division at
     the end.  (Mathematically the reference's softmax(QK^T / sqrt(D)) V, geo_attention.py:72-101, whatever the threshold.)"""
     L, H, D = q.shape
     K = k.shape[0]
@@ -669,9 +669,9 @@ def _flash_self_attention(q, k, v, st, tile: int = 32):
         need = (tmax - m) > defer                          # m = -inf: True
         mnew = torch.where(need, tmax, m)
         alpha = torch.where(need, torch.exp(m - mnew), torch.ones_like(m))
-        p = rt(torch.exp(x - mnew[..., None]), st)         # the rounded probabilities weight P.V AND make up the row sum (round 5: the
-        l = l * alpha + p.sum(dim=2)                       # kernel sums them on the matrix pipe, P^T against a ones operand, fp32)
-        o = o * alpha[..., None] + torch.einsum('lhs,shd->lhd', p, vt)
+        p = torch.exp(x - mnew[..., None])
+        l = l * alpha + p.sum(dim=2)
+        o = o * alpha[..., None] + torch.einsum('lhs,shd->lhd', rt(p, st), vt)
         m = mnew
     return rt(o / l[..., None], st)
 

@@ -152,8 +152,9 @@ EDGE = {'fp16': KNIFE_EDGE, 'bf16': 0.125}
 NOISE_CEIL = {KNIFE_EDGE: 0.10, 0.125: 0.125}        # keyed by the mode's EDGE (compare_with_storage_oracle gets the edge, not the mode)
 FINE_WIDEN = {KNIFE_EDGE: 1.0, 0.125: 8.0}           # the fine level's bands in bf16: 8 x fp16's (8 instead of 11 significant bits), as before
 # the two confidence matrices (entries > 1e-3): (max, mean) relative difference - 14 layers of storage round-off feed an
-# exponential with 1 / temperature = 10; the maxima measured on the MI355X (fp16: 0.053 on the bench's maps; bf16: 0.246 / 0.027) + margin
-CONF_TOL = {'fp16': (0.25, 1.2e-2), 'bf16': (0.4, 4e-2)}
+# exponential with 1 / temperature = 10; the maxima measured on the MI355X over all cases (fp16: 0.223 / 8.3e-3 on the HPatches-shaped maps,
+# 0.053 / 4.1e-3 on the bench's; bf16: 0.246 / 0.027) + a third
+CONF_TOL = {'fp16': (0.3, 1.2e-2), 'bf16': (0.4, 4e-2)}
 
 
 def measured_edge(oc, rc, thr, q=0.999):

@@ -1,5 +1,5 @@
 """Where the training step spends its time (torch profiler, top ops by device time).
-   python tools/train_profile.py [H W] [--no-fused] [--no-prof] [--bf16] [--hip] [--batch B] [--long]"""
+   python tools/train_profile.py [H W] [--no-fused] [--no-prof] [--bf16] [--hip] [--batch B] [--long] [--mega]"""
 import sys, time, torch
 HW = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 and sys.argv[1].isdigit() else (480, 640)
 FUSED = '--no-fused' not in sys.argv
@@ -12,7 +12,9 @@ from geoformer_amd.model.cvpr_ds_config import get_default_cfg
 from geoformer_amd.model.full_model import GeoFormer
 from geoformer_amd.model.geo_config import get_cfg_model
 from geoformer_amd.weights import deterministic_init_
-from geoformer_amd.train import TrainStep, synthetic_homography_batch
+from geoformer_amd.train import TrainStep, synthetic_homography_batch, synthetic_megadepth_batch
+if '--mega' in sys.argv:            # BASELINE configs[3]'s data contract: depth + pose supervision, padding masks, per-image scales
+    synthetic_homography_batch = synthetic_megadepth_batch
 g = get_cfg_model(); g.update(coarse_thr=0.0, fine_thr=0.0, precision='fp32')
 model = deterministic_init_(GeoFormer(get_default_cfg(), g)).cuda()
 PREC = 'bf16' if '--bf16' in sys.argv else 'fp32'
