@@ -175,6 +175,9 @@ __global__ __launch_bounds__(512, 2) void fine_layer(FlArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* vec = reinterpret_cast<float*>(smem + VEC_OFF);
     char* tile = smem + X_OFF + wave * TILE;
+#ifdef K11_PRIO       // -DK11_PRIO (experiment, round 5): the second-dispatched half of the waves at static priority 1, as in K10
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     const int my_groups = (a.groups - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     FlRing ring{fl_rsrc(a.wstream, (unsigned)NBLK * WBLK), smem, wave, lane, 0, 0, my_groups * NBLK};
     const FlRsrc xrs = fl_rsrc(a.x, (unsigned)a.Nw * a.Lw * (FC * 2)), srs = fl_rsrc(a.src, (unsigned)a.Nw * a.Lw * (FC * 2));

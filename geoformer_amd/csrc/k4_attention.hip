@@ -164,6 +164,9 @@ __global__ __launch_bounds__(64 * WV, WV == 16 ? 4 : WV == 8 ? (QB == 1 ? 4 : 2)
     const int n = id / gx, q0 = (id - n * gx) * (32 * QB * (WV / 4)) + (tid >> 8) * (32 * QB);
     const int head = (tid >> 6) & 3, lane = tid & 63, h = lane >> 5, lr = lane & 31;
     const int K = a.nkeys[(size_t)n * a.nkeys_stride];
+#ifdef K4_PRIO        // -DK4_PRIO (experiment, round 5): the second-dispatched half of an eight-wave workgroup at static priority 1, as in K10
+    if (WV == 8 && tid >= 256) __builtin_amdgcn_s_setprio(1);
+#endif
     // QB blocks of 32 queries per wave: a staged K / V tile (32 keys x 256 channels, 32 KiB) serves 32 QB queries of every head
     // (with one block a workgroup streams the image's whole K and V for 32 queries: L2-bound at ~1200 keys)
     Frag qf[QB][NG];
