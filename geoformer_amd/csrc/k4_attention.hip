@@ -145,7 +145,12 @@ __device__ __forceinline__ float half_max(float x) {
 // stream, not the matrix pipe, is what paces the two-wave forms: 1.95 GB per 16-image call at 1195 keys = 37 GB/s per CU, half of what
 // the LDS-DMA path reaches), 16 waves = four per SIMD, and a THREE-image ring: the tile after next is already requested when a tile is
 // computed (counted vmcnt: the wait at a tile's top leaves the next tile's pieces in flight).
-template <typename T, int QB, int WV, bool MSUM = false>
+// PRE (16-bit modes, round 5; the default): the softmax scale lives in the Q operand - q' = round(q * log2(e) / sqrt(D)) when the query
+// rows are loaded - and the query's reference m' enters the S MFMA chain as its C operand (a 16-register tile of -m', rewritten only when
+// the reference moves), so the accumulator IS the exponent's argument: per logit one exponential, half a max3, half a pair add and
+// half a conversion - no FMA.  The price is one more 16-bit rounding of q (the product q . k is then scaled BEFORE the sum instead of
+// after it: the same softmax(Q K^T / sqrt(D)) V; the oracle's storage mode rounds q * c the same way).
+template <typename T, int QB, int WV, bool MSUM = false, bool PRE = true>
 __global__ __launch_bounds__(64 * WV, WV == 16 ? 4 : WV == 8 ? (QB == 1 ? 4 : 2) : (QB <= 2 ? 2 : 1)) void attn_self(AtArgs a) {
     using M = Mma32<T>;
     using Frag = typename M::Frag;
@@ -177,11 +182,26 @@ __global__ __launch_bounds__(64 * WV, WV == 16 ? 4 : WV == 8 ? (QB == 1 ? 4 : 2)
 #pragma unroll
         for (int g = 0; g < NG; ++g) qf[qb][g] = *reinterpret_cast<const Frag*>(qp + g * KG + h * (KG / 2));
     }
+    constexpr bool PRESCALE = PRE && !F32;
+    if constexpr (PRESCALE) {
+        const float c2 = a.softmax_temp * 1.44269504088896341f;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int j8 = 0; j8 < (int)(sizeof(Frag) / sizeof(T)); ++j8) qf[qb][g][j8] = (T)(gf_to_float(qf[qb][g][j8]) * c2);
+    }
     v16f o[QB][2];
+    v16f negm[PRESCALE ? QB : 1];                        // PRE: -m' of the lane's query in every register (the S chain's C operand)
     float m[QB], l[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        m[qb] = -INFINITY;
+        m[qb] = PRESCALE ? 0.f : -INFINITY;              // PRE: the reference in scaled log2 units, set by the first tile
+        if constexpr (PRESCALE) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm[qb][r] = 0.f;
+        }
         l[qb] = 0.f;
 #pragma unroll
         for (int b = 0; b < 2; ++b)
@@ -215,8 +235,12 @@ __global__ __launch_bounds__(64 * WV, WV == 16 ? 4 : WV == 8 ? (QB == 1 ? 4 : 2)
         for (int qb = 0; qb < QB; ++qb) {
             // ---- S^T tile: rows = keys (registers), column = query (lane)
             v16f s;
+            if constexpr (PRESCALE) {
+                s = negm[qb];                                 // the chain starts at -m': s = q' . k - m' is the exponent's argument
+            } else {
     #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+                for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            }
     #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 const int chunk = (head * HD + g * KG + h * (KG / 2)) / EPC;
@@ -227,7 +251,43 @@ __global__ __launch_bounds__(64 * WV, WV == 16 ? 4 : WV == 8 ? (QB == 1 ? 4 : 2)
             float x[16];
             float tmax = -INFINITY;
             float psum = 0.f;
-            if constexpr (FAST) {
+            if constexpr (PRESCALE) {
+                if (ragged) {
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) s[r] = tile * KT + gf_acc_row(r, h) < K ? s[r] : -INFINITY;
+                }
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+                tmax = half_max(tmax);                        // the tile's maximum RELATIVE to the reference (finite: a real key in every tile)
+                // deferred reference: it moves up by d = tmax when the tile's maximum is more than K4_DEFER above it, and in the first
+                // tile (from 0 to the tile's maximum, whatever its sign); only the queries that need it (d = 0, alpha = 1 for the others)
+                const bool need = tmax > K4_DEFER || tile == 0;
+                if (__any(need)) {
+                    const float d = need ? tmax : 0.f;
+                    const float alpha = tile == 0 ? 0.f : __builtin_amdgcn_exp2f(-d);         // (first tile: O = l = 0; no 0 * inf)
+                    if constexpr (MSUM) lacc[qb][0] *= alpha;
+                    l[qb] *= alpha;
+    #pragma unroll
+                    for (int b = 0; b < 2; ++b)
+    #pragma unroll
+                        for (int r = 0; r < 16; ++r) o[qb][b][r] *= alpha;
+                    m[qb] += d;
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        negm[qb][r] = -m[qb];
+                        s[r] -= d;                            // this tile's logits against the new reference
+                    }
+                }
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) x[r] = __builtin_amdgcn_exp2f(s[r]);
+                if constexpr (!MSUM) {
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    f2 ps2{0.f, 0.f};
+    #pragma unroll
+                    for (int r = 0; r < 16; r += 2) ps2 += f2{x[r], x[r + 1]};
+                    psum = ps2.x + ps2.y;
+                }
+            } else if constexpr (FAST) {
                 // 16-bit modes: the running maximum is kept on the UNSCALED logits (scale2 > 0) and the scale rides in the
                 // exponent's FMA: exp2(s * scale2 - max * scale2); one max3 per two logits, one FMA, one exp2, one add per
                 // logit, all single-issue (the separate multiply was packed into v_pk_mul_f32 pairs: dear beside MFMAs)
@@ -265,9 +325,14 @@ __global__ __launch_bounds__(64 * WV, WV == 16 ? 4 : WV == 8 ? (QB == 1 ? 4 : 2)
                 }
                 const float nms = -m[qb] * scale2;
     #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    x[r] = __builtin_amdgcn_exp2f(fmaf(x[r], scale2, nms));
-                    if constexpr (!MSUM) psum += x[r];
+                for (int r = 0; r < 16; ++r) x[r] = __builtin_amdgcn_exp2f(fmaf(x[r], scale2, nms));
+                if constexpr (!MSUM) {
+                    // the row sum as PAIR adds (v_pk_add_f32: eight instructions instead of sixteen; the two partial sums meet at the end)
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    f2 ps2{0.f, 0.f};
+    #pragma unroll
+                    for (int r = 0; r < 16; r += 2) ps2 += f2{x[r], x[r + 1]};
+                    psum = ps2.x + ps2.y;
                 }
             } else {
                 if (ragged) {
@@ -389,15 +454,22 @@ __global__ __launch_bounds__(64 * WV, WV == 16 ? 4 : WV == 8 ? (QB == 1 ? 4 : 2)
         };
         if constexpr (NB == 2) {
             if (ntiles > 0) request(0, 0);
-            for (int tile = 0; tile < ntiles; ++tile) {
+            // (round 5: unrolled by the two images so that an image's base is a compile-time constant - the eight fragment addresses of
+            // a tile are lane constants + immediates instead of eight v_add3 per tile: the kernel is paced by its instruction count)
+            auto iter = [&](auto par_c, int tile) {
+                constexpr int PAR = decltype(par_c)::value;
                 K4_T(0);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 K4_T(1);
                 __syncthreads();
                 K4_T(2);
-                if (tile + 1 < ntiles) request(tile + 1, (tile + 1) & 1);
-                const char* img = smem + (tile & 1) * (2 * KBYTES);
+                if (tile + 1 < ntiles) request(tile + 1, PAR ^ 1);
+                const char* img = smem + PAR * (2 * KBYTES);
                 compute(tile, img, img + KBYTES);
+            };
+            for (int tile = 0; tile < ntiles; tile += 2) {
+                iter(std::integral_constant<int, 0>{}, tile);
+                if (tile + 1 < ntiles) iter(std::integral_constant<int, 1>{}, tile + 1);
             }
         } else {
             // three images: iteration t waits for ITS tile only (the 2 PW youngest requests are tile t + 1's), the barrier says that
@@ -758,6 +830,7 @@ extern "C" int gf_self_attention_gathered(const void* q, const void* kmap, const
     static const bool pipe = [] { const char* e = getenv("GF_K4_FORM"); return e && e[0] == 'p'; }();
     if (pipe && dtype != GF_F32) { wv = 32; qb = 2; }
     static const bool msum = [] { const char* e = getenv("GF_K4_MSUM"); return e && e[0] == '1'; }();      // A/B: row sums on the matrix pipe
+    static const bool nopre = [] { const char* e = getenv("GF_K4_PRE"); return e && e[0] == '0'; }();       // A/B: the scale in the exponent's FMA (round 4's arithmetic + deferred reference)
     static const int abl = [] { const char* e = getenv("GF_K4_ABL"); return e ? atoi(e) : 0; }();
     (void)abl;
     const dim3 ggrid(dtype == GF_F32 ? a.Kpad / KT : (a.Kpad / 8 < 64 ? a.Kpad / 8 : 64), N), agrid((L + 8 * qb * wv - 1) / (8 * qb * wv), N);
@@ -767,6 +840,7 @@ extern "C" int gf_self_attention_gathered(const void* q, const void* kmap, const
         else if (wv == 16) attn_self<T, 1, 16><<<agrid, 1024, 6 * KT * CC * 2, st>>>(a);           \
         else if (qb == 2) attn_self<T, 2, 8><<<agrid, 512, 4 * KT * CC * 2, st>>>(a);              \
         else if (msum) attn_self<T, 1, 8, true><<<agrid, 512, 4 * KT * CC * 2, st>>>(a);          \
+        else if (nopre) attn_self<T, 1, 8, false, false><<<agrid, 512, 4 * KT * CC * 2, st>>>(a);  \
         else attn_self<T, 1, 8><<<agrid, 512, 4 * KT * CC * 2, st>>>(a);                           \
     } while (0)
 #ifdef K4_ABLATE                    /* -DK4_ABLATE: the diagnostic instances of attn_self_pipe, picked by GF_K4_ABL=1..6 (fp16) */

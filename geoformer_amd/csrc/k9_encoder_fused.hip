@@ -38,6 +38,18 @@
 #ifndef K9_TRACE
 #define K9_TRACE 0
 #endif
+// Round-5 experiments, both bit-identical to the default and both SLOWER (same box, tools/k9_digest.py, 16 images: layer alone 145.8-148.5 us,
+// with the state tail 202.6-207.4 us):
+//   -DK9_HEADPIPE=1 (+ GF_K9_HEADPIPE=1 at pack time: the weight stream head-major, fused.py) - q projection, attention and merge as one
+//       head-pipelined stream (attention of head h inside the q-projection steps of head h + 1): 158.1 / 215.2 us;
+//   -DK9_MERGEPIPE=1 - the attention of head h + 1 inside the two merge steps of head h (the stream's order unchanged): 156.0 / 214.9 us.
+// The vector work placed inside the ring steps stretches their MFMA gaps by more than the phase it removes.
+#ifndef K9_HEADPIPE
+#define K9_HEADPIPE 0
+#endif
+#ifndef K9_MERGEPIPE
+#define K9_MERGEPIPE 0
+#endif
 #if K9_TRACE
 __device__ long long k9_trace[4096 * 4 * 16];
 #define K9_T(slot) do { if ((slot) < 16 && lane == 0 && blockIdx.x < 4096) k9_trace[(blockIdx.x * 4 + wave) * 16 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
@@ -256,6 +268,56 @@ __device__ __forceinline__ void ring_step(Ring& g, Frag (&cur)[8], Frag (&nxt)[8
         ++g.blk;
     }
 }
+// ring_step with ONE extra operand read per MFMA gap (`xr(j)` behind MFMA j): the head-pipelined q projection, whose eight MFMAs of a
+// step take eight DIFFERENT token-tile fragments (the k-steps of one head) - two ds_read_b128 per gap, the LDS's limit beside MFMAs
+template <typename Frag, typename MF, typename XF, typename VF>
+__device__ __forceinline__ void ring_step_q(Ring& g, Frag (&cur)[8], Frag (&nxt)[8], int st, MF mma, XF xr, VF valu) {
+#define K9_GAPQ(DMA, READS)                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  \
+        if (DMA) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);         \
+        __builtin_amdgcn_sched_group_barrier(0x100, READS, 0);
+    if (st != 3) {
+        const char* p = g.smem + W_OFF + (g.blk & 1) * WBLK + (st + 1) * 8 * FRAG + g.lane * 16;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            mma(j);
+            if (st == 0 && j < 4) dma_piece(g, g.blk + 1, 4 + j);
+            nxt[j] = ring_read<Frag>(p + j * FRAG);
+            xr(j);
+            K9_KEEP(cur[j]);
+            if (j == 0) valu();
+        }
+        K9_GAPQ(st == 0, 2) K9_GAPQ(st == 0, 2) K9_GAPQ(st == 0, 2) K9_GAPQ(st == 0, 2)
+        K9_GAPQ(false, 2) K9_GAPQ(false, 2) K9_GAPQ(false, 2) K9_GAPQ(false, 2)
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
+        mma(0);
+        xr(0);
+        mma(1);
+        xr(1);
+        __builtin_amdgcn_sched_barrier(0);
+        ring_turn();
+        const char* p = g.smem + W_OFF + ((g.blk + 1) & 1) * WBLK + g.lane * 16;
+#pragma unroll
+        for (int j = 2; j < 8; ++j) {
+            mma(j);
+            if (j < 6) dma_piece(g, g.blk + 2, j - 2);
+            if (j < 4) {
+                nxt[2 * (j - 2)] = ring_read<Frag>(p + 2 * (j - 2) * FRAG);
+                nxt[2 * (j - 2) + 1] = ring_read<Frag>(p + (2 * (j - 2) + 1) * FRAG);
+            } else {
+                nxt[j] = ring_read<Frag>(p + j * FRAG);
+            }
+            xr(j);
+            K9_KEEP(cur[j]);
+            if (j == 2) valu();
+        }
+        K9_GAPQ(true, 3) K9_GAPQ(true, 3) K9_GAPQ(true, 2) K9_GAPQ(true, 2) K9_GAPQ(false, 2) K9_GAPQ(false, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        ++g.blk;
+    }
+#undef K9_GAPQ
+}
 // prologue: block 0 whole and the first half of block 1 (its second half goes out in step 0, like every later block's)
 __device__ __forceinline__ void ring_start(const Ring& g) {
 #pragma unroll
@@ -385,6 +447,130 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
     // token-tile operand of 16-deep k-step ks (0..15)
     auto xfrag = [&](int ks) { return *reinterpret_cast<const Frag*>(xrow + (ks >> 2) * 16384 + gf_lds_off(myrow, 2 * (ks & 3) + h2)); };
 
+#if K9_HEADPIPE
+    v16f m[8];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) m[nb] = zero16();
+    if constexpr (ATTN) {
+        // Round 5: q projection, attention and merge as ONE head-pipelined instruction stream.  The weight stream is head-major
+        // (fused.py: Q0 Q1 M0 Q2 M1 ... Q7 M6 M7; Q(h) = the 16 k-steps of channel tile h into ONE accumulator, M(h) = the merge's
+        // k-steps 2h, 2h + 1 over tiles 0..7) and the attention of head h - phi, packing, the normaliser, its two state MFMAs,
+        // the normalisation - rides in the two steps of Q(h + 1) (AB7 in M6): its ~160 vector instructions issue under the 16 MFMAs of
+        // the neighbouring head instead of in a phase of their own with the matrix pipe idle (one wave per SIMD: nothing else overlaps
+        // them).  Every accumulator still adds its k-steps in ascending order - q[h]: 0..15, m[nb]: 0..15 - so the layer's output
+        // keeps its bits.  The token tile's 16 operand fragments are the B operands of EVERY head's projection: read once.
+        // The token tile's operand fragments: MFMA G of the phase (G = 16 head + k-step) takes k-step G % 16; a four-deep rotating
+        // window of them lives in registers (the fragment of MFMA G + 3 is requested behind MFMA G: three gaps ahead of its use)
+        Frag xq[4];
+        xq[0] = xfrag(0);
+        xq[1] = xfrag(1);
+        xq[2] = xfrag(2);
+        v16f qh[2];
+        const float qmul = (a.q_mask == nullptr || a.q_mask[(size_t)n * a.L + min(t0 + wave * 32 + (fresh_lane() & 31), a.L - 1)] != 0) ? 1.f : 0.f;
+        const float eps_s = a.attn_eps / (float)a.S;
+        struct HeadOps { Frag ks0, ks1; Frag kv0, kv1; };
+        auto head_ops = [&](int hh) {
+            HeadOps o;
+            o.ks0 = *reinterpret_cast<const Frag*>(smem + KS_OFF + ((hh * 2 + 0) * 2 + h2) * 16);
+            o.ks1 = *reinterpret_cast<const Frag*>(smem + KS_OFF + ((hh * 2 + 1) * 2 + h2) * 16);
+            o.kv0 = *reinterpret_cast<const Frag*>(smem + KV_OFF + (hh * 2) * FRAG + lane * 16);
+            o.kv1 = *reinterpret_cast<const Frag*>(smem + KV_OFF + (hh * 2 + 1) * FRAG + lane * 16);
+            return o;
+        };
+        v16f num;
+        float den = 0.f;
+        HeadOps hop;
+        // stage A(h): phi(q[h]) rounded by its packing, the normaliser from the PACKED operands, the two state MFMAs
+        auto stage_a = [&](int hh) {
+            float pq[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pq[r] = phi(qh[hh & 1][r]);
+            const Frag p0 = pack8<T>(pq[0], pq[1], pq[2], pq[3], pq[4], pq[5], pq[6], pq[7]);
+            const Frag p1 = pack8<T>(pq[8], pq[9], pq[10], pq[11], pq[12], pq[13], pq[14], pq[15]);
+            den = dot8(p1, hop.ks1, dot8(p0, hop.ks0, 0.f));
+            num = zero16();
+            Mm::mma(hop.kv0, p0, num);
+            Mm::mma(hop.kv1, p1, num);
+        };
+        // stage B(h): normalise and pack the message of head h = the B operand of M(h)
+        auto stage_b = [&](int hh) {
+            const float z = __builtin_amdgcn_rcpf(half_sum(den) + eps_s) * qmul;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) num[r] *= z;
+            mfrag[hh][0] = pack_step<T>(num, 0);
+            mfrag[hh][1] = pack_step<T>(num, 1);
+        };
+        int gs = 0;                                                       // step counter of the phase (everything below is unrolled)
+        auto q_slot = [&](auto hh_c, auto ab_c) {                          // Q(hh), with A(hh - 1) / B(hh - 1) riding in its two steps
+            constexpr int HH = decltype(hh_c)::value;
+            constexpr bool AB = decltype(ab_c)::value;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                Frag (&cur)[8] = (gs & 1) ? fb : fa;
+                Frag (&nxt)[8] = (gs & 1) ? fa : fb;
+                if (hf == 0) qh[HH & 1] = zero16();
+                ring_step_q(ring, cur, nxt, gs & 3,
+                            [&](int j) { Mm::mma(cur[j], xq[(8 * hf + j) & 3], qh[HH & 1]); },          // (16 HH + 8 hf + j) % 4
+                            [&](int j) { if (HH < 7 || 8 * hf + j + 3 < 16) xq[(8 * hf + j + 3) & 3] = xfrag((8 * hf + j + 3) & 15); },
+                            [&] {
+                                if constexpr (AB) {
+                                    if (hf == 0) stage_a(HH - 1);
+                                    else stage_b(HH - 1);
+                                }
+                            });
+                ++gs;
+            }
+        };
+        auto m_slot = [&](int hh, auto ab_c) {                             // M(hh), with A(7) / B(7) riding in M(6)
+            constexpr bool AB = decltype(ab_c)::value;
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+                Frag (&cur)[8] = (gs & 1) ? fb : fa;
+                Frag (&nxt)[8] = (gs & 1) ? fa : fb;
+                const Frag bf = mfrag[hh][sx];
+                ring_step<0>(ring, cur, nxt, gs & 3, [&](int nb) { Mm::mma(cur[nb], bf, m[nb]); },
+                             [&] {
+                                 if constexpr (AB) {
+                                     if (sx == 0) stage_a(7);
+                                     else stage_b(7);
+                                 }
+                             });
+                ++gs;
+            }
+        };
+        using std::true_type;
+        using std::false_type;
+        using std::integral_constant;
+        q_slot(integral_constant<int, 0>{}, false_type{});
+        hop = head_ops(0);
+        q_slot(integral_constant<int, 1>{}, true_type{});
+        m_slot(0, false_type{}); hop = head_ops(1); q_slot(integral_constant<int, 2>{}, true_type{});
+        m_slot(1, false_type{}); hop = head_ops(2); q_slot(integral_constant<int, 3>{}, true_type{});
+        m_slot(2, false_type{}); hop = head_ops(3); q_slot(integral_constant<int, 4>{}, true_type{});
+        m_slot(3, false_type{}); hop = head_ops(4); q_slot(integral_constant<int, 5>{}, true_type{});
+        m_slot(4, false_type{}); hop = head_ops(5); q_slot(integral_constant<int, 6>{}, true_type{});
+        m_slot(5, false_type{}); hop = head_ops(6); q_slot(integral_constant<int, 7>{}, true_type{});
+        hop = head_ops(7);
+        m_slot(6, true_type{});
+        m_slot(7, false_type{});
+        K9_T(2);
+        K9_T(3);
+    } else {
+        K9_T(3);
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            Frag (&cur)[8] = (st & 1) ? fb : fa;
+            Frag (&nxt)[8] = (st & 1) ? fa : fb;
+            const Frag bf = mfrag[st >> 1][st & 1];
+            ring_step<0>(ring, cur, nxt, st & 3, [&](int nb) { Mm::mma(cur[nb], bf, m[nb]); }, [] {});
+        }
+    }
+#else
+#if K9_MERGEPIPE
+    v16f m[8];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) m[nb] = zero16();
+#endif
     if constexpr (ATTN) {
         // ---------------- q = W_q x : 16 steps (k-step ks = step, tiles nb = 0..7)
         v16f q[8];
@@ -415,6 +601,11 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
             o.kv1 = *reinterpret_cast<const Frag*>(smem + KV_OFF + (hh * 2 + 1) * FRAG + lane * 16);
             return o;
         };
+#if K9_MERGEPIPE
+#define K9_HX(hh) 0
+#else
+#define K9_HX(hh) ((hh) & 1)
+#endif
         v16f num[2];
         float den[2];
         // phi(q) is rounded by its packing (one conversion per pair) and the denominator phi(q) . Ksum / S is summed from the PACKED
@@ -427,16 +618,16 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
             for (int r = 0; r < 16; ++r) pq[r] = phi(q[hh][r]);
             const Frag p0 = pack8<T>(pq[0], pq[1], pq[2], pq[3], pq[4], pq[5], pq[6], pq[7]);
             const Frag p1 = pack8<T>(pq[8], pq[9], pq[10], pq[11], pq[12], pq[13], pq[14], pq[15]);
-            den[hh & 1] = dot8(p1, ho.ks1, dot8(p0, ho.ks0, 0.f));
-            num[hh & 1] = zero16();
-            Mm::mma(ho.kv0, p0, num[hh & 1]);
-            Mm::mma(ho.kv1, p1, num[hh & 1]);
+            den[K9_HX(hh)] = dot8(p1, ho.ks1, dot8(p0, ho.ks0, 0.f));
+            num[K9_HX(hh)] = zero16();
+            Mm::mma(ho.kv0, p0, num[K9_HX(hh)]);
+            Mm::mma(ho.kv1, p1, num[K9_HX(hh)]);
         };
         auto stage_b = [&](int hh) {
-            float d = den[hh & 1];
+            float d = den[K9_HX(hh)];
             d = half_sum(d);
             const float z = __builtin_amdgcn_rcpf(d + eps_s) * qmul;
-            v16f& nm = num[hh & 1];
+            v16f& nm = num[K9_HX(hh)];
 #pragma unroll
             for (int r = 0; r < 16; ++r) nm[r] *= z;
             mfrag[hh][0] = pack_step<T>(nm, 0);
@@ -444,6 +635,43 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
         };
         HeadOps hops[2];
         hops[0] = head_ops(0);
+#if K9_MERGEPIPE
+        // Round 5 (-DK9_MERGEPIPE=1, an experiment): the merge's k-steps are head-major already (steps 2h, 2h + 1 = head h), so the
+        // attention of head h + 1 can ride in the two merge steps of head h - only head 0's attention stays a phase of its own.
+        // Same sums in the same order.
+        stage_a(0, hops[0]);
+        hops[0] = head_ops(1);
+        stage_b(0);
+        K9_T(3);
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            Frag (&cur)[8] = (st & 1) ? fb : fa;
+            Frag (&nxt)[8] = (st & 1) ? fa : fb;
+            const Frag bf = mfrag[st >> 1][st & 1];
+            const int hn = (st >> 1) + 1;                                   // the head whose attention rides in this step
+            ring_step<0>(ring, cur, nxt, st & 3, [&](int nb) { Mm::mma(cur[nb], bf, m[nb]); },
+                         [&] {
+                             if (hn < 8) {
+                                 if ((st & 1) == 0) {
+                                     stage_a(hn, hops[0]);                  // (one set of operands and one numerator: A and B of a head are a step apart)
+                                 } else {
+                                     stage_b(hn);
+                                     if (hn < 7) hops[0] = head_ops(hn + 1);
+                                 }
+                             }
+                         });
+        }
+    } else {
+        K9_T(3);
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            Frag (&cur)[8] = (st & 1) ? fb : fa;
+            Frag (&nxt)[8] = (st & 1) ? fa : fb;
+            const Frag bf = mfrag[st >> 1][st & 1];
+            ring_step<0>(ring, cur, nxt, st & 3, [&](int nb) { Mm::mma(cur[nb], bf, m[nb]); }, [] {});
+        }
+    }
+#else
 #pragma unroll
         for (int hh = 0; hh < 8; ++hh) {
             if (hh < 7) hops[(hh + 1) & 1] = head_ops(hh + 1);
@@ -452,7 +680,9 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
         }
         stage_b(7);
     }
+#endif
 
+#if !K9_MERGEPIPE
     K9_T(3);
     // ---------------- m = LN1(W_m msg) : 16 steps, operand (tile t = step / 2, k-step s = step % 2) from registers
     v16f m[8];
@@ -465,6 +695,8 @@ __global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
         const Frag bf = mfrag[st >> 1][st & 1];
         ring_step<0>(ring, cur, nxt, st & 3, [&](int nb) { Mm::mma(cur[nb], bf, m[nb]); }, [] {});
     }
+#endif
+#endif
     // nn.LayerNorm over the 256 channels of the lane's token, statistics in fp32; the other lane half holds the other
     // 128 channels.  One pass over the accumulators (they live in AGPRs: every use is a register move): sum and sum of
     // squares, var = E[x^2] - mean^2 (|x| = O(1) after a 256..512-deep product of O(1) operands: no cancellation issue).

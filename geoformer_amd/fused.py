@@ -12,6 +12,8 @@ Packing happens once per layer and dtype (cached by the modules), with plain tor
 """
 import ctypes
 
+import os
+
 import torch
 
 from . import _lib
@@ -51,6 +53,11 @@ def _steps(f, tiles, ksteps):
     return torch.cat([f[tiles, ks].reshape(-1) for group in ksteps for ks in group])
 
 
+# must agree with -DK9_HEADPIPE of csrc/k9_encoder_fused.hip (0 = the default build); GF_K9_HEADPIPE=1 with a -DK9_HEADPIPE=1 build: the round-5
+# experiment (head-major q / merge stream; bit-identical results, measured slower)
+HEAD_PIPELINE = os.environ.get('GF_K9_HEADPIPE', '0') == '1'
+
+
 def pack_layer_stream(wq, wm, w1, w2):
     """Stream of gf_encoder_layer, in steps of 8 fragments (4 steps = one 32-KiB block):
        [W_q: 16 steps (k-step ks: tiles 0..7)] + W_m: 16 steps (permuted order) + per 128-wide hidden slice sl
@@ -59,9 +66,27 @@ def pack_layer_stream(wq, wm, w1, w2):
     c = wm.shape[0]
     parts = []
     all8 = torch.arange(8, device=wm.device)
-    if wq is not None:
-        parts.append(_steps(fragments(wq, 'std'), all8, [[ks] for ks in range(16)]))
-    parts.append(_steps(fragments(wm, 'perm'), all8, [[ks] for ks in range(16)]))
+    fm = fragments(wm, 'perm')
+    if wq is not None and HEAD_PIPELINE:
+        # round 5: q projection and merge HEAD-MAJOR and interleaved, so that the attention of head h (vector work) runs under the
+        # MFMAs of its neighbours in one instruction stream: Q(h) = 2 steps = the 16 k-steps of channel tile h (one accumulator),
+        # M(h) = the merge's k-steps 2h, 2h + 1 (tiles 0..7) as before; order Q0 Q1 M0 Q2 M1 ... Q7 M6 M7.  Every accumulator still
+        # sums its k-steps in ascending order: the results keep their bits.
+        fq = fragments(wq, 'std')
+
+        def q_head(h):
+            return torch.cat([_steps(fq, torch.tensor([h], device=wm.device), [[8 * hf + j for j in range(8)]]) for hf in range(2)])
+
+        def m_head(h):
+            return _steps(fm, all8, [[2 * h], [2 * h + 1]])
+        parts += [q_head(0), q_head(1)]
+        for h in range(6):
+            parts += [m_head(h), q_head(h + 2)]
+        parts += [m_head(6), m_head(7)]
+    else:
+        if wq is not None:
+            parts.append(_steps(fragments(wq, 'std'), all8, [[ks] for ks in range(16)]))
+        parts.append(_steps(fm, all8, [[ks] for ks in range(16)]))
     f1x, f1m = fragments(w1[:, :c], 'std'), fragments(w1[:, c:], 'perm')   # [16, 16, 64, 8]
     pairs = [[2 * j, 2 * j + 1] for j in range(8)]
     for sl in range(4):

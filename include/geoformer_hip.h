@@ -351,9 +351,11 @@ int gf_inlier_index(const float* kp0, const float* kp1, const uint8_t* keep, con
  *   q [N,L,256], kmap/vmap [N,L,256] = k_proj/v_proj of EVERY token (row strides ld*), idx/nkeys =
  *   the token list of gf_inlier_index; out [N,L,256]; nkeys == 0 -> zeros (layer skipped by caller).
  *   16-bit modes: q and kmap 16-byte aligned with row strides that are multiples of 8 elements (rows move as 16-byte pieces).
- *   Arithmetic of the 16-bit modes (flash form): per query a softmax reference that moves only when a key tile's maximum exceeds
- *   it by more than 8 in log2 units, probabilities rounded to the storage type for P.V, their sum in fp32;
- *   mathematically softmax(Q K^T / sqrt(D)) V whatever the reference.  GF_F32: the exact running maximum, fp32 throughout.
+ *   Arithmetic of the 16-bit modes (flash form): the softmax scale lives in the query operand, q' = round(q * log2(e) / sqrt(D)) to the
+ *   storage type (one more 16-bit rounding of q), logits q' . k in fp32; per query a softmax reference that starts at the first key
+ *   tile's maximum and moves up only when a tile's maximum exceeds it by more than 8 (log2 units); probabilities rounded to the
+ *   storage type for P.V, their sum in fp32; mathematically softmax(Q K^T / sqrt(D)) V.  GF_F32: the exact running maximum, the
+ *   scale applied to the fp32 logits, fp32 throughout.
  * ------------------------------------------------------------------------------------------ */
 size_t gf_self_attention_workspace_bytes(int N, int L, int dtype);
 int gf_self_attention_gathered(const void* q, const void* kmap, const void* vmap, int dtype, int N, int L, int H,

@@ -651,28 +651,30 @@ K4_DEFER_LOG2 = 8.0      # geoformer_amd/csrc/k4_attention.hip:K4_DEFER
 
 def _flash_self_attention(q, k, v, st, tile: int = 32):
     """q [L,H,D], k, v [K,H,D] (rounded) -> [L,H,D]: online softmax over key tiles exactly as attn_self runs it in the 16-bit
-    modes - a reference m per query that moves only when a tile's maximum exceeds it by more than 8 in the exponent's log2 units
-    (always in the first tile; round 5: the kernel's deferred maximum, a per-query rule), probabilities exp(s - m) rounded to the
-    storage type for the P.V product while their sum stays fp32, rescale by exp(m_old - m_new) where m moved, one division at
-    the end.  (Mathematically the reference's softmax(QK^T / sqrt(D)) V, geo_attention.py:72-101, whatever the threshold.)"""
+    modes (round 5) - the softmax scale lives in the query operand, q' = round(q * log2(e) / sqrt(D)) to the storage type, so the
+    logits x = q' . k are the exponent's log2 argument; a reference m per query that starts at the first tile's maximum and then
+    moves up only when a tile's maximum exceeds it by more than 8 (the kernel's deferred maximum, a per-query rule);
+    probabilities 2^(x - m) rounded to the storage type for the P.V product while their sum stays fp32, rescale by 2^(m_old - m_new)
+    where m moved, one division at the end.  (Mathematically the reference's softmax(QK^T / sqrt(D)) V, geo_attention.py:72-101,
+    whatever the threshold; the one extra rounding is that of q * c.  With st = float32 nothing is rounded.)"""
     L, H, D = q.shape
     K = k.shape[0]
-    temp = 1.0 / D ** .5
-    defer = K4_DEFER_LOG2 * math.log(2.0)                 # on the scaled logits x = s * temp (natural-log units)
-    m = torch.full((L, H), float('-inf'))
+    c = math.log2(math.e) / D ** .5
+    qs = rt(q * c, st)
+    m = torch.zeros(L, H)
     l = torch.zeros(L, H)
     o = torch.zeros(L, H, D)
     for t0 in range(0, K, tile):
         kt, vt = k[t0:t0 + tile], v[t0:t0 + tile]
-        x = torch.einsum('lhd,shd->lhs', q, kt) * temp
-        tmax = x.max(dim=2)[0]
-        need = (tmax - m) > defer                          # m = -inf: True
-        mnew = torch.where(need, tmax, m)
-        alpha = torch.where(need, torch.exp(m - mnew), torch.ones_like(m))
-        p = torch.exp(x - mnew[..., None])
+        x = torch.einsum('lhd,shd->lhs', qs, kt)          # log2 units
+        tmax = x.max(dim=2)[0] - m
+        need = (tmax > K4_DEFER_LOG2) if t0 > 0 else torch.ones_like(tmax, dtype=torch.bool)
+        d = torch.where(need, tmax, torch.zeros_like(tmax))
+        alpha = torch.exp2(-d) if t0 > 0 else torch.zeros_like(d)      # first tile: O = l = 0
+        m = m + d
+        p = torch.exp2(x - m[..., None])
         l = l * alpha + p.sum(dim=2)
         o = o * alpha[..., None] + torch.einsum('lhs,shd->lhd', rt(p, st), vt)
-        m = mnew
     return rt(o / l[..., None], st)
 
 
