@@ -437,6 +437,11 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(ConvArgs a) {
                     if (first_turn) K10_T(13);
                     if constexpr (!R) K10_T2(20 + ts / BS);
                     __builtin_amdgcn_s_barrier();
+#ifdef K10_STAGGER     // -DK10_STAGGER=n (experiment, round 5; guide: 'two waves that run the same program with one barrier per block: try a stagger'):
+                    // the second-dispatched half of the waves sleeps 64 n cycles behind every ring turn, so that the two waves of a SIMD do not reach
+                    // their fragment-read bursts and MFMA runs together
+                    if (NW == 8 && wave >= 4) __builtin_amdgcn_s_sleep(K10_STAGGER);
+#endif
                     if constexpr (!R) K10_T2(24 + ts / BS);
                     if (first_turn) K10_T(14);
                     wslot ^= 1;                                                 // the landed block; the other slot is the one to fill
