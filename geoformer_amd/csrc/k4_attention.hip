@@ -119,6 +119,23 @@ __device__ long long k4_trace[2048 * 32];
 #define K4_T(slot)
 #endif
 
+// DIRECT form: 16-byte chunk of V row `row` that LDS slot `s` (0..31) of that row holds: the 32-byte block index XOR 2 (row & 3)
+__device__ __forceinline__ int k4_vslot_chunk(int row, int s) { return ((((s >> 1) ^ (2 * (row & 3))) << 1) | (s & 1)); }
+// A operand of the P.V product from the ROW-MAJOR V image [32 keys][512 B]: lane (channel blk32 * 16 + 16 (G & 1) + i of its 32-channel block,
+// half G >> 1) gets keys 16 s2 + 8 (j >> 2) + 4 (G >> 1) + (j & 3), j = 0..7 - the k order of the packed P^T
+template <typename T>
+__device__ __forceinline__ typename Mma32<T>::Frag k4_vtr_frag(const char* img, int blk0, int s2, int lane) {
+    const int G = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int row = 16 * s2 + 4 * (G >> 1) + q;
+    const char* base = img + row * 512 + (((blk0 + (G & 1)) ^ (2 * q)) << 5) + p * 8;
+    typedef __attribute__((address_space(3))) gf_v4s* LP;
+    const gf_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LP)(base));
+    const gf_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LP)(base + 8 * 512));
+    typedef short v8s __attribute__((__vector_size__(8 * sizeof(short))));
+    const v8s both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(typename Mma32<T>::Frag, both);
+}
+
 // LDS-DMA (16-bit modes): 64 lanes x 16 B of a staged tile straight from the compact K / V^T buffers into LDS, no registers.
 // MUBUF form: the waits the compiler inserts stay counted (the FLAT form makes every LDS wait lgkmcnt(0)).
 struct AtRsrc {
@@ -145,12 +162,17 @@ __device__ __forceinline__ float half_max(float x) {
 // stream, not the matrix pipe, is what paces the two-wave forms: 1.95 GB per 16-image call at 1195 keys = 37 GB/s per CU, half of what
 // the LDS-DMA path reaches), 16 waves = four per SIMD, and a THREE-image ring: the tile after next is already requested when a tile is
 // computed (counted vmcnt: the wait at a tile's top leaves the next tile's pieces in flight).
+// DIRECT (16-bit modes, round 5): no gather pass and no compact K / V^T buffers - the K AND V rows of a tile's 32 keys come straight from the
+// projected maps by LDS-DMA with a per-lane source row (the token list entry of the lane's row, read a tile ahead; rows behind the key count are
+// out-of-range lanes = zeros in LDS), both row-major in LDS; the P.V product's A operand (channels x keys) is fetched from the row-major V image
+// with the transposing read ds_read_b64_tr_b16 in the key order of the packed P^T (k2_linear_attention.hip's la16_tr_frag with the two 4-row
+// groups 8 rows apart); the V image's 32-byte blocks are XORed with 2 (row & 3) so that the four rows a 16-lane group reads fall on distinct banks.
 // PRE (16-bit modes, round 5; the default): the softmax scale lives in the Q operand - q' = round(q * log2(e) / sqrt(D)) when the query
 // rows are loaded - and the query's reference m' enters the S MFMA chain as its C operand (a 16-register tile of -m', rewritten only when
 // the reference moves), so the accumulator IS the exponent's argument: per logit one exponential, half a max3, half a pair add and
 // half a conversion - no FMA.  The price is one more 16-bit rounding of q (the product q . k is then scaled BEFORE the sum instead of
 // after it: the same softmax(Q K^T / sqrt(D)) V; the oracle's storage mode rounds q * c the same way).
-template <typename T, int QB, int WV, bool MSUM = false, bool PRE = true>
+template <typename T, int QB, int WV, bool MSUM = false, bool PRE = true, bool DIRECT = false>
 __global__ __launch_bounds__(64 * WV, WV == 16 ? 4 : WV == 8 ? (QB == 1 ? 4 : 2) : (QB <= 2 ? 2 : 1)) void attn_self(AtArgs a) {
     using M = Mma32<T>;
     using Frag = typename M::Frag;
@@ -383,7 +405,9 @@ __global__ __launch_bounds__(64 * WV, WV == 16 ? 4 : WV == 8 ? (QB == 1 ? 4 : 2)
                                   (T)x[8 * s2 + 4], (T)x[8 * s2 + 5], (T)x[8 * s2 + 6], (T)x[8 * s2 + 7]};
     #pragma unroll
                     for (int b = 0; b < 2; ++b) {
-                        const Frag vf = *reinterpret_cast<const Frag*>(vs + vt_off(head * HD + b * 32 + lr, 2 * s2 + h));
+                        Frag vf;
+                        if constexpr (DIRECT) vf = k4_vtr_frag<T>(vs, head * 4 + b * 2, s2, lane);
+                        else vf = *reinterpret_cast<const Frag*>(vs + vt_off(head * HD + b * 32 + lr, 2 * s2 + h));
                         M::mma(vf, pf, o[qb][b]);
                     }
                     if constexpr (MSUM) M::mma(ones, pf, lacc[qb]);
@@ -430,30 +454,68 @@ __global__ __launch_bounds__(64 * WV, WV == 16 ? 4 : WV == 8 ? (QB == 1 ? 4 : 2)
         // (round 3, with the tile passing through registers and two barriers: 335 us per 16-image call at 1195 keys, 218 us
         // with the staging compiled out)
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const AtRsrc rk = at_rsrc(kc, (unsigned)((size_t)a.Kpad * CC * sizeof(T)));
-        const AtRsrc rv = at_rsrc((const T*)a.vc + (size_t)n * CC * a.Kpad, (unsigned)((size_t)CC * a.Kpad * sizeof(T)));
+        const AtRsrc rk = DIRECT ? at_rsrc((const T*)a.kmap + (size_t)n * a.L * a.ldk, (unsigned)((size_t)a.L * a.ldk * sizeof(T)))
+                                 : at_rsrc(kc, (unsigned)((size_t)a.Kpad * CC * sizeof(T)));
+        const AtRsrc rv = DIRECT ? at_rsrc((const T*)a.vmap + (size_t)n * a.L * a.ldv, (unsigned)((size_t)a.L * a.ldv * sizeof(T)))
+                                 : at_rsrc((const T*)a.vc + (size_t)n * CC * a.Kpad, (unsigned)((size_t)CC * a.Kpad * sizeof(T)));
         // K image: 1 KiB group g = key rows 2g, 2g+1; slot s of row r holds chunk s ^ (r & 15) (k_off)
         // V^T image: group g = channels 16g..16g+15, 4 slots of 16 B; slot s of channel c holds chunk s ^ ((c >> 2) & 3) (vt_off)
+        // (DIRECT: the V image is row-major like K's: group g = key rows 2g, 2g+1, slot s of row r holds chunk k4_vslot_chunk(r, s))
         constexpr int PW = 16 / WV;                            // 1-KiB pieces per wave, tile and operand
         int kvo[PW], vvo[PW];
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
             const int g = wv * PW + i;
             const int krow = 2 * g + (lane >> 5), kslot = lane & 31;
-            kvo[i] = krow * (CC * (int)sizeof(T)) + ((kslot ^ (krow & 15)) << 4);
-            const int vrow = 16 * g + (lane >> 2), vslot = lane & 3;
-            vvo[i] = vrow * (a.Kpad * (int)sizeof(T)) + ((vslot ^ ((vrow >> 2) & 3)) << 4);
+            if constexpr (DIRECT) {
+                kvo[i] = (kslot ^ (krow & 15)) << 4;                       // inside the token's row; the row itself comes from the token list
+                vvo[i] = k4_vslot_chunk(krow, kslot) << 4;
+            } else {
+                kvo[i] = krow * (CC * (int)sizeof(T)) + ((kslot ^ (krow & 15)) << 4);
+                const int vrow = 16 * g + (lane >> 2), vslot = lane & 3;
+                vvo[i] = vrow * (a.Kpad * (int)sizeof(T)) + ((vslot ^ ((vrow >> 2) & 3)) << 4);
+            }
         }
         constexpr int NB = WV == 16 ? 3 : 2;                   // LDS images of the (K, V^T) tile
+        // DIRECT: the token of the lane's row of piece i, for the tile whose request comes next (read a tile ahead)
+        const int32_t* idxn = a.idx + (size_t)n * a.idx_stride;
+        int tokn[PW];
+        auto load_tok = [&](int tile) {
+#pragma unroll
+            for (int i = 0; i < PW; ++i) {
+                const int key = tile * KT + 2 * (wv * PW + i) + (lane >> 5);
+                tokn[i] = key < K ? idxn[key] : -1;
+            }
+        };
         auto request = [&](int tile, int slot) {
             char* img = smem + slot * (2 * KBYTES);
+            if constexpr (DIRECT) {
 #pragma unroll
-            for (int i = 0; i < PW; ++i) at_lds_dma(rk, img + (wv * PW + i) * 1024, kvo[i], tile * KBYTES);
+                for (int i = 0; i < PW; ++i) {
+                    // a key slot behind the count: an offset outside the map = an out-of-range lane: zeros in LDS
+                    const int kofs = tokn[i] >= 0 ? tokn[i] * (int)(a.ldk * sizeof(T)) + kvo[i] : 0x7FFFFFF0;
+                    at_lds_dma(rk, img + (wv * PW + i) * 1024, kofs, 0);
+                }
 #pragma unroll
-            for (int i = 0; i < PW; ++i) at_lds_dma(rv, img + KBYTES + (wv * PW + i) * 1024, vvo[i], tile * (KT * (int)sizeof(T)));
+                for (int i = 0; i < PW; ++i) {
+                    const int vofs = tokn[i] >= 0 ? tokn[i] * (int)(a.ldv * sizeof(T)) + vvo[i] : 0x7FFFFFF0;
+                    at_lds_dma(rv, img + KBYTES + (wv * PW + i) * 1024, vofs, 0);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < PW; ++i) at_lds_dma(rk, img + (wv * PW + i) * 1024, kvo[i], tile * KBYTES);
+#pragma unroll
+                for (int i = 0; i < PW; ++i) at_lds_dma(rv, img + KBYTES + (wv * PW + i) * 1024, vvo[i], tile * (KT * (int)sizeof(T)));
+            }
         };
         if constexpr (NB == 2) {
+            if constexpr (DIRECT) {
+                if (ntiles > 0) load_tok(0);                      // (waited for by the compiler in front of the first request)
+            }
             if (ntiles > 0) request(0, 0);
+            if constexpr (DIRECT) {
+                if (ntiles > 1) load_tok(1);
+            }
             // (round 5: unrolled by the two images so that an image's base is a compile-time constant - the eight fragment addresses of
             // a tile are lane constants + immediates instead of eight v_add3 per tile: the kernel is paced by its instruction count)
             auto iter = [&](auto par_c, int tile) {
@@ -464,6 +526,9 @@ __global__ __launch_bounds__(64 * WV, WV == 16 ? 4 : WV == 8 ? (QB == 1 ? 4 : 2)
                 __syncthreads();
                 K4_T(2);
                 if (tile + 1 < ntiles) request(tile + 1, PAR ^ 1);
+                if constexpr (DIRECT) {
+                    if (tile + 2 < ntiles) load_tok(tile + 2);    // lands under this tile's products; the next top's vmcnt(0) covers it
+                }
                 const char* img = smem + PAR * (2 * KBYTES);
                 compute(tile, img, img + KBYTES);
             };
@@ -830,9 +895,13 @@ extern "C" int gf_self_attention_gathered(const void* q, const void* kmap, const
     static const bool pipe = [] { const char* e = getenv("GF_K4_FORM"); return e && e[0] == 'p'; }();
     if (pipe && dtype != GF_F32) { wv = 32; qb = 2; }
     static const bool msum = [] { const char* e = getenv("GF_K4_MSUM"); return e && e[0] == '1'; }();      // A/B: row sums on the matrix pipe
+    static const bool gather_env = [] { const char* e = getenv("GF_K4_GATHER"); return e && e[0] == '1'; }();   // A/B: the compact-buffer form (gather pass + V^T image)
     static const bool nopre = [] { const char* e = getenv("GF_K4_PRE"); return e && e[0] == '0'; }();       // A/B: the scale in the exponent's FMA (round 4's arithmetic + deferred reference)
     static const int abl = [] { const char* e = getenv("GF_K4_ABL"); return e ? atoi(e) : 0; }();
     (void)abl;
+    // the gather-free form (round 5): the default form's K / V rows straight from the projected maps; needs 16-byte aligned value rows too
+    const bool direct = !gather_env && !msum && !nopre && wv == 8 && qb == 1 && dtype != GF_F32 && (uintptr_t)vmap % 16 == 0 && ldv % 8 == 0 &&
+                        (size_t)L * (size_t)(ldk > ldv ? ldk : ldv) * 2 < 0x7FFFFFF0ull;
     const dim3 ggrid(dtype == GF_F32 ? a.Kpad / KT : (a.Kpad / 8 < 64 ? a.Kpad / 8 : 64), N), agrid((L + 8 * qb * wv - 1) / (8 * qb * wv), N);
 #define GF_K4_WIDE_16(T)                                                                           \
     do {                                                                                           \
@@ -841,6 +910,7 @@ extern "C" int gf_self_attention_gathered(const void* q, const void* kmap, const
         else if (qb == 2) attn_self<T, 2, 8><<<agrid, 512, 4 * KT * CC * 2, st>>>(a);              \
         else if (msum) attn_self<T, 1, 8, true><<<agrid, 512, 4 * KT * CC * 2, st>>>(a);          \
         else if (nopre) attn_self<T, 1, 8, false, false><<<agrid, 512, 4 * KT * CC * 2, st>>>(a);  \
+        else if (direct) attn_self<T, 1, 8, false, true, true><<<agrid, 512, 4 * KT * CC * 2, st>>>(a); \
         else attn_self<T, 1, 8><<<agrid, 512, 4 * KT * CC * 2, st>>>(a);                           \
     } while (0)
 #ifdef K4_ABLATE                    /* -DK4_ABLATE: the diagnostic instances of attn_self_pipe, picked by GF_K4_ABL=1..6 (fp16) */
@@ -867,7 +937,7 @@ extern "C" int gf_self_attention_gathered(const void* q, const void* kmap, const
 #define GF_K4_LAUNCH(T, ES, GF_K4_WIDE)                                                                        \
     do {                                                                                           \
         const size_t LDSB = (ES == 4 ? 2 : 4) * KT * CC * ES;      /* 16-bit: two (K, V^T) images */       \
-        attn_gather_kv<T><<<ggrid, 256, 0, st>>>(a);                                               \
+        if (!direct) attn_gather_kv<T><<<ggrid, 256, 0, st>>>(a);                                  \
         if (wv >= 8) { GF_K4_WIDE(T); break; }                                                     \
         if (qb == 4) attn_self<T, 4, 4><<<agrid, 256, LDSB, st>>>(a);                     \
         else if (qb == 2) attn_self<T, 2, 4><<<agrid, 256, LDSB, st>>>(a);                \

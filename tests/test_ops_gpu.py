@@ -984,3 +984,56 @@ def test_linear_column_tiles_per_xcd(dtype, N):
     tol = (2e-5, 2e-5) if dtype == torch.float32 else (1e-2, 1e-2)
     close(ops.linear(x, w), ref, *tol)
     close(ops.linear(x, w, epilogue=ops.EPI_RELU), ref.clamp(min=0), *tol)
+
+
+def test_self_attention_forms_agree():
+    """The K4 forms kept for the record (GF_K4_QB / GF_K4_WV / GF_K4_FORM=pipe / GF_K4_MSUM / GF_K4_PRE=0 / GF_K4_GATHER=1 - read once per
+    process, hence one child process per form) compute the same attention as the default form: on one seeded problem with ragged key counts
+    every form stays within the storage type's resolution of the fp32 oracle, and the forms that share the default's arithmetic exactly
+    (other wave / block shapes) reproduce its bits."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = r'''
+import sys, hashlib
+sys.path.insert(0, %r); sys.path.insert(0, %r + '/oracle')
+import torch
+import geoformer_oracle as O
+from geoformer_amd import ops
+g = torch.Generator().manual_seed(41)
+N, L, C, H = 9, 3688, 256, 4
+q = torch.randn(N, L, C, generator=g).half(); kv = torch.randn(N, L, 2 * C, generator=g).half()
+nk = [333, 0, 70, 1, 32, 33, 500, 64, 97]
+idx = torch.zeros(N, L, dtype=torch.int32)
+for b in range(N):
+    idx[b, :nk[b]] = torch.sort(torch.randperm(L, generator=g)[:nk[b]])[0].int()
+out = ops.self_attention_gathered(q.cuda(), kv.cuda()[..., :C], kv.cuda()[..., C:], idx.cuda(), torch.tensor(nk, dtype=torch.int32).cuda(), H).cpu()
+worst = 0.0
+for b in range(N):
+    if nk[b] == 0:
+        assert float(out[b].abs().max()) == 0.0
+        continue
+    sel = idx[b, :nk[b]].long()
+    ref = O.full_attention(q[b].float().view(1, L, H, -1), kv[b, sel, :C].float().view(1, nk[b], H, -1), kv[b, sel, C:].float().view(1, nk[b], H, -1)).reshape(L, C)
+    worst = max(worst, float((out[b].float() - ref).abs().max()))
+print('RESULT', worst, hashlib.sha256(out.numpy().tobytes()).hexdigest()[:16])
+''' % (root, root)
+    forms = {'default': {}, 'qb2_wv4': {'GF_K4_QB': '2', 'GF_K4_WV': '4'}, 'qb1_wv4': {'GF_K4_QB': '1', 'GF_K4_WV': '4'},
+             'qb1_wv16': {'GF_K4_QB': '1', 'GF_K4_WV': '16'}, 'qb2_wv8': {'GF_K4_QB': '2', 'GF_K4_WV': '8'},
+             'pipe': {'GF_K4_FORM': 'pipe'}, 'msum': {'GF_K4_MSUM': '1'}, 'nopre': {'GF_K4_PRE': '0'}, 'gather': {'GF_K4_GATHER': '1'}}
+    res = {}
+    for name, env in forms.items():
+        e = {k: v for k, v in os.environ.items() if not k.startswith('GF_K4_')}
+        e.update(env)
+        r = subprocess.run([sys.executable, '-c', child], env=e, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith('RESULT')]
+        assert r.returncode == 0 and line, (name, r.stderr[-800:])
+        _, worst, dig = line[0].split()
+        res[name] = (float(worst), dig)
+    print(res)
+    for name, (worst, _) in res.items():
+        assert worst < 4e-3, (name, worst)
+    # same arithmetic per query, another shape of workgroup: the default's bits
+    for name in ('qb2_wv4', 'qb1_wv4', 'qb1_wv16', 'qb2_wv8', 'gather'):         # ('gather': the compact-buffer form of the default, which reads the maps directly)
+        assert res[name][1] == res['default'][1], (name, res[name], res['default'])

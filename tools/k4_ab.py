@@ -46,5 +46,7 @@ for v in variants:
         env.pop('GF_K4_FORM'); env['GF_K4_MSUM'] = '1'
     if len(v) > 2 and v[2] == 'nopre':
         env.pop('GF_K4_FORM'); env['GF_K4_PRE'] = '0'
+    if len(v) > 2 and v[2] == 'gather':
+        env.pop('GF_K4_FORM'); env['GF_K4_GATHER'] = '1'
     r = subprocess.run([sys.executable, '-c', CHILD, K], env=env, capture_output=True, text=True)
     print(f'QB={v[0]} WV={v[1]}' + (f' FORM={v[2]}' if len(v) > 2 else '') + (f' ABL={v[3]}' if len(v) > 3 else '') + ': ' + (r.stdout.strip() or r.stderr.strip()[-400:]), flush=True)
