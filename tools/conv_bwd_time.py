@@ -7,7 +7,7 @@ from geoformer_amd import miopen as gf_miopen
 gf_miopen.use_shipped_find_db()
 import torch
 import torch.nn.functional as F
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+N = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 16
 dt = torch.bfloat16
 
 
@@ -22,7 +22,10 @@ def timeit(fn, n=10):
     return (time.perf_counter() - t) / n * 1e3
 
 
-for (ci, co, h, s) in ((128, 128, 320, 1), (128, 196, 320, 2), (196, 196, 160, 1), (196, 256, 160, 2), (256, 256, 80, 1), (256, 256, 80, 1), (196, 196, 160, 1), (196, 128, 320, 1)):
+SHAPES = ((128, 128, 320, 1), (128, 196, 320, 2), (196, 196, 160, 1), (196, 256, 160, 2), (256, 256, 80, 1), (196, 128, 320, 1))
+if '--padded' in sys.argv:                      # the same layers with the 196-channel sides padded to 224 (what the inference backbone does)
+    SHAPES = ((128, 224, 320, 2), (224, 224, 160, 1), (224, 256, 160, 2), (224, 128, 320, 1))
+for (ci, co, h, s) in SHAPES:
     x = torch.randn(N, ci, h, h, device='cuda', dtype=dt)
     w = torch.randn(co, ci, 3, 3, device='cuda', dtype=dt) * 0.03
     y = F.conv2d(x, w, None, s, 1)
