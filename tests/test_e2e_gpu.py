@@ -140,8 +140,8 @@ FINE_ARGMAX_EDGE = 1e-3
 # Round 5 (VERDICT r04 #2b): the band edge of a case is MEASURED on that case - the 99.9th percentile of the relative
 # difference of the two confidence matrices over the decision-relevant entries (oracle confidence >= thr / 2; >= 1e-2 in the dense
 # mode) - and capped by the mode's EDGE below; a kernel whose round-off grows widens nothing: the measured percentile has its own
-# ceiling NOISE_CEIL = the largest value measured on the MI355X over all cases of the mode x 1.25 (gpurun_out/r05a_pytest.log: fp16
-# 0.002 ... 0.082, bf16 0.026 ... 0.100; the large values belong to the `g11` / HPatches-shaped planted maps whose confidences sit
+# ceiling NOISE_CEIL = the largest value measured on the MI355X over all cases of the mode + a quarter to a third (gpurun_out/r05*_pytest.log:
+# fp16 0.002 ... 0.082, bf16 0.025 ... 0.111 - the largest on the 60-match g10c case, where the percentile is nearly a maximum; the large values belong to the `g11` / HPatches-shaped planted maps whose confidences sit
 # close to the threshold, the bench's own maps measure 0.006 ... 0.020 in fp16 and 0.075 in bf16).  fp16 keeps EDGE = 3 % (every
 # difference ever seen sat inside it); bf16 was "8 x fp16" = 24 %, which made the band 40 % of all matches - its measured noise is no
 # larger than fp16's p99.9 on the same maps (0.085 / 0.099 against 0.082 / 0.081), so its edge is min(measured, 12.5 %): B = 147 ...
@@ -149,7 +149,7 @@ FINE_ARGMAX_EDGE = 1e-3
 # on the MI355X plus a small margin (the counts move by a few with every change of an fp32 summation order), == 0 where the case has
 # always been bit-exact.
 EDGE = {'fp16': KNIFE_EDGE, 'bf16': 0.125}
-NOISE_CEIL = {KNIFE_EDGE: 0.10, 0.125: 0.125}        # keyed by the mode's EDGE (compare_with_storage_oracle gets the edge, not the mode)
+NOISE_CEIL = {KNIFE_EDGE: 0.10, 0.125: 0.15}        # keyed by the mode's EDGE (compare_with_storage_oracle gets the edge, not the mode)
 FINE_WIDEN = {KNIFE_EDGE: 1.0, 0.125: 8.0}           # the fine level's bands in bf16: 8 x fp16's (8 instead of 11 significant bits), as before
 # the two confidence matrices (entries > 1e-3): (max, mean) relative difference - 14 layers of storage round-off feed an
 # exponential with 1 / temperature = 10; the maxima measured on the MI355X over all cases (fp16: 0.223 / 8.3e-3 on the HPatches-shaped maps,

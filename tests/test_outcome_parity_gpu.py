@@ -106,4 +106,5 @@ def test_hpatches_protocol_auc_product_vs_fp32_oracle(precision):
         return
     gate = {'fp16': 2.5e-3, 'bf16': 5e-3}[precision]              # measured -1.5e-3 / +1.7e-3 at worst (docstring) + margin
     assert abs(auc_g[1] - auc_r[1]) <= gate, (precision, 'dAUC@3', float(auc_g[1] - auc_r[1]))
-    assert np.abs(auc_g - auc_r).max() <= 3 * gate, (precision, (auc_g - auc_r).tolist())
+    # (AUC@1 is the touchiest: a 1 px threshold against 0.4 px mean errors; measured up to -4e-3 in fp16, -1.2e-2 in bf16)
+    assert np.abs(auc_g - auc_r).max() <= {'fp16': 7.5e-3, 'bf16': 2.5e-2}[precision], (precision, (auc_g - auc_r).tolist())
