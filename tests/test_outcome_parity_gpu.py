@@ -22,10 +22,12 @@ MEASURED (MI355X, round 5, gpurun_out/r05l_pytest.log; AUC@1/3/5/10 of the oracl
                      such cells sit at 0.2-0.25, i.e. AT the threshold), and a tie is decided by the last bit of an fp32 sum whose order differs
                      between the MFMA kernels and torch's CPU GEMM.  The reference-generated goldens (g5, g10, g11) have no such ties and are
                      reproduced bit for bit.  This is the noise floor of the protocol on this data; north_star's 1e-3 holds;
-  fp16 storage       dAUC@3 = -1.2e-3 ... -1.5e-3 (dAUC@1 -3e-3 ... -4e-3; per pair 7e-3 px mean, 0.05 px max): three times that floor - the fine
+  fp16 storage       dAUC@3 = -0.25e-3 ... -1.5e-3 over this round's arithmetic variants (dAUC@1 -2e-3 ... -4e-3; per pair 7e-3 ... 1e-2 px mean): up to three times that floor - the fine
                      arg-max flips and threshold-edge coarse matches of 16-bit storage.  north_star's 1e-3 is NOT met by the fp16 storage mode on
-                     this protocol (by 0.2e-3 ... 0.5e-3); the gate below is the measured value + margin, so that a regression shows;
-  bf16 storage       dAUC@3 = -3e-5 ... +1.7e-3 (per pair 4e-2 px mean, 0.7 px max: larger, sign-symmetric)."""
+                     this 65-pair set in every variant; the gate below is the measured value + margin, so that a regression shows;
+  bf16 storage       dAUC@3 = -2.5e-3 ... +1.7e-3 (per pair 4e-2 px mean, 0.7 px max: larger, sign-symmetric).
+On 260 pairs (tools/outcome_parity_large.py 52, one-off; profiles/r05_outcome_parity_260_pairs.txt): dAUC@3 fp32 -2.0e-4, fp16 -6.2e-4, bf16 -6.4e-4 - the 65-pair
+figures scatter around these with the sampling noise of the set; at that sample size the fp16 mode is inside north_star's 1e-3."""
 import numpy as np
 import pytest
 import torch
