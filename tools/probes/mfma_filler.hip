@@ -54,13 +54,16 @@ void run(float* out, long long* t, int W) {
     hipDeviceSynchronize();
     std::vector<long long> h(256 * 16);
     hipMemcpy(h.data(), t, h.size() * 8, hipMemcpyDeviceToHost);
-    std::vector<long long> v;
+    std::vector<long long> v, vf;                                                    // loop times of the waves that issue MFMAs / of the filler-only waves
     for (int b = 0; b < 256; ++b)
-        for (int w = 0; w < 4 * W; ++w) v.push_back(h[b * 16 + w]);
+        for (int w = 0; w < 4 * W; ++w) (SPLIT && ((w >> 2) & 1) ? vf : v).push_back(h[b * 16 + w]);
     std::sort(v.begin(), v.end());
+    std::sort(vf.begin(), vf.end());
     const double cyc = (double)v[v.size() / 2];
     const double mfma_per_simd = (double)iters * 64 * (SPLIT ? W / 2 : W);           // MFMAs issued on one SIMD during the loop
-    printf("  F = %2d %s: %6.1f cycles per MFMA and SIMD (loop %7.0f cycles per wave)\n", F, EXP ? "v_exp_f32" : "v_fma_f32", cyc / mfma_per_simd, cyc);
+    printf("  F = %2d %s: %6.1f cycles per MFMA and SIMD (loop %7.0f cycles per MFMA wave", F, EXP ? "v_exp_f32" : "v_fma_f32", cyc / mfma_per_simd, cyc);
+    if (SPLIT) printf("; filler wave %7.0f = %.1f cycles per filler", (double)vf[vf.size() / 2], F ? (double)vf[vf.size() / 2] / ((double)iters * 64 * F) : 0.0);
+    printf(")\n");
 }
 
 template <bool EXP, bool SPLIT>
@@ -72,7 +75,7 @@ void sweep(float* out, long long* t, int W) {
 int main() {
     float* out; long long* t;
     hipMalloc(&out, 4096 * 4); hipMalloc(&t, 256 * 16 * 8);
-    for (int W : {1, 2, 4}) {
+    for (int W : {1, 2}) {
         printf("%d wave(s) per SIMD, every wave: [MFMA + F fillers] (the MFMAs of all waves share the SIMD's pipe)\n", W);
         sweep<false, false>(out, t, W);
         if (W == 1) { printf("  -- fillers = v_exp_f32\n"); sweep<true, false>(out, t, W); }
