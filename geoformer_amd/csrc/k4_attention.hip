@@ -825,6 +825,259 @@ __global__ __launch_bounds__(512, 2) void attn_self_pipe(AtArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 5, the HEAD form (the default of the 16-bit modes once the chip is full).  Two measurements decide its structure:
+//  * tools/probes/mfma_filler.hip: ONE wave's own stream covers up to five vector instructions (two exponentials) per v_mfma_f32_32x32x16 for nothing
+//    (32.3 cycles per MFMA at one or two waves per SIMD), but an MFMA-only wave beside a vector-only wave on the same SIMD both crawl (76 cycles per
+//    MFMA): a kernel whose waves alternate an MFMA phase and a softmax phase - attn_self - spends its time in exactly that pairing.  Here every wave's
+//    tile is ONE pinned instruction stream in which the softmax of tile t sits between the MFMAs of S(t + 1) and of P(t).V(t):
+//        S(t+1): 4 MFMAs, two exponentials of tile t behind each  |  P.V keys 0..15: 2 MFMAs, four exponentials behind each  |  P.V keys 16..31: 2 MFMAs
+//    (left alone the compiler puts the sixteen exponentials in front and the eight MFMAs behind them; the order is pinned with sched_barrier);
+//  * the four-head workgroup of that stream (one 32 KiB image of 32 keys per 64 queries, eight waves, one barrier domain per CU: 240 us where attn_self
+//    takes 203; with four loader waves beside eight computing waves 258 us: the computing waves' tile costs ~1000 cycles, the 32 KiB of rows do not
+//    arrive faster than every ~1700).  Here a workgroup owns ONE head: a tile's image is [32 keys][64 channels] of K and of V = 8 KiB, a quarter of the
+//    stream per flop, requested as eight 1 KiB pieces - and FOUR waves (128 queries): three workgroups per CU (168 registers) are three barrier
+//    domains, whose waves on a SIMD are in different phases of their tiles.  Eight waves x 256 queries (one domain per CU): 206 us; four waves: 183 us
+//    (16 images x 6400 queries x 1195 keys, tools/k4_ab.py), 227 us against 257 at 1600 keys.
+// NS images form the ring: tile t + NS - 1 is requested while tile t is computed, with the tokens read NS tiles before their request so that the counted
+// wait at a tile's top (the counter is in-order) leaves all later requests in flight.  Arithmetic per query: attn_self's PRE / DIRECT form, bit for bit.
+//   K image: row = key (128 B), 16-B chunk c at c ^ ((key >> 1) & 7)  (a ds_read_b128 lane group - 16 keys, one chunk - covers the 64 banks)
+//   V image: row = key (128 B), 32-B block b (16 channels) at b ^ 2 ((key >> 1) & 1)  (a transposing read's 32 lanes - 4 keys x 2 blocks x 4 pieces -
+//            cover the 64 banks); the fragment's second half is 8 keys = 1 KiB further
+template <typename T, int NS, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void attn_self_head(AtArgs a) {
+    using M = Mma32<T>;
+    using Frag = typename M::Frag;
+    constexpr int KG = M::kGroup, NG = HD / KG, D = NS - 1, QW = 32 * NW;
+    constexpr bool BOTH = NW == 4;                                         // four waves: each requests its eight rows of K AND of V (one token read)
+    static_assert(NW == 4 || NW == 8, "a tile's image is eight 1 KiB requests");
+    constexpr int KBYTES = KT * HD * sizeof(T), IMG = 2 * KBYTES;                            // 4 KiB + 4 KiB
+    static_assert(NG == 4 && sizeof(T) == 2 && KBYTES == 4096 && NS * IMG <= 65536, "written for 64-channel heads in 16-bit storage");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int NH = CC / HD, nqb = (a.L + QW - 1) / QW, gx = nqb * NH, total = gx * a.N, tid = threadIdx.x;
+    int id = blockIdx.x;
+    if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);           // whole images per XCD (see attn_self)
+    const int n = id / gx, head = (id - n * gx) / nqb, q0 = (id - n * gx - head * nqb) * QW + (tid >> 6) * 32;
+    const int lane = tid & 63, h = lane >> 5, lr = lane & 31;
+    const int K = a.nkeys[(size_t)n * a.nkeys_stride];
+    const int ntiles = (K + KT - 1) / KT;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    Frag qf[NG];
+    {
+        const int qrow = min(q0 + lr, a.L - 1);
+        const T* qp = (const T*)a.q + ((size_t)n * a.L + qrow) * a.ldq + head * HD;
+        const float c2 = a.softmax_temp * 1.44269504088896341f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            qf[g] = *reinterpret_cast<const Frag*>(qp + g * KG + h * (KG / 2));
+#pragma unroll
+            for (int j8 = 0; j8 < (int)(sizeof(Frag) / sizeof(T)); ++j8) qf[g][j8] = (T)(gf_to_float(qf[g][j8]) * c2);
+        }
+    }
+    v16f o[2], negm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; negm[r] = 0.f; }
+    float m = 0.f, l = 0.f;
+    // the wave's request: waves 0..3 the K rows 8 wv .. 8 wv + 7 of a tile, waves 4..7 the V rows 8 (wv - 4) ..; lane = (row lane >> 3, LDS chunk lane & 7).
+    // STRUCTURED buffer over the map: record = one row, the lane's token is the record index (a record index of L or more - the padded keys of the
+    // ragged tile get 0x7FFFFFFF - writes zeros), its logical 16-byte chunk of the head's 128 bytes the offset
+    const bool isv = !BOTH && wv >= 4;
+    const int rrow = 8 * (wv & 3) + (lane >> 3), rs = lane & 7;
+    const int roffk = head * (HD * (int)sizeof(T)) + (rs ^ ((rrow >> 1) & 7)) * 16;
+    const int roffv = head * (HD * (int)sizeof(T)) + ((((rs >> 1) ^ (((rrow >> 1) & 1) << 1)) << 1) | (rs & 1)) * 16;
+    const int roff = isv ? roffv : roffk;
+    const __amdgpu_buffer_rsrc_t rvmap =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>((const T*)a.vmap + (size_t)n * a.L * a.ldv), (short)(a.ldv * sizeof(T)), a.L, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rkmap =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>((const T*)a.kmap + (size_t)n * a.L * a.ldk), (short)(a.ldk * sizeof(T)), a.L, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rmap = isv ? rvmap : rkmap;
+    // the token list as a raw buffer of K words: tile * 128 bytes is the scalar offset, a key behind the list reads 0
+    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.idx + (size_t)n * a.idx_stride), 0, K * 4, 0x00020000);
+    char* const rdst = smem + (isv ? KBYTES : 0) + (wv & 3) * 1024;
+    int tk[NS];                                                            // token of the lane's row in tile j (mod NS), read NS tiles before its request
+    auto load_tok = [&](int tile) { return (int)__builtin_amdgcn_raw_buffer_load_b32(ri, rrow * 4, tile * (KT * 4), 0); };
+    auto request = [&](int slot, int tile, int t) {
+        const int rec = tile * KT + rrow >= K ? 0x7FFFFFFF : t;
+        if constexpr (BOTH) {
+            __builtin_amdgcn_struct_ptr_buffer_load_lds(rkmap, (__attribute__((address_space(3))) void*)(rdst + slot * IMG), 16, rec, roffk, 0, 0, 0);
+            __builtin_amdgcn_struct_ptr_buffer_load_lds(rvmap, (__attribute__((address_space(3))) void*)(rdst + KBYTES + slot * IMG), 16, rec, roffv, 0, 0, 0);
+        } else {
+            __builtin_amdgcn_struct_ptr_buffer_load_lds(rmap, (__attribute__((address_space(3))) void*)(rdst + slot * IMG), 16, rec, roff, 0, 0, 0);
+        }
+    };
+    int koff[NG], voff[2];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) koff[g] = lr * 128 + (((g * 2 + h) ^ ((lr >> 1) & 7)) << 4);
+    {
+        const int G = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) voff[b] = KBYTES + (4 * (G >> 1) + qq) * 128 + (((b * 2 + (G & 1)) ^ (((qq >> 1) & 1) << 1)) << 5) + pp * 8;
+    }
+    // A operand of P.V from the row-major V image: keys 16 s2 + 8 (j >> 2) + 4 (lane >> 5) + (j & 3), the k order of the packed P^T (see k4_vtr_frag)
+    auto v_frag = [&](const char* img, int b, int s2) {
+        typedef __attribute__((address_space(3))) gf_v4s* LP;
+        const gf_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LP)(img + voff[b] + s2 * 2048));
+        const gf_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LP)(img + voff[b] + s2 * 2048 + 1024));
+        typedef short v8s __attribute__((__vector_size__(8 * sizeof(short))));
+        const v8s both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(Frag, both);
+    };
+    v16f sc;
+    float tmax = 0.f;
+    auto tile_max = [&](v16f& s, int tile, bool ragged) {
+        if (ragged && (tile + 1) * KT > K) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = tile * KT + gf_acc_row(r, h) < K ? s[r] : -INFINITY;
+        }
+        float t = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) t = fmaxf(t, s[r]);
+        return half_max(t);
+    };
+    if (ntiles > 0) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) tk[j] = load_tok(j);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            request(j, j, tk[j]);
+            tk[j] = load_tok(j + NS);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        Frag kf[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) kf[g] = *reinterpret_cast<const Frag*>(smem + koff[g]);
+        sc = negm;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) M::mma(kf[g], qf[g], sc);
+        tmax = tile_max(sc, 0, true);
+    }
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    // TAIL: the bodies in which tile t + 1 may be the ragged last tile (its mask is a branch)
+    auto body = [&](auto slot_c, auto tail_c, int tile) {
+        constexpr bool TAIL = decltype(tail_c)::value;
+        constexpr int SLOT = decltype(slot_c)::value, NSLOT = (SLOT + 1) % NS, FSLOT = (SLOT + D) % NS;
+        K4_T(0);
+        if (tile > 0) {
+            // tile + 1's rows (requested D - 1 tiles ago) have landed - this wave's; the requests and token reads issued since stay in flight
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BOTH ? 3 * D - 5 : 2 * D - 3) : "memory");
+            K4_T(1);
+            __syncthreads();
+        }
+        K4_T(2);
+        // tile + D into tile - 1's image, with the token read NS tiles ago; then the token of tile + D + NS into its place
+        request(FSLOT, tile + D, tk[FSLOT]);
+        tk[FSLOT] = load_tok(tile + D + NS);
+        // ---- deferred reference (attn_self's rule): up by d = the tile's maximum when that is more than K4_DEFER above it, and in the first tile
+        const bool need = tmax > K4_DEFER || tile == 0;
+        if (__any(need)) {
+            const float d = need ? tmax : 0.f;
+            const float alpha = tile == 0 ? 0.f : __builtin_amdgcn_exp2f(-d);
+            l *= alpha;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
+            m += d;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                negm[r] = -m;
+                sc[r] -= d;
+            }
+        }
+        // ---- one basic block, its issue order pinned segment by segment (sched_barrier): every MFMA is followed by the two to four exponentials and
+        // the few vector instructions its 32 cycles cover (left alone the compiler puts the sixteen exponentials in front and the eight MFMAs behind)
+        K4_T(3);
+        const char* cur = smem + SLOT * IMG;
+        const char* nxt = smem + NSLOT * IMG;
+        Frag kf[NG], vf[2][2];
+        float x[16];
+        f2 ps2{0.f, 0.f};
+        auto ex = [&](int r0, int r1) {
+#pragma unroll
+            for (int r = r0; r < r1; ++r) x[r] = __builtin_amdgcn_exp2f(sc[r]);
+        };
+        auto sum = [&](int r0, int r1) {
+#pragma unroll
+            for (int r = r0; r < r1; r += 2) ps2 += f2{x[r], x[r + 1]};
+        };
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) kf[g] = *reinterpret_cast<const Frag*>(nxt + koff[g]);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) vf[0][b] = v_frag(cur, b, 0);
+        v16f sn = negm;
+        __builtin_amdgcn_sched_barrier(0);
+        M::mma(kf[0], qf[0], sn);
+        ex(0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        M::mma(kf[1], qf[1], sn);
+        ex(2, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        M::mma(kf[2], qf[2], sn);
+        ex(4, 6);
+        sum(0, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        M::mma(kf[3], qf[3], sn);
+        ex(6, 8);
+        sum(4, 8);
+        const Frag pf0{(T)x[0], (T)x[1], (T)x[2], (T)x[3], (T)x[4], (T)x[5], (T)x[6], (T)x[7]};
+#pragma unroll
+        for (int b = 0; b < 2; ++b) vf[1][b] = v_frag(cur, b, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        K4_T(4);
+        M::mma(vf[0][0], pf0, o[0]);
+        ex(8, 12);
+        __builtin_amdgcn_sched_barrier(0);
+        M::mma(vf[0][1], pf0, o[1]);
+        ex(12, 16);
+        __builtin_amdgcn_sched_barrier(0);
+        const Frag pf1{(T)x[8], (T)x[9], (T)x[10], (T)x[11], (T)x[12], (T)x[13], (T)x[14], (T)x[15]};
+        M::mma(vf[1][0], pf1, o[0]);
+        sum(8, 16);
+        __builtin_amdgcn_sched_barrier(0);
+        M::mma(vf[1][1], pf1, o[1]);
+        K4_T(5);
+        l += ps2.x + ps2.y;
+        tmax = tile_max(sn, tile + 1, TAIL);                               // (behind the last tile: a value nobody uses)
+        sc = sn;
+        K4_T(6);
+    };
+    using std::integral_constant;
+    using std::false_type;
+    using std::true_type;
+    auto round = [&](auto tail_c, int tile) {                              // NS bodies, those inside the list
+        auto go = [&](auto self, auto j_c) {
+            constexpr int J = decltype(j_c)::value;
+            if constexpr (J < NS) {
+                if (!decltype(tail_c)::value || tile + J < ntiles) body(integral_constant<int, J>{}, tail_c, tile + J);
+                self(self, integral_constant<int, J + 1>{});
+            }
+        };
+        go(go, integral_constant<int, 0>{});
+    };
+    int tile = 0;
+    for (; tile + NS + 1 <= K / KT; tile += NS) round(false_type{}, tile);  // tile t + 1 of these is a full tile
+    for (; tile < ntiles; tile += NS) round(true_type{}, tile);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // nothing of the ring in flight behind the kernel's LDS
+    const float lsum = l + __shfl_xor(l, 32, 64);
+    const int qi = q0 + lr;
+    if (qi < a.L) {
+        T* op = (T*)a.out + ((size_t)n * a.L + qi) * CC + head * HD;
+        const float inv = K > 0 ? 1.0f / lsum : 0.f;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int d = b * 32 + 8 * r4 + 4 * h;
+                *reinterpret_cast<gf_vec<T, 4>*>(op + d) = gf_vec<T, 4>{(T)(o[b][4 * r4] * inv), (T)(o[b][4 * r4 + 1] * inv),
+                                                                        (T)(o[b][4 * r4 + 2] * inv), (T)(o[b][4 * r4 + 3] * inv)};
+            }
+    }
+}
+
 }   // namespace
 
 #if K4_TRACE
@@ -832,6 +1085,29 @@ extern "C" int gf_debug_k4_trace(long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(k4_trace), sizeof(long long) * 2048 * 32);
 }
 #endif
+
+namespace {
+template <typename T>
+void k4_launch_head(const AtArgs& a, hipStream_t st) {
+    if constexpr (std::is_same<T, float>::value) {
+        (void)a; (void)st;
+    } else {
+        static const int ns = [] { const char* e = getenv("GF_K4_NS"); return e ? atoi(e) : 4; }();
+        static const int nw = [] { const char* e = getenv("GF_K4_NW"); return e ? atoi(e) : 4; }();
+        const int NH = CC / HD, IMGB = 2 * KT * HD * 2;
+        if (nw == 8) {
+            const int blocks = ((a.L + 255) / 256) * NH * a.N;
+            if (ns == 4) attn_self_head<T, 4, 8><<<blocks, 512, 4 * IMGB, st>>>(a);
+            else attn_self_head<T, 8, 8><<<blocks, 512, 8 * IMGB, st>>>(a);
+        } else {
+            const int blocks = ((a.L + 127) / 128) * NH * a.N;
+            if (ns == 4) attn_self_head<T, 4, 4><<<blocks, 256, 4 * IMGB, st>>>(a);
+            else if (ns == 6) attn_self_head<T, 6, 4><<<blocks, 256, 6 * IMGB, st>>>(a);
+            else attn_self_head<T, 8, 4><<<blocks, 256, 8 * IMGB, st>>>(a);
+        }
+    }
+}
+}   // namespace
 
 extern "C" size_t gf_self_attention_workspace_bytes(int N, int L, int dtype) {
     if (N <= 0 || L <= 0) return 0;
@@ -868,6 +1144,10 @@ extern "C" int gf_self_attention_gathered(const void* q, const void* kmap, const
         (void)hipFuncSetAttribute((const void*)attn_self_pipe<_Float16, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * KT * CC * 2);
 #endif
         (void)hipFuncSetAttribute((const void*)attn_self_pipe<gf_bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * KT * CC * 2);
+        (void)hipFuncSetAttribute((const void*)attn_self_head<_Float16, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * KT * HD * 2);
+        (void)hipFuncSetAttribute((const void*)attn_self_head<gf_bf16, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * KT * HD * 2);
+        (void)hipFuncSetAttribute((const void*)attn_self_head<_Float16, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * KT * HD * 2);
+        (void)hipFuncSetAttribute((const void*)attn_self_head<gf_bf16, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * KT * HD * 2);
     }
     AtArgs a;
     a.q = q; a.kmap = kmap; a.vmap = vmap; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
@@ -900,6 +1180,14 @@ extern "C" int gf_self_attention_gathered(const void* q, const void* kmap, const
     static const int abl = [] { const char* e = getenv("GF_K4_ABL"); return e ? atoi(e) : 0; }();
     (void)abl;
     // the gather-free form (round 5): the default form's K / V rows straight from the projected maps; needs 16-byte aligned value rows too
+    const bool direct_ok = dtype != GF_F32 && (uintptr_t)vmap % 16 == 0 && ldv % 8 == 0 && (size_t)L * (size_t)(ldk > ldv ? ldk : ldv) * 2 < 0x7FFFFFF0ull;
+    // the head form (round 5, the default): one head and 128 queries per workgroup, K / V rows straight from the maps through structured buffers
+    // (stride field: 14 bits); GF_K4_FORM=rows keeps the previous default (attn_self, eight waves, four heads) for A/B
+    static const bool rows_env = [] { const char* e = getenv("GF_K4_FORM"); return e && e[0] == 'r'; }();
+    static const bool head_env = [] { const char* e = getenv("GF_K4_FORM"); return e && e[0] == 'h'; }();
+    const bool chip_full = (long)N * ((L + 63) / 64) >= 512;
+    const bool use_head = direct_ok && (size_t)(ldk > ldv ? ldk : ldv) * 2 < 16384 && !pipe && !msum && !nopre && !gather_env && !rows_env &&
+                          (head_env || (chip_full && !forced && !forced_wv));
     const bool direct = !gather_env && !msum && !nopre && wv == 8 && qb == 1 && dtype != GF_F32 && (uintptr_t)vmap % 16 == 0 && ldv % 8 == 0 &&
                         (size_t)L * (size_t)(ldk > ldv ? ldk : ldv) * 2 < 0x7FFFFFF0ull;
     const dim3 ggrid(dtype == GF_F32 ? a.Kpad / KT : (a.Kpad / 8 < 64 ? a.Kpad / 8 : 64), N), agrid((L + 8 * qb * wv - 1) / (8 * qb * wv), N);
@@ -937,6 +1225,7 @@ extern "C" int gf_self_attention_gathered(const void* q, const void* kmap, const
 #define GF_K4_LAUNCH(T, ES, GF_K4_WIDE)                                                                        \
     do {                                                                                           \
         const size_t LDSB = (ES == 4 ? 2 : 4) * KT * CC * ES;      /* 16-bit: two (K, V^T) images */       \
+        if (use_head) { k4_launch_head<T>(a, st); break; }                                         \
         if (!direct) attn_gather_kv<T><<<ggrid, 256, 0, st>>>(a);                                  \
         if (wv >= 8) { GF_K4_WIDE(T); break; }                                                     \
         if (qb == 4) attn_self<T, 4, 4><<<agrid, 256, LDSB, st>>>(a);                     \

@@ -987,7 +987,7 @@ def test_linear_column_tiles_per_xcd(dtype, N):
 
 
 def test_self_attention_forms_agree():
-    """The K4 forms kept for the record (GF_K4_QB / GF_K4_WV / GF_K4_FORM=pipe / GF_K4_MSUM / GF_K4_PRE=0 / GF_K4_GATHER=1 - read once per
+    """The K4 forms kept for the record (GF_K4_FORM=rows|head|pipe / GF_K4_NW / GF_K4_NS / GF_K4_QB / GF_K4_WV / GF_K4_MSUM / GF_K4_PRE=0 / GF_K4_GATHER=1 - read once per
     process, hence one child process per form) compute the same attention as the default form: on one seeded problem with ragged key counts
     every form stays within the storage type's resolution of the fp32 oracle, and the forms that share the default's arithmetic exactly
     (other wave / block shapes) reproduce its bits."""
@@ -1019,7 +1019,9 @@ for b in range(N):
     worst = max(worst, float((out[b].float() - ref).abs().max()))
 print('RESULT', worst, hashlib.sha256(out.numpy().tobytes()).hexdigest()[:16])
 ''' % (root, root)
-    forms = {'default': {}, 'qb2_wv4': {'GF_K4_QB': '2', 'GF_K4_WV': '4'}, 'qb1_wv4': {'GF_K4_QB': '1', 'GF_K4_WV': '4'},
+    forms = {'default': {}, 'rows': {'GF_K4_FORM': 'rows'}, 'head_8waves': {'GF_K4_FORM': 'head', 'GF_K4_NW': '8', 'GF_K4_NS': '8'},
+             'head_ring8': {'GF_K4_FORM': 'head', 'GF_K4_NS': '8'}, 'head_ring6': {'GF_K4_NS': '6'},
+             'qb2_wv4': {'GF_K4_QB': '2', 'GF_K4_WV': '4'}, 'qb1_wv4': {'GF_K4_QB': '1', 'GF_K4_WV': '4'},
              'qb1_wv16': {'GF_K4_QB': '1', 'GF_K4_WV': '16'}, 'qb2_wv8': {'GF_K4_QB': '2', 'GF_K4_WV': '8'},
              'pipe': {'GF_K4_FORM': 'pipe'}, 'msum': {'GF_K4_MSUM': '1'}, 'nopre': {'GF_K4_PRE': '0'}, 'gather': {'GF_K4_GATHER': '1'}}
     res = {}
@@ -1035,5 +1037,6 @@ print('RESULT', worst, hashlib.sha256(out.numpy().tobytes()).hexdigest()[:16])
     for name, (worst, _) in res.items():
         assert worst < 4e-3, (name, worst)
     # same arithmetic per query, another shape of workgroup: the default's bits
-    for name in ('qb2_wv4', 'qb1_wv4', 'qb1_wv16', 'qb2_wv8', 'gather'):         # ('gather': the compact-buffer form of the default, which reads the maps directly)
+    # ('rows': round 5's earlier default - four heads and 64 queries per workgroup; 'gather': its compact-buffer form; the default is the head form)
+    for name in ('rows', 'head_8waves', 'head_ring8', 'head_ring6', 'qb2_wv4', 'qb1_wv4', 'qb1_wv16', 'qb2_wv8', 'gather'):
         assert res[name][1] == res['default'][1], (name, res[name], res['default'])

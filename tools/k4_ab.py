@@ -1,4 +1,4 @@
-"""K4 forms side by side on one box: python tools/k4_ab.py [keys=1195] [QB,WV[,FORM] ...] - every (GF_K4_QB, GF_K4_WV[, GF_K4_FORM])
+"""K4 forms side by side on one box: python tools/k4_ab.py [keys=1195] [QB,WV[,FORM] | def,- ...] - every (GF_K4_QB, GF_K4_WV[, GF_K4_FORM])
 variant in a process of its own (the switches are read once), time per 16-image call and a digest of the output (the forms run the
 same arithmetic per query: the digests must be equal)."""
 import os
@@ -37,7 +37,7 @@ print(f'{best:.1f} us  {4.0 * N * L * K * 256 / best / 1e6:.0f} TFLOP/s  digest 
 K = sys.argv[1] if len(sys.argv) > 1 else '1195'
 variants = [v.split(',') for v in (sys.argv[2:] or ['2,4', '1,4', '2,8', '1,8'])]
 for v in variants:
-    env = dict(os.environ, GF_K4_QB=v[0], GF_K4_WV=v[1])
+    env = dict(os.environ, GF_K4_QB=v[0], GF_K4_WV=v[1]) if v[0] != 'def' else dict(os.environ)      # 'def,-': the library's own choice
     if len(v) > 2:
         env['GF_K4_FORM'] = v[2]
     if len(v) > 3:

@@ -18,6 +18,8 @@ buf = np.zeros(2048 * 32, dtype=np.int64)
 ctypes.CDLL(_lib.LIB_PATH).gf_debug_k4_trace(buf.ctypes.data_as(ctypes.c_void_p))
 t = buf.reshape(2048, 4, 8)[:1600, :, :7]
 names = ['wait own DMA', 'barrier', 'request next + S(qb0)', 'softmax(qb0)', 'P.V(qb0) issue', 'query block 1']
+if os.environ.get('GF_K4_FORM') in ('pipe2', 'head'):      # attn_self_pipe2's stamps
+    names = ['wait own DMA', 'barrier', 'request + tokens + reference test', 'fragment reads, S(t+1) | exp 0..7', 'P.V | exp 8..15', 'max of S(t+1)']
 for tl in range(4):
     d = np.diff(t[:, tl, :], axis=1)
     print(f'tile {4 + tl}: ' + ' | '.join(f'{n} {int(np.median(d[:, i]))}' for i, n in enumerate(names)) + f' | tile total {int(np.median(t[:, tl, 6] - t[:, tl, 0]))}', end='')
