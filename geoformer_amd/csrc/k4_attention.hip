@@ -845,7 +845,10 @@ __global__ __launch_bounds__(512, 2) void attn_self_pipe(AtArgs a) {
 //   K image: row = key (128 B), 16-B chunk c at c ^ ((key >> 1) & 7)  (a ds_read_b128 lane group - 16 keys, one chunk - covers the 64 banks)
 //   V image: row = key (128 B), 32-B block b (16 channels) at b ^ 2 ((key >> 1) & 1)  (a transposing read's 32 lanes - 4 keys x 2 blocks x 4 pieces -
 //            cover the 64 banks); the fragment's second half is 8 keys = 1 KiB further
-template <typename T, int NS, int NW>
+// ABL (diagnostic builds, -DK4_ABLATE, GF_K4_ABL): 1 no exponentials, 2 no barrier, 3 no fragment reads, 4 no requests, 5 no maximum, 6 no MFMA
+// ORD = 1: the tile opens with the exponentials of its first half (no LDS operand) under the fragment reads' latency, P.V keys 0..15 before the S chain,
+// the requests inside the S chain
+template <typename T, int NS, int NW, int ABL = 0, int ORD = 0>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void attn_self_head(AtArgs a) {
     using M = Mma32<T>;
     using Frag = typename M::Frag;
@@ -964,12 +967,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void attn_self_head(AtArg
             // tile + 1's rows (requested D - 1 tiles ago) have landed - this wave's; the requests and token reads issued since stay in flight
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BOTH ? 3 * D - 5 : 2 * D - 3) : "memory");
             K4_T(1);
-            __syncthreads();
+            if constexpr (ABL != 2) __syncthreads();
         }
         K4_T(2);
         // tile + D into tile - 1's image, with the token read NS tiles ago; then the token of tile + D + NS into its place
-        request(FSLOT, tile + D, tk[FSLOT]);
-        tk[FSLOT] = load_tok(tile + D + NS);
+        if constexpr (ABL != 4 && ORD == 0) {
+            request(FSLOT, tile + D, tk[FSLOT]);
+            tk[FSLOT] = load_tok(tile + D + NS);
+        }
         // ---- deferred reference (attn_self's rule): up by d = the tile's maximum when that is more than K4_DEFER above it, and in the first tile
         const bool need = tmax > K4_DEFER || tile == 0;
         if (__any(need)) {
@@ -997,51 +1002,98 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void attn_self_head(AtArg
         f2 ps2{0.f, 0.f};
         auto ex = [&](int r0, int r1) {
 #pragma unroll
-            for (int r = r0; r < r1; ++r) x[r] = __builtin_amdgcn_exp2f(sc[r]);
+            for (int r = r0; r < r1; ++r) x[r] = ABL == 1 ? sc[r] : __builtin_amdgcn_exp2f(sc[r]);
         };
         auto sum = [&](int r0, int r1) {
 #pragma unroll
             for (int r = r0; r < r1; r += 2) ps2 += f2{x[r], x[r + 1]};
         };
-        __builtin_amdgcn_sched_barrier(0);
+        auto mm = [&](const Frag& x_, const Frag& y_, v16f& c_) {
+            if constexpr (ABL == 6) c_[0] += gf_to_float(x_[0]) + gf_to_float(y_[0]);
+            else M::mma(x_, y_, c_);
+        };
+        v16f sn;
+        if constexpr (ORD == 0) {
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int g = 0; g < NG; ++g) kf[g] = *reinterpret_cast<const Frag*>(nxt + koff[g]);
+            for (int g = 0; g < NG; ++g) kf[g] = ABL == 3 ? qf[g] : *reinterpret_cast<const Frag*>(nxt + koff[g]);
 #pragma unroll
-        for (int b = 0; b < 2; ++b) vf[0][b] = v_frag(cur, b, 0);
-        v16f sn = negm;
-        __builtin_amdgcn_sched_barrier(0);
-        M::mma(kf[0], qf[0], sn);
-        ex(0, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        M::mma(kf[1], qf[1], sn);
-        ex(2, 4);
-        __builtin_amdgcn_sched_barrier(0);
-        M::mma(kf[2], qf[2], sn);
-        ex(4, 6);
-        sum(0, 4);
-        __builtin_amdgcn_sched_barrier(0);
-        M::mma(kf[3], qf[3], sn);
-        ex(6, 8);
-        sum(4, 8);
-        const Frag pf0{(T)x[0], (T)x[1], (T)x[2], (T)x[3], (T)x[4], (T)x[5], (T)x[6], (T)x[7]};
+            for (int b = 0; b < 2; ++b) vf[0][b] = ABL == 3 ? qf[b] : v_frag(cur, b, 0);
+            sn = negm;
+            __builtin_amdgcn_sched_barrier(0);
+            mm(kf[0], qf[0], sn);
+            ex(0, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(kf[1], qf[1], sn);
+            ex(2, 4);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(kf[2], qf[2], sn);
+            ex(4, 6);
+            sum(0, 4);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(kf[3], qf[3], sn);
+            ex(6, 8);
+            sum(4, 8);
+            const Frag pf0{(T)x[0], (T)x[1], (T)x[2], (T)x[3], (T)x[4], (T)x[5], (T)x[6], (T)x[7]};
 #pragma unroll
-        for (int b = 0; b < 2; ++b) vf[1][b] = v_frag(cur, b, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        K4_T(4);
-        M::mma(vf[0][0], pf0, o[0]);
-        ex(8, 12);
-        __builtin_amdgcn_sched_barrier(0);
-        M::mma(vf[0][1], pf0, o[1]);
-        ex(12, 16);
-        __builtin_amdgcn_sched_barrier(0);
-        const Frag pf1{(T)x[8], (T)x[9], (T)x[10], (T)x[11], (T)x[12], (T)x[13], (T)x[14], (T)x[15]};
-        M::mma(vf[1][0], pf1, o[0]);
-        sum(8, 16);
-        __builtin_amdgcn_sched_barrier(0);
-        M::mma(vf[1][1], pf1, o[1]);
+            for (int b = 0; b < 2; ++b) vf[1][b] = ABL == 3 ? qf[2 + b] : v_frag(cur, b, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            K4_T(4);
+            mm(vf[0][0], pf0, o[0]);
+            ex(8, 12);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(vf[0][1], pf0, o[1]);
+            ex(12, 16);
+            __builtin_amdgcn_sched_barrier(0);
+            const Frag pf1{(T)x[8], (T)x[9], (T)x[10], (T)x[11], (T)x[12], (T)x[13], (T)x[14], (T)x[15]};
+            mm(vf[1][0], pf1, o[0]);
+            sum(8, 16);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(vf[1][1], pf1, o[1]);
+        } else {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) vf[0][b] = ABL == 3 ? qf[b] : v_frag(cur, b, 0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) kf[g] = ABL == 3 ? qf[g] : *reinterpret_cast<const Frag*>(nxt + koff[g]);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) vf[1][b] = ABL == 3 ? qf[2 + b] : v_frag(cur, b, 1);
+            sn = negm;
+            __builtin_amdgcn_sched_barrier(0);
+            ex(0, 8);
+            sum(0, 8);
+            const Frag pf0{(T)x[0], (T)x[1], (T)x[2], (T)x[3], (T)x[4], (T)x[5], (T)x[6], (T)x[7]};
+            __builtin_amdgcn_sched_barrier(0);
+            K4_T(4);
+            mm(vf[0][0], pf0, o[0]);
+            ex(8, 10);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(vf[0][1], pf0, o[1]);
+            ex(10, 12);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(kf[0], qf[0], sn);
+            ex(12, 14);
+            if constexpr (ABL != 4) {
+                request(FSLOT, tile + D, tk[FSLOT]);
+                tk[FSLOT] = load_tok(tile + D + NS);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mm(kf[1], qf[1], sn);
+            ex(14, 16);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(kf[2], qf[2], sn);
+            const Frag pf1{(T)x[8], (T)x[9], (T)x[10], (T)x[11], (T)x[12], (T)x[13], (T)x[14], (T)x[15]};
+            sum(8, 16);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(kf[3], qf[3], sn);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(vf[1][0], pf1, o[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(vf[1][1], pf1, o[1]);
+        }
         K4_T(5);
         l += ps2.x + ps2.y;
-        tmax = tile_max(sn, tile + 1, TAIL);                               // (behind the last tile: a value nobody uses)
+        tmax = ABL == 5 ? sn[0] : tile_max(sn, tile + 1, TAIL);             // (behind the last tile: a value nobody uses)
         sc = sn;
         K4_T(6);
     };
@@ -1101,6 +1153,20 @@ void k4_launch_head(const AtArgs& a, hipStream_t st) {
             else attn_self_head<T, 8, 8><<<blocks, 512, 8 * IMGB, st>>>(a);
         } else {
             const int blocks = ((a.L + 127) / 128) * NH * a.N;
+#ifdef K4_ABLATE
+            static const int abl = [] { const char* e = getenv("GF_K4_ABL"); return e ? atoi(e) : 0; }();
+            switch (abl) {
+                case 1: attn_self_head<T, 4, 4, 1><<<blocks, 256, 4 * IMGB, st>>>(a); return;
+                case 2: attn_self_head<T, 4, 4, 2><<<blocks, 256, 4 * IMGB, st>>>(a); return;
+                case 3: attn_self_head<T, 4, 4, 3><<<blocks, 256, 4 * IMGB, st>>>(a); return;
+                case 4: attn_self_head<T, 4, 4, 4><<<blocks, 256, 4 * IMGB, st>>>(a); return;
+                case 5: attn_self_head<T, 4, 4, 5><<<blocks, 256, 4 * IMGB, st>>>(a); return;
+                case 6: attn_self_head<T, 4, 4, 6><<<blocks, 256, 4 * IMGB, st>>>(a); return;
+                default: break;
+            }
+#endif
+            static const int ord = [] { const char* e = getenv("GF_K4_ORD"); return e ? atoi(e) : 1; }();      // (ORD 1: 173.7 us against 175.9, 216.7 against 219.0 at 1600 keys)
+            if (ord == 1 && ns == 4) { attn_self_head<T, 4, 4, 0, 1><<<blocks, 256, 4 * IMGB, st>>>(a); return; }
             if (ns == 4) attn_self_head<T, 4, 4><<<blocks, 256, 4 * IMGB, st>>>(a);
             else if (ns == 6) attn_self_head<T, 6, 4><<<blocks, 256, 6 * IMGB, st>>>(a);
             else attn_self_head<T, 8, 4><<<blocks, 256, 8 * IMGB, st>>>(a);
