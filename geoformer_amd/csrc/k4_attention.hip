@@ -827,7 +827,7 @@ __global__ __launch_bounds__(512, 2) void attn_self_pipe(AtArgs a) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Round 5, the HEAD form (the default of the 16-bit modes once the chip is full).  Two measurements decide its structure:
+// Round 5, the HEAD form (the default of the 16-bit modes).  Two measurements decide its structure:
 //  * tools/probes/mfma_filler.hip: ONE wave's own stream covers up to five vector instructions (two exponentials) per v_mfma_f32_32x32x16 for nothing
 //    (32.3 cycles per MFMA at one or two waves per SIMD), but an MFMA-only wave beside a vector-only wave on the same SIMD both crawl (76 cycles per
 //    MFMA): a kernel whose waves alternate an MFMA phase and a softmax phase - attn_self - spends its time in exactly that pairing.  Here every wave's
@@ -900,8 +900,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void attn_self_head(AtArg
     char* const rdst = smem + (isv ? KBYTES : 0) + (wv & 3) * 1024;
     int tk[NS];                                                            // token of the lane's row in tile j (mod NS), read NS tiles before its request
     auto load_tok = [&](int tile) { return (int)__builtin_amdgcn_raw_buffer_load_b32(ri, rrow * 4, tile * (KT * 4), 0); };
-    auto request = [&](int slot, int tile, int t) {
-        const int rec = tile * KT + rrow >= K ? 0x7FFFFFFF : t;
+    auto request = [&](int slot, int tile, int t, bool ragged) {
+        const int rec = ragged && tile * KT + rrow >= K ? 0x7FFFFFFF : t;
         if constexpr (BOTH) {
             __builtin_amdgcn_struct_ptr_buffer_load_lds(rkmap, (__attribute__((address_space(3))) void*)(rdst + slot * IMG), 16, rec, roffk, 0, 0, 0);
             __builtin_amdgcn_struct_ptr_buffer_load_lds(rvmap, (__attribute__((address_space(3))) void*)(rdst + KBYTES + slot * IMG), 16, rec, roffv, 0, 0, 0);
@@ -944,7 +944,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void attn_self_head(AtArg
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int j = 0; j < D; ++j) {
-            request(j, j, tk[j]);
+            request(j, j, tk[j], true);
             tk[j] = load_tok(j + NS);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -958,7 +958,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void attn_self_head(AtArg
         tmax = tile_max(sc, 0, true);
     }
     typedef float f2 __attribute__((ext_vector_type(2)));
-    // TAIL: the bodies in which tile t + 1 may be the ragged last tile (its mask is a branch)
+    // TAIL: the bodies in which tile t + 1 (its mask is a branch) or the requested tile t + D (its padded keys: a select per request) may be the ragged last tile
     auto body = [&](auto slot_c, auto tail_c, int tile) {
         constexpr bool TAIL = decltype(tail_c)::value;
         constexpr int SLOT = decltype(slot_c)::value, NSLOT = (SLOT + 1) % NS, FSLOT = (SLOT + D) % NS;
@@ -972,7 +972,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void attn_self_head(AtArg
         K4_T(2);
         // tile + D into tile - 1's image, with the token read NS tiles ago; then the token of tile + D + NS into its place
         if constexpr (ABL != 4 && ORD == 0) {
-            request(FSLOT, tile + D, tk[FSLOT]);
+            request(FSLOT, tile + D, tk[FSLOT], TAIL);
             tk[FSLOT] = load_tok(tile + D + NS);
         }
         // ---- deferred reference (attn_self's rule): up by d = the tile's maximum when that is more than K4_DEFER above it, and in the first tile
@@ -1074,7 +1074,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void attn_self_head(AtArg
             mm(kf[0], qf[0], sn);
             ex(12, 14);
             if constexpr (ABL != 4) {
-                request(FSLOT, tile + D, tk[FSLOT]);
+                request(FSLOT, tile + D, tk[FSLOT], TAIL);
                 tk[FSLOT] = load_tok(tile + D + NS);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1111,7 +1111,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void attn_self_head(AtArg
         go(go, integral_constant<int, 0>{});
     };
     int tile = 0;
-    for (; tile + NS + 1 <= K / KT; tile += NS) round(false_type{}, tile);  // tile t + 1 of these is a full tile
+    for (; tile + NS + D <= K / KT; tile += NS) round(false_type{}, tile);  // tiles t + 1 .. t + D of these are full tiles
     for (; tile < ntiles; tile += NS) round(true_type{}, tile);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // nothing of the ring in flight behind the kernel's LDS
     const float lsum = l + __shfl_xor(l, 32, 64);
@@ -1251,9 +1251,10 @@ extern "C" int gf_self_attention_gathered(const void* q, const void* kmap, const
     // (stride field: 14 bits); GF_K4_FORM=rows keeps the previous default (attn_self, eight waves, four heads) for A/B
     static const bool rows_env = [] { const char* e = getenv("GF_K4_FORM"); return e && e[0] == 'r'; }();
     static const bool head_env = [] { const char* e = getenv("GF_K4_FORM"); return e && e[0] == 'h'; }();
-    const bool chip_full = (long)N * ((L + 63) / 64) >= 512;
+    // (every batch size: 2 images x 4800 queries x 1195 keys 30.8 us against 48.0 for the four-head form, 4 images 43.2 against 80.9 - its workgroups are
+    // four times as many and a quarter of the size)
     const bool use_head = direct_ok && (size_t)(ldk > ldv ? ldk : ldv) * 2 < 16384 && !pipe && !msum && !nopre && !gather_env && !rows_env &&
-                          (head_env || (chip_full && !forced && !forced_wv));
+                          (head_env || (!forced && !forced_wv));
     const bool direct = !gather_env && !msum && !nopre && wv == 8 && qb == 1 && dtype != GF_F32 && (uintptr_t)vmap % 16 == 0 && ldv % 8 == 0 &&
                         (size_t)L * (size_t)(ldk > ldv ? ldk : ldv) * 2 < 0x7FFFFFF0ull;
     const dim3 ggrid(dtype == GF_F32 ? a.Kpad / KT : (a.Kpad / 8 < 64 ? a.Kpad / 8 : 64), N), agrid((L + 8 * qb * wv - 1) / (8 * qb * wv), N);

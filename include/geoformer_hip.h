@@ -351,7 +351,9 @@ int gf_inlier_index(const float* kp0, const float* kp1, const uint8_t* keep, con
  *   q [N,L,256], kmap/vmap [N,L,256] = k_proj/v_proj of EVERY token (row strides ld*), idx/nkeys =
  *   the token list of gf_inlier_index; out [N,L,256]; nkeys == 0 -> zeros (layer skipped by caller).
  *   16-bit modes: q and kmap 16-byte aligned with row strides that are multiples of 8 elements (rows move as 16-byte pieces); with
- *   vmap aligned the same way the key / value rows are read from the maps directly (no gather pass; the workspace is then unused).
+ *   vmap aligned the same way the key / value rows are read from the maps directly (no gather pass; the workspace is then unused):
+ *   with row strides below 8192 elements by the head form - one head and 128 queries per workgroup, rows through structured buffer
+ *   descriptors - otherwise by the four-head form; both run the arithmetic below bit for bit.
  *   Arithmetic of the 16-bit modes (flash form): the softmax scale lives in the query operand, q' = round(q * log2(e) / sqrt(D)) to the
  *   storage type (one more 16-bit rounding of q), logits q' . k in fp32; per query a softmax reference that starts at the first key
  *   tile's maximum and moves up only when a tile's maximum exceeds it by more than 8 (log2 units); probabilities rounded to the

@@ -284,6 +284,39 @@ def test_self_attention_gathered_two_blocks_per_wave():
         close(out[b], ref, 4e-3, 4e-3)
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_self_attention_head_form_row_layouts(dtype):
+    """The head form (one head x 128 queries per workgroup, the default of a full chip) reads the K / V rows through structured buffer
+    descriptors whose stride is the caller's row stride: maps of their own (stride 256), slices of a wider tensor with unequal strides, and rows
+    too wide for the descriptor's 14-bit stride field (>= 8192 elements: the four-head form takes over) must all give the bits of the
+    [N, L, 512] layout, which stays within the storage type's resolution of the fp32 oracle."""
+    from geoformer_amd import ops
+    g = torch.Generator().manual_seed(15)
+    N, L, C, H = 9, 3688, 256, 4
+    q = torch.randn(N, L, C, generator=g).to(dtype)
+    kv = torch.randn(N, L, 2 * C, generator=g).to(dtype)
+    nk = [333, 5, 70, 1, 32, 33, 500, 64, 97]
+    idx = torch.zeros(N, L, dtype=torch.int32)
+    for b in range(N):
+        idx[b, :nk[b]] = torch.sort(torch.randperm(L, generator=g)[:nk[b]])[0].int()
+    nkeys = torch.tensor(nk, dtype=torch.int32).to(DEV)
+    qd, kvd, idxd = q.to(DEV), kv.to(DEV), idx.to(DEV)
+    base = ops.self_attention_gathered(qd, kvd[..., :C], kvd[..., C:], idxd, nkeys, H)
+    for b in (0, 3, 5, 6):
+        sel = idx[b, :nk[b]].long()
+        ref = O.full_attention(q[b].float().view(1, L, H, -1), kv[b, sel, :C].float().view(1, nk[b], H, -1),
+                               kv[b, sel, C:].float().view(1, nk[b], H, -1)).reshape(L, C)
+        close(base[b], ref, *_tol(dtype, None, (4e-3, 4e-3)))
+    own = ops.self_attention_gathered(qd, kvd[..., :C].contiguous(), kvd[..., C:].contiguous(), idxd, nkeys, H)
+    assert torch.equal(own, base)
+    wide_v = torch.zeros(N, L, 3 * C, device=DEV, dtype=dtype)
+    wide_v[..., C:2 * C] = kvd[..., C:]
+    assert torch.equal(ops.self_attention_gathered(qd, kvd[..., :C].contiguous(), wide_v[..., C:2 * C], idxd, nkeys, H), base)
+    huge = torch.zeros(N, L, 8192 + C, device=DEV, dtype=dtype)               # row stride 8448 elements: beyond the stride field
+    huge[..., 8192:] = kvd[..., :C]
+    assert torch.equal(ops.self_attention_gathered(qd, huge[..., 8192:], kvd[..., C:], idxd, nkeys, H), base)
+
+
 # ------------------------------------------------------------------ K5
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
 def test_window_cross_attention(dtype):

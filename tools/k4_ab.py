@@ -12,7 +12,7 @@ sys.path.insert(0, %r)
 import torch
 from geoformer_amd import ops
 K = int(sys.argv[1])
-N, L = 16, 6400
+N, L = int(os.environ.get('K4AB_N', '16')), int(os.environ.get('K4AB_L', '6400'))       # (K4AB_N / K4AB_L: other batch shapes)
 g = torch.Generator(device='cuda').manual_seed(5)
 q = torch.randn(N, L, 256, device='cuda', generator=g).half()
 kv = torch.randn(N, L, 512, device='cuda', generator=g).half()

@@ -68,7 +68,7 @@ TAG_FAMILIES = {
     'k1_conf': ['k1_conf'],
     'k1_unit': ['k1_'],
     'fine_layer': ['fine_layer<', 'fine_kv'],
-    'k4_self_attention': ['attn_self<', 'attn_gather_kv'],
+    'k4_self_attention': ['attn_self<', 'attn_self_head<', 'attn_gather_kv'],
     'k2_linear_attention': ['la16_', 'la_kv_', 'la_apply', 'la_small'],
     'k5_window_attention': ['window_cross_attention', 'window_cross_tiled'],
     'bias_act': ['bias_act<'],
@@ -76,7 +76,7 @@ TAG_FAMILIES = {
 }
 TAG_EXCLUDE = {'k3_linear': [', 4, 5, true>', ', 4, 0, true>']}
 # the family whose call count equals the number of tagged calls
-TAG_PRIMARY = {'k1_unit': 'k1_compact', 'fine_layer': 'fine_layer<', 'k4_self_attention': 'attn_self<', 'enc_layer': 'enc_layer<', 'enc_kv_state': 'enc_kv_state<', 'k3_linear': 'linear_kernel', 'k3_upadd': ', 4, 5, true>', 'conv1x1': ', 4, 0, true>', 'k1_stats': 'k1_stats',
+TAG_PRIMARY = {'k1_unit': 'k1_compact', 'fine_layer': 'fine_layer<', 'k4_self_attention': ('attn_self_head<', 'attn_self<'), 'enc_layer': 'enc_layer<', 'enc_kv_state': 'enc_kv_state<', 'k3_linear': 'linear_kernel', 'k3_upadd': ', 4, 5, true>', 'conv1x1': ', 4, 0, true>', 'k1_stats': 'k1_stats',
                'k1_conf': 'k1_conf', 'k2_linear_attention': ('la16_apply', 'la_apply', 'la_small'), 'k5_window_attention': ('window_cross_tiled', 'window_cross_attention'),
                'bias_act': 'bias_act<', 'conv3x3': 'conv3x3_kernel'}
 
