@@ -1074,8 +1074,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void attn_self_head(AtArg
             mm(kf[0], qf[0], sn);
             ex(12, 14);
             if constexpr (ABL != 4) {
+#ifdef K4H_PRIO                        // -DK4H_PRIO (experiment): the requests at raised wave priority
+                __builtin_amdgcn_s_setprio(3);
+#endif
                 request(FSLOT, tile + D, tk[FSLOT], TAIL);
                 tk[FSLOT] = load_tok(tile + D + NS);
+#ifdef K4H_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
             mm(kf[1], qf[1], sn);
