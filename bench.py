@@ -902,7 +902,8 @@ def side_measurements(args, model, dev, log, L, batches=None, planted=None, pipe
 def train_measurements(dev, log, steps=5, warmup=2):
     """The training step of BASELINE configs[2] / [3] at their per-GPU sizes (VERDICT r04 #6a), N = 1: mixed bf16 (fp32 master weights,
     `train_depth_geoformer.py:117-119`) with the fused HIP coarse loss and the HIP forward + backward Functions
-    (`TrainStep(precision='bf16', fused_coarse_loss=True, hip_backward=True)`): supervision -> forward -> loss -> backward -> clipped
+    and, since the end of round 5, the backbone's stride-1 3x3 convolutions forward + backward-data on K10
+    (`TrainStep(precision='bf16', fused_coarse_loss=True, hip_backward=True, hip_conv=True)`): supervision -> forward -> loss -> backward -> clipped
     AdamW step (`lightning_homo_geoformer.py:69-107`), batches made outside the timed steps.
       configs2_homo:      640 x 480 synthetic homography pairs, batch 4 per GPU (batch 32 over 8 GPUs; `homo_trainval_640.py:5`)
       configs3_megadepth: 640 x 640 MegaDepth-style pairs (depth + pose supervision, padding masks, per-image scales), batch 8 per GPU
@@ -919,7 +920,7 @@ def train_measurements(dev, log, steps=5, warmup=2):
         g = get_cfg_model()
         g.update(coarse_thr=0.0, fine_thr=0.0, precision='fp32')
         model = deterministic_init_(GeoFormer(get_default_cfg(), g)).to(dev)
-        step = TrainStep(model, batch_size=batch, fused_coarse_loss=True, precision='bf16', hip_backward=True)
+        step = TrainStep(model, batch_size=batch, fused_coarse_loss=True, precision='bf16', hip_backward=True, hip_conv=True)
         base = [make(batch, hw, seed=900 + i, device=dev) for i in range(2)]         # two resident batches, taken in turn (the step writes its
         data = [dict(base[i % 2]) for i in range(warmup + steps)]                    # supervision and outputs into the dict it is given: a fresh dict per step)
         losses = []
@@ -933,7 +934,7 @@ def train_measurements(dev, log, steps=5, warmup=2):
         el = time.perf_counter() - t0
         losses = [float(v) for v in losses]
         out[key] = {'value': steps * batch / el, 'unit': 'image-pairs/s', 'ms_per_step': 1e3 * el / steps, 'steps': steps, 'warmup': warmup,
-                    'batch_per_gpu': batch, 'image_hw': list(hw), 'precision': 'mixed bf16 (fp32 master weights)', 'hip_backward': True,
+                    'batch_per_gpu': batch, 'image_hw': list(hw), 'precision': 'mixed bf16 (fp32 master weights)', 'hip_backward': True, 'hip_conv': True,
                     'fused_coarse_loss': True, 'losses': losses, 'finite': all(math.isfinite(v) for v in losses)}
         log(f"train step {key}: {out[key]['ms_per_step']:.1f} ms at batch {batch} = {out[key]['value']:.1f} pairs/s, losses {losses[0]:.3f} -> {losses[-1]:.3f}")
         del step, model, data

@@ -697,6 +697,9 @@ int conv_dispatch(const ConvArgs& a, int cin, int cout, bool padl, bool rem, boo
     if (cin == 224 && cout == 128) return conv_launch_w<T, 224, 128>(a, st);
     if (cin == 256 && cout == 256) return conv_launch_w<T, 256, 256>(a, st);
     if (cin == 256 && cout == 224) return conv_launch_w<T, 256, 224>(a, st);
+    // the transposed widths of the two FPN heads: their backward-data passes as forward convolutions (train/hip_autograd.py:Conv3x3Function)
+    if (cin == 128 && cout == 224) return conv_launch_w<T, 128, 224>(a, st);
+    if (cin == 224 && cout == 256) return conv_launch_w<T, 224, 256>(a, st);
     return -1;
 }
 
@@ -707,7 +710,7 @@ extern "C" int gf_conv3x3s2_supported(int cin, int cout) { return (cin == 128 &&
 
 // 1 if gf_conv3x3_nhwc has a kernel for these channel counts
 extern "C" int gf_conv3x3_supported(int cin, int cout) {
-    return (cin == 128 && cout == 128) || (cin == 224 && (cout == 224 || cout == 128)) || (cin == 256 && (cout == 256 || cout == 224));
+    return (cin == 128 && (cout == 128 || cout == 224)) || (cin == 224 && (cout == 224 || cout == 128 || cout == 256)) || (cin == 256 && (cout == 256 || cout == 224));
 }
 
 // out = act(conv3x3(x, w) + shift + residual), channels-last 16-bit maps; wstream = fused.py:pack_conv3x3_stream(w);

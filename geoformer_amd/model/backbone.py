@@ -10,8 +10,27 @@ import torch.nn.functional as F
 from .. import fused, ops
 
 
+class _Conv2d(nn.Conv2d):
+    """nn.Conv2d (same parameters, same state-dict keys) whose TRAINING forward takes the HIP Function for the 3x3 / stride-1 shapes
+    K10 is built for when `TRAIN_HIP_CONV` is on (TrainStep(hip_conv=True): 16-bit autocast, channels_last maps) - forward and backward-data
+    on K10, backward-weights on the library (train/hip_autograd.py:HipConv3x3)."""
+
+    def forward(self, x):
+        if TRAIN_HIP_CONV and self.training and self.kernel_size == (3, 3) and self.stride == (1, 1) and x.is_cuda and torch.is_autocast_enabled():
+            from ..train import hip_autograd as HA
+            x16 = x.to(torch.get_autocast_dtype('cuda'))
+            if HA.conv3x3_supported(x16, self.weight):
+                x16 = x16.contiguous(memory_format=torch.channels_last)
+                with torch.autocast('cuda', enabled=False):
+                    return HA.conv3x3(x16, self.weight)
+        return super().forward(x)
+
+
+TRAIN_HIP_CONV = False
+
+
 def _conv(cin, cout, k, stride=1):
-    return nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=k // 2, bias=False)
+    return _Conv2d(cin, cout, kernel_size=k, stride=stride, padding=k // 2, bias=False)
 
 
 class BasicBlock(nn.Module):

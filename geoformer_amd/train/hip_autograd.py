@@ -183,6 +183,84 @@ class HipFineMatch(torch.autograd.Function):
         return (df0, df1) + (None,) * 10
 
 
+def _pad_width(c):
+    """the channel widths K10 is built for: the pyramid's 196-channel level runs zero-padded to 224 (model/backbone.py)"""
+    return {128: 128, 196: 224, 224: 224, 256: 256}.get(int(c))
+
+
+def _pad_channels(x, cp):
+    """channels_last [N, C, H, W] -> channels_last [N, cp, H, W], the new channels zero"""
+    if x.shape[1] == cp:
+        return x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
+    out = torch.zeros((x.shape[0], cp, x.shape[2], x.shape[3]), dtype=x.dtype, device=x.device).contiguous(memory_format=torch.channels_last)
+    out[:, :x.shape[1]] = x
+    return out
+
+
+def _conv_stream(w16, cout_p, cin_p):
+    """K10's fragment stream of the zero-padded [cout_p, cin_p, 3, 3] form of w16 (packed on the device: the weights move every step)"""
+    from .. import fused
+    co, ci = w16.shape[:2]
+    if (co, ci) != (cout_p, cin_p):
+        wp = torch.zeros((cout_p, cin_p, 3, 3), dtype=w16.dtype, device=w16.device)
+        wp[:co, :ci] = w16
+        w16 = wp
+    return fused.pack_conv3x3_stream(w16.contiguous())
+
+
+def conv3x3_supported(x, w, stride=1):
+    """a bias-free 3x3 / stride 1 / pad 1 convolution of a 16-bit channels_last map whose widths K10 has kernels for - forward AND,
+    with the widths swapped, backward-data"""
+    from .. import fused
+    if not (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float16, torch.bfloat16) and tuple(w.shape[2:]) == (3, 3) and stride == 1):
+        return False
+    cip, cop = _pad_width(w.shape[1]), _pad_width(w.shape[0])
+    return cip is not None and cop is not None and fused.conv3x3_supported(cip, cop) and fused.conv3x3_supported(cop, cip)
+
+
+class HipConv3x3(torch.autograd.Function):
+    """y = conv2d(x, w, stride 1, padding 1), no bias (the backbone's BasicBlock / FPN-head convolutions, resnet_fpn.py:9-40,60-83): forward on
+    K10 (`gf_conv3x3_nhwc`, no epilogue - train-mode BatchNorm follows as its own op), backward-DATA on K10 as well - dX = conv(dY, w'),
+    w'[ci, co, ky, kx] = w[co, ci, 2 - ky, 2 - kx]: the same kernel on dY with the transposed, flipped weights - and backward-WEIGHTS on
+    the library (aten::convolution_backward, output_mask = weights only).  x: 16-bit channels_last; w: fp32 master or 16-bit
+    [cout, cin, 3, 3]; 196-channel operands are zero-padded to 224 on the way in and sliced on the way out (one copy each)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        from .. import fused
+        w16 = w if w.dtype == x.dtype else WEIGHTS.cast(w, x.dtype)
+        co, ci = w16.shape[:2]
+        cop, cip = _pad_width(co), _pad_width(ci)
+        y = fused.conv3x3(_pad_channels(x, cip), _conv_stream(w16, cop, cip), cop)
+        if cop != co:
+            y = y[:, :co].contiguous(memory_format=torch.channels_last)
+        ctx.wdtype = w.dtype
+        ctx.save_for_backward(x, w16)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import fused
+        x, w16 = ctx.saved_tensors
+        co, ci = w16.shape[:2]
+        cop, cip = _pad_width(co), _pad_width(ci)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            wt = w16.flip(2, 3).transpose(0, 1)                            # [cin, cout, 3, 3]
+            dx = fused.conv3x3(_pad_channels(dy, cop), _conv_stream(wt, cip, cop), cip)
+            if cip != ci:
+                dx = dx[:, :ci].contiguous(memory_format=torch.channels_last)
+        if ctx.needs_input_grad[1]:
+            dyc = dy if dy.is_contiguous(memory_format=torch.channels_last) else dy.contiguous(memory_format=torch.channels_last)
+            dw = torch.ops.aten.convolution_backward(dyc, x, w16, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+            dw = dw.to(ctx.wdtype)
+        return dx, dw
+
+
+def conv3x3(x, w):
+    return HipConv3x3.apply(x, w)
+
+
 def linear_attention(q, k, v, nhead, q_mask=None, kv_mask=None):
     return HipLinearAttention.apply(q, k, v, nhead, q_mask, kv_mask)
 

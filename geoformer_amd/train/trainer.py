@@ -124,7 +124,7 @@ class TrainStep:
 
     def __init__(self, model, trainer_cfg=None, loss_cfg=None, batch_size=1, distributed=False, device_ids=None,
                  homography_fn: Optional[Callable] = None, sparse_spvs=True, fused_coarse_loss=False, precision='fp32',
-                 hip_backward=False, channels_last=False):
+                 hip_backward=False, channels_last=False, hip_conv=False):
         world = torch.distributed.get_world_size() if distributed else 1
         self.cfg = scale_trainer_cfg(trainer_cfg, world, batch_size)
         if model.precision != 'fp32':
@@ -141,6 +141,14 @@ class TrainStep:
         if hip_backward and precision != 'bf16':
             raise ValueError("hip_backward=True (K3 chain forward + backward in HIP) is built for the mixed-16-bit step: precision='bf16'")
         self.hip_backward = bool(hip_backward)
+        # hip_conv (round 5; with precision='bf16'): the backbone's 3x3 / stride-1 convolutions - forward and backward-data on K10
+        # (hip_autograd.HipConv3x3), backward-weights on the library; implies the NHWC backbone
+        if hip_conv and precision != 'bf16':
+            raise ValueError("hip_conv=True is built for the mixed-16-bit step: precision='bf16'")
+        self.hip_conv = bool(hip_conv)
+        if hip_conv and not channels_last:
+            channels_last = True
+            model.backbone.to(memory_format=torch.channels_last)
         core = _Core(model, GeoLoss(loss_cfg, model.config['match_coarse'].get('match_type', 'dual_softmax'), sparse_spvs),
                      homography_fn, fused_coarse_loss, torch.bfloat16 if precision == 'bf16' else None, channels_last)
         if distributed:
@@ -158,13 +166,16 @@ class TrainStep:
 
     def __call__(self, batch):
         from .functional import set_hip_backward
+        from ..model import backbone as _bb
         set_hip_backward(self.hip_backward)
+        _bb.TRAIN_HIP_CONV = self.hip_conv
         try:
             loss = self.core(batch)
         finally:
             set_hip_backward(False)
+            _bb.TRAIN_HIP_CONV = False
         hip_weights = None
-        if self.hip_backward:
+        if self.hip_backward or self.hip_conv:
             from .hip_autograd import WEIGHTS as hip_weights
         if 'loss_scalars' not in batch:          # the wrapper handed the forward a copy of the batch
             raise RuntimeError('the training forward did not write into the caller\'s batch')

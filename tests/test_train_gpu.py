@@ -437,3 +437,65 @@ def test_full_size_training_step(style):
     for k in ('loss_c', 'loss_d'):
         assert s1[k] == pytest.approx(s0[k], rel=2e-2), (k, s0, s1)
     assert n1 > 100 * B / 4
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('cin,cout,hw', [(128, 128, (40, 56)), (196, 196, (24, 36)), (256, 256, (17, 21)), (256, 196, (24, 36)), (196, 128, (40, 56))])
+def test_hip_conv3x3_function_against_the_library(dtype, cin, cout, hw):
+    """HipConv3x3 (the backbone's 3x3 / stride-1 convolutions in the mixed-16-bit training step: forward and backward-data on K10 -
+    backward-data as a forward convolution of dY with the transposed, flipped weights - backward-weights on the library) against
+    torch's own convolution forward + backward on the same 16-bit operands, evaluated in fp32: every stride-1 shape of
+    resnet_fpn.py (128 / 196 / 256-wide blocks, the two FPN heads), ragged map sizes, the 196-wide operands zero-padded to 224."""
+    from geoformer_amd.train import hip_autograd as HA
+    g = torch.Generator(device='cuda').manual_seed(cin + cout)
+    H, W = hw
+    x = (torch.randn(3, cin, H, W, device='cuda', generator=g)).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randn(cout, cin, 3, 3, device='cuda', generator=g) / (3 * cin ** 0.5)).requires_grad_(True)          # fp32 master weights
+    dy = torch.randn(3, cout, H, W, device='cuda', generator=g).to(dtype).contiguous(memory_format=torch.channels_last)
+    assert HA.conv3x3_supported(x, w)
+    y = HA.conv3x3(x, w)
+    assert y.dtype == dtype and y.shape == (3, cout, H, W) and y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(dy)
+    xr = x.detach().float().requires_grad_(True)
+    wr = w.detach().to(dtype).float().requires_grad_(True)                      # the kernel multiplies the 16-bit copy of the weights
+    yr = torch.nn.functional.conv2d(xr, wr, None, 1, 1)
+    yr.backward(dy.float())
+    ulp = 2.0 ** (-10 if dtype == torch.float16 else -7)
+    rel = lambda a, b: float(((a.detach().float() - b.detach()).abs() / b.detach().abs().clamp_min(float(b.detach().abs().mean()))).max())
+    assert rel(y, yr) < 1.5 * ulp, rel(y, yr)
+    assert x.grad.dtype == dtype and x.grad.shape == x.shape and rel(x.grad, xr.grad) < 1.5 * ulp, rel(x.grad, xr.grad)
+    # the weight gradient is the LIBRARY's 16-bit kernel (3 x H x W products per element; measured up to 7 ulp of its largest elements in fp16): the
+    # check is the wiring - right operands, fp32 parameter dtype - not its rounding
+    assert w.grad.dtype == torch.float32 and rel(w.grad, wr.grad) < 32 * ulp, rel(w.grad, wr.grad)
+
+
+def test_hip_conv_training_step_matches_the_autocast_step():
+    """TrainStep(hip_conv=True): the backbone's stride-1 3x3 convolutions through HipConv3x3 (NHWC backbone) - first-step loss terms within
+    2 % of the autocast step on the same batch and weights, losses falling, parameters fp32."""
+    from geoformer_amd.model.cvpr_ds_config import get_default_cfg
+    from geoformer_amd.model.full_model import GeoFormer
+    from geoformer_amd.model.geo_config import get_cfg_model
+    from geoformer_amd.train import TrainStep, synthetic_homography_batch
+    from geoformer_amd.weights import deterministic_init_
+    res = {}
+    for hipconv in (False, True):
+        g = get_cfg_model()
+        g.update(coarse_thr=0.0, fine_thr=0.0, precision='fp32')
+        model = deterministic_init_(GeoFormer(get_default_cfg(), g)).cuda()
+        step = TrainStep(model, trainer_cfg={'warmup_step': 0, 'canonical_lr': 1e-3, 'gradient_clipping': 0.0}, batch_size=2,
+                         fused_coarse_loss=True, precision='bf16', hip_backward=True, hip_conv=hipconv)
+        losses, scal = [], None
+        for it in range(4):
+            batch = synthetic_homography_batch(2, (480, 640), seed=5, device='cuda')
+            losses.append(float(step(batch)))
+            if it == 0:
+                scal = {k: float(v) for k, v in batch['loss_scalars'].items()}
+        assert all(p.dtype == torch.float32 for p in model.parameters())
+        res[hipconv] = (losses, scal)
+        del step, model
+        torch.cuda.empty_cache()
+    (l0, s0), (l1, s1) = res[False], res[True]
+    print(f'library convolutions: losses {l0}, first-step terms {s0} | HipConv3x3: losses {l1}, {s1}')
+    assert all(np.isfinite(l1)) and min(l1[1:]) < l1[0], l1
+    for k in ('loss_c', 'loss_d'):
+        assert s1[k] == pytest.approx(s0[k], rel=2e-2), (k, s0, s1)

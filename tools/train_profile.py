@@ -1,5 +1,5 @@
 """Where the training step spends its time (torch profiler, top ops by device time).
-   python tools/train_profile.py [H W] [--no-fused] [--no-prof] [--bf16] [--hip] [--batch B] [--long] [--mega]"""
+   python tools/train_profile.py [H W] [--no-fused] [--no-prof] [--bf16] [--hip] [--batch B] [--long] [--mega] [--cl] [--hipconv]"""
 import sys, time, torch
 HW = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 and sys.argv[1].isdigit() else (480, 640)
 FUSED = '--no-fused' not in sys.argv
@@ -18,7 +18,7 @@ if '--mega' in sys.argv:            # BASELINE configs[3]'s data contract: depth
 g = get_cfg_model(); g.update(coarse_thr=0.0, fine_thr=0.0, precision='fp32')
 model = deterministic_init_(GeoFormer(get_default_cfg(), g)).cuda()
 PREC = 'bf16' if '--bf16' in sys.argv else 'fp32'
-step = TrainStep(model, batch_size=B, fused_coarse_loss=FUSED, precision=PREC, hip_backward='--hip' in sys.argv, channels_last='--cl' in sys.argv)
+step = TrainStep(model, batch_size=B, fused_coarse_loss=FUSED, precision=PREC, hip_backward='--hip' in sys.argv, channels_last='--cl' in sys.argv, hip_conv='--hipconv' in sys.argv)
 nsteps = 10 if "--long" in sys.argv else 4
 batches = [synthetic_homography_batch(B, HW, seed=it, device='cuda') for it in range(nsteps)]      # (made outside the timed steps)
 torch.cuda.synchronize()
