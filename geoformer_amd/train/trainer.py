@@ -118,6 +118,9 @@ class TrainStep:
     GeoTransformer's cross attention K5 and gf_window_cross_attention_backward, FineMatching2 K8 and gf_fine_match_backward; the Geo
     SELF-attention core (K4), the backbone and the losses other than the fused coarse loss stay on autograd.  Step time at batch 2,
     640x640: 0.128 s -> 0.075 s.
+    `hip_conv=True` (with precision='bf16'; round 5): the backbone's 3x3 / stride-1 convolutions through `hip_autograd.HipConv3x3` - forward and
+    backward-data on K10 (`gf_conv3x3_nhwc`; backward-data = the forward kernel on dY with the transposed, flipped weights), backward-weights on
+    the library; the backbone runs in NHWC (implies channels_last).  MegaDepth-style step at batch 8, 640x640: 0.284 s -> 0.245 s.
     NOT bit-reproducible run to run with hip_backward=True: gf_window_cross_attention_backward sums dk / dv of the overlapping 5 x 5
     windows with fp32 atomic adds (the order of the adds varies; differences are at fp32 rounding level, ~1e-7 relative, and DDP ranks
     still hold identical parameters after the all-reduce).  Every other HIP backward sums its partials in a fixed order."""
