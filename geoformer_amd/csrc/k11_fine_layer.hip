@@ -54,9 +54,15 @@ extern "C" int gf_debug_k11_trace(long long* out) {
 namespace {
 
 constexpr int FC = 128;                           // d_model of the fine level
-constexpr int FW = 8;                             // waves (= windows) per workgroup
-constexpr int FRAG = 1024, WBLK = 32768;          // one weight block = 32 fragments of 64 lanes x 16 B
-constexpr int NBLK = 10;                          // blocks per layer
+// -DK11_FW=4 (experiment, round 5): FOUR waves = four windows per workgroup and weight blocks of 16 fragments - 66 KiB of LDS, TWO workgroups
+// (two barrier domains) per CU instead of one of eight waves; the stream and every wave's arithmetic are unchanged
+#ifndef K11_FW
+#define K11_FW 8
+#endif
+constexpr int FW = K11_FW;                        // waves (= windows) per workgroup
+static_assert(FW == 8 || FW == 4, "a weight block is 4 FW fragments: every wave moves four of them");
+constexpr int FRAG = 1024, WBLK = 4 * FW * FRAG;  // one weight block = 4 FW fragments of 64 lanes x 16 B = FW steps
+constexpr int NBLK = 320 / (4 * FW);              // blocks per layer (320 fragments)
 constexpr int TILE = 8192;                        // one window tile: [2 planes][32 rows][128 B], chunk-swizzled (gf_lds_off)
 constexpr int X_OFF = 0;
 constexpr int W_OFF = FW * TILE;                  // 65,536: two weight blocks
@@ -139,7 +145,7 @@ __device__ __forceinline__ void fl_load_step(const FlRing& r, Frag (&f)[4], int 
 // of block g+1 (requested one block ago), tile loads and output stores of earlier phases.
 template <typename Frag>
 __device__ __forceinline__ void fl_fetch_next(FlRing& r, Frag (&nx)[4], int st) {
-    if (st == 7) {
+    if (st == FW - 1) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (r.blk + 2 < r.total) {
@@ -168,7 +174,7 @@ __device__ __forceinline__ void fl_tile_dma(const FlRsrc& wins, int win_byte_off
 }
 
 template <typename T>
-__global__ __launch_bounds__(512, 2) void fine_layer(FlArgs a) {
+__global__ __launch_bounds__(64 * FW, 2) void fine_layer(FlArgs a) {
     using Mm = Mma32<T>;
     using Frag = typename Mm::Frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void fine_layer(FlArgs a) {
     const FlRsrc xrs = fl_rsrc(a.x, (unsigned)a.Nw * a.Lw * (FC * 2)), srs = fl_rsrc(a.src, (unsigned)a.Nw * a.Lw * (FC * 2));
     fl_dma_block(ring, 0, 0);
     fl_dma_block(ring, 1, 1);
-    vec[tid] = a.ln[tid];                                               // 512 threads = 4 x 128 floats
+    for (int i = tid; i < 4 * FC; i += 64 * FW) vec[i] = a.ln[i];       // 4 x 128 floats
     const bool same_src = a.src == a.x;
     const float inv_s = 1.0f / (float)a.Lw, eps_s = a.attn_eps * inv_s;
     // token-slot validity of accumulator row (r&3) + 8 (r>>2) + 4 h2 in the non-transposed products: row < Lw  <=>  its
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void fine_layer(FlArgs a) {
 #define FL_STEP_BEGIN(gs)                                               \
     Frag (&cur)[4] = ((gs) & 1) ? fb : fa;                               \
     Frag (&nxt)[4] = ((gs) & 1) ? fa : fb;                               \
-    fl_fetch_next(ring, nxt, (gs) & 7)
+    fl_fetch_next(ring, nxt, (gs) & (FW - 1))
 
     int git = -1;
     (void)git;
@@ -496,9 +502,9 @@ extern "C" int gf_fine_layer(const void* x, const void* src, void* out, int dtyp
         const int nw = (int)((Nw - w0) < per_launch ? (Nw - w0) : per_launch);
         FlArgs a{(const char*)x + w0 * win_bytes, (const char*)src + w0 * win_bytes, (char*)out + w0 * win_bytes, wstream, ln_params,
                  eps1, eps2, attn_eps, nw, Lw, (nw + FW - 1) / FW};
-        const int grid = a.groups < 256 ? a.groups : 256;
-        if (dtype == GF_F16) fine_layer<_Float16><<<grid, 512, LDS_BYTES, st>>>(a);
-        else fine_layer<gf_bf16><<<grid, 512, LDS_BYTES, st>>>(a);
+        const int slots = 256 * (8 / FW), grid = a.groups < slots ? a.groups : slots;
+        if (dtype == GF_F16) fine_layer<_Float16><<<grid, 64 * FW, LDS_BYTES, st>>>(a);
+        else fine_layer<gf_bf16><<<grid, 64 * FW, LDS_BYTES, st>>>(a);
     }
     gf_prof_end("fine_layer", pt, st);
     GF_CHECK_LAUNCH();
