@@ -192,7 +192,7 @@ def _pad_channels(x, cp):
     """channels_last [N, C, H, W] -> channels_last [N, cp, H, W], the new channels zero"""
     if x.shape[1] == cp:
         return x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
-    out = torch.zeros((x.shape[0], cp, x.shape[2], x.shape[3]), dtype=x.dtype, device=x.device).contiguous(memory_format=torch.channels_last)
+    out = torch.empty((x.shape[0], cp, x.shape[2], x.shape[3]), dtype=x.dtype, device=x.device, memory_format=torch.channels_last).zero_()
     out[:, :x.shape[1]] = x
     return out
 
