@@ -781,14 +781,29 @@ def main(argv=None):
         'roofline': dominant,
         'roofline_kernels': entries,
     }
+    # the correlation sweep's figures as top-level scalars (north_star: achieved HBM GB/s on the correlation sweep): a parser that keeps
+    # only scalar keys sees them too
+    for x in entries:
+        if x['tag'] in ('k1_conf', 'k1_unit', 'k1_stats', 'enc_layer', 'fine_layer', 'k4_self_attention', 'conv3x3'):
+            res[f"{x['tag']}_frac"] = x['frac']
+            res[f"{x['tag']}_us_per_launch"] = 1e3 * x['avg_launch_ms']
+            res[f"{x['tag']}_achieved_{'GBps' if x['bound'] == 'hbm' else 'TFLOPs'}"] = x['achieved']
     if world == 1 and not args.no_extras:
         res['side_measurements'] = side_measurements(args, model, dev, log, L, batches, planted, pipes)
         ind = res['side_measurements'].get('nominal_independent')
         if ind:                                   # what the two extra elementwise passes of the dependency cost the headline
             res['side_measurements']['dependency_cost_pct'] = 100.0 * (ind['value'] - res['value']) / ind['value']
+    if world == 1 and not args.no_extras:
+        del model, batches, planted
+        torch.cuda.empty_cache()
+        res['side_measurements']['hpatches_b1'] = hpatches_b1_measurements(dev, log, L, pipes if pipes.n == 2 and not pipes.serial else None)
+        hb = res['side_measurements']['hpatches_b1']
+        for k in ('nominal_pairs_per_s', 'nominal_latency_ms_p50', 'light_pairs_per_s', 'light_graphs_pairs_per_s'):
+            if k in hb:
+                res[f'hpatches_b1_{k}'] = hb[k]
+        model = batches = planted = None
     pipes.close()
     if world == 1 and not args.no_extras and not args.no_train:
-        del model, batches, planted
         torch.cuda.empty_cache()
         res['side_measurements']['train_step'] = train_measurements(dev, log)
         for k, v in res['side_measurements']['train_step'].items():      # top-level scalars as well
@@ -897,6 +912,134 @@ def side_measurements(args, model, dev, log, L, batches=None, planted=None, pipe
         torch.cuda.empty_cache()
         log(f"parity mode (fp32): {out['parity_mode']['value']:.1f} pairs/s")
     return out
+
+
+def hpatches_b1_measurements(dev, log, L, pipes=None, steps=60, warmup=6):
+    """BASELINE configs[1] (the HPatches loop: `eval_Hpatches.py` -> `hpatches_helper.py:167-182`, one pair per matcher call, `imsize: 480` =
+    shorter side 480 and both sides floored to a multiple of 8, `data_io.py:16-26`): batch 1, UNEQUAL shapes 480x640 against 480x608 (coarse
+    grids 60x80 = 4800 and 60x76 = 4560 tokens), bf16 features, the reference's thresholds 0.2 / 0.1.  Synthetic inputs, closed-form weights:
+      nominal  backbone on the two images (one call each: the shapes differ, full_model.py:58-59) + matching path on planted-correspondence
+               maps fed through that backbone output (the headline's construction at batch 1): thousands of matches per pair;
+      light    the full forward on a textured image pair under a homography (thresholds 0: random-init weights give few matches), eager and
+               with hipGraph replay of the static part (`GeoFormer.enable_graphs`: the loop repeats its shapes).
+    Per workload: pairs/s over two host pipelines (the loop's throughput when pairs are independent), per-pair latency on ONE stream with a
+    host synchronisation per pair (what `match_time` of hpatches_helper.py:174-182 records), host time to enqueue the static part, and the
+    per-launch time of the K9 / K1 kernels at these shapes (4800 x 4560 tiles on 256 CUs).  Side measurements, never `value`."""
+    import torch
+    out = {'shapes': [[480, 640], [480, 608]], 'dtype': 'bf16', 'batch': 1}
+    box = [pipes]
+    hw0, hw1, g0, g1 = (480, 640), (480, 608), (60, 80), (60, 76)
+    gen = torch.Generator().manual_seed(4242)
+
+    def textured(hw, shift):
+        base = torch.rand(1, 1, hw[0] // 8 + 4, hw[1] // 8 + 4, generator=gen)
+        img = torch.nn.functional.interpolate(base, size=(hw[0] + 32, hw[1] + 32), mode='bicubic', align_corners=True)
+        return img[:, :, shift:shift + hw[0], shift:shift + hw[1]].clamp(0, 1).contiguous().to(dev)
+
+    def planted(seed):
+        g = torch.Generator().manual_seed(seed)
+        big = torch.randn(1, 256, g0[0] + 1, g0[1] + 1, generator=g) * 0.5
+        bigf = torch.randn(1, 128, 4 * (g0[0] + 1), 4 * (g0[1] + 1), generator=g)
+        c0, f0 = big[:, :, :g0[0], :g0[1]], bigf[:, :, :4 * g0[0], :4 * g0[1]]
+        c1 = big[:, :, 1:1 + g1[0], 1:1 + g1[1]] + 0.35 * torch.randn(1, 256, *g1, generator=g)
+        f1 = bigf[:, :, 4:4 + 4 * g1[0], 4:4 + 4 * g1[1]] + 0.35 * torch.randn(1, 128, 4 * g1[0], 4 * g1[1], generator=g)
+        return [t.to(device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last) for t in (c0, f0, c1, f1)]
+
+    def run(tag, step, what):
+        with torch.no_grad():
+            r = step(0)
+            torch.cuda.synchronize()
+            M = len(r['b_ids'])
+            # latency: one stream, one host synchronisation per pair
+            lat = []
+            for i in range(warmup + steps):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                step(i)
+                torch.cuda.synchronize()
+                lat.append(time.perf_counter() - t)
+            lat = sorted(lat[warmup:])
+            # throughput: two host pipelines (the headline's own threads and streams when it ran on two)
+            el, p = measure_fn(step, steps, warmup, 2, dev, box[0])
+            box[0] = p
+        out[f'{tag}_pairs_per_s'] = steps / el
+        out[f'{tag}_latency_ms_p50'] = 1e3 * lat[len(lat) // 2]
+        out[f'{tag}_latency_ms_p99'] = 1e3 * lat[min(len(lat) - 1, int(0.99 * len(lat)))]
+        out[f'{tag}_coarse_matches_per_pair'] = M
+        out[f'{tag}_what'] = what
+        log(f"hpatches_b1 {tag}: {out[f'{tag}_pairs_per_s']:.1f} pairs/s on two pipelines, latency p50 {out[f'{tag}_latency_ms_p50']:.2f} ms "
+            f"p99 {out[f'{tag}_latency_ms_p99']:.2f} ms, M = {M}")
+
+    i0, i1 = textured(hw0, 8), textured(hw1, 16)
+    mn, _ = build_model('bf16', 0.2, 0.1, dev)
+    pl = [planted(70000 + i) for i in range(2)]
+
+    def nominal_step(i):
+        (fc0, ff0), (fc1, ff1) = mn._backbone(i0), mn._backbone(i1)
+        c0, f0, c1, f1 = pl[i % 2]
+        return mn.forward_features({'image0': i0, 'image1': i1}, torch.add(c0, fc0, alpha=0.0), torch.add(f0, ff0, alpha=0.0),
+                                   torch.add(c1, fc1, alpha=0.0), torch.add(f1, ff1, alpha=0.0))
+    run('nominal', nominal_step, 'backbone on 480x640 / 480x608 images + matching path on planted maps through the backbone output, thresholds 0.2 / 0.1')
+    # per-launch times of the hot-path kernels at these shapes (one stream, HIP events on every tagged launch)
+    L.gf_profile_filter(None)
+    L.gf_profile_enable(1)
+    with torch.no_grad():
+        for i in range(4):
+            nominal_step(i)
+    torch.cuda.synchronize()
+    kern = {}
+    for tag in ('enc_layer', 'enc_kv_state', 'k1_stats', 'k1_conf', 'k1_unit', 'fine_layer', 'k4_self_attention', 'k5_window_attention', 'conv3x3'):
+        ms, cnt, work = ctypes.c_double(0), ctypes.c_int(0), ctypes.c_double(0)
+        L.gf_profile_collect(tag.encode(), ctypes.byref(ms), ctypes.byref(cnt), ctypes.byref(work))
+        if cnt.value:
+            kern[tag] = {'us_per_launch': 1e3 * ms.value / cnt.value, 'launches_per_pair': cnt.value / 4.0, 'ms_per_pair': ms.value / 4.0}
+            if tag in ('enc_layer', 'enc_kv_state', 'k1_stats', 'fine_layer', 'conv3x3') and work.value > 0:
+                kern[tag]['frac_of_mfma_peak'] = work.value / (ms.value * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS['bf16']
+            if tag in ('k1_conf', 'k1_unit', 'k5_window_attention') and work.value > 0:
+                kern[tag]['frac_of_hbm_peak'] = work.value / (ms.value * 1e-3) / 1e9 / HBM_PEAK_GBPS
+    L.gf_profile_enable(0)
+    out['kernels_nominal'] = kern
+    ts = []
+    with torch.no_grad():
+        for _ in range(4):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            (fc0, ff0), (fc1, ff1) = mn._backbone(i0), mn._backbone(i1)
+            c0, f0, c1, f1 = pl[0]
+            mn.forward_features({'image0': i0, 'image1': i1}, torch.add(c0, fc0, alpha=0.0), torch.add(f0, ff0, alpha=0.0),
+                                torch.add(c1, fc1, alpha=0.0), torch.add(f1, ff1, alpha=0.0), static_only=True)
+            ts.append(time.perf_counter() - t)
+    torch.cuda.synchronize()
+    out['nominal_host_launch_us_per_pair'] = 1e6 * min(ts[1:])
+    del mn, pl
+    torch.cuda.empty_cache()
+    ml, _ = build_model('bf16', 0.0, 0.0, dev)
+    j1 = synth_rect_pair(hw0, hw1, 77, dev)
+    run('light', lambda i: ml({'image0': j1[0], 'image1': j1[1]}), 'full forward on a textured 480x640 image and its homography warp at 480x608, thresholds 0')
+    ml.enable_graphs()
+    run('light_graphs', lambda i: ml({'image0': j1[0], 'image1': j1[1]}), 'the same with hipGraph replay of the static part')
+    del ml
+    torch.cuda.empty_cache()
+    if pipes is None and box[0] is not None:
+        box[0].close()
+    return out
+
+
+def synth_rect_pair(hw0, hw1, seed, device):
+    """One textured image of hw0 and its warp under a small random homography, resampled at hw1 (the HPatches loop's unequal shapes)."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    H0, W0 = hw0
+    base = torch.rand(1, 1, H0 // 8 + 2, W0 // 8 + 2, generator=g)
+    img = torch.nn.functional.interpolate(base, size=(H0 + 16, W0 + 16), mode='bicubic', align_corners=True)
+    img = (img + 0.15 * torch.rand(1, 1, H0 + 16, W0 + 16, generator=g)).clamp(0, 1)
+    image0 = img[:, :, 8:8 + H0, 8:8 + W0].contiguous()
+    th = (torch.rand(1, generator=g) - 0.5) * 0.1
+    theta = torch.tensor([[[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]]) + torch.cat([torch.stack([torch.cos(th) - 1, -torch.sin(th), th]),
+                                                                          torch.stack([torch.sin(th), torch.cos(th) - 1, -th])]).view(1, 2, 3) * 0.5
+    grid = torch.nn.functional.affine_grid(theta, (1, 1, hw1[0], hw1[1]), align_corners=True) * 0.92
+    image1 = torch.nn.functional.grid_sample(img, grid, mode='bilinear', padding_mode='border', align_corners=True)
+    return image0.to(device), image1.contiguous().to(device)
 
 
 def train_measurements(dev, log, steps=5, warmup=2):

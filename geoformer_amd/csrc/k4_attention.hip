@@ -172,8 +172,13 @@ __device__ __forceinline__ float half_max(float x) {
 // the reference moves), so the accumulator IS the exponent's argument: per logit one exponential, half a max3, half a pair add and
 // half a conversion - no FMA.  The price is one more 16-bit rounding of q (the product q . k is then scaled BEFORE the sum instead of
 // after it: the same softmax(Q K^T / sqrt(D)) V; the oracle's storage mode rounds q * c the same way).
-template <typename T, int QB, int WV, bool MSUM = false, bool PRE = true, bool DIRECT = false>
-__global__ __launch_bounds__(64 * WV, WV == 16 ? 4 : WV == 8 ? (QB == 1 ? 4 : 2) : (QB <= 2 ? 2 : 1)) void attn_self(AtArgs a) {
+// (Round 6: this kernel is the FALLBACK of the head form - fp32 parity mode, unaligned or very wide rows - and is built in one configuration: four waves,
+// the compact K / V^T buffers of the gather pass, the prescaled Q operand.  The other settings of the constants below were round-5 experiments;
+// their measurements are in DESIGN.md section 3 and profiles/r05_k4_experiments.txt, their launch switches are gone.)
+template <typename T, int QB>
+__global__ __launch_bounds__(256, QB <= 2 ? 2 : 1) void attn_self(AtArgs a) {
+    constexpr int WV = 4;
+    constexpr bool MSUM = false, PRE = true, DIRECT = false;
     using M = Mma32<T>;
     using Frag = typename M::Frag;
     constexpr bool F32 = std::is_same<T, float>::value;
@@ -191,9 +196,6 @@ __global__ __launch_bounds__(64 * WV, WV == 16 ? 4 : WV == 8 ? (QB == 1 ? 4 : 2)
     const int n = id / gx, q0 = (id - n * gx) * (32 * QB * (WV / 4)) + (tid >> 8) * (32 * QB);
     const int head = (tid >> 6) & 3, lane = tid & 63, h = lane >> 5, lr = lane & 31;
     const int K = a.nkeys[(size_t)n * a.nkeys_stride];
-#ifdef K4_PRIO        // -DK4_PRIO (experiment, round 5): the second-dispatched half of an eight-wave workgroup at static priority 1, as in K10
-    if (WV == 8 && tid >= 256) __builtin_amdgcn_s_setprio(1);
-#endif
     // QB blocks of 32 queries per wave: a staged K / V tile (32 keys x 256 channels, 32 KiB) serves 32 QB queries of every head
     // (with one block a workgroup streams the image's whole K and V for 32 queries: L2-bound at ~1200 keys)
     Frag qf[QB][NG];
@@ -586,247 +588,6 @@ __global__ __launch_bounds__(64 * WV, WV == 16 ? 4 : WV == 8 ? (QB == 1 ? 4 : 2)
 
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Round 5: the 16-bit forward as a software pipeline.  What the counters said about attn_self (tools/kernel_pmc.sh,
-// 16 images x 1195 keys): SQ_ACTIVE_INST_VALU = 53 % of all SIMD cycles, the matrix pipe busy for 26 %, and the kernel's time = their
-// SUM plus waits - a wave alternates an MFMA-only phase (S, P.V) with a VALU-only phase (softmax) and with two (or four) waves per SIMD
-// the phases of different waves almost never fall beside each other; 113 vector instructions per 1024 logits, a third of them the
-// rescale of O, which ran in nearly every tile (the wave-wide `any running maximum moved` is true for most tiles of 38).  Hence:
-//   * deferred maximum (guide T13): a query's reference m moves only when its tile maximum exceeds it by more than THR = 8 in the
-//     exponent's log2 units (P <= 256: exact in fp16 / bf16 up to their rounding, the row sum stays fp32); the rescale becomes a rare
-//     side path of the loop and only the lanes that need it change m (alpha = 1 for the others: a per-QUERY rule the oracle restates);
-//   * S of tile t + 1 is computed WHILE tile t's softmax runs: one basic block per tile in which the 16 MFMAs of a wave (S_next of both
-//     query blocks, P.V of both) sit between the exponentials of the two blocks, so the matrix pipe works under the vector phases of the
-//     SAME wave instead of waiting for another wave's; tile t + 1 must have landed a tile early: three LDS images;
-//   * eight waves = two per head share a staged tile (half the L2 -> LDS bytes per query), one workgroup of 128 KiB per CU.
-// Arithmetic per query = attn_self's (same tile order, same operand order inside the MFMAs) except that the row sums here are vector adds
-// of the UNROUNDED probabilities (attn_self sums the rounded ones on the matrix pipe since): an experiment kept for the record, not a product path.
-// ABL != 0: diagnostic instances (GF_K4_ABL=n, fp16 only; results are wrong by construction): 1 no exponential, 2 no softmax
-// arithmetic at all, 3 no MFMA, 4 no fragment reads from LDS, 5 no LDS-DMA and no barrier, 6 no barrier only
-template <typename T, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void attn_self_pipe(AtArgs a) {
-    using M = Mma32<T>;
-    using Frag = typename M::Frag;
-    constexpr int KG = M::kGroup, NG = HD / KG, EPC = 16 / sizeof(T), QB = 2, PW = 2;
-    constexpr int KBYTES = KT * CC * sizeof(T);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int gx = gridDim.x, total = gx * gridDim.y, tid = threadIdx.x;
-    int id = blockIdx.y * gx + blockIdx.x;
-    if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);           // whole images per XCD (see attn_self)
-    const int n = id / gx, q0 = (id - n * gx) * (64 * QB) + (tid >> 8) * (32 * QB);
-    const int head = (tid >> 6) & 3, lane = tid & 63, h = lane >> 5, lr = lane & 31;
-    const int K = a.nkeys[(size_t)n * a.nkeys_stride];
-    Frag qf[QB][NG];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        const int qrow = min(q0 + 32 * qb + lr, a.L - 1);
-        const T* qp = (const T*)a.q + ((size_t)n * a.L + qrow) * a.ldq + head * HD;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) qf[qb][g] = *reinterpret_cast<const Frag*>(qp + g * KG + h * (KG / 2));
-    }
-    v16f o[QB][2];
-    float m[QB], l[QB];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        m[qb] = -INFINITY;
-        l[qb] = 0.f;
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[qb][b][r] = 0.f;
-    }
-    const T* kc = (const T*)a.kc + (size_t)n * a.Kpad * CC;
-    const int ntiles = (K + KT - 1) / KT;
-    const float scale2 = a.softmax_temp * 1.44269504088896341f;
-    const float defer = K4_DEFER / scale2;                               // the threshold on the unscaled logits
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const AtRsrc rk = at_rsrc(kc, (unsigned)((size_t)a.Kpad * CC * sizeof(T)));
-    const AtRsrc rv = at_rsrc((const T*)a.vc + (size_t)n * CC * a.Kpad, (unsigned)((size_t)CC * a.Kpad * sizeof(T)));
-    int kvo[PW], vvo[PW];
-#pragma unroll
-    for (int i = 0; i < PW; ++i) {
-        const int g = wv * PW + i;
-        const int krow = 2 * g + (lane >> 5), kslot = lane & 31;
-        kvo[i] = krow * (CC * (int)sizeof(T)) + ((kslot ^ (krow & 15)) << 4);
-        const int vrow = 16 * g + (lane >> 2), vslot = lane & 3;
-        vvo[i] = vrow * (a.Kpad * (int)sizeof(T)) + ((vslot ^ ((vrow >> 2) & 3)) << 4);
-    }
-    auto request = [&](int tile, int slot) {
-        if constexpr (ABL == 5) return;
-        char* img = smem + slot * (2 * KBYTES);
-#pragma unroll
-        for (int i = 0; i < PW; ++i) at_lds_dma(rk, img + (wv * PW + i) * 1024, kvo[i], tile * KBYTES);
-#pragma unroll
-        for (int i = 0; i < PW; ++i) at_lds_dma(rv, img + KBYTES + (wv * PW + i) * 1024, vvo[i], tile * (KT * (int)sizeof(T)));
-    };
-    // lane-constant LDS offsets of the fragments: K row lr, chunks of head-dim group g; V^T channel rows b * 32 + lr, key chunks 2 s2 + h
-    int koff[NG], voff[2][2];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) koff[g] = k_off<T>(lr, (head * HD + g * KG + h * (KG / 2)) / EPC);
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) voff[s2][b] = KBYTES + vt_off(head * HD + b * 32 + lr, 2 * s2 + h);
-    // FOUR LDS images (128 KiB): iteration t reads V of tile t and K of tile t + 1, tile t + 2 is in flight and tile t + 3 is requested
-    // into tile t - 1's image - two whole iterations for a request to land.  The tile loop is unrolled by the ring's length so that
-    // an image's base is a compile-time constant (fragment addresses = lane constant + immediate).
-    constexpr int NS = 4, IMG = 2 * KBYTES;
-    v16f sc[QB];
-    if (ntiles > 0) {
-        request(0, 0);
-        request(1, 1);
-        request(2, 2);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                   // tiles 0 and 1 (the 4 youngest requests are tile 2's)
-        __syncthreads();
-        Frag kf[NG];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) kf[g] = *reinterpret_cast<const Frag*>(smem + koff[g]);
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sc[qb][r] = 0.f;
-#pragma unroll
-            for (int g = 0; g < NG; ++g) M::mma(kf[g], qf[qb][g], sc[qb]);
-        }
-    }
-    auto body = [&](auto slot_c, int tile) {
-        constexpr int SLOT = decltype(slot_c)::value, NSLOT = (SLOT + 1) % NS, FSLOT = (SLOT + 3) % NS;
-        if (tile > 0) {
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");               // my pieces of tile + 1 (tile + 2's stay in flight)
-            if constexpr (ABL != 5 && ABL != 6) __syncthreads();           // everyone's; and everyone is done with tile - 1
-        }
-        request(tile + 3, FSLOT);                                          // into tile - 1's image (behind the last tile: bytes nobody reads)
-        // ---- the reference of each query: moves only when the tile's maximum is more than THR above it (and in the first tile)
-        if ((tile + 1) * KT > K) {                                         // the ragged last tile: key slots >= K do not count
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sc[qb][r] = tile * KT + gf_acc_row(r, h) < K ? sc[qb][r] : -INFINITY;
-        }
-        float tmax[QB];
-        bool need = false;
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            float t = sc[qb][0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) t = fmaxf(t, sc[qb][r]);
-            tmax[qb] = half_max(t);
-            need = need || (tmax[qb] - m[qb] > defer);                     // m = -inf: +inf > defer
-        }
-        if (__any(need)) {
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                const float mnew = (tmax[qb] - m[qb] > defer) ? tmax[qb] : m[qb];     // only the queries that need it
-                const float alpha = __builtin_amdgcn_exp2f((m[qb] - mnew) * scale2);  // 1 for the others, 0 in the first tile (O = l = 0)
-                l[qb] *= alpha;
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[qb][b][r] *= alpha;
-                m[qb] = mnew;
-            }
-        }
-        // ---- one basic block: S of tile + 1 and P.V of this tile between the exponentials of the two query blocks
-        const char* cur = smem + SLOT * IMG;
-        const char* nxt = smem + NSLOT * IMG;
-        Frag kf[NG], vf[2][2];
-        if constexpr (ABL == 4) {
-#pragma unroll
-            for (int g = 0; g < NG; ++g) kf[g] = qf[0][g];
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) vf[s2][b] = qf[1][2 * s2 + b];
-        } else {
-#pragma unroll
-            for (int g = 0; g < NG; ++g) kf[g] = *reinterpret_cast<const Frag*>(nxt + koff[g]);
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) vf[s2][b] = *reinterpret_cast<const Frag*>(cur + voff[s2][b]);
-        }
-        v16f sn[QB];
-        Frag pf[QB][2];
-        float psum[QB];
-        auto s_next = [&](int qb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sn[qb][r] = 0.f;
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                if constexpr (ABL == 3) sn[qb][g] += (float)kf[g][0] * (float)qf[qb][g][1];
-                else M::mma(kf[g], qf[qb][g], sn[qb]);
-            }
-        };
-        auto softmax = [&](int qb) {
-            const float nms = -m[qb] * scale2;
-            float x[16];
-            float ps = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if constexpr (ABL == 2) x[r] = sc[qb][r];
-                else if constexpr (ABL == 1) x[r] = fmaf(sc[qb][r], scale2, nms);
-                else x[r] = __builtin_amdgcn_exp2f(fmaf(sc[qb][r], scale2, nms));
-                if constexpr (ABL != 2) ps += x[r];
-            }
-            psum[qb] = ps;
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-                pf[qb][s2] = Frag{(T)x[8 * s2], (T)x[8 * s2 + 1], (T)x[8 * s2 + 2], (T)x[8 * s2 + 3],
-                                  (T)x[8 * s2 + 4], (T)x[8 * s2 + 5], (T)x[8 * s2 + 6], (T)x[8 * s2 + 7]};
-        };
-        auto pv = [&](int qb) {
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    if constexpr (ABL == 3) o[qb][b][s2] += (float)vf[s2][b][0] * (float)pf[qb][s2][1];
-                    else M::mma(vf[s2][b], pf[qb][s2], o[qb][b]);
-                }
-        };
-        s_next(0);
-        softmax(0);
-        pv(0);
-        s_next(1);
-        softmax(1);
-        pv(1);
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            l[qb] += psum[qb];
-            sc[qb] = sn[qb];
-        }
-    };
-    using std::integral_constant;
-    int tile = 0;
-    for (; tile + NS <= ntiles; tile += NS) {
-        body(integral_constant<int, 0>{}, tile);
-        body(integral_constant<int, 1>{}, tile + 1);
-        body(integral_constant<int, 2>{}, tile + 2);
-        body(integral_constant<int, 3>{}, tile + 3);
-    }
-    if (tile < ntiles) body(integral_constant<int, 0>{}, tile);
-    if (tile + 1 < ntiles) body(integral_constant<int, 1>{}, tile + 1);
-    if (tile + 2 < ntiles) body(integral_constant<int, 2>{}, tile + 2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // nothing of the ring in flight behind the kernel's LDS
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        const float lsum = l[qb] + __shfl_xor(l[qb], 32, 64);
-        const int qi = q0 + 32 * qb + lr;
-        if (qi < a.L) {
-            T* op = (T*)a.out + ((size_t)n * a.L + qi) * CC + head * HD;
-            const float inv = K > 0 ? 1.0f / lsum : 0.f;
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const int d = b * 32 + 8 * r4 + 4 * h;
-                    *reinterpret_cast<gf_vec<T, 4>*>(op + d) = gf_vec<T, 4>{(T)(o[qb][b][4 * r4] * inv), (T)(o[qb][b][4 * r4 + 1] * inv),
-                                                                            (T)(o[qb][b][4 * r4 + 2] * inv), (T)(o[qb][b][4 * r4 + 3] * inv)};
-                }
-        }
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------------
 // Round 5, the HEAD form (the default of the 16-bit modes).  Two measurements decide its structure:
 //  * tools/probes/mfma_filler.hip: ONE wave's own stream covers up to five vector instructions (two exponentials) per v_mfma_f32_32x32x16 for nothing
 //    (32.3 cycles per MFMA at one or two waves per SIMD), but an MFMA-only wave beside a vector-only wave on the same SIMD both crawl (76 cycles per
@@ -845,11 +606,12 @@ __global__ __launch_bounds__(512, 2) void attn_self_pipe(AtArgs a) {
 //   K image: row = key (128 B), 16-B chunk c at c ^ ((key >> 1) & 7)  (a ds_read_b128 lane group - 16 keys, one chunk - covers the 64 banks)
 //   V image: row = key (128 B), 32-B block b (16 channels) at b ^ 2 ((key >> 1) & 1)  (a transposing read's 32 lanes - 4 keys x 2 blocks x 4 pieces -
 //            cover the 64 banks); the fragment's second half is 8 keys = 1 KiB further
-// ABL (diagnostic builds, -DK4_ABLATE, GF_K4_ABL): 1 no exponentials, 2 no barrier, 3 no fragment reads, 4 no requests, 5 no maximum, 6 no MFMA
-// ORD = 1: the tile opens with the exponentials of its first half (no LDS operand) under the fragment reads' latency, P.V keys 0..15 before the S chain,
-// the requests inside the S chain
-template <typename T, int NS, int NW, int ABL = 0, int ORD = 0>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void attn_self_head(AtArgs a) {
+// Issue order of a tile: it opens with the exponentials of its first half (no LDS operand) under the fragment reads' latency, P.V keys 0..15 before
+// the S chain, the requests inside the S chain.  (The variants measured in round 5 and not kept - eight waves, 6- / 8-image rings, the S chain first,
+// the ablation instances - are in git history and profiles/r05_k4_experiments.txt.)
+template <typename T>
+__global__ __launch_bounds__(256, 3) void attn_self_head(AtArgs a) {
+    constexpr int NS = 4, NW = 4;                                          // images in the ring, waves per workgroup
     using M = Mma32<T>;
     using Frag = typename M::Frag;
     constexpr int KG = M::kGroup, NG = HD / KG, D = NS - 1, QW = 32 * NW;
@@ -967,14 +729,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void attn_self_head(AtArg
             // tile + 1's rows (requested D - 1 tiles ago) have landed - this wave's; the requests and token reads issued since stay in flight
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BOTH ? 3 * D - 5 : 2 * D - 3) : "memory");
             K4_T(1);
-            if constexpr (ABL != 2) __syncthreads();
+            __syncthreads();
         }
         K4_T(2);
-        // tile + D into tile - 1's image, with the token read NS tiles ago; then the token of tile + D + NS into its place
-        if constexpr (ABL != 4 && ORD == 0) {
-            request(FSLOT, tile + D, tk[FSLOT], TAIL);
-            tk[FSLOT] = load_tok(tile + D + NS);
-        }
         // ---- deferred reference (attn_self's rule): up by d = the tile's maximum when that is more than K4_DEFER above it, and in the first tile
         const bool need = tmax > K4_DEFER || tile == 0;
         if (__any(need)) {
@@ -1002,62 +759,22 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void attn_self_head(AtArg
         f2 ps2{0.f, 0.f};
         auto ex = [&](int r0, int r1) {
 #pragma unroll
-            for (int r = r0; r < r1; ++r) x[r] = ABL == 1 ? sc[r] : __builtin_amdgcn_exp2f(sc[r]);
+            for (int r = r0; r < r1; ++r) x[r] = __builtin_amdgcn_exp2f(sc[r]);
         };
         auto sum = [&](int r0, int r1) {
 #pragma unroll
             for (int r = r0; r < r1; r += 2) ps2 += f2{x[r], x[r + 1]};
         };
-        auto mm = [&](const Frag& x_, const Frag& y_, v16f& c_) {
-            if constexpr (ABL == 6) c_[0] += gf_to_float(x_[0]) + gf_to_float(y_[0]);
-            else M::mma(x_, y_, c_);
-        };
+        auto mm = [&](const Frag& x_, const Frag& y_, v16f& c_) { M::mma(x_, y_, c_); };
         v16f sn;
-        if constexpr (ORD == 0) {
+        {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int g = 0; g < NG; ++g) kf[g] = ABL == 3 ? qf[g] : *reinterpret_cast<const Frag*>(nxt + koff[g]);
+            for (int b = 0; b < 2; ++b) vf[0][b] = v_frag(cur, b, 0);
 #pragma unroll
-            for (int b = 0; b < 2; ++b) vf[0][b] = ABL == 3 ? qf[b] : v_frag(cur, b, 0);
-            sn = negm;
-            __builtin_amdgcn_sched_barrier(0);
-            mm(kf[0], qf[0], sn);
-            ex(0, 2);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(kf[1], qf[1], sn);
-            ex(2, 4);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(kf[2], qf[2], sn);
-            ex(4, 6);
-            sum(0, 4);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(kf[3], qf[3], sn);
-            ex(6, 8);
-            sum(4, 8);
-            const Frag pf0{(T)x[0], (T)x[1], (T)x[2], (T)x[3], (T)x[4], (T)x[5], (T)x[6], (T)x[7]};
+            for (int g = 0; g < NG; ++g) kf[g] = *reinterpret_cast<const Frag*>(nxt + koff[g]);
 #pragma unroll
-            for (int b = 0; b < 2; ++b) vf[1][b] = ABL == 3 ? qf[2 + b] : v_frag(cur, b, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            K4_T(4);
-            mm(vf[0][0], pf0, o[0]);
-            ex(8, 12);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(vf[0][1], pf0, o[1]);
-            ex(12, 16);
-            __builtin_amdgcn_sched_barrier(0);
-            const Frag pf1{(T)x[8], (T)x[9], (T)x[10], (T)x[11], (T)x[12], (T)x[13], (T)x[14], (T)x[15]};
-            mm(vf[1][0], pf1, o[0]);
-            sum(8, 16);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(vf[1][1], pf1, o[1]);
-        } else {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int b = 0; b < 2; ++b) vf[0][b] = ABL == 3 ? qf[b] : v_frag(cur, b, 0);
-#pragma unroll
-            for (int g = 0; g < NG; ++g) kf[g] = ABL == 3 ? qf[g] : *reinterpret_cast<const Frag*>(nxt + koff[g]);
-#pragma unroll
-            for (int b = 0; b < 2; ++b) vf[1][b] = ABL == 3 ? qf[2 + b] : v_frag(cur, b, 1);
+            for (int b = 0; b < 2; ++b) vf[1][b] = v_frag(cur, b, 1);
             sn = negm;
             __builtin_amdgcn_sched_barrier(0);
             ex(0, 8);
@@ -1073,16 +790,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void attn_self_head(AtArg
             __builtin_amdgcn_sched_barrier(0);
             mm(kf[0], qf[0], sn);
             ex(12, 14);
-            if constexpr (ABL != 4) {
-#ifdef K4H_PRIO                        // -DK4H_PRIO (experiment): the requests at raised wave priority
-                __builtin_amdgcn_s_setprio(3);
-#endif
-                request(FSLOT, tile + D, tk[FSLOT], TAIL);
-                tk[FSLOT] = load_tok(tile + D + NS);
-#ifdef K4H_PRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
-            }
+            request(FSLOT, tile + D, tk[FSLOT], TAIL);                      // tile + D into tile - 1's image, with the token read NS tiles ago;
+            tk[FSLOT] = load_tok(tile + D + NS);                            // then the token of tile + D + NS into its place
             __builtin_amdgcn_sched_barrier(0);
             mm(kf[1], qf[1], sn);
             ex(14, 16);
@@ -1099,7 +808,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void attn_self_head(AtArg
         }
         K4_T(5);
         l += ps2.x + ps2.y;
-        tmax = ABL == 5 ? sn[0] : tile_max(sn, tile + 1, TAIL);             // (behind the last tile: a value nobody uses)
+        tmax = tile_max(sn, tile + 1, TAIL);             // (behind the last tile: a value nobody uses)
         sc = sn;
         K4_T(6);
     };
@@ -1150,33 +859,8 @@ void k4_launch_head(const AtArgs& a, hipStream_t st) {
     if constexpr (std::is_same<T, float>::value) {
         (void)a; (void)st;
     } else {
-        static const int ns = [] { const char* e = getenv("GF_K4_NS"); return e ? atoi(e) : 4; }();
-        static const int nw = [] { const char* e = getenv("GF_K4_NW"); return e ? atoi(e) : 4; }();
-        const int NH = CC / HD, IMGB = 2 * KT * HD * 2;
-        if (nw == 8) {
-            const int blocks = ((a.L + 255) / 256) * NH * a.N;
-            if (ns == 4) attn_self_head<T, 4, 8><<<blocks, 512, 4 * IMGB, st>>>(a);
-            else attn_self_head<T, 8, 8><<<blocks, 512, 8 * IMGB, st>>>(a);
-        } else {
-            const int blocks = ((a.L + 127) / 128) * NH * a.N;
-#ifdef K4_ABLATE
-            static const int abl = [] { const char* e = getenv("GF_K4_ABL"); return e ? atoi(e) : 0; }();
-            switch (abl) {
-                case 1: attn_self_head<T, 4, 4, 1><<<blocks, 256, 4 * IMGB, st>>>(a); return;
-                case 2: attn_self_head<T, 4, 4, 2><<<blocks, 256, 4 * IMGB, st>>>(a); return;
-                case 3: attn_self_head<T, 4, 4, 3><<<blocks, 256, 4 * IMGB, st>>>(a); return;
-                case 4: attn_self_head<T, 4, 4, 4><<<blocks, 256, 4 * IMGB, st>>>(a); return;
-                case 5: attn_self_head<T, 4, 4, 5><<<blocks, 256, 4 * IMGB, st>>>(a); return;
-                case 6: attn_self_head<T, 4, 4, 6><<<blocks, 256, 4 * IMGB, st>>>(a); return;
-                default: break;
-            }
-#endif
-            static const int ord = [] { const char* e = getenv("GF_K4_ORD"); return e ? atoi(e) : 1; }();      // (ORD 1: 173.7 us against 175.9, 216.7 against 219.0 at 1600 keys)
-            if (ord == 1 && ns == 4) { attn_self_head<T, 4, 4, 0, 1><<<blocks, 256, 4 * IMGB, st>>>(a); return; }
-            if (ns == 4) attn_self_head<T, 4, 4><<<blocks, 256, 4 * IMGB, st>>>(a);
-            else if (ns == 6) attn_self_head<T, 6, 4><<<blocks, 256, 6 * IMGB, st>>>(a);
-            else attn_self_head<T, 8, 4><<<blocks, 256, 8 * IMGB, st>>>(a);
-        }
+        const int blocks = ((a.L + 127) / 128) * (CC / HD) * a.N;
+        attn_self_head<T><<<blocks, 256, 4 * 2 * KT * HD * 2, st>>>(a);     // four (K, V) images of 32 keys x 64 channels
     }
 }
 }   // namespace
@@ -1202,25 +886,6 @@ extern "C" int gf_self_attention_gathered(const void* q, const void* kmap, const
         gf_set_error("gf_self_attention_gathered: workspace too small");
         return GF_ERR_WORKSPACE;
     }
-    static std::atomic<uint64_t> attr{0};
-    if (gf_first_use_on_device(attr)) {                           // the three-image ring of the 16-wave form: 96 KiB
-        (void)hipFuncSetAttribute((const void*)attn_self<_Float16, 1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * KT * CC * 2);
-        (void)hipFuncSetAttribute((const void*)attn_self<gf_bf16, 1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * KT * CC * 2);
-        (void)hipFuncSetAttribute((const void*)attn_self_pipe<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * KT * CC * 2);
-#ifdef K4_ABLATE
-        (void)hipFuncSetAttribute((const void*)attn_self_pipe<_Float16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * KT * CC * 2);
-        (void)hipFuncSetAttribute((const void*)attn_self_pipe<_Float16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * KT * CC * 2);
-        (void)hipFuncSetAttribute((const void*)attn_self_pipe<_Float16, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * KT * CC * 2);
-        (void)hipFuncSetAttribute((const void*)attn_self_pipe<_Float16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * KT * CC * 2);
-        (void)hipFuncSetAttribute((const void*)attn_self_pipe<_Float16, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * KT * CC * 2);
-        (void)hipFuncSetAttribute((const void*)attn_self_pipe<_Float16, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * KT * CC * 2);
-#endif
-        (void)hipFuncSetAttribute((const void*)attn_self_pipe<gf_bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * KT * CC * 2);
-        (void)hipFuncSetAttribute((const void*)attn_self_head<_Float16, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * KT * HD * 2);
-        (void)hipFuncSetAttribute((const void*)attn_self_head<gf_bf16, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * KT * HD * 2);
-        (void)hipFuncSetAttribute((const void*)attn_self_head<_Float16, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * KT * HD * 2);
-        (void)hipFuncSetAttribute((const void*)attn_self_head<gf_bf16, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * KT * HD * 2);
-    }
     AtArgs a;
     a.q = q; a.kmap = kmap; a.vmap = vmap; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
     a.idx = idx; a.idx_stride = idx_stride; a.nkeys = nkeys; a.nkeys_stride = nkeys_stride; a.out = out;
@@ -1230,88 +895,27 @@ extern "C" int gf_self_attention_gathered(const void* q, const void* kmap, const
     a.vc = (char*)workspace + gf_align_up((size_t)N * a.Kpad * CC * es, 256);
     a.softmax_temp = 1.0f / sqrtf((float)D);
     hipStream_t st = (hipStream_t)stream;
-    // query blocks per wave (32 QB queries share a staged K / V tile) once there are enough workgroups to fill the chip;
-    // GF_K4_QB=1|2|4 overrides (measurements)
-    static const int forced = [] { const char* e = getenv("GF_K4_QB"); return e ? atoi(e) : 0; }();
-    static const int forced_wv = [] { const char* e = getenv("GF_K4_WV"); return e ? atoi(e) : 0; }();
-    int qb = forced ? forced : ((long)N * ((L + 63) / 64) >= 512 ? 2 : 1);
-    if (qb != 1 && qb != 2 && qb != 4) qb = 1;
-    int wv = (forced_wv == 8 || forced_wv == 16) && dtype != GF_F32 && qb <= 2 ? forced_wv : 4;
-    // round 5, 16-bit modes: once the chip is full, eight waves = two per head share each staged tile and a wave owns ONE query
-    // block (95 registers: two such workgroups per CU, four waves per SIMD) - 16 images x 1195 keys, same box: 224 us against 237
-    // for two blocks per wave of a four-wave workgroup (288 for one block per wave, 237 for sixteen waves, 257 for eight waves x
-    // two blocks; all with the deferred maximum; tools/k4_ab.py)
-    if (!forced && !forced_wv && dtype != GF_F32 && qb == 2) { wv = 8; qb = 1; }
-    if (wv == 16) qb = 1;
-    // GF_K4_FORM=pipe: the pipelined form (deferred maximum, S of the next tile under this tile's softmax; 128 queries per workgroup)
-    static const bool pipe = [] { const char* e = getenv("GF_K4_FORM"); return e && e[0] == 'p'; }();
-    if (pipe && dtype != GF_F32) { wv = 32; qb = 2; }
-    static const bool msum = [] { const char* e = getenv("GF_K4_MSUM"); return e && e[0] == '1'; }();      // A/B: row sums on the matrix pipe
-    static const bool gather_env = [] { const char* e = getenv("GF_K4_GATHER"); return e && e[0] == '1'; }();   // A/B: the compact-buffer form (gather pass + V^T image)
-    static const bool nopre = [] { const char* e = getenv("GF_K4_PRE"); return e && e[0] == '0'; }();       // A/B: the scale in the exponent's FMA (round 4's arithmetic + deferred reference)
-    static const int abl = [] { const char* e = getenv("GF_K4_ABL"); return e ? atoi(e) : 0; }();
-    (void)abl;
-    // the gather-free form (round 5): the default form's K / V rows straight from the projected maps; needs 16-byte aligned value rows too
-    const bool direct_ok = dtype != GF_F32 && (uintptr_t)vmap % 16 == 0 && ldv % 8 == 0 && (size_t)L * (size_t)(ldk > ldv ? ldk : ldv) * 2 < 0x7FFFFFF0ull;
-    // the head form (round 5, the default): one head and 128 queries per workgroup, K / V rows straight from the maps through structured buffers
-    // (stride field: 14 bits); GF_K4_FORM=rows keeps the previous default (attn_self, eight waves, four heads) for A/B
-    static const bool rows_env = [] { const char* e = getenv("GF_K4_FORM"); return e && e[0] == 'r'; }();
-    static const bool head_env = [] { const char* e = getenv("GF_K4_FORM"); return e && e[0] == 'h'; }();
-    // (every batch size: 2 images x 4800 queries x 1195 keys 30.8 us against 48.0 for the four-head form, 4 images 43.2 against 80.9 - its workgroups are
-    // four times as many and a quarter of the size)
-    const bool use_head = direct_ok && (size_t)(ldk > ldv ? ldk : ldv) * 2 < 16384 && !pipe && !msum && !nopre && !gather_env && !rows_env &&
-                          (head_env || (!forced && !forced_wv));
-    const bool direct = !gather_env && !msum && !nopre && wv == 8 && qb == 1 && dtype != GF_F32 && (uintptr_t)vmap % 16 == 0 && ldv % 8 == 0 &&
-                        (size_t)L * (size_t)(ldk > ldv ? ldk : ldv) * 2 < 0x7FFFFFF0ull;
-    const dim3 ggrid(dtype == GF_F32 ? a.Kpad / KT : (a.Kpad / 8 < 64 ? a.Kpad / 8 : 64), N), agrid((L + 8 * qb * wv - 1) / (8 * qb * wv), N);
-#define GF_K4_WIDE_16(T)                                                                           \
-    do {                                                                                           \
-        if (wv == 32) { GF_K4_PIPE(T); }                                                          \
-        else if (wv == 16) attn_self<T, 1, 16><<<agrid, 1024, 6 * KT * CC * 2, st>>>(a);           \
-        else if (qb == 2) attn_self<T, 2, 8><<<agrid, 512, 4 * KT * CC * 2, st>>>(a);              \
-        else if (msum) attn_self<T, 1, 8, true><<<agrid, 512, 4 * KT * CC * 2, st>>>(a);          \
-        else if (nopre) attn_self<T, 1, 8, false, false><<<agrid, 512, 4 * KT * CC * 2, st>>>(a);  \
-        else if (direct) attn_self<T, 1, 8, false, true, true><<<agrid, 512, 4 * KT * CC * 2, st>>>(a); \
-        else attn_self<T, 1, 8><<<agrid, 512, 4 * KT * CC * 2, st>>>(a);                           \
-    } while (0)
-#ifdef K4_ABLATE                    /* -DK4_ABLATE: the diagnostic instances of attn_self_pipe, picked by GF_K4_ABL=1..6 (fp16) */
-#define GF_K4_PIPE(T)                                                                              \
-    do {                                                                                           \
-        const dim3 pg((L + 127) / 128, N);                                                         \
-        if constexpr (std::is_same<T, _Float16>::value) {                                          \
-            switch (abl) {                                                                         \
-                case 1: attn_self_pipe<_Float16, 1><<<pg, 512, 8 * KT * CC * 2, st>>>(a); break;   \
-                case 2: attn_self_pipe<_Float16, 2><<<pg, 512, 8 * KT * CC * 2, st>>>(a); break;   \
-                case 3: attn_self_pipe<_Float16, 3><<<pg, 512, 8 * KT * CC * 2, st>>>(a); break;   \
-                case 4: attn_self_pipe<_Float16, 4><<<pg, 512, 8 * KT * CC * 2, st>>>(a); break;   \
-                case 5: attn_self_pipe<_Float16, 5><<<pg, 512, 8 * KT * CC * 2, st>>>(a); break;   \
-                case 6: attn_self_pipe<_Float16, 6><<<pg, 512, 8 * KT * CC * 2, st>>>(a); break;   \
-                default: attn_self_pipe<_Float16><<<pg, 512, 8 * KT * CC * 2, st>>>(a);            \
-            }                                                                                      \
-        } else {                                                                                   \
-            attn_self_pipe<T><<<pg, 512, 8 * KT * CC * 2, st>>>(a);                                \
-        }                                                                                          \
-    } while (0)
-#else
-#define GF_K4_PIPE(T) attn_self_pipe<T><<<dim3((L + 127) / 128, N), 512, 8 * KT * CC * 2, st>>>(a)
-#endif
-#define GF_K4_LAUNCH(T, ES, GF_K4_WIDE)                                                                        \
+    // The head form (16-bit modes): one head and 128 queries per workgroup, K / V rows straight from the projected maps through structured
+    // buffers - it needs 16-byte aligned rows whose stride fits the descriptor's 14-bit stride field.  Everything else - the fp32 parity
+    // mode, unaligned or very wide rows - takes the gather pass + the four-wave, four-head form (attn_self; QB query blocks per wave once
+    // there are enough workgroups to fill the chip), which computes the same arithmetic per query (same bits in the 16-bit modes).
+    const bool use_head = dtype != GF_F32 && (uintptr_t)vmap % 16 == 0 && ldv % 8 == 0 && (size_t)(ldk > ldv ? ldk : ldv) * 2 < 16384 &&
+                          (size_t)L * (size_t)(ldk > ldv ? ldk : ldv) * 2 < 0x7FFFFFF0ull;
+    const int qb = (long)N * ((L + 63) / 64) >= 512 ? 2 : 1;
+    const dim3 ggrid(dtype == GF_F32 ? a.Kpad / KT : (a.Kpad / 8 < 64 ? a.Kpad / 8 : 64), N), agrid((L + 32 * qb - 1) / (32 * qb), N);
+#define GF_K4_LAUNCH(T, ES)                                                                        \
     do {                                                                                           \
         const size_t LDSB = (ES == 4 ? 2 : 4) * KT * CC * ES;      /* 16-bit: two (K, V^T) images */       \
         if (use_head) { k4_launch_head<T>(a, st); break; }                                         \
-        if (!direct) attn_gather_kv<T><<<ggrid, 256, 0, st>>>(a);                                  \
-        if (wv >= 8) { GF_K4_WIDE(T); break; }                                                     \
-        if (qb == 4) attn_self<T, 4, 4><<<agrid, 256, LDSB, st>>>(a);                     \
-        else if (qb == 2) attn_self<T, 2, 4><<<agrid, 256, LDSB, st>>>(a);                \
-        else attn_self<T, 1, 4><<<agrid, 256, LDSB, st>>>(a);                             \
+        attn_gather_kv<T><<<ggrid, 256, 0, st>>>(a);                                               \
+        if (qb == 2) attn_self<T, 2><<<agrid, 256, LDSB, st>>>(a);                              \
+        else attn_self<T, 1><<<agrid, 256, LDSB, st>>>(a);                                      \
     } while (0)
     // the key counts live on the device: the caller that knows them (bench.py reads them back) declares the work, 4 L K C flops per sample
     void* pt = gf_prof_begin("k4_self_attention", st, 0.0);
-#define GF_K4_NOWIDE(T) do { } while (0)
-    if (dtype == GF_F32) GF_K4_LAUNCH(float, 4, GF_K4_NOWIDE);
-    else if (dtype == GF_F16) GF_K4_LAUNCH(_Float16, 2, GF_K4_WIDE_16);
-    else GF_K4_LAUNCH(gf_bf16, 2, GF_K4_WIDE_16);
-#undef GF_K4_NOWIDE
+    if (dtype == GF_F32) GF_K4_LAUNCH(float, 4);
+    else if (dtype == GF_F16) GF_K4_LAUNCH(_Float16, 2);
+    else GF_K4_LAUNCH(gf_bf16, 2);
     gf_prof_end("k4_self_attention", pt, st);
 #undef GF_K4_LAUNCH
     GF_CHECK_LAUNCH();

@@ -32,6 +32,18 @@
 #include <type_traits>
 
 #include "gf_common.h"
+#include "k9_args.h"
+
+// round 6: the channel-split wave-pair kernels (k9_encoder_pair.hip) behind the same entry points; GF_K9_PAIR=0 selects this file's
+// four-wave kernels (development A/B only - the two forms consume DIFFERENT weight-stream orders, fused.py follows the same switch)
+void gf_k9_pair_layer(const GfEncArgs& a, int act, bool attn, int dtype, hipStream_t st);
+void gf_k9_pair_state(const GfEncArgs& a, int dtype, hipStream_t st);
+void gf_k9_pair_reduce(const float* part, float* fin, int tiles, int len, int n, hipStream_t st);
+#include <stdlib.h>
+static bool k9_pair() {
+    static const bool on = [] { const char* e = getenv("GF_K9_PAIR"); return e == nullptr || e[0] != '0'; }();
+    return on;
+}
 
 // -DK9_TRACE=1 records s_memtime at the phase boundaries of every workgroup (tools/k9_trace.py reads them); a
 // diagnostic build only: the stamps serialise the wave, so only the SHARES of the phases are meaningful.
@@ -73,31 +85,7 @@ constexpr int VEC_OFF = KS_OFF + C * 4;           // gamma1 | beta1 | gamma2 | b
 constexpr int LDS_BYTES = VEC_OFF + 4 * C * 4;    // 152,576 B
 constexpr int SLAB_RS = 272;                      // epilogue slab row stride (256 B + pad)
 
-struct EncArgs {
-    const void* x;          // [N*L][ldx] tokens
-    long ldx;
-    const void* msg;        // [N*L][ldm] attention output (ATTN = false)
-    long ldm;
-    const float* kvfinal;   // [N][C*D + C] fp32: KV as [c][v] then Ksum[c]   (ATTN = true)
-    const uint8_t* q_mask;  // [N*L] or null: masked query rows -> phi(q) = 0 (linear_attention.py:35-36)
-    const void* wstream;    // packed fragments (see fused.py)
-    const float* ln;        // gamma1 | beta1 | gamma2 | beta2
-    float eps1, eps2, attn_eps;
-    void* out;
-    long ldo;
-    int N, L, S, tiles;     // tiles = ceil(L / 128) per image
-    const int32_t* flag;    // [N*L / flag_rows] or null: 0 -> out = x (GeoTransformer's "layer skipped")
-    int flag_rows;
-    // enc_kv_state
-    const uint8_t* kv_mask; // [N*S] or null
-    float* part;            // [N][tiles][C*D + C]
-    // enc_layer's state tail (round 4): the images n >= tail_first ALSO leave the linear-attention state of their OUTPUT rows for
-    // the layer call that reads them as its source: k / v projection with `wstream_tail` (that consumer's W_k | W_v stream)
-    // straight from the finished tile in LDS, per-tile partials in `part` ([N - tail_first][tiles][C*D + C]); q_mask doubles as
-    // the source mask (the rows are the same tokens).  null = no tail.
-    const void* wstream_tail;
-    int tail_first;
-};
+using EncArgs = GfEncArgs;
 
 // eight fp32 values -> one 16-byte operand; converted in pairs (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32, round to nearest even:
 // element by element the compiler sometimes emits the single conversion + a byte permute)
@@ -1116,9 +1104,14 @@ extern "C" int gf_encoder_kv_state(const void* src, long ld, int dtype, int N, i
     hipStream_t st = (hipStream_t)stream;
     const int len = C * D + C;
     void* pt = gf_prof_begin("enc_kv_state", st, 2.0 * N * (double)S * C * (2.0 * C + 2.0 * D));
-    if (dtype == GF_F16) enc_kv_state<_Float16><<<N * a.tiles, 256, W_OFF + 2 * WBLK + 8192, st>>>(a);
-    else enc_kv_state<gf_bf16><<<N * a.tiles, 256, W_OFF + 2 * WBLK + 8192, st>>>(a);
-    enc_kv_reduce<<<dim3((len + 255) / 256, N), 256, 0, st>>>(a.part, kv_state, a.tiles, len);
+    if (k9_pair()) {
+        gf_k9_pair_state(a, dtype, st);
+        gf_k9_pair_reduce(a.part, kv_state, a.tiles, len, N, st);
+    } else {
+        if (dtype == GF_F16) enc_kv_state<_Float16><<<N * a.tiles, 256, W_OFF + 2 * WBLK + 8192, st>>>(a);
+        else enc_kv_state<gf_bf16><<<N * a.tiles, 256, W_OFF + 2 * WBLK + 8192, st>>>(a);
+        enc_kv_reduce<<<dim3((len + 255) / 256, N), 256, 0, st>>>(a.part, kv_state, a.tiles, len);
+    }
     gf_prof_end("enc_kv_state", pt, st);
     GF_CHECK_LAUNCH();
     return GF_OK;
@@ -1154,10 +1147,15 @@ extern "C" int gf_encoder_layer_kv(const void* x, long ldx, const float* kv_stat
     const double per_tok = 2.0 * C * C + 2.0 * C * (D + 1) + 2.0 * C * C + 8.0 * C * C + 4.0 * C * C;
     const double tail_tok = 2.0 * C * (2.0 * C + 2.0 * D);                // the flops gf_encoder_kv_state declares per source token
     void* pt = gf_prof_begin("enc_layer", st, per_tok * N * (double)L + tail_tok * nt * (double)L);
-    if (dtype == GF_F16) enc_launch<_Float16>(a, activation, true, st);
-    else enc_launch<gf_bf16>(a, activation, true, st);
     const int len = C * D + C;
-    enc_kv_reduce<<<dim3((len + 255) / 256, nt), 256, 0, st>>>(a.part, kv_state_out, a.tiles, len);
+    if (k9_pair()) {
+        gf_k9_pair_layer(a, activation, true, dtype, st);
+        gf_k9_pair_reduce(a.part, kv_state_out, a.tiles, len, nt, st);
+    } else {
+        if (dtype == GF_F16) enc_launch<_Float16>(a, activation, true, st);
+        else enc_launch<gf_bf16>(a, activation, true, st);
+        enc_kv_reduce<<<dim3((len + 255) / 256, nt), 256, 0, st>>>(a.part, kv_state_out, a.tiles, len);
+    }
     gf_prof_end("enc_layer", pt, st);
     GF_CHECK_LAUNCH();
     return GF_OK;
@@ -1187,7 +1185,8 @@ extern "C" int gf_encoder_layer(const void* x, long ldx, const void* msg, long l
     // flops per token: [q 2C^2 + apply 2C(D+1)] + merge 2C^2 + mlp.0 2(2C)(2C) + mlp.2 2(2C)C
     const double per_tok = (attn ? 2.0 * C * C + 2.0 * C * (D + 1) : 0.0) + 2.0 * C * C + 8.0 * C * C + 4.0 * C * C;
     void* pt = gf_prof_begin("enc_layer", st, per_tok * N * (double)L);
-    if (dtype == GF_F16) enc_launch<_Float16>(a, activation, attn, st);
+    if (k9_pair()) gf_k9_pair_layer(a, activation, attn, dtype, st);
+    else if (dtype == GF_F16) enc_launch<_Float16>(a, activation, attn, st);
     else enc_launch<gf_bf16>(a, activation, attn, st);
     gf_prof_end("enc_layer", pt, st);
     GF_CHECK_LAUNCH();

@@ -53,40 +53,72 @@ def _steps(f, tiles, ksteps):
     return torch.cat([f[tiles, ks].reshape(-1) for group in ksteps for ks in group])
 
 
-# must agree with -DK9_HEADPIPE of csrc/k9_encoder_fused.hip (0 = the default build); GF_K9_HEADPIPE=1 with a -DK9_HEADPIPE=1 build: the round-5
-# experiment (head-major q / merge stream; bit-identical results, measured slower)
-HEAD_PIPELINE = os.environ.get('GF_K9_HEADPIPE', '0') == '1'
+# development switch of round 6 (must agree with the library's GF_K9_PAIR): '0' = the four-wave kernels of rounds 2-5 and their stream order
+PAIR = os.environ.get('GF_K9_PAIR', '1') != '0'
+HEAD_PIPELINE = False
+
+
+def _pair_block(f, tiles_w0, tiles_w1, ksteps):
+    """One 16-fragment block of the wave-pair kernels (csrc/k9_encoder_pair.hip): fragments 0..7 for wave half 0, 8..15 for half 1;
+    each half = its tiles x the block's k-steps, k-step-major."""
+    return torch.cat([f[torch.as_tensor(tiles, device=f.device), ks].reshape(-1) for tiles in (tiles_w0, tiles_w1) for ks in ksteps])
 
 
 def pack_layer_stream(wq, wm, w1, w2):
-    """Stream of gf_encoder_layer, in steps of 8 fragments (4 steps = one 32-KiB block):
+    """Stream of gf_encoder_layer: 16-KiB blocks of 16 fragments, 8 per wave half (half w owns the output channels 128 w .. 128 w + 127 of
+    every product = channel tiles 4 w .. 4 w + 3; of a 128-wide hidden slice the two tiles 2 w, 2 w + 1):
+       [W_q: 8 blocks (k-steps 2 b, 2 b + 1 x the half's 4 tiles)] + W_m: 8 blocks (same, permuted order) + the MLP's blocks, per 128-wide
+       hidden slice sl: W_1x(sl) = W_1[:, :256]: 4 blocks (k-steps 4 b .. 4 b + 3 x the half's 2 hidden tiles), W_1m(sl) = W_1[:, 256:]:
+       4 blocks (same, permuted), W_2(sl) = W_2[:, slice]: 4 blocks (k-steps 2 b, 2 b + 1 x the half's 4 output tiles, permuted), in the
+       kernel's software-pipelined order (below).   wq may be None (attention computed elsewhere).  1 MiB with W_q (64 blocks), 896 KiB
+       without (56)."""
+    if not PAIR:
+        return _pack_layer_stream_r5(wq, wm, w1, w2)
+    c = wm.shape[0]
+    lo, hi = [0, 1, 2, 3], [4, 5, 6, 7]
+    parts = []
+    if wq is not None:
+        fq = fragments(wq, 'std')
+        parts += [_pair_block(fq, lo, hi, [2 * b, 2 * b + 1]) for b in range(8)]
+    fm = fragments(wm, 'perm')
+    parts += [_pair_block(fm, lo, hi, [2 * b, 2 * b + 1]) for b in range(8)]
+    f1x, f1m = fragments(w1[:, :c], 'std'), fragments(w1[:, c:], 'perm')   # [16, 16, 64, 8]
+
+    def w1_blocks(f, sl):
+        return [_pair_block(f, [4 * sl, 4 * sl + 1], [4 * sl + 2, 4 * sl + 3], range(4 * b, 4 * b + 4)) for b in range(4)]
+
+    def w2_blocks(sl):
+        f2 = fragments(w2[:, 128 * sl:128 * sl + 128], 'perm')                # [8, 8, 64, 8]
+        return [_pair_block(f2, lo, hi, [2 * b, 2 * b + 1]) for b in range(4)]
+    # the MLP is software-pipelined (the exchange of slice s - 1's hidden operands hides behind W_1x(s)):
+    #   W_1x(0) W_1m(0) | W_1x(s) W_2(s - 1) W_1m(s), s = 1..3 | W_2(3)
+    parts += w1_blocks(f1x, 0) + w1_blocks(f1m, 0)
+    for sl in range(1, 4):
+        parts += w1_blocks(f1x, sl) + w2_blocks(sl - 1) + w1_blocks(f1m, sl)
+    parts += w2_blocks(3)
+    return torch.cat(parts).contiguous()
+
+
+def pack_kv_stream(wk, wv):
+    """Stream of gf_encoder_kv_state (and of the layer's state tail): W_k in 8 blocks (k-steps 2 b, 2 b + 1 x the half's 4 tiles), then W_v."""
+    if not PAIR:
+        return _pack_kv_stream_r5(wk, wv)
+    lo, hi = [0, 1, 2, 3], [4, 5, 6, 7]
+    return torch.cat([_pair_block(fragments(w, 'std'), lo, hi, [2 * b, 2 * b + 1]) for w in (wk, wv) for b in range(8)]).contiguous()
+
+
+def _pack_layer_stream_r5(wq, wm, w1, w2):
+    """rounds 2-5 (four-wave kernels): steps of 8 fragments (4 steps = one 32-KiB block):
        [W_q: 16 steps (k-step ks: tiles 0..7)] + W_m: 16 steps (permuted order) + per 128-wide hidden slice sl
        { W_1[:, :256]: 8 steps (k-steps 2j, 2j+1 x tiles 4sl..4sl+3), W_1[:, 256:]: 8 steps (same, permuted),
-         W_2[:, slice]: 8 steps (k-step u: tiles 0..7, permuted) }.   wq may be None (attention computed elsewhere)."""
+         W_2[:, slice]: 8 steps (k-step u: tiles 0..7, permuted) }."""
     c = wm.shape[0]
     parts = []
     all8 = torch.arange(8, device=wm.device)
     fm = fragments(wm, 'perm')
-    if wq is not None and HEAD_PIPELINE:
-        # round 5: q projection and merge HEAD-MAJOR and interleaved, so that the attention of head h (vector work) runs under the
-        # MFMAs of its neighbours in one instruction stream: Q(h) = 2 steps = the 16 k-steps of channel tile h (one accumulator),
-        # M(h) = the merge's k-steps 2h, 2h + 1 (tiles 0..7) as before; order Q0 Q1 M0 Q2 M1 ... Q7 M6 M7.  Every accumulator still
-        # sums its k-steps in ascending order: the results keep their bits.
-        fq = fragments(wq, 'std')
-
-        def q_head(h):
-            return torch.cat([_steps(fq, torch.tensor([h], device=wm.device), [[8 * hf + j for j in range(8)]]) for hf in range(2)])
-
-        def m_head(h):
-            return _steps(fm, all8, [[2 * h], [2 * h + 1]])
-        parts += [q_head(0), q_head(1)]
-        for h in range(6):
-            parts += [m_head(h), q_head(h + 2)]
-        parts += [m_head(6), m_head(7)]
-    else:
-        if wq is not None:
-            parts.append(_steps(fragments(wq, 'std'), all8, [[ks] for ks in range(16)]))
-        parts.append(_steps(fm, all8, [[ks] for ks in range(16)]))
+    if wq is not None:
+        parts.append(_steps(fragments(wq, 'std'), all8, [[ks] for ks in range(16)]))
+    parts.append(_steps(fm, all8, [[ks] for ks in range(16)]))
     f1x, f1m = fragments(w1[:, :c], 'std'), fragments(w1[:, c:], 'perm')   # [16, 16, 64, 8]
     pairs = [[2 * j, 2 * j + 1] for j in range(8)]
     for sl in range(4):
@@ -97,8 +129,7 @@ def pack_layer_stream(wq, wm, w1, w2):
     return torch.cat(parts).contiguous()
 
 
-def pack_kv_stream(wk, wv):
-    """Stream of gf_encoder_kv_state: W_k in 16 steps (k-step ks: tiles 0..7), then W_v."""
+def _pack_kv_stream_r5(wk, wv):
     all8 = torch.arange(8, device=wk.device)
     return torch.cat([_steps(fragments(w, 'std'), all8, [[ks] for ks in range(16)]) for w in (wk, wv)]).contiguous()
 

@@ -310,13 +310,22 @@ def inlier_index(kp0, kp1, keep, counts, N, L, S, w0, w1, scale=8):
 
 
 def self_attention_gathered(q, kmap, vmap, idx, nkeys, nhead=4):
-    """K4.  q, kmap, vmap [N,L,256] (row-strided views ok); idx int32 [N,>=L]; nkeys int32 view with one
-    entry per sample (any stride) -> [N,L,256]."""
+    """K4.  q, kmap, vmap [N,L,256]; idx int32 [N,>=L]; nkeys int32 view with one entry per sample (any stride) -> [N,L,256].
+    Row-strided views are taken as they are when the library can move their rows as 16-byte pieces (16-bit modes: a 16-byte aligned
+    base and a row stride that is a multiple of 8 elements - e.g. the halves of a [N, L, 512] k|v projection); any other view is
+    copied to a contiguous tensor first."""
     _need_cuda(q, kmap, vmap, idx, nkeys)
     N, L, C = q.shape
-    q, ldq = _rows(q)
-    kmap, ldk = _rows(kmap)
-    vmap, ldv = _rows(vmap)
+
+    def rows16(t):
+        t, ld = _rows(t)
+        if t.element_size() == 2 and (t.data_ptr() % 16 != 0 or ld % 8 != 0):
+            t = t.contiguous()
+            ld = t.shape[-1]
+        return t, ld
+    q, ldq = rows16(q)
+    kmap, ldk = rows16(kmap)
+    vmap, ldv = rows16(vmap)
     for t, ld in ((q, ldq), (kmap, ldk), (vmap, ldv)):
         if t.stride(0) != ld * L:
             raise ValueError('self_attention_gathered needs batch stride == L * row stride')

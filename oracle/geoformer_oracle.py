@@ -199,8 +199,9 @@ def linear_attention_fused(q, k, v, st, q_mask=None, kv_mask=None, eps: float = 
     return rt(num * (1.0 / den)[..., None], st)
 
 
-def _finish_fused(P, prefix, x, msg, kind, st):
-    """x, msg [N,L,C] (rounded) -> x + LN2(W_2 act(W_1 [x | LN1(W_m msg)]))."""
+def _finish_fused(P, prefix, x, msg, kind, st, round_out=True):
+    """x, msg [N,L,C] (rounded) -> x + LN2(W_2 act(W_1 [x | LN1(W_m msg)])).  round_out=False keeps the fp32 sum (the rounding
+    ablation of tools/rounding_ablation.py: what the features cost the dual-softmax by being STORED in 16 bits)."""
     c = x.shape[-1]
     W = lambda name: rt(P[prefix + name], st)                                    # noqa: E731
     m = F.linear(msg, W('merge.weight'))
@@ -208,10 +209,10 @@ def _finish_fused(P, prefix, x, msg, kind, st):
     hid = F.linear(torch.cat([x, m], dim=2), W('mlp.0.weight'))
     hid = rt(torch.relu(hid) if kind == 'loftr' else torch.tanh(hid), st)
     o = F.layer_norm(F.linear(hid, W('mlp.2.weight')), (c,), P[prefix + 'norm2.weight'], P[prefix + 'norm2.bias'])
-    return rt(x + o, st)
+    return rt(x + o, st) if round_out else x + o
 
 
-def encoder_layer_fused(P, prefix, x, source, nhead, st, x_mask=None, source_mask=None):
+def encoder_layer_fused(P, prefix, x, source, nhead, st, x_mask=None, source_mask=None, round_out=True):
     """LoFTR (linear attention, ReLU) layer in the 'fused' storage mode; x, source already rounded."""
     n, _, c = x.shape
     d = c // nhead
@@ -220,7 +221,7 @@ def encoder_layer_fused(P, prefix, x, source, nhead, st, x_mask=None, source_mas
     k = F.linear(source, W('k_proj.weight')).view(n, -1, nhead, d)
     v = F.linear(source, W('v_proj.weight')).view(n, -1, nhead, d)
     msg = linear_attention_fused(q, k, v, st, x_mask, source_mask).reshape(n, -1, c)
-    return _finish_fused(P, prefix, x, msg, 'loftr', st)
+    return _finish_fused(P, prefix, x, msg, 'loftr', st, round_out)
 
 
 def linear_attention_window(q, k, v, st, q_mask=None, kv_mask=None, eps: float = 1e-6):
@@ -678,7 +679,7 @@ def _flash_self_attention(q, k, v, st, tile: int = 32):
     return rt(o / l[..., None], st)
 
 
-def _geo_layer_storage(P, prefix, x, source, nhead, st, kv_mask=None, flash=False):
+def _geo_layer_storage(P, prefix, x, source, nhead, st, kv_mask=None, flash=False, round_out=True):
     """Geo encoder layer: x [n,L,C], source [n,S,C] (rounded)."""
     n, _, c = x.shape
     d = c // nhead
@@ -690,11 +691,12 @@ def _geo_layer_storage(P, prefix, x, source, nhead, st, kv_mask=None, flash=Fals
         msg = torch.stack([_flash_self_attention(q[i], k[i], v[i], st) for i in range(n)])
     else:
         msg = rt(full_attention(q, k, v, None, kv_mask), st)
-    return _finish_fused(P, prefix, x, msg.reshape(n, -1, c), 'geo', st)
+    return _finish_fused(P, prefix, x, msg.reshape(n, -1, c), 'geo', st, round_out)
 
 
-def geo_module_storage(P, f0, f1, hw0, hw1, data, geo_cfg, homography_fn: Callable, st):
-    """geo_module above with f0/f1 = the rounded position-encoded maps [N,L,C] / [N,S,C]."""
+def geo_module_storage(P, f0, f1, hw0, hw1, data, geo_cfg, homography_fn: Callable, st, round_last=True):
+    """geo_module above with f0/f1 = the rounded position-encoded maps [N,L,C] / [N,S,C].  round_last=False: the LAST layer's outputs stay
+    fp32 (tools/rounding_ablation.py)."""
     n, _, c = f0.shape
     (hh0, ww0), (hh1, ww1) = hw0, hw1
     H0, W0 = data['image0'].shape[2:]
@@ -733,20 +735,21 @@ def geo_module_storage(P, f0, f1, hw0, hw1, data, geo_cfg, homography_fn: Callab
     f0, f1 = f0.clone(), f1.clone()
     for idx, name in enumerate(geo_cfg['layer_names']):
         lp = f'geo_module.des_transformer.layers.{idx}.'
+        ro = round_last or idx != len(geo_cfg['layer_names']) - 1
         if name == 'self':
             for b in range(n):
                 if map0[b].any():
-                    f0[b] = _geo_layer_storage(P, lp, f0[b][None], f0[b][map0[b]][None], nhead, st, flash=True)[0]
+                    f0[b] = _geo_layer_storage(P, lp, f0[b][None], f0[b][map0[b]][None], nhead, st, flash=True, round_out=ro)[0]
                 if map1[b].any():
-                    f1[b] = _geo_layer_storage(P, lp, f1[b][None], f1[b][map1[b]][None], nhead, st, flash=True)[0]
+                    f1[b] = _geo_layer_storage(P, lp, f1[b][None], f1[b][map1[b]][None], nhead, st, flash=True, round_out=ro)[0]
         else:
             g0 = [None if win0[b] is None else sample_windows(win0[b], f0[b].T.reshape(c, hh0, ww0), scale) for b in range(n)]
             g1 = [None if win1[b] is None else sample_windows(win1[b], f1[b].T.reshape(c, hh1, ww1), scale) for b in range(n)]
             for b in range(n):
                 if g1[b] is None:
                     continue
-                f0[b] = _geo_layer_storage(P, lp, f0[b][:, None], g1[b], nhead, st, kv_mask=msk1[b])[:, 0]
-                f1[b] = _geo_layer_storage(P, lp, f1[b][:, None], g0[b], nhead, st, kv_mask=msk0[b])[:, 0]
+                f0[b] = _geo_layer_storage(P, lp, f0[b][:, None], g1[b], nhead, st, kv_mask=msk1[b], round_out=ro)[:, 0]
+                f1[b] = _geo_layer_storage(P, lp, f1[b][:, None], g0[b], nhead, st, kv_mask=msk0[b], round_out=ro)[:, 0]
     return f0, f1
 
 
