@@ -67,7 +67,7 @@ def _pair_block(f, tiles_w0, tiles_w1, ksteps):
 def pack_layer_stream(wq, wm, w1, w2):
     """Stream of gf_encoder_layer: 16-KiB blocks of 16 fragments, 8 per wave half (half w owns the output channels 128 w .. 128 w + 127 of
     every product = channel tiles 4 w .. 4 w + 3; of a 128-wide hidden slice the two tiles 2 w, 2 w + 1):
-       [W_q: 8 blocks (k-steps 2 b, 2 b + 1 x the half's 4 tiles)] + W_m: 8 blocks (same, permuted order) + the MLP's blocks, per 128-wide
+       [W_q: 8 blocks, head-major (block b: k-steps 8 (b & 1) .. + 7 of the half's head b >> 1)] + W_m: 8 blocks (same, permuted order) + the MLP's blocks, per 128-wide
        hidden slice sl: W_1x(sl) = W_1[:, :256]: 4 blocks (k-steps 4 b .. 4 b + 3 x the half's 2 hidden tiles), W_1m(sl) = W_1[:, 256:]:
        4 blocks (same, permuted), W_2(sl) = W_2[:, slice]: 4 blocks (k-steps 2 b, 2 b + 1 x the half's 4 output tiles, permuted), in the
        kernel's software-pipelined order (below).   wq may be None (attention computed elsewhere).  1 MiB with W_q (64 blocks), 896 KiB
@@ -78,8 +78,10 @@ def pack_layer_stream(wq, wm, w1, w2):
     lo, hi = [0, 1, 2, 3], [4, 5, 6, 7]
     parts = []
     if wq is not None:
+        # HEAD-MAJOR: block b = k-steps 8 (b & 1) .. + 7 of the half's head b >> 1 (one accumulator tile per head: its attention then rides in
+        # the next head's blocks)
         fq = fragments(wq, 'std')
-        parts += [_pair_block(fq, lo, hi, [2 * b, 2 * b + 1]) for b in range(8)]
+        parts += [torch.cat([fq[4 * wh + (b >> 1), 8 * (b & 1):8 * (b & 1) + 8].reshape(-1) for wh in range(2)]) for b in range(8)]
     fm = fragments(wm, 'perm')
     parts += [_pair_block(fm, lo, hi, [2 * b, 2 * b + 1]) for b in range(8)]
     f1x, f1m = fragments(w1[:, :c], 'std'), fragments(w1[:, c:], 'perm')   # [16, 16, 64, 8]
