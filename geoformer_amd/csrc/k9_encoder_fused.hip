@@ -1,32 +1,31 @@
-// K9: the encoder layer as TWO launches that touch HBM three times per token (read source, read x, write out) -
-// the algorithmic minimum of SURVEY 8d - instead of the eight launches / ~19 token-row transfers of the
-// K3 + K2 chain.  16-bit storage modes only (fp16 / bf16 operands, fp32 accumulation and statistics); the fp32 parity
-// mode keeps the unfused kernels.
+// K9: the encoder layer as ONE launch (plus a state pass for the sources no earlier launch produced) that touches HBM three times per token
+// (read source state, read x, write out) - the algorithmic minimum of SURVEY 8d - instead of the eight launches / ~19 token-row transfers of
+// the K3 + K2 chain.  16-bit storage modes only (fp16 / bf16 operands, fp32 accumulation and statistics); the fp32 parity mode keeps the
+// unfused kernels.  Round 6: rebuilt on CHANNEL-SPLIT WAVE PAIRS - eight waves (two per SIMD, <= 256 registers each) per 128-token
+// workgroup instead of four waves with the whole 512-register file (rounds 2-5; git history).
 //
-// Replaces LoFTREncoderLayer.forward (model/loftr_src/loftr/loftr_module/transformer.py:37-60, ReLU, linear
-// attention of linear_attention.py:21-51) and the part of its Geo twin after the attention
-// (model/geo_transformer/transformer.py:56-66, Tanh):
+// Replaces LoFTREncoderLayer.forward (model/loftr_src/loftr/loftr_module/transformer.py:37-60, ReLU, linear attention of
+// linear_attention.py:21-51) and the part of its Geo twin after the attention (model/geo_transformer/transformer.py:56-66, Tanh):
 //
-//   enc_kv_state   k, v = W_k src, W_v src ; KV[n,h] = sum_s phi(k_s)^T v_s ; Ksum[n,h] = sum_s phi(k_s)
-//                  per 128-token tile -> one fp32 partial state per tile ; enc_kv_reduce sums the tiles of an image.
-//                  k and v never exist in HBM.
-//   enc_layer      q = W_q x ; msg = phi(q) KV / (phi(q).Ksum + eps)            (ATTN: linear attention)
-//                  or msg = attention output read from HBM                        (Geo layers: K4 / K5 made it)
-//                  m = LN1(W_m msg) ; hid = act(W_1 [x | m]) ; out = x + LN2(W_2 hid)
+//   enc_pair_state  k, v = W_k src, W_v src ; KV[n,h] = sum_s phi(k_s)^T v_s ; Ksum[n,h] = sum_s phi(k_s)   (one partial per tile)
+//   enc_pair        q = W_q x ; msg = phi(q) KV / (phi(q).Ksum + eps)            (ATTN: linear attention)
+//                   or msg = attention output read from HBM                        (Geo layers: K4 / K5 made it)
+//                   m = LN1(W_m msg) ; hid = act(W_1 [x | m]) ; out = x + LN2(W_2 hid)   [+ the state of `out` for its consumer]
 //
-// One workgroup = 4 waves = 128 tokens, one wave per SIMD with the whole 512-register file; a wave owns 32 tokens
-// for the entire chain.  Products are computed transposed (MFMA A = 32 weight rows, B = 32 tokens), so a result
-// tile has the token on the lane and 32 channels in 16 registers per lane half - and that IS the B operand of
-// the next product (contraction over channels = over the tile's row index): 8 registers are packed to 16 bits
-// per 16-deep k-step and the next weight's A fragment is stored with the matching k order
-// (c = 32t + 16s + 8(j>>2) + 4h + (j&3) for element j of lane half h).  Activations therefore never pass through
-// LDS between the five GEMMs; LayerNorm, phi, the activation and the residual are lane-local.
+// Why pairs.  Rounds 2-5 ran one wave per SIMD: a wave owned 32 tokens x all 256 channels, so every LayerNorm / phi / packing phase
+// (~3300 vector instructions per tile) ran with the matrix pipe idle and every LDS-DMA piece or fragment read stretched an MFMA gap
+// (0.27 of the MFMA peak for three rounds).  Here a 32-token group belongs to TWO waves, wave half w = 0 / 1 owning the OUTPUT channels
+// [128 w, 128 w + 128) of every product: 64 accumulator registers per product instead of 128, no accumulator in AGPRs (no
+// v_accvgpr moves), and a SIMD always has a second wave whose MFMAs cover the first one's reads, requests and waits.
+// The contraction of the next product runs over ALL 256 channels, so the two waves of a pair exchange their packed 16-bit operands
+// through a 32-KiB LDS region between the products (msg, LN1 output, hidden slices: 4 KiB per wave and round); LayerNorm exchanges
+// two partial sums per token.  Every accumulator still adds its k-steps in ascending order.
 //
-// Weights are pre-packed on the host (geoformer_amd/fused.py) into the exact sequence of 1-KiB MFMA A fragments
-// the kernel consumes (`wstream`), 32 fragments = one 32-KiB block; every workgroup streams the same 1 MiB per
-// layer from L2 into a two-block LDS ring with LDS-DMA (global_load_lds_dwordx4: the fragment order makes the
-// LDS image lane-linear, so fragment reads are conflict-free ds_read_b128), one barrier per block of 32 MFMAs
-// per wave.  The token tile x stays in LDS for the whole kernel (B operand of the q and mlp.0 products, residual).
+// Weights: the host packs them (geoformer_amd/fused.py:pack_layer_stream) as a stream of 1-KiB MFMA A fragments in 16-KiB BLOCKS:
+// fragments 0..7 of a block belong to wave half 0, 8..15 to half 1, each half in the order its waves multiply them.  Every workgroup
+// streams the 1 MiB from L2 through a THREE-slot LDS ring by LDS-DMA (two 1-KiB pieces per wave and block, issued two blocks = ~1000
+// cycles ahead), one workgroup barrier per block of 8 MFMAs per wave.  The token tile x stays in LDS for the whole kernel (B operand
+// of the q and mlp.0 products, residual); the finished rows replace it in place and leave for HBM from there.
 #include <math.h>
 
 #include <type_traits>
@@ -34,61 +33,42 @@
 #include "gf_common.h"
 #include "k9_args.h"
 
-// round 6: the channel-split wave-pair kernels (k9_encoder_pair.hip) behind the same entry points; GF_K9_PAIR=0 selects this file's
-// four-wave kernels (development A/B only - the two forms consume DIFFERENT weight-stream orders, fused.py follows the same switch)
-void gf_k9_pair_layer(const GfEncArgs& a, int act, bool attn, int dtype, hipStream_t st);
-void gf_k9_pair_state(const GfEncArgs& a, int dtype, hipStream_t st);
-void gf_k9_pair_reduce(const float* part, float* fin, int tiles, int len, int n, hipStream_t st);
-#include <stdlib.h>
-static bool k9_pair() {
-    static const bool on = [] { const char* e = getenv("GF_K9_PAIR"); return e == nullptr || e[0] != '0'; }();
-    return on;
-}
-
-// -DK9_TRACE=1 records s_memtime at the phase boundaries of every workgroup (tools/k9_trace.py reads them); a
-// diagnostic build only: the stamps serialise the wave, so only the SHARES of the phases are meaningful.
-#ifndef K9_TRACE
-#define K9_TRACE 0
+// -DK9P_TRACE=1 records s_memtime at the phase boundaries of every wave of the first 1024 workgroups (tools/k9p_trace.py); a diagnostic
+// build only.  -DK9P_ABLATE=n (wrong results by construction, timing only): 1 = no ring requests behind the prologue's, 2 = no barrier
+// in the ring's turn, 3 = no fragment reads, 4 = no MFMAs.
+#ifndef K9P_TRACE
+#define K9P_TRACE 0
 #endif
-// Round-5 experiments, both bit-identical to the default and both SLOWER (same box, tools/k9_digest.py, 16 images: layer alone 145.8-148.5 us,
-// with the state tail 202.6-207.4 us):
-//   -DK9_HEADPIPE=1 (+ GF_K9_HEADPIPE=1 at pack time: the weight stream head-major, fused.py) - q projection, attention and merge as one
-//       head-pipelined stream (attention of head h inside the q-projection steps of head h + 1): 158.1 / 215.2 us;
-//   -DK9_MERGEPIPE=1 - the attention of head h + 1 inside the two merge steps of head h (the stream's order unchanged): 156.0 / 214.9 us.
-// The vector work placed inside the ring steps stretches their MFMA gaps by more than the phase it removes.
-#ifndef K9_HEADPIPE
-#define K9_HEADPIPE 0
+#ifndef K9P_ABLATE
+#define K9P_ABLATE 0
 #endif
-#ifndef K9_MERGEPIPE
-#define K9_MERGEPIPE 0
-#endif
-#if K9_TRACE
-__device__ long long k9_trace[4096 * 4 * 16];
-#define K9_T(slot) do { if ((slot) < 16 && lane == 0 && blockIdx.x < 4096) k9_trace[(blockIdx.x * 4 + wave) * 16 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-extern "C" int gf_debug_k9_trace(long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(k9_trace), sizeof(long long) * 4096 * 4 * 16);
+#if K9P_TRACE
+__device__ long long k9p_trace[1024 * 8 * 24];
+#define K9P_T(slot) do { if (lane == 0 && blockIdx.x < 1024) k9p_trace[(blockIdx.x * 8 + wave) * 24 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int gf_debug_k9p_trace(long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(k9p_trace), sizeof(long long) * 1024 * 8 * 24);
 }
 #else
-#define K9_T(slot)
+#define K9P_T(slot)
 #endif
 
 namespace {
 
-constexpr int C = 256, D = 32, NH = 8;            // coarse level: d_model 256, 8 heads of 32
-constexpr int TM = 128;                           // tokens per workgroup
-constexpr int WBLK = 32768, FRAG = 1024;          // one weight block = 32 fragments of 64 lanes x 16 B
-constexpr int X_OFF = 0;                          // [4 k-chunks][128 rows][128 B], chunk-swizzled (gf_lds_off)
-constexpr int W_OFF = 65536;                      // two weight blocks
-constexpr int KV_OFF = W_OFF + 2 * WBLK;          // [8 heads][2 k-steps][64 lanes][16 B]: KV/S as 16-bit A fragments
-constexpr int KS_OFF = KV_OFF + NH * 2 * FRAG;    // [256] float: Ksum/S rounded to the storage type
-constexpr int VEC_OFF = KS_OFF + C * 4;           // gamma1 | beta1 | gamma2 | beta2, [4][256] float
-constexpr int LDS_BYTES = VEC_OFF + 4 * C * 4;    // 152,576 B
-constexpr int SLAB_RS = 272;                      // epilogue slab row stride (256 B + pad)
+constexpr int C = 256, D = 32, NH = 8;
+constexpr int TM = 128;                            // tokens per workgroup
+constexpr int FRAG = 1024, BLK = 16 * FRAG;        // a weight block = 16 fragments of 64 lanes x 16 B (8 per wave half)
+constexpr int X_OFF = 0;                           // [4 k-chunks][128 rows][128 B], chunk-swizzled (gf_lds_off)
+constexpr int W_OFF = 65536;                       // three weight blocks
+constexpr int E_OFF = W_OFF + 3 * BLK;             // exchange region: 4 pairs x 8 fragment slots (slots 0-3 wave half 0, 4-7 half 1)
+constexpr int VEC_OFF = E_OFF + 32768;             // gamma1 | beta1 | gamma2 | beta2, [4][256] float
+constexpr int KS_OFF = VEC_OFF + 4 * C * 4;        // [256] T: Ksum/S rounded to the storage type, in operand order
+constexpr int ST_OFF = KS_OFF + 512;               // [8 waves][64 lanes] float2: LayerNorm partial sums
+constexpr int LDS_BYTES = ST_OFF + 8 * 64 * 8;     // 156,160 B
+constexpr int NB_Q = 8, NB_M = 8, NB_SLICE = 12, NB_KV = 16;   // blocks per phase (all even, NB_SLICE % 3 == 0)
 
 using EncArgs = GfEncArgs;
 
-// eight fp32 values -> one 16-byte operand; converted in pairs (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32, round to nearest even:
-// element by element the compiler sometimes emits the single conversion + a byte permute)
+// eight fp32 values -> one 16-byte operand; converted in pairs (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32, round to nearest even)
 template <typename T>
 __device__ __forceinline__ typename Mma32<T>::Frag pack8(float a0, float a1, float a2, float a3, float a4, float a5, float a6,
                                                           float a7) {
@@ -111,30 +91,25 @@ __device__ __forceinline__ F relu_packed(const F& f) {
     const v8s x = __builtin_bit_cast(v8s, f);
     return __builtin_bit_cast(F, x & ~(x >> 15));
 }
-// elu(x) + 1 (linear_attention.py:33-34) = max(x, 0) + exp(min(x, 0)): x + 1 for x > 0 (exp(0) = 1 exactly), exp(x)
-// otherwise - branch-free (a conditional exponential compiles to a divergent branch per element), hardware exponential
-// (round 5: exp(min(x, 0)) = the exponential CLAMPED to [0, 1] - `v_exp_f32 ... clamp`, the output modifier is free - instead of a
-// v_min in front of it: the same bits (for x <= 0 the clamp does nothing, for x > 0 both give exactly 1), one instruction less per value)
+// elu(x) + 1 (linear_attention.py:33-34) = max(x, 0) + exp(min(x, 0)): branch-free, hardware exponential with the minimum as its
+// CLAMP output modifier (for x <= 0 the clamp does nothing, for x > 0 both give exactly 1)
 __device__ __forceinline__ float phi(float x) {
     return fmaxf(x, 0.f) + __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(x * 1.44269504088896341f), 0.f, 1.f);
 }
 __device__ __forceinline__ v16f zero16() { return v16f{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; }
-// the lane id recomputed where a late phase needs it (two VALU instructions; volatile: neither hoisted nor merged): carried in a
-// register from the kernel's top it is the 511th live value of enc_layer and gets spilled - and a scratch reload waits for the
-// LDS-DMA in flight
+// the lane id recomputed where a late phase needs it (two VALU instructions; volatile: neither hoisted nor merged)
 __device__ __forceinline__ int fresh_lane() {
     int l;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
     return l;
 }
-// x[lane] + x[lane ^ 32] in every lane: one v_permlane32_swap (VALU, no address register, no LDS counter) instead of a ds_bpermute -
-// the permute's byte-address register stayed live from the first LayerNorm to the state tail and was the value that got spilled
+// x[lane] + x[lane ^ 32] in every lane: one v_permlane32_swap
 __device__ __forceinline__ float half_sum(float x) {
     const gf_v2u sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     return __uint_as_float(sw.x) + __uint_as_float(sw.y);
 }
-// sum_j a_j b_j over the 8 sixteen-bit elements of two packed operands, fp32 accumulation (v_dot2c_f32_f16 / _bf16: the products of
-// two 16-bit values are exact in fp32)
+// sum_j a_j b_j over the 8 sixteen-bit elements of two packed operands, fp32 accumulation (the products of two 16-bit values are
+// exact in fp32)
 __device__ __forceinline__ float dot8(const v8h& a, const v8h& b, float c) {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -147,798 +122,673 @@ __device__ __forceinline__ float dot8(const v8b& a, const v8b& b, float c) {
     for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_fdot2_f32_bf16(b2{a[2 * i], a[2 * i + 1]}, b2{b[2 * i], b[2 * i + 1]}, c, false);
     return c;
 }
-template <typename T>
-__device__ __forceinline__ float rnd(float x) { return gf_to_float(gf_from_float<T>(x)); }   // round to the storage type
 
-// The weight stream: 32-KiB blocks (32 fragments = 4 STEPS of 8 fragments = 8 MFMAs per wave) through a two-slot LDS ring.
-// Wave w moves fragments 8w .. 8w+7 of a block ("pieces" 0..7 of the wave) by LDS-DMA.  Requests behind the stream's end are
-// out of the buffer's range: they fetch nothing and leave zeros in the slot that has just been freed, which nobody reads
-// (tools/probes/lds_dma_oob.hip) - no conditional code inside the step bodies: one basic block per unrolled phase, so the
-// issue order below survives.
-struct Ring {
-    __amdgpu_buffer_rsrc_t rs;   // the stream as a raw buffer of exactly nblk blocks: a request behind its end is out of range (zeros)
-    __amdgpu_buffer_rsrc_t rs2;  // blocks nblk .. nblk + nblk2 - 1 come from a second stream (the state tail's W_k | W_v)
-    char* smem;
-    int wave, lane, blk, nblk;
-};
-__device__ __forceinline__ Ring ring_make(const void* wstream, char* smem, int wave, int lane, int nblk, const void* wstream2 = nullptr,
-                                          int nblk2 = 0) {
-    return Ring{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wstream), 0, nblk * WBLK, 0x00020000),
-                __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wstream2 ? wstream2 : wstream), 0, wstream2 ? nblk2 * WBLK : 0, 0x00020000),
-                smem, wave, lane, 0, nblk};
-}
-// LDS-DMA as buffer_load_dwordx4 ... lds (MUBUF), not global_load_lds: behind a FLAT-encoded LDS-DMA the compiler's wait
-// insertion treats every LDS counter wait as lgkmcnt(0) for as long as the request is pending (it may touch both address
-// spaces), i.e. for the whole kernel here; behind the MUBUF form it counts (lgkmcnt(7) in front of every MFMA below).  The
-// descriptor and the block offset are scalar: no 64-bit address arithmetic per piece.
-__device__ __forceinline__ void dma_piece(const Ring& g, int b, int i) {
-#if !defined(K9_ABLATE) || K9_ABLATE != 1
-    // b is wave-uniform: the descriptor select is scalar
-    const bool second = b >= g.nblk;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? g.rs2 : g.rs, (__attribute__((address_space(3))) void*)(g.smem + W_OFF + (b & 1) * WBLK + (g.wave * 8 + i) * FRAG), 16,
-                                             g.lane * 16 + g.wave * 8 * FRAG, (second ? b - g.nblk : b) * WBLK + i * FRAG, 0, 0);
+template <typename T>
+struct PMma {                     // the ring products' MFMA (ablation 4: compiled out, operands kept alive)
+    static __device__ __forceinline__ void mma(const typename Mma32<T>::Frag& a, const typename Mma32<T>::Frag& b, v16f& c) {
+#if K9P_ABLATE == 4
+        asm volatile("" : "+v"(c) : "v"(a), "v"(b));
+#else
+        Mma32<T>::mma(a, b, c);
 #endif
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The weight ring.  Block b lives in slot b % 3.  While block b is multiplied, block b + 1 has landed (it is read into registers
+// behind the MFMAs of block b) and block b + 2 is in flight; the turn inside block b (a workgroup barrier after every wave has
+// ALL of block b's fragments in registers) frees slot b % 3 for block b + 3.  Wave v moves fragments 2v, 2v + 1 of every block.
+// Requests behind the stream's end are out of the buffer's range: they fetch nothing and leave zeros in a slot nobody reads.
+// LDS-DMA in the MUBUF form (buffer_load_dwordx4 ... lds): the compiler counts LDS waits behind it (behind the FLAT form every
+// wait becomes lgkmcnt(0)); descriptor and block offset are scalar.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct Ring {
+    __amdgpu_buffer_rsrc_t rs;    // the stream as a raw buffer of exactly nblk blocks
+    __amdgpu_buffer_rsrc_t rs2;   // blocks nblk .. come from a second stream (the state tail's W_k | W_v)
+    char* smem;
+    int voff;                     // lane * 16 + wave * 2 KiB: this lane's bytes inside a block
+    int wave;
+    int rbase;                    // W_OFF + (wave & 1) * 8 KiB + lane * 16: this lane's fragment reads inside a slot
+    int blk, nblk;
+};
+__device__ __forceinline__ Ring ring_make(const void* wstream, char* smem, int wave, int lane, int nblk, const void* wstream2, int nblk2) {
+    return Ring{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wstream), 0, nblk * BLK, 0x00020000),
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wstream2 ? wstream2 : wstream), 0, wstream2 ? nblk2 * BLK : 0, 0x00020000),
+                smem, lane * 16 + wave * 2 * FRAG, wave, W_OFF + (wave & 1) * 8 * FRAG + lane * 16, 0, nblk};
 }
-// the next block has landed (every wave waits for its own pieces) and every wave is done reading the current one
-__device__ __forceinline__ void ring_turn() {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#if !defined(K9_ABLATE) || K9_ABLATE != 2
+// piece i (0, 1) of this wave of block b into slot `slot`
+__device__ __forceinline__ void dma_piece(const Ring& g, int slot, int b, int i) {
+#if K9P_ABLATE == 1
+    if (b >= 3) return;
+#endif
+    const bool second = b >= g.nblk;                  // wave-uniform: the descriptor select is scalar
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? g.rs2 : g.rs,
+                                             (__attribute__((address_space(3))) void*)(g.smem + W_OFF + slot * BLK + (g.wave * 2 + i) * FRAG), 16,
+                                             g.voff, (second ? b - g.nblk : b) * BLK + i * FRAG, 0, 0);
+}
+// all but the VM youngest vector-memory operations of this wave are done (its pieces of the next block have landed), every LDS
+// read it issued has returned; then the workgroup's barrier
+template <int VM>
+__device__ __forceinline__ void turn() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(VM) : "memory");
+#if K9P_ABLATE != 2
     __builtin_amdgcn_s_barrier();
 #endif
 }
+// exchange barrier: my LDS writes / reads are done, then everybody's
+__device__ __forceinline__ void xbar() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
 template <typename Frag>
-__device__ __forceinline__ Frag ring_read(const char* p) {
-#if defined(K9_ABLATE) && K9_ABLATE == 3
+__device__ __forceinline__ Frag lds_frag(const char* p) { return *reinterpret_cast<const Frag*>(p); }
+template <typename Frag>
+__device__ __forceinline__ Frag ring_frag(const char* p) {
+#if K9P_ABLATE == 3
     Frag f; asm volatile("" : "=v"(f)); return f;
 #else
     return *reinterpret_cast<const Frag*>(p);
 #endif
 }
-// One STEP = the 8 MFMAs `mma(0..7)` on the fragments the previous step fetched, and the fetch of the next step's 8
-// fragments into `nxt`: ONE ds_read_b128 behind each MFMA, waited for by the counted lgkmcnt the compiler derives (a fragment
-// is used 8 reads = 8 MFMAs = 256 cycles after its request).  [Before: two reads per gap in the first half of a step and
-// lgkmcnt(0) at its top - the four waves of a workgroup run in lock-step behind the ring barrier, so their read bursts met
-// at the LDS (2 x 4 waves x 1 KiB per 32-cycle gap = its whole 256 B/clk) and the stalled read issue held back the MFMAs:
-// with the fragment reads compiled out the layer took 120 us instead of 166.]
-// Step 3 of a block turns the ring after its first two MFMAs: block b+1 has landed, every wave holds block b's last fragments
-// in registers; pieces 0..3 of block b+2 are requested behind MFMAs 2..5 of this step, pieces 4..7 behind MFMAs 0..3 of the
-// next (a burst of 8 requests held the MFMA pipe idle for ~270 cycles per block).  xread() issues the step's EXTRA operand
-// reads (token-tile fragments of the next step).
-// the fragment MFMA j has just consumed stays allocated until the next read is out: the read lands in the register of the
-// MFMA BEFORE it (issued a gap earlier, operands long read) instead of overwriting the operand of an MFMA still in the queue
-#if defined(K9_NOKEEP)
-#define K9_KEEP(f)
-#else
-#define K9_KEEP(f) asm volatile("" ::"v"(f))
-#endif
-template <int EXTRA, typename Frag, typename MF, typename XF>
-__device__ __forceinline__ void ring_step(Ring& g, Frag (&cur)[8], Frag (&nxt)[8], int st, MF mma, XF xread) {
-    if (st != 3) {
-        const char* p = g.smem + W_OFF + (g.blk & 1) * WBLK + (st + 1) * 8 * FRAG + g.lane * 16;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            mma(j);
-            if (st == 0 && j < 4) dma_piece(g, g.blk + 1, 4 + j);
-            nxt[j] = ring_read<Frag>(p + j * FRAG);
-            K9_KEEP(cur[j]);
-            if (j == 0) xread();
-        }
-        // issue order: MFMA, [DMA request,] fragment read(s) - eight times
-#define K9_GAP(DMA, READS)                                                  \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  \
-        if (DMA) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);         \
-        __builtin_amdgcn_sched_group_barrier(0x100, READS, 0);
-        K9_GAP(st == 0, 1 + EXTRA) K9_GAP(st == 0, 1) K9_GAP(st == 0, 1) K9_GAP(st == 0, 1)
-        K9_GAP(false, 1) K9_GAP(false, 1) K9_GAP(false, 1) K9_GAP(false, 1)
-        __builtin_amdgcn_sched_barrier(0);
-    } else {
-        mma(0);
-        mma(1);
-        __builtin_amdgcn_sched_barrier(0);
-        ring_turn();
-        const char* p = g.smem + W_OFF + ((g.blk + 1) & 1) * WBLK + g.lane * 16;
-#pragma unroll
-        for (int j = 2; j < 8; ++j) {
-            mma(j);
-            if (j < 6) dma_piece(g, g.blk + 2, j - 2);
-            if (j < 4) {
-                nxt[2 * (j - 2)] = ring_read<Frag>(p + 2 * (j - 2) * FRAG);
-                nxt[2 * (j - 2) + 1] = ring_read<Frag>(p + (2 * (j - 2) + 1) * FRAG);
-            } else {
-                nxt[j] = ring_read<Frag>(p + j * FRAG);
-            }
-            K9_KEEP(cur[j]);
-            if (j == 2) xread();
-        }
-        K9_GAP(true, 2 + EXTRA) K9_GAP(true, 2) K9_GAP(true, 1) K9_GAP(true, 1) K9_GAP(false, 1) K9_GAP(false, 1)
+
+// One BLOCK = the wave's 8 MFMAs `mma(0..7)` on the fragments F[0..7] of the block in slot `slot`.  F is ONE rotating set of eight
+// operands: fragments 0..5 of a block are read behind MFMAs 4..7 of the block before it (behind the ring's turn), fragments 6, 7 behind
+// its own MFMAs 0, 1 - their registers hold the previous block's 6, 7 until then:
+//   MFMA 0 + read 6 (+ h0's operand reads) | MFMA 1 + read 7 | MFMA 2 | MFMA 3 | wait + barrier |
+//   MFMA 4 + piece 0 + reads 0', 1' (+ h4's) | MFMA 5 + piece 1 + reads 2', 3' | MFMA 6 + read 4' | MFMA 7 + read 5'
+// (x' = fragment x of the next block).  The turn after MFMA 3: every wave has ALL of this block's fragments in registers, so its slot is
+// free for block b + 3; the four MFMAs behind it cover the first reads of the next block.  NX0 / NX4 = LDS reads issued by the hooks
+// h0 / h4 (pinned behind MFMA 0 / MFMA 4); VM: see turn().
+#define K9_GAP(DMA, READS, VALU)                                            \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      \
+    if (DMA) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);             \
+    if (READS) __builtin_amdgcn_sched_group_barrier(0x100, READS, 0);       \
+    if (VALU) __builtin_amdgcn_sched_group_barrier(0x002, VALU, 0);
+// NV0 / NV4: vector instructions of the hooks to place behind each of MFMAs 0..3 / 4..7 (the hooks' arithmetic rides in the gaps)
+template <int NX0, int NX4, int VM, int NV0 = 0, int NV4 = 0, typename Frag, typename MF, typename H0, typename H4>
+__device__ __forceinline__ void pblock(Ring& g, Frag (&F)[8], int slot, MF mma, H0 h0, H4 h4) {
+    const char* pc = g.smem + g.rbase + slot * BLK;
+    mma(0);
+    F[6] = ring_frag<Frag>(pc + 6 * FRAG);
+    h0();
+    mma(1);
+    F[7] = ring_frag<Frag>(pc + 7 * FRAG);
+    mma(2);
+    mma(3);
+    K9_GAP(false, 1 + NX0, NV0) K9_GAP(false, 1, NV0) K9_GAP(false, 0, NV0) K9_GAP(false, 0, NV0)
+    __builtin_amdgcn_sched_barrier(0);
+    turn<VM>();
+    const char* p = g.smem + g.rbase + ((slot + 1) % 3) * BLK;
+    mma(4);
+    dma_piece(g, slot, g.blk + 3, 0);
+    F[0] = ring_frag<Frag>(p);
+    F[1] = ring_frag<Frag>(p + FRAG);
+    h4();
+    mma(5);
+    dma_piece(g, slot, g.blk + 3, 1);
+    F[2] = ring_frag<Frag>(p + 2 * FRAG);
+    F[3] = ring_frag<Frag>(p + 3 * FRAG);
+    mma(6);
+    F[4] = ring_frag<Frag>(p + 4 * FRAG);
+    mma(7);
+    F[5] = ring_frag<Frag>(p + 5 * FRAG);
+    K9_GAP(true, 2 + NX4, NV4) K9_GAP(true, 2, NV4) K9_GAP(false, 1, NV4) K9_GAP(false, 1, NV4)
+    __builtin_amdgcn_sched_barrier(0);
+    ++g.blk;
+}
 #undef K9_GAP
-        __builtin_amdgcn_sched_barrier(0);
-        ++g.blk;
-    }
-}
-// ring_step with ONE extra operand read per MFMA gap (`xr(j)` behind MFMA j): the head-pipelined q projection, whose eight MFMAs of a
-// step take eight DIFFERENT token-tile fragments (the k-steps of one head) - two ds_read_b128 per gap, the LDS's limit beside MFMAs
-template <typename Frag, typename MF, typename XF, typename VF>
-__device__ __forceinline__ void ring_step_q(Ring& g, Frag (&cur)[8], Frag (&nxt)[8], int st, MF mma, XF xr, VF valu) {
-#define K9_GAPQ(DMA, READS)                                                 \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  \
-        if (DMA) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);         \
-        __builtin_amdgcn_sched_group_barrier(0x100, READS, 0);
-    if (st != 3) {
-        const char* p = g.smem + W_OFF + (g.blk & 1) * WBLK + (st + 1) * 8 * FRAG + g.lane * 16;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            mma(j);
-            if (st == 0 && j < 4) dma_piece(g, g.blk + 1, 4 + j);
-            nxt[j] = ring_read<Frag>(p + j * FRAG);
-            xr(j);
-            K9_KEEP(cur[j]);
-            if (j == 0) valu();
-        }
-        K9_GAPQ(st == 0, 2) K9_GAPQ(st == 0, 2) K9_GAPQ(st == 0, 2) K9_GAPQ(st == 0, 2)
-        K9_GAPQ(false, 2) K9_GAPQ(false, 2) K9_GAPQ(false, 2) K9_GAPQ(false, 2)
-        __builtin_amdgcn_sched_barrier(0);
-    } else {
-        mma(0);
-        xr(0);
-        mma(1);
-        xr(1);
-        __builtin_amdgcn_sched_barrier(0);
-        ring_turn();
-        const char* p = g.smem + W_OFF + ((g.blk + 1) & 1) * WBLK + g.lane * 16;
-#pragma unroll
-        for (int j = 2; j < 8; ++j) {
-            mma(j);
-            if (j < 6) dma_piece(g, g.blk + 2, j - 2);
-            if (j < 4) {
-                nxt[2 * (j - 2)] = ring_read<Frag>(p + 2 * (j - 2) * FRAG);
-                nxt[2 * (j - 2) + 1] = ring_read<Frag>(p + (2 * (j - 2) + 1) * FRAG);
-            } else {
-                nxt[j] = ring_read<Frag>(p + j * FRAG);
-            }
-            xr(j);
-            K9_KEEP(cur[j]);
-            if (j == 2) valu();
-        }
-        K9_GAPQ(true, 3) K9_GAPQ(true, 3) K9_GAPQ(true, 2) K9_GAPQ(true, 2) K9_GAPQ(false, 2) K9_GAPQ(false, 2)
-        __builtin_amdgcn_sched_barrier(0);
-        ++g.blk;
-    }
-#undef K9_GAPQ
-}
-// prologue: block 0 whole and the first half of block 1 (its second half goes out in step 0, like every later block's)
+// prologue: blocks 0, 1, 2 requested
 __device__ __forceinline__ void ring_start(const Ring& g) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dma_piece(g, 0, i);
-    __builtin_amdgcn_sched_barrier(0);
-}
-__device__ __forceinline__ void ring_start2(const Ring& g) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dma_piece(g, 1, i);
+    for (int b = 0; b < 3; ++b) {
+        dma_piece(g, b, b, 0);
+        dma_piece(g, b, b, 1);
+    }
     __builtin_amdgcn_sched_barrier(0);
 }
 template <typename Frag>
-__device__ __forceinline__ void load_step0(const Ring& g, Frag (&f)[8]) {
-    const char* p = g.smem + W_OFF + g.lane * 16;
+__device__ __forceinline__ void load_block0(const Ring& g, Frag (&f)[8]) {      // fragments 0..5 of block 0 (6, 7: inside the block)
+    const char* p = g.smem + g.rbase;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) f[i] = ring_read<Frag>(p + i * FRAG);
+    for (int i = 0; i < 6; ++i) f[i] = ring_frag<Frag>(p + i * FRAG);
 }
 
-// x tile -> LDS: [kc][row][128 B] with the 16-B chunk index XORed with (row>>1)&7 (conflict-free ds_read_b128)
+// token tile -> LDS by LDS-DMA: [kc][row][128 B] with the 16-B chunk index XORed with (row >> 1) & 7 (conflict-free ds_read_b128).
+// A piece = 8 rows of one 64-channel plane (1 KiB, lane-linear): lane l fills row 8 p + (l >> 3), slot l & 7 with the row's chunk
+// (l & 7) ^ swizzle - the swizzle is applied on the SOURCE side.  `pieces` per wave; rows past the sequence are clamped to its last.
 template <typename T>
-__device__ __forceinline__ void load_tile(const T* base, long ld, int row0, int rows_valid, char* smem, int off, int tid) {
+__device__ __forceinline__ void tile_dma(const T* base, long ld, int rows_total, int row0, int nrows, char* smem, int off, int wave, int lane,
+                                         int waves) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, 0x7FFFFFFF, 0x00020000);
+    const int planes_pieces = nrows / 8;                                   // pieces per 64-channel plane
+    const int total = 4 * planes_pieces, per = total / waves;
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {
-        const int e = p * 256 + tid, row = e >> 5, c32 = e & 31;
-        const int r = min(row0 + row, rows_valid - 1);
-        const v4u v = *reinterpret_cast<const v4u*>(base + (size_t)r * ld + c32 * 8);
-        *reinterpret_cast<v4u*>(smem + off + (c32 >> 3) * 16384 + gf_lds_off(row, c32 & 7)) = v;
+    for (int i = 0; i < 8; ++i) {
+        if (i < per) {
+            const int q = wave * per + i, kc = q / planes_pieces, rp = q - kc * planes_pieces;
+            const int row = rp * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+            const int r = min(row0 + row, rows_total - 1);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + off + kc * (nrows * 128) + rp * 1024), 16,
+                                                     (int)(r * ld * 2) + kc * 128 + c * 16, 0, 0, 0);
+        }
     }
 }
 
 template <typename T>
-__device__ __forceinline__ void kv_tail(Ring& ring, typename Mma32<T>::Frag (&fa)[8], typename Mma32<T>::Frag (&fb)[8], char* smem, unsigned valid,
-                                        float* dst, int wave, int lane, int tid, int trace_base);
+__device__ __forceinline__ void kv_tail(Ring& ring, typename Mma32<T>::Frag (&F)[8], char* smem, unsigned valid,
+                                        float* dst, int wave, int lane, int tid, int slot0);
 
 template <typename T, int ACT, bool ATTN>
-__global__ __launch_bounds__(256, 1) void enc_layer(EncArgs a) {
+__global__ __launch_bounds__(512) void enc_pair(EncArgs a) {
     using Mm = Mma32<T>;
     using Frag = typename Mm::Frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h2 = lane >> 5, lr = lane & 31;
+    const int w = wave & 1, grp = wave >> 1;                           // channel half, 32-token group
     const int n = blockIdx.x / a.tiles, tile = blockIdx.x - n * a.tiles;
     const int t0 = tile * TM;                                         // first token of the tile inside image n
     const T* xg = (const T*)a.x + (size_t)n * a.L * a.ldx;
-    constexpr int NBLK = ATTN ? 32 : 28;
+    constexpr int NBLK = (ATTN ? NB_Q : 0) + NB_M + 4 * NB_SLICE;     // 64 / 56
     float* vec = reinterpret_cast<float*>(smem + VEC_OFF);
-    K9_T(0);
-    // state tail (see EncArgs): this image's finished rows also leave their linear-attention state; the tail's 8 weight blocks
-    // simply follow the layer's in the ring (requests behind the layer's last block are out of range without a tail: zeros)
     const bool tail = ATTN && a.wstream_tail != nullptr && n >= a.tail_first;
-    Ring ring = ring_make(a.wstream, smem, wave, lane, NBLK, tail ? a.wstream_tail : nullptr, 8);
-    ring_start(ring);
-#if !defined(K9_ABLATE) || K9_ABLATE != 7
-    load_tile<T>(xg, a.ldx, t0, a.L, smem, X_OFF, tid);
-#endif
+    K9P_T(0);
+    Ring ring = ring_make(a.wstream, smem, wave, lane, NBLK, tail ? a.wstream_tail : nullptr, NB_KV);
+    const int mytok = t0 + grp * 32 + lr;                             // this lane's token (accumulator column)
+    const int myrow = grp * 32 + lr;
+    // the prologue's plain loads go out FIRST: the waits of their consumers then do not cover the LDS-DMA requests behind them
+    const float lnv0 = a.ln[tid], lnv1 = a.ln[512 + tid];
+    unsigned char qm = 1;
+    if (a.q_mask != nullptr) qm = a.q_mask[(size_t)n * a.L + min(mytok, a.L - 1)];
+    float kvv[2][8], ksv = 0.f;
+    if constexpr (ATTN) {
+        const float* kvf = a.kvfinal + (size_t)n * (C * D + C);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) vec[i * C + tid] = a.ln[i * C + tid];
+        for (int p = 0; p < 2; ++p) {
+            const int sl = p * 512 + tid, ln = sl & 63, hs = sl >> 6, hh = hs >> 1, s = hs & 1;
+            const float* src = kvf + (size_t)(hh * D + 16 * s + 4 * (ln >> 5)) * D + (ln & 31);       // KV[c = (hh, d)][v]
+#pragma unroll
+            for (int j = 0; j < 8; ++j) kvv[p][j] = src[((j >> 2) * 8 + (j & 3)) * D];
+        }
+        {
+            const int tq = tid & 255, j = tq & 7, hx = (tq >> 3) & 1, sx = (tq >> 4) & 1, hh = tq >> 5;
+            ksv = kvf[C * D + hh * D + 16 * sx + 8 * (j >> 2) + 4 * hx + (j & 3)];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    tile_dma<T>(xg, a.ldx, a.L, t0, TM, smem, X_OFF, wave, lane, 8);
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        dma_piece(ring, b, b, 0);
+        dma_piece(ring, b, b, 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    K9P_T(13);
+    vec[tid] = lnv0;
+    vec[512 + tid] = lnv1;
+    const float qmul = qm != 0 ? 1.f : 0.f;                            // masked query -> 0
     if constexpr (ATTN) {
         // KV / S and Ksum / S of image n in the storage type (the reference's "prevent fp16 overflow" scaling,
         // linear_attention.py:45-49: out = (Q.KV/S) / (Q.Ksum/S + eps/S)), KV as A fragments in the k order of a
-        // packed accumulator: lane (v = lr, h2), element j  <->  d = 16s + 8(j>>2) + 4 h2 + (j&3)
-        const float* kvf = a.kvfinal + (size_t)n * (C * D + C);
+        // packed accumulator: lane (v = lr, h2), element j  <->  d = 16s + 8(j>>2) + 4 h2 + (j&3); parked in the exchange region
+        // (free until the first exchange), every wave then takes the fragments of its four heads into registers
         const float inv_s = 1.0f / (float)a.S;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int slot = p * 256 + tid, ln = slot & 63, hs = slot >> 6, hh = hs >> 1, s = hs & 1;
-            const float* src = kvf + (size_t)(hh * D + 16 * s + 4 * (ln >> 5)) * D + (ln & 31);       // KV[c = (hh, d)][v]
-            *reinterpret_cast<Frag*>(smem + KV_OFF + hs * FRAG + ln * 16) =
-                pack8<T>(src[0] * inv_s, src[D] * inv_s, src[2 * D] * inv_s, src[3 * D] * inv_s, src[8 * D] * inv_s, src[9 * D] * inv_s,
-                         src[10 * D] * inv_s, src[11 * D] * inv_s);
+        for (int p = 0; p < 2; ++p) {
+            const int sl = p * 512 + tid, ln = sl & 63, hs = sl >> 6;
+            *reinterpret_cast<Frag*>(smem + E_OFF + hs * FRAG + ln * 16) =
+                pack8<T>(kvv[p][0] * inv_s, kvv[p][1] * inv_s, kvv[p][2] * inv_s, kvv[p][3] * inv_s, kvv[p][4] * inv_s, kvv[p][5] * inv_s,
+                         kvv[p][6] * inv_s, kvv[p][7] * inv_s);
         }
-        {
-            // Ksum / S rounded to the storage type, as 16-byte operands in the k order of the packed phi(q): entry (hh, s, h2),
-            // element j = channel 32 hh + 16 s + 8 (j >> 2) + 4 h2 + (j & 3) - the denominator is then 4 dot-pair instructions per k-step
-            const int j = tid & 7, hx = (tid >> 3) & 1, sx = (tid >> 4) & 1, hh = tid >> 5;
-            reinterpret_cast<T*>(smem + KS_OFF)[tid] = gf_from_float<T>(kvf[C * D + hh * D + 16 * sx + 8 * (j >> 2) + 4 * hx + (j & 3)] * inv_s);
-        }
+        // Ksum / S rounded to the storage type, as 16-byte operands in the k order of the packed phi(q): entry (hh, s, h2),
+        // element j = channel 32 hh + 16 s + 8 (j >> 2) + 4 h2 + (j & 3)   (both halves of the workgroup write the same 256 values)
+        reinterpret_cast<T*>(smem + KS_OFF)[tid & 255] = gf_from_float<T>(ksv * inv_s);
     }
-    Frag mfrag[8][2];                      // the B operand of the merge product, then of the second half of mlp.0
+    // the B operands of the merge product (k-step ks = 2 head + s), then of the second half of mlp.0: ALL 16 k-steps in both waves
+    Frag ma[16];
     if constexpr (!ATTN) {
-        // the attention output of K4 / K5 comes from HBM: stage the 128 x 256 tile row-contiguously in the (still
-        // empty) second ring slot + the KV area ... it is 64 KiB, the ring is 64 KiB, block 0 is in slot 0: use the
-        // x-tile layout at W_OFF + WBLK is too small, so the tile goes through in two 64-token halves
+        // the attention output of K4 / K5 comes from HBM: the 128 x 256 tile goes through the exchange region in two 64-token
+        // halves ([kc][64 rows][128 B], swizzled like the x tile); both waves of a pair take all 16 operands of their 32 tokens
         const T* mg = (const T*)a.msg + (size_t)n * a.L * a.ldm;
-        __syncthreads();                   // nothing pending on slot 1; slot 0 holds block 0 (DMA may still be in flight: different bytes)
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            // 64 rows x 512 B = 32 KiB into slot 1, image [kc][64 rows][128 B]
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const int e = p * 256 + tid, row = e >> 5, c32 = e & 31;
-                const int r = min(t0 + half * 64 + row, a.L - 1);
-                const v4u v = *reinterpret_cast<const v4u*>(mg + (size_t)r * a.ldm + c32 * 8);
-                *reinterpret_cast<v4u*>(smem + W_OFF + WBLK + (c32 >> 3) * 8192 + gf_lds_off(row, c32 & 7)) = v;
-            }
-            __syncthreads();
-            if ((wave >> 1) == half) {     // waves 0,1 own rows 0..63, waves 2,3 rows 64..127
-                const int row = (wave & 1) * 32 + lr;
+            tile_dma<T>(mg, a.ldm, a.L, t0 + half * 64, 64, smem, E_OFF, wave, lane, 8);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if ((grp >> 1) == half) {      // groups 0, 1 own rows 0..63, groups 2, 3 rows 64..127
+                const int row = (grp & 1) * 32 + lr;
 #pragma unroll
                 for (int t = 0; t < 8; ++t)
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         // channels 32t + 16s + 4h2 + {0..3} and + 8: two 8-byte pieces of chunk (32t + 16s) / 8 and the next
                         const int c0 = 32 * t + 16 * s + 4 * h2, ch = c0 >> 3;           // c0 % 8 is 0 or 4
-                        const char* p0 = smem + W_OFF + WBLK + (ch >> 3) * 8192 + gf_lds_off(row, ch & 7) + (c0 & 7) * 2;
-                        const char* p1 = smem + W_OFF + WBLK + ((ch + 1) >> 3) * 8192 + gf_lds_off(row, (ch + 1) & 7) + (c0 & 7) * 2;
+                        const char* p0 = smem + E_OFF + (ch >> 3) * 8192 + gf_lds_off(row, ch & 7) + (c0 & 7) * 2;
+                        const char* p1 = smem + E_OFF + ((ch + 1) >> 3) * 8192 + gf_lds_off(row, (ch + 1) & 7) + (c0 & 7) * 2;
                         typedef short v4s __attribute__((ext_vector_type(4)));
                         typedef short v8s __attribute__((ext_vector_type(8)));
                         const v4s lo = *reinterpret_cast<const v4s*>(p0), hi = *reinterpret_cast<const v4s*>(p1);
                         const v8s both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                        mfrag[t][s] = __builtin_bit_cast(Frag, both);
+                        ma[2 * t + s] = __builtin_bit_cast(Frag, both);
                     }
             }
-            __syncthreads();
+            xbar();
         }
     }
-    // block 0 and the first half of block 1 are requested; wait for block 0 only (the 4 youngest requests are block 1's)
-    ring_start2(ring);
+    // block 0 and the tile have landed; blocks 1, 2 (the four youngest requests) may still be in flight
+    K9P_T(14);
     asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    K9P_T(15);
     __builtin_amdgcn_s_barrier();
 
-    K9_T(1);
-    const int tok = t0 + wave * 32 + lr;                              // this lane's token (accumulator column)
-    const char* xrow = smem + X_OFF;
-    const int myrow = wave * 32 + lr;
-    Frag fa[8], fb[8];                                                // fragments of the current / next step, alternating
-    load_step0(ring, fa);
+    K9P_T(1);
+    Frag F[8];                                                        // the rotating weight fragments (see pblock)
+    load_block0(ring, F);
     // token-tile operand of 16-deep k-step ks (0..15)
-    auto xfrag = [&](int ks) { return *reinterpret_cast<const Frag*>(xrow + (ks >> 2) * 16384 + gf_lds_off(myrow, 2 * (ks & 3) + h2)); };
+    auto xfrag = [&](int ks) { return lds_frag<Frag>(smem + X_OFF + (ks >> 2) * 16384 + gf_lds_off(myrow, 2 * (ks & 3) + h2)); };
+    // the pair's exchange slots (8 x 1 KiB): wave half 0 writes slots 0-3, half 1 slots 4-7, both read all eight
+    char* const ex = smem + E_OFF + grp * 8192 + lane * 16;
+    auto ex_put = [&](int i, const Frag& f) { *reinterpret_cast<Frag*>(ex + (4 * w + i) * FRAG) = f; };
+    auto ex_get = [&](int s) { return lds_frag<Frag>(ex + s * FRAG); };
+    int slot = 0;                                                     // slot of the current block (compile-time after unrolling)
 
-#if K9_HEADPIPE
-    v16f m[8];
+    // ---------------- linear attention (ATTN): q = W_q x HEAD-MAJOR - block b multiplies k-steps 8 (b & 1) .. + 7 of head t = b >> 1 (the wave's
+    // head 4 w + t), its token-tile operands X16 in registers - so that the attention of head t (phi, packing, normaliser, two state MFMAs,
+    // normalisation: ~110 vector instructions) rides in the MFMA gaps of head t + 1's two blocks (head 3's in the first two merge blocks)
+    // instead of a phase of its own with the matrix pipe idle.  The packed message of head t crosses the pair through slot set t & 1 of the
+    // exchange region (written behind the turn of block 2 t + 3, read behind the turn of block 2 t + 4: no barrier of its own); the merge
+    // product's block h multiplies head h, whose operands both waves hold by then.
+    Frag kvf[4][2];
+    v16f qacc[2];                                                     // q of the head being multiplied / of the head in the attention
+    v16f num;
+    float den = 0.f;
+    Frag p0, p1, msg0, msg1;
+    const float eps_s = ATTN ? a.attn_eps / (float)a.S : 0.f;
+    auto att_a0 = [&](int t) {                                        // phi(q) of registers 0..7: rounded by its packing; the normaliser from the PACKED operands
+        const int hh = 4 * w + t;
+        const Frag ks0 = lds_frag<Frag>(smem + KS_OFF + ((hh * 2 + 0) * 2 + h2) * 16);
+        const v16f& qh = qacc[t & 1];
+        p0 = pack8<T>(phi(qh[0]), phi(qh[1]), phi(qh[2]), phi(qh[3]), phi(qh[4]), phi(qh[5]), phi(qh[6]), phi(qh[7]));
+        den = dot8(p0, ks0, 0.f);
+    };
+    auto att_a1 = [&](int t) {
+        const int hh = 4 * w + t;
+        const Frag ks1 = lds_frag<Frag>(smem + KS_OFF + ((hh * 2 + 1) * 2 + h2) * 16);
+        const v16f& qh = qacc[t & 1];
+        p1 = pack8<T>(phi(qh[8]), phi(qh[9]), phi(qh[10]), phi(qh[11]), phi(qh[12]), phi(qh[13]), phi(qh[14]), phi(qh[15]));
+        den = dot8(p1, ks1, den);
+        num = zero16();
+        Mm::mma(kvf[t][0], p0, num);
+        Mm::mma(kvf[t][1], p1, num);
+    };
+    auto att_b0 = [&] {                                                // a masked query (phi(q) = 0 in linear_attention.py:35-36) is zeroed through its normaliser
+        const float z = __builtin_amdgcn_rcpf(half_sum(den) + eps_s) * qmul;
 #pragma unroll
-    for (int nb = 0; nb < 8; ++nb) m[nb] = zero16();
+        for (int r = 0; r < 16; ++r) num[r] *= z;
+        msg0 = pack_step<T>(num, 0);
+        msg1 = pack_step<T>(num, 1);
+    };
+    auto att_put = [&](int t) {                                        // slot set t & 1: slots 4 w + 2 (t & 1) + {0, 1}
+        *reinterpret_cast<Frag*>(ex + (4 * w + 2 * (t & 1)) * FRAG) = msg0;
+        *reinterpret_cast<Frag*>(ex + (4 * w + 2 * (t & 1) + 1) * FRAG) = msg1;
+    };
+    auto att_get = [&](int t) {                                        // heads t (wave half 0) and 4 + t (half 1): k-steps 2 t, 2 t + 1 and 8 + 2 t, 9 + 2 t
+        ma[2 * t] = ex_get(2 * (t & 1));
+        ma[2 * t + 1] = ex_get(2 * (t & 1) + 1);
+        ma[8 + 2 * t] = ex_get(4 + 2 * (t & 1));
+        ma[9 + 2 * t] = ex_get(5 + 2 * (t & 1));
+    };
     if constexpr (ATTN) {
-        // Round 5: q projection, attention and merge as ONE head-pipelined instruction stream.  The weight stream is head-major
-        // (fused.py: Q0 Q1 M0 Q2 M1 ... Q7 M6 M7; Q(h) = the 16 k-steps of channel tile h into ONE accumulator, M(h) = the merge's
-        // k-steps 2h, 2h + 1 over tiles 0..7) and the attention of head h - phi, packing, the normaliser, its two state MFMAs,
-        // the normalisation - rides in the two steps of Q(h + 1) (AB7 in M6): its ~160 vector instructions issue under the 16 MFMAs of
-        // the neighbouring head instead of in a phase of their own with the matrix pipe idle (one wave per SIMD: nothing else overlaps
-        // them).  Every accumulator still adds its k-steps in ascending order - q[h]: 0..15, m[nb]: 0..15 - so the layer's output
-        // keeps its bits.  The token tile's 16 operand fragments are the B operands of EVERY head's projection: read once.
-        // The token tile's operand fragments: MFMA G of the phase (G = 16 head + k-step) takes k-step G % 16; a four-deep rotating
-        // window of them lives in registers (the fragment of MFMA G + 3 is requested behind MFMA G: three gaps ahead of its use)
-        Frag xq[4];
-        xq[0] = xfrag(0);
-        xq[1] = xfrag(1);
-        xq[2] = xfrag(2);
-        v16f qh[2];
-        const float qmul = (a.q_mask == nullptr || a.q_mask[(size_t)n * a.L + min(t0 + wave * 32 + (fresh_lane() & 31), a.L - 1)] != 0) ? 1.f : 0.f;
-        const float eps_s = a.attn_eps / (float)a.S;
-        struct HeadOps { Frag ks0, ks1; Frag kv0, kv1; };
-        auto head_ops = [&](int hh) {
-            HeadOps o;
-            o.ks0 = *reinterpret_cast<const Frag*>(smem + KS_OFF + ((hh * 2 + 0) * 2 + h2) * 16);
-            o.ks1 = *reinterpret_cast<const Frag*>(smem + KS_OFF + ((hh * 2 + 1) * 2 + h2) * 16);
-            o.kv0 = *reinterpret_cast<const Frag*>(smem + KV_OFF + (hh * 2) * FRAG + lane * 16);
-            o.kv1 = *reinterpret_cast<const Frag*>(smem + KV_OFF + (hh * 2 + 1) * FRAG + lane * 16);
-            return o;
-        };
-        v16f num;
-        float den = 0.f;
-        HeadOps hop;
-        // stage A(h): phi(q[h]) rounded by its packing, the normaliser from the PACKED operands, the two state MFMAs
-        auto stage_a = [&](int hh) {
-            float pq[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) pq[r] = phi(qh[hh & 1][r]);
-            const Frag p0 = pack8<T>(pq[0], pq[1], pq[2], pq[3], pq[4], pq[5], pq[6], pq[7]);
-            const Frag p1 = pack8<T>(pq[8], pq[9], pq[10], pq[11], pq[12], pq[13], pq[14], pq[15]);
-            den = dot8(p1, hop.ks1, dot8(p0, hop.ks0, 0.f));
-            num = zero16();
-            Mm::mma(hop.kv0, p0, num);
-            Mm::mma(hop.kv1, p1, num);
-        };
-        // stage B(h): normalise and pack the message of head h = the B operand of M(h)
-        auto stage_b = [&](int hh) {
-            const float z = __builtin_amdgcn_rcpf(half_sum(den) + eps_s) * qmul;
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) num[r] *= z;
-            mfrag[hh][0] = pack_step<T>(num, 0);
-            mfrag[hh][1] = pack_step<T>(num, 1);
-        };
-        int gs = 0;                                                       // step counter of the phase (everything below is unrolled)
-        auto q_slot = [&](auto hh_c, auto ab_c) {                          // Q(hh), with A(hh - 1) / B(hh - 1) riding in its two steps
-            constexpr int HH = decltype(hh_c)::value;
-            constexpr bool AB = decltype(ab_c)::value;
+            for (int s = 0; s < 2; ++s) kvf[t][s] = lds_frag<Frag>(smem + E_OFF + ((4 * w + t) * 2 + s) * FRAG + lane * 16);
+        Frag X16[16];
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                Frag (&cur)[8] = (gs & 1) ? fb : fa;
-                Frag (&nxt)[8] = (gs & 1) ? fa : fb;
-                if (hf == 0) qh[HH & 1] = zero16();
-                ring_step_q(ring, cur, nxt, gs & 3,
-                            [&](int j) { Mm::mma(cur[j], xq[(8 * hf + j) & 3], qh[HH & 1]); },          // (16 HH + 8 hf + j) % 4
-                            [&](int j) { if (HH < 7 || 8 * hf + j + 3 < 16) xq[(8 * hf + j + 3) & 3] = xfrag((8 * hf + j + 3) & 15); },
-                            [&] {
-                                if constexpr (AB) {
-                                    if (hf == 0) stage_a(HH - 1);
-                                    else stage_b(HH - 1);
-                                }
-                            });
-                ++gs;
-            }
-        };
-        auto m_slot = [&](int hh, auto ab_c) {                             // M(hh), with A(7) / B(7) riding in M(6)
-            constexpr bool AB = decltype(ab_c)::value;
+        for (int ks = 0; ks < 16; ++ks) X16[ks] = xfrag(ks);
 #pragma unroll
-            for (int sx = 0; sx < 2; ++sx) {
-                Frag (&cur)[8] = (gs & 1) ? fb : fa;
-                Frag (&nxt)[8] = (gs & 1) ? fa : fb;
-                const Frag bf = mfrag[hh][sx];
-                ring_step<0>(ring, cur, nxt, gs & 3, [&](int nb) { Mm::mma(cur[nb], bf, m[nb]); },
-                             [&] {
-                                 if constexpr (AB) {
-                                     if (sx == 0) stage_a(7);
-                                     else stage_b(7);
-                                 }
-                             });
-                ++gs;
-            }
-        };
-        using std::true_type;
-        using std::false_type;
-        using std::integral_constant;
-        q_slot(integral_constant<int, 0>{}, false_type{});
-        hop = head_ops(0);
-        q_slot(integral_constant<int, 1>{}, true_type{});
-        m_slot(0, false_type{}); hop = head_ops(1); q_slot(integral_constant<int, 2>{}, true_type{});
-        m_slot(1, false_type{}); hop = head_ops(2); q_slot(integral_constant<int, 3>{}, true_type{});
-        m_slot(2, false_type{}); hop = head_ops(3); q_slot(integral_constant<int, 4>{}, true_type{});
-        m_slot(3, false_type{}); hop = head_ops(4); q_slot(integral_constant<int, 5>{}, true_type{});
-        m_slot(4, false_type{}); hop = head_ops(5); q_slot(integral_constant<int, 6>{}, true_type{});
-        m_slot(5, false_type{}); hop = head_ops(6); q_slot(integral_constant<int, 7>{}, true_type{});
-        hop = head_ops(7);
-        m_slot(6, true_type{});
-        m_slot(7, false_type{});
-        K9_T(2);
-        K9_T(3);
-    } else {
-        K9_T(3);
-#pragma unroll
-        for (int st = 0; st < 16; ++st) {
-            Frag (&cur)[8] = (st & 1) ? fb : fa;
-            Frag (&nxt)[8] = (st & 1) ? fa : fb;
-            const Frag bf = mfrag[st >> 1][st & 1];
-            ring_step<0>(ring, cur, nxt, st & 3, [&](int nb) { Mm::mma(cur[nb], bf, m[nb]); }, [] {});
+        for (int b = 0; b < NB_Q; ++b) {
+            const int t = b >> 1, hf = b & 1;
+            if (hf == 0) qacc[t & 1] = zero16();
+            auto mm = [&](int j) { PMma<T>::mma(F[j], X16[8 * hf + j], qacc[t & 1]); };
+            if (b < 2) pblock<0, 0, 2>(ring, F, slot, mm, [] {}, [] {});
+            else if (hf == 0) pblock<1, 5, 2, 10, 10>(ring, F, slot, mm, [&] { att_a0(t - 1); }, [&] { att_a1(t - 1); if (t >= 2) att_get(t - 2); });
+            else pblock<0, 0, 2, 8, 0>(ring, F, slot, mm, [&] { att_b0(); }, [&] { att_put(t - 1); });
+            slot = (slot + 1) % 3;
         }
+        K9P_T(2);
+        K9P_T(3);
     }
-#else
-#if K9_MERGEPIPE
-    v16f m[8];
-#pragma unroll
-    for (int nb = 0; nb < 8; ++nb) m[nb] = zero16();
-#endif
-    if constexpr (ATTN) {
-        // ---------------- q = W_q x : 16 steps (k-step ks = step, tiles nb = 0..7)
-        v16f q[8];
-#pragma unroll
-        for (int nb = 0; nb < 8; ++nb) q[nb] = zero16();
-        Frag tf = xfrag(0);
-#pragma unroll
-        for (int st = 0; st < 16; ++st) {
-            Frag (&cur)[8] = (st & 1) ? fb : fa;
-            Frag (&nxt)[8] = (st & 1) ? fa : fb;
-            Frag tn;
-            ring_step<1>(ring, cur, nxt, st & 3, [&](int nb) { Mm::mma(cur[nb], tf, q[nb]); }, [&] { tn = xfrag(st < 15 ? st + 1 : 15); });
-            tf = tn;
-        }
-        K9_T(2);
-        // ---------------- linear attention per head: tile h of q is head h (32 channels)
-        const float qmul = (a.q_mask == nullptr || a.q_mask[(size_t)n * a.L + min(t0 + wave * 32 + (fresh_lane() & 31), a.L - 1)] != 0) ? 1.f : 0.f;
-        const float eps_s = a.attn_eps / (float)a.S;
-        // Two-stage pipeline over the heads (same arithmetic, same order per head): stage A(h) = phi, denominator and the two
-        // state MFMAs of head h, stage B(h) = normalise and pack; B(h-1) runs behind A(h), under A(h)'s MFMAs, and the LDS operands
-        // of head h+1 (Ksum rows, state fragments) are requested a head ahead - one wave per SIMD: nothing else hides their latency.
-        struct HeadOps { Frag ks0, ks1; Frag kv0, kv1; };
-        auto head_ops = [&](int hh) {
-            HeadOps o;
-            o.ks0 = *reinterpret_cast<const Frag*>(smem + KS_OFF + ((hh * 2 + 0) * 2 + h2) * 16);
-            o.ks1 = *reinterpret_cast<const Frag*>(smem + KS_OFF + ((hh * 2 + 1) * 2 + h2) * 16);
-            o.kv0 = *reinterpret_cast<const Frag*>(smem + KV_OFF + (hh * 2) * FRAG + lane * 16);
-            o.kv1 = *reinterpret_cast<const Frag*>(smem + KV_OFF + (hh * 2 + 1) * FRAG + lane * 16);
-            return o;
-        };
-#if K9_MERGEPIPE
-#define K9_HX(hh) 0
-#else
-#define K9_HX(hh) ((hh) & 1)
-#endif
-        v16f num[2];
-        float den[2];
-        // phi(q) is rounded by its packing (one conversion per pair) and the denominator phi(q) . Ksum / S is summed from the PACKED
-        // operands (the 16-bit products are exact in fp32) - rounds 2-3 rounded every value by a conversion there and back, multiplied
-        // in fp32 and converted again for the packing; a masked query (phi(q) = 0 in linear_attention.py:35-36, message 0 / eps = 0)
-        // is zeroed through its normaliser instead of a multiply per value
-        auto stage_a = [&](int hh, const HeadOps& ho) {
-            float pq[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) pq[r] = phi(q[hh][r]);
-            const Frag p0 = pack8<T>(pq[0], pq[1], pq[2], pq[3], pq[4], pq[5], pq[6], pq[7]);
-            const Frag p1 = pack8<T>(pq[8], pq[9], pq[10], pq[11], pq[12], pq[13], pq[14], pq[15]);
-            den[K9_HX(hh)] = dot8(p1, ho.ks1, dot8(p0, ho.ks0, 0.f));
-            num[K9_HX(hh)] = zero16();
-            Mm::mma(ho.kv0, p0, num[K9_HX(hh)]);
-            Mm::mma(ho.kv1, p1, num[K9_HX(hh)]);
-        };
-        auto stage_b = [&](int hh) {
-            float d = den[K9_HX(hh)];
-            d = half_sum(d);
-            const float z = __builtin_amdgcn_rcpf(d + eps_s) * qmul;
-            v16f& nm = num[K9_HX(hh)];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) nm[r] *= z;
-            mfrag[hh][0] = pack_step<T>(nm, 0);
-            mfrag[hh][1] = pack_step<T>(nm, 1);
-        };
-        HeadOps hops[2];
-        hops[0] = head_ops(0);
-#if K9_MERGEPIPE
-        // Round 5 (-DK9_MERGEPIPE=1, an experiment): the merge's k-steps are head-major already (steps 2h, 2h + 1 = head h), so the
-        // attention of head h + 1 can ride in the two merge steps of head h - only head 0's attention stays a phase of its own.
-        // Same sums in the same order.
-        stage_a(0, hops[0]);
-        hops[0] = head_ops(1);
-        stage_b(0);
-        K9_T(3);
-#pragma unroll
-        for (int st = 0; st < 16; ++st) {
-            Frag (&cur)[8] = (st & 1) ? fb : fa;
-            Frag (&nxt)[8] = (st & 1) ? fa : fb;
-            const Frag bf = mfrag[st >> 1][st & 1];
-            const int hn = (st >> 1) + 1;                                   // the head whose attention rides in this step
-            ring_step<0>(ring, cur, nxt, st & 3, [&](int nb) { Mm::mma(cur[nb], bf, m[nb]); },
-                         [&] {
-                             if (hn < 8) {
-                                 if ((st & 1) == 0) {
-                                     stage_a(hn, hops[0]);                  // (one set of operands and one numerator: A and B of a head are a step apart)
-                                 } else {
-                                     stage_b(hn);
-                                     if (hn < 7) hops[0] = head_ops(hn + 1);
-                                 }
-                             }
-                         });
-        }
-    } else {
-        K9_T(3);
-#pragma unroll
-        for (int st = 0; st < 16; ++st) {
-            Frag (&cur)[8] = (st & 1) ? fb : fa;
-            Frag (&nxt)[8] = (st & 1) ? fa : fb;
-            const Frag bf = mfrag[st >> 1][st & 1];
-            ring_step<0>(ring, cur, nxt, st & 3, [&](int nb) { Mm::mma(cur[nb], bf, m[nb]); }, [] {});
-        }
-    }
-#else
-#pragma unroll
-        for (int hh = 0; hh < 8; ++hh) {
-            if (hh < 7) hops[(hh + 1) & 1] = head_ops(hh + 1);
-            stage_a(hh, hops[hh & 1]);
-            if (hh > 0) stage_b(hh - 1);
-        }
-        stage_b(7);
-    }
-#endif
 
-#if !K9_MERGEPIPE
-    K9_T(3);
-    // ---------------- m = LN1(W_m msg) : 16 steps, operand (tile t = step / 2, k-step s = step % 2) from registers
-    v16f m[8];
+    // ---------------- m = W_m msg for the wave's 128 channels: 8 blocks of (2 k-steps x 4 tiles), operands from registers
+    v16f m[4];
 #pragma unroll
-    for (int nb = 0; nb < 8; ++nb) m[nb] = zero16();
+    for (int t = 0; t < 4; ++t) m[t] = zero16();
+    Frag X[4];                                                        // token-tile operands of a W_1 block: X[kk] for MFMAs 2 kk, 2 kk + 1
 #pragma unroll
-    for (int st = 0; st < 16; ++st) {
-        Frag (&cur)[8] = (st & 1) ? fb : fa;
-        Frag (&nxt)[8] = (st & 1) ? fa : fb;
-        const Frag bf = mfrag[st >> 1][st & 1];
-        ring_step<0>(ring, cur, nxt, st & 3, [&](int nb) { Mm::mma(cur[nb], bf, m[nb]); }, [] {});
+    for (int b = 0; b < NB_M; ++b) {
+        auto mm = [&](int j) { PMma<T>::mma(F[j], ma[2 * b + (j >> 2)], m[j & 3]); };
+        if (ATTN && b == 0) pblock<1, 5, 2, 10, 10>(ring, F, slot, mm, [&] { att_a0(3); }, [&] { att_a1(3); att_get(2); });
+        else if (ATTN && b == 1) pblock<0, 0, 2, 8, 0>(ring, F, slot, mm, [&] { att_b0(); }, [&] { att_put(3); });
+        else if (ATTN && b == 2) pblock<0, 4, 2>(ring, F, slot, mm, [] {}, [&] { att_get(3); });
+        else if (b < NB_M - 1) pblock<0, 0, 2>(ring, F, slot, mm, [] {}, [] {});
+        else pblock<0, 2, 2>(ring, F, slot, mm, [] {}, [&] { X[0] = xfrag(0); X[1] = xfrag(1); });      // mlp.0's first operands
+        slot = (slot + 1) % 3;
     }
-#endif
-#endif
-    // nn.LayerNorm over the 256 channels of the lane's token, statistics in fp32; the other lane half holds the other
-    // 128 channels.  One pass over the accumulators (they live in AGPRs: every use is a register move): sum and sum of
-    // squares, var = E[x^2] - mean^2 (|x| = O(1) after a 256..512-deep product of O(1) operands: no cancellation issue).
-    auto ln_stats = [&](const v16f (&t)[8], float eps, float& mean, float& rstd) {
-        float s = 0.f, qd = 0.f;
+    K9P_T(4);
+    // nn.LayerNorm over the 256 channels of the lane's token, statistics in fp32: this lane half holds 64 of them, the other half 64,
+    // the pair's other wave 128: sum and sum of squares per wave (one pass, var = E[x^2] - mean^2), the two waves' partials through LDS
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    auto stats_add = [&](const v16f& t, float& s, float& qd) {
 #pragma unroll
-        for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = t[nb][r];
-                s += v;
-                qd = fmaf(v, v, qd);
-            }
-        s = half_sum(s);
-        qd = half_sum(qd);
+        for (int r = 0; r < 16; ++r) {
+            const float v = t[r];
+            s += v;
+            qd = fmaf(v, v, qd);
+        }
+    };
+    auto stats_put = [&](float s, float qd) { *reinterpret_cast<f2*>(smem + ST_OFF + (wave * 64 + lane) * 8) = f2{s, qd}; };
+    auto stats_finish = [&](float s, float qd, float eps, float& mean, float& rstd) {
+        const f2 o = *reinterpret_cast<const f2*>(smem + ST_OFF + ((wave ^ 1) * 64 + lane) * 8);
+        s += o.x;                                                      // a + b == b + a: both waves of the pair get the same bits
+        qd += o.y;
         mean = s * (1.0f / C);
         rstd = 1.0f / sqrtf(fmaxf(qd - s * mean, 0.f) * (1.0f / C) + eps);
     };
-    // gamma / beta of tile nb for this lane half (channels nb*32 + 8g + 4 h2 + {0..3}); requested a tile ahead of their use
-    struct LnOps { v4f ga[4], be[4]; };
-    auto ln_ops = [&](const float* gamma, const float* beta, int nb, int hl) {
+    // gamma / beta of the 8 channels nb*32 + 8g + 4 h2 + {0..3}, g = 2 sx, 2 sx + 1 (one packed operand = half a channel tile)
+    struct LnOps { v4f ga[2], be[2]; };
+    auto ln_ops = [&](const float* gamma, const float* beta, int nb, int sx) {
         LnOps o;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            o.ga[g] = *reinterpret_cast<const v4f*>(gamma + nb * 32 + 8 * g + 4 * hl);
-            o.be[g] = *reinterpret_cast<const v4f*>(beta + nb * 32 + 8 * g + 4 * hl);
+        for (int g = 0; g < 2; ++g) {
+            o.ga[g] = *reinterpret_cast<const v4f*>(gamma + nb * 32 + 8 * (2 * sx + g) + 4 * h2);
+            o.be[g] = *reinterpret_cast<const v4f*>(beta + nb * 32 + 8 * (2 * sx + g) + 4 * h2);
         }
         return o;
     };
-    // the four normalised values of registers 4g .. 4g+3 of a tile
     // (t - mean) rstd gamma + beta as two FMAs per value: t rstd - mean rstd, then times gamma plus beta (`nmr` = -mean rstd)
-    auto ln_apply = [&](const v16f& t, int g, const LnOps& p, float nmr, float rstd) {
-        return v4f{fmaf(fmaf(t[4 * g], rstd, nmr), p.ga[g].x, p.be[g].x), fmaf(fmaf(t[4 * g + 1], rstd, nmr), p.ga[g].y, p.be[g].y),
-                   fmaf(fmaf(t[4 * g + 2], rstd, nmr), p.ga[g].z, p.be[g].z), fmaf(fmaf(t[4 * g + 3], rstd, nmr), p.ga[g].w, p.be[g].w)};
+    auto ln_apply = [&](const v16f& t, int g, const v4f& ga, const v4f& be, float nmr, float rstd) {
+        return v4f{fmaf(fmaf(t[4 * g], rstd, nmr), ga.x, be.x), fmaf(fmaf(t[4 * g + 1], rstd, nmr), ga.y, be.y),
+                   fmaf(fmaf(t[4 * g + 2], rstd, nmr), ga.z, be.z), fmaf(fmaf(t[4 * g + 3], rstd, nmr), ga.w, be.w)};
     };
-    K9_T(4);
-    {
-        float mean, rstd;
-        ln_stats(m, a.eps1, mean, rstd);
-        const float nmr = -mean * rstd;
-        {
-            LnOps lp[2];
-            lp[0] = ln_ops(vec, vec + C, 0, h2);
+    // LN1 of tile t, operand sx -> one packed B operand of mlp.0's second half
+    auto ln1_pack = [&](int t, int sx, float nmr, float rstd) {
+        const LnOps p = ln_ops(vec, vec + C, 4 * w + t, sx);
+        const v4f lo = ln_apply(m[t], 2 * sx, p.ga[0], p.be[0], nmr, rstd), hi = ln_apply(m[t], 2 * sx + 1, p.ga[1], p.be[1], nmr, rstd);
+        return pack8<T>(lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w);
+    };
+
+    // ---------------- hid = act(W_1 [x | m]) in four 128-wide slices (the wave: 64 of them = 2 tiles), each consumed by
+    // out += W_2[:, slice] hid (the wave's 4 output tiles) - SOFTWARE-PIPELINED so that no product waits for an exchange:
+    //   stage 0: W_1x(0) [LN1 and the exchange of its output ride in these four blocks] W_1m(0)
+    //   stage s = 1..3: W_1x(s) W_2(s - 1) W_1m(s)        (slice s - 1's packed hidden operands cross the pair behind W_1x(s)'s turns)
+    //   last: W_2(3)
+    // W_1x / W_1m block: 4 k-steps x the wave's 2 hidden tiles; W_2 block: 2 k-steps x its 4 output tiles.
+    v16f o[4];
 #pragma unroll
-            for (int nb = 0; nb < 8; ++nb) {
-                if (nb < 7) lp[(nb + 1) & 1] = ln_ops(vec, vec + C, nb + 1, h2);
+    for (int t = 0; t < 4; ++t) o[t] = zero16();
+    v16f hd[2];
+    auto w1x = [&](int j) { PMma<T>::mma(F[j], X[j >> 1], hd[j & 1]); };
+    auto xh0 = [&](int b) { X[2] = xfrag(4 * b + 2); X[3] = xfrag(4 * b + 3); };
+    auto xh4 = [&](int b) { X[0] = xfrag(4 * b + 4); X[1] = xfrag(4 * b + 5); };
+    // activation + packing of the wave's two hidden tiles into the pair's exchange slots: for ReLU on the PACKED operand
+    // (relu(round(x)) = round(relu(x)))
+    auto act_put = [&] {
 #pragma unroll
-                for (int sx = 0; sx < 2; ++sx) {
-                    const v4f lo = ln_apply(m[nb], 2 * sx, lp[nb & 1], nmr, rstd), hi = ln_apply(m[nb], 2 * sx + 1, lp[nb & 1], nmr, rstd);
-                    mfrag[nb][sx] = pack8<T>(lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w);
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+                Frag f;
+                if constexpr (ACT == 0) {
+                    f = relu_packed(pack_step<T>(hd[t], sx));
+                } else {
+#pragma unroll
+                    for (int r = 8 * sx; r < 8 * sx + 8; ++r) hd[t][r] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * hd[t][r]) + 1.0f);   // tanh, ~1e-6 abs
+                    f = pack_step<T>(hd[t], sx);
                 }
+                ex_put(2 * t + sx, f);
             }
-        }
-    }
-
-    K9_T(5);
-    // ---------------- hid = act(W_1 [x | m]) in four 128-wide slices, each consumed at once by out += W_2[:, slice] hid
-    // per slice 24 steps: 8 (x half: tiles hb = 0..3 x k-steps 2j, 2j+1) + 8 (m half: tile j of m) + 8 (W_2: tiles nb, k-step u)
-    v16f o[8];
-#pragma unroll
-    for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[nb][r] = 0.f;
-#pragma unroll 1
-    for (int sl = 0; sl < 4; ++sl) {
-        v16f hd[4];
-#pragma unroll
-        for (int hb = 0; hb < 4; ++hb) hd[hb] = zero16();            // constant: the first MFMA of each chain takes C = 0 inline
-        if (sl == 1) K9_T(6);
-        Frag t0f = xfrag(0), t1f = xfrag(1);
-#pragma unroll
-        for (int st = 0; st < 8; ++st) {
-            Frag (&cur)[8] = (st & 1) ? fb : fa;
-            Frag (&nxt)[8] = (st & 1) ? fa : fb;
-            Frag n0, n1;
-            ring_step<2>(ring, cur, nxt, st & 3, [&](int j) { Mm::mma(cur[j], j < 4 ? t0f : t1f, hd[j & 3]); },
-                         [&] { n0 = xfrag(st < 7 ? 2 * st + 2 : 14); n1 = xfrag(st < 7 ? 2 * st + 3 : 15); });
-            t0f = n0;
-            t1f = n1;
-        }
-        if (sl == 0) K9_T(10);
-        if (sl == 1) K9_T(13);
-#pragma unroll
-        for (int st = 0; st < 8; ++st) {
-            Frag (&cur)[8] = (st & 1) ? fb : fa;
-            Frag (&nxt)[8] = (st & 1) ? fa : fb;
-            ring_step<0>(ring, cur, nxt, st & 3, [&](int j) { Mm::mma(cur[j], mfrag[st][j >> 2], hd[j & 3]); }, [] {});
-        }
-        if (sl == 0) K9_T(11);
-        if (sl == 1) K9_T(14);
-        // activation + packing of hidden tile hb (32 channels): for ReLU on the PACKED operand - relu(round(x)) = round(relu(x)),
-        // and on 16-bit floats it is 'sign bit set -> 0' (one v_pk_max_i16 per pair).  Tile 0 in front of the W_2 steps, tile
-        // hb + 1 inside steps 2 hb, 2 hb + 1 (a handful of VALU instructions per MFMA gap instead of ~350 in front of the loop).
-        Frag hfrag[4][2];
-        auto act_pack = [&](int hb, int sx) {
-            if constexpr (ACT == 0) {
-                hfrag[hb][sx] = relu_packed(pack_step<T>(hd[hb], sx));
-            } else {
-#pragma unroll
-                for (int r = 8 * sx; r < 8 * sx + 8; ++r) hd[hb][r] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * hd[hb][r]) + 1.0f);     // tanh, ~1e-6 abs
-                hfrag[hb][sx] = pack_step<T>(hd[hb], sx);
-            }
-        };
-        act_pack(0, 0);
-        act_pack(0, 1);
-        if (sl == 0) K9_T(12);
-        if (sl == 1) K9_T(15);
-#pragma unroll
-        for (int st = 0; st < 8; ++st) {                                // out += W_2[:, 128 sl + 16 st .. + 15] hid
-            Frag (&cur)[8] = (st & 1) ? fb : fa;
-            Frag (&nxt)[8] = (st & 1) ? fa : fb;
-            const Frag bf = hfrag[st >> 1][st & 1];
-            ring_step<0>(ring, cur, nxt, st & 3, [&](int nb) { Mm::mma(cur[nb], bf, o[nb]); }, [&] { if (st < 6) act_pack((st >> 1) + 1, st & 1); });
-        }
-    }
-
-    K9_T(7);
-    // ---------------- out = x + LN2(.) (one rounding), per-sample skip predicate, row-contiguous stores through a slab
-    float mean2, rstd2;
-#if defined(K9_ABLATE) && K9_ABLATE == 6
+    };
     {
-        float sacc = 0.f;
+        // ----- stage 0
+        hd[0] = zero16();
+        hd[1] = zero16();
+        float ls = 0.f, lq = 0.f, nmr = 0.f, rstd = 0.f;
+        Frag mo[4];                                                   // the wave's LN1 operands of tiles 2, 3 until their round
+        pblock<2, 2, 2, 8, 10>(ring, F, slot, w1x, [&] { xh0(0); stats_add(m[0], ls, lq); stats_add(m[1], ls, lq); }, [&] {
+            xh4(0);
+            stats_add(m[2], ls, lq);
+            stats_add(m[3], ls, lq);
+            ls = half_sum(ls);
+            lq = half_sum(lq);
+            stats_put(ls, lq);
+        });
+        slot = (slot + 1) % 3;
+        pblock<2, 3, 2, 0, 12>(ring, F, slot, w1x, [&] { xh0(1); }, [&] {
+            xh4(1);
+            float mean;
+            stats_finish(ls, lq, a.eps1, mean, rstd);
+            nmr = -mean * rstd;
 #pragma unroll
-        for (int nb = 0; nb < 8; ++nb) sacc += o[nb][0] + o[nb][15];
-        if (sacc == 1.2345f) ((float*)a.out)[threadIdx.x] = sacc;
-        return;
-    }
+            for (int i = 0; i < 4; ++i) ex_put(i, ln1_pack(i >> 1, i & 1, nmr, rstd));        // round A: the wave's k-steps 0..3
+        });
+        slot = (slot + 1) % 3;
+        pblock<2, 10, 2, 12, 0>(ring, F, slot, w1x, [&] {
+            xh0(2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mo[i] = ln1_pack(2 + (i >> 1), i & 1, nmr, rstd);
+        }, [&] {
+            xh4(2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ma[i] = ex_get(i);
+                ma[8 + i] = ex_get(4 + i);
+            }
+        });
+        slot = (slot + 1) % 3;
+        pblock<2, 0, 2>(ring, F, slot, w1x, [&] { xh0(3); }, [&] {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ex_put(i, mo[i]);                                       // round B: its k-steps 4..7
+        });
+        slot = (slot + 1) % 3;
+#if K9P_TRACE
+        K9P_T(6);
 #endif
-    ln_stats(o, a.eps2, mean2, rstd2);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            auto mm = [&](int j) { PMma<T>::mma(F[j], ma[4 * b + (j >> 1)], hd[j & 1]); };
+            if (b == 0) {
+                pblock<0, 8, 2>(ring, F, slot, mm, [] {}, [&] {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        ma[4 + i] = ex_get(i);
+                        ma[12 + i] = ex_get(4 + i);
+                    }
+                });
+            } else if (b < 3) {
+                pblock<0, 0, 2>(ring, F, slot, mm, [] {}, [] {});
+            } else {
+                pblock<0, 2, 2>(ring, F, slot, mm, [] {}, [&] { X[0] = xfrag(0); X[1] = xfrag(1); });
+            }
+            slot = (slot + 1) % 3;
+        }
+        act_put();
+#if K9P_TRACE
+        K9P_T(7);
+#endif
+    }
+    K9P_T(5);
+    constexpr int STAGE_SLOT = ((ATTN ? NB_Q : 0) + NB_M + 8) % 3;   // 12 blocks per stage: every stage starts in the same slot
+    Frag H[2];                                                        // hidden operands of a W_2 block: H[0] for MFMAs 0..3, H[1] for 4..7
+#pragma unroll 1
+    for (int st = 1; st < 4; ++st) {
+        int slot = STAGE_SLOT;
+        v16f hn[2];                                                   // this stage's hidden accumulators (hd: consumed by act_put above)
+        hn[0] = zero16();
+        hn[1] = zero16();
+        auto w1xn = [&](int j) { PMma<T>::mma(F[j], X[j >> 1], hn[j & 1]); };
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {                                   // W_1x(st); behind its first turn the hidden operands of st - 1 are visible
+            if (b < 3) pblock<2, 2, 2>(ring, F, slot, w1xn, [&] { xh0(b); }, [&] { xh4(b); });
+            else pblock<2, 1, 2>(ring, F, slot, w1xn, [&] { xh0(b); }, [&] { H[0] = ex_get(0); });
+            slot = (slot + 1) % 3;
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {                                   // out += W_2[:, 128 (st - 1) + 32 b .. + 31] hid(st - 1)
+            pblock<1, 1, 2>(ring, F, slot, [&](int j) { PMma<T>::mma(F[j], H[j >> 2], o[j & 3]); }, [&] { H[1] = ex_get(2 * b + 1); },
+                            [&] { if (b < 3) H[0] = ex_get(2 * b + 2); });
+            slot = (slot + 1) % 3;
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {                                   // W_1m(st)
+            auto mm = [&](int j) { PMma<T>::mma(F[j], ma[4 * b + (j >> 1)], hn[j & 1]); };
+            if (b < 3) pblock<0, 0, 2>(ring, F, slot, mm, [] {}, [] {});
+            else pblock<0, 2, 2>(ring, F, slot, mm, [] {}, [&] { X[0] = xfrag(0); X[1] = xfrag(1); });
+            slot = (slot + 1) % 3;
+        }
+        hd[0] = hn[0];
+        hd[1] = hn[1];
+        act_put();
+    }
+    K9P_T(8);
+    {
+        // ----- last: W_2(3).  Its operands cross the pair behind one exchange barrier (no ring turn in between)
+        xbar();
+        int slot = STAGE_SLOT;
+        H[0] = ex_get(0);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            pblock<1, 1, 2>(ring, F, slot, [&](int j) { PMma<T>::mma(F[j], H[j >> 2], o[j & 3]); }, [&] { H[1] = ex_get(2 * b + 1); },
+                            [&] { if (b < 3) H[0] = ex_get(2 * b + 2); });
+            slot = (slot + 1) % 3;
+        }
+    }
+    K9P_T(10);
+
+    // ---------------- out = x + LN2(.) (one rounding), per-sample skip predicate.  The finished values replace the x tile IN PLACE
+    // (a lane overwrites exactly the residual bytes it has just read) and leave for HBM from there: the wave's 32 rows x 256 B
+    // (its channel half), four rows per store instruction.  Only the wave's own bytes are touched: no workgroup barrier.
+    float mean2, rstd2;
+    {
+        float s2 = 0.f, q2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) stats_add(o[t], s2, q2);
+        s2 = half_sum(s2);
+        q2 = half_sum(q2);
+        stats_put(s2, q2);
+        xbar();
+        stats_finish(s2, q2, a.eps2, mean2, rstd2);
+    }
     const float nmr2 = -mean2 * rstd2;
-    K9_T(8);
+    K9P_T(11);
     // the predicate is per sample (flag_rows is a multiple of L in every caller): read it once, wave-uniformly
     const bool keep = a.flag == nullptr || __builtin_amdgcn_readfirstlane(a.flag[((size_t)n * a.L + t0) / a.flag_rows]) != 0;
-    // The finished rows replace the x tile IN PLACE (a lane overwrites exactly the residual bytes it has just read) and leave for
-    // HBM from there, two whole 512-byte rows per store instruction.  [Rounds 2-3 went through a slab in the ring's LDS: the ring had
-    // to be drained first and could not run on into the state tail.]  Only the wave's own 32 rows are touched: no workgroup barrier.
-    T* og = (T*)a.out + (size_t)n * a.L * a.ldo;
-    // one straight-line body per (layer kept?, tile inside the sequence?): as run-time branches inside the loops every join
-    // costs a conservative wait on the stores of the first channel half
-    auto finish = [&](auto keep_c, auto full_c) {
-        constexpr bool KEEP = decltype(keep_c)::value, FULL = decltype(full_c)::value;
+    {
         typedef T v4t __attribute__((ext_vector_type(4)));
-        const int el = fresh_lane();                                    // row offsets recomputed here, not carried through the layer
-        const int er = el & 31, eh2 = el >> 5, erow = wave * 32 + er;
-        // residual x[row][nb*32 + 8g + 4 eh2 ..+3]: 16-B chunk 4 nb + g of the row = k-chunk nb >> 1, slot (4 (nb & 1) + g) ^ swizzle:
-        // eight lane-constant slot addresses, everything else is an immediate offset
-        int xs[8];
+        if (keep) {
+            // residual x[row][nb*32 + 8g + 4 h2 ..+3], nb = 4 w + t: 16-B chunk 4 nb + g of the row = plane nb >> 1, slot
+            // (4 (nb & 1) + g) ^ swizzle: eight lane-constant slot addresses, the rest immediates
+            int xs[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) xs[k] = X_OFF + gf_lds_off(erow, k) + eh2 * 8;
-        struct FinOps { v4t x[4]; LnOps ln; };
-        auto fin_ops = [&](int nb) {
-            FinOps o;
+            for (int k = 0; k < 8; ++k) xs[k] = X_OFF + w * 32768 + gf_lds_off(myrow, k) + h2 * 8;
+            struct FinOps { v4t x[4]; LnOps ln[2]; };
+            auto fin_ops = [&](int t) {
+                FinOps fo;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) o.x[g] = *reinterpret_cast<const v4t*>(smem + xs[4 * (nb & 1) + g] + (nb >> 1) * 16384);
-            if constexpr (KEEP) o.ln = ln_ops(vec + 2 * C, vec + 3 * C, nb, eh2);
-            return o;
-        };
-        if constexpr (KEEP) {
+                for (int g = 0; g < 4; ++g) fo.x[g] = *reinterpret_cast<const v4t*>(smem + xs[4 * (t & 1) + g] + (t >> 1) * 16384);
+                fo.ln[0] = ln_ops(vec + 2 * C, vec + 3 * C, 4 * w + t, 0);
+                fo.ln[1] = ln_ops(vec + 2 * C, vec + 3 * C, 4 * w + t, 1);
+                return fo;
+            };
             FinOps fo[2];
-            fo[0] = fin_ops(0);                                         // the operands of tile nb + 1 are requested before tile nb is computed
+            fo[0] = fin_ops(0);
 #pragma unroll
-            for (int nb = 0; nb < 8; ++nb) {
-                if (nb < 7) fo[(nb + 1) & 1] = fin_ops(nb + 1);
-                const FinOps& p = fo[nb & 1];
+            for (int t = 0; t < 4; ++t) {
+                if (t < 3) fo[(t + 1) & 1] = fin_ops(t + 1);
+                const FinOps& p = fo[t & 1];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const v4f y = ln_apply(o[nb], g, p.ln, nmr2, rstd2);
+                    const v4f y = ln_apply(o[t], g, p.ln[g >> 1].ga[g & 1], p.ln[g >> 1].be[g & 1], nmr2, rstd2);
                     v4t ov;
                     ov[0] = gf_from_float<T>(gf_to_float(p.x[g][0]) + y.x);
                     ov[1] = gf_from_float<T>(gf_to_float(p.x[g][1]) + y.y);
                     ov[2] = gf_from_float<T>(gf_to_float(p.x[g][2]) + y.z);
                     ov[3] = gf_from_float<T>(gf_to_float(p.x[g][3]) + y.w);
-                    *reinterpret_cast<v4t*>(smem + xs[4 * (nb & 1) + g] + (nb >> 1) * 16384) = ov;
+                    *reinterpret_cast<v4t*>(smem + xs[4 * (t & 1) + g] + (t >> 1) * 16384) = ov;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+        K9P_T(17);
         // (layer skipped: out = x, the tile is the result as it stands)
-        // 16-B piece c32 of a row = plane c32 >> 3, slot c32 & 7: lanes 0..31 one row, lanes 32..63 the next
-        const int c32 = el & 31, rsel = el >> 5;
-        v4u rows[16];
+        // 16-B piece c16 of the wave's half row = piece 16 w + c16 of the row: plane 2 w + (c16 >> 3), slot c16 & 7; lanes 16 r .. 16 r + 15
+        // one row.  Buffer stores: rows past the sequence are out of the descriptor's range and dropped (always 8 store instructions:
+        // the ring's counted waits behind them stay exact)
+        T* og = (T*)a.out + (size_t)n * a.L * a.ldo;
+        const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(og, 0, (int)min((long)a.L * a.ldo * 2, 0x7FFFFFFFL), 0x00020000);
+        const int c16 = lane & 15, rsel = lane >> 4;
+        v4u rows[8];
 #pragma unroll
-        for (int it = 0; it < 16; ++it)
-            rows[it] = *reinterpret_cast<const v4u*>(smem + X_OFF + (c32 >> 3) * 16384 + gf_lds_off(wave * 32 + 2 * it + rsel, c32 & 7));
+        for (int it = 0; it < 8; ++it)
+            rows[it] = *reinterpret_cast<const v4u*>(smem + X_OFF + (2 * w + (c16 >> 3)) * 16384 + gf_lds_off(grp * 32 + 4 * it + rsel, c16 & 7));
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int tg = t0 + wave * 32 + 2 * it + rsel;
-            if (FULL || tg < a.L) *reinterpret_cast<v4u*>(og + (size_t)tg * a.ldo + c32 * 8) = rows[it];
+        for (int it = 0; it < 8; ++it) {
+            const int tg = t0 + grp * 32 + 4 * it + rsel;
+            __builtin_amdgcn_raw_buffer_store_b128(rows[it], ors, (int)(tg * a.ldo * 2) + (16 * w + c16) * 16, 0, 0);
         }
-    };
-    using std::integral_constant;
-    const bool full = t0 + TM <= a.L;
-    if (keep) {
-        if (full) finish(integral_constant<bool, true>{}, integral_constant<bool, true>{});
-        else finish(integral_constant<bool, true>{}, integral_constant<bool, false>{});
-    } else {
-        if (full) finish(integral_constant<bool, false>{}, integral_constant<bool, true>{});
-        else finish(integral_constant<bool, false>{}, integral_constant<bool, false>{});
     }
-    K9_T(9);
+    K9P_T(12);
     if constexpr (ATTN) {
         if (tail) {
             // the finished rows (storage type, in the x tile's place) are the source tile of the state: masked or out-of-sequence
             // tokens do not count (linear_attention.py:37-39).  The ring runs on: its next blocks are the tail's W_k | W_v.
-            const int tl = fresh_lane();                                // the tail's lane-derived addresses are computed here, not carried through the layer
-            ring.lane = tl;
-            const int ttok = t0 + wave * 32 + (tl & 31);
+            xbar();                                                    // the pair's other half of the rows is in place
+            const int tl = fresh_lane();                               // the tail's lane-derived values are computed here, not carried through the layer
+            const int ttok = t0 + grp * 32 + (tl & 31);
             const bool ok = ttok < a.L && (a.q_mask == nullptr || a.q_mask[(size_t)n * a.L + min(ttok, a.L - 1)] != 0);
             const unsigned valid = (unsigned)__ballot(ok && (tl >> 5) == 0);
-            kv_tail<T>(ring, fa, fb, smem, valid, a.part + ((size_t)(n - a.tail_first) * a.tiles + tile) * (C * D + C), wave, tl, wave * 64 + tl, 16);
+            kv_tail<T>(ring, F, smem, valid, a.part + ((size_t)(n - a.tail_first) * a.tiles + tile) * (C * D + C), wave, tl, wave * 64 + tl, NBLK % 3);
         }
     }
 }
 
-// The body both enc_kv_state and enc_layer's state tail run: the token tile is in LDS at X_OFF (x-tile layout), the ring's
-// current block is the first block of a W_k | W_v stream with its step-0 fragments in `fa`; `valid` = bit mask of the wave's 32
-// tokens that count.  Ends with the tile's partial state in `dst`; uses ALL of the workgroup's LDS at the end (the tile and the
-// ring are dead by then).
+// The body both enc_pair_state and enc_pair's state tail run: the token tile is in LDS at X_OFF (x-tile layout), the ring's
+// current block (slot `slot0`) is the first block of a W_k | W_v stream with its fragments in `fa`; `valid` = bit mask of the
+// wave's 32 tokens that count.  Here the products are NOT transposed (A = 32 token rows from the LDS tile, B = 32 weight rows): the
+// result has the channel on the lane and the tokens in registers, so the state KV[d][v] = sum_tok phi(k)[tok][d] v[tok][v] - a
+// contraction over the tiles' ROW index - takes both accumulators as MFMA operands directly (phi(k) as A gives phi(k)^T . v).  A wave
+// computes k and v of its four heads (head = channel tile: k_h and v_h belong to the same wave, no exchange).  Ends with the tile's
+// partial state in `dst`; uses ALL of the workgroup's LDS at the end (the tile and the ring are dead by then).
 template <typename T>
-__device__ __forceinline__ void kv_tail(Ring& ring, typename Mma32<T>::Frag (&fa)[8], typename Mma32<T>::Frag (&fb)[8], char* smem, unsigned valid,
-                                        float* dst, int wave, int lane, int tid, int trace_base) {
+__device__ __forceinline__ void kv_tail(Ring& ring, typename Mma32<T>::Frag (&F)[8], char* smem, unsigned valid,
+                                        float* dst, int wave, int lane, int tid, int slot0) {
     using Mm = Mma32<T>;
     using Frag = typename Mm::Frag;
-    const int h2 = lane >> 5, lr = lane & 31;
-    const int myrow = wave * 32 + lr;
-    auto xfrag = [&](int ks) { return *reinterpret_cast<const Frag*>(smem + X_OFF + (ks >> 2) * 16384 + gf_lds_off(myrow, 2 * (ks & 3) + h2)); };
-    auto project = [&](v16f (&acc)[8], auto between) {                  // acc = src tile x W^T: 16 steps (k-step = step)
+    const int h2 = lane >> 5, lr = lane & 31, w = wave & 1, grp = wave >> 1;
+    const int myrow = grp * 32 + lr;
+    auto xfrag = [&](int ks) { return lds_frag<Frag>(smem + X_OFF + (ks >> 2) * 16384 + gf_lds_off(myrow, 2 * (ks & 3) + h2)); };
+    int slot = slot0;
+    auto project = [&](v16f (&acc)[4], auto between) {                  // acc = src tile x W^T: 8 blocks of (2 k-steps x 4 tiles)
 #pragma unroll
-        for (int nb = 0; nb < 8; ++nb)
+        for (int t = 0; t < 4; ++t) acc[t] = zero16();
+        Frag X[2];
+        X[0] = xfrag(0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-        Frag tf = xfrag(0);
-#pragma unroll
-        for (int st = 0; st < 16; ++st) {
-            Frag (&cur)[8] = (st & 1) ? fb : fa;
-            Frag (&nxt)[8] = (st & 1) ? fa : fb;
-            Frag tn;
-            ring_step<1>(ring, cur, nxt, st & 3, [&](int nb) { Mm::mma(tf, cur[nb], acc[nb]); }, [&] { tn = xfrag(st < 15 ? st + 1 : 15); between(st); });
-            tf = tn;
+        for (int b = 0; b < 8; ++b) {
+            pblock<1, 1, 2>(ring, F, slot, [&](int j) { PMma<T>::mma(X[j >> 2], F[j], acc[j & 3]); }, [&] { X[1] = xfrag(2 * b + 1); },
+                            [&] { X[0] = xfrag(b < 7 ? 2 * b + 2 : 15); between(b); });
+            slot = (slot + 1) % 3;
         }
     };
-    // k first; phi(k) = elu + 1, its sum and the packing of head hh as MFMA operands then ride in the gaps of the v projection's
-    // steps 2 hh, 2 hh + 1 (eight values per lane and step: ~60 VALU instructions beside 8 MFMAs) - as a phase of its own between the
-    // two projections they were ~5 of the tail's ~20 thousand cycles with the matrix pipe idle
-    Frag kf[8][2];
-    float ksum[8];
+    // k first; phi(k) = elu + 1, its sum and the packing of head t as MFMA operands then ride in the v projection's blocks 2 t, 2 t + 1
+    Frag kf[4][2];
+    float ksum[4];
     float vm[16];                                                       // 1 / 0 per accumulator row (token) of this lane half
 #pragma unroll
     for (int r = 0; r < 16; ++r) vm[r] = ((valid >> gf_acc_row(r, h2)) & 1u) ? 1.f : 0.f;
-    v16f k[8];
+    v16f k[4];
     project(k, [](int) {});
-    K9_T(trace_base + 0);
     float srun = 0.f;
     auto phi_half = [&](int st) {
         const int hh = st >> 1, sx = st & 1;
@@ -953,61 +803,52 @@ __device__ __forceinline__ void kv_tail(Ring& ring, typename Mma32<T>::Frag (&fa
         if (sx == 0) srun = s;
         else ksum[hh] = half_sum(s);                                  // lane lr = channel d
     };
-    // state of the wave's 32 tokens: head h = channel tile h; rows = d, lane = v
-    v16f kv[8];
+    // state of the wave's 32 tokens and four heads: rows = d, lane = v
+    v16f kv[4];
     {
-        v16f v[8];
-        K9_T(trace_base + 1);
+        v16f v[4];
         project(v, phi_half);
-        K9_T(trace_base + 2);
 #pragma unroll
-        for (int hh = 0; hh < 8; ++hh) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) kv[hh][r] = 0.f;
+        for (int hh = 0; hh < 4; ++hh) {
+            kv[hh] = zero16();
             Mm::mma(kf[hh][0], pack_step<T>(v[hh], 0), kv[hh]);
             Mm::mma(kf[hh][1], pack_step<T>(v[hh], 1), kv[hh]);
         }
     }
-    K9_T(trace_base + 3);
-    // sum of the four waves, then one partial per tile: every wave parks its partial in LDS (4 x 34 KiB: the tile and the ring
-    // are dead by now), and all 256 threads add the four copies - in the order (w0 + w2) + (w1 + w3) - and store the partial
-    // (a tree that ended with ONE wave adding and storing 33 KB took 9 of the kernel's 35 thousand cycles)
-    constexpr int KVN = 8 * 16 * 64, SLOT = KVN + 8 * 64;              // floats per wave: kv[hh][r][lane] | ksum[hh][lane]
+    // sum over the four token groups, one partial per tile: every wave parks its partial in LDS (8 x 17 KiB: the tile and the ring
+    // are dead by now), all 512 threads add the four copies of a half - in the order (g0 + g2) + (g1 + g3) - and store the partial
+    constexpr int KVN = 4 * 16 * 64, SLOT = KVN + 4 * 64;               // floats per wave: kv[hh][r][lane] | ksum[hh][lane]
     float* red = reinterpret_cast<float*>(smem);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the requests behind the stream's end (out of range: zeros) have landed
     __syncthreads();
 #pragma unroll
-    for (int hh = 0; hh < 8; ++hh) {
+    for (int hh = 0; hh < 4; ++hh) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[wave * SLOT + (hh * 16 + r) * 64 + lane] = kv[hh][r];
         red[wave * SLOT + KVN + hh * 64 + lane] = ksum[hh];
     }
     __syncthreads();
-    K9_T(trace_base + 4);
 #pragma unroll 4
-    for (int e = tid; e < KVN; e += 256) {
-        const float sum = (red[e] + red[2 * SLOT + e]) + (red[SLOT + e] + red[3 * SLOT + e]);
-        const int hh = e >> 10, r = (e >> 6) & 15, ln = e & 63;
+    for (int e2 = tid; e2 < 2 * KVN; e2 += 512) {
+        const int wh = e2 >> 12, e = e2 & (KVN - 1);                    // wave half, element of its partial
+        const float* r0 = red + wh * SLOT + e;                          // wave 2 g + wh: group g's copy is 2 SLOT further per group
+        const float sum = (r0[0] + r0[4 * SLOT]) + (r0[2 * SLOT] + r0[6 * SLOT]);
+        const int hh = 4 * wh + (e >> 10), r = (e >> 6) & 15, ln = e & 63;
         dst[(size_t)(hh * D + gf_acc_row(r, ln >> 5)) * D + (ln & 31)] = sum;                               // [c][v]: 128-B runs
     }
-    for (int e = tid; e < 8 * 64; e += 256) {
-        const int ln = e & 63;
-        if (ln < 32) {
-            const int o = KVN + e;
-            dst[C * D + (e >> 6) * D + ln] = (red[o] + red[2 * SLOT + o]) + (red[SLOT + o] + red[3 * SLOT + o]);
-        }
+    if (tid < 256) {
+        const int wh = tid >> 7, e = tid & 127, hh = e >> 5, ln = e & 31;
+        const float* r0 = red + wh * SLOT + KVN + hh * 64 + ln;
+        dst[C * D + (4 * wh + hh) * D + ln] = (r0[0] + r0[4 * SLOT]) + (r0[2 * SLOT] + r0[6 * SLOT]);
     }
 }
 
 // -------------------------------------------------------------------------------------------------------------
-// enc_kv_state: k, v projections of a 128-token source tile and its linear-attention state, in registers.
-// Here the products are NOT transposed (A = 32 token rows from the LDS tile, B = 32 weight rows): the result has
-// the channel on the lane and the tokens in registers, so the state KV[d][v] = sum_tok phi(k)[tok][d] v[tok][v] - a
-// contraction over the tiles' ROW index - takes both accumulators as MFMA operands directly (phi(k) as A gives
-// phi(k)^T . v).  Stream: the four 64-deep blocks of W_k, then the four of W_v.
+// enc_pair_state: k, v projections of a 128-token source tile and its linear-attention state (a pass of its own: the first
+// layer's sources and image 0's rows in front of a 'self' layer).  Stream: 8 blocks of W_k, then 8 of W_v.
 // -------------------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256, 1) void enc_kv_state(EncArgs a) {
+__global__ __launch_bounds__(512) void enc_pair_state(EncArgs a) {
     using Mm = Mma32<T>;
     using Frag = typename Mm::Frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1015,26 +856,28 @@ __global__ __launch_bounds__(256, 1) void enc_kv_state(EncArgs a) {
     const int n = blockIdx.x / a.tiles, tile = blockIdx.x - n * a.tiles;
     const int t0 = tile * TM;
     const T* xg = (const T*)a.x + (size_t)n * a.S * a.ldx;
-    constexpr int NBLK = 8;
-    K9_T(0);
-    Ring ring = ring_make(a.wstream, smem, wave, lane, NBLK);
-    ring_start(ring);
-    load_tile<T>(xg, a.ldx, t0, a.S, smem, X_OFF, tid);
+    Ring ring = ring_make(a.wstream, smem, wave, lane, NB_KV, nullptr, 0);
+    tile_dma<T>(xg, a.ldx, a.S, t0, TM, smem, X_OFF, wave, lane, 8);
+    dma_piece(ring, 0, 0, 0);
+    dma_piece(ring, 0, 0, 1);
+    __builtin_amdgcn_sched_barrier(0);
     // validity of the wave's 32 tokens as a bit mask (tail of the image, padding mask of linear_attention.py:37-39)
-    const int mytok = t0 + wave * 32 + lr;
+    const int mytok = t0 + (wave >> 1) * 32 + lr;
     const bool ok = mytok < a.S && (a.kv_mask == nullptr || a.kv_mask[(size_t)n * a.S + min(mytok, a.S - 1)] != 0);
     const unsigned valid = (unsigned)__ballot(ok && h2 == 0);
-    ring_start2(ring);
-    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");      // block 0 and the tile; block 1's first half stays in flight
+    dma_piece(ring, 1, 1, 0);
+    dma_piece(ring, 1, 1, 1);
+    dma_piece(ring, 2, 2, 0);
+    dma_piece(ring, 2, 2, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");      // block 0 and the tile; blocks 1, 2 stay in flight
     __builtin_amdgcn_s_barrier();
-    K9_T(1);
-    Frag fa[8], fb[8];
-    load_step0(ring, fa);
-    kv_tail<T>(ring, fa, fb, smem, valid, a.part + ((size_t)n * a.tiles + tile) * (C * D + C), wave, lane, tid, 2);
-    K9_T(7);
+    Frag F[8];
+    load_block0(ring, F);
+    kv_tail<T>(ring, F, smem, valid, a.part + ((size_t)n * a.tiles + tile) * (C * D + C), wave, lane, tid, 0);
 }
 
-__global__ void enc_kv_reduce(const float* part, float* fin, int tiles, int len) {
+__global__ void enc_pair_reduce(const float* part, float* fin, int tiles, int len) {
     const int n = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= len) return;
     const float* p = part + (size_t)n * tiles * len + i;
@@ -1052,29 +895,28 @@ __global__ void enc_kv_reduce(const float* part, float* fin, int tiles, int len)
 }
 
 template <typename T>
-int enc_launch(const EncArgs& a, int act, bool attn, hipStream_t st) {
+void pair_launch(const EncArgs& a, int act, bool attn, hipStream_t st) {
     const dim3 grid(a.N * a.tiles);
     if (attn) {
-        if (act == 0) enc_layer<T, 0, true><<<grid, 256, LDS_BYTES, st>>>(a);
-        else enc_layer<T, 1, true><<<grid, 256, LDS_BYTES, st>>>(a);
+        if (act == 0) enc_pair<T, 0, true><<<grid, 512, LDS_BYTES, st>>>(a);
+        else enc_pair<T, 1, true><<<grid, 512, LDS_BYTES, st>>>(a);
     } else {
-        if (act == 0) enc_layer<T, 0, false><<<grid, 256, LDS_BYTES, st>>>(a);
-        else enc_layer<T, 1, false><<<grid, 256, LDS_BYTES, st>>>(a);
+        if (act == 0) enc_pair<T, 0, false><<<grid, 512, LDS_BYTES, st>>>(a);
+        else enc_pair<T, 1, false><<<grid, 512, LDS_BYTES, st>>>(a);
     }
-    return 0;
 }
 
-std::atomic<uint64_t> enc_attr_done{0};
+std::atomic<uint64_t> pair_attr_done{0};
 template <typename K>
-void enc_allow_lds(K kern) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); }
-void enc_init() {
-    if (!gf_first_use_on_device(enc_attr_done)) return;
-    enc_allow_lds(enc_layer<_Float16, 0, true>); enc_allow_lds(enc_layer<_Float16, 1, true>);
-    enc_allow_lds(enc_layer<_Float16, 0, false>); enc_allow_lds(enc_layer<_Float16, 1, false>);
-    enc_allow_lds(enc_kv_state<_Float16>);
-    enc_allow_lds(enc_layer<gf_bf16, 0, true>); enc_allow_lds(enc_layer<gf_bf16, 1, true>);
-    enc_allow_lds(enc_layer<gf_bf16, 0, false>); enc_allow_lds(enc_layer<gf_bf16, 1, false>);
-    enc_allow_lds(enc_kv_state<gf_bf16>);
+void pair_allow_lds(K kern) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); }
+void pair_init() {
+    if (!gf_first_use_on_device(pair_attr_done)) return;
+    pair_allow_lds(enc_pair<_Float16, 0, true>); pair_allow_lds(enc_pair<_Float16, 1, true>);
+    pair_allow_lds(enc_pair<_Float16, 0, false>); pair_allow_lds(enc_pair<_Float16, 1, false>);
+    pair_allow_lds(enc_pair_state<_Float16>);
+    pair_allow_lds(enc_pair<gf_bf16, 0, true>); pair_allow_lds(enc_pair<gf_bf16, 1, true>);
+    pair_allow_lds(enc_pair<gf_bf16, 0, false>); pair_allow_lds(enc_pair<gf_bf16, 1, false>);
+    pair_allow_lds(enc_pair_state<gf_bf16>);
 }
 
 }   // namespace
@@ -1097,21 +939,16 @@ extern "C" int gf_encoder_kv_state(const void* src, long ld, int dtype, int N, i
         gf_set_error("gf_encoder_kv_state: workspace too small");
         return GF_ERR_WORKSPACE;
     }
-    enc_init();
+    pair_init();
     EncArgs a{};
     a.x = src; a.ldx = ld; a.N = N; a.L = S; a.S = S; a.tiles = (S + TM - 1) / TM; a.kv_mask = kv_mask; a.wstream = wstream_kv;
     a.part = (float*)workspace;
     hipStream_t st = (hipStream_t)stream;
     const int len = C * D + C;
     void* pt = gf_prof_begin("enc_kv_state", st, 2.0 * N * (double)S * C * (2.0 * C + 2.0 * D));
-    if (k9_pair()) {
-        gf_k9_pair_state(a, dtype, st);
-        gf_k9_pair_reduce(a.part, kv_state, a.tiles, len, N, st);
-    } else {
-        if (dtype == GF_F16) enc_kv_state<_Float16><<<N * a.tiles, 256, W_OFF + 2 * WBLK + 8192, st>>>(a);
-        else enc_kv_state<gf_bf16><<<N * a.tiles, 256, W_OFF + 2 * WBLK + 8192, st>>>(a);
-        enc_kv_reduce<<<dim3((len + 255) / 256, N), 256, 0, st>>>(a.part, kv_state, a.tiles, len);
-    }
+    if (dtype == GF_F16) enc_pair_state<_Float16><<<N * a.tiles, 512, LDS_BYTES, st>>>(a);
+    else enc_pair_state<gf_bf16><<<N * a.tiles, 512, LDS_BYTES, st>>>(a);
+    enc_pair_reduce<<<dim3((len + 255) / 256, N), 256, 0, st>>>(a.part, kv_state, a.tiles, len);
     gf_prof_end("enc_kv_state", pt, st);
     GF_CHECK_LAUNCH();
     return GF_OK;
@@ -1137,7 +974,7 @@ extern "C" int gf_encoder_layer_kv(const void* x, long ldx, const float* kv_stat
         gf_set_error("gf_encoder_layer_kv: workspace too small");
         return GF_ERR_WORKSPACE;
     }
-    enc_init();
+    pair_init();
     EncArgs a{};
     a.x = x; a.ldx = ldx; a.kvfinal = kv_state; a.q_mask = q_mask; a.wstream = wstream; a.ln = ln_params;
     a.eps1 = eps1; a.eps2 = eps2; a.attn_eps = attn_eps; a.out = out; a.ldo = ldo; a.N = N; a.L = L; a.S = S;
@@ -1148,14 +985,9 @@ extern "C" int gf_encoder_layer_kv(const void* x, long ldx, const float* kv_stat
     const double tail_tok = 2.0 * C * (2.0 * C + 2.0 * D);                // the flops gf_encoder_kv_state declares per source token
     void* pt = gf_prof_begin("enc_layer", st, per_tok * N * (double)L + tail_tok * nt * (double)L);
     const int len = C * D + C;
-    if (k9_pair()) {
-        gf_k9_pair_layer(a, activation, true, dtype, st);
-        gf_k9_pair_reduce(a.part, kv_state_out, a.tiles, len, nt, st);
-    } else {
-        if (dtype == GF_F16) enc_launch<_Float16>(a, activation, true, st);
-        else enc_launch<gf_bf16>(a, activation, true, st);
-        enc_kv_reduce<<<dim3((len + 255) / 256, nt), 256, 0, st>>>(a.part, kv_state_out, a.tiles, len);
-    }
+    if (dtype == GF_F16) pair_launch<_Float16>(a, activation, true, st);
+    else pair_launch<gf_bf16>(a, activation, true, st);
+    enc_pair_reduce<<<dim3((len + 255) / 256, nt), 256, 0, st>>>(a.part, kv_state_out, a.tiles, len);
     gf_prof_end("enc_layer", pt, st);
     GF_CHECK_LAUNCH();
     return GF_OK;
@@ -1175,7 +1007,7 @@ extern "C" int gf_encoder_layer(const void* x, long ldx, const void* msg, long l
     GF_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)msg % 16 == 0 && (uintptr_t)wstream % 16 == 0,
                  "tensors must be 16-byte aligned");
     GF_CHECK_ARG(row_flag == nullptr || flag_rows > 0, "flag_rows must be > 0");
-    enc_init();
+    pair_init();
     EncArgs a{};
     a.x = x; a.ldx = ldx; a.msg = msg; a.ldm = ldm; a.kvfinal = kv_state; a.q_mask = q_mask; a.wstream = wstream; a.ln = ln_params;
     a.eps1 = eps1; a.eps2 = eps2; a.attn_eps = attn_eps; a.out = out; a.ldo = ldo; a.N = N; a.L = L; a.S = S > 0 ? S : 1;
@@ -1185,9 +1017,8 @@ extern "C" int gf_encoder_layer(const void* x, long ldx, const void* msg, long l
     // flops per token: [q 2C^2 + apply 2C(D+1)] + merge 2C^2 + mlp.0 2(2C)(2C) + mlp.2 2(2C)C
     const double per_tok = (attn ? 2.0 * C * C + 2.0 * C * (D + 1) : 0.0) + 2.0 * C * C + 8.0 * C * C + 4.0 * C * C;
     void* pt = gf_prof_begin("enc_layer", st, per_tok * N * (double)L);
-    if (k9_pair()) gf_k9_pair_layer(a, activation, attn, dtype, st);
-    else if (dtype == GF_F16) enc_launch<_Float16>(a, activation, attn, st);
-    else enc_launch<gf_bf16>(a, activation, attn, st);
+    if (dtype == GF_F16) pair_launch<_Float16>(a, activation, attn, st);
+    else pair_launch<gf_bf16>(a, activation, attn, st);
     gf_prof_end("enc_layer", pt, st);
     GF_CHECK_LAUNCH();
     return GF_OK;

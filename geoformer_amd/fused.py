@@ -1,7 +1,8 @@
 """Host side of the fused encoder-layer kernels (csrc/k9_encoder_fused.hip): weight pre-packing and the two ops.
 
 The kernels consume weights as a linear stream of 1-KiB MFMA A fragments (64 lanes x 8 sixteen-bit elements) in
-exactly the order the kernel multiplies them, 32 fragments per 32-KiB block.  Two fragment orders exist:
+exactly the order the kernel multiplies them (K9: 16-KiB blocks of 16 fragments, 8 per wave half; K11: 32-KiB blocks).  Two fragment
+orders exist:
 
   standard   element j of lane l = W[32 nb + (l & 31)][16 ks + 8 (l >> 5) + j]
              (the other operand comes from the token tile in LDS, natural k order)
@@ -11,8 +12,6 @@ exactly the order the kernel multiplies them, 32 fragments per 32-KiB block.  Tw
 Packing happens once per layer and dtype (cached by the modules), with plain torch gathers.
 """
 import ctypes
-
-import os
 
 import torch
 
@@ -48,18 +47,13 @@ def fragments(w, order):
 
 
 def _steps(f, tiles, ksteps):
-    """f [NB, KS, 64, 8] -> stream piece: for each k-step in `ksteps` (a list of lists: the k-steps of one 8-fragment
-    step) the fragments of the tiles `tiles`, k-step-major inside the step."""
+    """f [NB, KS, 64, 8] -> stream piece: for each k-step in `ksteps` (a list of lists: the k-steps of one step) the fragments of the
+    tiles `tiles`, k-step-major inside the step (the fine-level layer's stream, pack_fine_layer_stream)."""
     return torch.cat([f[tiles, ks].reshape(-1) for group in ksteps for ks in group])
 
 
-# development switch of round 6 (must agree with the library's GF_K9_PAIR): '0' = the four-wave kernels of rounds 2-5 and their stream order
-PAIR = os.environ.get('GF_K9_PAIR', '1') != '0'
-HEAD_PIPELINE = False
-
-
 def _pair_block(f, tiles_w0, tiles_w1, ksteps):
-    """One 16-fragment block of the wave-pair kernels (csrc/k9_encoder_pair.hip): fragments 0..7 for wave half 0, 8..15 for half 1;
+    """One 16-fragment block of the wave-pair kernels (csrc/k9_encoder_fused.hip): fragments 0..7 for wave half 0, 8..15 for half 1;
     each half = its tiles x the block's k-steps, k-step-major."""
     return torch.cat([f[torch.as_tensor(tiles, device=f.device), ks].reshape(-1) for tiles in (tiles_w0, tiles_w1) for ks in ksteps])
 
@@ -72,8 +66,6 @@ def pack_layer_stream(wq, wm, w1, w2):
        4 blocks (same, permuted), W_2(sl) = W_2[:, slice]: 4 blocks (k-steps 2 b, 2 b + 1 x the half's 4 output tiles, permuted), in the
        kernel's software-pipelined order (below).   wq may be None (attention computed elsewhere).  1 MiB with W_q (64 blocks), 896 KiB
        without (56)."""
-    if not PAIR:
-        return _pack_layer_stream_r5(wq, wm, w1, w2)
     c = wm.shape[0]
     lo, hi = [0, 1, 2, 3], [4, 5, 6, 7]
     parts = []
@@ -103,37 +95,8 @@ def pack_layer_stream(wq, wm, w1, w2):
 
 def pack_kv_stream(wk, wv):
     """Stream of gf_encoder_kv_state (and of the layer's state tail): W_k in 8 blocks (k-steps 2 b, 2 b + 1 x the half's 4 tiles), then W_v."""
-    if not PAIR:
-        return _pack_kv_stream_r5(wk, wv)
     lo, hi = [0, 1, 2, 3], [4, 5, 6, 7]
     return torch.cat([_pair_block(fragments(w, 'std'), lo, hi, [2 * b, 2 * b + 1]) for w in (wk, wv) for b in range(8)]).contiguous()
-
-
-def _pack_layer_stream_r5(wq, wm, w1, w2):
-    """rounds 2-5 (four-wave kernels): steps of 8 fragments (4 steps = one 32-KiB block):
-       [W_q: 16 steps (k-step ks: tiles 0..7)] + W_m: 16 steps (permuted order) + per 128-wide hidden slice sl
-       { W_1[:, :256]: 8 steps (k-steps 2j, 2j+1 x tiles 4sl..4sl+3), W_1[:, 256:]: 8 steps (same, permuted),
-         W_2[:, slice]: 8 steps (k-step u: tiles 0..7, permuted) }."""
-    c = wm.shape[0]
-    parts = []
-    all8 = torch.arange(8, device=wm.device)
-    fm = fragments(wm, 'perm')
-    if wq is not None:
-        parts.append(_steps(fragments(wq, 'std'), all8, [[ks] for ks in range(16)]))
-    parts.append(_steps(fm, all8, [[ks] for ks in range(16)]))
-    f1x, f1m = fragments(w1[:, :c], 'std'), fragments(w1[:, c:], 'perm')   # [16, 16, 64, 8]
-    pairs = [[2 * j, 2 * j + 1] for j in range(8)]
-    for sl in range(4):
-        tiles = torch.arange(4 * sl, 4 * sl + 4, device=wm.device)
-        parts.append(_steps(f1x, tiles, pairs))
-        parts.append(_steps(f1m, tiles, pairs))
-        parts.append(_steps(fragments(w2[:, 128 * sl:128 * sl + 128], 'perm'), all8, [[u] for u in range(8)]))
-    return torch.cat(parts).contiguous()
-
-
-def _pack_kv_stream_r5(wk, wv):
-    all8 = torch.arange(8, device=wk.device)
-    return torch.cat([_steps(fragments(w, 'std'), all8, [[ks] for ks in range(16)]) for w in (wk, wv)]).contiguous()
 
 
 def _state_out(out, n, C, device):

@@ -1,4 +1,4 @@
-"""Phase timeline of the wave-pair encoder kernel (needs a -DK9P_TRACE=1 build: tools/variant.sh k9p_trace k9_encoder_pair.hip -DK9P_TRACE=1,
+"""Phase timeline of the wave-pair encoder kernel (needs a -DK9P_TRACE=1 build: tools/variant.sh k9p_trace k9_encoder_fused.hip -DK9P_TRACE=1,
 run with GF_LIB_PATH=tools/ab/k9p_trace.so).  Prints median s_memtime offsets (shader cycles) of the phase boundaries."""
 import sys, os, ctypes
 import numpy as np, torch
