@@ -315,12 +315,11 @@ __global__ __launch_bounds__(512) void enc_pair(EncArgs a) {
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    // the token tile and weight block 0 only: a CU's LDS-DMA moves ~30 B per cycle, so the 112 KiB of "tile + three blocks" took ~3.9 thousand
+    // cycles to REQUEST (round 6 trace); blocks 1 and 2 go out behind the prologue's barrier, in front of the first MFMAs
     tile_dma<T>(xg, a.ldx, a.L, t0, TM, smem, X_OFF, wave, lane, 8);
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-        dma_piece(ring, b, b, 0);
-        dma_piece(ring, b, b, 1);
-    }
+    dma_piece(ring, 0, 0, 0);
+    dma_piece(ring, 0, 0, 1);
     __builtin_amdgcn_sched_barrier(0);
     K9P_T(13);
     vec[tid] = lnv0;
@@ -374,11 +373,16 @@ __global__ __launch_bounds__(512) void enc_pair(EncArgs a) {
             xbar();
         }
     }
-    // block 0 and the tile have landed; blocks 1, 2 (the four youngest requests) may still be in flight
+    // block 0 and the tile have landed
     K9P_T(14);
-    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     K9P_T(15);
     __builtin_amdgcn_s_barrier();
+    dma_piece(ring, 1, 1, 0);
+    dma_piece(ring, 1, 1, 1);
+    dma_piece(ring, 2, 2, 0);
+    dma_piece(ring, 2, 2, 1);
+    __builtin_amdgcn_sched_barrier(0);
 
     K9P_T(1);
     Frag F[8];                                                        // the rotating weight fragments (see pblock)
