@@ -329,6 +329,9 @@ def test_fp16_mode_ids_bit_exact_vs_storage_oracle(golden, name):
     assert len(a & b) >= 0.9 * max(len(a), len(b)), (len(a), len(b), len(a & b))
 
 
+OVERLAP_640 = {'fp16': 0.95, 'bf16': 0.80}           # (set from the round-6 measurement below)
+
+
 @pytest.mark.parametrize('precision', ['fp16', 'bf16'])
 def test_640_16bit_mode_vs_storage_oracle(golden, precision):
     """BASELINE size (80x80 grids, L = S = 6400) in the fast modes: panel K1, fused encoder layers, flash self-attention,
@@ -339,9 +342,14 @@ def test_640_16bit_mode_vs_storage_oracle(golden, precision):
     assert len(ref['b_ids']) > 1000
     compare_with_storage_oracle(out, ref, case['coarse_thr'], f'640 {precision}', fine_thr=case['fine_thr'], edge=EDGE[precision],
                                 conf_tol=CONF_TOL[precision], max_diff={'fp16': 14, 'bf16': 30}[precision])     # measured 6-9 / 18-20
+    # ... and against the REFERENCE's own fp32 run of this pair (g11: 1209 coarse matches): the share of its matches the 16-bit mode reproduces,
+    # printed and gated at the measured value minus a margin (VERDICT r05 #2c; measured on MI355X, round 6: see OVERLAP_640)
     a = set(zip(out['i_ids'].tolist(), out['j_ids'].tolist()))
     b = set(zip(G['i_ids'].astype(np.int64).tolist(), G['j_ids'].astype(np.int64).tolist()))
-    assert len(a & b) >= (0.95 if precision == 'fp16' else 0.8) * max(len(a), len(b)), (len(a), len(b), len(a & b))     # vs the reference's own fp32 run
+    overlap = len(a & b) / max(len(a), len(b))
+    print(f'640x640 {precision}: {len(a)} coarse matches, the reference (fp32) {len(b)}, common {len(a & b)} = {overlap:.4f} of the larger set; '
+          f'only here {len(a - b)}, only there {len(b - a)}')
+    assert overlap >= OVERLAP_640[precision], (precision, len(a), len(b), len(a & b))
 
 
 @pytest.mark.parametrize('mode', ['nominal', 'dense', 'nominal_bf16'])
