@@ -1,6 +1,10 @@
 """MIOpen (the backbone's convolutions) plumbing: the repo ships the plain-text user find-db with the tuned
 algorithm picks for the bench / eval shapes on gfx950 (`geoformer_amd/miopen_db/*.udb.txt, *.ufdb.txt`), so
-MIOpen's immediate mode picks them without a multi-minute search.
+MIOpen's immediate mode picks them without a multi-minute search.  Round 6: the find-db also holds the problems of the fp32 parity leg
+and of the two training steps (forward, backward-data and backward-weights of the backbone's convolutions at 640x480x4 and 640x640x8:
+without them the FIRST training step of a process spent ~160 s inside MIOpen - `tools/r06_miopen_db2.sh` is the run that found them),
+and MIOpen's compiled-kernel cache of those picks (`miopen_db/cache/*.ukdb`, a build artefact: git-ignored, it travels with the working
+tree like the built .so; without it the first use of a pick compiles its kernel).
 
 `use_shipped_find_db()` must run before the first convolution of the process.  It points MIOPEN_USER_DB_PATH at
 a PRIVATE per-process copy of the shipped files: several processes (one per GPU) or threads opening the same
@@ -26,7 +30,12 @@ def use_shipped_find_db(force=False):
     for f in glob.glob(os.path.join(SHIPPED, '*.txt')):
         shutil.copy(f, d)
     os.environ['MIOPEN_USER_DB_PATH'] = d
-    os.environ.setdefault('MIOPEN_CUSTOM_CACHE_DIR', os.path.join(d, 'cache'))
+    if 'MIOPEN_CUSTOM_CACHE_DIR' not in os.environ:
+        cache = os.path.join(d, 'cache')
+        os.makedirs(cache, exist_ok=True)
+        for f in glob.glob(os.path.join(SHIPPED, 'cache', '*.ukdb')):      # the compiled kernels of the shipped picks
+            shutil.copy(f, cache)
+        os.environ['MIOPEN_CUSTOM_CACHE_DIR'] = cache
     _private[0] = d
     atexit.register(shutil.rmtree, d, True)
     return d
