@@ -225,6 +225,9 @@ class LocalFeatureTransformer(nn.Module):
         mboth = torch.cat([mask0, mask1], 0) if (same and mask0 is not None) else None
         if same and both.is_cuda and all(ly.fusable(both.dtype) for ly in self.layers):
             return self._forward_fused(both, n, mask0, mask1, mboth)
+        if (not same and feat0.is_cuda and feat0.dim() == 3 and feat0.shape[0] == feat1.shape[0]
+                and all(ly.fusable(feat0.dtype) for ly in self.layers)):
+            return self._forward_fused_unequal(feat0, feat1, mask0, mask1)
         for layer, name in zip(self.layers, self.layer_names):
             if name == 'self':
                 if same:
@@ -244,6 +247,42 @@ class LocalFeatureTransformer(nn.Module):
             else:
                 raise KeyError
         return (both[:n], both[n:]) if same else (feat0, feat1)
+
+    def _forward_fused_unequal(self, f0, f1, m0, m1):
+        """_forward_fused for a pair whose images have DIFFERENT token counts (the HPatches loop: 480x640 against 480x608, data_io.py:16-26;
+        BASELINE configs[1]) - the two images cannot share a launch, but the state tails work per launch: the call that produces an image's
+        rows leaves their state for the call that reads them as its source.  Own gf_encoder_kv_state passes are left for the first layer's
+        two sources and for image 0's rows in front of every later 'self' layer: 5 instead of 16 per forward (round 6; bit-identical
+        features: a tail's state equals a separate pass's, tests/test_encoder_fused.py)."""
+        layers, names = list(self.layers), list(self.layer_names)
+        L0, L1 = f0.shape[1], f1.shape[1]
+        have = {}                                                # image -> state of its current rows under the layer about to run
+        for idx, (layer, name) in enumerate(zip(layers, names)):
+            nxt_layer = layers[idx + 1] if idx + 1 < len(layers) else None
+            nxt_name = names[idx + 1] if nxt_layer is not None else None
+            if name == 'self':
+                st0 = have[0] if 0 in have else layer.kv_state(f0, m0)
+                st1 = have[1] if 1 in have else layer.kv_state(f1, m1)
+                have = {}
+                if nxt_name == 'self':                            # the next layer reads both images' new rows
+                    f0, have[0] = layer.forward_state(f0, st0, L0, m0, tail_layer=nxt_layer, tail_first=0)
+                else:
+                    f0 = layer.forward_state(f0, st0, L0, m0)
+                if nxt_layer is None:
+                    f1 = layer.forward_state(f1, st1, L1, m1)
+                else:                                             # 'cross': its first call reads image 1's rows
+                    f1, have[1] = layer.forward_state(f1, st1, L1, m1, tail_layer=nxt_layer, tail_first=0)
+            elif name == 'cross':                                 # feat1 attends to the UPDATED feat0 (transformer.py:99-100)
+                st1 = have[1] if 1 in have else layer.kv_state(f1, m1)
+                f0, st0 = layer.forward_state(f0, st1, L1, m0, tail_layer=layer, tail_first=0)
+                have = {}
+                if nxt_layer is None:
+                    f1 = layer.forward_state(f1, st0, L0, m1)
+                else:                                             # 'self' and 'cross' alike read image 1's new rows (first)
+                    f1, have[1] = layer.forward_state(f1, st0, L0, m1, tail_layer=nxt_layer, tail_first=0)
+            else:
+                raise KeyError
+        return f0, f1
 
     def _forward_fused(self, both, n, mask0, mask1, mboth):
         """The same schedule (transformer.py:82-104) on the fused 16-bit layer kernels, one launch per layer call: the state a

@@ -208,3 +208,37 @@ def test_transformer_with_state_tails_equals_layer_by_layer(masked):
                 b0 = layer(b0, b1, m0, m1)
                 b1 = layer(b1, b0, m1, m0)
     assert torch.equal(a0, b0) and torch.equal(a1, b1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('masked', [False, True])
+def test_transformer_unequal_pair_with_state_tails_equals_layer_by_layer(masked):
+    """Round 6: a pair whose images have different token counts (the HPatches loop's shapes, BASELINE configs[1]) on the fused path with state
+    tails (5 state passes of their own instead of 16) against the same eight layers run call by call, each with its own gf_encoder_kv_state
+    pass: bit-identical features."""
+    from geoformer_amd.model.modules import LocalFeatureTransformer
+    from geoformer_amd.model.cvpr_ds_config import get_default_cfg
+    cfg = get_default_cfg()['coarse']
+    m = LocalFeatureTransformer(cfg)
+    W = O.make_weights()
+    m.load_state_dict({k[len('loftr_coarse.'):]: v for k, v in W.items() if k.startswith('loftr_coarse.')})
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(19)
+    n, L0, L1 = 1, 4800, 4560
+    f0 = (torch.randn(n, L0, 256, generator=g) * 0.7).to(DEV).to(torch.bfloat16)
+    f1 = (torch.randn(n, L1, 256, generator=g) * 0.7).to(DEV).to(torch.bfloat16)
+    m0 = m1 = None
+    if masked:
+        m0 = torch.ones(n, L0, dtype=torch.bool, device=DEV); m0[0, 4700:] = False
+        m1 = torch.ones(n, L1, dtype=torch.bool, device=DEV); m1[0, :50] = False
+    with torch.no_grad():
+        a0, a1 = m(f0, f1, m0, m1)
+        b0, b1 = f0, f1
+        for layer, name in zip(m.layers, m.layer_names):
+            if name == 'self':
+                b0, b1 = layer(b0, b0, m0, m0), layer(b1, b1, m1, m1)
+            else:
+                b0 = layer(b0, b1, m0, m1)
+                b1 = layer(b1, b0, m1, m0)
+    assert a0.shape == (n, L0, 256) and a1.shape == (n, L1, 256)
+    assert torch.equal(a0, b0) and torch.equal(a1, b1)
