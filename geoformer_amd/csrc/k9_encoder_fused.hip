@@ -7,8 +7,8 @@
 // Replaces LoFTREncoderLayer.forward (model/loftr_src/loftr/loftr_module/transformer.py:37-60, ReLU, linear attention of
 // linear_attention.py:21-51) and the part of its Geo twin after the attention (model/geo_transformer/transformer.py:56-66, Tanh):
 //
-//   enc_pair_state  k, v = W_k src, W_v src ; KV[n,h] = sum_s phi(k_s)^T v_s ; Ksum[n,h] = sum_s phi(k_s)   (one partial per tile)
-//   enc_pair        q = W_q x ; msg = phi(q) KV / (phi(q).Ksum + eps)            (ATTN: linear attention)
+//   enc_kv_state  k, v = W_k src, W_v src ; KV[n,h] = sum_s phi(k_s)^T v_s ; Ksum[n,h] = sum_s phi(k_s)   (one partial per tile)
+//   enc_layer        q = W_q x ; msg = phi(q) KV / (phi(q).Ksum + eps)            (ATTN: linear attention)
 //                   or msg = attention output read from HBM                        (Geo layers: K4 / K5 made it)
 //                   m = LN1(W_m msg) ; hid = act(W_1 [x | m]) ; out = x + LN2(W_2 hid)   [+ the state of `out` for its consumer]
 //
@@ -279,7 +279,7 @@ __device__ __forceinline__ void kv_tail(Ring& ring, typename Mma32<T>::Frag (&F)
                                         float* dst, int wave, int lane, int tid, int slot0);
 
 template <typename T, int ACT, bool ATTN>
-__global__ __launch_bounds__(512) void enc_pair(EncArgs a) {
+__global__ __launch_bounds__(512) void enc_layer(EncArgs a) {
     using Mm = Mma32<T>;
     using Frag = typename Mm::Frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(512) void enc_pair(EncArgs a) {
     }
 }
 
-// The body both enc_pair_state and enc_pair's state tail run: the token tile is in LDS at X_OFF (x-tile layout), the ring's
+// The body both enc_kv_state and enc_layer's state tail run: the token tile is in LDS at X_OFF (x-tile layout), the ring's
 // current block (slot `slot0`) is the first block of a W_k | W_v stream with its fragments in `fa`; `valid` = bit mask of the
 // wave's 32 tokens that count.  Here the products are NOT transposed (A = 32 token rows from the LDS tile, B = 32 weight rows): the
 // result has the channel on the lane and the tokens in registers, so the state KV[d][v] = sum_tok phi(k)[tok][d] v[tok][v] - a
@@ -848,11 +848,11 @@ __device__ __forceinline__ void kv_tail(Ring& ring, typename Mma32<T>::Frag (&F)
 }
 
 // -------------------------------------------------------------------------------------------------------------
-// enc_pair_state: k, v projections of a 128-token source tile and its linear-attention state (a pass of its own: the first
+// enc_kv_state: k, v projections of a 128-token source tile and its linear-attention state (a pass of its own: the first
 // layer's sources and image 0's rows in front of a 'self' layer).  Stream: 8 blocks of W_k, then 8 of W_v.
 // -------------------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(512) void enc_pair_state(EncArgs a) {
+__global__ __launch_bounds__(512) void enc_kv_state(EncArgs a) {
     using Mm = Mma32<T>;
     using Frag = typename Mm::Frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -881,7 +881,7 @@ __global__ __launch_bounds__(512) void enc_pair_state(EncArgs a) {
     kv_tail<T>(ring, F, smem, valid, a.part + ((size_t)n * a.tiles + tile) * (C * D + C), wave, lane, tid, 0);
 }
 
-__global__ void enc_pair_reduce(const float* part, float* fin, int tiles, int len) {
+__global__ void enc_kv_reduce(const float* part, float* fin, int tiles, int len) {
     const int n = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= len) return;
     const float* p = part + (size_t)n * tiles * len + i;
@@ -902,11 +902,11 @@ template <typename T>
 void pair_launch(const EncArgs& a, int act, bool attn, hipStream_t st) {
     const dim3 grid(a.N * a.tiles);
     if (attn) {
-        if (act == 0) enc_pair<T, 0, true><<<grid, 512, LDS_BYTES, st>>>(a);
-        else enc_pair<T, 1, true><<<grid, 512, LDS_BYTES, st>>>(a);
+        if (act == 0) enc_layer<T, 0, true><<<grid, 512, LDS_BYTES, st>>>(a);
+        else enc_layer<T, 1, true><<<grid, 512, LDS_BYTES, st>>>(a);
     } else {
-        if (act == 0) enc_pair<T, 0, false><<<grid, 512, LDS_BYTES, st>>>(a);
-        else enc_pair<T, 1, false><<<grid, 512, LDS_BYTES, st>>>(a);
+        if (act == 0) enc_layer<T, 0, false><<<grid, 512, LDS_BYTES, st>>>(a);
+        else enc_layer<T, 1, false><<<grid, 512, LDS_BYTES, st>>>(a);
     }
 }
 
@@ -915,12 +915,12 @@ template <typename K>
 void pair_allow_lds(K kern) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); }
 void pair_init() {
     if (!gf_first_use_on_device(pair_attr_done)) return;
-    pair_allow_lds(enc_pair<_Float16, 0, true>); pair_allow_lds(enc_pair<_Float16, 1, true>);
-    pair_allow_lds(enc_pair<_Float16, 0, false>); pair_allow_lds(enc_pair<_Float16, 1, false>);
-    pair_allow_lds(enc_pair_state<_Float16>);
-    pair_allow_lds(enc_pair<gf_bf16, 0, true>); pair_allow_lds(enc_pair<gf_bf16, 1, true>);
-    pair_allow_lds(enc_pair<gf_bf16, 0, false>); pair_allow_lds(enc_pair<gf_bf16, 1, false>);
-    pair_allow_lds(enc_pair_state<gf_bf16>);
+    pair_allow_lds(enc_layer<_Float16, 0, true>); pair_allow_lds(enc_layer<_Float16, 1, true>);
+    pair_allow_lds(enc_layer<_Float16, 0, false>); pair_allow_lds(enc_layer<_Float16, 1, false>);
+    pair_allow_lds(enc_kv_state<_Float16>);
+    pair_allow_lds(enc_layer<gf_bf16, 0, true>); pair_allow_lds(enc_layer<gf_bf16, 1, true>);
+    pair_allow_lds(enc_layer<gf_bf16, 0, false>); pair_allow_lds(enc_layer<gf_bf16, 1, false>);
+    pair_allow_lds(enc_kv_state<gf_bf16>);
 }
 
 }   // namespace
@@ -950,9 +950,9 @@ extern "C" int gf_encoder_kv_state(const void* src, long ld, int dtype, int N, i
     hipStream_t st = (hipStream_t)stream;
     const int len = C * D + C;
     void* pt = gf_prof_begin("enc_kv_state", st, 2.0 * N * (double)S * C * (2.0 * C + 2.0 * D));
-    if (dtype == GF_F16) enc_pair_state<_Float16><<<N * a.tiles, 512, LDS_BYTES, st>>>(a);
-    else enc_pair_state<gf_bf16><<<N * a.tiles, 512, LDS_BYTES, st>>>(a);
-    enc_pair_reduce<<<dim3((len + 255) / 256, N), 256, 0, st>>>(a.part, kv_state, a.tiles, len);
+    if (dtype == GF_F16) enc_kv_state<_Float16><<<N * a.tiles, 512, LDS_BYTES, st>>>(a);
+    else enc_kv_state<gf_bf16><<<N * a.tiles, 512, LDS_BYTES, st>>>(a);
+    enc_kv_reduce<<<dim3((len + 255) / 256, N), 256, 0, st>>>(a.part, kv_state, a.tiles, len);
     gf_prof_end("enc_kv_state", pt, st);
     GF_CHECK_LAUNCH();
     return GF_OK;
@@ -991,7 +991,7 @@ extern "C" int gf_encoder_layer_kv(const void* x, long ldx, const float* kv_stat
     const int len = C * D + C;
     if (dtype == GF_F16) pair_launch<_Float16>(a, activation, true, st);
     else pair_launch<gf_bf16>(a, activation, true, st);
-    enc_pair_reduce<<<dim3((len + 255) / 256, nt), 256, 0, st>>>(a.part, kv_state_out, a.tiles, len);
+    enc_kv_reduce<<<dim3((len + 255) / 256, nt), 256, 0, st>>>(a.part, kv_state_out, a.tiles, len);
     gf_prof_end("enc_layer", pt, st);
     GF_CHECK_LAUNCH();
     return GF_OK;
