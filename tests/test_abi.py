@@ -110,3 +110,22 @@ def test_config_and_state_dict_contract():
     from geoformer_amd.weights import deterministic_init_
     m2 = deterministic_init_(GeoFormer(cvpr_ds_config.get_default_cfg(), geo_config.get_cfg_model()))
     assert all(torch.equal(m2.state_dict()[k], W[k]) for k in W)
+
+
+def test_reference_module_paths_resolve_through_the_alias_packages():
+    """inference.py:6-9 / eval_tool/immatch/modules/geoformer.py:6-10 import `model.full_model`, `model.geo_config` and
+    `model.loftr_src.loftr.utils.cvpr_ds_config`: with geoformer_amd/compat on the path those lines resolve to this package unchanged."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('from model.full_model import GeoFormer\n'
+            'from model.geo_config import default_cfg as g\n'
+            'from model.loftr_src.loftr.utils.cvpr_ds_config import default_cfg as c\n'
+            "assert GeoFormer.__module__ == 'geoformer_amd.model.full_model'\n"
+            "assert {'layer_names', 'nhead', 'coarse_thr', 'fine_temperature', 'fine_thr', 'window_size', 'topk'} <= set(g)\n"
+            "assert {'backbone_type', 'resolution', 'coarse', 'match_coarse', 'fine'} <= set(c)\n"
+            "print('ok')\n")
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.path.join(root, 'geoformer_amd', 'compat'))
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == 'ok', r.stderr[-800:]
