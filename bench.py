@@ -172,28 +172,70 @@ def _cpulist(text):
     return out
 
 
-def rank_cpu_set(local, nlocal, allowed=None, sysfs='/sys'):
-    """The host cores rank `local` of `nlocal` on this node should run on: the cores of its GPU's NUMA node (amdgpu PCI functions in
-    bus order = HIP device order; ranks that share a node split its cores), else an even contiguous split of the allowed cores.  Reads
-    sysfs only - nothing here touches the GPU, so it can run before the first HIP call of the process."""
+PIN_RULE = None          # which rule rank_cpu_set used in this process ('numa', 'numa via HIP_VISIBLE_DEVICES', 'even split: <why>'): in the JSON line
+
+
+def _visible_device_index(local, env=None):
+    """The physical device behind local rank `local`: HIP_VISIBLE_DEVICES (applied to what ROCR_VISIBLE_DEVICES leaves visible) as lists of
+    indices.  (index, variable name) - (local, None) when neither is set; (None, name) when a list cannot be read as indices (UUID form) or
+    is too short: the caller then falls back to the even split instead of guessing a NUMA node."""
+    env = os.environ if env is None else env
+    idx, used = local, None
+    for name in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES'):           # HIP's list indexes into ROCr's
+        v = env.get(name)
+        if v is None or v.strip() == '':
+            continue
+        try:
+            ids = [int(t) for t in v.split(',')]
+        except ValueError:
+            return None, name
+        if idx >= len(ids) or ids[idx] < 0:
+            return None, name
+        idx, used = ids[idx], (name if used is None else used + '+' + name)
+    return idx, used
+
+
+def rank_cpu_set(local, nlocal, allowed=None, sysfs='/sys', env=None):
+    """The host cores rank `local` of `nlocal` on this node should run on: the cores of its GPU's NUMA node, shared evenly by the ranks on
+    that node.  The GPU of a rank = the amdgpu PCI functions of DISPLAY / PROCESSING-ACCELERATOR class in bus order (= HIP device order
+    without remapping), indexed by the local rank translated through HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when those are set (a
+    partial lease such as GPUs 4-7).  Whenever that chain has a gap (no sysfs, an unreadable device list, a node without cores) the rule is an
+    even contiguous split of the allowed cores; PIN_RULE records which rule was used.  Reads sysfs only - nothing here touches the GPU,
+    so it can run before the first HIP call of the process."""
+    global PIN_RULE
     allowed = sorted(os.sched_getaffinity(0)) if allowed is None else sorted(allowed)
-    nodes = []
+    nodes, why = [], 'no amdgpu devices in sysfs'
     try:
         drv = os.path.join(sysfs, 'bus/pci/drivers/amdgpu')
         for d in sorted(x for x in os.listdir(drv) if ':' in x):
-            nodes.append(int(open(os.path.join(drv, d, 'numa_node')).read()))
+            try:                                                   # 0x03xxxx display, 0x12xxxx processing accelerator; other functions
+                cls = int(open(os.path.join(drv, d, 'class')).read(), 16) >> 16    # (audio, USB ...) bound to amdgpu are not devices
+            except (OSError, ValueError):
+                cls = 0x03                                         # no class file (the unit test's tree): count it
+            if cls in (0x03, 0x12):
+                nodes.append(int(open(os.path.join(drv, d, 'numa_node')).read()))
     except (OSError, ValueError):
         nodes = []
-    if len(nodes) >= nlocal and all(n >= 0 for n in nodes[:nlocal]):
-        node = nodes[local]
+    dev = [_visible_device_index(r, env) for r in range(nlocal)]
+    via = dev[local][1]
+    if any(i is None for i, _ in dev):
+        why = f'{via} is not a list of indices covering {nlocal} ranks'
+    elif nodes and all(i < len(nodes) and nodes[i] >= 0 for i, _ in dev):
+        mine = [nodes[i] for i, _ in dev]
+        node = mine[local]
         try:
             cores = [c for c in _cpulist(open(os.path.join(sysfs, f'devices/system/node/node{node}/cpulist')).read()) if c in set(allowed)]
         except OSError:
             cores = []
-        sharers = [r for r in range(nlocal) if nodes[r] == node]
+        sharers = [r for r in range(nlocal) if mine[r] == node]
         if len(cores) >= len(sharers):
             k, per = sharers.index(local), len(cores) // len(sharers)
+            PIN_RULE = 'numa' + (f' via {via}' if via else '')
             return cores[k * per:(k + 1) * per]
+        why = f'NUMA node {node} has fewer allowed cores than ranks'
+    elif nodes:
+        why = 'a device index beyond the amdgpu list, or a device without a NUMA node'
+    PIN_RULE = 'even split: ' + why
     per = max(1, len(allowed) // max(nlocal, 1))
     return allowed[local * per:(local + 1) * per] or allowed
 
@@ -254,7 +296,7 @@ def dry_run(args):
     if rank == 0:
         print(json.dumps({'metric': 'image-pairs/sec (640x640)', 'value': 0.0, 'unit': 'image-pairs/s', 'n_gpus': world,
                           'steps': args.steps, 'warmup': args.warmup, 'dry_run': True, 'elapsed_max_s': float(t[0]),
-                          'shard_plan': plan, 'scaling': 'weak', 'rank_cpu_sets': pins}), flush=True)
+                          'shard_plan': plan, 'scaling': 'weak', 'rank_cpu_sets': pins, 'rank_pin_rule': PIN_RULE}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -760,6 +802,7 @@ def main(argv=None):
         # its host launch time per step and the number of host cores it is pinned to (0 = not pinned: a single rank)
         'per_rank': [{'rank': r[3], 'ms_per_step': 1e3 * r[6][0] / args.steps, 'host_launch_us_per_step': r[7], 'pinned_cores': r[8]}
                      for r in sorted(rows, key=lambda r: r[3])],
+        'rank_pin_rule': PIN_RULE,                  # rank 0's rule for its host cores (rank_cpu_set); None = not pinned
         'rank_ms_per_step_min': 1e3 * min(r[6][0] for r in rows) / args.steps,
         'rank_ms_per_step_max': 1e3 * max(r[6][0] for r in rows) / args.steps,     # [rank, first pair, one past the last pair] of the job's pair list
         'config': {'workload': f'batched inference, synthetic {args.size}x{args.size} pairs (BASELINE configs[4]: static shard of the '

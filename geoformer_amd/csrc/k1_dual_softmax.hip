@@ -310,13 +310,20 @@ __global__ __launch_bounds__(NT, 4) void k1_stats(K1Args a) {
 // Round 5: the caching allocator hands the address of a freed feature tensor to the next one of the same shape (the
 // second CoarseMatching pass, the next batch), so pointers alone do not tell whose statistics the workspace holds: the LAST word is a
 // fingerprint of the CONTENT - 32 eight-byte samples of each tensor, evenly spaced, one per lane of a wave, mixed and XOR-reduced.
+// A SAMPLED check (512 bytes): it catches the workspace being reused for other tensors at the same addresses (the case that happens:
+// the caching allocator hands the next batch the same blocks), not an in-place edit of a few rows between the two calls - a caller that
+// edits f0 / f1 in place re-runs the statistics pass (ops.py says so).
 constexpr int K1_STAMP_WORDS = 5;          // the words k1_stamp_word() makes; word K1_STAMP_WORDS is the fingerprint
 __device__ __forceinline__ unsigned long long k1_fingerprint(const void* f0, const void* f1, size_t bytes0, size_t bytes1, int lane) {
     const bool second = lane >= 32;
-    const unsigned long long* p = (const unsigned long long*)(second ? f1 : f0);
-    const size_t words = (second ? bytes1 : bytes0) / 8;
+    const unsigned short* p = (const unsigned short*)(second ? f1 : f0);      // two-byte pieces: a 16-bit tensor at an odd storage offset
+    const size_t words = (second ? bytes1 : bytes0) / 8;                      // is only 2-byte aligned
     const int k = lane & 31;
-    unsigned long long w = words ? p[(words - 1) * (size_t)k / 31] : 0ull;
+    unsigned long long w = 0ull;
+    if (words) {
+        const unsigned short* q = p + 4 * ((words - 1) * (size_t)k / 31);
+        w = (unsigned long long)q[0] | ((unsigned long long)q[1] << 16) | ((unsigned long long)q[2] << 32) | ((unsigned long long)q[3] << 48);
+    }
     w = (w + 0x9e3779b97f4a7c15ull * (unsigned long long)(lane + 1)) * 0xff51afd7ed558ccdull;
     w ^= w >> 33;
     unsigned lo = (unsigned)w, hi = (unsigned)(w >> 32);

@@ -67,8 +67,10 @@ def dual_softmax_conf_at(f0, f1, temperature, b, i, j):
     values).  The workspace is stamped by that call with (N, L, S, C, temperature, the two feature pointers): when the stamp
     does not belong to THESE arguments - another pair of feature tensors was matched since (GeoFormer.forward runs two
     CoarseMatching passes on one workspace), the shape changed - or an index is out of range, the entry comes back NaN.  The stamp also
-    carries a fingerprint of the features' CONTENT (64 sampled 8-byte words): a new tensor that the caching allocator placed at a freed
-    tensor's address does not pass for it.  The features must be contiguous (the very tensors the match call got): a copy made here
+    carries a fingerprint of the features' CONTENT (64 sampled 8-byte words, 512 bytes in all): a new tensor that the caching allocator
+    placed at a freed tensor's address does not pass for it.  It is a SAMPLED check: an in-place edit of the stamped tensors that misses
+    the sampled words (one masked row, say) still passes - after editing the features in place, call dual_softmax_match again before
+    asking for entries.  The features must be contiguous (the very tensors the match call got): a copy made here
     would never carry the stamped pointers."""
     _need_cuda(f0, f1)
     if not (f0.is_contiguous() and f1.is_contiguous()):

@@ -239,11 +239,14 @@ def synthetic_homography_batch(n, hw, seed, device='cpu', max_shift=0.12):
 
 def synthetic_megadepth_batch(n, hw, seed, device='cpu'):
     """A MegaDepth-style batch (BASELINE configs[3]; the keys lightning_depth_geoformer.py:87-99 feeds: image*, depth*, T_*, K*, scale*,
-    mask*, dataset_name) without the dataset: a smooth random texture seen by two cameras 0.27 units apart over a slanted plane at
-    depth ~6 (focal length 180: image 1 is image 0 shifted by ~8 px = one coarse cell, the depth / pose supervision finds those
-    correspondences), zero-padded to (H, W) the way the MegaDepth loader pads to its square size - the bottom eighth of image 0 in the odd
-    samples and the right eighth of image 1 in the even ones are padding (`mask0` / `mask1` at 1/8 scale) -, per-image scales
-    (depth maps live at the original resolution, up to 1.5x the padded one)."""
+    mask*, dataset_name) without the dataset: a smooth random texture, image 1 = image 0 shifted by 8 px (one coarse cell); two cameras
+    0.27 units apart over a slanted plane at depth ~6, focal length 180; zero-padded to (H, W) the way the MegaDepth loader pads to its
+    square size - the bottom eighth of image 0 in the odd samples and the right eighth of image 1 in the even ones are padding
+    (`mask0` / `mask1` at 1/8 scale) -, per-image scales (depth maps live at the original resolution, up to 1.5x the padded one).
+    The SUPERVISION follows the declared geometry (cell * scale -> K, depth, T -> / scale, as spvs_coarse does), not the picture: every
+    sample has one non-unit scale, so its labels say ((x - 8) / 1.5, (y - 8) / 1.25) where the image content says (x - 8, y - 8).  The
+    batch exercises every branch of the supervision (scales, padding masks, depth consistency) at the shapes of configs[3] for the
+    timing leg of bench.py and the loss-falls checks; it is not a realism check and nothing is concluded from the fitted matches."""
     H, W = hw
     g = torch.Generator().manual_seed(seed)
     base = torch.rand(n, 1, H // 8 + 3, W // 8 + 3, generator=g)

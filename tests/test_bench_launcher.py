@@ -95,3 +95,21 @@ def test_rank_cpu_set_follows_the_gpus_numa_nodes(tmp_path):
     # no sysfs information: contiguous even split
     assert bench.rank_cpu_set(1, 4, allowed, str(tmp_path / 'none')) == list(range(8, 16))
     assert bench.rank_cpu_set(0, 1, [3, 4], str(tmp_path / 'none')) == [3, 4]
+    assert bench.PIN_RULE.startswith('even split')
+    # a partial lease: the local rank goes through HIP_VISIBLE_DEVICES - ranks 0, 1 on GPUs 2, 3 = NUMA node 1
+    env = {'HIP_VISIBLE_DEVICES': '2,3'}
+    assert bench.rank_cpu_set(0, 2, allowed, str(root), env) == [8, 9, 10, 11, 12, 13, 14, 15]
+    assert bench.rank_cpu_set(1, 2, allowed, str(root), env) == [24, 25, 26, 27, 28, 29, 30, 31]
+    assert bench.PIN_RULE == 'numa via HIP_VISIBLE_DEVICES'
+    # HIP's list indexes into what ROCr leaves visible
+    env = {'ROCR_VISIBLE_DEVICES': '1,2,3', 'HIP_VISIBLE_DEVICES': '0,2'}
+    assert bench.rank_cpu_set(0, 2, allowed, str(root), env) == list(range(0, 8)) + list(range(16, 24))     # GPU 1: alone on node 0
+    assert bench.rank_cpu_set(1, 2, allowed, str(root), env) == list(range(8, 16)) + list(range(24, 32))    # GPU 3: alone on node 1
+    # a list that cannot be read as indices (UUIDs), or one shorter than the ranks: even split, and the rule says why
+    assert bench.rank_cpu_set(1, 2, allowed, str(root), {'HIP_VISIBLE_DEVICES': 'GPU-abc,GPU-def'}) == list(range(16, 32))
+    assert bench.PIN_RULE.startswith('even split: HIP_VISIBLE_DEVICES')
+    assert bench.rank_cpu_set(1, 2, allowed, str(root), {'HIP_VISIBLE_DEVICES': '3'}) == list(range(16, 32))
+    # functions bound to amdgpu that are not devices (class != display / processing accelerator) do not shift the order
+    d = root / 'bus/pci/drivers/amdgpu' / '0000:05:00.1'
+    d.mkdir(parents=True); (d / 'numa_node').write_text('1\n'); (d / 'class').write_text('0x040300\n')
+    assert bench.rank_cpu_set(0, 4, allowed, str(root), {}) == [0, 1, 2, 3, 4, 5, 6, 7]
