@@ -617,6 +617,53 @@ def linear_attention_backward(q, k, v, dout, nhead, q_mask=None, kv_mask=None, e
     return dq, dkv[0], dkv[1]
 
 
+def _rows16(t, rows):
+    """A [N, rows, C] 16-bit tensor as the training attention kernels take it: last dim contiguous, 16-byte aligned rows with a stride
+    that is a multiple of 8 elements, batch stride = rows x row stride; anything else is copied."""
+    if (t.stride(-1) != 1 or t.data_ptr() % 16 or t.stride(-2) % 8 or t.stride(-2) < t.shape[-1] or
+            (t.shape[0] > 1 and t.stride(0) != rows * t.stride(-2))):
+        t = t.contiguous()
+    return t, t.stride(-2)
+
+
+def full_attention_train_forward(q, k, v, nhead):
+    """K4 (training): softmax(q k^T / sqrt(D)) v of FullAttention (geo_attention.py:72-101, no masks) on q [N,L,256], k, v [N,S,256] 16-bit
+    tensors with 4 heads of 64 -> (out [N,L,256], lse fp32 [N,4,L] = base-2 log-sum-exp of the scaled logits, kept for the backward)."""
+    _need_cuda(q, k, v)
+    N, L, C = q.shape
+    S = k.shape[1]
+    D = C // nhead
+    q, ldq = _rows16(q, L)
+    k, ldk = _rows16(k, S)
+    v, ldv = _rows16(v, S)
+    out = torch.empty(N, L, C, dtype=q.dtype, device=q.device)
+    lse = torch.empty(N, nhead, L, dtype=torch.float32, device=q.device)
+    check(_lib.lib().gf_full_attention_train_forward(_p(q), _p(k), _p(v), _dt(q), N, L, S, nhead, D, ldq, ldk, ldv, 1.0 / D ** 0.5, _p(out), C,
+                                                     _p(lse), _stream()), 'gf_full_attention_train_forward')
+    return out, lse
+
+
+def full_attention_backward(q, k, v, out, dout, lse, nhead):
+    """(dq [N,L,256], dk, dv [N,S,256]) of full_attention_train_forward given its out / lse and dout [N,L,256]."""
+    _need_cuda(q, k, v, out, dout, lse)
+    N, L, C = q.shape
+    S = k.shape[1]
+    D = C // nhead
+    q, ldq = _rows16(q, L)
+    k, ldk = _rows16(k, S)
+    v, ldv = _rows16(v, S)
+    out, ldo = _rows16(out, L)
+    dout, lddo = _rows16(dout, L)
+    dq = torch.empty(N, L, C, dtype=q.dtype, device=q.device)
+    dkv = torch.empty(2, N, S, C, dtype=q.dtype, device=q.device)
+    L_ = _lib.lib()
+    ws = _ws.get('k4bwd', L_.gf_full_attention_backward_workspace_bytes(N, L, nhead), q.device)
+    check(L_.gf_full_attention_backward(_p(q), _p(k), _p(v), _p(out), _p(dout), _p(_contig(lse)), _dt(q), N, L, S, nhead, D, ldq, ldk, ldv, ldo, lddo,
+                                        1.0 / D ** 0.5, _p(dq), _p(dkv[0]), _p(dkv[1]), _p(ws), ws.numel(), _stream()),
+          'gf_full_attention_backward')
+    return dq, dkv[0], dkv[1]
+
+
 def window_linear_attention_backward(q, k, v, dout, eps=1e-6):
     """(dq, dk, dv) [Nw, Lw, 128] of the fine level's window linear attention (8 heads of 16, Lw <= 32, no masks) given dout."""
     _need_cuda(q, k, v, dout)

@@ -101,6 +101,7 @@ def full_attention(q, k, v, kv_mask=None):
 
 
 _HIP_BACKWARD = [False]
+_OWN_FULL_ATTENTION = [True]      # the Geo 'self' layers of the HIP step on csrc/k4_attention_train.hip (False: the library's fused attention, for A/B)
 
 
 def set_hip_backward(on: bool):
@@ -127,6 +128,8 @@ def _encoder_layer_hip(P, prefix, x, source, nhead, kind, x_mask, source_mask):
     elif (kind == 'loftr' and d == 16 and c == 128 and x.shape[1] <= 32 and source.shape[1] == x.shape[1] and x_mask is None
           and source_mask is None):                      # the fine level's 25-token windows: K2's window form and its backward
         msg = HA.window_linear_attention(q, k, v, nhead)
+    elif kind == 'geo' and d == 64 and c == 256 and source_mask is None and _OWN_FULL_ATTENTION[0]:
+        msg = HA.full_attention(q, k, v, nhead)          # GeoTransformer's 'self' layers: K4's training kernels, forward and backward
     else:
         q, k, v = (t.view(n, -1, nhead, d) for t in (q, k, v))
         msg = linear_attention(q, k, v, x_mask, source_mask) if kind == 'loftr' else full_attention(q, k, v, source_mask)

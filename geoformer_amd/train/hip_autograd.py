@@ -124,6 +124,25 @@ class HipLinearAttention(torch.autograd.Function):
         return dq, dk, dv, None, None, None
 
 
+class HipFullAttention(torch.autograd.Function):
+    """FullAttention.forward (geo_attention.py:72-101, no masks) as GeoTransformer's 'self' branch calls it (transformer.py:111-124): q [N,L,256]
+    against the projected inlier rows k, v [N,S,256], 4 heads of 64, 16-bit tensors.  forward = gf_full_attention_train_forward (keeps the
+    rows' log-sum-exp), backward = gf_full_attention_backward (csrc/k4_attention_train.hip: flash form, bit-reproducible)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, nhead):
+        out, lse = ops.full_attention_train_forward(q, k, v, nhead)
+        ctx.nhead = nhead
+        ctx.save_for_backward(q, k, v, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        dq, dk, dv = ops.full_attention_backward(q, k, v, out, dout, lse, ctx.nhead)
+        return dq, dk, dv, None
+
+
 class HipWindowLinearAttention(torch.autograd.Function):
     """LinearAttention.forward on the fine level's windows ([Nw, Lw <= 32, 128], 8 heads of 16, no masks; full_model.py:97-98):
     forward = K2's window form (la_window_mfma), backward = gf_window_linear_attention_backward (csrc/k_train.hip)."""
@@ -267,6 +286,10 @@ def linear_attention(q, k, v, nhead, q_mask=None, kv_mask=None):
 
 def window_linear_attention(q, k, v, nhead):
     return HipWindowLinearAttention.apply(q, k, v, nhead)
+
+
+def full_attention(q, k, v, nhead=4):
+    return HipFullAttention.apply(q, k, v, nhead)
 
 
 def window_cross_attention(q, kmap, vmap, win, nhead=4):

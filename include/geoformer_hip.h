@@ -132,6 +132,27 @@ int gf_window_linear_attention_backward(const void* q, const void* k, const void
                                         float eps, void* dq, void* dk, void* dv, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K4 (training)  FullAttention.forward with saved softmax statistics, and its backward (flash form)
+ * replaces, for the training step, model/geo_transformer/geo_attention.py:72-101 as GeoTransformer's 'self' branch calls it
+ *          (model/geo_transformer/transformer.py:111-124: every cell of an image against the projected rows of its inlier cells,
+ *          no masks) and the autograd backward through it.  Nothing of size L x S is stored.
+ *   q [N, L, 4 x 64], k, v [N, S, 4 x 64]: row-strided views (ld* in elements, multiples of 8, 16-byte aligned rows; batch stride =
+ *   rows x row stride), GF_F16 / GF_BF16; softmax_temp = 1 / sqrt(64) is applied to the fp32 logits (not folded into q).
+ *   forward:  out [N, L, ldo] = softmax(q k^T softmax_temp) v, lse fp32 [N, 4, L] = log2 of the row's sum of exponentials (base 2,
+ *             scaled logits: m + log2 l);  S == 0: out = 0.
+ *   backward: dq [N, L, 256], dk, dv [N, S, 256] (contiguous, `dtype`) given out, dout [N, L, ld] and the forward's lse;
+ *             P and dS are rounded to `dtype` for the second product of each pair, accumulation fp32, partial sums in a fixed
+ *             order (bit-reproducible).  workspace: gf_full_attention_backward_workspace_bytes (the rows' dO . O).
+ * ------------------------------------------------------------------------------------------ */
+int gf_full_attention_train_forward(const void* q, const void* k, const void* v, int dtype, int N, int L, int S, int H, int D, long ldq,
+                                    long ldk, long ldv, float softmax_temp, void* out, long ldo, float* lse, void* stream);
+size_t gf_full_attention_backward_workspace_bytes(int N, int L, int H);
+int gf_full_attention_backward(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
+                               int dtype, int N, int L, int S, int H, int D, long ldq, long ldk, long ldv, long ldo, long lddo,
+                               float softmax_temp, void* dq, void* dk, void* dv, void* workspace, size_t workspace_bytes,
+                               void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * K1 (training)  sparse-supervision focal loss on the dual-softmax confidence, forward and backward
  * replaces, for the training step, CoarseMatching.forward's conf_matrix (coarse_matching.py:113-125) as consumed by
  *          GeoLoss.compute_coarse_loss, focal / sparse_spvs / dual_softmax branch (loftr_loss.py:246-270), and the

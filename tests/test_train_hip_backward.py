@@ -305,3 +305,55 @@ def test_window_cross_attention_backward(dtype):
     for name, x, y in zip(('dq', 'dk', 'dv'), b, a):
         rel = float((x.grad.float() - y.grad.float()).norm() / y.grad.float().norm())
         assert rel < (1e-4 if dtype == torch.float32 else 2e-2), (name, rel)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('N,L,S', [(1, 6400, 1195), (1, 300, 33), (2, 130, 64), (1, 37, 1), (1, 128, 32)])
+def test_full_attention_train_forward_backward(dtype, N, L, S):
+    """GeoTransformer's 'self' attention of the training step (all L cells against the S projected inlier rows, 4 heads of 64, no masks;
+    geo_attention.py:72-101): HipFullAttention - gf_full_attention_train_forward / gf_full_attention_backward, flash form - against
+    autograd of the oracle's explicit full_attention in fp32 on the same 16-bit inputs; ragged query and key tiles, one key, a batch,
+    row-strided views (q, k, v as slices of one fused projection).  The backward is bit-reproducible (no atomics)."""
+    import geoformer_oracle as O
+    from geoformer_amd.train import hip_autograd as HA
+    g = torch.Generator().manual_seed(5 + L + S)
+    C = 256
+    x = (torch.randn(N, L, 3 * C, generator=g) * 1.5).to(DEV).to(dtype)
+    q = x[..., :C]                                         # a row-strided view (ld = 768)
+    k = (torch.randn(N, S, C, generator=g) * 1.5).to(DEV).to(dtype)
+    v = (torch.randn(N, S, C, generator=g)).to(DEV).to(dtype)
+    dout = (torch.randn(N, L, C, generator=g) * 0.5).to(DEV).to(dtype)
+    a = [t.float().clone().requires_grad_(True) for t in (q, k, v)]
+    ref = O.full_attention(a[0].view(N, L, 4, 64), a[1].view(N, S, 4, 64), a[2].view(N, S, 4, 64)).reshape(N, L, C)
+    ref.backward(dout.float())
+    b = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    out = HA.full_attention(*b, 4)
+    out.backward(dout)
+    eps = {torch.float16: 2.0 ** -10, torch.bfloat16: 2.0 ** -7}[dtype]
+    # forward: P rounded to the storage type in the second product, the output rounded once
+    assert float((out.float() - ref).abs().max()) < 3 * eps * max(1.0, float(ref.abs().max()))
+    for name, x_, y_ in zip(('dq', 'dk', 'dv'), b, a):
+        floor = 1e-2 * float(dout.float().norm())          # one key: dq is exactly zero in the reference, rounding noise here
+        rel = float((x_.grad.float() - y_.grad).norm() / y_.grad.norm().clamp_min(floor))
+        assert rel < 4 * eps, (name, rel)
+    # the saved statistics: base-2 log-sum-exp of the scaled logits
+    from geoformer_amd import ops
+    _, lse = ops.full_attention_train_forward(q, k, v, 4)
+    logits = torch.einsum('nlhd,nshd->nhls', q.float().view(N, L, 4, 64), k.float().view(N, S, 4, 64)) * 0.125
+    want = torch.logsumexp(logits, dim=-1) * 1.4426950408889634
+    assert float((lse - want).abs().max()) < 2e-3
+    # reproducible
+    b2 = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    HA.full_attention(*b2, 4).backward(dout)
+    assert all(torch.equal(x_.grad, y_.grad) for x_, y_ in zip(b, b2))
+
+
+def test_full_attention_train_no_keys():
+    """S = 0 (an image without inliers): the forward writes zeros, every gradient is zero."""
+    from geoformer_amd.train import hip_autograd as HA
+    q = torch.randn(1, 70, 256, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    k = torch.zeros(1, 0, 256, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    v = torch.zeros(1, 0, 256, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    out = HA.full_attention(q, k, v, 4)
+    out.backward(torch.ones_like(out))
+    assert float(out.abs().max()) == 0.0 and float(q.grad.abs().max()) == 0.0 and k.grad.shape == (1, 0, 256)
