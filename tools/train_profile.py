@@ -1,5 +1,6 @@
 """Where the training step spends its time (torch profiler, top ops by device time).
-   python tools/train_profile.py [H W] [--no-fused] [--no-prof] [--bf16] [--hip] [--batch B] [--long] [--mega] [--cl] [--hipconv]"""
+   python tools/train_profile.py [H W] [--no-fused] [--no-prof] [--bf16] [--hip] [--batch B] [--long] [--mega] [--cl] [--hipconv] [--stacks]
+   --stacks: additionally the call sites (python stacks) of the elementwise copy / cast kernels by device time"""
 import sys, time, torch
 HW = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 and sys.argv[1].isdigit() else (480, 640)
 FUSED = '--no-fused' not in sys.argv
@@ -28,7 +29,7 @@ for it in range(nsteps):
 if '--no-prof' in sys.argv:
     sys.exit(0)
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes='--stacks' in sys.argv) as prof:
     step(synthetic_homography_batch(B, HW, seed=9, device='cuda')); torch.cuda.synchronize()
 ka = prof.key_averages()
 print(ka.table(sort_by='cuda_time_total', row_limit=25, max_name_column_width=50))
@@ -36,3 +37,14 @@ dev = sum(getattr(e, 'self_device_time_total', getattr(e, 'self_cuda_time_total'
 ncalls = sum(e.count for e in ka if getattr(e, 'self_device_time_total', getattr(e, 'self_cuda_time_total', 0)) > 0)
 print(f'device time (sum over kernels) {dev:.1f} ms in {ncalls} device-side calls; host ops recorded {sum(e.count for e in ka)}')
 print(ka.table(sort_by='self_cpu_time_total', row_limit=15, max_name_column_width=50))
+
+if '--stacks' in sys.argv:          # (python stacks are not recorded on this build: the operand shapes tell the call sites apart)
+    dt = lambda e: getattr(e, 'self_device_time_total', getattr(e, 'self_cuda_time_total', 0))
+    for op in ('aten::copy_', 'aten::add', 'aten::add_', 'aten::mul', 'aten::fill_', 'aten::cat', 'aten::convolution_backward', 'aten::conv2d',
+               'aten::miopen_convolution', 'aten::_convolution'):
+        rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key == op and (dt(e) > 0 or op.startswith('aten::conv'))]
+        key = (lambda e: e.device_time_total) if op.startswith('aten::conv') else dt
+        rows.sort(key=key, reverse=True)
+        print(f'== {op}: {sum(key(e) for e in rows) * 1e-3:.2f} ms in {sum(e.count for e in rows)} calls; by operand shapes')
+        for e in rows[:16]:
+            print(f'   {key(e) * 1e-3:7.3f} ms  x{e.count:4d}  {str(e.input_shapes)[:150]}')
