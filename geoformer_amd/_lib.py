@@ -46,6 +46,9 @@ SIGNATURES = {
                                                     c_void_p, c_void_p]),
     'gf_linear_attention_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long,
                                              c_long, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'gf_conv3x3_wgrad_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    'gf_conv3x3_wgrad_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
+                                      c_void_p]),
     'gf_full_attention_train_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long,
                                                 c_float, c_void_p, c_long, c_void_p, c_void_p]),
     'gf_full_attention_backward_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),

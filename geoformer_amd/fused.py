@@ -329,3 +329,22 @@ def conv3x3(x, wstream, cout, shift=None, residual=None, act=0, slope=0.01, pad1
                                      int(act) | (CONV_PAD16 if pad16 else 0) | (CONV_REM8 if rem8 else 0) | (CONV_S2 if stride == 2 else 0),
                                      float(slope), _dt(x), _stream()), 'gf_conv3x3_nhwc')
     return out
+
+
+def conv3x3_wgrad(x, dy, cin=None, cout=None):
+    """K10 (training): dW fp32 [cout, cin, 3, 3] of y = conv3x3(x, W, stride 1, pad 1) from channels_last 16-bit x [N, cx, H, W] and
+    dy [N, cy, H, W]; cin / cout = the real widths when the maps carry padding channels (default: the stored ones)."""
+    _need_cuda(x, dy)
+    for t in (x, dy):
+        if t.dim() != 4 or not t.is_contiguous(memory_format=torch.channels_last):
+            raise ValueError('conv3x3_wgrad expects channels_last [N, C, H, W] tensors')
+    N, cx, H, W = x.shape
+    cy = dy.shape[1]
+    if dy.shape[0] != N or tuple(dy.shape[2:]) != (H, W) or dy.dtype != x.dtype:
+        raise ValueError('x and dy must agree in batch, size and dtype')
+    cin, cout = int(cin or cx), int(cout or cy)
+    dw = torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=x.device)
+    L_ = _lib.lib()
+    ws = _ws.get('k10wgrad', L_.gf_conv3x3_wgrad_workspace_bytes(N, H, W, cin, cout), x.device)
+    check(L_.gf_conv3x3_wgrad_nhwc(_p(x), _p(dy), _dt(x), N, H, W, cx, cy, cin, cout, _p(dw), _p(ws), ws.numel(), _stream()), 'gf_conv3x3_wgrad_nhwc')
+    return dw

@@ -237,12 +237,16 @@ def conv3x3_supported(x, w, stride=1):
     return cip is not None and cop is not None and fused.conv3x3_supported(cip, cop) and fused.conv3x3_supported(cop, cip)
 
 
+_OWN_CONV_WGRAD = [True]      # the weight gradients of HipConv3x3 on csrc/k10_conv3x3_wgrad.hip (False: aten::convolution_backward, for A/B)
+
+
 class HipConv3x3(torch.autograd.Function):
     """y = conv2d(x, w, stride 1, padding 1), no bias (the backbone's BasicBlock / FPN-head convolutions, resnet_fpn.py:9-40,60-83): forward on
     K10 (`gf_conv3x3_nhwc`, no epilogue - train-mode BatchNorm follows as its own op), backward-DATA on K10 as well - dX = conv(dY, w'),
     w'[ci, co, ky, kx] = w[co, ci, 2 - ky, 2 - kx]: the same kernel on dY with the transposed, flipped weights - and backward-WEIGHTS on
-    the library (aten::convolution_backward, output_mask = weights only).  x: 16-bit channels_last; w: fp32 master or 16-bit
-    [cout, cin, 3, 3]; 196-channel operands are zero-padded to 224 on the way in and sliced on the way out (one copy each)."""
+    K10's weight-gradient kernel (`gf_conv3x3_wgrad_nhwc`, round 6: pixels as the contraction index, bit-reproducible).  x: 16-bit
+    channels_last; w: fp32 master or 16-bit [cout, cin, 3, 3]; 196-channel operands are zero-padded to 224 on the way in (the padded
+    x is what is kept for the backward) and sliced on the way out (one copy each)."""
 
     @staticmethod
     def forward(ctx, x, w):
@@ -250,28 +254,33 @@ class HipConv3x3(torch.autograd.Function):
         w16 = w if w.dtype == x.dtype else WEIGHTS.cast(w, x.dtype)
         co, ci = w16.shape[:2]
         cop, cip = _pad_width(co), _pad_width(ci)
-        y = fused.conv3x3(_pad_channels(x, cip), _conv_stream(w16, cop, cip), cop)
+        xp = _pad_channels(x, cip)
+        y = fused.conv3x3(xp, _conv_stream(w16, cop, cip), cop)
         if cop != co:
             y = y[:, :co].contiguous(memory_format=torch.channels_last)
         ctx.wdtype = w.dtype
-        ctx.save_for_backward(x, w16)
+        ctx.save_for_backward(xp, w16)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         from .. import fused
-        x, w16 = ctx.saved_tensors
+        xp, w16 = ctx.saved_tensors
         co, ci = w16.shape[:2]
         cop, cip = _pad_width(co), _pad_width(ci)
         dx = dw = None
+        dyp = _pad_channels(dy, cop)
         if ctx.needs_input_grad[0]:
             wt = w16.flip(2, 3).transpose(0, 1)                            # [cin, cout, 3, 3]
-            dx = fused.conv3x3(_pad_channels(dy, cop), _conv_stream(wt, cip, cop), cip)
+            dx = fused.conv3x3(dyp, _conv_stream(wt, cip, cop), cip)
             if cip != ci:
                 dx = dx[:, :ci].contiguous(memory_format=torch.channels_last)
         if ctx.needs_input_grad[1]:
-            dyc = dy if dy.is_contiguous(memory_format=torch.channels_last) else dy.contiguous(memory_format=torch.channels_last)
-            dw = torch.ops.aten.convolution_backward(dyc, x, w16, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+            if _OWN_CONV_WGRAD[0]:
+                dw = fused.conv3x3_wgrad(xp, dyp, ci, co)
+            else:
+                dw = torch.ops.aten.convolution_backward(dyp[:, :co], xp[:, :ci], w16, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                         [False, True, False])[1]
             dw = dw.to(ctx.wdtype)
         return dx, dw
 

@@ -132,6 +132,19 @@ int gf_window_linear_attention_backward(const void* q, const void* k, const void
                                         float eps, void* dq, void* dk, void* dv, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K10 (training)  weight gradient of the backbone's 3x3 / stride 1 / pad 1 convolutions
+ * replaces, for the training step, autograd's weight gradient of the BasicBlock / FPN-head convolutions
+ *          (model/loftr_src/loftr/backbone/resnet_fpn.py:9-40,60-83; the library call is aten::convolution_backward, weights only).
+ *   x  channels-last [N, H, W, cx], dy channels-last [N, H, W, cy] (GF_F16 / GF_BF16; cx, cy = STORED widths, multiples of 8 - the
+ *   196-channel level is stored 224 wide), cin <= cx, cout <= cy the real widths;
+ *   dw fp32 [cout][cin][3][3] (overwritten) = sum_n,y,x dy[n,y,x,co] * x[n, y+ky-1, x+kx-1, ci]; fp32 accumulation, partial sums
+ *   per run of strip rows added in a fixed order (bit-reproducible).  workspace: gf_conv3x3_wgrad_workspace_bytes.
+ * ------------------------------------------------------------------------------------------ */
+size_t gf_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int cin, int cout);
+int gf_conv3x3_wgrad_nhwc(const void* x, const void* dy, int dtype, int N, int H, int W, int cx, int cy, int cin, int cout, float* dw,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * K4 (training)  FullAttention.forward with saved softmax statistics, and its backward (flash form)
  * replaces, for the training step, model/geo_transformer/geo_attention.py:72-101 as GeoTransformer's 'self' branch calls it
  *          (model/geo_transformer/transformer.py:111-124: every cell of an image against the projected rows of its inlier cells,
