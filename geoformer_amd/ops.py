@@ -24,8 +24,22 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_raw_device = getattr(torch._C, '_cuda_getDevice', None)
+
+
+def _stream_handle(device=None):
+    """torch's current HIP stream (of `device`, default: the current device) as an integer handle.  Through the two C-level getters when
+    this torch build has them: torch.cuda.current_stream() costs ~8 us of Python per call - a millisecond per batch-1 pair at 113 launches."""
+    if _raw_stream is not None and _raw_device is not None:
+        idx = _raw_device() if device is None else (device.index if isinstance(device, torch.device) else device)
+        if isinstance(idx, int):
+            return _raw_stream(idx)
+    return torch.cuda.current_stream(device).cuda_stream
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_stream_handle())
 
 
 def _need_cuda(*ts):
@@ -41,7 +55,7 @@ class _Workspaces:
         self.bufs = {}
 
     def get(self, tag, nbytes, device):
-        key = (device, tag, torch.cuda.current_stream(device).cuda_stream)
+        key = (device, tag, _stream_handle(device))
         b = self.bufs.get(key)
         if b is None or b.numel() < nbytes:
             b = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
