@@ -329,7 +329,9 @@ def test_fp16_mode_ids_bit_exact_vs_storage_oracle(golden, name):
     assert len(a & b) >= 0.9 * max(len(a), len(b)), (len(a), len(b), len(a & b))
 
 
-OVERLAP_640 = {'fp16': 0.95, 'bf16': 0.80}           # (set from the round-6 measurement below)
+# share of the reference's fp32 coarse matches (g11: 1209) the 16-bit modes reproduce at 640 x 640; measured on MI355X in round 6: fp16 1205 of
+# 1209 common (0.9967; 1 only here, 4 only there), bf16 1199 (0.9917; 8 / 10).  Gates = measured minus a margin of about as many matches again.
+OVERLAP_640 = {'fp16': 0.992, 'bf16': 0.982}
 
 
 @pytest.mark.parametrize('precision', ['fp16', 'bf16'])
