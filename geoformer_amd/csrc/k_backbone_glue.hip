@@ -120,18 +120,20 @@ struct StArgs {
     const void* img;        // [N][H][W]
     const float* w;         // [128][7][7], BatchNorm scale folded in
     const float* shift;     // [128]
-    _Float16* out;          // [N][Ho][Wo][128]
+    void* out;              // [N][Ho][Wo][128] of the compute type (fp16 / bf16)
     int N, H, W, Ho, Wo;
     int tiles_x, tiles_y;   // 32-pixel x 4-row output tiles
 };
 
-template <typename TI>
+template <typename TI, typename T>
 __global__ __launch_bounds__(256, 2) void stem_conv(StArgs a) {
+    using Frag = typename Mma32<T>::Frag;
+    typedef T v4t __attribute__((ext_vector_type(4)));
     constexpr int TW = 72, TH = 14, RS = 272;
-    __shared__ __attribute__((aligned(16))) _Float16 tile[TH * TW];
+    __shared__ __attribute__((aligned(16))) T tile[TH * TW];
     __shared__ __attribute__((aligned(16))) char slab[4 * 32 * RS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, lr = lane & 31;
-    v8h wf[4][4];
+    Frag wf[4][4];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv(StArgs a) {
             const int ky = 2 * g + h;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                wf[nb][g][j] = (ky < 7 && j < 7) ? (_Float16)a.w[(nb * 32 + lr) * 49 + ky * 7 + j] : (_Float16)0.f;
+                wf[nb][g][j] = (ky < 7 && j < 7) ? (T)a.w[(nb * 32 + lr) * 49 + ky * 7 + j] : (T)0.f;
         }
     float sh[4][16];
 #pragma unroll
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv(StArgs a) {
     // the image pixels of a tile: requested into registers one tile AHEAD, in front of the previous tile's output stores (the memory
     // counter retires in issue order: requested behind them, every tile waited for its predecessor's stores to come back)
     constexpr int NPRE = (TH * TW + 255) / 256;
-    _Float16 pre[NPRE];
+    T pre[NPRE];
     auto request = [&](long t) {
         const int tx = (int)(t % a.tiles_x);
         const long q = t / a.tiles_x;
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv(StArgs a) {
         for (int i = 0; i < NPRE; ++i) {
             const int e = tid + 256 * i, r = e / TW, c = e % TW;
             const int y = 8 * ty - 3 + r, x = 64 * tx - 3 + c;
-            pre[i] = (e < TH * TW && y >= 0 && y < a.H && x >= 0 && x < a.W) ? (_Float16)gf_to_float(img[(long)y * a.W + x]) : (_Float16)0.f;
+            pre[i] = (e < TH * TW && y >= 0 && y < a.H && x >= 0 && x < a.W) ? (T)gf_to_float(img[(long)y * a.W + x]) : (T)0.f;
         }
     };
     if ((long)blockIdx.x < ntiles) request(blockIdx.x);
@@ -185,9 +187,9 @@ __global__ __launch_bounds__(256, 2) void stem_conv(StArgs a) {
         for (int g = 0; g < 4; ++g) {
             const uint32_t* src = reinterpret_cast<const uint32_t*>(tile + (2 * wave + 2 * g + h) * TW + 2 * lr);
             v4u raw{src[0], src[1], src[2], src[3]};
-            const v8h tf = __builtin_bit_cast(v8h, raw);
+            const Frag tf = __builtin_bit_cast(Frag, raw);
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[nb][g], tf, acc[nb], 0, 0, 0);
+            for (int nb = 0; nb < 4; ++nb) Mma32<T>::mma(wf[nb][g], tf, acc[nb]);
         }
         // shift + ReLU, lane = pixel ox0 + lr of row oy0 + wave; channels nb*32 + acc_row(r, h)
         char* ot = slab + wave * 32 * RS;
@@ -196,23 +198,23 @@ __global__ __launch_bounds__(256, 2) void stem_conv(StArgs a) {
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const int c = nb * 32 + 8 * r4 + 4 * h;
-                v4h o;
+                v4t o;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) o[k] = (_Float16)fmaxf(acc[nb][4 * r4 + k] + sh[nb][4 * r4 + k], 0.f);
-                *reinterpret_cast<v4h*>(ot + lr * RS + c * 2) = o;
+                for (int k = 0; k < 4; ++k) o[k] = (T)fmaxf(acc[nb][4 * r4 + k] + sh[nb][4 * r4 + k], 0.f);
+                *reinterpret_cast<v4t*>(ot + lr * RS + c * 2) = o;
             }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int oy = oy0 + wave;
         if (oy < a.Ho) {
-            _Float16* orow = a.out + (((long)n * a.Ho + oy) * a.Wo + ox0) * 128;
+            T* orow = (T*)a.out + (((long)n * a.Ho + oy) * a.Wo + ox0) * 128;
             const int prow = lane >> 4, pch = lane & 15;
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int px = it * 4 + prow;
                 if (ox0 + px < a.Wo)
-                    *reinterpret_cast<v8h*>(orow + px * 128 + pch * 8) = *reinterpret_cast<const v8h*>(ot + px * RS + pch * 16);
+                    *reinterpret_cast<Frag*>(orow + px * 128 + pch * 8) = *reinterpret_cast<const Frag*>(ot + px * RS + pch * 16);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -282,20 +284,31 @@ extern "C" int gf_upsample_add_nhwc(const void* lo, const void* hi, void* out, i
     return GF_OK;
 }
 
-extern "C" int gf_stem_conv7x7(const void* image, int image_dtype, const float* weight, const float* shift, void* out,
-                               int N, int H, int W, int C, void* stream) {
+extern "C" int gf_stem_conv7x7_dt(const void* image, int image_dtype, const float* weight, const float* shift, void* out, int out_dtype,
+                                  int N, int H, int W, int C, void* stream) {
     GF_CHECK_ARG(image && weight && shift && out, "null pointer");
     GF_CHECK_ARG(N > 0 && H > 0 && W > 0, "empty problem");
-    GF_CHECK_ARG(image_dtype == GF_F32 || image_dtype == GF_F16, "image dtype must be GF_F32 or GF_F16");
+    GF_CHECK_ARG(image_dtype == GF_F32 || image_dtype == out_dtype, "image dtype must be GF_F32 or the output's");
+    GF_CHECK_ARG(out_dtype == GF_F16 || out_dtype == GF_BF16, "output dtype must be GF_F16 or GF_BF16");
     GF_CHECK_ARG(C == 128, "the stem kernel is built for 128 output channels (resnetfpn.initial_dim)");
     GF_CHECK_ARG((uintptr_t)out % 16 == 0, "output must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const int Ho = (H + 2 * 3 - 7) / 2 + 1, Wo = (W + 2 * 3 - 7) / 2 + 1;
-    StArgs a{image, weight, shift, (_Float16*)out, N, H, W, Ho, Wo, (Wo + 31) / 32, (Ho + 3) / 4};
+    StArgs a{image, weight, shift, out, N, H, W, Ho, Wo, (Wo + 31) / 32, (Ho + 3) / 4};
     const long ntiles = (long)N * a.tiles_x * a.tiles_y;
     const int blocks = (int)(ntiles < 512 ? ntiles : 512);               // persistent: two workgroups per CU
-    if (image_dtype == GF_F32) stem_conv<float><<<blocks, 256, 0, st>>>(a);
-    else stem_conv<_Float16><<<blocks, 256, 0, st>>>(a);
+    if (out_dtype == GF_F16) {
+        if (image_dtype == GF_F32) stem_conv<float, _Float16><<<blocks, 256, 0, st>>>(a);
+        else stem_conv<_Float16, _Float16><<<blocks, 256, 0, st>>>(a);
+    } else {
+        if (image_dtype == GF_F32) stem_conv<float, gf_bf16><<<blocks, 256, 0, st>>>(a);
+        else stem_conv<gf_bf16, gf_bf16><<<blocks, 256, 0, st>>>(a);
+    }
     GF_CHECK_LAUNCH();
     return GF_OK;
+}
+
+extern "C" int gf_stem_conv7x7(const void* image, int image_dtype, const float* weight, const float* shift, void* out,
+                               int N, int H, int W, int C, void* stream) {
+    return gf_stem_conv7x7_dt(image, image_dtype, weight, shift, out, GF_F16, N, H, W, C, stream);
 }

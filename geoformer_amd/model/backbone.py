@@ -124,7 +124,7 @@ class FusedInferenceBackbone:
         # 1 -> 128 channel 7x7 stem: own implicit-GEMM kernel (conv + shift + ReLU, NHWC out); other widths
         # go through MIOpen like the rest
         self.stem_hip = None
-        if dtype == torch.float16 and tuple(bb.conv1.weight.shape) == (128, 1, 7, 7) and bb.conv1.stride == (2, 2):
+        if dtype in (torch.float16, torch.bfloat16) and tuple(bb.conv1.weight.shape) == (128, 1, 7, 7) and bb.conv1.stride == (2, 2):
             self.stem_hip = (_fold(bb.conv1, bb.bn1, torch.float32)[0].contiguous(), self.stem[1])
         self.blocks = []
         self._pad16 = {}
@@ -214,7 +214,7 @@ class FusedInferenceBackbone:
 
     def __call__(self, x):
         if self.stem_hip is not None:
-            x = ops.stem_conv7x7(x.contiguous(), *self.stem_hip)
+            x = ops.stem_conv7x7(x.contiguous() if x.dtype in (torch.float32, self.dtype) else x.float().contiguous(), *self.stem_hip, dtype=self.dtype)
         else:
             x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
             x = ops.bias_act_(self._conv(x, self.stem[0], 2), self.stem[1], None, ops.ACT_RELU)

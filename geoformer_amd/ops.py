@@ -217,18 +217,18 @@ def conv1x1(x, weight, stride=1):
     return out
 
 
-def stem_conv7x7(image, weight, shift):
-    """Backbone stem: image [N,1,H,W] (fp32/fp16, contiguous), weight fp32 [128,1,7,7] (BN folded), shift fp32 [128]
-    -> relu(conv 7x7 / stride 2 / pad 3 + shift), fp16 channels_last [N,128,Ho,Wo]."""
+def stem_conv7x7(image, weight, shift, dtype=torch.float16):
+    """Backbone stem: image [N,1,H,W] (fp32 or `dtype`, contiguous), weight fp32 [128,1,7,7] (BN folded), shift fp32 [128]
+    -> relu(conv 7x7 / stride 2 / pad 3 + shift), `dtype` (fp16 / bf16) channels_last [N,128,Ho,Wo]."""
     _need_cuda(image, weight, shift)
     N, one, H, W = image.shape
     if one != 1 or not image.is_contiguous():
         raise ValueError('stem_conv7x7 needs a contiguous [N,1,H,W] image')
     C = weight.shape[0]
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    out = torch.empty(N, C, Ho, Wo, dtype=torch.float16, device=image.device, memory_format=torch.channels_last)
-    check(_lib.lib().gf_stem_conv7x7(_p(image), _dt(image), _p(weight), _p(shift), _p(out), N, H, W, C, _stream()),
-          'gf_stem_conv7x7')
+    out = torch.empty(N, C, Ho, Wo, dtype=dtype, device=image.device, memory_format=torch.channels_last)
+    check(_lib.lib().gf_stem_conv7x7_dt(_p(image), _dt(image), _p(weight), _p(shift), _p(out), _DTYPES[dtype], N, H, W, C, _stream()),
+          'gf_stem_conv7x7_dt')
     return out
 
 

@@ -475,6 +475,10 @@ int gf_conv1x1_nhwc(const void* x, const void* w, void* out, int N, int H, int W
  *                         image [N,H,W] fp32 or fp16, weight fp32 [C,7,7], shift fp32 [C], out fp16 [N,Ho,Wo,C], C = 128 */
 int gf_stem_conv7x7(const void* image, int image_dtype, const float* weight, const float* shift, void* out, int N,
                     int H, int W, int C, void* stream);
+/*   gf_stem_conv7x7_dt:   the same with the output / compute type as an argument (GF_F16 or GF_BF16: the operands of the matrix product
+ *                         are rounded to it, accumulation fp32); image fp32 or of that type. */
+int gf_stem_conv7x7_dt(const void* image, int image_dtype, const float* weight, const float* shift, void* out, int out_dtype, int N,
+                       int H, int W, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K8  fine matching

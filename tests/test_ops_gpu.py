@@ -913,21 +913,24 @@ def test_conv3x3_rejects_unsupported():
         fused.conv3x3(x, torch.zeros(128 * 128 * 9, device='cuda', dtype=torch.float16), 128)
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+@pytest.mark.parametrize('dtype,out_dtype', [(torch.float32, torch.float16), (torch.float16, torch.float16), (torch.float32, torch.bfloat16),
+                                             (torch.bfloat16, torch.bfloat16)])
 @pytest.mark.parametrize('hw', [(64, 96), (37, 51), (480, 640)])
-def test_stem_conv_vs_torch(dtype, hw):
-    """7x7/2 stem + shift + ReLU against torch's fp32 convolution of the same fp16-rounded operands."""
+def test_stem_conv_vs_torch(dtype, out_dtype, hw):
+    """7x7/2 stem + shift + ReLU against torch's fp32 convolution of the same operands rounded to the compute type (fp16; bf16 since round 6:
+    the bf16 mode's stem had been a library convolution with its layout passes)."""
     from geoformer_amd import ops
     torch.manual_seed(6)
     H, W = hw
     img = torch.rand(2, 1, H, W, device='cuda').to(dtype)
     w = torch.randn(128, 1, 7, 7, device='cuda') * 0.2
     b = torch.randn(128, device='cuda') * 0.1
-    out = ops.stem_conv7x7(img, w, b)
-    ref = torch.relu(torch.nn.functional.conv2d(img.half().float(), w.half().float(), b, 2, 3))
-    assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
-    # fp32 accumulation of exact fp16 products; one fp16 rounding of the result
-    assert torch.allclose(out.float(), ref, atol=2e-3, rtol=2e-3), (out.float() - ref).abs().max().item()
+    out = ops.stem_conv7x7(img, w, b, dtype=out_dtype)
+    ref = torch.relu(torch.nn.functional.conv2d(img.to(out_dtype).float(), w.to(out_dtype).float(), b, 2, 3))
+    assert out.dtype == out_dtype and out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
+    # fp32 accumulation of exact 16-bit products; one rounding of the result to the storage type
+    tol = 2e-3 if out_dtype == torch.float16 else 1.6e-2
+    assert torch.allclose(out.float(), ref, atol=tol, rtol=tol), (out.float() - ref).abs().max().item()
 
 
 def test_conv1x1_upsample_add_vs_torch():
