@@ -101,6 +101,7 @@ def full_attention(q, k, v, kv_mask=None):
 
 
 _HIP_BACKWARD = [False]
+_BATCHED_GEO = [True]             # the Geo layers' per-token operations once per layer on all images of the batch (False: image by image, for A/B)
 _OWN_FULL_ATTENTION = [True]      # the Geo 'self' layers of the HIP step on csrc/k4_attention_train.hip (False: the library's fused attention, for A/B)
 
 
@@ -149,15 +150,52 @@ def _finish_layer_hip(P, prefix, x, x16, msg, kind):
 
 
 def _geo_cross_layer_hip(P, prefix, x, kmap, vmap, win, nhead):
-    """One side of GeoTransformer's 'cross' layer (geo_transformer/transformer.py:125-139) on the HIP Functions: x [L, C] attends to
-    the 25 window positions `win` [L, 25] (cells of the other image, -1 = masked) of the other image's PROJECTED maps kmap / vmap
-    [S, C] (project-then-gather: k_proj / v_proj have no bias, so gathering their outputs equals projecting the gathered rows)."""
+    """One side of GeoTransformer's 'cross' layer (geo_transformer/transformer.py:125-139) on the HIP Functions: x [L, C] (or a batch
+    [A, L, C]) attends to the 25 window positions `win` [A, L, 25] (cells of the other image, -1 = masked) of the other image's PROJECTED
+    maps kmap / vmap [A, S, C] (project-then-gather: k_proj / v_proj have no bias, so gathering their outputs equals projecting the
+    gathered rows)."""
     from . import hip_autograd as HA
     dt = torch.get_autocast_dtype('cuda')
-    x16 = x.to(dt)[None]
+    single = x.dim() == 2
+    xb = x[None] if single else x
+    x16 = xb.to(dt)
     q = HA.linear(x16, P[prefix + 'q_proj.weight'])
     msg = HA.window_cross_attention(q, kmap, vmap, win, nhead)
-    return _finish_layer_hip(P, prefix, x[None], x16, msg, 'geo')[0]
+    out = _finish_layer_hip(P, prefix, xb, x16, msg, 'geo')
+    return out[0] if single else out
+
+
+def _geo_self_layers_batched(P, prefix, feats, idxs, nhead):
+    """GeoTransformer's 'self' layer (transformer.py:111-124) for ALL images of the batch in one chain of HIP Functions: the per-token
+    operations (q / k / v projections, merge, LayerNorms, MLP) run once on the concatenated rows of every image that has inlier cells -
+    per image they were 6400-row GEMMs at a tenth of the batched rate, 16 launches each where one does - and only the attention core runs
+    per image (its key sets differ in length).  Same arithmetic per token as _encoder_layer_hip; images without inliers pass through."""
+    from . import hip_autograd as HA
+    dt = torch.get_autocast_dtype('cuda')
+    act = [i for i, ix in enumerate(idxs) if ix.numel()]
+    if not act:
+        return feats
+    lens = [feats[i].shape[0] for i in act]
+    X = torch.cat([feats[i] for i in act], 0)[None]                     # [1, T, C] fp32 residual stream
+    X16 = X.to(dt)
+    rows, o = [], 0
+    for i, l in zip(act, lens):
+        rows.append(X16[0, o:o + l].index_select(0, idxs[i]))
+        o += l
+    src = torch.cat(rows, 0)[None]
+    q = HA.linear(X16, P[prefix + 'q_proj.weight'])
+    k = HA.linear(src, P[prefix + 'k_proj.weight'])
+    v = HA.linear(src, P[prefix + 'v_proj.weight'])
+    msgs, o, so = [], 0, 0
+    for i, l in zip(act, lens):
+        S = idxs[i].numel()
+        msgs.append(HA.full_attention(q[:, o:o + l], k[:, so:so + S], v[:, so:so + S], nhead))
+        o, so = o + l, so + S
+    out = _finish_layer_hip(P, prefix, X, X16, torch.cat(msgs, 1), 'geo')[0].split(lens, 0)
+    feats = list(feats)
+    for j, i in enumerate(act):
+        feats[i] = out[j]
+    return feats
 
 
 def encoder_layer(P, prefix, x, source, nhead, kind, x_mask=None, source_mask=None):
@@ -314,7 +352,31 @@ def geo_module(P, cnn0, cnn1, data, geo_cfg, homography_fn: Callable):
     cells = [None] * n                      # HIP path: (win1 cells, win0 cells) int32 [1, L, 25] per sample, -1 = masked
     for idx, name in enumerate(geo_cfg['layer_names']):
         lp = f'geo_module.des_transformer.layers.{idx}.'
-        if name == 'self':
+        hip = _HIP_BACKWARD[0] and cnn0.is_cuda and torch.is_autocast_enabled() and c == 256 and nhead == 4
+        if name == 'self' and hip and _OWN_FULL_ATTENTION[0] and _BATCHED_GEO[0]:
+            both = _geo_self_layers_batched(P, lp, f0 + f1, idx0 + idx1, nhead)
+            f0, f1 = both[:n], both[n:]
+        elif name == 'cross' and hip and wsz == 5 and _BATCHED_GEO[0]:
+            # K5 forward and backward in HIP on the projected maps (both images' keys / values from the PRE-update features, :126-129), all
+            # samples that have a homography in one batch per side
+            from . import hip_autograd as HA
+            dt = torch.get_autocast_dtype('cuda')
+            act = [b for b in range(n) if win1[b] is not None]
+            if act:
+                for b in act:
+                    if cells[b] is None:
+                        with torch.no_grad():
+                            cells[b] = tuple(torch.where(m, (k[..., 1] // scale) * wk_ + k[..., 0] // scale, -1).to(torch.int32)[None].contiguous()
+                                             for k, m, wk_ in ((win1[b], msk1[b], ww1), (win0[b], msk0[b], ww0)))
+                X0, X1 = torch.stack([f0[b] for b in act]), torch.stack([f1[b] for b in act])
+                s0, s1 = X0.to(dt), X1.to(dt)
+                k0, v0 = HA.linear(s0, P[lp + 'k_proj.weight']), HA.linear(s0, P[lp + 'v_proj.weight'])
+                k1, v1 = HA.linear(s1, P[lp + 'k_proj.weight']), HA.linear(s1, P[lp + 'v_proj.weight'])
+                o0 = _geo_cross_layer_hip(P, lp, X0, k1, v1, torch.cat([cells[b][0] for b in act], 0), nhead)
+                o1 = _geo_cross_layer_hip(P, lp, X1, k0, v0, torch.cat([cells[b][1] for b in act], 0), nhead)
+                for j, b in enumerate(act):
+                    f0[b], f1[b] = o0[j], o1[j]
+        elif name == 'self':
             for b in range(n):
                 if idx0[b].numel():
                     f0[b] = encoder_layer(P, lp, f0[b][None], f0[b].index_select(0, idx0[b])[None], nhead, 'geo')[0]

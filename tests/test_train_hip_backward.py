@@ -357,3 +357,49 @@ def test_full_attention_train_no_keys():
     out = HA.full_attention(q, k, v, 4)
     out.backward(torch.ones_like(out))
     assert float(out.abs().max()) == 0.0 and float(q.grad.abs().max()) == 0.0 and k.grad.shape == (1, 0, 256)
+
+
+def test_batched_geo_layers_equal_the_image_by_image_form():
+    """Round 6: the HIP step runs the Geo layers' per-token operations once per layer on all images of the batch (functional._BATCHED_GEO) and
+    only the attention cores per image.  Against the image-by-image form on the same batch and weights: every loss term equal to 1e-5
+    relative (the forward's per-token arithmetic does not depend on the batching), the total loss's parameter gradients aligned (the weight
+    gradients are sums over other chunks of rows), MegaDepth-style batch with masks and per-image scales as well as the homography batch."""
+    from geoformer_amd.model.cvpr_ds_config import get_default_cfg
+    from geoformer_amd.model.full_model import GeoFormer
+    from geoformer_amd.model.geo_config import get_cfg_model
+    from geoformer_amd.train import TrainStep, synthetic_homography_batch, synthetic_megadepth_batch
+    from geoformer_amd.train import functional as TF
+    from geoformer_amd.train.hip_autograd import WEIGHTS
+    for make, hw in ((synthetic_homography_batch, (128, 256)), (synthetic_megadepth_batch, (192, 192))):
+        res = {}
+        for batched in (False, True):
+            g = get_cfg_model()
+            g.update(coarse_thr=0.0, fine_thr=0.0, precision='fp32')
+            model = GeoFormer(get_default_cfg(), g)
+            sd = model.state_dict(); O.closed_form_fill(sd); model.load_state_dict(sd)
+            model.cuda()
+            step = TrainStep(model, trainer_cfg={'warmup_step': 0, 'canonical_lr': 1e-2, 'gradient_clipping': 0.0}, batch_size=3,
+                             fused_coarse_loss=True, precision='bf16', hip_backward=True)
+            batch = make(3, hw, seed=77, device='cuda')
+            TF._BATCHED_GEO[0] = batched
+            TF.set_hip_backward(True)
+            try:
+                loss = step.core(batch)
+                step.optimizer.zero_grad(set_to_none=True)
+                loss.backward()
+            finally:
+                TF.set_hip_backward(False)
+                TF._BATCHED_GEO[0] = True
+                WEIGHTS.clear()
+            grads = {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
+            res[batched] = ({k: float(v) for k, v in batch['loss_scalars'].items()}, grads)
+        (s0, g0), (s1, g1) = res[False], res[True]
+        print(f'{make.__name__}: image by image {s0} | batched {s1}')
+        for k in s0:
+            assert s1[k] == pytest.approx(s0[k], rel=1e-5, abs=1e-7), (k, s0, s1)
+        geo = [n for n in g0 if n in g1 and n.startswith('geo_module')]
+        assert len(geo) >= 20
+        dot = sum(float((g0[n] * g1[n]).sum()) for n in geo)
+        na, nb = (sum(float((g[n] ** 2).sum()) for n in geo) ** 0.5 for g in (g0, g1))
+        print(f'   cosine of the Geo layers\' gradients {dot / (na * nb):.6f}, norms {na:.4e} {nb:.4e}')
+        assert dot / (na * nb) > 0.999 and abs(na - nb) < 2e-2 * na
