@@ -435,7 +435,9 @@ def test_full_size_training_step(style):
     assert all(np.isfinite(l1)) and min(l1[1:]) < l1[0] and l1[-1] < l1[0] + 0.05, l1
     assert all(np.isfinite(l0)) and min(l0[1:]) < l0[0], l0
     for k in ('loss_c', 'loss_d'):
-        assert s1[k] == pytest.approx(s0[k], rel=2e-2), (k, s0, s1)
+        # 4 %: the autocast step alone spreads by 1.7 % from run to run on one box (loss_c 3.085 / 3.091 / 3.116 / 3.136 in four runs of round 6;
+        # the library's kernels are not bit-reproducible), so the 2 % of earlier rounds failed one run in a few
+        assert s1[k] == pytest.approx(s0[k], rel=4e-2), (k, s0, s1)
     assert n1 > 100 * B / 4
 
 
@@ -523,4 +525,6 @@ def test_hip_conv_training_step_matches_the_autocast_step():
     print(f'library convolutions: losses {l0}, first-step terms {s0} | HipConv3x3: losses {l1}, {s1}')
     assert all(np.isfinite(l1)) and min(l1[1:]) < l1[0], l1
     for k in ('loss_c', 'loss_d'):
-        assert s1[k] == pytest.approx(s0[k], rel=2e-2), (k, s0, s1)
+        # 4 %: the autocast step alone spreads by 1.7 % from run to run on one box (loss_c 3.085 / 3.091 / 3.116 / 3.136 in four runs of round 6;
+        # the library's kernels are not bit-reproducible), so the 2 % of earlier rounds failed one run in a few
+        assert s1[k] == pytest.approx(s0[k], rel=4e-2), (k, s0, s1)

@@ -197,7 +197,9 @@ def test_hip_backward_train_step_matches_autocast_step():
     (s0, g0, l0), (s1, g1, l1) = res[False], res[True]
     print(f'autocast {s0} losses {l0} | hip backward {s1} losses {l1}')
     for k in ('loss_c', 'loss_d'):
-        assert s1[k] == pytest.approx(s0[k], rel=2e-2), (k, s0, s1)
+        # 4 %: the autocast step alone spreads by 1.7 % from run to run on one box (loss_c 3.085 / 3.091 / 3.116 / 3.136 in four runs of round 6;
+        # the library's kernels are not bit-reproducible), so the 2 % of earlier rounds failed one run in a few
+        assert s1[k] == pytest.approx(s0[k], rel=4e-2), (k, s0, s1)
     common = [n for n in g0 if n in g1 and n.startswith('loftr_coarse')]
     assert len(common) >= 40
     dot = sum(float((g0[n] * g1[n]).sum()) for n in common)
@@ -361,45 +363,54 @@ def test_full_attention_train_no_keys():
 
 def test_batched_geo_layers_equal_the_image_by_image_form():
     """Round 6: the HIP step runs the Geo layers' per-token operations once per layer on all images of the batch (functional._BATCHED_GEO) and
-    only the attention cores per image.  Against the image-by-image form on the same batch and weights: every loss term equal to 1e-5
-    relative (the forward's per-token arithmetic does not depend on the batching), the total loss's parameter gradients aligned (the weight
-    gradients are sums over other chunks of rows), MegaDepth-style batch with masks and per-image scales as well as the homography batch."""
-    from geoformer_amd.model.cvpr_ds_config import get_default_cfg
-    from geoformer_amd.model.full_model import GeoFormer
-    from geoformer_amd.model.geo_config import get_cfg_model
-    from geoformer_amd.train import TrainStep, synthetic_homography_batch, synthetic_megadepth_batch
+    only the attention cores per image.  functional.geo_module on fixed feature maps, matches and homographies (the whole step is not
+    bit-reproducible upstream: the library's train-mode convolutions), batched against image by image: outputs bit-equal (the per-token
+    arithmetic does not depend on the batching), input gradients equal to 16-bit rounding of a handful of elements (K5's backward adds with
+    atomics), the Geo layers' parameter gradients aligned (sums over other chunks of rows).  Three samples: one with a homography and 60
+    inlier cells, one with 5 matches (no RANSAC: self layers only), one without any match (every layer skipped)."""
     from geoformer_amd.train import functional as TF
     from geoformer_amd.train.hip_autograd import WEIGHTS
-    for make, hw in ((synthetic_homography_batch, (128, 256)), (synthetic_megadepth_batch, (192, 192))):
-        res = {}
-        for batched in (False, True):
-            g = get_cfg_model()
-            g.update(coarse_thr=0.0, fine_thr=0.0, precision='fp32')
-            model = GeoFormer(get_default_cfg(), g)
-            sd = model.state_dict(); O.closed_form_fill(sd); model.load_state_dict(sd)
-            model.cuda()
-            step = TrainStep(model, trainer_cfg={'warmup_step': 0, 'canonical_lr': 1e-2, 'gradient_clipping': 0.0}, batch_size=3,
-                             fused_coarse_loss=True, precision='bf16', hip_backward=True)
-            batch = make(3, hw, seed=77, device='cuda')
-            TF._BATCHED_GEO[0] = batched
-            TF.set_hip_backward(True)
-            try:
-                loss = step.core(batch)
-                step.optimizer.zero_grad(set_to_none=True)
-                loss.backward()
-            finally:
-                TF.set_hip_backward(False)
-                TF._BATCHED_GEO[0] = True
-                WEIGHTS.clear()
-            grads = {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
-            res[batched] = ({k: float(v) for k, v in batch['loss_scalars'].items()}, grads)
-        (s0, g0), (s1, g1) = res[False], res[True]
-        print(f'{make.__name__}: image by image {s0} | batched {s1}')
-        for k in s0:
-            assert s1[k] == pytest.approx(s0[k], rel=1e-5, abs=1e-7), (k, s0, s1)
-        geo = [n for n in g0 if n in g1 and n.startswith('geo_module')]
-        assert len(geo) >= 20
-        dot = sum(float((g0[n] * g1[n]).sum()) for n in geo)
-        na, nb = (sum(float((g[n] ** 2).sum()) for n in geo) ** 0.5 for g in (g0, g1))
-        print(f'   cosine of the Geo layers\' gradients {dot / (na * nb):.6f}, norms {na:.4e} {nb:.4e}')
-        assert dot / (na * nb) > 0.999 and abs(na - nb) < 2e-2 * na
+    h, w, n = 20, 24, 3
+    g = torch.Generator().manual_seed(9)
+    W = O.make_weights()
+    cells = torch.randperm((h - 2) * (w - 2), generator=g)[:60]
+    mk0 = torch.stack([cells % (w - 2), cells // (w - 2)], 1).float() * 8
+    mk0b = torch.tensor([[0., 0.], [8., 16.], [24., 8.], [56., 40.], [40., 32.]])
+    data0 = {'image0': torch.zeros(n, 1, h * 8, w * 8), 'image1': torch.zeros(n, 1, h * 8, w * 8), 'hw0_i': torch.tensor([h * 8, w * 8]),
+             'hw0_c': torch.tensor([h, w]), 'mkpts0_c': torch.cat([mk0, mk0b]).cuda(), 'mkpts1_c': torch.cat([mk0 + 8, mk0b.flip(0)]).cuda(),
+             'm_bids': torch.cat([torch.zeros(60, dtype=torch.long), torch.ones(5, dtype=torch.long)]).cuda()}
+    M = torch.tensor([[1., 0, 8], [0, 1, 8], [0, 0, 1]], dtype=torch.float64)
+    hfn = lambda b, kp0, kp1: (M, torch.ones(len(kp0), dtype=torch.bool, device=kp0.device))
+    c0 = torch.randn(n, 256, h, w, generator=g).cuda()
+    c1 = torch.randn(n, 256, h, w, generator=g).cuda()
+    dout = [torch.randn(n, h * w, 256, generator=g).cuda() for _ in range(2)]
+    res = {}
+    for batched in (False, True):
+        P = {k: v.detach().clone().cuda().requires_grad_(True) for k, v in W.items() if k.startswith('geo_module.')}
+        a0, a1 = c0.clone().requires_grad_(True), c1.clone().requires_grad_(True)
+        TF._BATCHED_GEO[0] = batched
+        TF.set_hip_backward(True)
+        try:
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                o0, o1 = TF.geo_module(P, a0, a1, dict(data0), O.default_geo_config(), hfn)
+            (o0 * dout[0]).sum().add((o1 * dout[1]).sum()).backward()
+        finally:
+            TF.set_hip_backward(False)
+            TF._BATCHED_GEO[0] = True
+            WEIGHTS.clear()
+        res[batched] = (o0.detach(), o1.detach(), a0.grad, a1.grad, {k: v.grad for k, v in P.items() if v.grad is not None})
+    r0, r1 = res[False], res[True]
+    assert torch.equal(r0[0], r1[0]) and torch.equal(r0[1], r1[1])
+    for k in (2, 3):
+        d = (r0[k] - r1[k]).abs().max() / r0[k].abs().max()
+        assert float(d) < 2e-2, (k, float(d))
+        assert float((r0[k] - r1[k]).norm() / r0[k].norm()) < 1e-2          # measured 3e-3: bf16 gradients, K5's atomic adds
+    names = [k for k in r0[4] if k in r1[4]]
+    assert len(names) >= 20 and len(names) == len(r0[4])
+    dot = sum(float((r0[4][k] * r1[4][k]).sum()) for k in names)
+    na, nb = (sum(float((r[4][k] ** 2).sum()) for k in names) ** 0.5 for r in (r0, r1))
+    print(f'Geo layers batched against image by image: outputs bit-equal, cosine of the parameter gradients {dot / (na * nb):.6f}, norms {na:.4e} {nb:.4e}')
+    assert dot / (na * nb) > 0.9995 and abs(na - nb) < 1e-2 * na
+    # the sample without matches: every layer skipped - its rows leave as they came (position encoding added), its gradient is dout
+    pe = TF.add_pe(c0[2:3]).flatten(2).transpose(1, 2)[0]
+    assert torch.equal(r1[0][2], pe) and torch.equal(r1[2][2], dout[0][2].transpose(0, 1).reshape(256, h, w))
