@@ -419,8 +419,10 @@ class Pipelines:
                 job = self.jobs[w].get()
                 if job is None:
                     return
-                first, count = job
+                first, count = job[:2]
                 try:
+                    if len(job) > 2 and job[2] > 0 and w > 0:
+                        time.sleep(w * job[2])      # staggered start (see run)
                     for i in (range(first, first + 1) if count == 0 else range(first + w, first + count, self.n)):
                         out = self.step_fn(i)
                         self._record(i, out)
@@ -436,7 +438,11 @@ class Pipelines:
         if isinstance(r, BaseException):
             raise r
 
-    def run(self, first, count):
+    def run(self, first, count, stagger=0.0):
+        """`stagger` (seconds): pipeline w starts w * stagger late.  Two pipelines that start a region together at batch 1 often stay IN PHASE for the
+        whole region - both enqueue at the same time (sharing the interpreter), then both wait for the device: ~230 pairs/s where the out-of-phase
+        mode (one enqueues while the other's kernels run) gives ~530 and one stream alone 318 (tools/b1_pipeline_probe.py, round 6); half a step of
+        stagger starts them out of phase.  The headline region does not use it (8-pair steps are device-bound in either phase)."""
         if self.serial:
             for i in range(first, first + count):
                 out = self.step_fn(i)
@@ -445,7 +451,7 @@ class Pipelines:
             self.torch.cuda.synchronize()
             return
         for w in range(self.n):
-            self.jobs[w].put((first, count))
+            self.jobs[w].put((first, count, stagger))
         for _ in range(self.n):
             r = self.done.get()
             if isinstance(r, BaseException):
@@ -1004,8 +1010,8 @@ def hpatches_b1_measurements(dev, log, L, pipes=None, steps=60, warmup=6):
             lat = sorted(lat[warmup:])
             # throughput: two host pipelines (the headline's own threads and streams when it ran on two)
             rates = []
-            for _ in range(3):            # three back-to-back regions, the median reported (two Python threads share one interpreter: a region
-                el, p = measure_fn(step, steps, warmup, 2, dev, box[0])      # in which they fall into lockstep runs at half the rate)
+            for _ in range(3):            # three back-to-back regions (the second pipeline half a step late), the median reported (a region
+                el, p = measure_fn(step, steps, warmup, 2, dev, box[0], stagger=0.5 * lat[len(lat) // 2])   # in which they stay in phase runs at half the rate: Pipelines.run)
                 box[0] = p
                 rates.append(steps / el)
         out[f'{tag}_pairs_per_s'] = sorted(rates)[1]
@@ -1132,8 +1138,8 @@ def train_measurements(dev, log, steps=5, warmup=2):
     return out
 
 
-def measure_fn(step, steps, warmup, nstreams, dev, pipes=None):
-    """`measure` for an arbitrary step function (side measurements): warm-up, then `steps` timed steps on the pipelines."""
+def measure_fn(step, steps, warmup, nstreams, dev, pipes=None, stagger=0.0):
+    """`measure` for an arbitrary step function (side measurements): warm-up, then `steps` timed steps on the pipelines (`stagger`: Pipelines.run)."""
     import torch
     if pipes is None:
         pipes = Pipelines(step, max(1, min(nstreams, steps)), dev)
@@ -1143,10 +1149,10 @@ def measure_fn(step, steps, warmup, nstreams, dev, pipes=None):
     torch.cuda.synchronize()
     for w in range(pipes.n):
         pipes.run_single(w, w)
-    pipes.run(0, warmup)
+    pipes.run(0, warmup, stagger)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pipes.run(warmup, steps)
+    pipes.run(warmup, steps, stagger)
     torch.cuda.synchronize()
     return time.perf_counter() - t0, pipes
 

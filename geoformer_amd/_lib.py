@@ -143,7 +143,12 @@ def lib():
         # ROCm-capable device is detected" once torch has initialised the device through the other copy (seen with
         # `python __graft_entry__.py smoke`, where build() loads the library before anything imports torch)
         import torch  # noqa: F401
-        h = ctypes.CDLL(LIB_PATH)
+        # PyDLL: the interpreter lock is NOT released around a call.  Every entry point enqueues and returns in microseconds (the ones that wait -
+        # gf_profile_collect, the gf_debug_* trace readers - are diagnostics); with CDLL each of the ~113 launches of a batch-1 forward released and
+        # re-took the lock, and two host threads feeding two streams fell into a convoy: 230 pairs/s on two pipelines where one stream alone gives
+        # 318 and the lock-holding form 530 (tools/b1_pipeline_probe.py, round 6).  A thread now gives the interpreter up where torch does - at its
+        # device synchronisations - which is exactly when the other pipeline should be enqueueing.
+        h = ctypes.PyDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)       # AttributeError if the symbol is missing: fail loudly
             fn.restype, fn.argtypes = res, args
