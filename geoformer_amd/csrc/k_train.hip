@@ -135,9 +135,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce(WgArgs a) {
     *d = a.accumulate ? *d + s : s;
 }
 
+#ifndef WG_CHUNK_TARGET
+#define WG_CHUNK_TARGET 768
+#endif
 int wgrad_chunks(long T, int cout, int cin) {
     // about three workgroups per CU, at least 128 tokens per chunk
-    const long tiles = (long)(cout / 128) * (cin / 128), want = (768 + tiles - 1) / tiles, most = (T + 127) / 128;
+    const long tiles = (long)(cout / 128) * (cin / 128), want = (WG_CHUNK_TARGET + tiles - 1) / tiles, most = (T + 127) / 128;
     long c = want < most ? want : most;
     return (int)(c < 1 ? 1 : c);
 }
