@@ -136,10 +136,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce(WgArgs a) {
 }
 
 #ifndef WG_CHUNK_TARGET
-#define WG_CHUNK_TARGET 768
+#define WG_CHUNK_TARGET 384
 #endif
 int wgrad_chunks(long T, int cout, int cin) {
-    // about three workgroups per CU, at least 128 tokens per chunk
+    // about 1.5 workgroups per CU (round 6: 768 -> 384, -13 % at the training shapes: half the partial sums to write and add; tools/wgrad_chunks_time.py),
+    // at least 128 tokens per chunk
     const long tiles = (long)(cout / 128) * (cin / 128), want = (WG_CHUNK_TARGET + tiles - 1) / tiles, most = (T + 127) / 128;
     long c = want < most ? want : most;
     return (int)(c < 1 ? 1 : c);
