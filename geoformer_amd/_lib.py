@@ -109,6 +109,7 @@ SIGNATURES = {
                                c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'gf_bias_act_nhwc': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_int, c_void_p]),
     'gf_upsample_add_nhwc': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'gf_upsample_bilinear_backward_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'gf_conv1x1_upsample_add_nhwc': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                              c_int, c_void_p]),
     'gf_conv1x1_nhwc': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -29,6 +29,15 @@ class _Conv2d(nn.Conv2d):
 TRAIN_HIP_CONV = False
 
 
+def _upsample(x, size, training):
+    """The FPN's bilinear upsampling (resnet_fpn.py:104-105, :110-111); in the HIP training step (TRAIN_HIP_CONV) with the own backward."""
+    if (TRAIN_HIP_CONV and training and x.is_cuda and x.requires_grad and x.shape[1] % 4 == 0
+            and x.is_contiguous(memory_format=torch.channels_last) and x.dtype in (torch.float32, torch.float16, torch.bfloat16)):
+        from ..train import hip_autograd as HA
+        return HA.upsample_bilinear(x, tuple(size))
+    return F.interpolate(x, size=size, mode='bilinear', align_corners=True)
+
+
 def _conv(cin, cout, k, stride=1):
     return _Conv2d(cin, cout, kernel_size=k, stride=stride, padding=k // 2, bias=False)
 
@@ -79,9 +88,9 @@ class ResNetFPN_8_2(nn.Module):
         x3 = self.layer3(x2)
         c3 = self.layer3_outconv(x3)
         c2 = self.layer2_outconv(x2)
-        c2 = self.layer2_outconv2(c2 + F.interpolate(c3, size=c2.shape[2:], mode='bilinear', align_corners=True))
+        c2 = self.layer2_outconv2(c2 + _upsample(c3, c2.shape[2:], self.training))
         c1 = self.layer1_outconv(x1)
-        c1 = self.layer1_outconv2(c1 + F.interpolate(c2, size=c1.shape[2:], mode='bilinear', align_corners=True))
+        c1 = self.layer1_outconv2(c1 + _upsample(c2, c1.shape[2:], self.training))
         return [c3, c1]
 
 

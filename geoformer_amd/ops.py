@@ -186,6 +186,18 @@ def upsample_add_(hi, lo):
     return hi
 
 
+def upsample_bilinear_backward(dhi, h, w):
+    """Training: the gradient of F.interpolate(lo, size=(H, W), mode='bilinear', align_corners=True) with respect to lo [N, C, h, w], given
+    dhi [N, C, H, W] channels_last (fp32 / fp16 / bf16, C % 4 == 0); a gather, bit-reproducible."""
+    _need_cuda(dhi)
+    _nhwc(dhi)
+    N, C, H, W = dhi.shape
+    dlo = torch.empty(N, C, int(h), int(w), dtype=dhi.dtype, device=dhi.device, memory_format=torch.channels_last)
+    check(_lib.lib().gf_upsample_bilinear_backward_nhwc(_p(dhi), _p(dlo), N, int(h), int(w), H, W, C, _dt(dhi), _stream()),
+          'gf_upsample_bilinear_backward_nhwc')
+    return dlo
+
+
 def conv1x1_upsample_add(x, weight, lo):
     """Backbone glue: 1x1 convolution of channels_last x [N,Cin,H,W] with weight [Cout,Cin(,1,1)] plus the bilinear
     (align_corners=True) upsampling of channels_last lo [N,Cout,h,w], in one K3 launch -> channels_last [N,Cout,H,W]."""

@@ -285,6 +285,26 @@ class HipConv3x3(torch.autograd.Function):
         return dx, dw
 
 
+class HipUpsampleBilinear(torch.autograd.Function):
+    """F.interpolate(x, size, mode='bilinear', align_corners=True) of the FPN's top-down merge (resnet_fpn.py:104-105, :110-111): the forward
+    is the library's, the backward `gf_upsample_bilinear_backward_nhwc` - a gather per low-resolution pixel where the library scatters
+    with atomics (3.3 ms per call at 16 x 196 x 320 x 320, 0.4 here)."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        ctx.hw = tuple(x.shape[2:])
+        return torch.nn.functional.interpolate(x, size=size, mode='bilinear', align_corners=True)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy if dy.is_contiguous(memory_format=torch.channels_last) else dy.contiguous(memory_format=torch.channels_last)
+        return ops.upsample_bilinear_backward(dy, *ctx.hw), None
+
+
+def upsample_bilinear(x, size):
+    return HipUpsampleBilinear.apply(x, size)
+
+
 def conv3x3(x, w):
     return HipConv3x3.apply(x, w)
 

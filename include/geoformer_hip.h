@@ -453,6 +453,9 @@ int gf_bias_act_nhwc(const void* x, const float* bias, const void* residual, voi
                      float slope, int dtype, void* stream);
 int gf_upsample_add_nhwc(const void* lo, const void* hi, void* out, int N, int h, int w, int H, int W, int C,
                          int dtype, void* stream);
+/*   gf_upsample_bilinear_backward_nhwc (training): dlo [N,h,w,C] = the gradient of bilinear(lo -> HxW, align_corners=True) with respect to lo
+ *                         given dhi [N,H,W,C] (F.interpolate of resnet_fpn.py:104-105,:110-111 under autograd); a gather, no atomics. */
+int gf_upsample_bilinear_backward_nhwc(const void* dhi, void* dlo, int N, int h, int w, int H, int W, int C, int dtype, void* stream);
 /*   gf_conv1x1_upsample_add_nhwc: out = conv1x1(x; w [Cout,Cin]) + bilinear(lo -> HxW, align_corners=True): the FPN lateral
  *                         convolution with the top-down merge as its epilogue (resnet_fpn.py:109-111); fp16, Cin % 64 == 0 */
 int gf_conv1x1_upsample_add_nhwc(const void* x, const void* w, const void* lo, void* out, int N, int h, int wl, int H,

@@ -528,3 +528,27 @@ def test_hip_conv_training_step_matches_the_autocast_step():
         # 4 %: the autocast step alone spreads by 1.7 % from run to run on one box (loss_c 3.085 / 3.091 / 3.116 / 3.136 in four runs of round 6;
         # the library's kernels are not bit-reproducible), so the 2 % of earlier rounds failed one run in a few
         assert s1[k] == pytest.approx(s0[k], rel=4e-2), (k, s0, s1)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [(2, 196, 20, 24, 40, 48), (1, 256, 10, 10, 20, 20), (2, 8, 7, 5, 13, 11), (1, 4, 1, 3, 2, 6), (1, 12, 3, 1, 7, 1)])
+def test_upsample_bilinear_backward(dtype, shape):
+    """gf_upsample_bilinear_backward_nhwc (the FPN merge's upsampling under autograd: a gather per low-resolution pixel) against autograd of
+    F.interpolate(..., 'bilinear', align_corners=True) in fp32 on the same gradient: the x 2 sizes of the backbone, other ratios, one-row and
+    one-column maps; and through the Function the training backbone calls."""
+    from geoformer_amd import ops
+    from geoformer_amd.train import hip_autograd as HA
+    N, C, h, w, H, W = shape
+    g = torch.Generator(device='cuda').manual_seed(h * W)
+    dy = torch.randn(N, C, H, W, device='cuda', generator=g).to(dtype).contiguous(memory_format=torch.channels_last)
+    x = torch.randn(N, C, h, w, device='cuda', generator=g).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    torch.nn.functional.interpolate(x, size=(H, W), mode='bilinear', align_corners=True).backward(dy.float())
+    got = ops.upsample_bilinear_backward(dy, h, w)
+    assert got.shape == x.shape and got.dtype == dtype and got.is_contiguous(memory_format=torch.channels_last)
+    tol = {torch.float32: 1e-5, torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dtype]
+    assert float((got.float() - x.grad).abs().max()) <= tol * max(1.0, float(x.grad.abs().max()))
+    xx = x.detach().to(dtype).requires_grad_(True)
+    y = HA.upsample_bilinear(xx, (H, W))
+    assert torch.equal(y, torch.nn.functional.interpolate(xx.detach(), size=(H, W), mode='bilinear', align_corners=True))
+    y.backward(dy)
+    assert torch.equal(xx.grad, got)
