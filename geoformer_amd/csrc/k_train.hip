@@ -361,14 +361,22 @@ extern "C" int gf_activation_backward(const void* dh, const void* h, void* dz, s
 // given dout:  num = Q KV,  dnum = dout S / den,  dden = -(dout . num) S / den^2
 //   dQ = dnum KV^T + dden Ksum,  dKV = sum_l Q_l^T dnum_l,  dKsum = sum_l dden_l Q_l
 //   dK_s = vs_s dKV^T + dKsum,   dvs_s = K_s dKV,   dq = dQ phi'(q) [q_mask], dk = dK phi'(k) [kv_mask], dv = dvs / S [kv_mask]
-// with phi'(x) = 1 (x > 0) | exp(x) = phi(x) (x <= 0).  Heads of D = 32; fp32 arithmetic on 16-bit operands (the state's two
-// operands rounded to the storage type as the forward rounds them); per-(image, head) states by chunk partials added in chunk
-// order (deterministic).  Five launches: state partials, sum, per-query pass (+ gradient-state partials), sum, per-source pass.
+// with phi'(x) = 1 (x > 0) | exp(x) = phi(x) (x <= 0).  Heads of D = 32.  Round 6: every product on v_mfma_f32_32x32x16 (rounds 3-5 ran
+// them as fp32 loops over LDS rows: 812 us per 8-image call, the per-source pass alone 477).  All per-token products are computed
+// TRANSPOSED - A = the 32 x 32 state (a register fragment per workgroup), B = the token rows as they lie in memory (lane = token) - so
+// that the accumulator's column is the lane's own token and everything per token (den, dout . num, phi') is lane-local arithmetic plus
+// one exchange between the wave halves; an accumulator is packed as it stands into the next product's operand.  The two state sums
+// contract over TOKENS: their operands are transposes of token tiles, read with ds_read_b64_tr_b16 from [token][64 B] LDS images
+// (wave-private, no workgroup barrier in the loop); Ksum / dKsum ride along as a product with a column of ones / of dden.  16-bit
+// operands (phi(q), phi(k), v / S, the states, dnum, dden rounded to the storage type), fp32 accumulation; per-(image, head) states by
+// chunk partials added in chunk order (deterministic).  Five launches: state partials, sum, per-query pass (+ gradient-state partials),
+// sum, per-source pass.
 // =====================================================================================================================
 namespace {
 
-constexpr int LB_D = 32, LB_TOK = 128, LB_RS = 36;        // head width, tokens per workgroup, LDS row stride (floats; 16-byte rows)
+constexpr int LB_D = 32, LB_TOK = 128;                    // head width; the chunk size the workspace is sized for
 constexpr int LB_STATE = LB_D * LB_D + LB_D;              // KV [d][v] | Ksum [d]
+constexpr int L2_TOK = 256, L2_IMG = 32 * 64;             // tokens per workgroup (4 waves x 2 sub-tiles of 32); a [32 tokens][64 B] image
 
 struct LbArgs {
     const void* q; const void* k; const void* v; const void* dout;
@@ -381,65 +389,140 @@ struct LbArgs {
 };
 
 __device__ __forceinline__ float lb_phi(float x) { return x > 0.f ? x + 1.f : __expf(x); }
-template <typename T>
-__device__ __forceinline__ void lb_load16(const T* p, float (&o)[16]) {
-    const gf_vec<T, 8> a = *reinterpret_cast<const gf_vec<T, 8>*>(p), b = *reinterpret_cast<const gf_vec<T, 8>*>(p + 8);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { o[i] = gf_to_float(a[i]); o[8 + i] = gf_to_float(b[i]); }
-}
-template <typename T>
-__device__ __forceinline__ void lb_store16(T* p, const float (&o)[16]) {
-    gf_vec<T, 8> a, b;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { a[i] = gf_from_float<T>(o[i]); b[i] = gf_from_float<T>(o[8 + i]); }
-    *reinterpret_cast<gf_vec<T, 8>*>(p) = a;
-    *reinterpret_cast<gf_vec<T, 8>*>(p + 8) = b;
-}
 
-// sum over the workgroup's tokens of a_t^T b_t (32 x 32) and of w_t a_t (32): rows staged in LDS [LB_TOK][LB_RS] by the caller;
-// thread -> output row d = tid >> 3, four columns v4 = (tid & 7) * 4; ROUND: a_t rounded to T inside the product (the forward's KV
-// operand), un-rounded in the weighted row sum.  Writes one partial of LB_STATE floats.
-template <typename T, bool ROUND>
-__device__ __forceinline__ void lb_outer(const float* sa, const float* sb, const float* sw, int tokens, float* dst) {
-    const int tid = threadIdx.x, d = tid >> 3, v4 = (tid & 7) * 4;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < tokens; ++t) {
-        float a = sa[t * LB_RS + d];
-        if (ROUND) a = gf_to_float(gf_from_float<T>(a));
-        const v4f b = *reinterpret_cast<const v4f*>(sb + t * LB_RS + v4);
-        acc[0] += a * b.x; acc[1] += a * b.y; acc[2] += a * b.z; acc[3] += a * b.w;
+template <typename T>
+using LFrag = typename Mma32<T>::Frag;
+
+// the lane's token row of a head: channels 16 g + 8 half .. + 7 (the MFMA operand fragment of k-step g), as floats
+template <typename T>
+__device__ __forceinline__ void lb_row(const T* p, int h, float (&o)[2][8]) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const LFrag<T> f = *reinterpret_cast<const LFrag<T>*>(p + 16 * g + 8 * h);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[g][j] = gf_to_float(f[j]);
     }
-    *reinterpret_cast<v4f*>(dst + d * LB_D + v4) = v4f{acc[0], acc[1], acc[2], acc[3]};
-    if (tid < LB_D) {
+}
+// the same row in ACCUMULATOR order: element r = channel gf_acc_row(r, half) (four 8-byte pieces)
+template <typename T>
+__device__ __forceinline__ void lb_row_acc(const T* p, int h, float (&o)[16]) {
+#pragma unroll
+    for (int j4 = 0; j4 < 4; ++j4) {
+        const gf_vec<T, 4> f = *reinterpret_cast<const gf_vec<T, 4>*>(p + 8 * j4 + 4 * h);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[4 * j4 + i] = gf_to_float(f[i]);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void lb_store_acc(T* p, int h, const float (&o)[16]) {
+#pragma unroll
+    for (int j4 = 0; j4 < 4; ++j4)
+        *reinterpret_cast<gf_vec<T, 4>*>(p + 8 * j4 + 4 * h) = gf_vec<T, 4>{(T)o[4 * j4], (T)o[4 * j4 + 1], (T)o[4 * j4 + 2], (T)o[4 * j4 + 3]};
+}
+template <typename T>
+__device__ __forceinline__ LFrag<T> lb_pack(const float* x) {
+    return LFrag<T>{(T)x[0], (T)x[1], (T)x[2], (T)x[3], (T)x[4], (T)x[5], (T)x[6], (T)x[7]};
+}
+// transposing fragment of a [32 tokens][64 B] image: lane (channel lane & 31, half) gets tokens 16 s + 8 half + 0..7
+template <typename T>
+__device__ __forceinline__ LFrag<T> lb_tr(const char* img, int s, int lane) {
+    const int G = lane >> 4, i = lane & 15;
+    const char* p = img + (16 * s + 8 * (G >> 1) + (i >> 2)) * 64 + (16 * (G & 1) + 4 * (i & 3)) * 2;
+    typedef __attribute__((address_space(3))) gf_v4s* LP;
+    const gf_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LP)p);
+    const gf_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LP)(p + 4 * 64));
+    typedef short v8s __attribute__((__vector_size__(8 * sizeof(short))));
+    const v8s both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(LFrag<T>, both);
+}
+// state operands from the fp32 state [d][v]:  rows(g): lane (row lr, half) elements [lr][16 g + 8 half + j]  (contiguous);
+//                                             cols(g): lane (column lr, half) elements [16 g + 8 half + j][lr];
+//                                             rows_acc(s): lane (row lr, half) elements [lr][16 s + 8 (i >> 2) + 4 half + (i & 3)]
+template <typename T>
+__device__ __forceinline__ LFrag<T> lb_state_rows(const float* st, int g, int lr, int h) {
+    return lb_pack<T>(st + lr * LB_D + 16 * g + 8 * h);
+}
+template <typename T>
+__device__ __forceinline__ LFrag<T> lb_state_cols(const float* st, int g, int lr, int h) {
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = st[(16 * g + 8 * h + j) * LB_D + lr];
+    return lb_pack<T>(x);
+}
+template <typename T>
+__device__ __forceinline__ LFrag<T> lb_state_rows_acc(const float* st, int s, int lr, int h) {
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = st[lr * LB_D + 16 * s + 8 * (i >> 2) + 4 * h + (i & 3)];
+    return lb_pack<T>(x);
+}
+// the four waves' accumulators (acc[0]: the 32 x 32 sum, acc[1]: its column 0 = the weighted row sum) added in wave order -> one partial
+__device__ __forceinline__ void lb_reduce_store(const v16f (&acc)[2], float* red, float* dst) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __syncthreads();
+#pragma unroll
+    for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave * 2 + a2) * 16 + r) * 64 + lane] = acc[a2][r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + 256 * i, r = e >> 6, ln = e & 63;
         float s = 0.f;
-        for (int t = 0; t < tokens; ++t) s += sw[t] * sa[t * LB_RS + tid];
-        dst[LB_D * LB_D + tid] = s;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += red[((w * 2) * 16 + r) * 64 + ln];
+        dst[gf_acc_row(r, ln >> 5) * LB_D + (ln & 31)] = s;
+    }
+    if (tid < 32) {
+        const int r = tid >> 1, hh = tid & 1;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += red[((w * 2 + 1) * 16 + r) * 64 + 32 * hh];
+        dst[LB_D * LB_D + gf_acc_row(r, hh)] = s;
     }
 }
 
-// forward state partials: a = K = phi(k) [mask], b = vs = round(v [mask] / S), w = 1
+// forward state partials: KV = K^T vs, Ksum = K^T 1 over the workgroup's tokens
 template <typename T>
 __global__ __launch_bounds__(256) void lb_state_partial(LbArgs a) {
-    __shared__ __attribute__((aligned(16))) float sa[LB_TOK * LB_RS], sb[LB_TOK * LB_RS];
-    __shared__ float sw[LB_TOK];
+    using M = Mma32<T>;
+    __shared__ __attribute__((aligned(16))) char img[4 * 2 * L2_IMG];
+    __shared__ float red[4 * 2 * 16 * 64];
     const int chunk = blockIdx.x, nh = blockIdx.y, n = nh / a.H, hh = nh - n * a.H, tid = threadIdx.x;
-    const int tok = tid >> 1, half = tid & 1, s = chunk * LB_TOK + tok;
-    const int tokens = min(LB_TOK, a.S - chunk * LB_TOK);
-    float kk[16], vv[16];
+    const int lane = tid & 63, wave = tid >> 6, h = lane >> 5, lr = lane & 31;
+    char* kimg = img + wave * 2 * L2_IMG;
+    char* vimg = kimg + L2_IMG;
+    v16f acc[2];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { kk[i] = 0.f; vv[i] = 0.f; }
-    if (s < a.S && (a.kv_mask == nullptr || a.kv_mask[(size_t)n * a.S + s] != 0)) {
-        lb_load16<T>((const T*)a.k + ((size_t)n * a.S + s) * a.ldk + hh * LB_D + half * 16, kk);
-        lb_load16<T>((const T*)a.v + ((size_t)n * a.S + s) * a.ldv + hh * LB_D + half * 16, vv);
-        const float inv_s = 1.0f / (float)a.S;
+    for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+    LFrag<T> ones;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { kk[i] = lb_phi(kk[i]); vv[i] = gf_to_float(gf_from_float<T>(vv[i] * inv_s)); }
+    for (int j = 0; j < 8; ++j) ones[j] = (T)1.f;
+    const float inv_s = 1.0f / (float)a.S;
+    for (int j2 = 0; j2 < 2; ++j2) {
+        const int s = chunk * L2_TOK + (wave + 4 * j2) * 32 + lr;
+        float kk[2][8], vv[2][8];
+        const bool live = s < a.S && (a.kv_mask == nullptr || a.kv_mask[(size_t)n * a.S + s] != 0);
+        const size_t row = (size_t)n * a.S + min(s, a.S - 1);
+        lb_row<T>((const T*)a.k + row * a.ldk + hh * LB_D, h, kk);
+        lb_row<T>((const T*)a.v + row * a.ldv + hh * LB_D, h, vv);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { kk[g][j] = live ? lb_phi(kk[g][j]) : 0.f; vv[g][j] = live ? vv[g][j] * inv_s : 0.f; }
+            *reinterpret_cast<LFrag<T>*>(kimg + lr * 64 + (16 * g + 8 * h) * 2) = lb_pack<T>(kk[g]);
+            *reinterpret_cast<LFrag<T>*>(vimg + lr * 64 + (16 * g + 8 * h) * 2) = lb_pack<T>(vv[g]);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const LFrag<T> kt = lb_tr<T>(kimg, s2, lane);
+            M::mma(kt, lb_tr<T>(vimg, s2, lane), acc[0]);          // rows d, columns v
+            M::mma(kt, ones, acc[1]);                              // every column: sum over the tokens of K[.][d]
+        }
+        __builtin_amdgcn_wave_barrier();
     }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { sa[tok * LB_RS + half * 16 + i] = kk[i]; sb[tok * LB_RS + half * 16 + i] = vv[i]; }
-    if (half == 0) sw[tok] = 1.f;
-    __syncthreads();
-    lb_outer<T, true>(sa, sb, sw, tokens, a.part + ((size_t)nh * a.chunksS + chunk) * LB_STATE);
+    lb_reduce_store(acc, red, a.part + ((size_t)nh * a.chunksS + chunk) * LB_STATE);
 }
 
 __global__ __launch_bounds__(256) void lb_state_sum(const float* part, float* state, int chunks) {
@@ -451,127 +534,145 @@ __global__ __launch_bounds__(256) void lb_state_sum(const float* part, float* st
     }
 }
 
-// per-query pass: dq, and the partials of the gradient state (a = Q, b = dnum, w = dden)
+// per-query pass: dq, and the partials of the gradient state dKV = Q^T dnum, dKsum = Q^T dden
 template <typename T>
 __global__ __launch_bounds__(256) void lb_query_pass(LbArgs a) {
-    __shared__ __attribute__((aligned(16))) float sa[LB_TOK * LB_RS], sb[LB_TOK * LB_RS];
-    __shared__ float sw[LB_TOK];
-    __shared__ __attribute__((aligned(16))) float kv[LB_STATE];
+    using M = Mma32<T>;
+    __shared__ __attribute__((aligned(16))) char img[4 * 3 * L2_IMG];
+    __shared__ float red[4 * 2 * 16 * 64];
     const int chunk = blockIdx.x, nh = blockIdx.y, n = nh / a.H, hh = nh - n * a.H, tid = threadIdx.x;
-    const int tok = tid >> 1, half = tid & 1, l = chunk * LB_TOK + tok;
-    const int tokens = min(LB_TOK, a.L - chunk * LB_TOK);
-    for (int e = tid; e < LB_STATE; e += 256) kv[e] = a.state[(size_t)nh * LB_STATE + e];
-    const bool live = l < a.L && (a.q_mask == nullptr || a.q_mask[(size_t)n * a.L + l] != 0);
-    float qr[16], qo[16], dr[16], dro[16];                   // this thread's half of the head (q, dout) and the other half
+    const int lane = tid & 63, wave = tid >> 6, h = lane >> 5, lr = lane & 31;
+    char* qimg = img + wave * 3 * L2_IMG;
+    char* dimg = qimg + L2_IMG;
+    char* wimg = dimg + L2_IMG;
+    for (int e = lane; e < L2_IMG / 16; e += 64) reinterpret_cast<v4u*>(wimg)[e] = v4u{0u, 0u, 0u, 0u};      // only channel 0 is ever written again
+    const float* st = a.state + (size_t)nh * LB_STATE;
+    LFrag<T> kvt[2], kvr[2];
+    float ksf[2][8], ksr[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { qr[i] = 0.f; qo[i] = 0.f; dr[i] = 0.f; dro[i] = 0.f; }
-    const int lc = min(l, a.L - 1);
-    const T* qp = (const T*)a.q + ((size_t)n * a.L + lc) * a.ldq + hh * LB_D;
-    const T* dp = (const T*)a.dout + ((size_t)n * a.L + lc) * a.ldo + hh * LB_D;
-    float qraw[16];
-    lb_load16<T>(qp + half * 16, qraw);
-    if (live) {
-        lb_load16<T>(qp + (half ^ 1) * 16, qo);
-        lb_load16<T>(dp + half * 16, dr);
-        lb_load16<T>(dp + (half ^ 1) * 16, dro);
+    for (int g = 0; g < 2; ++g) {
+        kvt[g] = lb_state_cols<T>(st, g, lr, h);                   // A of num^T: rows v, k = d
+        kvr[g] = lb_state_rows_acc<T>(st, g, lr, h);               // A of dQ^T: rows d, k = v in the order of a packed accumulator
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { qr[i] = lb_phi(qraw[i]); qo[i] = lb_phi(qo[i]); }
+        for (int j = 0; j < 8; ++j) ksf[g][j] = st[LB_D * LB_D + 16 * g + 8 * h + j];
     }
-    __syncthreads();
-    // full rows in "head order": index d = half * 16 + i for the own half
-    float Q[32], G[32];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        Q[half * 16 + i] = qr[i]; Q[(half ^ 1) * 16 + i] = qo[i];
-        G[half * 16 + i] = dr[i]; G[(half ^ 1) * 16 + i] = dro[i];
-    }
-    float den = a.eps;
+    for (int r = 0; r < 16; ++r) ksr[r] = st[LB_D * LB_D + gf_acc_row(r, h)];
+    v16f acc[2];
 #pragma unroll
-    for (int d = 0; d < 32; ++d) den += Q[d] * kv[LB_D * LB_D + d];
-    // num[v] for all v (needed for dden), from the state in LDS (broadcast reads)
-    float num[32];
+    for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+    const float sl = (float)a.S;
+    for (int j2 = 0; j2 < 2; ++j2) {
+        const int l = chunk * L2_TOK + (wave + 4 * j2) * 32 + lr;
+        const bool live = l < a.L && (a.q_mask == nullptr || a.q_mask[(size_t)n * a.L + l] != 0);
+        const size_t row = (size_t)n * a.L + min(l, a.L - 1);
+        const T* qp = (const T*)a.q + row * a.ldq + hh * LB_D;
+        float qq[2][8], qa[16], ga[16];
+        lb_row<T>(qp, h, qq);
+        lb_row_acc<T>(qp, h, qa);
+        lb_row_acc<T>((const T*)a.dout + row * a.ldo + hh * LB_D, h, ga);
+        float den = 0.f;
+        LFrag<T> qf[2];
 #pragma unroll
-    for (int v = 0; v < 32; ++v) num[v] = 0.f;
-    for (int d = 0; d < 32; ++d) {
-        const float qd = Q[d];
+        for (int g = 0; g < 2; ++g) {
 #pragma unroll
-        for (int v = 0; v < 32; v += 4) {
-            const v4f r = *reinterpret_cast<const v4f*>(kv + d * LB_D + v);
-            num[v] += qd * r.x; num[v + 1] += qd * r.y; num[v + 2] += qd * r.z; num[v + 3] += qd * r.w;
+            for (int j = 0; j < 8; ++j) {
+                qq[g][j] = live ? lb_phi(qq[g][j]) : 0.f;
+                den += qq[g][j] * ksf[g][j];
+            }
+            qf[g] = lb_pack<T>(qq[g]);
         }
-    }
-    const float sl = (float)a.S, z = sl / den;
-    float dot = 0.f;
+        den += __shfl_xor(den, 32, 64);
+        den += a.eps;
+        v16f num;
 #pragma unroll
-    for (int v = 0; v < 32; ++v) dot += G[v] * num[v];
-    const float dden = live ? -dot * z / den : 0.f;
-    float dnum[32];
+        for (int r = 0; r < 16; ++r) num[r] = 0.f;
 #pragma unroll
-    for (int v = 0; v < 32; ++v) dnum[v] = live ? G[v] * z : 0.f;
-    // dQ for the own half: dQ[d] = sum_v dnum[v] KV[d][v] + dden Ksum[d];  dq = dQ phi'(q)
-    float dq[16];
+        for (int g = 0; g < 2; ++g) M::mma(kvt[g], qf[g], num);                      // rows v, column = the lane's token
+        float dot = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int d = half * 16 + i;
-        float s = dden * kv[LB_D * LB_D + d];
+        for (int r = 0; r < 16; ++r) dot += ga[r] * num[r];
+        dot += __shfl_xor(dot, 32, 64);
+        const float z = sl / den, dden = live ? -dot * z / den : 0.f;
+        float dnum[16];
 #pragma unroll
-        for (int v = 0; v < 32; v += 4) {
-            const v4f r = *reinterpret_cast<const v4f*>(kv + d * LB_D + v);
-            s += dnum[v] * r.x + dnum[v + 1] * r.y + dnum[v + 2] * r.z + dnum[v + 3] * r.w;
+        for (int r = 0; r < 16; ++r) dnum[r] = live ? ga[r] * z : 0.f;
+        v16f dqt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqt[r] = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) M::mma(kvr[s2], lb_pack<T>(dnum + 8 * s2), dqt);   // rows d, column = the lane's token
+        float dq[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[r] = live ? (dqt[r] + dden * ksr[r]) * (qa[r] > 0.f ? 1.f : __expf(qa[r])) : 0.f;
+        if (l < a.L) lb_store_acc<T>((T*)a.dq + ((size_t)n * a.L + l) * (a.H * LB_D) + hh * LB_D, h, dq);
+        // the tile's Q, dnum and dden rows -> images, then their transposes as operands of the gradient state
+#pragma unroll
+        for (int g = 0; g < 2; ++g) *reinterpret_cast<LFrag<T>*>(qimg + lr * 64 + (16 * g + 8 * h) * 2) = qf[g];
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4)
+            *reinterpret_cast<gf_vec<T, 4>*>(dimg + lr * 64 + (8 * j4 + 4 * h) * 2) =
+                gf_vec<T, 4>{(T)dnum[4 * j4], (T)dnum[4 * j4 + 1], (T)dnum[4 * j4 + 2], (T)dnum[4 * j4 + 3]};
+        if (h == 0) *reinterpret_cast<T*>(wimg + lr * 64) = (T)dden;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const LFrag<T> qt = lb_tr<T>(qimg, s2, lane);
+            M::mma(qt, lb_tr<T>(dimg, s2, lane), acc[0]);          // dKV: rows d, columns v
+            M::mma(qt, lb_tr<T>(wimg, s2, lane), acc[1]);          // column 0: dKsum
         }
-        dq[i] = live ? s * (qraw[i] > 0.f ? 1.f : qr[i]) : 0.f;
+        __builtin_amdgcn_wave_barrier();
     }
-    if (l < a.L) lb_store16<T>((T*)a.dq + ((size_t)n * a.L + l) * (a.H * LB_D) + hh * LB_D + half * 16, dq);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { sa[tok * LB_RS + half * 16 + i] = qr[i]; sb[tok * LB_RS + half * 16 + i] = dnum[half * 16 + i]; }
-    if (half == 0) sw[tok] = dden;
-    __syncthreads();
-    lb_outer<T, false>(sa, sb, sw, tokens, a.part + ((size_t)nh * a.chunksL + chunk) * LB_STATE);
+    lb_reduce_store(acc, red, a.part + ((size_t)nh * a.chunksL + chunk) * LB_STATE);
 }
 
-// per-source pass: dk, dv from the gradient state
+// per-source pass: dk, dv from the gradient state (no LDS: both products are state x token rows)
 template <typename T>
 __global__ __launch_bounds__(256) void lb_source_pass(LbArgs a) {
-    __shared__ __attribute__((aligned(16))) float g[LB_STATE];
+    using M = Mma32<T>;
     const int chunk = blockIdx.x, nh = blockIdx.y, n = nh / a.H, hh = nh - n * a.H, tid = threadIdx.x;
-    const int tok = tid >> 1, half = tid & 1, s = chunk * LB_TOK + tok;
-    for (int e = tid; e < LB_STATE; e += 256) g[e] = a.gstate[(size_t)nh * LB_STATE + e];
-    __syncthreads();
-    if (s >= a.S) return;
-    const bool live = a.kv_mask == nullptr || a.kv_mask[(size_t)n * a.S + s] != 0;
-    float kraw[16], ko[16], vo[16], vr[16], out_k[16], out_v[16];
-    const T* kp = (const T*)a.k + ((size_t)n * a.S + s) * a.ldk + hh * LB_D;
-    const T* vp = (const T*)a.v + ((size_t)n * a.S + s) * a.ldv + hh * LB_D;
-    lb_load16<T>(kp + half * 16, kraw);
-    lb_load16<T>(kp + (half ^ 1) * 16, ko);
-    lb_load16<T>(vp + half * 16, vr);
-    lb_load16<T>(vp + (half ^ 1) * 16, vo);
+    const int lane = tid & 63, wave = tid >> 6, h = lane >> 5, lr = lane & 31;
+    const float* g = a.gstate + (size_t)nh * LB_STATE;
+    LFrag<T> gr[2], gc[2];
+    float dks[16];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+        gr[k2] = lb_state_rows<T>(g, k2, lr, h);                   // A of dK^T: rows d, k = v
+        gc[k2] = lb_state_cols<T>(g, k2, lr, h);                   // A of dvs^T: rows v, k = d
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dks[r] = g[LB_D * LB_D + gf_acc_row(r, h)];
     const float inv_s = 1.0f / (float)a.S;
-    float K[32], V[32];                                       // K rounded as the forward's state operand; vs = round(v / S)
+    for (int j2 = 0; j2 < 2; ++j2) {
+        const int s = chunk * L2_TOK + (wave + 4 * j2) * 32 + lr;
+        const bool live = s < a.S && (a.kv_mask == nullptr || a.kv_mask[(size_t)n * a.S + s] != 0);
+        const size_t row = (size_t)n * a.S + min(s, a.S - 1);
+        const T* kp = (const T*)a.k + row * a.ldk + hh * LB_D;
+        float kk[2][8], vv[2][8], ka[16];
+        lb_row<T>(kp, h, kk);
+        lb_row<T>((const T*)a.v + row * a.ldv + hh * LB_D, h, vv);
+        lb_row_acc<T>(kp, h, ka);
+        v16f dkt, dvt;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        K[half * 16 + i] = gf_to_float(gf_from_float<T>(lb_phi(kraw[i])));
-        K[(half ^ 1) * 16 + i] = gf_to_float(gf_from_float<T>(lb_phi(ko[i])));
-        V[half * 16 + i] = gf_to_float(gf_from_float<T>(vr[i] * inv_s));
-        V[(half ^ 1) * 16 + i] = gf_to_float(gf_from_float<T>(vo[i] * inv_s));
-    }
+        for (int r = 0; r < 16; ++r) dkt[r] = dvt[r] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int d = half * 16 + i;                          // dK[d] = sum_v vs[v] dKV[d][v] + dKsum[d]
-        float sk = g[LB_D * LB_D + d];
+        for (int k2 = 0; k2 < 2; ++k2) {
 #pragma unroll
-        for (int v = 0; v < 32; v += 4) {
-            const v4f r = *reinterpret_cast<const v4f*>(g + d * LB_D + v);
-            sk += V[v] * r.x + V[v + 1] * r.y + V[v + 2] * r.z + V[v + 3] * r.w;
+            for (int j = 0; j < 8; ++j) { kk[k2][j] = lb_phi(kk[k2][j]); vv[k2][j] *= inv_s; }
+            M::mma(gr[k2], lb_pack<T>(vv[k2]), dkt);               // dK^T = dKV vs^T: rows d, column = the lane's token
+            M::mma(gc[k2], lb_pack<T>(kk[k2]), dvt);               // dvs^T = dKV^T K^T: rows v
         }
-        out_k[i] = live ? sk * (kraw[i] > 0.f ? 1.f : lb_phi(kraw[i])) : 0.f;
-        float sv = 0.f;                                       // dvs[v = d] = sum_dd K[dd] dKV[dd][v]
+        float ok[16], ov[16];
 #pragma unroll
-        for (int dd = 0; dd < 32; ++dd) sv += K[dd] * g[dd * LB_D + d];
-        out_v[i] = live ? sv * inv_s : 0.f;
+        for (int r = 0; r < 16; ++r) {
+            ok[r] = live ? (dkt[r] + dks[r]) * (ka[r] > 0.f ? 1.f : __expf(ka[r])) : 0.f;
+            ov[r] = live ? dvt[r] * inv_s : 0.f;
+        }
+        if (s < a.S) {
+            lb_store_acc<T>((T*)a.dk + ((size_t)n * a.S + s) * (a.H * LB_D) + hh * LB_D, h, ok);
+            lb_store_acc<T>((T*)a.dv + ((size_t)n * a.S + s) * (a.H * LB_D) + hh * LB_D, h, ov);
+        }
     }
-    lb_store16<T>((T*)a.dk + ((size_t)n * a.S + s) * (a.H * LB_D) + hh * LB_D + half * 16, out_k);
-    lb_store16<T>((T*)a.dv + ((size_t)n * a.S + s) * (a.H * LB_D) + hh * LB_D + half * 16, out_v);
 }
 
 template <typename T>
@@ -608,7 +709,7 @@ extern "C" int gf_linear_attention_backward(const void* q, const void* k, const 
     LbArgs a{};
     a.q = q; a.k = k; a.v = v; a.dout = dout; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.q_mask = q_mask; a.kv_mask = kv_mask;
     a.dq = dq; a.dk = dk; a.dv = dv; a.N = N; a.L = L; a.S = S; a.H = H; a.eps = eps;
-    a.chunksL = (L + LB_TOK - 1) / LB_TOK; a.chunksS = (S + LB_TOK - 1) / LB_TOK;
+    a.chunksL = (L + L2_TOK - 1) / L2_TOK; a.chunksS = (S + L2_TOK - 1) / L2_TOK;     // (the workspace is sized for chunks of LB_TOK: larger)
     const size_t c = a.chunksL > a.chunksS ? a.chunksL : a.chunksS;
     a.part = (float*)workspace;
     a.state = a.part + (size_t)N * H * c * LB_STATE;
