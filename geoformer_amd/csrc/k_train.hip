@@ -419,6 +419,11 @@ __device__ __forceinline__ void lb_store_acc(T* p, int h, const float (&o)[16]) 
     for (int j4 = 0; j4 < 4; ++j4)
         *reinterpret_cast<gf_vec<T, 4>*>(p + 8 * j4 + 4 * h) = gf_vec<T, 4>{(T)o[4 * j4], (T)o[4 * j4 + 1], (T)o[4 * j4 + 2], (T)o[4 * j4 + 3]};
 }
+template <typename T, int S2>
+__device__ __forceinline__ LFrag<T> lb_pack_acc(const v16f& x) {       // registers 8 S2 .. 8 S2 + 7 of an accumulator: k-step S2 of the next product
+    return LFrag<T>{(T)x[8 * S2], (T)x[8 * S2 + 1], (T)x[8 * S2 + 2], (T)x[8 * S2 + 3], (T)x[8 * S2 + 4], (T)x[8 * S2 + 5], (T)x[8 * S2 + 6],
+                    (T)x[8 * S2 + 7]};
+}
 template <typename T>
 __device__ __forceinline__ LFrag<T> lb_pack(const float* x) {
     return LFrag<T>{(T)x[0], (T)x[1], (T)x[2], (T)x[3], (T)x[4], (T)x[5], (T)x[6], (T)x[7]};
@@ -728,131 +733,163 @@ extern "C" int gf_linear_attention_backward(const void* q, const void* k, const 
 // num = A KV, out = Lw num / den:
 //   dnum = dout Lw / den,  dden = -(dout . num) Lw / den^2,  dA = dnum KV^T + dden ks,  dKV = A^T dnum,  dks = sum_l dden_l A_l,
 //   dB = vs dKV^T + dks,  dvs = B dKV,  dq = dA phi'(q),  dk = dB phi'(k),  dv = dvs / Lw,   phi'(x) = x > 0 ? 1 : exp(x).
-// One workgroup of 128 threads per window (thread = channel (head, d)), everything in LDS, fp32 arithmetic on the 16-bit
-// operands; the state's MFMA operands are rounded to the storage type where the forward rounds them (phi(q), phi(k), vs).
+// Round 6: ONE WAVE per window, every product on v_mfma_f32_32x32x16 (rounds 4-5: one workgroup of 128 threads per window, fp32 loops over
+// LDS rows, 2.6 ms per 42 k-window call).  The 128 channels go as four blocks of two heads; a block's two 16 x 16 states are the diagonal
+// quadrants of one 32 x 32 product (the others are zeroed).  lane = token: rows are loaded once, in ACCUMULATOR channel order, so a row is
+// at once the B operand of the per-token products and lane-local for phi' / den / dout . num; the token-contracting products (KV, dKV and
+// their transposes - both orientations are multiplied, which saves transposing an accumulator - and the row sums against a column of
+// ones) read transposes of [token][64 B] LDS images with ds_read_b64_tr_b16; every state operand of the per-token products is an
+// accumulator packed as it stands.  16-bit operands (phi(q), phi(k), vs, the states, dnum, dden phi(q)), fp32 accumulation.
 // =====================================================================================================================
 namespace {
 
-constexpr int WB_C = 128, WB_D = 16, WB_H = 8, WB_L = 32;
+constexpr int WB_C = 128, WB_L = 32;
 
 template <typename T>
-__global__ __launch_bounds__(128) void window_la_backward(const T* q, const T* k, const T* v, const T* dout, T* dq, T* dk, T* dv, int Lw, float eps) {
-    extern __shared__ __attribute__((aligned(16))) char wb_smem[];                     // 4 x [Lw][129] floats: phi(q) | phi(k) | v / Lw | dout -> dnum
-    typedef float Row[WB_C + 1];
-    Row* sA = reinterpret_cast<Row*>(wb_smem);
-    Row* sB = sA + Lw;
-    Row* sV = sB + Lw;
-    Row* sG = sV + Lw;
-    __shared__ float sKV[WB_H][WB_D][WB_D + 1], sdKV[WB_H][WB_D][WB_D + 1];
-    __shared__ float sks[WB_C], sdks[WB_C], sden[WB_L][WB_H], sdd[WB_L][WB_H];
-    const int w = blockIdx.x, c = threadIdx.x, h = c >> 4, d = c & 15;
-    const size_t base = (size_t)w * Lw * WB_C;
-    const float inv_l = 1.0f / (float)Lw, fl = (float)Lw;
-    auto rt = [](float x) { return gf_to_float(gf_from_float<T>(x)); };
-    auto phi = [](float x) { return x > 0.f ? x + 1.f : __expf(x); };
-    for (int l = 0; l < Lw; ++l) {
-        sA[l][c] = rt(phi(gf_to_float(q[base + (size_t)l * WB_C + c])));
-        sB[l][c] = rt(phi(gf_to_float(k[base + (size_t)l * WB_C + c])));
-        sV[l][c] = rt(gf_to_float(v[base + (size_t)l * WB_C + c]) * inv_l);
-        sG[l][c] = gf_to_float(dout[base + (size_t)l * WB_C + c]);
-    }
-    __syncthreads();
-    // ---- forward state: ks, KV[h][d][:] (thread (h, d))
-    {
-        float s = 0.f, kv[WB_D];
+__global__ __launch_bounds__(256) void window_la_backward(const T* q, const T* k, const T* v, const T* dout, T* dq, T* dk, T* dv, int Nw, int Lw,
+                                                          float eps) {
+    using M = Mma32<T>;
+    __shared__ __attribute__((aligned(16))) char img[4 * 5 * L2_IMG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, lr = lane & 31;
+    const int win = blockIdx.x * 4 + wave;
+    if (win >= Nw) return;                                          // (whole waves: no workgroup barrier below)
+    char* kimg = img + wave * 5 * L2_IMG;
+    char* vimg = kimg + L2_IMG;
+    char* qimg = vimg + L2_IMG;
+    char* dimg = qimg + L2_IMG;
+    char* wimg = dimg + L2_IMG;
+    const bool live = lr < Lw;
+    const size_t row = ((size_t)win * Lw + min(lr, Lw - 1)) * WB_C;
+    const float lw = (float)Lw, inv_l = 1.0f / lw;
+    LFrag<T> ones;
 #pragma unroll
-        for (int u = 0; u < WB_D; ++u) kv[u] = 0.f;
-        for (int l = 0; l < Lw; ++l) {
-            const float b = sB[l][c];
-            s += b;
+    for (int j = 0; j < 8; ++j) ones[j] = (T)1.f;
+    auto put = [&](char* im, const float (&x)[16]) {               // a row in accumulator channel order -> its image row
 #pragma unroll
-            for (int u = 0; u < WB_D; ++u) kv[u] += b * sV[l][h * WB_D + u];
+        for (int j4 = 0; j4 < 4; ++j4)
+            *reinterpret_cast<gf_vec<T, 4>*>(im + lr * 64 + (8 * j4 + 4 * h) * 2) =
+                gf_vec<T, 4>{(T)x[4 * j4], (T)x[4 * j4 + 1], (T)x[4 * j4 + 2], (T)x[4 * j4 + 3]};
+    };
+    auto zero = [](v16f& x) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = 0.f;
+    };
+    auto diag = [&](v16f& x) {                                      // keep the two heads' own quadrants: row head r >> 3, column head lr >> 4
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = (r >> 3) == (lr >> 4) ? x[r] : 0.f;
+    };
+    for (int pb = 0; pb < 4; ++pb) {
+        const int c0 = 32 * pb;
+        float qa[16], ka[16], va[16], ga[16], qp[16], kp[16], vs[16];
+        lb_row_acc<T>(q + row + c0, h, qa);
+        lb_row_acc<T>(k + row + c0, h, ka);
+        lb_row_acc<T>(v + row + c0, h, va);
+        lb_row_acc<T>(dout + row + c0, h, ga);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            qp[r] = live ? lb_phi(qa[r]) : 0.f;
+            kp[r] = live ? lb_phi(ka[r]) : 0.f;
+            vs[r] = live ? va[r] * inv_l : 0.f;
+            ga[r] = live ? ga[r] : 0.f;
         }
-        sks[c] = s;
+        put(kimg, kp);
+        put(vimg, vs);
+        put(qimg, qp);
+        __builtin_amdgcn_wave_barrier();
+        v16f kv, vk, ks;
+        zero(kv); zero(vk); zero(ks);
 #pragma unroll
-        for (int u = 0; u < WB_D; ++u) sKV[h][d][u] = kv[u];
-    }
-    __syncthreads();
-    // ---- den[l][h] (threads < Lw * 8), then num[l][(h, v)] on thread (h, v): dnum, and dden through sdd
-    for (int e = c; e < Lw * WB_H; e += 128) {
-        const int l = e >> 3, hh = e & 7;
-        float s = 0.f;
-#pragma unroll
-        for (int u = 0; u < WB_D; ++u) s += sA[l][hh * WB_D + u] * sks[hh * WB_D + u];
-        sden[l][hh] = s + eps;
-        sdd[l][hh] = 0.f;
-    }
-    __syncthreads();
-    for (int l = 0; l < Lw; ++l) {
-        float num = 0.f;
-#pragma unroll
-        for (int u = 0; u < WB_D; ++u) num += sA[l][h * WB_D + u] * sKV[h][u][d];          // (thread's d plays v here)
-        const float g = sG[l][c], den = sden[l][h];
-        sG[l][c] = g * fl / den;                                                            // dnum
-        // dden[l][h] = -(sum_v dout num) Lw / den^2: sum over the head's 16 lanes
-        float t = g * num;
-#pragma unroll
-        for (int o = 8; o >= 1; o >>= 1) t += __shfl_xor(t, o, 64);
-        if (d == 0) sdd[l][h] = -t * fl / (den * den);
-    }
-    __syncthreads();
-    // ---- dA -> dq; dKV, dks (thread (h, d))
-    {
-        float dkv[WB_D], dks = 0.f;
-#pragma unroll
-        for (int u = 0; u < WB_D; ++u) dkv[u] = 0.f;
-        const float ksd = sks[c];
-        for (int l = 0; l < Lw; ++l) {
-            float da = sdd[l][h] * ksd;
-#pragma unroll
-            for (int u = 0; u < WB_D; ++u) da += sG[l][h * WB_D + u] * sKV[h][d][u];
-            const float a = sA[l][c];
-#pragma unroll
-            for (int u = 0; u < WB_D; ++u) dkv[u] += a * sG[l][h * WB_D + u];
-            dks += sdd[l][h] * a;
-            const float x = gf_to_float(q[base + (size_t)l * WB_C + c]);
-            dq[base + (size_t)l * WB_C + c] = gf_from_float<T>(da * (x > 0.f ? 1.f : __expf(x)));
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const LFrag<T> kt = lb_tr<T>(kimg, s2, lane), vt = lb_tr<T>(vimg, s2, lane);
+            M::mma(kt, vt, kv);                                     // rows d, columns v
+            M::mma(vt, kt, vk);                                     // rows v, columns d
+            M::mma(kt, ones, ks);                                   // every column: ks[d]
         }
+        diag(kv); diag(vk);
+        // per token and head: den, num, dout . num
+        float den[2] = {0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < WB_D; ++u) sdKV[h][d][u] = dkv[u];
-        sdks[c] = dks;
-    }
-    __syncthreads();
-    // ---- dB -> dk (thread (h, d)); dvs -> dv (thread (h, v))
-    for (int l = 0; l < Lw; ++l) {
-        float db = sdks[c], dvs = 0.f;
+        for (int r = 0; r < 16; ++r) den[r >> 3] += qp[r] * ks[r];
+        v16f num;
+        zero(num);
+        M::mma(lb_pack_acc<T, 0>(kv), lb_pack<T>(qp), num);          // rows v, column = the lane's token
+        M::mma(lb_pack_acc<T, 1>(kv), lb_pack<T>(qp + 8), num);
+        float dot[2] = {0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < WB_D; ++u) {
-            db += sV[l][h * WB_D + u] * sdKV[h][d][u];
-            dvs += sB[l][h * WB_D + u] * sdKV[h][u][d];
+        for (int r = 0; r < 16; ++r) dot[r >> 3] += ga[r] * num[r];
+        float z[2], dden[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            den[e] += __shfl_xor(den[e], 32, 64);
+            dot[e] += __shfl_xor(dot[e], 32, 64);
+            den[e] += eps;
+            z[e] = lw / den[e];
+            dden[e] = -dot[e] * z[e] / den[e];
         }
-        const float x = gf_to_float(k[base + (size_t)l * WB_C + c]);
-        dk[base + (size_t)l * WB_C + c] = gf_from_float<T>(db * (x > 0.f ? 1.f : __expf(x)));
-        dv[base + (size_t)l * WB_C + c] = gf_from_float<T>(dvs * inv_l);
+        float dnum[16], qw[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            dnum[r] = ga[r] * z[r >> 3];
+            qw[r] = qp[r] * dden[r >> 3];
+        }
+        v16f dqt;
+        zero(dqt);
+        M::mma(lb_pack_acc<T, 0>(vk), lb_pack<T>(dnum), dqt);        // rows d, column = the lane's token
+        M::mma(lb_pack_acc<T, 1>(vk), lb_pack<T>(dnum + 8), dqt);
+        float o[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = (dqt[r] + dden[r >> 3] * ks[r]) * (qa[r] > 0.f ? 1.f : __expf(qa[r]));
+        if (live) lb_store_acc<T>(dq + row + c0, h, o);
+        // the gradient state: dKV = Q^T dnum (both orientations), dks = (dden Q)^T 1
+        put(dimg, dnum);
+        put(wimg, qw);
+        __builtin_amdgcn_wave_barrier();
+        v16f gkv, gvk, gks;
+        zero(gkv); zero(gvk); zero(gks);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const LFrag<T> qt = lb_tr<T>(qimg, s2, lane), dt = lb_tr<T>(dimg, s2, lane);
+            M::mma(qt, dt, gkv);                                    // rows d, columns v
+            M::mma(dt, qt, gvk);                                    // rows v, columns d
+            M::mma(lb_tr<T>(wimg, s2, lane), ones, gks);            // every column: dks[d]
+        }
+        diag(gkv); diag(gvk);
+        v16f dkt, dvt;
+        zero(dkt); zero(dvt);
+        M::mma(lb_pack_acc<T, 0>(gvk), lb_pack<T>(vs), dkt);         // dB^T = dKV vs^T: rows d
+        M::mma(lb_pack_acc<T, 1>(gvk), lb_pack<T>(vs + 8), dkt);
+        M::mma(lb_pack_acc<T, 0>(gkv), lb_pack<T>(kp), dvt);         // dvs^T = dKV^T B^T: rows v
+        M::mma(lb_pack_acc<T, 1>(gkv), lb_pack<T>(kp + 8), dvt);
+        float ok[16], ov[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            ok[r] = (dkt[r] + gks[r]) * (ka[r] > 0.f ? 1.f : __expf(ka[r]));
+            ov[r] = dvt[r] * inv_l;
+        }
+        if (live) {
+            lb_store_acc<T>(dk + row + c0, h, ok);
+            lb_store_acc<T>(dv + row + c0, h, ov);
+        }
+        __builtin_amdgcn_wave_barrier();                           // the images are rewritten by the next block
     }
 }
 
 }   // namespace
 
-// dq, dk, dv [Nw, Lw, 128] (contiguous, `dtype`) of the fine-level window linear attention (8 heads of 16, no masks) given dout
+// dq, dk, dv [Nw, Lw, 128] (contiguous, `dtype`) of the fine-level window attention given dout; q, k, v, dout contiguous [Nw, Lw, 128]
 extern "C" int gf_window_linear_attention_backward(const void* q, const void* k, const void* v, const void* dout, int dtype, int Nw, int Lw,
                                                    float eps, void* dq, void* dk, void* dv, void* stream) {
     GF_CHECK_ARG(q && k && v && dout && dq && dk && dv, "null pointer");
     GF_CHECK_ARG(dtype == GF_F16 || dtype == GF_BF16, "built for 16-bit activations");
     GF_CHECK_ARG(Nw > 0 && Lw > 0 && Lw <= WB_L, "windows of 1 .. 32 tokens");
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (size_t)4 * Lw * (WB_C + 1) * sizeof(float);                  // 66 KB at Lw = 32
-    static std::atomic<uint64_t> attr{0};
-    if (gf_first_use_on_device(attr)) {
-        (void)hipFuncSetAttribute((const void*)window_la_backward<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WB_L * (WB_C + 1) * 4);
-        (void)hipFuncSetAttribute((const void*)window_la_backward<gf_bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WB_L * (WB_C + 1) * 4);
-    }
+    const unsigned grid = (unsigned)((Nw + 3) / 4);
     if (dtype == GF_F16)
-        window_la_backward<_Float16><<<Nw, 128, lds, st>>>((const _Float16*)q, (const _Float16*)k, (const _Float16*)v, (const _Float16*)dout,
-                                                        (_Float16*)dq, (_Float16*)dk, (_Float16*)dv, Lw, eps);
+        window_la_backward<_Float16><<<grid, 256, 0, st>>>((const _Float16*)q, (const _Float16*)k, (const _Float16*)v, (const _Float16*)dout,
+                                                        (_Float16*)dq, (_Float16*)dk, (_Float16*)dv, Nw, Lw, eps);
     else
-        window_la_backward<gf_bf16><<<Nw, 128, lds, st>>>((const gf_bf16*)q, (const gf_bf16*)k, (const gf_bf16*)v, (const gf_bf16*)dout, (gf_bf16*)dq,
-                                                       (gf_bf16*)dk, (gf_bf16*)dv, Lw, eps);
+        window_la_backward<gf_bf16><<<grid, 256, 0, st>>>((const gf_bf16*)q, (const gf_bf16*)k, (const gf_bf16*)v, (const gf_bf16*)dout, (gf_bf16*)dq,
+                                                       (gf_bf16*)dk, (gf_bf16*)dv, Nw, Lw, eps);
     GF_CHECK_LAUNCH();
     return GF_OK;
 }
