@@ -1095,7 +1095,7 @@ def synth_rect_pair(hw0, hw1, seed, device):
     return image0.to(device), image1.contiguous().to(device)
 
 
-def train_measurements(dev, log, steps=5, warmup=2):
+def train_measurements(dev, log, steps=6, warmup=4):
     """The training step of BASELINE configs[2] / [3] at their per-GPU sizes (VERDICT r04 #6a), N = 1: mixed bf16 (fp32 master weights,
     `train_depth_geoformer.py:117-119`) with the fused HIP coarse loss and the HIP forward + backward Functions
     and, since the end of round 5, the backbone's stride-1 3x3 convolutions forward + backward-data on K10
@@ -1103,7 +1103,9 @@ def train_measurements(dev, log, steps=5, warmup=2):
     AdamW step (`lightning_homo_geoformer.py:69-107`), batches made outside the timed steps.
       configs2_homo:      640 x 480 synthetic homography pairs, batch 4 per GPU (batch 32 over 8 GPUs; `homo_trainval_640.py:5`)
       configs3_megadepth: 640 x 640 MegaDepth-style pairs (depth + pose supervision, padding masks, per-image scales), batch 8 per GPU
-    Closed-form random-init weights, thresholds 0 / 0 (untrained weights give no match above 0.2); a side measurement, never `value`."""
+    Closed-form random-init weights, thresholds 0 / 0 (untrained weights give no match above 0.2); a side measurement, never `value`.
+    Four warm-up steps: steps 2 and 3 of a fresh model still run 40-50 % slow (the caching allocator and the workspaces growing to the step's
+    peak; 0.32 / 0.31 s against 0.19 in `tools/train_profile.py`), which with two warm-up steps put 232 ms into a line whose steady state is 190."""
     import torch
     from geoformer_amd.model.cvpr_ds_config import get_default_cfg
     from geoformer_amd.model.full_model import GeoFormer
