@@ -1125,16 +1125,23 @@ def train_measurements(dev, log, steps=6, warmup=4):
         for i in range(warmup):
             losses.append(float(step(data[i])))
         torch.cuda.synchronize()
+        allocs0 = torch.cuda.memory_stats(dev).get('num_device_alloc', 0)
         t0 = time.perf_counter()
+        host = []
         for i in range(warmup, warmup + steps):
+            th = time.perf_counter()
             losses.append(step(data[i]))
+            host.append(1e3 * (time.perf_counter() - th))          # host time of the step's enqueue (the device runs behind)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        allocs = torch.cuda.memory_stats(dev).get('num_device_alloc', 0) - allocs0
         losses = [float(v) for v in losses]
         out[key] = {'value': steps * batch / el, 'unit': 'image-pairs/s', 'ms_per_step': 1e3 * el / steps, 'steps': steps, 'warmup': warmup,
                     'batch_per_gpu': batch, 'image_hw': list(hw), 'precision': 'mixed bf16 (fp32 master weights)', 'hip_backward': True, 'hip_conv': True,
-                    'fused_coarse_loss': True, 'losses': losses, 'finite': all(math.isfinite(v) for v in losses)}
-        log(f"train step {key}: {out[key]['ms_per_step']:.1f} ms at batch {batch} = {out[key]['value']:.1f} pairs/s, losses {losses[0]:.3f} -> {losses[-1]:.3f}")
+                    'fused_coarse_loss': True, 'losses': losses, 'finite': all(math.isfinite(v) for v in losses),
+                    'host_enqueue_ms_per_step': host, 'device_allocations_in_timed_steps': allocs}
+        log(f"train step {key}: {out[key]['ms_per_step']:.1f} ms at batch {batch} = {out[key]['value']:.1f} pairs/s, losses {losses[0]:.3f} -> {losses[-1]:.3f}; "
+            f"host enqueue {' '.join(f'{h:.0f}' for h in host)} ms, {allocs} device allocations inside the timed steps")
         del step, model, data
         torch.cuda.empty_cache()
     return out
