@@ -71,7 +71,7 @@ def warp_kpts(kpts0, depth0, depth1, T_0to1, K0, K1):
     h1, w1 = depth1.shape[1:3]
     inside = (warped[..., 0] > 0) * (warped[..., 0] < w1 - 1) * (warped[..., 1] > 0) * (warped[..., 1] < h1 - 1)
     tgt = warped.long()
-    tgt[~inside, :] = 0
+    tgt = tgt.masked_fill(~inside[..., None], 0)              # (masked_fill, not `tgt[~inside] = 0`: boolean-mask assignment synchronises with the device)
     z1 = depth1[rows, tgt[..., 1], tgt[..., 0]]
     agree = ((z1 - z_proj) / z1).abs() < 0.2
     return (z0 != 0) * inside * agree, warped
@@ -101,14 +101,14 @@ class _CellGrid:
         self.step = step                                   # pixels per cell: scalar, or [N,1,2] with per-image scale
         self.centres = step * _pixel_lattice(h, w, device)[None].repeat(n, 1, 1)
         if mask is not None:
-            self.centres[~mask.flatten(-2).bool()] = 0
+            self.centres.masked_fill_(~mask.flatten(-2).bool()[..., None], 0)
 
     def cell_of(self, pts):
         """Flat index of the cell nearest to each pixel position; positions outside the grid -> 0."""
         c = (pts / self.step).round().long()
         flat = c[..., 0] + c[..., 1] * self.w
         outside = (c[..., 0] < 0) | (c[..., 0] >= self.w) | (c[..., 1] < 0) | (c[..., 1] >= self.h)
-        flat[outside] = 0
+        flat.masked_fill_(outside, 0)
         return flat
 
 
@@ -174,7 +174,7 @@ def spvs_fine2(data, resolution=(8, 2)):
                 continue
             one = {k: data[k][s:s + 1] for k in ('depth0', 'depth1', 'T_0to1', 'K0', 'K1')}
             ok, qs = warp_kpts(p0[sel].reshape(1, -1, 2), one['depth0'], one['depth1'], one['T_0to1'], one['K0'], one['K1'])
-            qs[~ok] = -100000
+            qs.masked_fill_(~ok[..., None], -100000)
             q[sel] = qs.view(-1, WW, 2)
     else:
         Hm = data['H_0to1']
