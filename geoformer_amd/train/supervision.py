@@ -64,10 +64,10 @@ def warp_kpts(kpts0, depth0, depth1, T_0to1, K0, K1):
     z0 = depth0[rows, px[..., 1].clamp(0, depth0.shape[1] - 1), px[..., 0].clamp(0, depth0.shape[2] - 1)]
     rays = torch.cat([kpts0, torch.ones_like(kpts0[..., :1])], dim=-1) * z0[..., None]
     k0_inv = _inv3x3(K0) if K0.is_cuda else K0.inverse()          # (the CPU path keeps the reference's call: geometry.py:27)
-    in_cam1 = T_0to1[:, :3, :3] @ (k0_inv @ rays.transpose(2, 1)) + T_0to1[:, :3, [3]]
+    in_cam1 = T_0to1[:, :3, :3] @ (k0_inv @ rays.transpose(2, 1)) + T_0to1[:, :3, 3:4]          # (slices, not `[3]`: a list index is a host tensor copied to the device - a synchronisation)
     z_proj = in_cam1[:, 2, :]
     img = (K1 @ in_cam1).transpose(2, 1)
-    warped = img[..., :2] / (img[..., [2]] + 1e-4)
+    warped = img[..., :2] / (img[..., 2:3] + 1e-4)
     h1, w1 = depth1.shape[1:3]
     inside = (warped[..., 0] > 0) * (warped[..., 0] < w1 - 1) * (warped[..., 1] > 0) * (warped[..., 1] < h1 - 1)
     tgt = warped.long()
