@@ -80,9 +80,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgArgs a) {
             const long t = t0 + tok;
             ry[p] = zero;
             rx[p] = zero;
-            if (t < t_end) {
-                ry[p] = *reinterpret_cast<const v4u*>(yp + t * a.lddy + c8);
-                rx[p] = *reinterpret_cast<const v4u*>(xp + t * a.ldx + c8);
+            if (t < t_end) {                                  // (channels behind the matrix: zeros - widths need not be multiples of 128)
+                if (m0 + c8 < a.cout) ry[p] = *reinterpret_cast<const v4u*>(yp + t * a.lddy + c8);
+                if (n0 + c8 < a.cin) rx[p] = *reinterpret_cast<const v4u*>(xp + t * a.ldx + c8);
             }
         }
     };
@@ -115,7 +115,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dst[(size_t)(i * 32 + gf_acc_row(r, h2)) * a.cin + j * 32] = acc[i][j][r];
+            for (int r = 0; r < 16; ++r)
+                if (m0 + wm * 64 + i * 32 + gf_acc_row(r, h2) < a.cout && n0 + wn * 64 + j * 32 + lr < a.cin)
+                    dst[(size_t)(i * 32 + gf_acc_row(r, h2)) * a.cin + j * 32] = acc[i][j][r];
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce(WgArgs a) {
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce(WgArgs a) {
 int wgrad_chunks(long T, int cout, int cin) {
     // about 1.5 workgroups per CU (round 6: 768 -> 384, -13 % at the training shapes: half the partial sums to write and add; tools/wgrad_chunks_time.py),
     // at least 128 tokens per chunk
-    const long tiles = (long)(cout / 128) * (cin / 128), want = (WG_CHUNK_TARGET + tiles - 1) / tiles, most = (T + 127) / 128;
+    const long tiles = (long)((cout + 127) / 128) * ((cin + 127) / 128), want = (WG_CHUNK_TARGET + tiles - 1) / tiles, most = (T + 127) / 128;
     long c = want < most ? want : most;
     return (int)(c < 1 ? 1 : c);
 }
@@ -255,7 +257,7 @@ constexpr int LN_BWD_WGS = 512;
 }   // namespace
 
 extern "C" size_t gf_linear_wgrad_workspace_bytes(long T, int cout, int cin) {
-    if (T <= 0 || cout <= 0 || cin <= 0 || cout % 128 || cin % 128) return 0;
+    if (T <= 0 || cout <= 0 || cin <= 0 || cout % 8 || cin % 8) return 0;
     return gf_align_up(sizeof(float) * (size_t)wgrad_chunks(T, cout, cin) * cout * cin, 256);
 }
 
@@ -264,7 +266,7 @@ extern "C" int gf_linear_wgrad(const void* dy, long lddy, const void* x, long ld
                                long lddw, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
     GF_CHECK_ARG(dy && x && dw, "null pointer");
     GF_CHECK_ARG(dtype == GF_F16 || dtype == GF_BF16, "built for 16-bit activations (GF_F16 / GF_BF16)");
-    GF_CHECK_ARG(T > 0 && cout > 0 && cin > 0 && cout % 128 == 0 && cin % 128 == 0, "cout and cin must be multiples of 128");
+    GF_CHECK_ARG(T > 0 && cout > 0 && cin > 0 && cout % 8 == 0 && cin % 8 == 0, "cout and cin must be multiples of 8");
     GF_CHECK_ARG((lddy * 2) % 16 == 0 && (ldx * 2) % 16 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)x % 16 == 0, "rows must be 16-byte aligned");
     GF_CHECK_ARG(lddw >= cin, "lddw < cin");
     if (workspace == nullptr || workspace_bytes < gf_linear_wgrad_workspace_bytes(T, cout, cin)) {
@@ -279,7 +281,7 @@ extern "C" int gf_linear_wgrad(const void* dy, long lddy, const void* x, long ld
     a.part = (float*)workspace; a.dw = dw; a.lddw = lddw; a.accumulate = accumulate;
     hipStream_t st = (hipStream_t)stream;
     void* pt = gf_prof_begin("wgrad", st, 2.0 * (double)T * cout * cin);
-    const dim3 grid(cin / 128, cout / 128, a.chunks);
+    const dim3 grid((cin + 127) / 128, (cout + 127) / 128, a.chunks);
     if (dtype == GF_F16) wgrad_kernel<_Float16><<<grid, 256, 0, st>>>(a);
     else wgrad_kernel<gf_bf16><<<grid, 256, 0, st>>>(a);
     wgrad_reduce<<<(unsigned)(((size_t)cout * cin + 255) / 256), 256, 0, st>>>(a);

@@ -23,6 +23,12 @@ class _Conv2d(nn.Conv2d):
                 x16 = x16.contiguous(memory_format=torch.channels_last)
                 with torch.autocast('cuda', enabled=False):
                     return HA.conv3x3(x16, self.weight)
+        if (TRAIN_HIP_CONV and self.training and self.kernel_size == (1, 1) and self.stride == (1, 1) and x.is_cuda and torch.is_autocast_enabled()
+                and self.in_channels % 4 == 0 and self.out_channels % 4 == 0):
+            from ..train import hip_autograd as HA                 # the FPN's 1x1 convolutions on the K3 engine (round 6)
+            x16 = x.to(torch.get_autocast_dtype('cuda')).contiguous(memory_format=torch.channels_last)
+            with torch.autocast('cuda', enabled=False):
+                return HA.conv1x1(x16, self.weight)
         return super().forward(x)
 
 

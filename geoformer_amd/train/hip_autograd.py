@@ -285,6 +285,55 @@ class HipConv3x3(torch.autograd.Function):
         return dx, dw
 
 
+def _pad32(c):
+    return (int(c) + 31) // 32 * 32
+
+
+class HipConv1x1(torch.autograd.Function):
+    """y = conv2d(x, w) for a 1x1 / stride-1 kernel without bias (the FPN's lateral and output convolutions, resnet_fpn.py:69-83) on the K3
+    engine: forward `gf_conv1x1_nhwc`, backward-data the same kernel with the transposed weight, backward-weights `gf_linear_wgrad` on the
+    pixel rows (round 6; the library's 1x1 at 16 x 128 -> 196 x 320 x 320 took 1.97 ms forward: 42 TFLOP/s).  x: 16-bit channels_last; w:
+    fp32 master or 16-bit [cout, cin, 1, 1]; widths that are not multiples of 32 (196) are zero-padded on the way in and sliced on the way
+    out (one copy each)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        w16 = w if w.dtype == x.dtype else WEIGHTS.cast(w, x.dtype)
+        co, ci = w16.shape[:2]
+        cop, cip = _pad32(co), _pad32(ci)
+        wp = w16.reshape(co, ci)
+        if (cop, cip) != (co, ci):
+            wp = torch.zeros(cop, cip, dtype=w16.dtype, device=w16.device)
+            wp[:co, :ci] = w16.reshape(co, ci)
+        xp = _pad_channels(x, cip)
+        y = ops.conv1x1(xp, wp)
+        if cop != co:
+            y = y[:, :co].contiguous(memory_format=torch.channels_last)
+        ctx.wdtype, ctx.dims = w.dtype, (co, ci)
+        ctx.save_for_backward(xp, wp)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, wp = ctx.saved_tensors
+        co, ci = ctx.dims
+        cop, cip = wp.shape
+        dx = dw = None
+        dyp = _pad_channels(dy, cop)
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv1x1(dyp, wp.t().contiguous())
+            if cip != ci:
+                dx = dx[:, :ci].contiguous(memory_format=torch.channels_last)
+        if ctx.needs_input_grad[1]:
+            rows = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])          # channels_last maps as [pixels, C] rows (a view)
+            dw = ops.linear_wgrad(rows(dyp), rows(xp))[:co, :ci].reshape(co, ci, 1, 1).to(ctx.wdtype)
+        return dx, dw
+
+
+def conv1x1(x, w):
+    return HipConv1x1.apply(x, w)
+
+
 class HipUpsampleBilinear(torch.autograd.Function):
     """F.interpolate(x, size, mode='bilinear', align_corners=True) of the FPN's top-down merge (resnet_fpn.py:104-105, :110-111): the forward
     is the library's, the backward `gf_upsample_bilinear_backward_nhwc` - a gather per low-resolution pixel where the library scatters

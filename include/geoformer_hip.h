@@ -96,7 +96,7 @@ int gf_dual_softmax_match(const void* f0, const void* f1, int dtype, int N, int 
  *          lightning/train_depth_geoformer.py:117-119 runs the step under 16-bit autocast; fp32 master weights / gradients.
  *   y = x W^T:   dX = dY W is gf_linear with the transposed weight;  dW = dY^T X is gf_linear_wgrad (fp32 [cout, cin], row
  *   stride lddw, optionally accumulated): the contraction runs over the T token rows of both operands (MFMA operands by
- *   transpose reads), split over token chunks, partials added in chunk order (deterministic).  cout, cin multiples of 128.
+ *   transpose reads), split over token chunks, partials added in chunk order (deterministic).  cout, cin multiples of 8 (round 6; 128 before).
  *   gf_layernorm_forward keeps stats[t] = (mean, rstd); gf_layernorm_backward returns dy and dgamma / dbeta (fp32 [C],
  *   optionally accumulated); C in {128, 256, 512}.  gf_activation_backward: dz = dh * act'(z) from the OUTPUT h of the
  *   activation (kind 0 ReLU, 1 Tanh).  All activations GF_F16 or GF_BF16, statistics and parameter gradients fp32.

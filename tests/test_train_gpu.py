@@ -552,3 +552,30 @@ def test_upsample_bilinear_backward(dtype, shape):
     assert torch.equal(y, torch.nn.functional.interpolate(xx.detach(), size=(H, W), mode='bilinear', align_corners=True))
     y.backward(dy)
     assert torch.equal(xx.grad, got)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('cin,cout,hw', [(128, 196, (40, 56)), (196, 256, (24, 36)), (256, 256, (17, 21))])
+def test_hip_conv1x1_function_against_the_library(dtype, cin, cout, hw):
+    """HipConv1x1 (the FPN's 1x1 convolutions in the mixed-16-bit training step: forward and backward-data on the K3 engine, backward-weights
+    gf_linear_wgrad on the pixel rows - widths that are not multiples of 128 since round 6, 196-wide operands zero-padded to 224) against torch's
+    convolution forward + backward on the same 16-bit operands, evaluated in fp32."""
+    from geoformer_amd.train import hip_autograd as HA
+    g = torch.Generator(device='cuda').manual_seed(cin + cout)
+    H, W = hw
+    x = (torch.randn(3, cin, H, W, device='cuda', generator=g)).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randn(cout, cin, 1, 1, device='cuda', generator=g) / cin ** 0.5).requires_grad_(True)          # fp32 master weights
+    dy = torch.randn(3, cout, H, W, device='cuda', generator=g).to(dtype).contiguous(memory_format=torch.channels_last)
+    y = HA.conv1x1(x, w)
+    assert y.dtype == dtype and y.shape == (3, cout, H, W) and y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(dy)
+    xr = x.detach().float().requires_grad_(True)
+    wr = w.detach().to(dtype).float().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, wr)
+    yr.backward(dy.float())
+    ulp = 2.0 ** (-10 if dtype == torch.float16 else -7)
+    rel = lambda a, b: float(((a.detach().float() - b.detach()).abs() / b.detach().abs().clamp_min(float(b.detach().abs().mean()))).max())
+    assert rel(y, yr) < 1.5 * ulp, rel(y, yr)
+    assert x.grad.dtype == dtype and x.grad.shape == x.shape and rel(x.grad, xr.grad) < 1.5 * ulp, rel(x.grad, xr.grad)
+    nrel = float((w.grad - wr.grad).norm() / wr.grad.norm())
+    assert w.grad.dtype == torch.float32 and w.grad.shape == w.shape and nrel < 1e-5, nrel

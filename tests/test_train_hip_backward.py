@@ -12,7 +12,7 @@ DEV = 'cuda:0'
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('T,cout,cin', [(12800, 256, 256), (6400 + 37, 512, 512), (100, 128, 256), (31, 256, 128)])
+@pytest.mark.parametrize('T,cout,cin', [(12800, 256, 256), (6400 + 37, 512, 512), (100, 128, 256), (31, 256, 128), (5000, 224, 128), (777, 256, 224), (300, 8, 136)])
 def test_linear_wgrad(dtype, T, cout, cin):
     """dW = dY^T X with fp32 accumulation: against the fp64 product of the same 16-bit operands (ragged token counts, all the
     layer widths); a column block of a wider gradient (the torch.cat([x, m]) halves); accumulation."""
