@@ -101,6 +101,10 @@ SIGNATURES = {
                                           c_long, c_long, c_long, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     'gf_window_cross_attention_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                                    c_long, c_long, c_long, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'gf_window_cross_attention_backward_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'gf_window_cross_attention_backward_gather': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_long,
+                                                          c_long, c_long, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                          c_void_p, c_size_t, c_void_p]),
     'gf_window_cross_attention_tiled': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                                 c_int, c_long, c_long, c_long, c_void_p, c_int, c_void_p, c_void_p,
                                                 c_void_p]),

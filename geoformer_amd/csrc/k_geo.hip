@@ -299,13 +299,20 @@ struct CbArgs {
     long ldq, ldk, ldv;
     const int32_t* win;     // [N][L][WW]
     void* dq;               // [N][L][256] of T
-    float* dk;              // [N][S][256] fp32, zeroed by the caller
+    float* dk;              // [N][S][256] fp32, zeroed by the caller      (scatter form)
     float* dv;
     int N, L, S;
     float softmax_temp;
+    // gather form (round 6): the per-query pass leaves (dlogit, p) per (query, window position, head) here instead of scattering, and
+    // window_cross_gather adds every cell's contributions in the order of the caller's inverse index: no atomics, bit-reproducible
+    float2* dlp;            // [N][L][WW][4]
+    const int32_t* entries; // [N * L * WW]: l * WW + k of the contributions, sorted by cell (stable); cells < 0 at the end
+    const int32_t* offsets; // [N * S + 1]: the contributions of global cell n * S + s are entries[offsets[.] .. offsets[. + 1])
+    void* dk16;             // [N][S][256] of T
+    void* dv16;
 };
 
-template <typename T, int WW>
+template <typename T, int WW, bool GATHER>
 __global__ __launch_bounds__(256) void window_cross_attention_backward(CbArgs a) {
     using Raw = typename Raw4<T>::type;
     const int n = blockIdx.y, lane = threadIdx.x & 63;
@@ -382,6 +389,10 @@ __global__ __launch_bounds__(256) void window_cross_attention_backward(CbArgs a)
         const float p = dot[k], dl = p * (dp[k] - pd) * a.softmax_temp;
         const v4f kv = widen4(kraw[k]);
         acc.x += dl * kv.x; acc.y += dl * kv.y; acc.z += dl * kv.z; acc.w += dl * kv.w;
+        if constexpr (GATHER) {                                  // the head's (dlogit, p) from its first lane; the cell's sum is window_cross_gather's
+            if ((lane & 15) == 0) a.dlp[(((size_t)n * a.L + l) * WW + k) * 4 + (lane >> 4)] = make_float2(dl, p);
+            continue;
+        }
         *reinterpret_cast<v4f*>(&tr[wave][0][lane * 4]) = v4f{dl * q.x, dl * q.y, dl * q.z, dl * q.w};
         *reinterpret_cast<v4f*>(&tr[wave][1][lane * 4]) = v4f{p * go.x, p * go.y, p * go.z, p * go.w};
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -398,6 +409,41 @@ __global__ __launch_bounds__(256) void window_cross_attention_backward(CbArgs a)
         __builtin_amdgcn_wave_barrier();
     }
     store4<T>(dq, acc);
+}
+
+// dk[cell] = sum over the (query, window position) pairs that look at the cell of dlogit q_query, dv[cell] = sum of p dout_query: one wave
+// per cell (lane = 4 channels, head = lane / 16) walks the cell's slice of the inverse index - ~25 entries for a smooth warp - in its order
+template <typename T, int WW>
+__global__ __launch_bounds__(256) void window_cross_gather(CbArgs a) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long gc = (long)blockIdx.x * 4 + wave;
+    if (gc >= (long)a.N * a.S) return;
+    const int n = (int)(gc / a.S), head = lane >> 4;
+    const int beg = a.offsets[gc], end = a.offsets[gc + 1];
+    const T* qb = (const T*)a.q + (size_t)n * a.L * a.ldq + lane * 4;
+    const T* gb = (const T*)a.dout + (size_t)n * a.L * 256 + lane * 4;
+    const float2* wb = a.dlp + (size_t)n * a.L * WW * 4 + head;
+    v4f dk{0.f, 0.f, 0.f, 0.f}, dv{0.f, 0.f, 0.f, 0.f};
+    int e = beg;
+    for (; e + 2 <= end; e += 2) {                               // two contributions in flight
+        const int i0 = a.entries[e], i1 = a.entries[e + 1], l0 = i0 / WW, l1 = i1 / WW;
+        const float2 w0 = wb[(size_t)i0 * 4], w1 = wb[(size_t)i1 * 4];
+        const v4f q0 = load4<T>(qb + (size_t)l0 * a.ldq), g0 = load4<T>(gb + (size_t)l0 * 256);
+        const v4f q1 = load4<T>(qb + (size_t)l1 * a.ldq), g1 = load4<T>(gb + (size_t)l1 * 256);
+        dk.x += w0.x * q0.x; dk.y += w0.x * q0.y; dk.z += w0.x * q0.z; dk.w += w0.x * q0.w;
+        dv.x += w0.y * g0.x; dv.y += w0.y * g0.y; dv.z += w0.y * g0.z; dv.w += w0.y * g0.w;
+        dk.x += w1.x * q1.x; dk.y += w1.x * q1.y; dk.z += w1.x * q1.z; dk.w += w1.x * q1.w;
+        dv.x += w1.y * g1.x; dv.y += w1.y * g1.y; dv.z += w1.y * g1.z; dv.w += w1.y * g1.w;
+    }
+    if (e < end) {
+        const int i0 = a.entries[e], l0 = i0 / WW;
+        const float2 w0 = wb[(size_t)i0 * 4];
+        const v4f q0 = load4<T>(qb + (size_t)l0 * a.ldq), g0 = load4<T>(gb + (size_t)l0 * 256);
+        dk.x += w0.x * q0.x; dk.y += w0.x * q0.y; dk.z += w0.x * q0.z; dk.w += w0.x * q0.w;
+        dv.x += w0.y * g0.x; dv.y += w0.y * g0.y; dv.z += w0.y * g0.z; dv.w += w0.y * g0.w;
+    }
+    store4<T>((T*)a.dk16 + (size_t)gc * 256 + lane * 4, dk);
+    store4<T>((T*)a.dv16 + (size_t)gc * 256 + lane * 4, dv);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -704,12 +750,52 @@ extern "C" int gf_window_cross_attention_backward(const void* q, const void* kma
     GF_CHECK_ARG(H == 4 && D == 64 && WW == 25, "built for nhead=4, head dim 64, 5x5 windows (geo_config.py:12,16)");
     GF_CHECK_ARG((double)S * (double)(ldk > ldv ? ldk : ldv) < 4294967296.0, "key map too large for 32-bit row offsets");
     GF_CHECK_ARG(dtype >= GF_F32 && dtype <= GF_BF16, "bad dtype");
-    CbArgs a{q, kmap, vmap, dout, ldq, ldk, ldv, win, dq, dk, dv, N, L, S, 1.0f / sqrtf((float)D)};
+    CbArgs a{};
+    a.q = q; a.kmap = kmap; a.vmap = vmap; a.dout = dout; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.win = win; a.dq = dq; a.dk = dk; a.dv = dv;
+    a.N = N; a.L = L; a.S = S; a.softmax_temp = 1.0f / sqrtf((float)D);
     const dim3 grid((L + 3) / 4, N);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == GF_F32) window_cross_attention_backward<float, 25><<<grid, 256, 0, st>>>(a);
-    else if (dtype == GF_F16) window_cross_attention_backward<_Float16, 25><<<grid, 256, 0, st>>>(a);
-    else window_cross_attention_backward<gf_bf16, 25><<<grid, 256, 0, st>>>(a);
+    if (dtype == GF_F32) window_cross_attention_backward<float, 25, false><<<grid, 256, 0, st>>>(a);
+    else if (dtype == GF_F16) window_cross_attention_backward<_Float16, 25, false><<<grid, 256, 0, st>>>(a);
+    else window_cross_attention_backward<gf_bf16, 25, false><<<grid, 256, 0, st>>>(a);
+    GF_CHECK_LAUNCH();
+    return GF_OK;
+}
+
+extern "C" size_t gf_window_cross_attention_backward_workspace_bytes(int N, int L, int WW) {
+    return (N <= 0 || L <= 0 || WW <= 0) ? 0 : gf_align_up((size_t)N * L * WW * 4 * sizeof(float2), 256);
+}
+
+// The same gradients WITHOUT atomics: dk, dv [N][S][256] of `dtype` are gathered cell by cell along the caller's inverse index of `win`
+// (entries sorted by global cell n * S + cell, stable; offsets [N * S + 1]) - bit-reproducible, and the fp32 maps are gone.
+extern "C" int gf_window_cross_attention_backward_gather(const void* q, const void* kmap, const void* vmap, const void* dout, int dtype, int N,
+                                                         int L, int S, int H, int D, long ldq, long ldk, long ldv, const int32_t* win, int WW,
+                                                         const int32_t* entries, const int32_t* offsets, void* dq, void* dk, void* dv,
+                                                         void* workspace, size_t workspace_bytes, void* stream) {
+    GF_CHECK_ARG(q && kmap && vmap && dout && win && entries && offsets && dq && dk && dv && workspace, "null pointer");
+    GF_CHECK_ARG(N > 0 && L > 0 && S > 0, "empty problem");
+    GF_CHECK_ARG(H == 4 && D == 64 && WW == 25, "built for nhead=4, head dim 64, 5x5 windows (geo_config.py:12,16)");
+    GF_CHECK_ARG((double)S * (double)(ldk > ldv ? ldk : ldv) < 4294967296.0, "key map too large for 32-bit row offsets");
+    GF_CHECK_ARG((double)N * L * WW < 2147483648.0 && (double)N * S < 2147483647.0, "index ranges");
+    GF_CHECK_ARG(dtype >= GF_F32 && dtype <= GF_BF16, "bad dtype");
+    GF_CHECK_ARG(workspace_bytes >= gf_window_cross_attention_backward_workspace_bytes(N, L, WW), "workspace too small");
+    CbArgs a{};
+    a.q = q; a.kmap = kmap; a.vmap = vmap; a.dout = dout; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.win = win; a.dq = dq;
+    a.N = N; a.L = L; a.S = S; a.softmax_temp = 1.0f / sqrtf((float)D);
+    a.dlp = (float2*)workspace; a.entries = entries; a.offsets = offsets; a.dk16 = dk; a.dv16 = dv;
+    const dim3 grid((L + 3) / 4, N);
+    const unsigned cells = (unsigned)(((long)N * S + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GF_F32) {
+        window_cross_attention_backward<float, 25, true><<<grid, 256, 0, st>>>(a);
+        window_cross_gather<float, 25><<<cells, 256, 0, st>>>(a);
+    } else if (dtype == GF_F16) {
+        window_cross_attention_backward<_Float16, 25, true><<<grid, 256, 0, st>>>(a);
+        window_cross_gather<_Float16, 25><<<cells, 256, 0, st>>>(a);
+    } else {
+        window_cross_attention_backward<gf_bf16, 25, true><<<grid, 256, 0, st>>>(a);
+        window_cross_gather<gf_bf16, 25><<<cells, 256, 0, st>>>(a);
+    }
     GF_CHECK_LAUNCH();
     return GF_OK;
 }

@@ -393,6 +393,44 @@ def window_cross_attention(q, kmap, vmap, win, valid=None, nhead=4, hw_q=None, h
     return out
 
 
+def window_inverse_index(win, S):
+    """The inverse of the window table win int32 [N, L, WW] (cell of the other image per window position, < 0 = masked) for the gather form
+    of K5's backward: (entries int32 [N*L*WW] = l*WW + k sorted - stably - by global cell n*S + cell, masked positions last;
+    offsets int32 [N*S + 1]).  torch ops only, no host synchronisation; one sort of N*L*WW keys."""
+    N, L, WW = win.shape
+    base = (torch.arange(N, device=win.device, dtype=torch.int64) * S)[:, None, None]
+    key = torch.where(win >= 0, win.to(torch.int64) + base, N * S).reshape(-1)
+    key, order = torch.sort(key, stable=True)
+    entries = (order % (L * WW)).to(torch.int32)
+    counts = torch.bincount(key, minlength=N * S + 1)[:N * S]
+    offsets = torch.zeros(N * S + 1, dtype=torch.int32, device=win.device)
+    offsets[1:] = counts.cumsum(0).to(torch.int32)
+    return entries, offsets
+
+
+def window_cross_attention_backward_gather(q, kmap, vmap, dout, win, index, nhead=4):
+    """(dq [N,L,256], dk, dv [N,S,256], all of q's dtype) of window_cross_attention given dout [N,L,256], the cell sums gathered along
+    `index` = window_inverse_index(win, S): no atomics, bit-reproducible."""
+    _need_cuda(q, kmap, vmap, dout, win)
+    N, L, C = q.shape
+    S = kmap.shape[1]
+    q, ldq = _rows(q)
+    kmap, ldk = _rows(kmap)
+    vmap, ldv = _rows(vmap)
+    if q.stride(0) != ldq * L or kmap.stride(0) != ldk * S or vmap.stride(0) != ldv * S:
+        raise ValueError('window_cross_attention_backward needs batch stride == rows * row stride')
+    dout = _contig(dout)
+    entries, offsets = index
+    dq = torch.empty(N, L, C, dtype=q.dtype, device=q.device)
+    dkv = torch.empty(2, N, S, C, dtype=q.dtype, device=q.device)
+    L_ = _lib.lib()
+    ws = _ws.get('k5bwd', L_.gf_window_cross_attention_backward_workspace_bytes(N, L, win.shape[-1]), q.device)
+    check(L_.gf_window_cross_attention_backward_gather(_p(q), _p(kmap), _p(vmap), _p(dout), _dt(q), N, L, S, nhead, C // nhead, ldq, ldk, ldv,
+                                                       _p(win), win.shape[-1], _p(entries), _p(offsets), _p(dq), _p(dkv[0]), _p(dkv[1]),
+                                                       _p(ws), ws.numel(), _stream()), 'gf_window_cross_attention_backward_gather')
+    return dq, dkv[0], dkv[1]
+
+
 def window_cross_attention_backward(q, kmap, vmap, dout, win, nhead=4):
     """(dq [N,L,256] of q's dtype, dk, dv fp32 [N,S,256]) of window_cross_attention given dout [N,L,256]."""
     _need_cuda(q, kmap, vmap, dout, win)

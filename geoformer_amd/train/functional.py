@@ -350,6 +350,7 @@ def geo_module(P, cnn0, cnn1, data, geo_cfg, homography_fn: Callable):
     f0 = [f0[b] for b in range(n)]          # per-sample lists: no in-place writes into autograd inputs
     f1 = [f1[b] for b in range(n)]
     cells = [None] * n                      # HIP path: (win1 cells, win0 cells) int32 [1, L, 25] per sample, -1 = masked
+    cat_cells = None
     for idx, name in enumerate(geo_cfg['layer_names']):
         lp = f'geo_module.des_transformer.layers.{idx}.'
         hip = _HIP_BACKWARD[0] and cnn0.is_cuda and torch.is_autocast_enabled() and c == 256 and nhead == 4
@@ -372,8 +373,10 @@ def geo_module(P, cnn0, cnn1, data, geo_cfg, homography_fn: Callable):
                 s0, s1 = X0.to(dt), X1.to(dt)
                 k0, v0 = HA.linear(s0, P[lp + 'k_proj.weight']), HA.linear(s0, P[lp + 'v_proj.weight'])
                 k1, v1 = HA.linear(s1, P[lp + 'k_proj.weight']), HA.linear(s1, P[lp + 'v_proj.weight'])
-                o0 = _geo_cross_layer_hip(P, lp, X0, k1, v1, torch.cat([cells[b][0] for b in act], 0), nhead)
-                o1 = _geo_cross_layer_hip(P, lp, X1, k0, v0, torch.cat([cells[b][1] for b in act], 0), nhead)
+                if cat_cells is None:                    # one table per side for all 'cross' layers of the step (its inverse index is kept on it)
+                    cat_cells = (torch.cat([cells[b][0] for b in act], 0), torch.cat([cells[b][1] for b in act], 0))
+                o0 = _geo_cross_layer_hip(P, lp, X0, k1, v1, cat_cells[0], nhead)
+                o1 = _geo_cross_layer_hip(P, lp, X1, k0, v0, cat_cells[1], nhead)
                 for j, b in enumerate(act):
                     f0[b], f1[b] = o0[j], o1[j]
         elif name == 'self':

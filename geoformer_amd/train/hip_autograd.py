@@ -160,6 +160,9 @@ class HipWindowLinearAttention(torch.autograd.Function):
         return dq, dk, dv, None
 
 
+_GATHER_K5_BACKWARD = [True]       # K5's backward as a gather along the inverse window table (False: the fp32 atomic scatter, for A/B)
+
+
 class HipWindowCrossAttention(torch.autograd.Function):
     """FullAttention.forward over the 25 keys of each query's window (geo_attention.py:72-101 as GeoTransformer's 'cross' branch
     calls it, transformer.py:125-139) on the PROJECTED maps: q [N,L,256], kmap / vmap [N,S,256] = k_proj / v_proj of every token of
@@ -177,6 +180,15 @@ class HipWindowCrossAttention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         q, kmap, vmap, win = ctx.saved_tensors
+        if _GATHER_K5_BACKWARD[0]:
+            # round 6: the cells' sums gathered along the inverse of the window table (one sort per table, kept on the table: both
+            # 'cross' layers of a step use the same one) instead of fp32 atomic adds: bit-reproducible, no fp32 maps
+            index = getattr(win, '_gf_inverse_index', None)
+            if index is None or index[2] != (kmap.shape[1], win._version):
+                index = ops.window_inverse_index(win, kmap.shape[1]) + ((kmap.shape[1], win._version),)
+                win._gf_inverse_index = index
+            dq, dk, dv = ops.window_cross_attention_backward_gather(q, kmap, vmap, dout, win, index[:2], ctx.nhead)
+            return dq, dk, dv, None, None
         dq, dk, dv = ops.window_cross_attention_backward(q, kmap, vmap, dout, win, ctx.nhead)
         return dq, dk.to(kmap.dtype), dv.to(vmap.dtype), None, None
 

@@ -417,6 +417,15 @@ int gf_window_cross_attention(const void* q, const void* kmap, const void* vmap,
 int gf_window_cross_attention_backward(const void* q, const void* kmap, const void* vmap, const void* dout, int dtype, int N, int L,
                                        int S, int H, int D, long ldq, long ldk, long ldv, const int32_t* win, int WW, void* dq,
                                        float* dk, float* dv, void* stream);
+/* the same gradients without atomics (round 6): dk, dv [N, S, 256] of `dtype` gathered cell by cell along the caller's inverse index of
+ * `win` - entries int32 [N * L * WW] = l * WW + k of every (query, window position), sorted (stable) by global cell n * S + cell with the masked
+ * positions (cell < 0) last; offsets int32 [N * S + 1] - so the sums run in a fixed order (bit-reproducible) and no fp32 maps are needed.
+ * workspace: gf_window_cross_attention_backward_workspace_bytes (the per-(query, position, head) dlogit and p). */
+size_t gf_window_cross_attention_backward_workspace_bytes(int N, int L, int WW);
+int gf_window_cross_attention_backward_gather(const void* q, const void* kmap, const void* vmap, const void* dout, int dtype, int N, int L,
+                                              int S, int H, int D, long ldq, long ldk, long ldv, const int32_t* win, int WW,
+                                              const int32_t* entries, const int32_t* offsets, void* dq, void* dk, void* dv, void* workspace,
+                                              size_t workspace_bytes, void* stream);
 /* The same operation when the query map is hq x wq cells and the key map hk x wk cells (L = hq*wq, S = hk*wk, cells row-major as
  * gf_window_geometry numbers them).  16-bit storage: one workgroup per tile of 8 x 4 query cells and head; the windows of a
  * tile overlap, so the key / value rows of their bounding rectangle are staged in LDS once (a tile whose rectangle exceeds 144

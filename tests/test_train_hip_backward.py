@@ -307,6 +307,19 @@ def test_window_cross_attention_backward(dtype):
     for name, x, y in zip(('dq', 'dk', 'dv'), b, a):
         rel = float((x.grad.float() - y.grad.float()).norm() / y.grad.float().norm())
         assert rel < (1e-4 if dtype == torch.float32 else 2e-2), (name, rel)
+    # round 6: dk / dv are gathered along the inverse window table (no atomics): a second run gives the same bits, and the scatter form
+    # (fp32 atomic adds, kept for A/B) agrees to the rounding of the storage type
+    b2 = [t.clone().requires_grad_(True) for t in (q, km, vm)]
+    HA.window_cross_attention(*b2, win, 4).backward(dout)
+    assert all(torch.equal(x.grad, y.grad) for x, y in zip(b, b2))
+    HA._GATHER_K5_BACKWARD[0] = False
+    try:
+        b3 = [t.clone().requires_grad_(True) for t in (q, km, vm)]
+        HA.window_cross_attention(*b3, win, 4).backward(dout)
+    finally:
+        HA._GATHER_K5_BACKWARD[0] = True
+    for x, y in zip(b, b3):
+        assert float((x.grad.float() - y.grad.float()).norm() / y.grad.float().norm()) < (1e-5 if dtype == torch.float32 else 6e-3)
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
