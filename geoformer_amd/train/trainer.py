@@ -116,14 +116,16 @@ class TrainStep:
     gf_activation_backward) instead of torch's GEMM / autograd; the coarse layers' linear attention runs K2 forward and
     gf_linear_attention_backward, the fine level's 25-token windows K2's window form and gf_window_linear_attention_backward,
     GeoTransformer's cross attention K5 and gf_window_cross_attention_backward, FineMatching2 K8 and gf_fine_match_backward; the Geo
-    SELF-attention core (K4), the backbone and the losses other than the fused coarse loss stay on autograd.  Step time at batch 2,
-    640x640: 0.128 s -> 0.075 s.
+    SELF-attention core (K4: gf_full_attention_train_forward / _backward since round 6; the Geo layers batched over the images of the step),
+    the backbone and the losses other than the fused coarse loss stay on autograd.  Step time at batch 2, 640x640: 0.128 s -> 0.075 s.
     `hip_conv=True` (with precision='bf16'; round 5): the backbone's 3x3 / stride-1 convolutions through `hip_autograd.HipConv3x3` - forward and
     backward-data on K10 (`gf_conv3x3_nhwc`; backward-data = the forward kernel on dY with the transposed, flipped weights), backward-weights on
-    the library; the backbone runs in NHWC (implies channels_last).  MegaDepth-style step at batch 8, 640x640: 0.284 s -> 0.245 s.
-    NOT bit-reproducible run to run with hip_backward=True: gf_window_cross_attention_backward sums dk / dv of the overlapping 5 x 5
-    windows with fp32 atomic adds (the order of the adds varies; differences are at fp32 rounding level, ~1e-7 relative, and DDP ranks
-    still hold identical parameters after the all-reduce).  Every other HIP backward sums its partials in a fixed order."""
+    K10's weight-gradient kernel (round 6), the stride-1 1x1 convolutions on the K3 engine and the FPN upsampling's backward as a gather
+    (round 6); the backbone runs in NHWC (implies channels_last).  MegaDepth-style step at batch 8, 640x640: 0.284 s -> 0.245 s (round 5)
+    -> 0.18-0.19 s (round 6).
+    Every HIP backward sums its partials in a fixed order since round 6 (K5's backward gathers along the inverse window table; its
+    fp32-atomics form is kept behind hip_autograd._GATHER_K5_BACKWARD for comparison); what is NOT bit-reproducible run to run is the
+    library's part of the step (train-mode convolutions / BatchNorm of the backbone: loss terms move by ~1 % between identical runs)."""
 
     def __init__(self, model, trainer_cfg=None, loss_cfg=None, batch_size=1, distributed=False, device_ids=None,
                  homography_fn: Optional[Callable] = None, sparse_spvs=True, fused_coarse_loss=False, precision='fp32',
