@@ -438,10 +438,20 @@ def fine_preprocess(P, feat_f0, feat_f1, feat_c0, feat_c1, data, W):
         return e, e
     w0 = _fine_windows(feat_f0, b, i, int(data['hw0_c'][1]), stride, W)
     w1 = _fine_windows(feat_f1, b, j, int(data['hw1_c'][1]), stride, W)
-    cwin = F.linear(torch.cat([feat_c0[b, i], feat_c1[b, j]], 0), P['fine_preprocess.down_proj.weight'],
-                    P['fine_preprocess.down_proj.bias'])
-    both = torch.cat([torch.cat([w0, w1], 0), cwin[:, None].expand(-1, W * W, -1)], -1)
-    both = F.linear(both, P['fine_preprocess.merge_feat.weight'], P['fine_preprocess.merge_feat.bias'])
+    cc = torch.cat([feat_c0[b, i], feat_c1[b, j]], 0)
+    hip = _HIP_BACKWARD[0] and cc.is_cuda and torch.is_autocast_enabled() and cf == 128 and cc.shape[1] == 256
+
+    def lin(x, name):
+        # the two projections of FinePreprocess (fine_preprocess.py:23-24, 66-72): on the K3 engine in the HIP step (the library's GEMM of the
+        # 2 M x 25 window rows ran at 80 TFLOP/s: 1.7 ms per call), bias added in the storage type as autocast's linear does
+        if hip:
+            from . import hip_autograd as HA
+            dt = torch.get_autocast_dtype('cuda')
+            return HA.linear(x.to(dt), P[name + '.weight']) + P[name + '.bias'].to(dt)
+        return F.linear(x, P[name + '.weight'], P[name + '.bias'])
+    cwin = lin(cc, 'fine_preprocess.down_proj')
+    both = torch.cat([torch.cat([w0, w1], 0).to(cwin.dtype), cwin[:, None].expand(-1, W * W, -1)], -1)
+    both = lin(both, 'fine_preprocess.merge_feat')
     return torch.chunk(both, 2, dim=0)
 
 
