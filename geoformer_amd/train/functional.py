@@ -101,6 +101,7 @@ def full_attention(q, k, v, kv_mask=None):
 
 
 _HIP_BACKWARD = [False]
+_FP16_MATCHING = [True]           # the fused coarse stage's matching (no gradient) on fp16 copies of the features (False: fp32, for A/B)
 _BATCHED_GEO = [True]             # the Geo layers' per-token operations once per layer on all images of the batch (False: image by image, for A/B)
 _OWN_FULL_ATTENTION = [True]      # the Geo 'self' layers of the HIP step on csrc/k4_attention_train.hip (False: the library's fused attention, for A/B)
 
@@ -528,7 +529,10 @@ def _fused_coarse_stage(f0, f1, data, temp, thr, focal, m0=None, m1=None):
     L x S tensor enters the autograd graph.  Returns (conf_matrix without grad, match dict, (loss_sum, count))."""
     from .. import ops
     scale = float(data['hw0_i'][0]) / float(data['hw0_c'][0])
-    r = ops.dual_softmax_match(f0.detach(), f1.detach(), temp, thr, data['hw0_c'], data['hw1_c'], scale, mask0=m0, mask1=m1,
+    # the matches carry no gradient: K1 reads fp16 copies of the features (its 16-bit kernels: 0.5 ms per 8-pair stage where the exact-fp32
+    # matrix path took 4 ms).  11 significant bits - the reference's own mixed-precision run forms this similarity under bf16 autocast (8 bits).
+    h0, h1 = (t.detach().to(torch.float16) if (_FP16_MATCHING[0] and t.dtype == torch.float32) else t.detach() for t in (f0, f1))
+    r = ops.dual_softmax_match(h0, h1, temp, thr, data['hw0_c'], data['hw1_c'], scale, mask0=m0, mask1=m1,
                                scale0=data.get('scale0'), scale1=data.get('scale1'), force_one='dataset_name' in data)
     m = int(r['counts'][0])
     match = {k: r[k][:m] for k in ('b_ids', 'i_ids', 'j_ids', 'mkpts0_c', 'mkpts1_c')}
