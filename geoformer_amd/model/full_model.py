@@ -23,6 +23,9 @@ from .modules import (CoarseMatching, FineMatching2, FinePreprocess, GeoModule, 
 _PRECISIONS = {'fp32': torch.float32, 'fp16': torch.float16, 'bf16': torch.bfloat16}
 
 
+_CONCURRENT_BACKBONES = [True]    # unequal-shape pairs: the two backbone calls on two streams (False: one after the other, for A/B)
+
+
 class GeoFormer(nn.Module):
     def __init__(self, loftr_config, geoformer_cfg=default_cfg):
         super().__init__()
@@ -40,6 +43,7 @@ class GeoFormer(nn.Module):
         self.fine_matching = FineMatching2(geoformer_cfg['fine_temperature'], geoformer_cfg['fine_thr'])
         self.geo_module = GeoModule(geoformer_cfg, loftr_config['coarse']['d_model'])
         self._fused = [None]     # holder list: keeps the folded inference copy out of the module tree / state dict
+        self._side_streams = {}  # (device, current stream) -> the stream image 1's backbone runs on (unequal-shape pairs)
         self.set_precision(geoformer_cfg.get('precision', 'fp32'))
 
     # -- precision of the matching path: 'fp32' (parity mode), 'fp16' or 'bf16' (16-bit storage, fp32 accumulate)
@@ -81,6 +85,28 @@ class GeoFormer(nn.Module):
         if x.is_cuda and self.backbone_dtype != torch.float32 and not self.training:
             return self._inference_backbone()(x)
         return self.backbone(x)
+
+    def _backbone_unequal(self, img0, img1):
+        """The two backbone calls of a pair whose images differ in shape (full_model.py:58-59; the HPatches loop, batch 1).  On the
+        16-bit inference path they run CONCURRENTLY, image 1 on a side stream: at batch 1 a convolution launches 150-300 workgroups on
+        256 CUs for ~40 us, two of them side by side fill the chip (round 6: -0.5 ms of a 3.3 ms pair).  Sequential under graph
+        capture, in training and in the fp32 mode (the library's handles are per stream)."""
+        if (not img0.is_cuda or self.training or self.backbone_dtype == torch.float32 or torch.cuda.is_current_stream_capturing()
+                or not _CONCURRENT_BACKBONES[0]):
+            return self._backbone(img0), self._backbone(img1)
+        cur = torch.cuda.current_stream(img0.device)
+        key = (img0.device.index, cur.cuda_stream)
+        side = self._side_streams.get(key)
+        if side is None:
+            side = self._side_streams[key] = torch.cuda.Stream(device=img0.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            out1 = self._backbone(img1)
+        out0 = self._backbone(img0)
+        cur.wait_stream(side)
+        for t in out1:
+            t.record_stream(cur)                 # allocated on the side stream, consumed on the current one
+        return out0, out1
 
     # -- hipGraph replay of the static part (SURVEY 8f rank 4).  Everything before the first host synchronisation has
     # data-independent launches (the device RANSAC and the device-side counts keep it that way), so per (shapes, stream)
@@ -140,7 +166,7 @@ class GeoFormer(nn.Module):
             feats_c, feats_f = self._backbone(torch.cat([img0, img1], dim=0))
             (feat_c0, feat_c1), (feat_f0, feat_f1) = feats_c.split(n), feats_f.split(n)
         else:
-            (feat_c0, feat_f0), (feat_c1, feat_f1) = self._backbone(img0), self._backbone(img1)
+            (feat_c0, feat_f0), (feat_c1, feat_f1) = self._backbone_unequal(img0, img1)
         return self.forward_features(data, feat_c0, feat_f0, feat_c1, feat_f1)
 
     def forward_static(self, data):
@@ -154,7 +180,7 @@ class GeoFormer(nn.Module):
             feats_c, feats_f = self._backbone(torch.cat([img0, img1], dim=0))
             (feat_c0, feat_c1), (feat_f0, feat_f1) = feats_c.split(n), feats_f.split(n)
         else:
-            (feat_c0, feat_f0), (feat_c1, feat_f1) = self._backbone(img0), self._backbone(img1)
+            (feat_c0, feat_f0), (feat_c1, feat_f1) = self._backbone_unequal(img0, img1)
         return self.forward_features(data, feat_c0, feat_f0, feat_c1, feat_f1, static_only=True)
 
     def forward_dynamic(self, data):
