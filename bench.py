@@ -994,8 +994,10 @@ def hpatches_b1_measurements(dev, log, L, pipes=None, steps=60, warmup=6):
         f1 = bigf[:, :, 4:4 + 4 * g1[0], 4:4 + 4 * g1[1]] + 0.35 * torch.randn(1, 128, 4 * g1[0], 4 * g1[1], generator=g)
         return [t.to(device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last) for t in (c0, f0, c1, f1)]
 
-    def run(tag, step, what):
+    def run(tag, step, what, model=None):
         with torch.no_grad():
+            if model is not None:
+                model.concurrent_backbones = True      # latency: the two backbone calls of the unequal-shape pair on two streams
             r = step(0)
             torch.cuda.synchronize()
             M = len(r['b_ids'])
@@ -1008,6 +1010,8 @@ def hpatches_b1_measurements(dev, log, L, pipes=None, steps=60, warmup=6):
                 torch.cuda.synchronize()
                 lat.append(time.perf_counter() - t)
             lat = sorted(lat[warmup:])
+            if model is not None:
+                model.concurrent_backbones = False     # throughput on two pipelines: one stream per pipeline gives more pairs per second
             # throughput: two host pipelines (the headline's own threads and streams when it ran on two)
             rates = []
             for _ in range(3):            # three back-to-back regions (the second pipeline half a step late), the median reported (a region
@@ -1068,7 +1072,9 @@ def hpatches_b1_measurements(dev, log, L, pipes=None, steps=60, warmup=6):
     torch.cuda.empty_cache()
     ml, _ = build_model('bf16', 0.0, 0.0, dev)
     j1 = synth_rect_pair(hw0, hw1, 77, dev)
-    run('light', lambda i: ml({'image0': j1[0], 'image1': j1[1]}), 'full forward on a textured 480x640 image and its homography warp at 480x608, thresholds 0')
+    run('light', lambda i: ml({'image0': j1[0], 'image1': j1[1]}),
+        'full forward on a textured 480x640 image and its homography warp at 480x608, thresholds 0; latency with the two backbone calls on two streams, '
+        'throughput with one stream per pipeline', model=ml)
     ml.enable_graphs()
     run('light_graphs', lambda i: ml({'image0': j1[0], 'image1': j1[1]}), 'the same with hipGraph replay of the static part')
     del ml

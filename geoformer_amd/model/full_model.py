@@ -44,6 +44,10 @@ class GeoFormer(nn.Module):
         self.geo_module = GeoModule(geoformer_cfg, loftr_config['coarse']['d_model'])
         self._fused = [None]     # holder list: keeps the folded inference copy out of the module tree / state dict
         self._side_streams = {}  # (device, current stream) -> the stream image 1's backbone runs on (unequal-shape pairs)
+        # unequal-shape pairs: image 1's backbone beside image 0's on a second stream.  Shortens ONE pair (2.8 instead of 3.1 ms at the
+        # HPatches shapes); a host that already feeds the GPU from several threads / streams gets MORE pairs per second with it off
+        # (two pipelines: 560 against 420 pairs/s) - bench.py measures latency with it on and throughput with it off
+        self.concurrent_backbones = True
         self.set_precision(geoformer_cfg.get('precision', 'fp32'))
 
     # -- precision of the matching path: 'fp32' (parity mode), 'fp16' or 'bf16' (16-bit storage, fp32 accumulate)
@@ -92,7 +96,7 @@ class GeoFormer(nn.Module):
         256 CUs for ~40 us, two of them side by side fill the chip (round 6: -0.5 ms of a 3.3 ms pair).  Sequential under graph
         capture, in training and in the fp32 mode (the library's handles are per stream)."""
         if (not img0.is_cuda or self.training or self.backbone_dtype == torch.float32 or torch.cuda.is_current_stream_capturing()
-                or not _CONCURRENT_BACKBONES[0]):
+                or not _CONCURRENT_BACKBONES[0] or not self.concurrent_backbones):
             return self._backbone(img0), self._backbone(img1)
         cur = torch.cuda.current_stream(img0.device)
         key = (img0.device.index, cur.cuda_stream)
@@ -104,8 +108,10 @@ class GeoFormer(nn.Module):
             out1 = self._backbone(img1)
         out0 = self._backbone(img0)
         cur.wait_stream(side)
-        for t in out1:
-            t.record_stream(cur)                 # allocated on the side stream, consumed on the current one
+        # out1 lives in the side stream's pool and is consumed on the current stream.  No record_stream (it makes the allocator hold the
+        # blocks back until an event completes: with two pipelines the light-load leg fell from 560 to 330 pairs/s): the side stream is
+        # used by this function only, and every use starts with side.wait_stream(cur) - issued after the consumers of the previous pair
+        # were enqueued on cur -, so a block of out1 that returns to the side pool is not touched again before they have run
         return out0, out1
 
     # -- hipGraph replay of the static part.  Everything before the first host synchronisation has
