@@ -1032,11 +1032,12 @@ def hpatches_b1_measurements(dev, log, L, pipes=None, steps=60, warmup=6):
     pl = [planted(70000 + i) for i in range(2)]
 
     def nominal_step(i):
-        (fc0, ff0), (fc1, ff1) = mn._backbone(i0), mn._backbone(i1)
+        (fc0, ff0), (fc1, ff1) = mn._backbone_unequal(i0, i1)             # what GeoFormer.forward does with an unequal-shape pair
         c0, f0, c1, f1 = pl[i % 2]
         return mn.forward_features({'image0': i0, 'image1': i1}, torch.add(c0, fc0, alpha=0.0), torch.add(f0, ff0, alpha=0.0),
                                    torch.add(c1, fc1, alpha=0.0), torch.add(f1, ff1, alpha=0.0))
-    run('nominal', nominal_step, 'backbone on 480x640 / 480x608 images + matching path on planted maps through the backbone output, thresholds 0.2 / 0.1')
+    run('nominal', nominal_step, 'backbone on 480x640 / 480x608 images + matching path on planted maps through the backbone output, thresholds 0.2 / 0.1; '
+        'latency with the two backbone calls on two streams, throughput with one stream per pipeline', model=mn)
     # per-launch times of the hot-path kernels at these shapes (one stream, HIP events on every tagged launch)
     L.gf_profile_filter(None)
     L.gf_profile_enable(1)
@@ -1061,7 +1062,7 @@ def hpatches_b1_measurements(dev, log, L, pipes=None, steps=60, warmup=6):
         for _ in range(4):
             torch.cuda.synchronize()
             t = time.perf_counter()
-            (fc0, ff0), (fc1, ff1) = mn._backbone(i0), mn._backbone(i1)
+            (fc0, ff0), (fc1, ff1) = mn._backbone_unequal(i0, i1)
             c0, f0, c1, f1 = pl[0]
             mn.forward_features({'image0': i0, 'image1': i1}, torch.add(c0, fc0, alpha=0.0), torch.add(f0, ff0, alpha=0.0),
                                 torch.add(c1, fc1, alpha=0.0), torch.add(f1, ff1, alpha=0.0), static_only=True)
